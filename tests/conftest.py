@@ -1,0 +1,71 @@
+"""Shared pytest fixtures.  `-m "not gpu"` runs on a CPU-only box; `-m gpu` needs an MI355X."""
+import ctypes
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _make(target_dir, *targets):
+    subprocess.run(["make", "-s", "-C", target_dir, *targets], check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+@pytest.fixture(scope="session")
+def oracle_dir():
+    """oracle/ with liboracle.so + oracle_classify built (test infrastructure)."""
+    d = os.path.join(ROOT, "oracle")
+    _make(d, "liboracle.so", "oracle_classify")
+    return d
+
+
+@pytest.fixture(scope="session")
+def oracle_lib(oracle_dir):
+    from tests import oracle_binding
+    return oracle_binding.load(os.path.join(oracle_dir, "liboracle.so"))
+
+
+def golden_cases():
+    out = []
+    for name in sorted(os.listdir(GOLDEN)):
+        cj = os.path.join(GOLDEN, name, "case.json")
+        if os.path.exists(cj):
+            meta = json.load(open(cj))
+            for run in sorted(meta["runs"]):
+                out.append((name, run))
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden_workdir(tmp_path_factory):
+    """Golden inputs copied to a temp dir with the k-mer files gunzipped (the reference reads
+    them with std::ifstream, classify.cpp:31, so they must be plain text)."""
+    base = tmp_path_factory.mktemp("golden")
+    for name in sorted(os.listdir(GOLDEN)):
+        src = os.path.join(GOLDEN, name)
+        if not os.path.isdir(src):
+            continue
+        dst = base / name
+        shutil.copytree(src, dst)
+        for fn in ("hap0.mer", "hap1.mer"):
+            gzp = dst / (fn + ".gz")
+            if gzp.exists():
+                with gzip.open(gzp, "rb") as f, open(dst / fn, "wb") as g:
+                    shutil.copyfileobj(f, g)
+    return base
+
+
+def load_case(name):
+    return json.load(open(os.path.join(GOLDEN, name, "case.json")))

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the build container only).
+
+Every case directory holds the INPUTS we made up here (k-mer text files, FASTQ files, the
+argv in case.json) and the EXPECTED stdout produced by the REAL reference binary
+`oracle/_ref/classify` (compiled by oracle/Makefile straight from
+/root/reference/01.classify_stlfr_reads/{classify.cpp,gzstream/gzstream.C}, shipped flags).
+Nothing of the reference's source is stored; fixtures are data only.
+
+    python tests/golden/gen_golden.py          # rewrites tests/golden/<case>/...
+
+The reference is the sole author of every expected.tsv; tests then require
+  oracle (CPU restatement) == expected.tsv     (tests/test_oracle_golden.py, CPU)
+  product classify (HIP)   == expected.tsv     (tests/test_cli_gpu.py, GPU)
+"""
+import gzip
+import json
+import os
+import random
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "classify")
+ADAPTOR_F = "CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA"
+ADAPTOR_R = "TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def rc(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def write(path, data, gz=False):
+    if gz:
+        with gzip.GzipFile(path, "wb", mtime=0) as f:
+            f.write(data.encode())
+    else:
+        with open(path, "w") as f:
+            f.write(data)
+
+
+def run_ref(case_dir, args):
+    out = subprocess.run([REF] + args, cwd=case_dir, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return out.stdout.decode(), out.stderr.decode()
+
+
+def finish_case(name, files, runs):
+    """files: {fname: (text, gz?)}; runs: {run_name: argv list (relative file names)}"""
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    for fn, (text, gz) in files.items():
+        write(os.path.join(d, fn), text, gz)
+    meta = {"runs": {}}
+    for rn, argv in runs.items():
+        stdout, stderr = run_ref(d, argv)
+        exp = "expected.%s.tsv" % rn
+        write(os.path.join(d, exp), stdout)
+        sizes = [l for l in stderr.splitlines() if l.startswith("Recorded") or "erase a adaptor" in l]
+        meta["runs"][rn] = {"argv": argv, "expected": exp, "ref_log": sizes}
+    with open(os.path.join(d, "case.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote", name, {k: len(open(os.path.join(d, v["expected"])).read().splitlines())
+                          for k, v in meta["runs"].items()})
+
+
+def fq(records, trailing_newline=True):
+    s = "".join("%s\n%s\n+\n%s\n" % (h, q, "F" * len(q)) for h, q in records)
+    return s if trailing_newline else s[:-1]
+
+
+# ------------------------------------------------------------------------------------------
+def case_edge():
+    """Hand-made K=7 case covering SURVEY Appendix A.3 traps."""
+    k = 7
+    p_only = ["ACGTACC", "GGATCCA", "TTGACCA", "CAGTTGA"]
+    m_only = ["ACCGGTA", "TGCATGG", "GATTACA", "CCATGCA"]
+    both = ["AGGCTTA"]
+    # hap0: duplicate line, reverse-complement duplicate, lower-case line, key shared with hap1,
+    #       an adaptor k-mer (erased by InitAdaptor), unterminated last line (dropped)
+    hap0_lines = p_only + [p_only[0], rc(p_only[1]), p_only[2].lower()] + both + [ADAPTOR_F[3:3 + k]]
+    hap0 = "\n".join(hap0_lines) + "\n" + "TTTTTTT"          # last piece unterminated -> dropped
+    hap1_lines = m_only + both + [rc(ADAPTOR_R[5:5 + k])]
+    hap1 = "\n".join(hap1_lines) + "\n"
+    filler = "AAAAAAAAAA"  # poly-A: canonical AAAAAAA, in neither set
+    recs = [
+        ("@V1#1_1_1/1", filler + p_only[0] + filler),                  # fwd hit hap0
+        ("@V2#1_1_1/2", filler + rc(p_only[1]) + filler),              # rc-strand hit hap0
+        ("@V3#2_2_2/1\tx/y\t1", filler + m_only[0] + filler),          # extra '/' and tab fields
+        ("@V4#0_0_0/1", filler + p_only[2] + filler),                  # 0_0_0 always -1, counts printed
+        ("@V5#3_3_3/1", filler + p_only[0] + "N" + m_only[1]),         # N => whole read skipped
+        ("@V6#3_3_3/2", (filler + m_only[1] + filler).lower()),        # lower-case read still hits
+        ("@V7#4_4_4/1", "acgtn" + "ACGTACC" + "nnnn"),                 # lower-case n is NOT a skip
+        ("@V8#5_5_5/1", filler + filler),                              # zero-hit barcode still printed
+        ("@V9#6_6_6/1", m_only[2]),                                    # len == K read
+        ("@V10#7_7_7/1", filler + both[0] + filler),                   # key in both sets => tie => -1
+        ("@V11#8_8_8/1", p_only[3] + p_only[3] + p_only[3]),           # repeated positions count each time
+        ("@V12#8_8_8/1", filler + m_only[3] + filler),
+        ("@noBarcode/1", filler + p_only[0]),                          # no '#': barcode starts at 0
+        ("@V13#9_9_9", filler + m_only[0]),                            # no '/': to end of line
+        ("@a/b#10_10_10", filler + p_only[1]),                         # '/' before '#': to end of line
+        ("@V14#0_0/1", filler + p_only[0]),                            # "0_0"
+        ("@V15#0/1", filler + m_only[0]),                              # "0"
+        ("@V16#11_11_11/1", ADAPTOR_F),                                # adaptor k-mers were erased
+        ("@V17#11_11_11/2", ADAPTOR_R),
+        ("@V18#100_1_1/1", filler + p_only[0]),                        # byte-wise row order
+        ("@V19#1000_1_1/1", filler + m_only[0]),
+        ("@V20#12_12_12/1", filler + p_only[0] + p_only[1] + m_only[0] + filler),
+    ]
+    files = {
+        "hap0.mer": (hap0, False),
+        "hap1.mer": (hap1, False),
+        "r1.fq": (fq(recs), False),
+        "r1_nonl.fq": (fq(recs, trailing_newline=False), False),       # last line unterminated
+        "r2.fq.gz": (fq(recs[:9]), True),
+    }
+    base = ["--hap0", "hap0.mer", "--hap1", "hap1.mer"]
+    runs = {
+        "plain": base + ["--read", "r1.fq", "-t", "2"],
+        "nonl": base + ["--read", "r1_nonl.fq", "-t", "1"],
+        "two_files_w104": base + ["--read", "r1.fq", "--read", "r2.fq.gz", "--thread", "3", "--weight0", "1.04"],
+        "weight1": base + ["-r", "r1.fq", "-u", "2.5", "-t", "8"],
+        "custom_adaptors": ["-p", "hap0.mer", "-m", "hap1.mer", "-r", "r1.fq", "-t", "4",
+                            "-f", filler + p_only[0] + filler, "-q", "GATTACAGATTACA"],
+    }
+    finish_case("edge_k7", files, runs)
+
+
+def random_case(name, k, n_keys, n_pairs, n_barcodes, seed, read_len=100, extra_runs=True):
+    rng = random.Random(seed)
+    keys = [[], []]
+    for h in range(2):
+        for _ in range(n_keys):
+            s = rand_seq(rng, k)
+            keys[h].append(s if rng.random() < 0.5 else rc(s))   # files are not canonical-only
+    shared = [rand_seq(rng, k) for _ in range(max(4, n_keys // 100))]
+    keys[0] += shared
+    keys[1] += [rc(s) for s in shared]
+    keys[0] += keys[0][:5]                                       # duplicates
+    keys[1] += [rc(s) for s in keys[1][:5]]
+    keys[0].append(ADAPTOR_F[2:2 + k]) if k <= 40 else None
+    keys[1].append(rc(ADAPTOR_R[1:1 + k]))
+    rng.shuffle(keys[1])
+    first = keys[0][0]
+    rest = keys[0][1:]
+    rng.shuffle(rest)
+    keys[0] = [first] + rest
+    barcodes = ["0_0_0"] + ["%d_%d_%d" % (rng.randint(1, 1536), rng.randint(1, 1536), rng.randint(1, 1536))
+                            for _ in range(n_barcodes - 1)]
+    truth = [rng.randint(0, 1) for _ in barcodes]
+    recs = [[], []]
+    for i in range(n_pairs):
+        b = rng.randrange(len(barcodes)) if rng.random() > 0.1 else 0
+        for mate in range(2):
+            L = read_len if rng.random() < 0.9 else rng.randint(k, read_len)
+            s = list(rand_seq(rng, L))
+            for _ in range(rng.randint(0, 3)):
+                h = truth[b] if rng.random() < 0.8 else 1 - truth[b]
+                km = rng.choice(keys[h])
+                if rng.random() < 0.5:
+                    km = rc(km)
+                if L > k:
+                    off = rng.randint(0, L - k)
+                    s[off:off + k] = list(km)
+            if rng.random() < 0.01:
+                s[rng.randrange(L)] = "N"
+            if rng.random() < 0.01:
+                s = [c.lower() for c in s]
+            if rng.random() < 0.005 and L >= 45:
+                s[0:45] = list(ADAPTOR_F)[:45]
+            recs[mate].append(("@V300R%09d#%s/%d\t%d\t1" % (i, barcodes[b], mate + 1, i), "".join(s)))
+    files = {
+        "hap0.mer": ("\n".join(keys[0]) + "\n", True),
+        "hap1.mer": ("\n".join(keys[1]) + "\n", True),
+        "r1.fq.gz": (fq(recs[0]), True),
+        "r2.fq.gz": (fq(recs[1]), True),
+    }
+    # k-mer files must be plain text for the reference (std::ifstream): tests gunzip them to a
+    # temp dir; they are stored compressed only to keep the repository small.
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    write(os.path.join(d, "hap0.mer"), files["hap0.mer"][0])
+    write(os.path.join(d, "hap1.mer"), files["hap1.mer"][0])
+    base = ["--hap0", "hap0.mer", "--hap1", "hap1.mer"]
+    runs = {"pair_w104": base + ["--read", "r1.fq.gz", "--read", "r2.fq.gz", "--thread", "8", "--weight0", "1.04"]}
+    if extra_runs:
+        runs["single_w1"] = base + ["--read", "r2.fq.gz", "-t", "3"]
+    try:
+        finish_case(name, {k_: v for k_, v in files.items() if k_.startswith("r")}, runs)
+    finally:
+        for fn in ("hap0.mer", "hap1.mer"):
+            p = os.path.join(d, fn)
+            write(p + ".gz", open(p).read(), gz=True)
+            os.remove(p)
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("build the reference first: make -C oracle ref")
+    case_edge()
+    random_case("rand_k21", 21, 3000, 1500, 60, seed=21)
+    random_case("rand_k31", 31, 1500, 600, 40, seed=31, extra_runs=False)
+    random_case("rand_k11", 11, 2000, 600, 40, seed=11, read_len=80, extra_runs=False)
+    random_case("rand_k32", 32, 500, 200, 20, seed=32, read_len=120, extra_runs=False)
+
+
+if __name__ == "__main__":
+    main()
