@@ -1,0 +1,300 @@
+"""ctypes binding of libhast.so (include/hast.h).  Loads the in-tree build; fails loudly if absent."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p, u32p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
+
+STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "TABLE_FULL", 6: "FORMAT", 7: "RCCL", 8: "IO"}
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed_k", C.c_uint64), ("seed_r", C.c_uint64), ("seed_b", C.c_uint64),
+                ("n_keys_per_hap", C.c_uint64), ("n_barcodes", C.c_uint32), ("read_len", C.c_uint32),
+                ("k", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/hast.h declares: name -> (restype, argtypes)
+ABI_SYMBOLS = {
+    "hast_version": (C.c_char_p, []),
+    "hast_last_error": (C.c_char_p, []),
+    "hast_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
+    "hast_ctx_destroy": (None, [vp]),
+    "hast_ctx_k": (C.c_int, [vp]),
+    "hast_ctx_device": (C.c_int, [vp]),
+    "hast_ctx_stream": (vp, [vp]),
+    "hast_stream_sync": (C.c_int, [vp, vp]),
+    "hast_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "hast_dev_free": (C.c_int, [vp, vp]),
+    "hast_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "hast_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "hast_memset_d": (C.c_int, [vp, vp, C.c_int, C.c_size_t, vp]),
+    "hast_table_reserve": (C.c_int, [vp, C.c_uint64, C.c_double]),
+    "hast_table_insert_text": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t, u64p]),
+    "hast_table_insert_keys": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "hast_table_insert_keys_device": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
+    "hast_table_erase": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "hast_table_sizes": (C.c_int, [vp, u64p, u64p]),
+    "hast_table_lookup": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "hast_table_info": (C.c_int, [vp, u64p, u64p]),
+    "hast_counts_resize": (C.c_int, [vp, C.c_size_t]),
+    "hast_counts_bind": (C.c_int, [vp, vp, C.c_size_t]),
+    "hast_counts_zero": (C.c_int, [vp, vp]),
+    "hast_counts_read": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+    "hast_counts_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "hast_classify_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
+    "hast_classify_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
+    "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "hast_get_hap": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
+    "hast_canon_kmer": (C.c_uint64, [C.c_char_p, C.c_int]),
+    "hast_chop_read": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_int, u64p]),
+    "hast_kmer_to_str": (None, [C.c_uint64, C.c_int, C.c_char_p]),
+    "hast_synth_keys_host": (C.c_int, [C.POINTER(SynthParams), C.c_int, C.c_uint64, C.c_size_t, vp]),
+    "hast_synth_reads_host": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, C.c_size_t, vp, vp]),
+    "hast_synth_keys_device": (C.c_int, [vp, C.POINTER(SynthParams), C.c_int, C.c_uint64, C.c_size_t, vp, vp]),
+    "hast_synth_reads_device": (C.c_int, [vp, C.POINTER(SynthParams), C.c_uint64, C.c_size_t, vp, vp, vp]),
+    "hast_synth_table_build": (C.c_int, [vp, C.POINTER(SynthParams)]),
+}
+
+
+def B_ALG_PER_READ(read_len: int, k: int) -> int:
+    """Algorithmic HBM bytes per read: every base once + one 64-B line per window."""
+    return read_len + max(0, read_len - k + 1) * 64
+
+
+class HastError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("hast: %s: %s" % (STATUS.get(status, status), msg))
+        self.status = status
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhast.so")
+
+
+def classify_exe():
+    return os.path.join(_HERE, "classify")
+
+
+def build(verbose=False):
+    """Compile libhast.so + classify for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if verbose or res.returncode:
+        print(res.stdout.decode())
+    if res.returncode:
+        raise RuntimeError("building libhast.so failed")
+
+
+def lib():
+    """The loaded library.  No fallback: a missing libhast.so is an error."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(or make -C hast_amd/csrc); there is no Python/CPU fallback" % p)
+        l = C.CDLL(p)
+        for name, (res, args) in ABI_SYMBOLS.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _LIB = l
+    return _LIB
+
+
+def _ck(st):
+    if st != 0:
+        raise HastError(st, lib().hast_last_error().decode())
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    return a
+
+
+# ---- host-side pieces --------------------------------------------------------------------------
+def parse_barcode(head: bytes) -> bytes:
+    s, n = C.c_size_t(), C.c_size_t()
+    lib().hast_parse_barcode(head, len(head), C.byref(s), C.byref(n))
+    return head[s.value:s.value + n.value]
+
+
+def get_hap(barcode: bytes, c0, c1, n0, n1, w0=1.0, w1=1.0) -> int:
+    return lib().hast_get_hap(barcode, len(barcode), c0, c1, n0, n1, w0, w1)
+
+
+def canon_kmer(s: bytes) -> int:
+    return lib().hast_canon_kmer(s, len(s))
+
+
+def chop_read(seq: bytes, k: int):
+    n = max(0, len(seq) - k + 1)
+    out = (C.c_uint64 * max(1, n))()
+    got = lib().hast_chop_read(seq, len(seq), k, out)
+    return [out[i] for i in range(got)]
+
+
+def make_params(k, read_len=150, n_keys_per_hap=0, n_barcodes=1, seed_k=0, seed_r=0, seed_b=0):
+    return SynthParams(seed_k, seed_r, seed_b, n_keys_per_hap, n_barcodes, read_len, k, 0)
+
+
+def synth_keys_host(p: SynthParams, hap, first, n):
+    out = np.empty(n, dtype=np.uint64)
+    _ck(lib().hast_synth_keys_host(C.byref(p), hap, first, n, _ptr(out)))
+    return out
+
+
+def synth_reads_host(p: SynthParams, first, n):
+    bases = np.empty(n * p.read_len, dtype=np.uint8)
+    ids = np.empty(n, dtype=np.uint32)
+    _ck(lib().hast_synth_reads_host(C.byref(p), first, n, _ptr(bases), _ptr(ids)))
+    return bases, ids
+
+
+# ---- device context ----------------------------------------------------------------------------
+class Context:
+    """One GPU context (hast_ctx).  Raises HastError(NO_DEVICE) when there is no GPU."""
+
+    def __init__(self, k, device=0):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        _ck(self._lib.hast_ctx_create(device, k, C.byref(self._h)))
+        self.k = k
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.hast_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self._lib.hast_ctx_stream(self._h)
+
+    def sync(self, stream=None):
+        _ck(self._lib.hast_stream_sync(self._h, stream))
+
+    # raw device memory
+    def alloc(self, nbytes) -> int:
+        p = C.c_void_p()
+        _ck(self._lib.hast_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        _ck(self._lib.hast_dev_free(self._h, C.c_void_p(dptr)))
+
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        d = self.alloc(max(arr.nbytes, 1))
+        _ck(self._lib.hast_memcpy_h2d(self._h, C.c_void_p(d), _ptr(arr), arr.nbytes))
+        return d
+
+    def to_host(self, dptr, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        _ck(self._lib.hast_memcpy_d2h(self._h, _ptr(out), C.c_void_p(dptr), out.nbytes))
+        return out
+
+    def memset(self, dptr, byte, nbytes, stream=None):
+        _ck(self._lib.hast_memset_d(self._h, C.c_void_p(dptr), byte, nbytes, stream))
+
+    # table
+    def table_reserve(self, max_keys, load_factor=0.5):
+        _ck(self._lib.hast_table_reserve(self._h, max_keys, load_factor))
+
+    def table_insert_text(self, hap, text: bytes) -> int:
+        lines = C.c_uint64()
+        _ck(self._lib.hast_table_insert_text(self._h, hap, text, len(text), C.byref(lines)))
+        return lines.value
+
+    def table_insert_keys(self, hap, keys: np.ndarray):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        _ck(self._lib.hast_table_insert_keys(self._h, hap, _ptr(keys), keys.size))
+
+    def table_insert_keys_device(self, hap, d_keys, n, stream=None):
+        _ck(self._lib.hast_table_insert_keys_device(self._h, hap, C.c_void_p(d_keys), n, stream))
+
+    def table_erase(self, keys) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        hit = np.zeros(keys.size, dtype=np.uint8)
+        _ck(self._lib.hast_table_erase(self._h, _ptr(keys), keys.size, _ptr(hit)))
+        return hit
+
+    def table_sizes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _ck(self._lib.hast_table_sizes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def table_lookup(self, keys) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        tags = np.zeros(keys.size, dtype=np.uint8)
+        _ck(self._lib.hast_table_lookup(self._h, _ptr(keys), keys.size, _ptr(tags)))
+        return tags
+
+    def table_info(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _ck(self._lib.hast_table_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # counters
+    def counts_resize(self, n):
+        _ck(self._lib.hast_counts_resize(self._h, n))
+
+    def counts_bind(self, d_counts, n):
+        _ck(self._lib.hast_counts_bind(self._h, C.c_void_p(d_counts), n))
+
+    def counts_zero(self, stream=None):
+        _ck(self._lib.hast_counts_zero(self._h, stream))
+
+    def counts_read(self, n):
+        c0 = np.zeros(n, dtype=np.uint32)
+        c1 = np.zeros(n, dtype=np.uint32)
+        neg = np.zeros(n, dtype=np.uint32)
+        _ck(self._lib.hast_counts_read(self._h, _ptr(c0), _ptr(c1), _ptr(neg), n))
+        return c0, c1, neg
+
+    # classify
+    def classify_device(self, d_bases, bases_bytes, n_reads, read_len, d_offsets=None, d_barcode_ids=None,
+                        d_votes=None, stream=None):
+        _ck(self._lib.hast_classify_device(self._h, C.c_void_p(d_bases), bases_bytes,
+                                           C.c_void_p(d_offsets) if d_offsets else None, read_len,
+                                           C.c_void_p(d_barcode_ids) if d_barcode_ids else None,
+                                           C.c_void_p(d_votes) if d_votes else None, n_reads, stream))
+
+    def classify_batch(self, bases: np.ndarray, offsets: np.ndarray, ids: np.ndarray, max_read_len):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        _ck(self._lib.hast_classify_batch(self._h, _ptr(bases), _ptr(offsets), _ptr(ids), ids.size, max_read_len))
+
+    # synthetic
+    def synth_keys_device(self, p, hap, first, n, d_out, stream=None):
+        _ck(self._lib.hast_synth_keys_device(self._h, C.byref(p), hap, first, n, C.c_void_p(d_out), stream))
+
+    def synth_reads_device(self, p, first, n, d_bases, d_ids, stream=None):
+        _ck(self._lib.hast_synth_reads_device(self._h, C.byref(p), first, n, C.c_void_p(d_bases),
+                                              C.c_void_p(d_ids) if d_ids else None, stream))
+
+    def synth_table_build(self, p):
+        _ck(self._lib.hast_synth_table_build(self._h, C.byref(p)))

@@ -1,0 +1,356 @@
+// classify_main.cpp -- the drop-in `classify` executable for HAST stage 01 on MI355X.
+//
+// Same command line, same stdout rows and same stderr skeleton as the reference program
+// (/root/reference/01.classify_stlfr_reads/classify.cpp:373-450), so
+// 01.classify_stlfr_reads/classify_stlfr_reads.sh:148-149 runs unchanged against it.  All k-mer
+// work (table build, adaptor scrub, read classification) happens on the GPU through the C ABI of
+// include/hast.h; this file only does what the reference does on the host around it: flag parsing,
+// FASTQ framing, barcode names -> dense ids, getHap + printing.
+//
+// Deliberate, documented deviations (all on inputs the reference does not survive either):
+//   * unopenable k-mer/read file: error + exit 2 (the reference loops forever, classify.cpp:41);
+//   * ragged k-mer line / read shorter than K: error + exit 3 (the reference assert-aborts,
+//     kmer.h:154,171);
+//   * K must be in [1,31] (the reference is correct up to 32 and silently wrong above).
+// Additive flags: --device N (GPU ordinal, default 0), --batch-reads N, --stats (timings on stderr).
+#include <getopt.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/hast.h"
+#include "fastq_reader.h"
+
+namespace {
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void logtime() {                                  // classify.cpp:17-21
+    time_t now = time(0);
+    fprintf(stderr, "%s\n", ctime(&now));
+}
+
+void print_usage() {                              // classify.cpp:280-310 (same text)
+    fputs("\n"
+          "Uasge :\n"
+          "    classify --hap0 hap0 --hap1 hap1 --read read1.fq [options]\n"
+          "\n"
+          "Options:\n"
+          "        -h/--help                       print this uasge and exit.\n"
+          "        -p/--hap0                       unshared kmer set of hap0.\n"
+          "        -m/--hap1                       unshared kmer set of hap1.\n"
+          "        -r/--read                       filial reads in fastq format. gzip file must be ended by \".gz\".\n"
+          "        -t/--thread   (8 default)       thread number to used.\n"
+          "        -w/--weight0  (1.0 default)     weight of hap0.\n"
+          "        -u/--weight1  (1.0 default)     weight of hap1.\n"
+          "        -f/--adaptor_f                  forward adaptor sequence.\n"
+          "                                        default \"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA\"\n"
+          "        -q/--adaptor_r                  reverse adaptor sequence.\n"
+          "                                        default \"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG\"\n"
+          "        --device N    (0 default)       MI355X ordinal to run on.\n"
+          "\n"
+          "Examples:\n"
+          "    ./classify --hap0 p.kmers --hap1 m.kmers --read input.fastq.gz\n"
+          "\n"
+          "    ./classify --hap0 p.kmers --hap1 m.kmers --read input.L01.fastq.gz --read input.L02.fastq.gz\n"
+          "\n"
+          "    ./classify --hap0 p.kmers --hap1 m.kmers --read input.L01.fastq.gz --read input.L02.fastq.gz -t 24 --weight1 1.04 -f CTGTCTCTTATACACATCTTAGGAAGACAA -q TCTGCTGAGTCGAGAACGTCTCTG\n"
+          "\n"
+          "Output format:\n"
+          "barcode\thaplotype(0/1/-1)\tkmer_count_hap0\tkmer_count_hap1\n"
+          "\n"
+          "Usage done.\n",
+          stderr);
+}
+
+[[noreturn]] void die(int code, const char *what) {
+    fprintf(stderr, "classify: ERROR: %s", what);
+    const char *e = hast_last_error();
+    if (e && *e) fprintf(stderr, " (%s)", e);
+    fputc('\n', stderr);
+    exit(code);
+}
+#define CK(call, what) do { if ((call) != HAST_OK) die(4, what); } while (0)
+
+bool slurp(const std::string &path, std::vector<char> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(sz > 0 ? (size_t)sz : 0);
+    bool ok = sz <= 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+    fclose(f);
+    return ok;
+}
+
+// the reference's startup self-test (TestAll, classify.cpp:341-367) on our host primitives
+bool self_test() {
+    size_t s, n;
+    const char *h = "VSDSDS#XXX_xxx_s/1";
+    hast_parse_barcode(h, strlen(h), &s, &n);
+    if (std::string(h + s, n) != "XXX_xxx_s") return false;
+    if (hast_canon_kmer("AGCTC", 5) != 0xD9 || hast_canon_kmer("GAGCT", 5) != 0xD9) return false;
+    uint64_t km[2];
+    if (hast_chop_read("GAGCTA", 6, 5, km) != 2 || km[0] != 0xD9 || km[1] != 0xD8) return false;
+    char buf[8];
+    hast_kmer_to_str(km[0], 5, buf);
+    if (strcmp(buf, "AGCTC")) return false;
+    hast_kmer_to_str(km[1], 5, buf);
+    return strcmp(buf, "AGCTA") == 0;
+}
+
+struct Barcodes {                                  // BarcodeCache keys (classify.cpp:51) -> dense ids
+    std::unordered_map<std::string, uint32_t> id;
+    std::vector<const std::string *> name;
+    uint32_t get(std::string_view bc) {
+        key_.assign(bc.data(), bc.size());
+        auto it = id.find(key_);
+        if (it != id.end()) return it->second;
+        uint32_t v = (uint32_t)name.size();
+        auto ins = id.emplace(key_, v);
+        name.push_back(&ins.first->first);
+        return v;
+    }
+    std::string key_;
+};
+
+struct Counts {                                    // host accumulators behind the device counters
+    std::vector<uint64_t> c0, c1, neg;
+    size_t device_cap = 0;
+};
+
+void flush_counts(hast_ctx *ctx, Counts &acc, size_t n_known, size_t new_cap) {
+    // fold what the device has counted so far into the host sums, then (re)size the device array
+    if (acc.device_cap) {
+        std::vector<uint32_t> a(acc.device_cap), b(acc.device_cap), c(acc.device_cap);
+        CK(hast_counts_read(ctx, a.data(), b.data(), c.data(), acc.device_cap), "reading counters");
+        if (acc.c0.size() < acc.device_cap) {
+            acc.c0.resize(acc.device_cap);
+            acc.c1.resize(acc.device_cap);
+            acc.neg.resize(acc.device_cap);
+        }
+        for (size_t i = 0; i < acc.device_cap; i++) {
+            acc.c0[i] += a[i];
+            acc.c1[i] += b[i];
+            acc.neg[i] += c[i];
+        }
+    }
+    (void)n_known;
+    CK(hast_counts_resize(ctx, new_cap), "allocating counters");
+    acc.device_cap = new_cap;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (!self_test()) {
+        fprintf(stderr, "classify: self-test failed\n");
+        return 1;
+    }
+    static struct option long_options[] = {                       // classify.cpp:375-386 + additive
+        {"hap0", required_argument, NULL, 'p'},      {"hap1", required_argument, NULL, 'm'},
+        {"read", required_argument, NULL, 'r'},      {"thread", required_argument, NULL, 't'},
+        {"weight0", required_argument, NULL, 'w'},   {"weight1", required_argument, NULL, 'u'},
+        {"adaptor_f", required_argument, NULL, 'f'}, {"adaptor_r", required_argument, NULL, 'q'},
+        {"help", no_argument, NULL, 'h'},            {"device", required_argument, NULL, 1001},
+        {"batch-reads", required_argument, NULL, 1002}, {"stats", no_argument, NULL, 1003},
+        {0, 0, 0, 0}};
+    static char optstring[] = "p:m:l:r:t:w:u:f:q:h";             // classify.cpp:387
+    std::string hap0, hap1;
+    std::string r1("CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA");   // classify.cpp:312
+    std::string r2("TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG");   // classify.cpp:313
+    std::vector<std::string> read;
+    int t_num = 8, device = 0;
+    size_t batch_reads = 1u << 20;
+    bool stats = false;
+    double w0 = 1.0, w1 = 1.0;
+    for (;;) {
+        int c = getopt_long(argc, argv, optstring, long_options, NULL);
+        if (c < 0) break;
+        switch (c) {
+        case 'f': r1 = optarg; break;
+        case 'q': r2 = optarg; break;
+        case 'p': hap0 = optarg; break;
+        case 'm': hap1 = optarg; break;
+        case 'r': read.push_back(optarg); break;
+        case 't': t_num = atoi(optarg); break;
+        case 'u': w1 = atof(optarg); break;
+        case 'w': w0 = atof(optarg); break;
+        case 1001: device = atoi(optarg); break;
+        case 1002: batch_reads = (size_t)std::max(1L, atol(optarg)); break;
+        case 1003: stats = true; break;
+        case 'h':
+        default: print_usage(); return -1;
+        }
+    }
+    if (hap0.empty() || hap1.empty() || read.empty() || t_num < 1) {   // classify.cpp:425-428
+        print_usage();
+        return -1;
+    }
+    fprintf(stderr, "__START__\n");
+    fprintf(stderr, " use hap0 weight %g\n", w0);
+    fprintf(stderr, " use hap1 weight %g\n", w1);
+    logtime();
+    const double t_start = now_s();
+
+    // ---- load_kmers (classify.cpp:30-46): both files to memory, table built on the GPU --------
+    std::vector<char> txt[2];
+    if (!slurp(hap0, txt[0])) die(2, ("cannot read " + hap0).c_str());
+    if (!slurp(hap1, txt[1])) die(2, ("cannot read " + hap1).c_str());
+    const void *nl0 = memchr(txt[0].data(), '\n', txt[0].size());
+    const size_t K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // :35-36
+    if (K < 1 || K > 31) {
+        fprintf(stderr, "classify: ERROR: K=%zu (length of the first line of %s) is outside [1,31]\n", K, hap0.c_str());
+        return 3;
+    }
+    hast_ctx *ctx = nullptr;
+    if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+    CK(hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.5), "allocating the k-mer table");
+    for (int h = 0; h < 2; h++) {
+        fprintf(stderr, "__load hap%d kmers__\n", h);
+        uint64_t lines = 0;
+        hast_status st = hast_table_insert_text(ctx, h, txt[h].data(), txt[h].size(), &lines);
+        if (st == HAST_ERR_FORMAT) die(3, "k-mer file is not one K-mer per line");
+        if (st != HAST_OK) die(4, "building the k-mer table");
+        if (h == 0 && !nl0 && txt[0].size() == K) {
+            // a single unterminated line: the reference still inserts the FIRST line of hap0 (:35-39)
+            uint64_t key = hast_canon_kmer(txt[0].data(), (int)K);
+            CK(hast_table_insert_keys(ctx, 0, &key, 1), "building the k-mer table");
+            lines = 1;
+        }
+        fprintf(stderr, "Recorded %llu haplotype %d specific %zu-mers\n", (unsigned long long)lines, h, K);   // :45
+        std::vector<char>().swap(txt[h]);
+    }
+    const double t_loaded = now_s();
+
+    // ---- InitAdaptor (classify.cpp:314-339) ---------------------------------------------------
+    fprintf(stderr, "Adaptor forward :%s\n", r1.c_str());
+    fprintf(stderr, "Adaptor reverse :%s\n", r2.c_str());
+    {
+        std::vector<uint64_t> keys;
+        for (const std::string *ad : {&r1, &r2}) {
+            if (ad->size() < K) {
+                fprintf(stderr, " WARN : adaptor shorter than K ignored\n");
+                continue;
+            }
+            std::vector<uint64_t> km(ad->size() - K + 1);
+            size_t n = hast_chop_read(ad->data(), ad->size(), (int)K, km.data());
+            for (size_t i = 0; i < n; i++)
+                if (std::find(keys.begin(), keys.end(), km[i]) == keys.end()) keys.push_back(km[i]);   // a repeat finds nothing the 2nd time
+        }
+        std::vector<uint8_t> hit(keys.size());
+        CK(hast_table_erase(ctx, keys.data(), keys.size(), hit.data()), "adaptor scrub");
+        char buf[40];
+        for (size_t i = 0; i < keys.size(); i++)
+            for (int h = 0; h < 2; h++)
+                if (hit[i] & (1 << h)) {
+                    hast_kmer_to_str(keys[i], (int)K, buf);
+                    fprintf(stderr, " INFO : erase a adaptor kmer from hap %d ; kmer= %s\n", h, buf);   // :321,325
+                }
+    }
+    uint64_t n_set[2] = {0, 0};
+    CK(hast_table_sizes(ctx, &n_set[0], &n_set[1]), "counting set sizes");
+    logtime();
+
+    // ---- processFastq (classify.cpp:238-278) for each --read, in order ------------------------
+    Barcodes barcodes;
+    Counts acc;
+    flush_counts(ctx, acc, 0, 1u << 20);
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> ids;
+    bases.reserve(batch_reads * 160);
+    offsets.reserve(batch_reads + 1);
+    ids.reserve(batch_reads);
+    uint32_t max_len = 0;
+    uint64_t total_reads = 0, total_bases = 0;
+    auto submit = [&]() {
+        if (ids.empty()) return;
+        if (barcodes.name.size() > acc.device_cap)
+            flush_counts(ctx, acc, barcodes.name.size(), std::max(barcodes.name.size() * 2, acc.device_cap * 2));
+        offsets.push_back(bases.size());
+        CK(hast_classify_batch(ctx, bases.data(), offsets.data(), ids.data(), ids.size(), max_len), "classifying a batch");
+        bases.clear();
+        offsets.clear();
+        ids.clear();
+        max_len = 0;
+    };
+    for (const auto &r : read) {
+        fprintf(stderr, "__process read: %s\n", r.c_str());
+        hast::LineSource in;
+        if (!in.open(r)) die(2, ("cannot open " + r).c_str());
+        for (;;) {
+            bool eof;
+            std::string_view head = in.getline(eof);
+            if (eof) break;                                                       // :257
+            size_t bs, bn;
+            hast_parse_barcode(head.data(), head.size(), &bs, &bn);               // :189
+            const uint32_t id = barcodes.get(head.substr(bs, bn));
+            std::string_view seq = in.getline(eof);                               // :258
+            const bool has_n = memchr(seq.data(), 'N', seq.size()) != nullptr;
+            if (seq.size() < K && !has_n) {
+                fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s (record %llu)\n", K, r.c_str(),
+                        (unsigned long long)total_reads);
+                return 3;                                                         // reference: assert, kmer.h:171
+            }
+            offsets.push_back(bases.size());
+            bases.insert(bases.end(), seq.begin(), seq.end());
+            ids.push_back(id);
+            max_len = std::max<uint32_t>(max_len, (uint32_t)seq.size());
+            total_reads++;
+            total_bases += seq.size();
+            in.getline(eof);                                                      // :267-268
+            in.getline(eof);
+            if (ids.size() >= batch_reads) submit();
+        }
+        submit();
+        logtime();
+        fprintf(stderr, "__process read done__\n");
+    }
+    flush_counts(ctx, acc, barcodes.name.size(), 1);
+    const double t_classified = now_s();
+
+    // ---- printBarcodeInfos (classify.cpp:93-102): byte-wise sorted rows ------------------------
+    fprintf(stderr, "__print result__\n");
+    std::vector<uint32_t> order(barcodes.name.size());
+    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return *barcodes.name[a] < *barcodes.name[b]; });
+    std::string out;
+    out.reserve(1 << 20);
+    char num[64];
+    for (uint32_t i : order) {
+        const std::string &bc = *barcodes.name[i];
+        const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
+        int hap = hast_get_hap(bc.data(), bc.size(), (uint32_t)c0, (uint32_t)c1, n_set[0], n_set[1], w0, w1);
+        out += bc;
+        snprintf(num, sizeof(num), "\t%d\t%d\t%d\n", hap, (int)c0, (int)c1);      // `int` counters, classify.cpp:51
+        out += num;
+        if (out.size() > (1 << 20) - 256) {
+            fwrite(out.data(), 1, out.size(), stdout);
+            out.clear();
+        }
+    }
+    fwrite(out.data(), 1, out.size(), stdout);
+    fflush(stdout);
+    logtime();
+    if (stats) {
+        double dt = t_classified - t_loaded;
+        fprintf(stderr, "__stats__ K=%zu set0=%llu set1=%llu reads=%llu bases=%llu barcodes=%zu load_s=%.3f classify_s=%.3f Mbp_per_s=%.1f\n",
+                K, (unsigned long long)n_set[0], (unsigned long long)n_set[1], (unsigned long long)total_reads,
+                (unsigned long long)total_bases, barcodes.name.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
+    }
+    fprintf(stderr, "__END__\n");
+    hast_ctx_destroy(ctx);
+    return 0;
+}

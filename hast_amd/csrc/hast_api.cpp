@@ -1,0 +1,658 @@
+// hast_api.cpp -- the C ABI of include/hast.h: context, table, counters, classify, synthetic data.
+// Host C++ over the HIP runtime; all device work is in hast_kernels.hip.  No CPU fallback exists:
+// every compute entry point needs a context, and a context needs a GPU.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/hast.h"
+#include "hast_common.h"
+#include "hast_device.h"
+
+using namespace hast;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+hast_status fail(hast_status st, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                \
+    } while (0)
+
+struct Staging {          // one pinned+device buffer set of hast_classify_batch's double buffer
+    uint8_t *h_bases = nullptr, *d_bases = nullptr;
+    uint64_t *h_off = nullptr, *d_off = nullptr;
+    uint32_t *h_ids = nullptr, *d_ids = nullptr;
+    size_t cap_bases = 0, cap_reads = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+}  // namespace
+
+struct hast_ctx {
+    int device = 0;
+    int k = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    // table
+    uint64_t *d_slots = nullptr;
+    uint32_t nbuckets = 0;
+    // counters
+    uint32_t *d_counts = nullptr;
+    size_t n_barcodes = 0;
+    bool counts_owned = false;
+    // small scratch
+    uint32_t *d_err = nullptr;              // [4]
+    unsigned long long *d_cnt = nullptr;    // [2]
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    Staging stage[2];
+    unsigned batch_no = 0;
+};
+
+namespace {
+
+hast_status use(hast_ctx *c) {
+    if (!c) return fail(HAST_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return HAST_OK;
+}
+
+hast_status ensure_scratch(hast_ctx *c, size_t bytes) {
+    if (c->scratch_bytes >= bytes) return HAST_OK;
+    if (c->d_scratch) HIP_TRY(hipFree(c->d_scratch));
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+    return HAST_OK;
+}
+
+constexpr size_t kChunkBytes = 64u << 20;   // staging granule for table input
+
+hast_status check_err_word(hast_ctx *c, hipStream_t s) {
+    uint32_t e = 0;
+    HIP_TRY(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (e) HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), s));
+    if (e & 2) return fail(HAST_ERR_FORMAT, "k-mer text: a line is not exactly K=%d bytes", c->k);
+    if (e & 1) return fail(HAST_ERR_TABLE_FULL, "k-mer table full: reserve more keys");
+    return HAST_OK;
+}
+
+SynthParams resolve(const hast_synth_params *p) {
+    SynthParams r;
+    r.seed_k = p->seed_k ? p->seed_k : 0x4841535401ull;
+    r.seed_r = p->seed_r ? p->seed_r : 0x4841535402ull;
+    r.seed_b = p->seed_b ? p->seed_b : 0x4841535403ull;
+    r.n_keys_per_hap = p->n_keys_per_hap;
+    r.n_barcodes = p->n_barcodes ? p->n_barcodes : 1;
+    r.read_len = p->read_len;
+    r.k = p->k;
+    r.reserved = 0;
+    return r;
+}
+
+hast_status check_synth(const hast_synth_params *p) {
+    if (!p) return fail(HAST_ERR_INVALID, "null synth params");
+    if (p->k < 1 || p->k > 31) return fail(HAST_ERR_INVALID, "synth k=%u out of [1,31]", p->k);
+    return HAST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hast_version(void) { return "hast-mi355x 0.1 (gfx950)"; }
+const char *hast_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
+    if (!out) return fail(HAST_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (k < 1 || k > 31) return fail(HAST_ERR_INVALID, "K=%d out of [1,31]", k);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(HAST_ERR_NO_DEVICE, "no HIP device (%s); libhast has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(HAST_ERR_NO_DEVICE, "device %d not in [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hast_ctx *c = new (std::nothrow) hast_ctx();
+    if (!c) return fail(HAST_ERR_OOM, "host allocation failed");
+    c->device = device;
+    c->k = k;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    hast_status st = HAST_OK;
+    auto bail = [&](hipError_t he, const char *what) {
+        if (he != hipSuccess && st == HAST_OK) st = fail(HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
+    };
+    bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
+    bail(hipMalloc(&c->d_cnt, 2 * sizeof(unsigned long long)), "hipMalloc(cnt)");
+    if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
+    if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    for (auto &s : c->stage)
+        if (st == HAST_OK) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+    if (st != HAST_OK) {
+        hast_ctx_destroy(c);
+        return st;
+    }
+    *out = c;
+    return HAST_OK;
+}
+
+void hast_ctx_destroy(hast_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->stage) {
+        if (s.h_bases) (void)hipHostFree(s.h_bases);
+        if (s.h_off) (void)hipHostFree(s.h_off);
+        if (s.h_ids) (void)hipHostFree(s.h_ids);
+        if (s.d_bases) (void)hipFree(s.d_bases);
+        if (s.d_off) (void)hipFree(s.d_off);
+        if (s.d_ids) (void)hipFree(s.d_ids);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (c->d_slots) (void)hipFree(c->d_slots);
+    if (c->counts_owned && c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int hast_ctx_k(const hast_ctx *c) { return c ? c->k : 0; }
+int hast_ctx_device(const hast_ctx *c) { return c ? c->device : -1; }
+hast_stream hast_ctx_stream(const hast_ctx *c) { return c ? (hast_stream)c->stream : nullptr; }
+
+hast_status hast_stream_sync(hast_ctx *c, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    HIP_TRY(hipStreamSynchronize(s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+hast_status hast_dev_alloc(hast_ctx *c, size_t bytes, void **d_out) {
+    if (hast_status st = use(c)) return st;
+    if (!d_out) return fail(HAST_ERR_INVALID, "d_out is null");
+    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    return HAST_OK;
+}
+hast_status hast_dev_free(hast_ctx *c, void *p) {
+    if (hast_status st = use(c)) return st;
+    if (p) HIP_TRY(hipFree(p));
+    return HAST_OK;
+}
+hast_status hast_memcpy_h2d(hast_ctx *c, void *d, const void *s, size_t n) {
+    if (hast_status st = use(c)) return st;
+    if (n) HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice));
+    return HAST_OK;
+}
+hast_status hast_memcpy_d2h(hast_ctx *c, void *d, const void *s, size_t n) {
+    if (hast_status st = use(c)) return st;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
+    return HAST_OK;
+}
+hast_status hast_memset_d(hast_ctx *c, void *d, int byte, size_t n, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (n) HIP_TRY(hipMemsetAsync(d, byte, n, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
+    if (hast_status st = use(c)) return st;
+    if (lf <= 0) lf = 0.5;
+    if (lf > 0.9) return fail(HAST_ERR_INVALID, "load factor %.3f > 0.9", lf);
+    double want = (double)(max_keys ? max_keys : 1) / lf / kSlotsPerBucket;
+    uint64_t nb = (uint64_t)want + 1;
+    if (nb < 64) nb = 64;
+    if (nb >= (1ull << 32)) return fail(HAST_ERR_INVALID, "table of %llu buckets exceeds 2^32", (unsigned long long)nb);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_slots) HIP_TRY(hipFree(c->d_slots));
+    c->d_slots = nullptr;
+    c->nbuckets = 0;
+    size_t bytes = (size_t)nb * kSlotsPerBucket * sizeof(uint64_t);
+    HIP_TRY(hipMalloc(&c->d_slots, bytes));
+    HIP_TRY(hipMemsetAsync(c->d_slots, 0xFF, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->nbuckets = (uint32_t)nb;
+    return HAST_OK;
+}
+
+static hast_status need_table(hast_ctx *c, int hap) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_slots) return fail(HAST_ERR_INVALID, "call hast_table_reserve first");
+    if (hap != 0 && hap != 1) return fail(HAST_ERR_INVALID, "hap must be 0 or 1");
+    return HAST_OK;
+}
+
+hast_status hast_table_insert_keys_device(hast_ctx *c, int hap, const uint64_t *d_keys, size_t n, hast_stream s) {
+    if (hast_status st = need_table(c, hap)) return st;
+    hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    HIP_TRY(launch_insert_keys(c->d_slots, c->nbuckets, d_keys, n, 1u << hap, c->d_err, hs));
+    return check_err_word(c, hs);
+}
+
+hast_status hast_table_insert_keys(hast_ctx *c, int hap, const uint64_t *keys, size_t n) {
+    if (hast_status st = need_table(c, hap)) return st;
+    if (n && !keys) return fail(HAST_ERR_INVALID, "keys is null");
+    const size_t per = kChunkBytes / sizeof(uint64_t);
+    if (hast_status st = ensure_scratch(c, std::min(n, per) * sizeof(uint64_t) + 16)) return st;
+    for (size_t i = 0; i < n; i += per) {
+        size_t m = std::min(per, n - i);
+        HIP_TRY(hipMemcpyAsync(c->d_scratch, keys + i, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_insert_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return check_err_word(c, c->stream);
+}
+
+hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_t nbytes, uint64_t *lines_out) {
+    if (hast_status st = need_table(c, hap)) return st;
+    if (lines_out) *lines_out = 0;
+    if (nbytes && !text) return fail(HAST_ERR_INVALID, "text is null");
+    const size_t stride = (size_t)c->k + 1;
+    // classify.cpp:41: pieces are '\n'-terminated lines; a trailing piece without '\n' is dropped.
+    // With fixed-width lines that is floor(nbytes/stride) lines, provided every line really is K bytes
+    // (checked on the device); a ragged file fails the check (the reference asserts, kmer.h:154).
+    size_t n_lines = nbytes / stride;
+    size_t rem = nbytes - n_lines * stride;
+    // the dropped tail must itself not contain a newline (else lines are ragged)
+    if (rem && memchr(text + n_lines * stride, '\n', rem)) return fail(HAST_ERR_FORMAT, "k-mer text: ragged last line");
+    const size_t per = (kChunkBytes / stride);
+    if (hast_status st = ensure_scratch(c, std::min(n_lines, per) * stride + 16)) return st;
+    for (size_t i = 0; i < n_lines; i += per) {
+        size_t m = std::min(per, n_lines - i);
+        HIP_TRY(hipMemcpyAsync(c->d_scratch, text + i * stride, m * stride, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_insert_text(c->d_slots, c->nbuckets, (const char *)c->d_scratch, m, c->k, 1u << hap, c->d_err, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (hast_status st = check_err_word(c, c->stream)) return st;
+    if (lines_out) *lines_out = n_lines;
+    return HAST_OK;
+}
+
+hast_status hast_table_erase(hast_ctx *c, const uint64_t *keys, size_t n, uint8_t *out_hit) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n == 0) return HAST_OK;
+    if (!keys) return fail(HAST_ERR_INVALID, "keys is null");
+    size_t kb = n * sizeof(uint64_t);
+    if (hast_status st = ensure_scratch(c, kb + n + 16)) return st;
+    uint8_t *d_hit = (uint8_t *)c->d_scratch + kb;
+    HIP_TRY(hipMemcpyAsync(c->d_scratch, keys, kb, hipMemcpyHostToDevice, c->stream));
+    // one key at a time per launch order is not required: distinct keys touch distinct slots, and a
+    // key listed twice reports its tags once (the second atomicAnd sees them already cleared) --
+    // the same as the reference's find-then-erase loop (classify.cpp:318-337).
+    HIP_TRY(launch_erase_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, n, d_hit, c->stream));
+    std::vector<uint8_t> hit(n);
+    HIP_TRY(hipMemcpyAsync(hit.data(), d_hit, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out_hit) memcpy(out_hit, hit.data(), n);
+    return HAST_OK;
+}
+
+hast_status hast_table_lookup(hast_ctx *c, const uint64_t *keys, size_t n, uint8_t *out_tags) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n == 0) return HAST_OK;
+    if (!keys || !out_tags) return fail(HAST_ERR_INVALID, "null argument");
+    size_t kb = n * sizeof(uint64_t);
+    if (hast_status st = ensure_scratch(c, kb + n + 16)) return st;
+    uint8_t *d_tags = (uint8_t *)c->d_scratch + kb;
+    HIP_TRY(hipMemcpyAsync(c->d_scratch, keys, kb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_lookup_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, n, d_tags, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_tags, d_tags, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_table_sizes(hast_ctx *c, uint64_t *n0, uint64_t *n1) {
+    if (hast_status st = need_table(c, 0)) return st;
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(h), c->stream));
+    HIP_TRY(launch_count_tags(c->d_slots, (size_t)c->nbuckets * kSlotsPerBucket, c->d_cnt, c->stream));
+    HIP_TRY(hipMemcpyAsync(h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n0) *n0 = h[0];
+    if (n1) *n1 = h[1];
+    return HAST_OK;
+}
+
+hast_status hast_table_info(const hast_ctx *c, uint64_t *n_buckets, uint64_t *bytes) {
+    if (!c) return fail(HAST_ERR_INVALID, "null context");
+    if (n_buckets) *n_buckets = c->nbuckets;
+    if (bytes) *bytes = (uint64_t)c->nbuckets * kSlotsPerBucket * sizeof(uint64_t);
+    return HAST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+hast_status hast_counts_resize(hast_ctx *c, size_t n) {
+    if (hast_status st = use(c)) return st;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->counts_owned && c->d_counts) HIP_TRY(hipFree(c->d_counts));
+    c->d_counts = nullptr;
+    c->n_barcodes = 0;
+    c->counts_owned = false;
+    size_t bytes = (n ? n : 1) * 4 * sizeof(uint32_t);
+    HIP_TRY(hipMalloc(&c->d_counts, bytes));
+    c->counts_owned = true;
+    c->n_barcodes = n;
+    HIP_TRY(hipMemsetAsync(c->d_counts, 0, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_counts_bind(hast_ctx *c, uint32_t *d_counts, size_t n) {
+    if (hast_status st = use(c)) return st;
+    if (!d_counts) return fail(HAST_ERR_INVALID, "d_counts is null");
+    if ((uintptr_t)d_counts & 15) return fail(HAST_ERR_INVALID, "d_counts must be 16-byte aligned");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->counts_owned && c->d_counts) HIP_TRY(hipFree(c->d_counts));
+    c->d_counts = d_counts;
+    c->counts_owned = false;
+    c->n_barcodes = n;
+    return HAST_OK;
+}
+
+hast_status hast_counts_zero(hast_ctx *c, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters: call hast_counts_resize/bind");
+    HIP_TRY(hipMemsetAsync(c->d_counts, 0, c->n_barcodes * 4 * sizeof(uint32_t), s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_counts_read(hast_ctx *c, uint32_t *c0, uint32_t *c1, uint32_t *neg, size_t n) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters");
+    if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
+    std::vector<uint32_t> h(n * 4);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpy(h.data(), c->d_counts, n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        if (c0) c0[i] = h[4 * i];
+        if (c1) c1[i] = h[4 * i + 1];
+        if (neg) neg[i] = h[4 * i + 2];
+    }
+    return HAST_OK;
+}
+
+// RCCL, resolved lazily so that single-GPU users never load it.
+hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
+    if (!ctxs || n < 1) return fail(HAST_ERR_INVALID, "no contexts");
+    if (n == 1) return HAST_OK;
+    typedef void *comm_t;
+    typedef int (*init_all_t)(comm_t *, int, const int *);
+    typedef int (*allreduce_t)(const void *, void *, size_t, int, int, comm_t, hipStream_t);
+    typedef int (*group_t)(void);
+    typedef int (*destroy_t)(comm_t);
+    static void *lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(HAST_ERR_RCCL, "cannot load librccl: %s", dlerror());
+    auto init_all = (init_all_t)dlsym(lib, "ncclCommInitAll");
+    auto allreduce = (allreduce_t)dlsym(lib, "ncclAllReduce");
+    auto gstart = (group_t)dlsym(lib, "ncclGroupStart");
+    auto gend = (group_t)dlsym(lib, "ncclGroupEnd");
+    auto destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
+    if (!init_all || !allreduce || !gstart || !gend || !destroy) return fail(HAST_ERR_RCCL, "librccl lacks symbols");
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !ctxs[i]->d_counts || ctxs[i]->n_barcodes != ctxs[0]->n_barcodes)
+            return fail(HAST_ERR_INVALID, "contexts need equal-size counters");
+        devs[i] = ctxs[i]->device;
+    }
+    std::vector<comm_t> comms(n);
+    if (int rc = init_all(comms.data(), n, devs.data())) return fail(HAST_ERR_RCCL, "ncclCommInitAll failed (%d)", rc);
+    const int kUint32 = 3, kSum = 0;   // ncclUint32, ncclSum
+    int rc = gstart();
+    for (int i = 0; i < n && !rc; i++) {
+        (void)hipSetDevice(ctxs[i]->device);
+        rc = allreduce(ctxs[i]->d_counts, ctxs[i]->d_counts, ctxs[i]->n_barcodes * 4, kUint32, kSum, comms[i], ctxs[i]->stream);
+    }
+    int rc2 = gend();
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(ctxs[i]->device);
+        (void)hipStreamSynchronize(ctxs[i]->stream);
+    }
+    for (auto cm : comms) destroy(cm);
+    if (rc || rc2) return fail(HAST_ERR_RCCL, "ncclAllReduce failed (%d/%d)", rc, rc2);
+    return HAST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                 uint32_t read_len, const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads,
+                                 hast_stream s) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n_reads == 0) return HAST_OK;
+    if (!d_bases) return fail(HAST_ERR_INVALID, "d_bases is null");
+    if (d_barcode_ids && !c->d_counts) return fail(HAST_ERR_INVALID, "barcode ids given but no counters bound");
+    if (read_len == 0 || read_len > (1u << 24)) return fail(HAST_ERR_INVALID, "read_len %u out of range", read_len);
+    if (!d_offsets && (uint64_t)n_reads * read_len > bases_bytes)
+        return fail(HAST_ERR_INVALID, "bases_bytes too small for %zu reads of %u", n_reads, read_len);
+    ClassifyArgs a;
+    a.bases = d_bases;
+    a.bases_bytes = bases_bytes;
+    a.offsets = d_offsets;
+    a.barcode_ids = d_barcode_ids;
+    a.votes = d_votes;
+    a.counts = c->d_counts;
+    a.slots = c->d_slots;
+    a.n_reads = n_reads;
+    a.nbuckets = c->nbuckets;
+    a.read_len = read_len;
+    a.k = c->k;
+    a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
+    a.w64 = (read_len + 31) / 32;
+    // reads per tile: as many as fit ~24 KB of LDS, at most 64, so that >= 6 workgroups fit a CU
+    const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 4 + 4 + 8;
+    uint32_t tr = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (24u << 10) / per_read));
+    a.tile_reads = tr;
+    const size_t smem = per_read * tr;
+    if (smem > (160u << 10)) return fail(HAST_ERR_INVALID, "read_len %u needs %zu B of LDS", read_len, smem);
+    a.div_magic = 0;
+    if (a.max_pos > 0) {
+        // __umulhi(q, magic) == q / max_pos for every q the kernel forms (q < tr*P + 256)
+        uint64_t qmax = (uint64_t)tr * a.max_pos + 1024;
+        if (qmax * a.max_pos < (1ull << 32)) a.div_magic = (uint32_t)((1ull << 32) / a.max_pos) + 1;
+        if (a.max_pos == 1) a.div_magic = 0;   // 2^32/1+1 does not fit; plain division
+    }
+    const uint64_t n_tiles = (n_reads + tr - 1) / tr;
+    const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
+    HIP_TRY(launch_classify(a, grid, smem, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+static hast_status stage_reserve(hast_ctx *c, Staging &s, size_t nbytes, size_t nreads) {
+    (void)c;
+    if (s.cap_bases < nbytes) {
+        if (s.h_bases) HIP_TRY(hipHostFree(s.h_bases));
+        if (s.d_bases) HIP_TRY(hipFree(s.d_bases));
+        s.h_bases = s.d_bases = nullptr;
+        s.cap_bases = 0;
+        size_t cap = nbytes + nbytes / 4 + 64;
+        HIP_TRY(hipHostMalloc((void **)&s.h_bases, cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&s.d_bases, cap));
+        s.cap_bases = cap;
+    }
+    if (s.cap_reads < nreads) {
+        if (s.h_off) HIP_TRY(hipHostFree(s.h_off));
+        if (s.h_ids) HIP_TRY(hipHostFree(s.h_ids));
+        if (s.d_off) HIP_TRY(hipFree(s.d_off));
+        if (s.d_ids) HIP_TRY(hipFree(s.d_ids));
+        s.h_off = s.d_off = nullptr;
+        s.h_ids = s.d_ids = nullptr;
+        s.cap_reads = 0;
+        size_t cap = nreads + nreads / 4 + 16;
+        HIP_TRY(hipHostMalloc((void **)&s.h_off, (cap + 1) * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&s.d_off, (cap + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void **)&s.d_ids, cap * sizeof(uint32_t)));
+        s.cap_reads = cap;
+    }
+    return HAST_OK;
+}
+
+hast_status hast_classify_batch(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids,
+                                size_t n_reads, uint32_t max_read_len) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n_reads == 0) return HAST_OK;
+    if (!bases || !offsets || !ids) return fail(HAST_ERR_INVALID, "null argument");
+    if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters bound");
+    Staging &s = c->stage[c->batch_no++ & 1];
+    if (s.in_flight) {
+        HIP_TRY(hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    const size_t nbytes = offsets[n_reads] - offsets[0];
+    if (hast_status st = stage_reserve(c, s, nbytes, n_reads)) return st;
+    memcpy(s.h_bases, bases + offsets[0], nbytes);
+    const uint64_t o0 = offsets[0];
+    for (size_t i = 0; i <= n_reads; i++) s.h_off[i] = offsets[i] - o0;
+    memcpy(s.h_ids, ids, n_reads * sizeof(uint32_t));
+    HIP_TRY(hipMemcpyAsync(s.d_bases, s.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_ids, s.h_ids, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (hast_status st = hast_classify_device(c, s.d_bases, nbytes, s.d_off, max_read_len, s.d_ids, nullptr, n_reads, c->stream))
+        return st;
+    HIP_TRY(hipEventRecord(s.done, c->stream));
+    s.in_flight = true;
+    return HAST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side pieces
+void hast_parse_barcode(const char *head, size_t len, size_t *start, size_t *n) {
+    // classify.cpp:112-119: last '#', last '/'; substr(s+1, e-s-1) where a negative count means "to the end"
+    ptrdiff_t s = -1, e = -1;
+    for (size_t i = 0; i < len; i++) {
+        if (head[i] == '#') s = (ptrdiff_t)i;
+        else if (head[i] == '/') e = (ptrdiff_t)i;
+    }
+    size_t pos = (size_t)(s + 1);
+    size_t avail = len - pos;
+    ptrdiff_t cnt = e - s - 1;
+    *start = pos;
+    *n = (cnt < 0 || (size_t)cnt > avail) ? avail : (size_t)cnt;
+}
+
+int hast_get_hap(const char *bc, size_t blen, uint32_t c0, uint32_t c1, uint64_t n0, uint64_t n1, double w0, double w1) {
+    // classify.cpp:66-86
+    if ((blen == 5 && !memcmp(bc, "0_0_0", 5)) || (blen == 3 && !memcmp(bc, "0_0", 3)) || (blen == 1 && bc[0] == '0'))
+        return -1;
+    if (c0 > 0 && c1 > 0) {
+        // the reference holds counts in `int` (classify.cpp:51) and converts int -> double
+        double df0 = double((int)c0) / double(n0);
+        double df1 = double((int)c1) / double(n1);
+        df0 *= w0;
+        df1 *= w1;
+        if (df0 > df1) return 0;
+        if (df1 > df0) return 1;
+        return -1;
+    }
+    if (c0 > 0) return 0;
+    if (c1 > 0) return 1;
+    return -1;
+}
+
+uint64_t hast_canon_kmer(const char *s, int k) { return kmer_canon(kmer_pack(s, k), k); }
+
+size_t hast_chop_read(const char *seq, size_t len, int k, uint64_t *out) {
+    if (k < 1 || k > 31 || len < (size_t)k) return 0;
+    const uint64_t mask = kmer_mask(k);
+    uint64_t w = kmer_pack(seq, k);
+    size_t n = 0;
+    out[n++] = kmer_canon(w, k);
+    for (size_t i = (size_t)k; i < len; i++) {
+        w = ((w << 2) & mask) | base_code((uint8_t)seq[i]);
+        out[n++] = kmer_canon(w, k);
+    }
+    return n;
+}
+
+void hast_kmer_to_str(uint64_t kmer, int k, char *out) {
+    for (int i = 0; i < k; i++) {
+        out[k - 1 - i] = "ACTG"[kmer & 3];   // kmer.h:12
+        kmer >>= 2;
+    }
+    out[k] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+hast_status hast_synth_keys_host(const hast_synth_params *p, int hap, uint64_t first, size_t n, uint64_t *out) {
+    if (hast_status st = check_synth(p)) return st;
+    SynthParams sp = resolve(p);
+    for (size_t i = 0; i < n; i++) out[i] = synth_key(sp, hap, first + i);
+    return HAST_OK;
+}
+
+hast_status hast_synth_reads_host(const hast_synth_params *p, uint64_t first, size_t n, uint8_t *bases, uint32_t *ids) {
+    if (hast_status st = check_synth(p)) return st;
+    SynthParams sp = resolve(p);
+    if (sp.read_len == 0) return fail(HAST_ERR_INVALID, "read_len is 0");
+    for (size_t i = 0; i < n; i++) {
+        uint32_t bc;
+        synth_read(sp, first + i, bases + i * (size_t)sp.read_len, &bc);
+        if (ids) ids[i] = bc;
+    }
+    return HAST_OK;
+}
+
+hast_status hast_synth_keys_device(hast_ctx *c, const hast_synth_params *p, int hap, uint64_t first, size_t n,
+                                   uint64_t *d_out, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (hast_status st = check_synth(p)) return st;
+    HIP_TRY(launch_synth_keys(resolve(p), hap, first, n, d_out, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_synth_reads_device(hast_ctx *c, const hast_synth_params *p, uint64_t first, size_t n, uint8_t *d_bases,
+                                    uint32_t *d_ids, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (hast_status st = check_synth(p)) return st;
+    if (p->read_len == 0) return fail(HAST_ERR_INVALID, "read_len is 0");
+    HIP_TRY(launch_synth_reads(resolve(p), first, n, d_bases, d_ids, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_synth_table_build(hast_ctx *c, const hast_synth_params *p) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (hast_status st = check_synth(p)) return st;
+    if ((int)p->k != c->k) return fail(HAST_ERR_INVALID, "synth k=%u != context K=%d", p->k, c->k);
+    SynthParams sp = resolve(p);
+    const size_t per = kChunkBytes / sizeof(uint64_t);
+    if (hast_status st = ensure_scratch(c, std::min<uint64_t>(sp.n_keys_per_hap, per) * sizeof(uint64_t) + 16)) return st;
+    for (int hap = 0; hap < 2; hap++)
+        for (uint64_t i = 0; i < sp.n_keys_per_hap; i += per) {
+            size_t m = (size_t)std::min<uint64_t>(per, sp.n_keys_per_hap - i);
+            HIP_TRY(launch_synth_keys(sp, hap, i, m, (uint64_t *)c->d_scratch, c->stream));
+            HIP_TRY(launch_insert_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+        }
+    return check_err_word(c, c->stream);
+}
+
+}  // extern "C"

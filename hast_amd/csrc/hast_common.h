@@ -1,0 +1,119 @@
+// hast_common.h -- integer primitives shared by host C++ and gfx950 device code.
+//
+// K-mer arithmetic follows the reference's kmer/kmer.h semantics (A0 C1 T2 G3 via (c&6)>>1,
+// first base most significant, canonical = min(fwd, revcomp)); the bit tricks are our own.
+// Table hashing and the synthetic-workload generator are ours (nothing in the reference
+// corresponds to them).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HAST_HD __host__ __device__ __forceinline__
+#else
+#define HAST_HD inline
+#endif
+
+namespace hast {
+
+// ---- 2-bit k-mers (kmer.h:11-13, 129-166, 196-210) -----------------------------------------
+HAST_HD uint32_t base_code(uint32_t c) { return (c & 6u) >> 1; }              // kmer.h:11
+HAST_HD uint64_t kmer_mask(int k) { return (1ull << (2 * k)) - 1; }            // k <= 31
+
+// reverse complement of a 2K-bit value: complement = code^2 (kmer.h:13), then reverse the order
+// of the 2-bit groups and right-align (kmer.h:196-210).
+HAST_HD uint64_t kmer_revcomp(uint64_t x, int k) {
+    x ^= 0xAAAAAAAAAAAAAAAAull;
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brevll(x);                                         // full bit reversal (2 x v_bfrev_b32)
+    x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);  // un-swap pairs
+#else
+    x = ((x & 0x3333333333333333ull) << 2) | ((x >> 2) & 0x3333333333333333ull);
+    x = ((x & 0x0F0F0F0F0F0F0F0Full) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);
+    x = __builtin_bswap64(x);
+#endif
+    return x >> (64 - 2 * k);
+}
+
+HAST_HD uint64_t kmer_canon(uint64_t fwd, int k) {
+    uint64_t rc = kmer_revcomp(fwd, k);
+    return fwd < rc ? fwd : rc;                                                // kmer.h:161-165
+}
+
+HAST_HD uint64_t kmer_pack(const char *s, int k) {                             // kmer.h:156-160
+    uint64_t w = 0;
+    for (int i = 0; i < k; i++) w = (w << 2) | base_code((uint8_t)s[i]);
+    return w;
+}
+
+// ---- table geometry ---------------------------------------------------------------------------
+constexpr int      kSlotsPerBucket = 8;            // 8 x 8 B = one 64-B line
+constexpr uint64_t kEmptySlot = ~0ull;             // (key<<2|tags) can never be all ones: the
+                                                   // all-G k-mer is never canonical (all-C is smaller)
+
+// home bucket of a canonical key; nbuckets < 2^32
+HAST_HD uint32_t bucket_hash32(uint64_t key) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull;
+    uint32_t h = (uint32_t)(x >> 32) ^ (uint32_t)x;
+    return h * 0x85EBCA6Bu;
+}
+HAST_HD uint32_t home_bucket(uint64_t key, uint32_t nbuckets) {
+    return (uint32_t)(((uint64_t)bucket_hash32(key) * nbuckets) >> 32);
+}
+
+// ---- synthetic workload ----------------------------------------------------------
+HAST_HD uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+HAST_HD uint64_t synth_rand(uint64_t seed, uint64_t a, uint64_t b) {
+    return splitmix64(splitmix64(seed ^ splitmix64(a)) + b);
+}
+
+struct SynthParams {          // mirrors hast_synth_params with defaults resolved
+    uint64_t seed_k, seed_r, seed_b;
+    uint64_t n_keys_per_hap;
+    uint32_t n_barcodes, read_len, k, reserved;
+};
+
+// key j of haplotype h: canonical(random 2K bits).  Duplicates / keys in both sets occur by chance.
+HAST_HD uint64_t synth_key(const SynthParams &p, int hap, uint64_t j) {
+    return kmer_canon(synth_rand(p.seed_k, (uint64_t)hap, j) & kmer_mask((int)p.k), (int)p.k);
+}
+
+HAST_HD uint32_t synth_barcode(const SynthParams &p, uint64_t read) {
+    return (uint32_t)(synth_rand(p.seed_b, read, 0) % p.n_barcodes);
+}
+
+// One read: uniform random ACGT, then n in {0..3} planted parental k-mers (80 % from the
+// barcode's true haplotype = id&1, random strand, random offset), then with p = 1/200 one 'N'.
+// Writes read_len ASCII bytes.
+HAST_HD void synth_read(const SynthParams &p, uint64_t read, uint8_t *out, uint32_t *barcode_out) {
+    const uint32_t L = p.read_len, K = p.k;
+    const uint32_t bc = synth_barcode(p, read);
+    *barcode_out = bc;
+    for (uint32_t j0 = 0; j0 < L; j0 += 32) {
+        uint64_t w = synth_rand(p.seed_r, read, j0 >> 5);
+        uint32_t n = (L - j0 < 32) ? (L - j0) : 32;
+        for (uint32_t j = 0; j < n; j++) out[j0 + j] = (uint8_t)"ACGT"[(w >> (2 * j)) & 3];
+    }
+    if (L >= K && p.n_keys_per_hap > 0) {
+        const uint32_t nplant = (uint32_t)(synth_rand(p.seed_r, read, 1000) & 3);
+        for (uint32_t t = 0; t < nplant; t++) {
+            uint64_t w = synth_rand(p.seed_r, read, 1001 + t);
+            int truth = (int)(bc & 1u);
+            int hap = ((w & 0xFF) < 205) ? truth : 1 - truth;
+            uint32_t off = (uint32_t)((w >> 16) & 0xFFFF) % (L - K + 1);
+            uint64_t key = synth_key(p, hap, (w >> 32) % p.n_keys_per_hap);
+            if ((w >> 8) & 1) key = kmer_revcomp(key, (int)K);
+            for (uint32_t j = 0; j < K; j++)
+                out[off + j] = (uint8_t)"ACTG"[(key >> (2 * (K - 1 - j))) & 3];   // kmer.h:12 int2base
+        }
+    }
+    uint64_t w = synth_rand(p.seed_r, read, 2000);
+    if (w % 200 == 0) out[(uint32_t)(w >> 16) % L] = 'N';
+}
+
+}  // namespace hast

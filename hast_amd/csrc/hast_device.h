@@ -1,0 +1,39 @@
+// hast_device.h -- host-visible declarations of the device launchers in hast_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "hast_common.h"
+
+namespace hast {
+
+struct ClassifyArgs {
+    const uint8_t *bases;        // ASCII bases, reads back to back
+    uint64_t bases_bytes;        // readable bytes at `bases`
+    const uint64_t *offsets;     // n_reads+1 offsets or nullptr (fixed length)
+    const uint32_t *barcode_ids; // per read, or nullptr
+    uint32_t *votes;             // [n_reads][2] or nullptr
+    uint32_t *counts;            // [n_barcodes][4] = {c0,c1,neg,reserved}
+    const uint64_t *slots;       // table
+    uint64_t n_reads;
+    uint32_t nbuckets;
+    uint32_t read_len;           // fixed length, or upper bound when offsets != nullptr
+    uint32_t max_pos;            // read_len-K+1 (0 when read_len<K): position stride per read
+    uint32_t w64;                // 64-bit LDS words per read (32 bases each), excluding the pad word
+    uint32_t tile_reads;         // reads per workgroup tile
+    uint32_t div_magic;          // floor(2^32/max_pos)+1 when exact over the tile's range, else 0
+    int k;
+};
+
+hipError_t launch_insert_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint32_t tag,
+                              uint32_t *d_err, hipStream_t s);
+hipError_t launch_insert_text(uint64_t *slots, uint32_t nbuckets, const char *d_text, size_t n_lines, int k,
+                              uint32_t tag, uint32_t *d_err, hipStream_t s);
+hipError_t launch_erase_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s);
+hipError_t launch_lookup_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
+hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s);
+hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
+hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
+hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);
+
+}  // namespace hast

@@ -1,0 +1,382 @@
+// hast_kernels.hip -- gfx950 (MI355X, CDNA4) device code for HAST stage-01 read classification.
+//
+// Written for wave64 / 256 CUs / HBM3E directly: no CUDA-compat macros, no multi-backend paths.
+// The workload is integer + random 64-B HBM reads (no MFMA anywhere by design):
+//   K1  table build   : k_insert_keys / k_insert_text / k_erase_keys / k_count_tags
+//   K3  classify      : k_classify   (the hot kernel; roofline = HBM under random 64-B access)
+//   synthetic inputs  : k_synth_keys / k_synth_reads
+//
+// Reference semantics implemented (paths under /root/reference/01.classify_stlfr_reads/):
+//   classify.cpp:30-46 (load_kmers), :182-209 (containN + process_reads), :314-339 (InitAdaptor),
+//   kmer/kmer.h:11,153-166,169-194 (coding, str2Kmer, chopRead2Kmer).
+#include "hast_common.h"
+#include "hast_device.h"
+
+namespace hast {
+
+// ------------------------------------------------------------------------------------------
+// Table build.  slot = (key << 2) | tags, empty = all ones.  A key lives in the first bucket, in
+// probe order from its home bucket, that had a free slot when it was inserted; slots never become
+// empty again (erase only clears tag bits), so lookups may stop at the first bucket with an empty slot.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool table_insert(uint64_t *slots, uint32_t nbuckets, uint64_t key, uint32_t tag) {
+    const uint64_t want = (key << 2) | tag;
+    uint32_t b = home_bucket(key, nbuckets);
+    for (uint32_t probe = 0; probe < nbuckets; ++probe) {
+        unsigned long long *bs = reinterpret_cast<unsigned long long *>(slots) + (size_t)b * kSlotsPerBucket;
+        for (int i = 0; i < kSlotsPerBucket; ++i) {
+            unsigned long long cur = __hip_atomic_load(&bs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                if (cur == kEmptySlot) {
+                    unsigned long long old = atomicCAS(&bs[i], (unsigned long long)kEmptySlot, (unsigned long long)want);
+                    if (old == kEmptySlot) return true;
+                    cur = old;               // someone else took the slot: look at what they wrote
+                    continue;
+                }
+                if ((cur >> 2) == key) {
+                    if ((cur & tag) == 0) atomicOr(&bs[i], (unsigned long long)tag);
+                    return true;
+                }
+                break;
+            }
+        }
+        b = (b + 1 == nbuckets) ? 0 : b + 1;
+    }
+    return false;
+}
+
+// returns the address of the slot holding `key`, or nullptr
+__device__ __forceinline__ unsigned long long *table_find(uint64_t *slots, uint32_t nbuckets, uint64_t key) {
+    uint32_t b = home_bucket(key, nbuckets);
+    for (uint32_t probe = 0; probe < nbuckets; ++probe) {
+        unsigned long long *bs = reinterpret_cast<unsigned long long *>(slots) + (size_t)b * kSlotsPerBucket;
+        bool any_empty = false;
+        for (int i = 0; i < kSlotsPerBucket; ++i) {
+            unsigned long long cur = bs[i];
+            if (cur == kEmptySlot) any_empty = true;
+            else if ((cur >> 2) == key) return &bs[i];
+        }
+        if (any_empty) return nullptr;
+        b = (b + 1 == nbuckets) ? 0 : b + 1;
+    }
+    return nullptr;
+}
+
+__global__ void __launch_bounds__(256) k_insert_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *keys,
+                                                     size_t n, uint32_t tag, uint32_t *err) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (!table_insert(slots, nbuckets, keys[i], tag)) atomicOr(&err[0], 1u);
+}
+
+// load_kmers (classify.cpp:30-46): line i = text[i*(K+1) .. +K), text[i*(K+1)+K] must be '\n'.
+// err bit0: table full, bit1: a line is not exactly K bytes.
+__global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, uint32_t nbuckets, const char *text,
+                                                     size_t n_lines, int k, uint32_t tag, uint32_t *err) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_lines; i += (size_t)gridDim.x * blockDim.x) {
+        const char *s = text + i * (size_t)(k + 1);
+        uint64_t w = 0;
+        bool bad = s[k] != '\n';
+        for (int j = 0; j < k; ++j) {
+            uint32_t c = (uint8_t)s[j];
+            bad |= (c == '\n');
+            w = (w << 2) | base_code(c);
+        }
+        if (bad) { atomicOr(&err[0], 2u); continue; }
+        if (!table_insert(slots, nbuckets, kmer_canon(w, k), tag)) atomicOr(&err[0], 1u);
+    }
+}
+
+// InitAdaptor (classify.cpp:314-339): clear both tag bits of each key; report which were set.
+__global__ void k_erase_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *keys, size_t n, uint8_t *hit) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long *p = table_find(slots, nbuckets, keys[i]);
+    unsigned long long old = p ? atomicAnd(p, ~3ull) : 0ull;
+    hit[i] = (uint8_t)(old & 3);
+}
+
+__global__ void k_lookup_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *keys, size_t n, uint8_t *tags) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long *p = table_find(slots, nbuckets, keys[i]);
+    tags[i] = p ? (uint8_t)(*p & 3) : 0;
+}
+
+// g_kmers[h].size(): number of slots with tag bit h.  Streaming 16 B/lane.
+__global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *out) {
+    unsigned long long c0 = 0, c1 = 0;
+    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(slots);
+    size_t n2 = nslots / 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        ulonglong2 s = v[i];
+        if (s.x != kEmptySlot) { c0 += s.x & 1; c1 += (s.x >> 1) & 1; }
+        if (s.y != kEmptySlot) { c0 += s.y & 1; c1 += (s.y >> 1) & 1; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_down(c0, off, 64);
+        c1 += __shfl_down(c1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(&out[0], c0);
+        if (c1) atomicAdd(&out[1], c1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: classify.
+//
+// Workgroup = 256 threads = 4 waves; it walks tiles of TR reads:
+//   A  pack   : each lane turns 16 ASCII bases (aligned dword loads + v_alignbyte) into 32 bits of
+//               2-bit codes ((c&6)>>1, kmer.h:11) in LDS, first base most significant, and flags
+//               reads that contain 'N' (classify.cpp:182-185).
+//   B  probe  : the tile's (read, offset) k-mer positions are flattened over QUADS of lanes.  A quad
+//               extracts the window from LDS (funnel shift, no rolling state), canonicalises
+//               (v_bfrev), hashes, and its 4 lanes load the 4 x 16 B of ONE 64-B bucket: one
+//               global_load_dwordx4 wave-instruction = 16 buckets = 16 coalesced 64-B lines.
+//               U such loads are in flight per lane.  Hits (rare) go to per-read LDS counters.
+//   C  commit : one lane per read does ONE global atomic on the read's barcode record
+//               {c0,c1} as a single u64 add, or neg++ (classify.cpp:203-208).
+// ------------------------------------------------------------------------------------------
+constexpr int kThreads = 256;
+constexpr int kQuads = kThreads / 4;
+constexpr int kUnroll = 4;
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack4(uint32_t x) {
+    // four ASCII bytes (first base = lowest byte) -> 8 bits, first base in the top pair
+    uint32_t t = (x >> 1) & 0x03030303u;
+    return (t * 0x40100401u) >> 24;
+}
+__device__ __forceinline__ uint32_t has_byte_N(uint32_t x) {
+    uint32_t y = x ^ 0x4E4E4E4Eu;                       // 'N' -> 0
+    return (y - 0x01010101u) & ~y & 0x80808080u;        // != 0 iff some byte of y is 0
+}
+
+__global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t TR = a.tile_reads;
+    const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
+    unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(smem);            // [TR][WS]
+    unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
+    uint32_t *s_len = reinterpret_cast<uint32_t *>(s_vote + TR);                           // [TR]
+    uint32_t *s_flag = s_len + TR;                                                         // [TR]
+    unsigned long long *s_off = reinterpret_cast<unsigned long long *>(s_flag + TR);       // [TR]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t sub = tid & 3;                // which 16 B of the bucket this lane loads
+    const uint32_t quad = tid >> 2;              // 0..63
+    const int K = a.k;
+    const uint32_t kshift = 64 - 2 * K;
+    const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
+    const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
+    const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t r0 = tile * TR;
+        const uint32_t tra = (uint32_t)((a.n_reads - r0 < TR) ? (a.n_reads - r0) : TR);
+
+        // ---- per-read header --------------------------------------------------------------
+        if (tid < tra) {
+            uint64_t off, len;
+            if (a.offsets) { off = a.offsets[r0 + tid]; len = a.offsets[r0 + tid + 1] - off; }
+            else           { off = (r0 + tid) * (uint64_t)a.read_len; len = a.read_len; }
+            if (len > a.read_len) len = a.read_len;          // contract: read_len bounds every read
+            s_off[tid] = off;
+            s_len[tid] = (uint32_t)len;
+            s_flag[tid] = 0;
+            s_vote[tid] = 0;
+        }
+        __syncthreads();
+
+        // ---- A: pack ----------------------------------------------------------------------
+        const uint32_t HW = a.w64 * 2;                                // 16-base half-words per read
+        for (uint32_t t = tid; t < tra * HW; t += kThreads) {
+            const uint32_t r = t / HW, j = t - r * HW;
+            const uint32_t len = s_len[r];
+            if (16 * j >= len) continue;
+            const uint32_t nb = (len - 16 * j < 16) ? (len - 16 * j) : 16;
+            const uintptr_t addr = base_addr + s_off[r] + 16 * j;
+            const uintptr_t a4 = addr & ~(uintptr_t)3;
+            const uint32_t bsh = (uint32_t)(addr & 3);
+            uint32_t d[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                uintptr_t p = a4 + 4 * i;
+                d[i] = (p < end_addr) ? *reinterpret_cast<const uint32_t *>(p) : 0x41414141u;
+            }
+            uint32_t packed = 0, nflag = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], bsh);   // bytes addr+4i .. +4i+3
+                int vb = (int)nb - 4 * i;                                        // valid bytes in x
+                if (vb < 4) {
+                    uint32_t m = (vb <= 0) ? 0u : ((1u << (8 * vb)) - 1u);
+                    x = (x & m) | (0x41414141u & ~m);                            // pad with 'A'
+                }
+                nflag |= has_byte_N(x);
+                packed = (packed << 8) | pack4(x);
+            }
+            // 64-bit LDS word w = bases 32w..32w+31, first base most significant: the even
+            // half-word is the HIGH 32 bits (little-endian: +4 bytes)
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_pack + (size_t)r * WS + (j >> 1)) + (1 - (j & 1));
+            *dst = packed;
+            if (nflag) atomicOr(&s_flag[r], 1u);
+        }
+        __syncthreads();
+
+        // ---- B: probe ---------------------------------------------------------------------
+        const uint32_t P = a.max_pos;                                 // positions per read (stride)
+        const uint32_t Q = tra * P;
+        for (uint32_t qb = 0; qb < Q; qb += kQuads * kUnroll) {
+            uint64_t key[kUnroll];
+            uint32_t rd[kUnroll];
+            uint32_t bkt[kUnroll];
+            bool valid[kUnroll];
+            u64x2 sl[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const uint32_t q = qb + u * kQuads + quad;
+                uint32_t r = a.div_magic ? __umulhi(q, a.div_magic) : (q / P);
+                uint32_t p = q - r * P;
+                bool ok = q < Q;
+                r = ok ? r : 0;
+                const uint32_t len = s_len[r];
+                ok = ok && (p + K <= len) && (s_flag[r] == 0);
+                const unsigned long long *wp = s_pack + (size_t)r * WS + (p >> 5);
+                const unsigned long long w0 = wp[0], w1 = wp[1];
+                const uint32_t sh = (p & 31) * 2;
+                unsigned long long x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));     // sh==0 safe
+                const uint64_t fwd = x >> kshift;
+                const uint64_t ck = kmer_canon(fwd, K);
+                key[u] = ck;
+                rd[u] = r;
+                valid[u] = ok;
+                bkt[u] = home_bucket(ck, a.nbuckets);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const u64x2 *bp = reinterpret_cast<const u64x2 *>(a.slots + (size_t)bkt[u] * kSlotsPerBucket) + sub;
+                const u64x2 none = {kEmptySlot, kEmptySlot};
+                sl[u] = valid[u] ? *bp : none;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const bool mx = (sl[u].x >> 2) == key[u], my = (sl[u].y >> 2) == key[u];
+                bool hit = valid[u] && (mx || my);
+                uint32_t tags = hit ? (uint32_t)((mx ? sl[u].x : sl[u].y) & 3) : 0;
+                bool stop = hit || sl[u].x == kEmptySlot || sl[u].y == kEmptySlot;
+                // quad vote: did any of the 4 lanes of my quad see a match or an empty slot?
+                unsigned long long m = __ballot(stop);
+                bool more = valid[u] && (((m >> (lane & 60)) & 0xF) == 0);
+                uint32_t b = bkt[u];
+                uint32_t guard = 0;
+                while (__any(more)) {                       // bucket overflow chain: rare
+                    u64x2 s2 = {kEmptySlot, kEmptySlot};
+                    if (more) {
+                        b = (b + 1 == a.nbuckets) ? 0 : b + 1;
+                        s2 = *(reinterpret_cast<const u64x2 *>(a.slots + (size_t)b * kSlotsPerBucket) + sub);
+                    }
+                    const bool nx = (s2.x >> 2) == key[u], ny = (s2.y >> 2) == key[u];
+                    const bool h2 = more && (nx || ny);
+                    if (h2) tags = (uint32_t)((nx ? s2.x : s2.y) & 3);
+                    const bool st2 = more && (h2 || s2.x == kEmptySlot || s2.y == kEmptySlot);
+                    unsigned long long m2 = __ballot(st2);
+                    if (((m2 >> (lane & 60)) & 0xF) != 0 || ++guard >= a.nbuckets) more = false;
+                }
+                if (tags) atomicAdd(&s_vote[rd[u]], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+            }
+        }
+        __syncthreads();
+
+        // ---- C: commit (classify.cpp:203-208) ------------------------------------------------
+        if (tid < tra) {
+            const unsigned long long v = s_vote[tid];
+            if (a.votes) {
+                a.votes[2 * (r0 + tid)] = (uint32_t)v;
+                a.votes[2 * (r0 + tid) + 1] = (uint32_t)(v >> 32);
+            }
+            if (a.barcode_ids) {
+                uint32_t *rec = a.counts + 4 * (size_t)a.barcode_ids[r0 + tid];
+                if (v) atomicAdd(reinterpret_cast<unsigned long long *>(rec), v);   // {c0,c1} in one add
+                else atomicAdd(rec + 2, 1u);                                        // key -1
+            }
+        }
+        // no barrier needed here: the next tile's header only touches this lane's own s_* entries
+        // and is followed by a barrier before anyone else reads them.
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic workload; same integer functions as the host generator
+// ------------------------------------------------------------------------------------------
+__global__ void k_synth_keys(SynthParams p, int hap, uint64_t first, size_t n, uint64_t *out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = synth_key(p, hap, first + i);
+}
+
+__global__ void k_synth_reads(SynthParams p, uint64_t first, size_t n, uint8_t *bases, uint32_t *barcodes) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t bc;
+        synth_read(p, first + i, bases + i * (size_t)p.read_len, &bc);
+        if (barcodes) barcodes[i] = bc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers (host side, called from hast_api.cpp)
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(size_t n, int block, int cap) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)cap ? (size_t)cap : g);
+}
+
+hipError_t launch_insert_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint32_t tag,
+                              uint32_t *d_err, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, nbuckets, d_keys, n, tag, d_err);
+    return hipGetLastError();
+}
+hipError_t launch_insert_text(uint64_t *slots, uint32_t nbuckets, const char *d_text, size_t n_lines, int k,
+                              uint32_t tag, uint32_t *d_err, hipStream_t s) {
+    if (n_lines == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, nbuckets, d_text, n_lines, k, tag, d_err);
+    return hipGetLastError();
+}
+hipError_t launch_erase_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_erase_keys, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, slots, nbuckets, d_keys, n, d_hit);
+    return hipGetLastError();
+}
+hipError_t launch_lookup_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lookup_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slots, nbuckets, d_keys, n, d_tags);
+    return hipGetLastError();
+}
+hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_tags, dim3(grid_for(nslots / 2, 256, 256 * 8)), dim3(256), 0, s, slots, nslots, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+    if (a.n_reads == 0) return hipSuccess;
+    if (smem > (48u << 10)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kThreads), smem, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_keys, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, p, hap, first, n, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, p, first, n, d_bases, d_bc);
+    return hipGetLastError();
+}
+
+}  // namespace hast

@@ -1,0 +1,169 @@
+/*
+ * hast.h -- C ABI of libhast.so, the MI355X-native (gfx950) implementation of HAST's stage-01
+ * read-classification hot path.
+ *
+ * What it replaces.  The reference has no FFI for this path: it is a process
+ * (`01.classify_stlfr_reads/classify`, argv in / TSV on stdout, classify.cpp:373-450).  The
+ * drop-in boundary is therefore the `classify` executable built from hast_amd/csrc/classify_main.cpp,
+ * and THIS header is the seam between that host program (and bench.py / pytest via ctypes) and
+ * the HIP device code.  Each entry point cites the reference code whose work it takes over
+ * (paths relative to /root/reference/01.classify_stlfr_reads/).
+ *
+ * Conventions
+ *   - plain C types only; every call returns a hast_status and never throws across the ABI;
+ *     hast_last_error() gives a thread-local message for the last failing call.
+ *   - the caller owns host buffers; pointers named d_* are DEVICE pointers (from hast_dev_alloc
+ *     or from any other allocator on the same device, e.g. a torch tensor's data_ptr()).
+ *   - one context per device; calls on one context are serialised by the caller.
+ *   - hast_stream is a hipStream_t passed as void* (NULL = the context's own stream).
+ *   - there is NO CPU fallback: with no usable GPU hast_ctx_create fails with HAST_ERR_NO_DEVICE.
+ */
+#ifndef HAST_H
+#define HAST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HAST_OK = 0,
+    HAST_ERR_INVALID = 1,    /* bad argument / K out of [1,31] / wrong call order            */
+    HAST_ERR_NO_DEVICE = 2,  /* no HIP device, or the device is not usable                  */
+    HAST_ERR_HIP = 3,        /* a HIP runtime call failed (message in hast_last_error)      */
+    HAST_ERR_OOM = 4,        /* host or device allocation failed                            */
+    HAST_ERR_TABLE_FULL = 5, /* more distinct keys than hast_table_reserve planned for      */
+    HAST_ERR_FORMAT = 6,     /* k-mer text is not fixed-width K-byte lines (kmer.h:154)     */
+    HAST_ERR_RCCL = 7,       /* the RCCL all-reduce failed                                  */
+    HAST_ERR_IO = 8          /* file could not be opened / read                             */
+} hast_status;
+
+typedef struct hast_ctx hast_ctx;
+typedef void *hast_stream;
+
+const char *hast_version(void);
+const char *hast_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------
+ * Holds what the reference keeps in process globals: g_K (classify.cpp:29), g_kmers[2]
+ * (classify.cpp:27) as ONE merged open-addressed table in HBM, and the per-barcode counters
+ * (BarcodeCache, classify.cpp:50-64).  k in [1,31]. */
+hast_status hast_ctx_create(int device_ordinal, int k, hast_ctx **out);
+void        hast_ctx_destroy(hast_ctx *);
+int         hast_ctx_k(const hast_ctx *);
+int         hast_ctx_device(const hast_ctx *);
+hast_stream hast_ctx_stream(const hast_ctx *);
+hast_status hast_stream_sync(hast_ctx *, hast_stream);
+
+/* ---- raw device memory (for callers without another allocator, e.g. ctypes tests) ---------- */
+hast_status hast_dev_alloc(hast_ctx *, size_t bytes, void **d_out);
+hast_status hast_dev_free(hast_ctx *, void *d_ptr);
+hast_status hast_memcpy_h2d(hast_ctx *, void *d_dst, const void *src, size_t bytes);
+hast_status hast_memcpy_d2h(hast_ctx *, void *dst, const void *d_src, size_t bytes);
+hast_status hast_memset_d(hast_ctx *, void *d_dst, int byte, size_t bytes, hast_stream);
+
+/* ---- the k-mer table: g_kmers[0], g_kmers[1] (classify.cpp:27) -----------------------------
+ * One table, slot = (canonical_key << 2) | tags, tag bit h set <=> key in haplotype h's set.
+ * Buckets of 8 slots = 64 B; home bucket from a multiplicative hash; overflow to the next bucket. */
+
+/* Size the table for up to `max_keys` distinct keys (both haplotypes together) at the given
+ * load factor (0 => 0.5).  Discards any previous table. */
+hast_status hast_table_reserve(hast_ctx *, uint64_t max_keys, double load_factor);
+
+/* load_kmers (classify.cpp:30-46) on an in-memory image of the file: '\n'-separated K-byte lines,
+ * parsed, canonicalised (Kmer::str2Kmer, kmer.h:153-166) and inserted ON THE DEVICE.  A final piece
+ * without '\n' is dropped (classify.cpp:41).  *lines_out = number of lines used ("Recorded N").
+ * HAST_ERR_FORMAT if any line is not exactly K bytes (the reference asserts, kmer.h:154). */
+hast_status hast_table_insert_text(hast_ctx *, int hap, const char *text, size_t nbytes,
+                                   uint64_t *lines_out);
+/* Same, keys already canonical 2K-bit values (host / device resident). */
+hast_status hast_table_insert_keys(hast_ctx *, int hap, const uint64_t *canon_keys, size_t n);
+hast_status hast_table_insert_keys_device(hast_ctx *, int hap, const uint64_t *d_canon_keys, size_t n,
+                                          hast_stream);
+
+/* InitAdaptor (classify.cpp:314-339): remove each key from BOTH sets.  out_hit[i] (optional) gets
+ * bit h set when key i was present in haplotype h's set (the reference logs one INFO line each). */
+hast_status hast_table_erase(hast_ctx *, const uint64_t *canon_keys, size_t n, uint8_t *out_hit);
+
+/* g_kmers[h].size() as used by getHap (classify.cpp:70-71): distinct canonical keys per haplotype
+ * after any erase. */
+hast_status hast_table_sizes(hast_ctx *, uint64_t *n_hap0, uint64_t *n_hap1);
+
+/* Membership of host keys (test/diagnostic entry): out_tags[i] = tag bits of key i (0 = absent). */
+hast_status hast_table_lookup(hast_ctx *, const uint64_t *canon_keys, size_t n, uint8_t *out_tags);
+
+/* geometry, for roofline accounting */
+hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *bytes);
+
+/* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
+ * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:
+ *   c0/c1 = sum of per-read votes for key 0/1 (classify.cpp:203-206), neg = key -1 (:191,:207-208).
+ * A barcode was "seen" (gets an output row, classify.cpp:94) iff c0|c1|neg != 0. */
+hast_status hast_counts_resize(hast_ctx *, size_t n_barcodes);                 /* library-owned, zeroed */
+hast_status hast_counts_bind(hast_ctx *, uint32_t *d_counts, size_t n_barcodes); /* caller-owned buffer */
+hast_status hast_counts_zero(hast_ctx *, hast_stream);
+hast_status hast_counts_read(hast_ctx *, uint32_t *c0, uint32_t *c1, uint32_t *neg, size_t n_barcodes);
+/* Thread-merge of the reference (collectBarcodes/BarcodeCache::Add, classify.cpp:57-63,226-229)
+ * across the GPUs of ONE process: a single in-place RCCL all-reduce(sum,u32) over the counters of
+ * n_ctx contexts (one per device, same n_barcodes). */
+hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
+
+/* ---- classification: MultiThread::process_reads (classify.cpp:186-209) ---------------------
+ * For each read: whole-read skip when it holds an upper-case 'N' (containN, :182-185,190-193);
+ * otherwise every window of K bases is 2-bit coded ((c&6)>>1, kmer.h:11), canonicalised
+ * (kmer.h:169-194) and looked up in both sets (:195-202); votes go to the read's barcode (:203-208).
+ *
+ *   d_bases        ASCII bases of all reads, back to back (device)
+ *   d_offsets      n_reads+1 byte offsets into d_bases, or NULL => fixed length: read i at i*read_len
+ *   read_len       fixed read length (d_offsets==NULL) or an upper bound on every read's length
+ *   d_barcode_ids  per-read dense barcode id (< n_barcodes), or NULL => counters untouched
+ *   d_votes        optional [n_reads][2] per-read (vote0, vote1) output (per-read mode), or NULL
+ *   bases_bytes    total bytes readable at d_bases (reads never look past it)
+ * A read shorter than K has no windows (the reference aborts, kmer.h:171): it votes 0/0.
+ * Asynchronous on `stream`. */
+hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
+                                 const uint64_t *d_offsets, uint32_t read_len,
+                                 const uint32_t *d_barcode_ids, uint32_t *d_votes,
+                                 size_t n_reads, hast_stream);
+/* Same with HOST buffers: staged to the device through the context's pinned double buffer
+ * (what the classify CLI uses).  Returns once the batch is enqueued; buffers may be reused on return. */
+hast_status hast_classify_batch(hast_ctx *, const uint8_t *bases, const uint64_t *offsets,
+                                const uint32_t *barcode_ids, size_t n_reads, uint32_t max_read_len);
+
+/* ---- host-side pieces of the path (no device work) ---------------------------------------- */
+/* parseName (classify.cpp:112-119): barcode = head[last '#' + 1 .. last '/'). */
+void     hast_parse_barcode(const char *head, size_t len, size_t *start, size_t *n);
+/* getHap (classify.cpp:66-86). */
+int      hast_get_hap(const char *barcode, size_t blen, uint32_t c0, uint32_t c1,
+                      uint64_t n_hap0, uint64_t n_hap1, double w0, double w1);
+/* Kmer::str2Kmer (kmer.h:153-166) / chopRead2Kmer (kmer.h:169-194) on the host, used for the
+ * <=2x(45-K+1) adaptor keys of InitAdaptor. */
+uint64_t hast_canon_kmer(const char *s, int k);
+size_t   hast_chop_read(const char *seq, size_t len, int k, uint64_t *out);
+void     hast_kmer_to_str(uint64_t kmer, int k, char *out /* k+1 */);
+
+/* ---- synthetic workload; identical generator on host and device -------------- */
+typedef struct {
+    uint64_t seed_k, seed_r, seed_b; /* 0 => defaults 0x4841535401/02/03 */
+    uint64_t n_keys_per_hap;
+    uint32_t n_barcodes;
+    uint32_t read_len;
+    uint32_t k;
+    uint32_t reserved;
+} hast_synth_params;
+
+hast_status hast_synth_keys_host(const hast_synth_params *, int hap, uint64_t first, size_t n, uint64_t *out);
+hast_status hast_synth_reads_host(const hast_synth_params *, uint64_t first_read, size_t n_reads,
+                                  uint8_t *bases /* n*read_len */, uint32_t *barcode_ids);
+hast_status hast_synth_keys_device(hast_ctx *, const hast_synth_params *, int hap, uint64_t first, size_t n,
+                                   uint64_t *d_out, hast_stream);
+hast_status hast_synth_reads_device(hast_ctx *, const hast_synth_params *, uint64_t first_read, size_t n_reads,
+                                    uint8_t *d_bases, uint32_t *d_barcode_ids, hast_stream);
+/* generate + insert both haplotypes' keys on the device (no host copy of the keys) */
+hast_status hast_synth_table_build(hast_ctx *, const hast_synth_params *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/hast.h declares,
+its host-side pieces (no device work) agree with the oracle, and it refuses to run without a GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hast_amd
+from hast_amd.binding import make_params
+from tests import oracle_binding as ob
+from tests.conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    hast_amd.build()
+    return hast_amd.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "hast.h")).read()
+    declared = set(re.findall(r"\b(hast_[a-z0-9_]+)\s*\(", hdr)) - {"hast_status"}
+    assert declared == set(hast_amd.ABI_SYMBOLS), declared ^ set(hast_amd.ABI_SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", hast_amd.lib_path()], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = set(re.findall(r" T (hast_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hast_amd.HastError) as ei:
+        hast_amd.Context(21)
+    assert ei.value.status == 2 and "no CPU path" in str(ei.value)
+    r = subprocess.run([hast_amd.classify_exe(), "--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "r1.fq"],
+                       cwd=os.path.join(ROOT, "tests", "golden", "edge_k7"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 4 and r.stdout == b""
+
+
+def test_product_does_not_link_oracle(lib):
+    for f in (hast_amd.lib_path(), hast_amd.classify_exe()):
+        out = subprocess.run(["ldd", f], stdout=subprocess.PIPE).stdout.decode()
+        assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "hast_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(root, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower() or fn == "__init__.py", (fn, "product code must not reference oracle/")
+
+
+def test_host_kmer_primitives_match_oracle(lib, oracle_lib):
+    import random
+    rng = random.Random(7)
+    assert hast_amd.canon_kmer(b"AGCTC") == 0xD9 and hast_amd.canon_kmer(b"GAGCT") == 0xD9     # classify.cpp:351-354
+    assert hast_amd.chop_read(b"GAGCTA", 5) == [0xD9, 0xD8]                                     # classify.cpp:355-362
+    for k in (1, 2, 5, 11, 16, 21, 27, 31):
+        seq = "".join(rng.choice("ACGTacgtNnRYK-") for _ in range(300)).encode()
+        assert hast_amd.chop_read(seq, k) == ob.chop(oracle_lib, seq, k)
+        for i in range(0, 250, 17):
+            assert hast_amd.canon_kmer(seq[i:i + k]) == oracle_lib.ho_canon_str(seq[i:i + k], k)
+
+
+def test_host_parse_barcode_and_get_hap_match_oracle(lib, oracle_lib):
+    import random
+    rng = random.Random(3)
+    heads = [b"VSDSDS#XXX_xxx_s/1", b"@V3#2_2_2/1\tx/y\t1", b"@noBarcode/1", b"@V13#9_9_9", b"@a/b#10_10_10", b"", b"#", b"/",
+             b"#/", b"/#", b"a#b#c/d/e"]
+    for _ in range(300):
+        heads.append(bytes(rng.choice(b"ab#/_1\t") for _ in range(rng.randint(0, 20))))
+    for h in heads:
+        assert hast_amd.parse_barcode(h) == ob.parse_name(oracle_lib, h), h
+    for bc in (b"0_0_0", b"0_0", b"0", b"1_2_3", b"00", b"0_0_0_0"):
+        for _ in range(200):
+            c0, c1 = rng.choice([0, 0, 1, 5, 1000, 2 ** 31 - 1]), rng.choice([0, 0, 1, 5, 999, 2 ** 31 - 1])
+            n0, n1 = rng.randint(1, 10 ** 9), rng.randint(1, 10 ** 9)
+            w0, w1 = rng.choice([1.0, 1.04, 0.5]), rng.choice([1.0, 1.04, 2.5])
+            assert hast_amd.get_hap(bc, c0, c1, n0, n1, w0, w1) == oracle_lib.ho_get_hap(bc, len(bc), c0, c1, n0, n1, w0, w1)
+
+
+def test_synth_host_generator_properties(lib, oracle_lib):
+    """The synthetic reads are deterministic, plant real parental k-mers, and some carry N."""
+    k, L, n_keys = 21, 150, 4000
+    p = make_params(k, L, n_keys, 128)
+    a, ids = hast_amd.synth_reads_host(p, 100, 2000)
+    b, ids2 = hast_amd.synth_reads_host(p, 100, 2000)
+    assert np.array_equal(a, b) and np.array_equal(ids, ids2)
+    c, _ = hast_amd.synth_reads_host(p, 1100, 1000)
+    assert np.array_equal(a[1000 * L:], c)                        # counter-based: independent of batch split
+    assert ids.max() < 128 and set(np.unique(a)) <= set(b"ACGTN")
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    oc = oracle_lib.ho_new()
+    for h in (0, 1):
+        assert oracle_lib.ho_load_keys(oc, keys[h].ctypes.data, n_keys, h, k) == 0
+    e = [np.zeros(128, np.uint32) for _ in range(3)]
+    off = np.arange(2001, dtype=np.uint64) * L
+    oracle_lib.ho_classify_ids(oc, a.ctypes.data, off.ctypes.data, ids.ctypes.data, 2000, e[0].ctypes.data, e[1].ctypes.data,
+                               e[2].ctypes.data, None, 2)
+    oracle_lib.ho_free(oc)
+    hits = int(e[0].sum() + e[1].sum())
+    assert 1500 < hits < 4000                                     # ~1.5 planted k-mers per read
+    assert 0 < (a == ord("N")).sum() < 40

@@ -1,0 +1,294 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI (libhast.so) against the oracle
+(CPU restatement of the reference, pinned by tests/test_oracle_golden.py).  Integer work: every
+comparison is bit-exact."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import hast_amd
+from hast_amd.binding import make_params
+from tests import oracle_binding as ob
+from tests.conftest import golden_cases, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(hast_amd.lib_path()):
+        hast_amd.build()
+    return hast_amd.lib()
+
+
+def oracle_from_keys(o, k, keys0, keys1):
+    oc = o.ho_new()
+    for h, keys in ((0, keys0), (1, keys1)):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        assert o.ho_load_keys(oc, keys.ctypes.data, keys.size, h, k) == 0
+    return oc
+
+
+def oracle_counts(o, oc, bases, offsets, ids, n_bc, threads=4):
+    e0, e1, eneg = (np.zeros(n_bc, np.uint32) for _ in range(3))
+    o.ho_classify_ids(oc, bases.ctypes.data, offsets.ctypes.data, ids.ctypes.data, ids.size,
+                      e0.ctypes.data, e1.ctypes.data, eneg.ctypes.data, None, threads)
+    return e0, e1, eneg
+
+
+def oracle_votes(o, oc, bases, offsets):
+    n = offsets.size - 1
+    out = np.zeros((n, 2), np.uint32)
+    v0, v1, hn = C.c_uint32(), C.c_uint32(), C.c_int()
+    raw = bases.tobytes()
+    for i in range(n):
+        s = raw[int(offsets[i]):int(offsets[i + 1])]
+        o.ho_read_votes(oc, s, len(s), C.byref(v0), C.byref(v1), C.byref(hn))
+        out[i] = (v0.value, v1.value)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def test_table_build_sizes_lookup_erase(built, oracle_lib):
+    k = 21
+    rng = np.random.default_rng(1)
+    mask = (1 << (2 * k)) - 1
+    raw0 = rng.integers(0, mask, 40000, dtype=np.uint64)
+    raw1 = rng.integers(0, mask, 40000, dtype=np.uint64)
+    canon = lambda a: np.array([min(int(x), oracle_lib.ho_revcomp(int(x), k)) for x in a], dtype=np.uint64)
+    k0, k1 = canon(raw0), canon(raw1)
+    k1[:500] = k0[:500]                       # keys in both sets
+    k0 = np.concatenate([k0, k0[:1000]])      # duplicates
+    oc = oracle_from_keys(oracle_lib, k, k0, k1)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(k0.size + k1.size)
+        ctx.table_insert_keys(0, k0)
+        ctx.table_insert_keys(1, k1)
+        assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        ctx.table_insert_keys(0, k0)          # idempotent
+        assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        probe = np.concatenate([k0[:3000], k1[:3000], canon(rng.integers(0, mask, 3000, dtype=np.uint64))])
+        tags = ctx.table_lookup(probe)
+        exp = np.array([oracle_lib.ho_contains(oc, 0, int(x)) | (oracle_lib.ho_contains(oc, 1, int(x)) << 1) for x in probe], np.uint8)
+        assert np.array_equal(tags, exp)
+        # erase (InitAdaptor semantics): both sets lose the key; report which had it
+        victims = np.concatenate([k0[:10], k1[600:610], k0[100:105]])     # k0[:10] are in both sets
+        hit = ctx.table_erase(victims)
+        assert np.array_equal(hit, exp_hit(oracle_lib, oc, victims))
+        assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        assert not ctx.table_lookup(victims).any()
+    oracle_lib.ho_free(oc)
+
+
+def exp_hit(o, oc, victims):
+    """what the reference's find-then-erase loop reports, replayed on the oracle's sets"""
+    import ctypes
+    out = []
+    for v in victims:
+        h = o.ho_contains(oc, 0, int(v)) | (o.ho_contains(oc, 1, int(v)) << 1)
+        out.append(h)
+        buf = ctypes.create_string_buffer(40)
+        o.ho_kmer_to_str(int(v), o.ho_k(oc), buf)
+        o.ho_init_adaptor(oc, buf.value, buf.value, None)     # erases exactly this canonical key
+    return np.array(out, np.uint8)
+
+
+def test_table_high_load_overflow_chains(built, oracle_lib):
+    """Load factor 0.9 forces bucket-overflow chains through insert, lookup and classify."""
+    k = 15
+    n = 30000
+    p = make_params(k, 100, n, 37)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n) for h in (0, 1)]
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    bases, ids = hast_amd.synth_reads_host(p, 0, 5000)
+    off = np.arange(5001, dtype=np.uint64) * 100
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(int(oracle_lib.ho_set_size(oc, 0) + oracle_lib.ho_set_size(oc, 1)), 0.9)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        ctx.counts_resize(37)
+        ctx.classify_batch(bases, off, ids, 100)
+        got = ctx.counts_read(37)
+    exp = oracle_counts(oracle_lib, oc, bases, off, ids, 37)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    oracle_lib.ho_free(oc)
+
+
+def test_table_full_is_reported(built):
+    with hast_amd.Context(21) as ctx:
+        ctx.table_reserve(100, 0.9)                      # 64 buckets minimum = 512 slots
+        keys = np.arange(1, 2000, dtype=np.uint64)       # small values are canonical enough to be distinct
+        with pytest.raises(hast_amd.HastError) as ei:
+            ctx.table_insert_keys(0, keys)
+        assert ei.value.status == 5
+
+
+def test_insert_text_matches_reference_set_sizes(built, oracle_lib, golden_workdir):
+    for case in ("edge_k7", "rand_k21", "rand_k31", "rand_k11"):
+        d = golden_workdir / case
+        t0, t1 = open(d / "hap0.mer", "rb").read(), open(d / "hap1.mer", "rb").read()
+        k = t0.index(b"\n")
+        oc = oracle_lib.ho_new()
+        assert oracle_lib.ho_load_kmers_text(oc, t0, len(t0), 0) == 0
+        assert oracle_lib.ho_load_kmers_text(oc, t1, len(t1), 1) == 0
+        with hast_amd.Context(k) as ctx:
+            ctx.table_reserve(len(t0) // (k + 1) + len(t1) // (k + 1) + 2)
+            assert ctx.table_insert_text(0, t0) == oracle_lib.ho_lines_loaded(oc, 0)
+            assert ctx.table_insert_text(1, t1) == oracle_lib.ho_lines_loaded(oc, 1)
+            assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        oracle_lib.ho_free(oc)
+
+
+def test_insert_text_rejects_ragged_lines(built):
+    with hast_amd.Context(5) as ctx:
+        ctx.table_reserve(100)
+        with pytest.raises(hast_amd.HastError) as ei:
+            ctx.table_insert_text(0, b"ACGTA\nACG\nACGTACC\n")
+        assert ei.value.status == 6
+
+
+# ------------------------------------------------------------------------------------------------
+def test_synth_generators_agree(built):
+    p = make_params(21, 150, 5000, 100)
+    with hast_amd.Context(21) as ctx:
+        n = 3000
+        d_b, d_i, d_k = ctx.alloc(n * 150), ctx.alloc(n * 4), ctx.alloc(n * 8)
+        ctx.synth_reads_device(p, 12345, n, d_b, d_i)
+        ctx.synth_keys_device(p, 1, 77, n, d_k)
+        ctx.sync()
+        hb, hi = hast_amd.synth_reads_host(p, 12345, n)
+        assert np.array_equal(ctx.to_host(d_b, (n * 150,), np.uint8), hb)
+        assert np.array_equal(ctx.to_host(d_i, (n,), np.uint32), hi)
+        assert np.array_equal(ctx.to_host(d_k, (n,), np.uint64), hast_amd.synth_keys_host(p, 1, 77, n))
+
+
+@pytest.mark.parametrize("k,L", [(21, 150), (31, 150), (11, 100), (5, 64), (27, 151), (1, 40)])
+def test_classify_fixed_length_vs_oracle(built, oracle_lib, k, L):
+    n_keys, n_reads, n_bc = 20000, 20011, 333
+    if k <= 5:
+        n_keys = 200
+    p = make_params(k, L, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    bases, ids = hast_amd.synth_reads_host(p, 0, n_reads)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.synth_table_build(p)
+        assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        ctx.counts_resize(n_bc)
+        d_b, d_i, d_v = ctx.alloc(n_reads * L), ctx.alloc(n_reads * 4), ctx.alloc(n_reads * 8)
+        ctx.synth_reads_device(p, 0, n_reads, d_b, d_i)
+        ctx.classify_device(d_b, n_reads * L, n_reads, L, d_barcode_ids=d_i, d_votes=d_v)
+        ctx.sync()
+        got = ctx.counts_read(n_bc)
+        votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+    exp = oracle_counts(oracle_lib, oc, bases, off, ids, n_bc)
+    assert np.array_equal(votes[:2000], oracle_votes(oracle_lib, oc, bases[:2000 * L], off[:2001]))
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    assert int(exp[0].sum()) + int(exp[1].sum()) > 0
+    oracle_lib.ho_free(oc)
+
+
+def ragged_reads(rng, k, keys, n, max_len):
+    seqs = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.02:
+            L = 0
+        elif r < 0.06:
+            L = rng.randint(1, k - 1) if k > 1 else 1
+        elif r < 0.10:
+            L = k
+        else:
+            L = rng.randint(k, max_len)
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if L >= k and rng.random() < 0.6:
+            for _ in range(rng.randint(1, 3)):
+                key = int(rng.choice(keys))
+                km = "".join("ACTG"[(key >> (2 * (k - 1 - j))) & 3] for j in range(k))
+                o = rng.randint(0, L - k)
+                s[o:o + k] = km
+        if L and rng.random() < 0.05:
+            s[rng.randrange(L)] = "N"
+        if L and rng.random() < 0.05:
+            s[rng.randrange(L)] = "n"               # lower-case n is NOT a skip (kmer.h:11 -> G)
+        if rng.random() < 0.05:
+            s = [c.lower() for c in s]
+        if L and rng.random() < 0.03:
+            s[rng.randrange(L)] = rng.choice("RYKM*-.")
+        seqs.append("".join(s).encode())
+    return seqs
+
+
+@pytest.mark.parametrize("k,max_len", [(21, 180), (31, 97), (7, 300), (13, 2500)])
+def test_classify_ragged_reads_vs_oracle(built, oracle_lib, k, max_len):
+    """Variable-length reads through offsets: empty, shorter than K (the reference aborts; we define
+    0 windows), len==K, N / n / lower-case / IUPAC bytes, unaligned starts."""
+    rng = random.Random(k * 1000 + max_len)
+    n_keys, n_bc = 3000, 50
+    p = make_params(k, 100, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    seqs = ragged_reads(rng, k, np.concatenate(keys), 6000 if max_len < 1000 else 700, max_len)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    ids = np.array([rng.randrange(n_bc) for _ in seqs], dtype=np.uint32)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        ctx.counts_resize(n_bc)
+        d_b, d_o, d_i = ctx.to_device(bases), ctx.to_device(off), ctx.to_device(ids)
+        d_v = ctx.alloc(len(seqs) * 8)
+        ctx.classify_device(d_b, bases.size, len(seqs), int(lens.max()), d_offsets=d_o, d_barcode_ids=d_i, d_votes=d_v)
+        ctx.sync()
+        got = ctx.counts_read(n_bc)
+        votes = ctx.to_host(d_v, (len(seqs), 2), np.uint32)
+        # same reads through the host-buffer entry point (what the CLI uses), on top: counts double
+        ctx.classify_batch(bases, off, ids, int(lens.max()))
+        got2 = ctx.counts_read(n_bc)
+    assert np.array_equal(votes, oracle_votes(oracle_lib, oc, bases, off))
+    exp = oracle_counts(oracle_lib, oc, bases, off, ids, n_bc)
+    for g, g2, e in zip(got, got2, exp):
+        assert np.array_equal(g, e)
+        assert np.array_equal(g2, 2 * e)                 # linearity
+    oracle_lib.ho_free(oc)
+
+
+def test_classify_votes_only_and_linearity(built, oracle_lib):
+    """Per-read mode (no barcodes) and additivity over batches: counts(A)+counts(B) == counts(A u B)."""
+    k, L, n_keys, n_bc, n = 21, 150, 10000, 97, 30000
+    p = make_params(k, L, n_keys, n_bc)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.synth_table_build(p)
+        d_b, d_i, d_v = ctx.alloc(n * L), ctx.alloc(n * 4), ctx.alloc(n * 8)
+        ctx.synth_reads_device(p, 5000, n, d_b, d_i)
+        ctx.counts_resize(n_bc)
+        ctx.classify_device(d_b, n * L, n, L, d_barcode_ids=d_i)
+        whole = ctx.counts_read(n_bc)
+        ctx.counts_zero()
+        h = 12345
+        ctx.classify_device(d_b, n * L, h, L, d_barcode_ids=d_i)
+        ctx.classify_device(d_b + h * L, (n - h) * L, n - h, L, d_barcode_ids=d_i + 4 * h)
+        parts = ctx.counts_read(n_bc)
+        ctx.counts_zero()
+        ctx.classify_device(d_b, n * L, n, L, d_votes=d_v)          # votes only: counters untouched
+        ctx.sync()
+        untouched = ctx.counts_read(n_bc)
+        votes = ctx.to_host(d_v, (n, 2), np.uint32)
+        ids = ctx.to_host(d_i, (n,), np.uint32)
+    for w, q, u in zip(whole, parts, untouched):
+        assert np.array_equal(w, q)
+        assert not u.any()
+    assert np.array_equal(np.bincount(ids, weights=votes[:, 0], minlength=n_bc).astype(np.uint32), whole[0])
+    assert np.array_equal(np.bincount(ids, weights=votes[:, 1], minlength=n_bc).astype(np.uint32), whole[1])
+    assert np.array_equal(np.bincount(ids, weights=(votes.sum(1) == 0), minlength=n_bc).astype(np.uint32), whole[2])
