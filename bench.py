@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- classified read-bp/s of the HAST stage-01 hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (hast_classify_device -> k_classify) over one HBM-resident
+batch of synthetic 150-bp reads; every step uses a different batch (counter-based generator,
+SURVEY 8(d)).  Default workload = the configuration the metric is quoted on: K=21, 200M+200M
+synthetic parental 21-mers (merged 6.4 GB table), 10M barcodes.  Tables are replicated per GPU, reads
+are sharded by index (weak scaling: every rank classifies steps*batch reads of its own), and the
+per-barcode counters are combined with ONE RCCL all-reduce + one D2H inside the timed region.
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     k_classify against the HBM roofline: algorithmic bytes (150 + 130*64 per read,
+               SURVEY 8(d)) per launch / average launch duration from HIP events on the launch stream.
+  cpu_baseline the oracle's CPU restatement of the reference algorithm ("port": two hash sets, two
+               probes per k-mer, t worker threads) on this box's host cores, on a bounded sample of the
+               same reads against the same full-size sets; a reported baseline, not the target.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_keys_per_hap, n_barcodes, description)
+    "c3": (200_000_000, 10_000_000, "C3 human-trio scale: 200M+200M synthetic 21-mers, 10M barcodes, 150bp reads"),
+    "c2": (50_000_000, 1_000_000, "C2: 50M+50M synthetic 21-mers, 1M barcodes, 150bp reads"),
+    "c1": (1_000_000, 10_000, "C1 plumbing: 1M+1M synthetic 21-mers, 10k barcodes, 150bp reads"),
+}
+ADAPTOR_F = b"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA"   # classify.cpp:312
+ADAPTOR_R = b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"   # classify.cpp:313
+HBM_PEAK_GBS = 8000.0                                           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--batch-reads", type=int, default=16_000_000)
+    ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores of this process")
+    ap.add_argument("--max-resident-gb", type=float, default=96.0, help="HBM budget for resident read batches")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch                      # first: libhast then binds to the HIP runtime torch already loaded
+    import torch.distributed as dist
+    import hast_amd
+    from hast_amd.binding import make_params, B_ALG_PER_READ
+    from hast_amd.sharding import shard_first_read
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_keys, n_bc, wl_desc = WORKLOADS[args.workload]
+    K, L, R = args.k, args.read_len, args.batch_reads
+    p = make_params(K, L, n_keys, n_bc)
+    ctx = hast_amd.Context(K, local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    hs = C.c_void_p(stream.cuda_stream)
+
+    # ---- table (replicated per GPU): generate + insert on the device, scrub adaptors ------------
+    t0 = time.time()
+    ctx.table_reserve(2 * n_keys, args.load_factor)
+    ctx.synth_table_build(p)
+    akeys = []
+    for ad in (ADAPTOR_F, ADAPTOR_R):
+        for kmer in hast_amd.chop_read(ad, K):
+            if kmer not in akeys:
+                akeys.append(kmer)
+    ctx.table_erase(np.array(akeys, dtype=np.uint64))
+    set_sizes = ctx.table_sizes()
+    n_buckets, table_bytes = ctx.table_info()
+    t_table = time.time() - t0
+    if rank == 0:
+        log("table: %d+%d keys -> sets %s, %d buckets, %.2f GB, built in %.3f s" %
+            (n_keys, n_keys, set_sizes, n_buckets, table_bytes / 1e9, t_table))
+
+    # ---- counters: caller-owned torch tensor so torch.distributed can all-reduce it -------------
+    counts = torch.zeros((n_bc, 4), dtype=torch.int32, device=dev)
+    ctx.counts_bind(counts.data_ptr(), n_bc)
+
+    # ---- HBM-resident read batches, all distinct (rank r, step s -> reads [(s*world+r)*R, +R)) ----
+    n_total = args.steps + args.warmup
+    per_batch = R * L + R * 4
+    n_res = max(1, min(n_total, int(args.max_resident_gb * 1e9 // per_batch)))
+    t0 = time.time()
+    batches = []
+    for j in range(n_res):
+        b = torch.empty(R * L + 64, dtype=torch.uint8, device=dev)
+        ids = torch.empty(R, dtype=torch.int32, device=dev)
+        ctx.synth_reads_device(p, shard_first_read(j, world, rank, R), R, b.data_ptr(), ids.data_ptr(), hs)
+        batches.append((b, ids))
+    stream.synchronize()
+    if rank == 0:
+        log("%d resident batches x %d reads (%.2f GB) generated in %.1f s" % (n_res, R, n_res * per_batch / 1e9, time.time() - t0))
+
+    def step(j):
+        b, ids = batches[j % n_res]
+        ctx.classify_device(b.data_ptr(), R * L, R, L, d_barcode_ids=ids.data_ptr(), stream=hs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    # ---- warmup -----------------------------------------------------------------------------------
+    for j in range(args.warmup):
+        step(j)
+    stream.synchronize()
+    counts.zero_()
+    torch.cuda.synchronize()
+
+    # ---- timed region: K steps + ONE all-reduce + D2H of the counters -------------------------------
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for s in range(args.steps):
+            ev0[s].record(stream)
+            step(args.warmup + s)
+            ev1[s].record(stream)
+        if world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)          # RCCL, uint32-as-int32 sums
+        counts_host = counts.cpu() if rank == 0 else None
+    stream.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    total_bp = world * args.steps * R * L
+    value = total_bp / elapsed
+    b_alg = B_ALG_PER_READ(L, K) * R                                # algorithmic bytes per launch
+    achieved = b_alg / (kern_avg_ms * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        ch = counts_host.numpy().view(np.uint32)
+        result = {
+            "metric": "classified read-bp/sec at k=%d, %dbp reads, %dM unique-mers/hap" % (K, L, n_keys // 1_000_000),
+            "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": wl_desc, "k": K, "read_len": L, "keys_per_hap": n_keys, "barcodes": n_bc,
+                       "batch_reads": R, "reads_total": world * args.steps * R, "table_gb": round(table_bytes / 1e9, 3),
+                       "load_factor": args.load_factor, "set_sizes": list(set_sizes), "sharding": "reads by index, tables replicated",
+                       "collective": "1x all_reduce(sum,u32[%d]) + D2H in timed region" % (n_bc * 4) if world > 1 else "none (D2H of counters in timed region)",
+                       "resident_batches": n_res},
+            "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": kern_avg_ms,
+                         "kernel_ms_min": min(kern_ms), "kernel_ms_max": max(kern_ms)},
+            "hits": {"c0": int(ch[:, 0].sum(dtype=np.uint64)), "c1": int(ch[:, 1].sum(dtype=np.uint64)),
+                     "neg_reads": int(ch[:, 2].sum(dtype=np.uint64))},
+        }
+        traffic = _committed_traffic(args, R)
+        if traffic:
+            result["roofline"].update(traffic)
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle's port on this box's host cores -----------------
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, ctx, p, batches[0], set_sizes, hs, stream)
+        except Exception as e:                                       # the baseline never gates the GPU number
+            result["cpu_baseline"] = {"value": None, "unit": "bp/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _committed_traffic(args, R):
+    """HBM bytes per launch from the committed rocprofv3 PMC profile of this same command, if one exists
+    (profiles/pmc_traffic.json, written by profiles/collect_pmc.sh); None otherwise."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("workload") != args.workload or d.get("batch_reads") != R:
+        return None
+    return {"traffic": d.get("hbm_bytes_per_launch"), "traffic_source": d.get("source")}
+
+
+def cpu_baseline(args, ctx, p, batch0, set_sizes, hs, stream):
+    """TEST-INFRASTRUCTURE leg: times oracle/liboracle.so (CPU restatement of the reference algorithm)
+    on a bounded sample of batch 0, against full-size sets built from the same synthetic keys, and
+    checks the GPU's counts for that sample against it."""
+    import subprocess
+    import numpy as np
+    import torch
+    import hast_amd
+    from tests import oracle_binding as ob
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True)
+    o = ob.load(os.path.join(ROOT, "oracle", "liboracle.so"))
+    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    K, L, n_keys, n_bc = p.k, p.read_len, p.n_keys_per_hap, p.n_barcodes
+    t0 = time.time()
+    oc = o.ho_new()
+    dk = torch.empty(n_keys, dtype=torch.int64, device=batch0[0].device)
+    for h in (0, 1):
+        ctx.synth_keys_device(p, h, 0, n_keys, dk.data_ptr(), hs)
+        stream.synchronize()
+        keys = dk.cpu().numpy()
+        assert o.ho_load_keys_mt(oc, keys.ctypes.data, keys.size, h, K, threads) == 0
+    del dk
+    o.ho_init_adaptor(oc, ADAPTOR_F, ADAPTOR_R, None)
+    assert (o.ho_set_size(oc, 0), o.ho_set_size(oc, 1)) == tuple(set_sizes), "CPU/GPU set sizes differ"
+    log("cpu_baseline: sets built on %d threads in %.1f s" % (threads, time.time() - t0))
+    bases = batch0[0][:args.batch_reads * L].cpu().numpy()
+    ids = batch0[1].cpu().numpy().view(np.uint32)
+
+    def run(n):
+        off = np.arange(n + 1, dtype=np.uint64) * L
+        e = [np.zeros(n_bc, np.uint32) for _ in range(3)]
+        t = time.perf_counter()
+        o.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, n, e[0].ctypes.data, e[1].ctypes.data,
+                          e[2].ctypes.data, None, threads)
+        return time.perf_counter() - t, e
+
+    n_probe = min(args.batch_reads, 20000 * threads)
+    dt, _ = run(n_probe)
+    rate = n_probe / dt
+    # wall seconds of the sample so that (threads x wall) is a bounded amount of CPU work
+    n = int(min(args.batch_reads, max(n_probe, rate * args.cpu_seconds)))
+    dt, e = run(n)
+    # parity of the same sample on the GPU
+    ctx.counts_resize(n_bc)
+    ctx.classify_device(batch0[0].data_ptr(), n * L, n, L, d_barcode_ids=batch0[1].data_ptr())
+    g = ctx.counts_read(n_bc)
+    parity = all(np.array_equal(a, b) for a, b in zip(g, e))
+    o.ho_free(oc)
+    return {"value": n * L / dt, "unit": "bp/s", "cores": threads, "kind": "port",
+            "sample": "first %d reads of batch 0 (%.1f s wall on %d threads), full %dM+%dM-key sets, oracle/hast_oracle.c -O2"
+                      % (n, dt, threads, n_keys // 1_000_000, n_keys // 1_000_000),
+            "gpu_counts_match_cpu_on_sample": bool(parity)}
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,7 @@ int      ho_load_kmers_file(ho_classifier *, const char *path, int hap);
 int      ho_load_kmers_text(ho_classifier *, const char *text, size_t nbytes, int hap);
 /* Bulk entry for large synthetic sets: keys are already canonical 2K-bit values.            */
 int      ho_load_keys(ho_classifier *, const uint64_t *canon_keys, size_t n, int hap, int k);
+int      ho_load_keys_mt(ho_classifier *, const uint64_t *canon_keys, size_t n, int hap, int k, int threads);
 int      ho_contains(const ho_classifier *, int hap, uint64_t canon_key);
 
 /* classify.cpp:314-339 InitAdaptor: erase every canonical k-mer of both adaptors from both

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (written by profiles/collect.sh on the GPU box) into the small tracked
+summaries under profiles/:  <tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json, <tag>_pmc.json and
+pmc_traffic.json (the per-launch HBM traffic bench.py reports in roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", "prof_" + tag)
+dst = "profiles"
+
+
+def counters(d):
+    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    out = {}
+    if not f:
+        return out
+    for r in csv.DictReader(open(f[0])):
+        out.setdefault(r["Kernel_Name"].split("(")[0], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return out
+
+
+shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "stats_bench.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
+bench = json.load(open(os.path.join(src, "stats_bench.json")))
+pmc = {}
+for d in sorted(os.listdir(src)):
+    if d.startswith(("pmc_", "cal_")) and os.path.isdir(os.path.join(src, d)):
+        for kern, cs in counters(d).items():
+            if "k_classify" in kern or "k_rand" in kern:
+                for c, v in cs.items():
+                    # last dispatch of the run (k_rand: the 256-iteration launch; k_classify: a timed step)
+                    pmc.setdefault(kern, {})[c] = v[-1]
+cal_line = json.loads(open(os.path.join(src, "cal_FETCH_SIZE.json")).read().strip().splitlines()[-1])
+kr = [k for k in pmc if "k_rand" in k][0]
+kc = [k for k in pmc if "k_classify" in k][0]
+cal_factor = cal_line["bytes"] / (pmc[kr]["FETCH_SIZE"] * 1024.0)
+fetch = pmc[kc]["FETCH_SIZE"] * 1024.0 * cal_factor
+write = pmc[kc]["WRITE_SIZE"] * 1024.0
+summary = {
+    "tag": tag,
+    "command": "python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 (one PMC pass per counter group, --kernel-trace only)",
+    "k_classify_per_launch": pmc[kc],
+    "calibration": {"tool": "tools/hbm_randread 6.4 64 4 256 2048 (random 64-B lines, 4 lanes x 16 B, same shape as k_classify)",
+                    "known_bytes": cal_line["bytes"], "FETCH_SIZE_KB": pmc[kr]["FETCH_SIZE"],
+                    "factor_known_over_counter": cal_factor, "TCC_EA0_RDREQ": pmc[kr].get("TCC_EA0_RDREQ_sum"),
+                    "note": "FETCH_SIZE (KB) x 1024 reads the random-line bytes exactly (factor ~1.00); the gfx950 x2 "
+                            "correction applies to wide coalesced streams only (here: the 2.4 GB of read bases, <2 % of traffic)"},
+    "hbm_bytes_per_launch": fetch + write,
+    "fetch_bytes": fetch, "write_bytes": write,
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "traffic_over_algorithmic": (fetch + write) / bench["roofline"]["algorithmic_bytes_per_launch"],
+    "l2_hit_rate": pmc[kc]["TCC_HIT_sum"] / (pmc[kc]["TCC_HIT_sum"] + pmc[kc]["TCC_MISS_sum"]),
+}
+json.dump(summary, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+json.dump({"workload": "c3", "batch_reads": bench["config"]["batch_reads"], "hbm_bytes_per_launch": fetch + write,
+           "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on tools/hbm_randread)" % tag},
+          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+if os.path.exists("gpurun_out/randread.jsonl"):
+    shutil.copy("gpurun_out/randread.jsonl", os.path.join(dst, tag + "_hbm_randread.jsonl"))
+print(json.dumps(summary, indent=1))

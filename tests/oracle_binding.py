@@ -27,6 +27,7 @@ def load(path):
         "ho_load_kmers_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
         "ho_load_kmers_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]),
         "ho_load_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+        "ho_load_keys_mt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]),
         "ho_contains": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
         "ho_init_adaptor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p]),
         "ho_process_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),

@@ -1,0 +1,81 @@
+// hbm_randread.hip -- measurement tool, not product code: what random line reads can MI355X HBM3E
+// sustain in the access shape k_classify uses (G lanes x 16 B = one aligned LINE-byte line per group)?
+// Gives the empirical ceiling next to the 8 TB/s spec peak, and a known-byte-count workload for
+// calibrating rocprofv3's FETCH_SIZE on this access pattern (MI355X_MICROARCH.md, HBM section).
+//
+//   hbm_randread <table_GB> <line_bytes 64|128> <unroll 1|2|4|8> [iters] [blocks]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <int LINE, int U>
+__global__ void __launch_bounds__(256) k_rand(const u32x4 *tab, uint32_t nlines, uint32_t iters, uint32_t *sink) {
+    constexpr int G = LINE / 16;
+    const uint64_t gid = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) / G;
+    const uint32_t sub = threadIdx.x % G;
+    u32x4 acc = {0, 0, 0, 0};
+    for (uint32_t it = 0; it < iters; ++it) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t h = (uint32_t)(mix(gid * 0x10001ull + (uint64_t)it * U + u) >> 32);
+            uint32_t line = (uint32_t)(((uint64_t)h * nlines) >> 32);
+            v[u] = tab[(size_t)line * G + sub];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
+template <int LINE, int U>
+double run(const u32x4 *tab, uint32_t nlines, uint32_t iters, int blocks, uint32_t *sink) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k_rand<LINE, U>), dim3(blocks), dim3(256), 0, 0, tab, nlines, 2u, sink);   // warm
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_rand<LINE, U>), dim3(blocks), dim3(256), 0, 0, tab, nlines, iters, sink);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+int main(int argc, char **argv) {
+    double gb = argc > 1 ? atof(argv[1]) : 6.4;
+    int line = argc > 2 ? atoi(argv[2]) : 64;
+    int unroll = argc > 3 ? atoi(argv[3]) : 4;
+    uint32_t iters = argc > 4 ? (uint32_t)atoi(argv[4]) : 256;
+    int blocks = argc > 5 ? atoi(argv[5]) : 2048;
+    size_t bytes = (size_t)(gb * 1e9) / line * line;
+    uint32_t nlines = (uint32_t)(bytes / line);
+    u32x4 *tab;
+    uint32_t *sink;
+    CK(hipMalloc(&tab, bytes));
+    CK(hipMalloc(&sink, 4));
+    CK(hipMemset(tab, 0x5A, bytes));
+    CK(hipDeviceSynchronize());
+    double ms = 0;
+#define CASE(L, U) if (line == L && unroll == U) ms = run<L, U>(tab, nlines, iters, blocks, sink);
+    CASE(64, 1) CASE(64, 2) CASE(64, 4) CASE(64, 8) CASE(128, 1) CASE(128, 2) CASE(128, 4) CASE(128, 8)
+    if (ms == 0) { fprintf(stderr, "unsupported line/unroll\n"); return 1; }
+    double groups = (double)blocks * 256 / (line / 16);
+    double lines = groups * iters * unroll;
+    printf("{\"table_gb\": %.2f, \"line\": %d, \"unroll\": %d, \"blocks\": %d, \"lines\": %.0f, \"bytes\": %.0f, \"ms\": %.3f, \"Glines_per_s\": %.2f, \"GB_per_s\": %.1f}\n",
+           gb, line, unroll, blocks, lines, lines * line, ms, lines / ms / 1e6, lines * line / ms / 1e6);
+    return 0;
+}
