@@ -26,6 +26,8 @@ ABI_SYMBOLS = {
     "hast_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
     "hast_ctx_destroy": (None, [vp]),
     "hast_ctx_k": (C.c_int, [vp]),
+    "hast_ctx_minimizer": (C.c_int, [vp]),
+    "hast_ctx_set_minimizer": (C.c_int, [vp, C.c_int]),
     "hast_ctx_device": (C.c_int, [vp]),
     "hast_ctx_stream": (vp, [vp]),
     "hast_stream_sync": (C.c_int, [vp, vp]),
@@ -165,12 +167,18 @@ def synth_reads_host(p: SynthParams, first, n):
 class Context:
     """One GPU context (hast_ctx).  Raises HastError(NO_DEVICE) when there is no GPU."""
 
-    def __init__(self, k, device=0):
+    def __init__(self, k, device=0, minimizer=None):
         self._h = C.c_void_p()
         self._lib = lib()
         _ck(self._lib.hast_ctx_create(device, k, C.byref(self._h)))
         self.k = k
         self.device = device
+        if minimizer is not None:
+            _ck(self._lib.hast_ctx_set_minimizer(self._h, minimizer))
+
+    @property
+    def minimizer(self):
+        return self._lib.hast_ctx_minimizer(self._h)
 
     def close(self):
         if self._h:
@@ -220,7 +228,7 @@ class Context:
         _ck(self._lib.hast_memset_d(self._h, C.c_void_p(dptr), byte, nbytes, stream))
 
     # table
-    def table_reserve(self, max_keys, load_factor=0.5):
+    def table_reserve(self, max_keys, load_factor=0.0):
         _ck(self._lib.hast_table_reserve(self._h, max_keys, load_factor))
 
     def table_insert_text(self, hap, text: bytes) -> int:

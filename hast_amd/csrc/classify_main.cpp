@@ -216,7 +216,7 @@ int main(int argc, char **argv) {
     }
     hast_ctx *ctx = nullptr;
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
-    CK(hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.5), "allocating the k-mer table");
+    CK(hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.0), "allocating the k-mer table");
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "__load hap%d kmers__\n", h);
         uint64_t lines = 0;

@@ -52,6 +52,7 @@ struct Staging {          // one pinned+device buffer set of hast_classify_batch
 struct hast_ctx {
     int device = 0;
     int k = 0;
+    int m = 0;                  // minimizer length used for bucket placement (fixed once a table exists)
     int n_cu = 256;
     hipStream_t stream = nullptr;
     // table
@@ -71,6 +72,18 @@ struct hast_ctx {
 };
 
 namespace {
+
+TableGeom geom(const hast_ctx *c) { return TableGeom{c->nbuckets, c->k, c->m}; }
+
+// default minimizer length: w = K-m+1 consecutive windows can share a bucket line; m stays >= 17 so that
+// the minimizer space (4^m/2) dwarfs human-scale key counts and buckets stay evenly loaded
+int default_minimizer(int k) {
+    if (const char *e = getenv("HAST_MINIMIZER")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= k) return v;
+    }
+    return k <= 17 ? k : std::max(17, k - 8);
+}
 
 hast_status use(hast_ctx *c) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
@@ -141,6 +154,7 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     if (!c) return fail(HAST_ERR_OOM, "host allocation failed");
     c->device = device;
     c->k = k;
+    c->m = default_minimizer(k);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     hast_status st = HAST_OK;
@@ -185,6 +199,15 @@ void hast_ctx_destroy(hast_ctx *c) {
 }
 
 int hast_ctx_k(const hast_ctx *c) { return c ? c->k : 0; }
+int hast_ctx_minimizer(const hast_ctx *c) { return c ? c->m : 0; }
+
+hast_status hast_ctx_set_minimizer(hast_ctx *c, int m) {
+    if (!c) return fail(HAST_ERR_INVALID, "null context");
+    if (m < 1 || m > c->k) return fail(HAST_ERR_INVALID, "minimizer length %d out of [1,%d]", m, c->k);
+    if (c->d_slots) return fail(HAST_ERR_INVALID, "minimizer length is fixed once the table exists");
+    c->m = m;
+    return HAST_OK;
+}
 int hast_ctx_device(const hast_ctx *c) { return c ? c->device : -1; }
 hast_stream hast_ctx_stream(const hast_ctx *c) { return c ? (hast_stream)c->stream : nullptr; }
 
@@ -226,7 +249,7 @@ hast_status hast_memset_d(hast_ctx *c, void *d, int byte, size_t n, hast_stream 
 // ---------------------------------------------------------------------------------------------
 hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     if (hast_status st = use(c)) return st;
-    if (lf <= 0) lf = 0.5;
+    if (lf <= 0) lf = 0.25;
     if (lf > 0.9) return fail(HAST_ERR_INVALID, "load factor %.3f > 0.9", lf);
     double want = (double)(max_keys ? max_keys : 1) / lf / kSlotsPerBucket;
     uint64_t nb = (uint64_t)want + 1;
@@ -254,7 +277,7 @@ static hast_status need_table(hast_ctx *c, int hap) {
 hast_status hast_table_insert_keys_device(hast_ctx *c, int hap, const uint64_t *d_keys, size_t n, hast_stream s) {
     if (hast_status st = need_table(c, hap)) return st;
     hipStream_t hs = s ? (hipStream_t)s : c->stream;
-    HIP_TRY(launch_insert_keys(c->d_slots, c->nbuckets, d_keys, n, 1u << hap, c->d_err, hs));
+    HIP_TRY(launch_insert_keys(c->d_slots, geom(c), d_keys, n, 1u << hap, c->d_err, hs));
     return check_err_word(c, hs);
 }
 
@@ -266,7 +289,7 @@ hast_status hast_table_insert_keys(hast_ctx *c, int hap, const uint64_t *keys, s
     for (size_t i = 0; i < n; i += per) {
         size_t m = std::min(per, n - i);
         HIP_TRY(hipMemcpyAsync(c->d_scratch, keys + i, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_insert_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+        HIP_TRY(launch_insert_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return check_err_word(c, c->stream);
@@ -289,7 +312,7 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
     for (size_t i = 0; i < n_lines; i += per) {
         size_t m = std::min(per, n_lines - i);
         HIP_TRY(hipMemcpyAsync(c->d_scratch, text + i * stride, m * stride, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_insert_text(c->d_slots, c->nbuckets, (const char *)c->d_scratch, m, c->k, 1u << hap, c->d_err, c->stream));
+        HIP_TRY(launch_insert_text(c->d_slots, geom(c), (const char *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (hast_status st = check_err_word(c, c->stream)) return st;
@@ -308,7 +331,7 @@ hast_status hast_table_erase(hast_ctx *c, const uint64_t *keys, size_t n, uint8_
     // one key at a time per launch order is not required: distinct keys touch distinct slots, and a
     // key listed twice reports its tags once (the second atomicAnd sees them already cleared) --
     // the same as the reference's find-then-erase loop (classify.cpp:318-337).
-    HIP_TRY(launch_erase_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, n, d_hit, c->stream));
+    HIP_TRY(launch_erase_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, n, d_hit, c->stream));
     std::vector<uint8_t> hit(n);
     HIP_TRY(hipMemcpyAsync(hit.data(), d_hit, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -324,7 +347,7 @@ hast_status hast_table_lookup(hast_ctx *c, const uint64_t *keys, size_t n, uint8
     if (hast_status st = ensure_scratch(c, kb + n + 16)) return st;
     uint8_t *d_tags = (uint8_t *)c->d_scratch + kb;
     HIP_TRY(hipMemcpyAsync(c->d_scratch, keys, kb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_lookup_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, n, d_tags, c->stream));
+    HIP_TRY(launch_lookup_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, n, d_tags, c->stream));
     HIP_TRY(hipMemcpyAsync(out_tags, d_tags, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HAST_OK;
@@ -466,21 +489,23 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.nbuckets = c->nbuckets;
     a.read_len = read_len;
     a.k = c->k;
+    a.m = c->m;
     a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
+    a.mh_stride = read_len >= (uint32_t)c->m ? read_len - c->m + 1 : 0;
     a.w64 = (read_len + 31) / 32;
-    // reads per tile: as many as fit ~24 KB of LDS, at most 64, so that >= 6 workgroups fit a CU
-    const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 4 + 4 + 8;
-    uint32_t tr = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (24u << 10) / per_read));
+    // reads per tile: as many as fit ~19.5 KB of LDS (8 workgroups per CU), at most 64
+    const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4;
+    uint32_t tr = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (size_t)19968 / per_read));
     a.tile_reads = tr;
     const size_t smem = per_read * tr;
     if (smem > (160u << 10)) return fail(HAST_ERR_INVALID, "read_len %u needs %zu B of LDS", read_len, smem);
-    a.div_magic = 0;
-    if (a.max_pos > 0) {
-        // __umulhi(q, magic) == q / max_pos for every q the kernel forms (q < tr*P + 256)
-        uint64_t qmax = (uint64_t)tr * a.max_pos + 1024;
-        if (qmax * a.max_pos < (1ull << 32)) a.div_magic = (uint32_t)((1ull << 32) / a.max_pos) + 1;
-        if (a.max_pos == 1) a.div_magic = 0;   // 2^32/1+1 does not fit; plain division
-    }
+    // __umulhi(q, magic) == q / d for every q the kernel forms (exact while q*d < 2^32)
+    auto magic = [](uint64_t qmax, uint32_t d) -> uint32_t {
+        if (d <= 1 || qmax * d >= (1ull << 32)) return 0;
+        return (uint32_t)((1ull << 32) / d) + 1;
+    };
+    a.div_magic = magic((uint64_t)tr * a.max_pos + 1024, a.max_pos);
+    a.div_mh = magic((uint64_t)tr * a.mh_stride + 1024, a.mh_stride);
     const uint64_t n_tiles = (n_reads + tr - 1) / tr;
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
     HIP_TRY(launch_classify(a, grid, smem, s ? (hipStream_t)s : c->stream));
@@ -650,7 +675,7 @@ hast_status hast_synth_table_build(hast_ctx *c, const hast_synth_params *p) {
         for (uint64_t i = 0; i < sp.n_keys_per_hap; i += per) {
             size_t m = (size_t)std::min<uint64_t>(per, sp.n_keys_per_hap - i);
             HIP_TRY(launch_synth_keys(sp, hap, i, m, (uint64_t *)c->d_scratch, c->stream));
-            HIP_TRY(launch_insert_keys(c->d_slots, c->nbuckets, (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+            HIP_TRY(launch_insert_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
         }
     return check_err_word(c, c->stream);
 }

@@ -51,14 +51,30 @@ constexpr int      kSlotsPerBucket = 8;            // 8 x 8 B = one 64-B line
 constexpr uint64_t kEmptySlot = ~0ull;             // (key<<2|tags) can never be all ones: the
                                                    // all-G k-mer is never canonical (all-C is smaller)
 
-// home bucket of a canonical key; nbuckets < 2^32
-HAST_HD uint32_t bucket_hash32(uint64_t key) {
-    uint64_t x = key * 0x9E3779B97F4A7C15ull;
-    uint32_t h = (uint32_t)(x >> 32) ^ (uint32_t)x;
-    return h * 0x85EBCA6Bu;
+// Home bucket of a canonical key = f(minimizer of the key), so that the K-m+1.. consecutive windows of a
+// read that share a minimizer probe the SAME 64-B line (the memory system merges them: one HBM request
+// instead of several).  minimizer hash = min over the key's m-mers of hash32(canonical m-mer); it is
+// strand-independent because an m-mer and its reverse complement have the same canonical form.
+// m == k degenerates to plain hashing of the key.
+HAST_HD uint32_t mmer_hash32(uint64_t canon_mmer) {
+    return (uint32_t)((canon_mmer * 0x9E3779B97F4A7C15ull) >> 32);
 }
-HAST_HD uint32_t home_bucket(uint64_t key, uint32_t nbuckets) {
-    return (uint32_t)(((uint64_t)bucket_hash32(key) * nbuckets) >> 32);
+HAST_HD uint32_t minimizer_hash(uint64_t kmer, int k, int m) {
+    const uint64_t mm_mask = kmer_mask(m);
+    uint32_t best = 0xFFFFFFFFu;
+    for (int j = 0; j + m <= k; ++j) {
+        uint64_t mm = (kmer >> (2 * (k - m - j))) & mm_mask;
+        uint32_t h = mmer_hash32(kmer_canon(mm, m));
+        best = h < best ? h : best;
+    }
+    return best;
+}
+// the minimum of several hashes is biased towards 0: re-spread it before range reduction
+HAST_HD uint32_t bucket_of_minhash(uint32_t minh, uint32_t nbuckets) {
+    return (uint32_t)(((uint64_t)(minh * 0x9E3779B1u) * nbuckets) >> 32);
+}
+HAST_HD uint32_t home_bucket(uint64_t key, int k, int m, uint32_t nbuckets) {
+    return bucket_of_minhash(minimizer_hash(key, k, m), nbuckets);
 }
 
 // ---- synthetic workload ----------------------------------------------------------

@@ -7,6 +7,12 @@
 
 namespace hast {
 
+struct TableGeom {
+    uint32_t nbuckets;
+    int k;          // k-mer length
+    int m;          // minimizer length (m == k: plain hashing of the key)
+};
+
 struct ClassifyArgs {
     const uint8_t *bases;        // ASCII bases, reads back to back
     uint64_t bases_bytes;        // readable bytes at `bases`
@@ -22,15 +28,18 @@ struct ClassifyArgs {
     uint32_t w64;                // 64-bit LDS words per read (32 bases each), excluding the pad word
     uint32_t tile_reads;         // reads per workgroup tile
     uint32_t div_magic;          // floor(2^32/max_pos)+1 when exact over the tile's range, else 0
+    uint32_t mh_stride;          // m-mer positions per read: read_len-m+1 (0 when read_len<m)
+    uint32_t div_mh;             // same trick for mh_stride
     int k;
+    int m;                       // minimizer length
 };
 
-hipError_t launch_insert_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint32_t tag,
+hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t tag,
                               uint32_t *d_err, hipStream_t s);
-hipError_t launch_insert_text(uint64_t *slots, uint32_t nbuckets, const char *d_text, size_t n_lines, int k,
+hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, size_t n_lines,
                               uint32_t tag, uint32_t *d_err, hipStream_t s);
-hipError_t launch_erase_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s);
-hipError_t launch_lookup_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
+hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s);
+hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
 hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);

@@ -19,9 +19,10 @@ namespace hast {
 // probe order from its home bucket, that had a free slot when it was inserted; slots never become
 // empty again (erase only clears tag bits), so lookups may stop at the first bucket with an empty slot.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool table_insert(uint64_t *slots, uint32_t nbuckets, uint64_t key, uint32_t tag) {
+__device__ __forceinline__ bool table_insert(uint64_t *slots, const TableGeom g, uint64_t key, uint32_t tag) {
+    const uint32_t nbuckets = g.nbuckets;
     const uint64_t want = (key << 2) | tag;
-    uint32_t b = home_bucket(key, nbuckets);
+    uint32_t b = home_bucket(key, g.k, g.m, nbuckets);
     for (uint32_t probe = 0; probe < nbuckets; ++probe) {
         unsigned long long *bs = reinterpret_cast<unsigned long long *>(slots) + (size_t)b * kSlotsPerBucket;
         for (int i = 0; i < kSlotsPerBucket; ++i) {
@@ -46,8 +47,9 @@ __device__ __forceinline__ bool table_insert(uint64_t *slots, uint32_t nbuckets,
 }
 
 // returns the address of the slot holding `key`, or nullptr
-__device__ __forceinline__ unsigned long long *table_find(uint64_t *slots, uint32_t nbuckets, uint64_t key) {
-    uint32_t b = home_bucket(key, nbuckets);
+__device__ __forceinline__ unsigned long long *table_find(uint64_t *slots, const TableGeom g, uint64_t key) {
+    const uint32_t nbuckets = g.nbuckets;
+    uint32_t b = home_bucket(key, g.k, g.m, nbuckets);
     for (uint32_t probe = 0; probe < nbuckets; ++probe) {
         unsigned long long *bs = reinterpret_cast<unsigned long long *>(slots) + (size_t)b * kSlotsPerBucket;
         bool any_empty = false;
@@ -62,16 +64,17 @@ __device__ __forceinline__ unsigned long long *table_find(uint64_t *slots, uint3
     return nullptr;
 }
 
-__global__ void __launch_bounds__(256) k_insert_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *keys,
+__global__ void __launch_bounds__(256) k_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *keys,
                                                      size_t n, uint32_t tag, uint32_t *err) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        if (!table_insert(slots, nbuckets, keys[i], tag)) atomicOr(&err[0], 1u);
+        if (!table_insert(slots, g, keys[i], tag)) atomicOr(&err[0], 1u);
 }
 
 // load_kmers (classify.cpp:30-46): line i = text[i*(K+1) .. +K), text[i*(K+1)+K] must be '\n'.
 // err bit0: table full, bit1: a line is not exactly K bytes.
-__global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, uint32_t nbuckets, const char *text,
-                                                     size_t n_lines, int k, uint32_t tag, uint32_t *err) {
+__global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, TableGeom g, const char *text,
+                                                     size_t n_lines, uint32_t tag, uint32_t *err) {
+    const int k = g.k;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_lines; i += (size_t)gridDim.x * blockDim.x) {
         const char *s = text + i * (size_t)(k + 1);
         uint64_t w = 0;
@@ -82,23 +85,23 @@ __global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, uint32_t n
             w = (w << 2) | base_code(c);
         }
         if (bad) { atomicOr(&err[0], 2u); continue; }
-        if (!table_insert(slots, nbuckets, kmer_canon(w, k), tag)) atomicOr(&err[0], 1u);
+        if (!table_insert(slots, g, kmer_canon(w, k), tag)) atomicOr(&err[0], 1u);
     }
 }
 
 // InitAdaptor (classify.cpp:314-339): clear both tag bits of each key; report which were set.
-__global__ void k_erase_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *keys, size_t n, uint8_t *hit) {
+__global__ void k_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *keys, size_t n, uint8_t *hit) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long *p = table_find(slots, nbuckets, keys[i]);
+    unsigned long long *p = table_find(slots, g, keys[i]);
     unsigned long long old = p ? atomicAnd(p, ~3ull) : 0ull;
     hit[i] = (uint8_t)(old & 3);
 }
 
-__global__ void k_lookup_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *keys, size_t n, uint8_t *tags) {
+__global__ void k_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *keys, size_t n, uint8_t *tags) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long *p = table_find(slots, nbuckets, keys[i]);
+    unsigned long long *p = table_find(slots, g, keys[i]);
     tags[i] = p ? (uint8_t)(*p & 3) : 0;
 }
 
@@ -125,21 +128,28 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 // ------------------------------------------------------------------------------------------
 // K3: classify.
 //
-// Workgroup = 256 threads = 4 waves; it walks tiles of TR reads:
+// Workgroup = 256 threads = 4 wave64; it walks tiles of TR reads through LDS:
 //   A  pack   : each lane turns 16 ASCII bases (aligned dword loads + v_alignbyte) into 32 bits of
-//               2-bit codes ((c&6)>>1, kmer.h:11) in LDS, first base most significant, and flags
-//               reads that contain 'N' (classify.cpp:182-185).
-//   B  probe  : the tile's (read, offset) k-mer positions are flattened over QUADS of lanes.  A quad
-//               extracts the window from LDS (funnel shift, no rolling state), canonicalises
-//               (v_bfrev), hashes, and its 4 lanes load the 4 x 16 B of ONE 64-B bucket: one
-//               global_load_dwordx4 wave-instruction = 16 buckets = 16 coalesced 64-B lines.
-//               U such loads are in flight per lane.  Hits (rare) go to per-read LDS counters.
+//               2-bit codes ((c&6)>>1, kmer.h:11), first base most significant, and flags reads that
+//               contain 'N' (classify.cpp:182-185).
+//   M  m-mers : one lane per m-mer position: hash32(canonical m-mer) -> LDS.  The minimum over the
+//               K-m+1 m-mers of a window is that window's minimizer hash = its home bucket
+//               (hast_common.h), so consecutive windows mostly probe the same 64-B line.
+//   B  probe  : (read, offset) windows are flattened; every LANE owns one window: funnel-shift it out
+//               of two LDS words (no rolling state), canonicalise (v_bfrev), window-min of the m-mer
+//               hashes.  Then 4 rounds: in round j each QUAD takes the window of its lane j (DPP
+//               quad broadcast) and its 4 lanes load the 4 x 16 B of that window's bucket, i.e. one
+//               global_load_dwordx4 wave-instruction = 16 buckets, lanes of a quad coalesced into one
+//               64-B line, adjacent quads = consecutive windows (same line when they share a
+//               minimizer).  kBlocks x 4 loads are in flight per lane.  A bucket is full iff its last
+//               slot is taken (slots fill in order), so "no match and slot.y of some lane empty"
+//               ends the probe; full buckets without a match (rare at load factor 0.25) take the
+//               chain walk.  Hits (about 1 % of windows) go to per-read LDS counters.
 //   C  commit : one lane per read does ONE global atomic on the read's barcode record
-//               {c0,c1} as a single u64 add, or neg++ (classify.cpp:203-208).
+//               ({c0,c1} as a single u64 add, or neg++; classify.cpp:203-208).
 // ------------------------------------------------------------------------------------------
 constexpr int kThreads = 256;
-constexpr int kQuads = kThreads / 4;
-constexpr int kUnroll = 4;
+constexpr int kBlocks = 2;                    // 64-window blocks per wave in flight together
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack4(uint32_t x) {
@@ -151,26 +161,43 @@ __device__ __forceinline__ uint32_t has_byte_N(uint32_t x) {
     uint32_t y = x ^ 0x4E4E4E4Eu;                       // 'N' -> 0
     return (y - 0x01010101u) & ~y & 0x80808080u;        // != 0 iff some byte of y is 0
 }
+// bases [p, p+n) of a packed read (n <= 31), right-aligned
+__device__ __forceinline__ uint64_t window_bits(const unsigned long long *words, uint32_t p, uint32_t shift_out) {
+    const unsigned long long w0 = words[p >> 5], w1 = words[(p >> 5) + 1];
+    const uint32_t sh = (p & 31) * 2;
+    const unsigned long long x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));       // sh == 0 safe
+    return x >> shift_out;
+}
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);   // quad_perm [J,J,J,J]
+}
 
 __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
     const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
+    const uint32_t MS = a.mh_stride;                                 // m-mer positions per read (stride)
     unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(smem);            // [TR][WS]
     unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
-    uint32_t *s_len = reinterpret_cast<uint32_t *>(s_vote + TR);                           // [TR]
+    unsigned long long *s_off = s_vote + TR;                                               // [TR]
+    uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
     uint32_t *s_flag = s_len + TR;                                                         // [TR]
-    unsigned long long *s_off = reinterpret_cast<unsigned long long *>(s_flag + TR);       // [TR]
+    uint32_t *s_mh = s_flag + TR;                                                          // [TR][MS]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t sub = tid & 3;                // which 16 B of the bucket this lane loads
-    const uint32_t quad = tid >> 2;              // 0..63
-    const int K = a.k;
-    const uint32_t kshift = 64 - 2 * K;
+    const uint32_t sub = tid & 3;                // which 16 B of a bucket this lane loads
+    // lane -> window inside the wave's 64-window block, so that in round j quad g holds window 16j+g
+    const uint32_t wofs = (tid & ~63u) + 16 * sub + (lane >> 2);
+    const int K = a.k, M = a.m;
+    const uint32_t W = (uint32_t)(K - M + 1);
+    const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
+    const uint32_t nb = a.nbuckets;
     const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
+    const u64x2 none = {kEmptySlot, kEmptySlot};
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t r0 = tile * TR;
@@ -195,7 +222,7 @@ __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
             const uint32_t r = t / HW, j = t - r * HW;
             const uint32_t len = s_len[r];
             if (16 * j >= len) continue;
-            const uint32_t nb = (len - 16 * j < 16) ? (len - 16 * j) : 16;
+            const uint32_t nbases = (len - 16 * j < 16) ? (len - 16 * j) : 16;
             const uintptr_t addr = base_addr + s_off[r] + 16 * j;
             const uintptr_t a4 = addr & ~(uintptr_t)3;
             const uint32_t bsh = (uint32_t)(addr & 3);
@@ -209,7 +236,7 @@ __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], bsh);   // bytes addr+4i .. +4i+3
-                int vb = (int)nb - 4 * i;                                        // valid bytes in x
+                int vb = (int)nbases - 4 * i;                                    // valid bytes in x
                 if (vb < 4) {
                     uint32_t m = (vb <= 0) ? 0u : ((1u << (8 * vb)) - 1u);
                     x = (x & m) | (0x41414141u & ~m);                            // pad with 'A'
@@ -225,66 +252,103 @@ __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
         }
         __syncthreads();
 
+        // ---- M: m-mer hashes; reads with 'N' get length 0 (whole-read skip, classify.cpp:190-193) ----
+        for (uint32_t t = tid; t < tra * MS; t += kThreads) {
+            const uint32_t r = a.div_mh ? __umulhi(t, a.div_mh) : (t / MS);
+            const uint32_t q = t - r * MS;
+            uint32_t h = 0xFFFFFFFFu;
+            if (q + M <= s_len[r]) {
+                const uint64_t mm = window_bits(s_pack + (size_t)r * WS, q, mshift);
+                h = mmer_hash32(kmer_canon(mm, M));
+            }
+            s_mh[(size_t)r * MS + q] = h;
+        }
+        __syncthreads();
+        if (tid < tra && s_flag[tid]) s_len[tid] = 0;
+        __syncthreads();
+
         // ---- B: probe ---------------------------------------------------------------------
-        const uint32_t P = a.max_pos;                                 // positions per read (stride)
+        const uint32_t P = a.max_pos;                                 // windows per read (stride)
         const uint32_t Q = tra * P;
-        for (uint32_t qb = 0; qb < Q; qb += kQuads * kUnroll) {
-            uint64_t key[kUnroll];
-            uint32_t rd[kUnroll];
-            uint32_t bkt[kUnroll];
-            bool valid[kUnroll];
-            u64x2 sl[kUnroll];
+        for (uint32_t qb = 0; qb < Q; qb += kThreads * kBlocks) {
+            uint32_t o_klo[kBlocks], o_khi[kBlocks], o_bkt[kBlocks], o_meta[kBlocks];   // this lane's own window
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const uint32_t q = qb + u * kQuads + quad;
+            for (int u = 0; u < kBlocks; ++u) {
+                const uint32_t q = qb + u * kThreads + wofs;
                 uint32_t r = a.div_magic ? __umulhi(q, a.div_magic) : (q / P);
-                uint32_t p = q - r * P;
+                const uint32_t p = q - r * P;
                 bool ok = q < Q;
                 r = ok ? r : 0;
-                const uint32_t len = s_len[r];
-                ok = ok && (p + K <= len) && (s_flag[r] == 0);
-                const unsigned long long *wp = s_pack + (size_t)r * WS + (p >> 5);
-                const unsigned long long w0 = wp[0], w1 = wp[1];
-                const uint32_t sh = (p & 31) * 2;
-                unsigned long long x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));     // sh==0 safe
-                const uint64_t fwd = x >> kshift;
-                const uint64_t ck = kmer_canon(fwd, K);
-                key[u] = ck;
-                rd[u] = r;
-                valid[u] = ok;
-                bkt[u] = home_bucket(ck, a.nbuckets);
+                ok = ok && (p + K <= s_len[r]);
+                const uint64_t ck = kmer_canon(window_bits(s_pack + (size_t)r * WS, p, kshift), K);
+                const uint32_t *mh = s_mh + (size_t)r * MS + p;
+                uint32_t mn = mh[0];
+                for (uint32_t j = 1; j < W; ++j) mn = min(mn, mh[j]);
+                o_klo[u] = (uint32_t)(ck << 2);
+                o_khi[u] = (uint32_t)(ck >> 30);
+                o_bkt[u] = bucket_of_minhash(mn, nb);
+                o_meta[u] = r | (ok ? 0x80000000u : 0u);
             }
+            u64x2 sl[kBlocks][4];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const u64x2 *bp = reinterpret_cast<const u64x2 *>(a.slots + (size_t)bkt[u] * kSlotsPerBucket) + sub;
-                const u64x2 none = {kEmptySlot, kEmptySlot};
-                sl[u] = valid[u] ? *bp : none;
-            }
+            for (int u = 0; u < kBlocks; ++u) {
+                const uint32_t bk[4] = {quad_bcast<0>(o_bkt[u]), quad_bcast<1>(o_bkt[u]), quad_bcast<2>(o_bkt[u]), quad_bcast<3>(o_bkt[u])};
+                const uint32_t mt[4] = {quad_bcast<0>(o_meta[u]), quad_bcast<1>(o_meta[u]), quad_bcast<2>(o_meta[u]), quad_bcast<3>(o_meta[u])};
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const bool mx = (sl[u].x >> 2) == key[u], my = (sl[u].y >> 2) == key[u];
-                bool hit = valid[u] && (mx || my);
-                uint32_t tags = hit ? (uint32_t)((mx ? sl[u].x : sl[u].y) & 3) : 0;
-                bool stop = hit || sl[u].x == kEmptySlot || sl[u].y == kEmptySlot;
-                // quad vote: did any of the 4 lanes of my quad see a match or an empty slot?
-                unsigned long long m = __ballot(stop);
-                bool more = valid[u] && (((m >> (lane & 60)) & 0xF) == 0);
-                uint32_t b = bkt[u];
-                uint32_t guard = 0;
-                while (__any(more)) {                       // bucket overflow chain: rare
-                    u64x2 s2 = {kEmptySlot, kEmptySlot};
-                    if (more) {
-                        b = (b + 1 == a.nbuckets) ? 0 : b + 1;
-                        s2 = *(reinterpret_cast<const u64x2 *>(a.slots + (size_t)b * kSlotsPerBucket) + sub);
-                    }
-                    const bool nx = (s2.x >> 2) == key[u], ny = (s2.y >> 2) == key[u];
-                    const bool h2 = more && (nx || ny);
-                    if (h2) tags = (uint32_t)((nx ? s2.x : s2.y) & 3);
-                    const bool st2 = more && (h2 || s2.x == kEmptySlot || s2.y == kEmptySlot);
-                    unsigned long long m2 = __ballot(st2);
-                    if (((m2 >> (lane & 60)) & 0xF) != 0 || ++guard >= a.nbuckets) more = false;
+                for (int j = 0; j < 4; ++j) {
+                    const u64x2 *bp = reinterpret_cast<const u64x2 *>(a.slots + (size_t)bk[j] * kSlotsPerBucket) + sub;
+                    sl[u][j] = ((int)mt[j] < 0) ? *bp : none;
                 }
-                if (tags) atomicAdd(&s_vote[rd[u]], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+            }
+#pragma unroll
+            for (int u = 0; u < kBlocks; ++u) {
+                uint32_t moremask = 0;
+                // the window's key and read are re-broadcast here rather than kept live across the loads
+                const uint32_t kl[4] = {quad_bcast<0>(o_klo[u]), quad_bcast<1>(o_klo[u]), quad_bcast<2>(o_klo[u]), quad_bcast<3>(o_klo[u])};
+                const uint32_t kh[4] = {quad_bcast<0>(o_khi[u]), quad_bcast<1>(o_khi[u]), quad_bcast<2>(o_khi[u]), quad_bcast<3>(o_khi[u])};
+                const uint32_t mt[4] = {quad_bcast<0>(o_meta[u]), quad_bcast<1>(o_meta[u]), quad_bcast<2>(o_meta[u]), quad_bcast<3>(o_meta[u])};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
+                    const bool mx = (sl[u][j].x & ~3ull) == kq, my = (sl[u][j].y & ~3ull) == kq;
+                    const bool valid = (int)mt[j] < 0;
+                    const bool hit = valid && (mx || my);
+                    // bucket full <=> last slot taken <=> no lane of the quad sees an empty .y
+                    const unsigned long long m = __ballot(hit || sl[u][j].y == kEmptySlot);
+                    if (hit) {
+                        const uint32_t tags = (uint32_t)((mx ? sl[u][j].x : sl[u][j].y) & 3);
+                        atomicAdd(&s_vote[mt[j] & 0xFFFF],
+                                  (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+                    }
+                    if (valid && ((m >> (lane & 60)) & 0xF) == 0) moremask |= 1u << j;
+                }
+                // chain walk for full buckets without a match (quad-uniform mask; rare)
+                while (__any(moremask != 0)) {
+                    const bool act = moremask != 0;
+                    const uint32_t j = act ? (uint32_t)__ffs(moremask) - 1 : 0;
+                    const int src = (int)((lane & 60) | j);
+                    const unsigned long long kq = ((unsigned long long)__shfl((int)o_khi[u], src) << 32) | (uint32_t)__shfl((int)o_klo[u], src);
+                    uint32_t b = (uint32_t)__shfl((int)o_bkt[u], src);
+                    const uint32_t rd = (uint32_t)__shfl((int)o_meta[u], src) & 0xFFFF;
+                    bool pending = act;
+                    uint32_t guard = 0;
+                    while (__any(pending)) {
+                        u64x2 s2 = none;
+                        if (pending) {
+                            b = (b + 1 == nb) ? 0 : b + 1;
+                            s2 = *(reinterpret_cast<const u64x2 *>(a.slots + (size_t)b * kSlotsPerBucket) + sub);
+                        }
+                        const bool nx = (s2.x & ~3ull) == kq, ny = (s2.y & ~3ull) == kq;
+                        const bool h2 = pending && (nx || ny);
+                        const unsigned long long m2 = __ballot(h2 || (pending && s2.y == kEmptySlot));
+                        if (h2) {
+                            const uint32_t tags = (uint32_t)((nx ? s2.x : s2.y) & 3);
+                            atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+                        }
+                        if (((m2 >> (lane & 60)) & 0xF) != 0 || ++guard >= nb) pending = false;
+                    }
+                    moremask &= moremask - 1;
+                }
             }
         }
         __syncthreads();
@@ -332,26 +396,26 @@ static inline int grid_for(size_t n, int block, int cap) {
     return (int)(g > (size_t)cap ? (size_t)cap : g);
 }
 
-hipError_t launch_insert_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint32_t tag,
+hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t tag,
                               uint32_t *d_err, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, nbuckets, d_keys, n, tag, d_err);
+    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_keys, n, tag, d_err);
     return hipGetLastError();
 }
-hipError_t launch_insert_text(uint64_t *slots, uint32_t nbuckets, const char *d_text, size_t n_lines, int k,
+hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, size_t n_lines,
                               uint32_t tag, uint32_t *d_err, hipStream_t s) {
     if (n_lines == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, nbuckets, d_text, n_lines, k, tag, d_err);
+    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_text, n_lines, tag, d_err);
     return hipGetLastError();
 }
-hipError_t launch_erase_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s) {
+hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_erase_keys, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, slots, nbuckets, d_keys, n, d_hit);
+    hipLaunchKernelGGL(k_erase_keys, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, slots, g, d_keys, n, d_hit);
     return hipGetLastError();
 }
-hipError_t launch_lookup_keys(uint64_t *slots, uint32_t nbuckets, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s) {
+hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lookup_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slots, nbuckets, d_keys, n, d_tags);
+    hipLaunchKernelGGL(k_lookup_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slots, g, d_keys, n, d_tags);
     return hipGetLastError();
 }
 hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s) {

@@ -52,6 +52,10 @@ const char *hast_last_error(void);
 hast_status hast_ctx_create(int device_ordinal, int k, hast_ctx **out);
 void        hast_ctx_destroy(hast_ctx *);
 int         hast_ctx_k(const hast_ctx *);
+/* Tuning: length m of the minimizer that places a key's bucket (see hast_common.h).  Defaults to
+ * K for K<=17, else max(17, K-8).  May only be changed before hast_table_reserve. */
+int         hast_ctx_minimizer(const hast_ctx *);
+hast_status hast_ctx_set_minimizer(hast_ctx *, int m);
 int         hast_ctx_device(const hast_ctx *);
 hast_stream hast_ctx_stream(const hast_ctx *);
 hast_status hast_stream_sync(hast_ctx *, hast_stream);
@@ -65,10 +69,12 @@ hast_status hast_memset_d(hast_ctx *, void *d_dst, int byte, size_t bytes, hast_
 
 /* ---- the k-mer table: g_kmers[0], g_kmers[1] (classify.cpp:27) -----------------------------
  * One table, slot = (canonical_key << 2) | tags, tag bit h set <=> key in haplotype h's set.
- * Buckets of 8 slots = 64 B; home bucket from a multiplicative hash; overflow to the next bucket. */
+ * Buckets of 8 slots = 64 B; home bucket from the hash of the key's minimizer (consecutive windows of
+ * a read then mostly share a bucket line); overflow to the next bucket. */
 
 /* Size the table for up to `max_keys` distinct keys (both haplotypes together) at the given
- * load factor (0 => 0.5).  Discards any previous table. */
+ * load factor (0 => 0.25: 288 GB of HBM make a sparse table free, and full buckets rare).  Discards
+ * any previous table. */
 hast_status hast_table_reserve(hast_ctx *, uint64_t max_keys, double load_factor);
 
 /* load_kmers (classify.cpp:30-46) on an in-memory image of the file: '\n'-separated K-byte lines,

@@ -292,3 +292,42 @@ def test_classify_votes_only_and_linearity(built, oracle_lib):
     assert np.array_equal(np.bincount(ids, weights=votes[:, 0], minlength=n_bc).astype(np.uint32), whole[0])
     assert np.array_equal(np.bincount(ids, weights=votes[:, 1], minlength=n_bc).astype(np.uint32), whole[1])
     assert np.array_equal(np.bincount(ids, weights=(votes.sum(1) == 0), minlength=n_bc).astype(np.uint32), whole[2])
+
+
+@pytest.mark.parametrize("k,m", [(21, 1), (21, 5), (21, 11), (21, 16), (21, 20), (21, 21), (31, 9), (31, 31), (12, 7)])
+def test_minimizer_length_does_not_change_results(built, oracle_lib, k, m):
+    """Bucket placement by minimizer (any m in [1,K]) is invisible in the results: table sizes, lookups,
+    per-read votes and per-barcode counts stay bit-exact against the oracle; ragged reads included."""
+    rng = random.Random(k * 100 + m)
+    n_keys, n_bc = 6000, 41
+    p = make_params(k, 100, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    seqs = ragged_reads(rng, k, np.concatenate(keys), 3000, 160)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    ids = np.array([rng.randrange(n_bc) for _ in seqs], dtype=np.uint32)
+    with hast_amd.Context(k, minimizer=m) as ctx:
+        assert ctx.minimizer == m
+        ctx.table_reserve(2 * n_keys, 0.6)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        with pytest.raises(hast_amd.HastError):
+            hast_amd.lib().hast_ctx_set_minimizer(ctx._h, k)       # fixed once the table exists
+            raise hast_amd.HastError(1, hast_amd.lib().hast_last_error().decode())
+        assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+        probe = np.concatenate([keys[0][:500], keys[1][:500]])
+        assert (ctx.table_lookup(probe) != 0).all()
+        ctx.counts_resize(n_bc)
+        d_b, d_o, d_i = ctx.to_device(bases), ctx.to_device(off), ctx.to_device(ids)
+        d_v = ctx.alloc(len(seqs) * 8)
+        ctx.classify_device(d_b, bases.size, len(seqs), int(lens.max()), d_offsets=d_o, d_barcode_ids=d_i, d_votes=d_v)
+        ctx.sync()
+        got = ctx.counts_read(n_bc)
+        votes = ctx.to_host(d_v, (len(seqs), 2), np.uint32)
+    assert np.array_equal(votes, oracle_votes(oracle_lib, oc, bases, off))
+    exp = oracle_counts(oracle_lib, oc, bases, off, ids, n_bc)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    oracle_lib.ho_free(oc)

@@ -3,7 +3,8 @@
 // Gives the empirical ceiling next to the 8 TB/s spec peak, and a known-byte-count workload for
 // calibrating rocprofv3's FETCH_SIZE on this access pattern (MI355X_MICROARCH.md, HBM section).
 //
-//   hbm_randread <table_GB> <line_bytes 64|128> <unroll 1|2|4|8> [iters] [blocks]
+//   hbm_randread <table_GB> <line_bytes 64|128> <unroll 1|2|4|8> [iters] [blocks] [share]
+//   share = number of ADJACENT lane groups of one wave-instruction that read the same line (locality model)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,9 +22,9 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) {
 }
 
 template <int LINE, int U>
-__global__ void __launch_bounds__(256) k_rand(const u32x4 *tab, uint32_t nlines, uint32_t iters, uint32_t *sink) {
+__global__ void __launch_bounds__(256) k_rand(const u32x4 *tab, uint32_t nlines, uint32_t iters, uint32_t *sink, uint32_t share) {
     constexpr int G = LINE / 16;
-    const uint64_t gid = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) / G;
+    const uint64_t gid = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) / G / share;
     const uint32_t sub = threadIdx.x % G;
     u32x4 acc = {0, 0, 0, 0};
     for (uint32_t it = 0; it < iters; ++it) {
@@ -41,13 +42,13 @@ __global__ void __launch_bounds__(256) k_rand(const u32x4 *tab, uint32_t nlines,
 }
 
 template <int LINE, int U>
-double run(const u32x4 *tab, uint32_t nlines, uint32_t iters, int blocks, uint32_t *sink) {
+double run(const u32x4 *tab, uint32_t nlines, uint32_t iters, int blocks, uint32_t *sink, uint32_t share) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k_rand<LINE, U>), dim3(blocks), dim3(256), 0, 0, tab, nlines, 2u, sink);   // warm
+    hipLaunchKernelGGL((k_rand<LINE, U>), dim3(blocks), dim3(256), 0, 0, tab, nlines, 2u, sink, share);   // warm
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((k_rand<LINE, U>), dim3(blocks), dim3(256), 0, 0, tab, nlines, iters, sink);
+    hipLaunchKernelGGL((k_rand<LINE, U>), dim3(blocks), dim3(256), 0, 0, tab, nlines, iters, sink, share);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms = 0;
@@ -61,6 +62,7 @@ int main(int argc, char **argv) {
     int unroll = argc > 3 ? atoi(argv[3]) : 4;
     uint32_t iters = argc > 4 ? (uint32_t)atoi(argv[4]) : 256;
     int blocks = argc > 5 ? atoi(argv[5]) : 2048;
+    uint32_t share = argc > 6 ? (uint32_t)atoi(argv[6]) : 1;
     size_t bytes = (size_t)(gb * 1e9) / line * line;
     uint32_t nlines = (uint32_t)(bytes / line);
     u32x4 *tab;
@@ -70,12 +72,12 @@ int main(int argc, char **argv) {
     CK(hipMemset(tab, 0x5A, bytes));
     CK(hipDeviceSynchronize());
     double ms = 0;
-#define CASE(L, U) if (line == L && unroll == U) ms = run<L, U>(tab, nlines, iters, blocks, sink);
+#define CASE(L, U) if (line == L && unroll == U) ms = run<L, U>(tab, nlines, iters, blocks, sink, share);
     CASE(64, 1) CASE(64, 2) CASE(64, 4) CASE(64, 8) CASE(128, 1) CASE(128, 2) CASE(128, 4) CASE(128, 8)
     if (ms == 0) { fprintf(stderr, "unsupported line/unroll\n"); return 1; }
     double groups = (double)blocks * 256 / (line / 16);
     double lines = groups * iters * unroll;
-    printf("{\"table_gb\": %.2f, \"line\": %d, \"unroll\": %d, \"blocks\": %d, \"lines\": %.0f, \"bytes\": %.0f, \"ms\": %.3f, \"Glines_per_s\": %.2f, \"GB_per_s\": %.1f}\n",
-           gb, line, unroll, blocks, lines, lines * line, ms, lines / ms / 1e6, lines * line / ms / 1e6);
+    printf("{\"table_gb\": %.2f, \"line\": %d, \"unroll\": %d, \"blocks\": %d, \"share\": %u, \"lines\": %.0f, \"bytes\": %.0f, \"ms\": %.3f, \"Gprobes_per_s\": %.2f, \"Glines_per_s\": %.2f, \"GB_per_s\": %.1f}\n",
+           gb, line, unroll, blocks, share, lines / share, lines / share * line, ms, lines / ms / 1e6, lines / share / ms / 1e6, lines / share * line / ms / 1e6);
     return 0;
 }
