@@ -51,9 +51,10 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=16_000_000)
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--load-factor", type=float, default=0.25)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores of this process")
+    ap.add_argument("--minimizer", type=int, default=0, help="minimizer length for bucket placement (0 = library default)")
     ap.add_argument("--max-resident-gb", type=float, default=96.0, help="HBM budget for resident read batches")
     args = ap.parse_args()
 
@@ -82,7 +83,7 @@ def main():
     n_keys, n_bc, wl_desc = WORKLOADS[args.workload]
     K, L, R = args.k, args.read_len, args.batch_reads
     p = make_params(K, L, n_keys, n_bc)
-    ctx = hast_amd.Context(K, local_rank)
+    ctx = hast_amd.Context(K, local_rank, minimizer=args.minimizer or None)
     stream = torch.cuda.Stream(device=dev)
     hs = C.c_void_p(stream.cuda_stream)
 
@@ -177,7 +178,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": wl_desc, "k": K, "read_len": L, "keys_per_hap": n_keys, "barcodes": n_bc,
                        "batch_reads": R, "reads_total": world * args.steps * R, "table_gb": round(table_bytes / 1e9, 3),
-                       "load_factor": args.load_factor, "set_sizes": list(set_sizes), "sharding": "reads by index, tables replicated",
+                       "load_factor": args.load_factor, "minimizer": ctx.minimizer, "set_sizes": list(set_sizes), "sharding": "reads by index, tables replicated",
                        "collective": "1x all_reduce(sum,u32[%d]) + D2H in timed region" % (n_bc * 4) if world > 1 else "none (D2H of counters in timed region)",
                        "resident_batches": n_res},
             "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -493,11 +493,25 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
     a.mh_stride = read_len >= (uint32_t)c->m ? read_len - c->m + 1 : 0;
     a.w64 = (read_len + 31) / 32;
-    // reads per tile: as many as fit ~19.5 KB of LDS (8 workgroups per CU), at most 64
+    // Reads per tile: at most what fits ~19.5 KB of LDS (8 workgroups per CU) and at most 64; among the
+    // candidates take the one whose windows fill the waves' 64-window blocks best (a workgroup walks
+    // 4 waves x 2 blocks per iteration: 150-bp reads => 31 reads = 4030 windows = 63 of 64 block slots).
+    // The m-mer hash array is padded by W entries so window-min reads past a read's last window stay in bounds.
+    const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
     const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4;
-    uint32_t tr = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (size_t)19968 / per_read));
+    const size_t pad = (size_t)wlen * 4 + 64;
+    const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, ((size_t)19968 - pad) / per_read));
+    uint32_t tr = tr_max;
+    if (a.max_pos > 0) {
+        double best = -1;
+        for (uint32_t t = tr_max; t >= 1 && t + 8 > tr_max; --t) {
+            const uint64_t q = (uint64_t)t * a.max_pos, blocks = (q + 63) / 64, slots = (blocks + 7) / 8 * 8;
+            const double eff = (double)q / (double)(slots * 64);
+            if (eff > best + 1e-9) { best = eff; tr = t; }
+        }
+    }
     a.tile_reads = tr;
-    const size_t smem = per_read * tr;
+    const size_t smem = per_read * tr + pad;
     if (smem > (160u << 10)) return fail(HAST_ERR_INVALID, "read_len %u needs %zu B of LDS", read_len, smem);
     // __umulhi(q, magic) == q / d for every q the kernel forms (exact while q*d < 2^32)
     auto magic = [](uint64_t qmax, uint32_t d) -> uint32_t {
@@ -506,6 +520,7 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     };
     a.div_magic = magic((uint64_t)tr * a.max_pos + 1024, a.max_pos);
     a.div_mh = magic((uint64_t)tr * a.mh_stride + 1024, a.mh_stride);
+    a.div_hw = magic((uint64_t)tr * a.w64 * 2 + 1024, a.w64 * 2);
     const uint64_t n_tiles = (n_reads + tr - 1) / tr;
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
     HIP_TRY(launch_classify(a, grid, smem, s ? (hipStream_t)s : c->stream));

@@ -30,6 +30,7 @@ struct ClassifyArgs {
     uint32_t div_magic;          // floor(2^32/max_pos)+1 when exact over the tile's range, else 0
     uint32_t mh_stride;          // m-mer positions per read: read_len-m+1 (0 when read_len<m)
     uint32_t div_mh;             // same trick for mh_stride
+    uint32_t div_hw;             // same trick for 2*w64 (16-base half-words per read)
     int k;
     int m;                       // minimizer length
 };

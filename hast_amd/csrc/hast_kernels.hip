@@ -173,6 +173,9 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);   // quad_perm [J,J,J,J]
 }
 
+// WT  = number of m-mers per window (K-m+1) when known at compile time, 0 = runtime loop
+// FAST = all index divisions are exact multiply-high (host-checked); false = plain division
+template <int WT, bool FAST>
 __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
@@ -183,21 +186,22 @@ __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
     unsigned long long *s_off = s_vote + TR;                                               // [TR]
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
     uint32_t *s_flag = s_len + TR;                                                         // [TR]
-    uint32_t *s_mh = s_flag + TR;                                                          // [TR][MS]
+    uint32_t *s_mh = s_flag + TR;                                                          // [TR][MS] (+ W pad)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
+    const uint32_t wave = tid >> 6;
     const uint32_t sub = tid & 3;                // which 16 B of a bucket this lane loads
-    // lane -> window inside the wave's 64-window block, so that in round j quad g holds window 16j+g
-    const uint32_t wofs = (tid & ~63u) + 16 * sub + (lane >> 2);
+    // lane -> window inside a 64-window block, so that in round j quad g holds window 16j+g
+    const uint32_t wofs = 16 * sub + (lane >> 2);
     const int K = a.k, M = a.m;
-    const uint32_t W = (uint32_t)(K - M + 1);
+    const uint32_t W = WT ? (uint32_t)WT : (uint32_t)(K - M + 1);
     const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
     const uint32_t nb = a.nbuckets;
     const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
-    const u64x2 none = {kEmptySlot, kEmptySlot};
+    const u64x2 *tab = reinterpret_cast<const u64x2 *>(a.slots) + sub;     // this lane's 16 B of bucket 0
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t r0 = tile * TR;
@@ -219,7 +223,8 @@ __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
         // ---- A: pack ----------------------------------------------------------------------
         const uint32_t HW = a.w64 * 2;                                // 16-base half-words per read
         for (uint32_t t = tid; t < tra * HW; t += kThreads) {
-            const uint32_t r = t / HW, j = t - r * HW;
+            const uint32_t r = FAST ? __umulhi(t, a.div_hw) : (t / HW);
+            const uint32_t j = t - r * HW;
             const uint32_t len = s_len[r];
             if (16 * j >= len) continue;
             const uint32_t nbases = (len - 16 * j < 16) ? (len - 16 * j) : 16;
@@ -254,100 +259,113 @@ __global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
 
         // ---- M: m-mer hashes; reads with 'N' get length 0 (whole-read skip, classify.cpp:190-193) ----
         for (uint32_t t = tid; t < tra * MS; t += kThreads) {
-            const uint32_t r = a.div_mh ? __umulhi(t, a.div_mh) : (t / MS);
+            const uint32_t r = FAST ? __umulhi(t, a.div_mh) : (t / MS);
             const uint32_t q = t - r * MS;
-            uint32_t h = 0xFFFFFFFFu;
-            if (q + M <= s_len[r]) {
-                const uint64_t mm = window_bits(s_pack + (size_t)r * WS, q, mshift);
-                h = mmer_hash32(kmer_canon(mm, M));
-            }
-            s_mh[(size_t)r * MS + q] = h;
+            const uint64_t mm = window_bits(s_pack + (size_t)r * WS, q, mshift);
+            const uint32_t h = mmer_hash32(kmer_canon(mm, M));
+            s_mh[t] = (q + M <= s_len[r]) ? h : 0xFFFFFFFFu;
         }
         __syncthreads();
         if (tid < tra && s_flag[tid]) s_len[tid] = 0;
         __syncthreads();
 
-        // ---- B: probe ---------------------------------------------------------------------
+        // ---- B: probe.  Each wave walks 64-window blocks b = wave, wave+4, ... two at a time -------
         const uint32_t P = a.max_pos;                                 // windows per read (stride)
         const uint32_t Q = tra * P;
-        for (uint32_t qb = 0; qb < Q; qb += kThreads * kBlocks) {
+        const uint32_t nblk = (Q + 63) >> 6;
+        for (uint32_t b0 = wave; b0 < nblk; b0 += 4 * kBlocks) {
             uint32_t o_klo[kBlocks], o_khi[kBlocks], o_bkt[kBlocks], o_meta[kBlocks];   // this lane's own window
 #pragma unroll
             for (int u = 0; u < kBlocks; ++u) {
-                const uint32_t q = qb + u * kThreads + wofs;
-                uint32_t r = a.div_magic ? __umulhi(q, a.div_magic) : (q / P);
-                const uint32_t p = q - r * P;
-                bool ok = q < Q;
-                r = ok ? r : 0;
-                ok = ok && (p + K <= s_len[r]);
+                const uint32_t q = (b0 + 4 * u) * 64 + wofs;
+                uint32_t r = FAST ? __umulhi(q, a.div_magic) : (q / P);
+                const bool inq = q < Q;
+                r = inq ? r : 0;
+                const uint32_t p = inq ? q - r * P : 0;
+                const bool ok = inq && (p + K <= s_len[r]);
                 const uint64_t ck = kmer_canon(window_bits(s_pack + (size_t)r * WS, p, kshift), K);
-                const uint32_t *mh = s_mh + (size_t)r * MS + p;
+                const uint32_t *mh = s_mh + r * MS + p;
                 uint32_t mn = mh[0];
-                for (uint32_t j = 1; j < W; ++j) mn = min(mn, mh[j]);
+                if (WT) {
+#pragma unroll
+                    for (int j = 1; j < (WT ? WT : 1); ++j) mn = min(mn, mh[j]);
+                } else {
+                    for (uint32_t j = 1; j < W; ++j) mn = min(mn, mh[j]);
+                }
                 o_klo[u] = (uint32_t)(ck << 2);
                 o_khi[u] = (uint32_t)(ck >> 30);
-                o_bkt[u] = bucket_of_minhash(mn, nb);
+                o_bkt[u] = ok ? bucket_of_minhash(mn, nb) : 0;       // invalid windows read bucket 0 (harmless)
                 o_meta[u] = r | (ok ? 0x80000000u : 0u);
             }
             u64x2 sl[kBlocks][4];
 #pragma unroll
             for (int u = 0; u < kBlocks; ++u) {
-                const uint32_t bk[4] = {quad_bcast<0>(o_bkt[u]), quad_bcast<1>(o_bkt[u]), quad_bcast<2>(o_bkt[u]), quad_bcast<3>(o_bkt[u])};
-                const uint32_t mt[4] = {quad_bcast<0>(o_meta[u]), quad_bcast<1>(o_meta[u]), quad_bcast<2>(o_meta[u]), quad_bcast<3>(o_meta[u])};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u64x2 *bp = reinterpret_cast<const u64x2 *>(a.slots + (size_t)bk[j] * kSlotsPerBucket) + sub;
-                    sl[u][j] = ((int)mt[j] < 0) ? *bp : none;
-                }
+                sl[u][0] = tab[(size_t)quad_bcast<0>(o_bkt[u]) * 4];
+                sl[u][1] = tab[(size_t)quad_bcast<1>(o_bkt[u]) * 4];
+                sl[u][2] = tab[(size_t)quad_bcast<2>(o_bkt[u]) * 4];
+                sl[u][3] = tab[(size_t)quad_bcast<3>(o_bkt[u]) * 4];
             }
 #pragma unroll
             for (int u = 0; u < kBlocks; ++u) {
-                uint32_t moremask = 0;
                 // the window's key and read are re-broadcast here rather than kept live across the loads
                 const uint32_t kl[4] = {quad_bcast<0>(o_klo[u]), quad_bcast<1>(o_klo[u]), quad_bcast<2>(o_klo[u]), quad_bcast<3>(o_klo[u])};
                 const uint32_t kh[4] = {quad_bcast<0>(o_khi[u]), quad_bcast<1>(o_khi[u]), quad_bcast<2>(o_khi[u]), quad_bcast<3>(o_khi[u])};
                 const uint32_t mt[4] = {quad_bcast<0>(o_meta[u]), quad_bcast<1>(o_meta[u]), quad_bcast<2>(o_meta[u]), quad_bcast<3>(o_meta[u])};
+                uint32_t hitmask = 0, fullmask = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
-                    const bool mx = (sl[u][j].x & ~3ull) == kq, my = (sl[u][j].y & ~3ull) == kq;
                     const bool valid = (int)mt[j] < 0;
-                    const bool hit = valid && (mx || my);
-                    // bucket full <=> last slot taken <=> no lane of the quad sees an empty .y
-                    const unsigned long long m = __ballot(hit || sl[u][j].y == kEmptySlot);
-                    if (hit) {
-                        const uint32_t tags = (uint32_t)((mx ? sl[u][j].x : sl[u][j].y) & 3);
-                        atomicAdd(&s_vote[mt[j] & 0xFFFF],
-                                  (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
-                    }
-                    if (valid && ((m >> (lane & 60)) & 0xF) == 0) moremask |= 1u << j;
+                    const bool mx = (sl[u][j].x & ~3ull) == kq, my = (sl[u][j].y & ~3ull) == kq;
+                    if (valid && (mx || my)) hitmask |= 1u << j;
+                    // bucket full <=> its last slot (lane 3's .y) is taken, because slots fill in order
+                    if (valid && sl[u][j].y != kEmptySlot && sub == 3) fullmask |= 1u << j;
                 }
-                // chain walk for full buckets without a match (quad-uniform mask; rare)
-                while (__any(moremask != 0)) {
-                    const bool act = moremask != 0;
-                    const uint32_t j = act ? (uint32_t)__ffs(moremask) - 1 : 0;
-                    const int src = (int)((lane & 60) | j);
-                    const unsigned long long kq = ((unsigned long long)__shfl((int)o_khi[u], src) << 32) | (uint32_t)__shfl((int)o_klo[u], src);
-                    uint32_t b = (uint32_t)__shfl((int)o_bkt[u], src);
-                    const uint32_t rd = (uint32_t)__shfl((int)o_meta[u], src) & 0xFFFF;
-                    bool pending = act;
-                    uint32_t guard = 0;
-                    while (__any(pending)) {
-                        u64x2 s2 = none;
-                        if (pending) {
-                            b = (b + 1 == nb) ? 0 : b + 1;
-                            s2 = *(reinterpret_cast<const u64x2 *>(a.slots + (size_t)b * kSlotsPerBucket) + sub);
+                if (hitmask) {                                  // ~1 % of windows
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (hitmask & (1u << j)) {
+                            const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
+                            const uint32_t tags = (uint32_t)(((sl[u][j].x & ~3ull) == kq ? sl[u][j].x : sl[u][j].y) & 3);
+                            atomicAdd(&s_vote[mt[j] & 0xFFFF],
+                                      (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
                         }
-                        const bool nx = (s2.x & ~3ull) == kq, ny = (s2.y & ~3ull) == kq;
-                        const bool h2 = pending && (nx || ny);
-                        const unsigned long long m2 = __ballot(h2 || (pending && s2.y == kEmptySlot));
-                        if (h2) {
-                            const uint32_t tags = (uint32_t)((nx ? s2.x : s2.y) & 3);
-                            atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
-                        }
-                        if (((m2 >> (lane & 60)) & 0xF) != 0 || ++guard >= nb) pending = false;
+                }
+                if (__any(fullmask != 0)) {                     // some bucket of this block is full (rare at LF 0.25)
+                    // quad-uniform masks: a full bucket needs the chain walk unless some lane of the quad hit
+                    uint32_t moremask = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned long long f = __ballot((fullmask >> j) & 1), h = __ballot((hitmask >> j) & 1);
+                        const uint32_t sh = lane & 60;
+                        if (((f >> sh) & 0xF) != 0 && ((h >> sh) & 0xF) == 0) moremask |= 1u << j;
                     }
-                    moremask &= moremask - 1;
+                    while (__any(moremask != 0)) {
+                        const bool act = moremask != 0;
+                        const uint32_t j = act ? (uint32_t)__ffs(moremask) - 1 : 0;
+                        const int src = (int)((lane & 60) | j);
+                        const unsigned long long kq = ((unsigned long long)__shfl((int)o_khi[u], src) << 32) | (uint32_t)__shfl((int)o_klo[u], src);
+                        uint32_t b = (uint32_t)__shfl((int)o_bkt[u], src);
+                        const uint32_t rd = (uint32_t)__shfl((int)o_meta[u], src) & 0xFFFF;
+                        bool pending = act;
+                        uint32_t guard = 0;
+                        while (__any(pending)) {
+                            u64x2 s2 = {kEmptySlot, kEmptySlot};
+                            if (pending) {
+                                b = (b + 1 == nb) ? 0 : b + 1;
+                                s2 = tab[(size_t)b * 4];
+                            }
+                            const bool nx = (s2.x & ~3ull) == kq, ny = (s2.y & ~3ull) == kq;
+                            const bool h2 = pending && (nx || ny);
+                            const unsigned long long m2 = __ballot(h2 || (pending && s2.y == kEmptySlot));
+                            if (h2) {
+                                const uint32_t tags = (uint32_t)((nx ? s2.x : s2.y) & 3);
+                                atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+                            }
+                            if (((m2 >> (lane & 60)) & 0xF) != 0 || ++guard >= nb) pending = false;
+                        }
+                        moremask &= moremask - 1;
+                    }
                 }
             }
         }
@@ -422,15 +440,34 @@ hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long
     hipLaunchKernelGGL(k_count_tags, dim3(grid_for(nslots / 2, 256, 256 * 8)), dim3(256), 0, s, slots, nslots, d_out);
     return hipGetLastError();
 }
-hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
-    if (a.n_reads == 0) return hipSuccess;
+template <int WT, bool FAST>
+static hipError_t launch_classify_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<WT, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kThreads), smem, s, a);
+    hipLaunchKernelGGL((k_classify<WT, FAST>), dim3(grid), dim3(kThreads), smem, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+    if (a.n_reads == 0) return hipSuccess;
+    const int w = a.k - a.m + 1;
+    const bool fast = a.div_magic && a.div_mh && a.div_hw;
+    if (!fast) return launch_classify_t<0, false>(a, grid, smem, s);
+    switch (w) {
+    case 1: return launch_classify_t<1, true>(a, grid, smem, s);
+    case 2: return launch_classify_t<2, true>(a, grid, smem, s);
+    case 3: return launch_classify_t<3, true>(a, grid, smem, s);
+    case 4: return launch_classify_t<4, true>(a, grid, smem, s);
+    case 5: return launch_classify_t<5, true>(a, grid, smem, s);
+    case 6: return launch_classify_t<6, true>(a, grid, smem, s);
+    case 7: return launch_classify_t<7, true>(a, grid, smem, s);
+    case 8: return launch_classify_t<8, true>(a, grid, smem, s);
+    case 9: return launch_classify_t<9, true>(a, grid, smem, s);
+    default: return launch_classify_t<0, true>(a, grid, smem, s);
+    }
 }
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s) {
     if (n == 0) return hipSuccess;

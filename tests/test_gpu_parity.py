@@ -313,9 +313,7 @@ def test_minimizer_length_does_not_change_results(built, oracle_lib, k, m):
         ctx.table_reserve(2 * n_keys, 0.6)
         ctx.table_insert_keys(0, keys[0])
         ctx.table_insert_keys(1, keys[1])
-        with pytest.raises(hast_amd.HastError):
-            hast_amd.lib().hast_ctx_set_minimizer(ctx._h, k)       # fixed once the table exists
-            raise hast_amd.HastError(1, hast_amd.lib().hast_last_error().decode())
+        assert hast_amd.lib().hast_ctx_set_minimizer(ctx._h, k) != 0       # fixed once the table exists
         assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
         probe = np.concatenate([keys[0][:500], keys[1][:500]])
         assert (ctx.table_lookup(probe) != 0).all()
