@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=16_000_000)
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--load-factor", type=float, default=0.25)
+    ap.add_argument("--load-factor", type=float, default=0.2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores of this process")
     ap.add_argument("--minimizer", type=int, default=0, help="minimizer length for bucket placement (0 = library default)")

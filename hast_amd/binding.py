@@ -76,7 +76,7 @@ class HastError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhast.so")
+    return os.environ.get("HAST_LIB") or os.path.join(_HERE, "libhast.so")
 
 
 def classify_exe():

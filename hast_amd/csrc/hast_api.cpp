@@ -75,14 +75,15 @@ namespace {
 
 TableGeom geom(const hast_ctx *c) { return TableGeom{c->nbuckets, c->k, c->m}; }
 
-// default minimizer length: w = K-m+1 consecutive windows can share a bucket line; m stays >= 17 so that
-// the minimizer space (4^m/2) dwarfs human-scale key counts and buckets stay evenly loaded
+// default minimizer length: w = K-m+1 consecutive windows can share a bucket line; m stays >= 16 so that
+// the minimizer space (4^m/2 = 2.1 G) is well above human-scale key counts (4e8) and buckets stay evenly
+// loaded; measured sweep in DESIGN.md
 int default_minimizer(int k) {
     if (const char *e = getenv("HAST_MINIMIZER")) {
         int v = atoi(e);
         if (v >= 1 && v <= k) return v;
     }
-    return k <= 17 ? k : std::max(17, k - 8);
+    return k <= 16 ? k : std::max(16, k - 8);
 }
 
 hast_status use(hast_ctx *c) {
@@ -249,7 +250,7 @@ hast_status hast_memset_d(hast_ctx *c, void *d, int byte, size_t n, hast_stream 
 // ---------------------------------------------------------------------------------------------
 hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     if (hast_status st = use(c)) return st;
-    if (lf <= 0) lf = 0.25;
+    if (lf <= 0) lf = 0.2;
     if (lf > 0.9) return fail(HAST_ERR_INVALID, "load factor %.3f > 0.9", lf);
     double want = (double)(max_keys ? max_keys : 1) / lf / kSlotsPerBucket;
     uint64_t nb = (uint64_t)want + 1;

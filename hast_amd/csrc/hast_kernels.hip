@@ -149,7 +149,13 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 //               ({c0,c1} as a single u64 add, or neg++; classify.cpp:203-208).
 // ------------------------------------------------------------------------------------------
 constexpr int kThreads = 256;
-constexpr int kBlocks = 2;                    // 64-window blocks per wave in flight together
+#ifndef HAST_KBLOCKS
+#define HAST_KBLOCKS 2
+#endif
+#ifndef HAST_MINWAVES
+#define HAST_MINWAVES 1
+#endif
+constexpr int kBlocks = HAST_KBLOCKS;         // 64-window blocks per wave in flight together
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack4(uint32_t x) {
@@ -176,7 +182,7 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 // WT  = number of m-mers per window (K-m+1) when known at compile time, 0 = runtime loop
 // FAST = all index divisions are exact multiply-high (host-checked); false = plain division
 template <int WT, bool FAST>
-__global__ void __launch_bounds__(kThreads) k_classify(ClassifyArgs a) {
+__global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
     const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad

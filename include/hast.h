@@ -53,7 +53,7 @@ hast_status hast_ctx_create(int device_ordinal, int k, hast_ctx **out);
 void        hast_ctx_destroy(hast_ctx *);
 int         hast_ctx_k(const hast_ctx *);
 /* Tuning: length m of the minimizer that places a key's bucket (see hast_common.h).  Defaults to
- * K for K<=17, else max(17, K-8).  May only be changed before hast_table_reserve. */
+ * K for K<=16, else max(16, K-8).  May only be changed before hast_table_reserve. */
 int         hast_ctx_minimizer(const hast_ctx *);
 hast_status hast_ctx_set_minimizer(hast_ctx *, int m);
 int         hast_ctx_device(const hast_ctx *);
@@ -73,7 +73,7 @@ hast_status hast_memset_d(hast_ctx *, void *d_dst, int byte, size_t bytes, hast_
  * a read then mostly share a bucket line); overflow to the next bucket. */
 
 /* Size the table for up to `max_keys` distinct keys (both haplotypes together) at the given
- * load factor (0 => 0.25: 288 GB of HBM make a sparse table free, and full buckets rare).  Discards
+ * load factor (0 => 0.2: 288 GB of HBM make a sparse table free, and full buckets rare).  Discards
  * any previous table. */
 hast_status hast_table_reserve(hast_ctx *, uint64_t max_keys, double load_factor);
 
