@@ -51,6 +51,8 @@ ABI_SYMBOLS = {
     "hast_counts_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
     "hast_classify_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
     "hast_classify_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
+    "hast_batch_begin": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "hast_batch_submit": (C.c_int, [vp, C.c_size_t, C.c_uint32]),
     "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hast_get_hap": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
     "hast_canon_kmer": (C.c_uint64, [C.c_char_p, C.c_int]),

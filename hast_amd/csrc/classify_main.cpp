@@ -12,7 +12,9 @@
 //   * ragged k-mer line / read shorter than K: error + exit 3 (the reference assert-aborts,
 //     kmer.h:154,171);
 //   * K must be in [1,31] (the reference is correct up to 32 and silently wrong above).
-// Additive flags: --device N (GPU ordinal, default 0), --batch-reads N, --stats (timings on stderr).
+// Additive flags: --device N (GPU ordinal, default 0), --block-mb N (ingest block size), --batch-reads N
+// (approximate records per GPU batch, for tests), --initial-barcodes N, --stats (timings on stderr).
+// -t/--thread N is honoured as the number of host parser threads.
 #include <getopt.h>
 
 #include <algorithm>
@@ -28,6 +30,7 @@
 
 #include "../../include/hast.h"
 #include "fastq_reader.h"
+#include "ingest.h"
 
 namespace {
 
@@ -110,21 +113,6 @@ bool self_test() {
     return strcmp(buf, "AGCTA") == 0;
 }
 
-struct Barcodes {                                  // BarcodeCache keys (classify.cpp:51) -> dense ids
-    std::unordered_map<std::string, uint32_t> id;
-    std::vector<const std::string *> name;
-    uint32_t get(std::string_view bc) {
-        key_.assign(bc.data(), bc.size());
-        auto it = id.find(key_);
-        if (it != id.end()) return it->second;
-        uint32_t v = (uint32_t)name.size();
-        auto ins = id.emplace(key_, v);
-        name.push_back(&ins.first->first);
-        return v;
-    }
-    std::string key_;
-};
-
 struct Counts {                                    // host accumulators behind the device counters
     std::vector<uint64_t> c0, c1, neg;
     size_t device_cap = 0;
@@ -165,6 +153,7 @@ int main(int argc, char **argv) {
         {"adaptor_f", required_argument, NULL, 'f'}, {"adaptor_r", required_argument, NULL, 'q'},
         {"help", no_argument, NULL, 'h'},            {"device", required_argument, NULL, 1001},
         {"batch-reads", required_argument, NULL, 1002}, {"stats", no_argument, NULL, 1003},
+        {"block-mb", required_argument, NULL, 1004},    {"initial-barcodes", required_argument, NULL, 1005},
         {0, 0, 0, 0}};
     static char optstring[] = "p:m:l:r:t:w:u:f:q:h";             // classify.cpp:387
     std::string hap0, hap1;
@@ -172,7 +161,7 @@ int main(int argc, char **argv) {
     std::string r2("TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG");   // classify.cpp:313
     std::vector<std::string> read;
     int t_num = 8, device = 0;
-    size_t batch_reads = 1u << 20;
+    size_t batch_reads = 0, block_mb = 256, initial_barcodes = 1u << 20;
     bool stats = false;
     double w0 = 1.0, w1 = 1.0;
     for (;;) {
@@ -190,6 +179,8 @@ int main(int argc, char **argv) {
         case 1001: device = atoi(optarg); break;
         case 1002: batch_reads = (size_t)std::max(1L, atol(optarg)); break;
         case 1003: stats = true; break;
+        case 1004: block_mb = (size_t)std::max(1L, atol(optarg)); break;
+        case 1005: initial_barcodes = (size_t)std::max(1L, atol(optarg)); break;
         case 'h':
         default: print_usage(); return -1;
         }
@@ -264,76 +255,172 @@ int main(int argc, char **argv) {
     logtime();
 
     // ---- processFastq (classify.cpp:238-278) for each --read, in order ------------------------
-    Barcodes barcodes;
+    // reader thread -> blocks of raw bytes -> t_num workers index newlines and parse records in parallel
+    // -> pinned staging of the GPU library -> classify (asynchronous, double-buffered)
+    hast::WorkerPool pool(t_num);
+    hast::BarcodeDict dict;
+    std::vector<hast::BarcodeDict::Cache> caches(pool.size());
     Counts acc;
-    flush_counts(ctx, acc, 0, 1u << 20);
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> offsets;
-    std::vector<uint32_t> ids;
-    bases.reserve(batch_reads * 160);
-    offsets.reserve(batch_reads + 1);
-    ids.reserve(batch_reads);
-    uint32_t max_len = 0;
+    flush_counts(ctx, acc, 0, initial_barcodes);
+    const int T = pool.size();
+    // --batch-reads N (tests / small inputs): shrink the blocks so that a batch holds about N records
+    size_t block_bytes = block_mb << 20;
+    if (batch_reads) block_bytes = std::max<size_t>(4096, std::min(block_bytes, batch_reads * 320));
     uint64_t total_reads = 0, total_bases = 0;
-    auto submit = [&]() {
-        if (ids.empty()) return;
-        if (barcodes.name.size() > acc.device_cap)
-            flush_counts(ctx, acc, barcodes.name.size(), std::max(barcodes.name.size() * 2, acc.device_cap * 2));
-        offsets.push_back(bases.size());
-        CK(hast_classify_batch(ctx, bases.data(), offsets.data(), ids.data(), ids.size(), max_len), "classifying a batch");
-        bases.clear();
-        offsets.clear();
-        ids.clear();
-        max_len = 0;
-    };
+    std::vector<std::vector<uint32_t>> nl(T);          // per-worker newline positions of the current block
+    std::vector<uint32_t> allnl;
+    std::vector<uint64_t> part_bytes(T + 1);
+    std::vector<uint32_t> part_max(T), part_err(T);
     for (const auto &r : read) {
         fprintf(stderr, "__process read: %s\n", r.c_str());
-        hast::LineSource in;
-        if (!in.open(r)) die(2, ("cannot open " + r).c_str());
-        for (;;) {
-            bool eof;
-            std::string_view head = in.getline(eof);
-            if (eof) break;                                                       // :257
-            size_t bs, bn;
-            hast_parse_barcode(head.data(), head.size(), &bs, &bn);               // :189
-            const uint32_t id = barcodes.get(head.substr(bs, bn));
-            std::string_view seq = in.getline(eof);                               // :258
-            const bool has_n = memchr(seq.data(), 'N', seq.size()) != nullptr;
-            if (seq.size() < K && !has_n) {
-                fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s (record %llu)\n", K, r.c_str(),
-                        (unsigned long long)total_reads);
-                return 3;                                                         // reference: assert, kmer.h:171
+        hast::BlockSource src;
+        if (!src.open(r, block_bytes)) die(2, ("cannot open " + r).c_str());
+        std::vector<char> carry;                       // bytes of an incomplete record at the end of a block
+        uint64_t file_records = 0;
+        // parse `n_rec` complete records whose newline positions are in allnl (4 per record) from `data`
+        auto parse_records = [&](const char *data, size_t n_rec) {
+            if (n_rec == 0) return;
+            uint8_t *hb;
+            uint64_t *ho;
+            uint32_t *hi;
+            const size_t span = (size_t)allnl[4 * n_rec - 1] + 1;
+            CK(hast_batch_begin(ctx, span, n_rec, &hb, &ho, &hi), "staging a batch");
+            auto rec_range = [&](int t, size_t &lo, size_t &hi_) { lo = n_rec * (size_t)t / T; hi_ = n_rec * (size_t)(t + 1) / T; };
+            pool.run([&](int t) {                          // pass 1: bytes of bases per worker
+                size_t lo, hi_;
+                rec_range(t, lo, hi_);
+                uint64_t sum = 0;
+                uint32_t mx = 0;
+                for (size_t i = lo; i < hi_; i++) {
+                    uint32_t len = allnl[4 * i + 1] - allnl[4 * i] - 1;
+                    sum += len;
+                    mx = std::max(mx, len);
+                }
+                part_bytes[t + 1] = sum;
+                part_max[t] = mx;
+            });
+            part_bytes[0] = 0;
+            for (int t = 0; t < T; t++) part_bytes[t + 1] += part_bytes[t];
+            pool.run([&](int t) {                          // pass 2: barcode ids + bases into pinned staging
+                size_t lo, hi_;
+                rec_range(t, lo, hi_);
+                uint64_t off = part_bytes[t];
+                uint32_t err = 0;
+                for (size_t i = lo; i < hi_; i++) {
+                    const size_t h0 = i ? (size_t)allnl[4 * i - 1] + 1 : 0, h1 = allnl[4 * i], s1 = allnl[4 * i + 1];
+                    size_t bs, bn;
+                    hast_parse_barcode(data + h0, h1 - h0, &bs, &bn);                          // classify.cpp:189
+                    hi[i] = dict.get(std::string_view(data + h0 + bs, bn), caches[t]);
+                    const size_t len = s1 - h1 - 1;
+                    ho[i] = off;
+                    memcpy(hb + off, data + h1 + 1, len);
+                    if (len < K && !memchr(data + h1 + 1, 'N', len)) err = 1;                  // kmer.h:171
+                    off += len;
+                }
+                part_err[t] = err;
+            });
+            ho[n_rec] = part_bytes[T];
+            uint32_t mx = 0;
+            for (int t = 0; t < T; t++) {
+                mx = std::max(mx, part_max[t]);
+                if (part_err[t]) {
+                    fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, r.c_str());
+                    exit(3);                                                                   // reference: assert abort
+                }
             }
-            offsets.push_back(bases.size());
-            bases.insert(bases.end(), seq.begin(), seq.end());
-            ids.push_back(id);
-            max_len = std::max<uint32_t>(max_len, (uint32_t)seq.size());
-            total_reads++;
-            total_bases += seq.size();
-            in.getline(eof);                                                      // :267-268
-            in.getline(eof);
-            if (ids.size() >= batch_reads) submit();
+            if (dict.size() > acc.device_cap) flush_counts(ctx, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
+            CK(hast_batch_submit(ctx, n_rec, mx), "classifying a batch");
+            total_reads += n_rec;
+            total_bases += part_bytes[T];
+            file_records += n_rec;
+        };
+        for (;;) {
+            std::vector<char> blk = src.next();
+            const bool last = blk.empty();
+            constexpr size_t kPad = hast::BlockSource::kFrontPad;
+            // work area = carry (incomplete record of the previous block) + this block's data
+            const char *data;
+            size_t len;
+            if (last) {
+                data = carry.data();
+                len = carry.size();
+            } else if (carry.size() <= kPad) {
+                memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());   // in front, no block copy
+                data = blk.data() + kPad - carry.size();
+                len = blk.size() - kPad + carry.size();
+            } else {                                                                     // giant record: slow path
+                carry.insert(carry.end(), blk.begin() + kPad, blk.end());
+                data = carry.data();
+                len = carry.size();
+            }
+            if (len == 0) break;
+            if (len >= (1ull << 32)) die(3, "a single FASTQ record spans more than 4 GB");
+            // newline index, in parallel
+            pool.run([&](int t) {
+                auto &v = nl[t];
+                v.clear();
+                const size_t lo = len * (size_t)t / T, hi_ = len * (size_t)(t + 1) / T;
+                const char *p = data + lo, *e = data + hi_;
+                while (p < e && (p = (const char *)memchr(p, '\n', (size_t)(e - p)))) {
+                    v.push_back((uint32_t)(p - data));
+                    ++p;
+                }
+            });
+            size_t total_nl = 0;
+            std::vector<size_t> cum(T + 1, 0);
+            for (int t = 0; t < T; t++) cum[t + 1] = cum[t] + nl[t].size();
+            total_nl = cum[T];
+            allnl.resize(total_nl);
+            pool.run([&](int t) { if (!nl[t].empty()) memcpy(allnl.data() + cum[t], nl[t].data(), nl[t].size() * 4); });
+            const size_t n_rec = total_nl / 4;
+            parse_records(data, n_rec);
+            const size_t consumed = n_rec ? (size_t)allnl[4 * n_rec - 1] + 1 : 0;
+            if (last) {
+                // end of input: what is left holds < 4 newlines.  Reference framing (classify.cpp:257-268): the
+                // header must be newline-terminated; bases are whatever follows up to the next newline or EOF.
+                const char *p = data + consumed, *e = data + len;
+                const char *h_end = (const char *)memchr(p, '\n', (size_t)(e - p));
+                if (h_end) {
+                    const char *s0 = h_end + 1;
+                    const char *s_end = (const char *)memchr(s0, '\n', (size_t)(e - s0));
+                    if (!s_end) s_end = e;
+                    std::string tail(p, (size_t)(h_end - p));
+                    tail.push_back('\n');
+                    tail.append(s0, (size_t)(s_end - s0));
+                    tail.append("\n+\n\n");
+                    allnl.clear();
+                    for (size_t i = 0; i < tail.size(); i++)
+                        if (tail[i] == '\n') allnl.push_back((uint32_t)i);
+                    parse_records(tail.data(), 1);
+                }
+                break;
+            }
+            // keep the incomplete record for the next block
+            std::vector<char> rest(data + consumed, data + len);
+            carry.swap(rest);
+            src.recycle(std::move(blk));
         }
-        submit();
         logtime();
         fprintf(stderr, "__process read done__\n");
+        (void)file_records;
     }
-    flush_counts(ctx, acc, barcodes.name.size(), 1);
+    flush_counts(ctx, acc, dict.size(), 1);
     const double t_classified = now_s();
+    const std::vector<std::string_view> names = dict.names();
 
     // ---- printBarcodeInfos (classify.cpp:93-102): byte-wise sorted rows ------------------------
     fprintf(stderr, "__print result__\n");
-    std::vector<uint32_t> order(barcodes.name.size());
+    std::vector<uint32_t> order(names.size());
     for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return *barcodes.name[a] < *barcodes.name[b]; });
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
     std::string out;
     out.reserve(1 << 20);
     char num[64];
     for (uint32_t i : order) {
-        const std::string &bc = *barcodes.name[i];
+        const std::string_view bc = names[i];
         const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
         int hap = hast_get_hap(bc.data(), bc.size(), (uint32_t)c0, (uint32_t)c1, n_set[0], n_set[1], w0, w1);
-        out += bc;
+        out.append(bc.data(), bc.size());
         snprintf(num, sizeof(num), "\t%d\t%d\t%d\n", hap, (int)c0, (int)c1);      // `int` counters, classify.cpp:51
         out += num;
         if (out.size() > (1 << 20) - 256) {
@@ -348,7 +435,7 @@ int main(int argc, char **argv) {
         double dt = t_classified - t_loaded;
         fprintf(stderr, "__stats__ K=%zu set0=%llu set1=%llu reads=%llu bases=%llu barcodes=%zu load_s=%.3f classify_s=%.3f Mbp_per_s=%.1f\n",
                 K, (unsigned long long)n_set[0], (unsigned long long)n_set[1], (unsigned long long)total_reads,
-                (unsigned long long)total_bases, barcodes.name.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
+                (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
     fprintf(stderr, "__END__\n");
     hast_ctx_destroy(ctx);

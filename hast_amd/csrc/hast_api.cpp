@@ -558,31 +558,55 @@ static hast_status stage_reserve(hast_ctx *c, Staging &s, size_t nbytes, size_t 
     return HAST_OK;
 }
 
-hast_status hast_classify_batch(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids,
-                                size_t n_reads, uint32_t max_read_len) {
+hast_status hast_batch_begin(hast_ctx *c, size_t bases_capacity, size_t reads_capacity, uint8_t **bases,
+                             uint64_t **offsets, uint32_t **ids) {
     if (hast_status st = need_table(c, 0)) return st;
-    if (n_reads == 0) return HAST_OK;
     if (!bases || !offsets || !ids) return fail(HAST_ERR_INVALID, "null argument");
     if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters bound");
-    Staging &s = c->stage[c->batch_no++ & 1];
+    Staging &s = c->stage[c->batch_no & 1];
     if (s.in_flight) {
         HIP_TRY(hipEventSynchronize(s.done));
         s.in_flight = false;
     }
-    const size_t nbytes = offsets[n_reads] - offsets[0];
-    if (hast_status st = stage_reserve(c, s, nbytes, n_reads)) return st;
-    memcpy(s.h_bases, bases + offsets[0], nbytes);
-    const uint64_t o0 = offsets[0];
-    for (size_t i = 0; i <= n_reads; i++) s.h_off[i] = offsets[i] - o0;
-    memcpy(s.h_ids, ids, n_reads * sizeof(uint32_t));
-    HIP_TRY(hipMemcpyAsync(s.d_bases, s.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    if (hast_status st = stage_reserve(c, s, bases_capacity, reads_capacity)) return st;
+    *bases = s.h_bases;
+    *offsets = s.h_off;
+    *ids = s.h_ids;
+    return HAST_OK;
+}
+
+hast_status hast_batch_submit(hast_ctx *c, size_t n_reads, uint32_t max_read_len) {
+    if (hast_status st = need_table(c, 0)) return st;
+    Staging &s = c->stage[c->batch_no & 1];
+    if (n_reads == 0) return HAST_OK;
+    if (n_reads > s.cap_reads) return fail(HAST_ERR_INVALID, "batch of %zu reads exceeds the staged capacity", n_reads);
+    const size_t nbytes = s.h_off[n_reads];
+    if (nbytes > s.cap_bases || s.h_off[0] != 0) return fail(HAST_ERR_INVALID, "bad staged offsets");
+    c->batch_no++;
+    if (nbytes) HIP_TRY(hipMemcpyAsync(s.d_bases, s.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(s.d_ids, s.h_ids, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    if (hast_status st = hast_classify_device(c, s.d_bases, nbytes, s.d_off, max_read_len, s.d_ids, nullptr, n_reads, c->stream))
-        return st;
+    hast_status st = hast_classify_device(c, s.d_bases, nbytes ? nbytes : 1, s.d_off, max_read_len ? max_read_len : 1, s.d_ids,
+                                          nullptr, n_reads, c->stream);
     HIP_TRY(hipEventRecord(s.done, c->stream));
     s.in_flight = true;
-    return HAST_OK;
+    return st;
+}
+
+hast_status hast_classify_batch(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, const uint32_t *ids,
+                                size_t n_reads, uint32_t max_read_len) {
+    if (n_reads == 0) return c ? HAST_OK : fail(HAST_ERR_INVALID, "null context");
+    if (!bases || !offsets || !ids) return fail(HAST_ERR_INVALID, "null argument");
+    const size_t nbytes = offsets[n_reads] - offsets[0];
+    uint8_t *hb;
+    uint64_t *ho;
+    uint32_t *hi;
+    if (hast_status st = hast_batch_begin(c, nbytes, n_reads, &hb, &ho, &hi)) return st;
+    memcpy(hb, bases + offsets[0], nbytes);
+    const uint64_t o0 = offsets[0];
+    for (size_t i = 0; i <= n_reads; i++) ho[i] = offsets[i] - o0;
+    memcpy(hi, ids, n_reads * sizeof(uint32_t));
+    return hast_batch_submit(c, n_reads, max_read_len);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,294 @@
+// ingest.h -- multi-threaded FASTQ ingest + barcode dictionary for the classify CLI.
+//
+// Replaces the reference's single producer thread (01.classify_stlfr_reads/classify.cpp:257-273:
+// one getline at a time through a 303-byte gzstream buffer) while accepting exactly the same input
+// framing (classify.cpp:238-278):
+//   * gzip iff the file NAME ends in ".gz", otherwise raw bytes;
+//   * a record is four '\n'-separated lines counted from the start of the file; only line 1 (header)
+//     and line 2 (bases) are used; no '@'/'+' validation, no CR stripping;
+//   * input ends at the first header line that reaches EOF before a '\n' (that record is dropped);
+//     an unterminated line 2..4 of the last record is still accepted.
+// Design: a reader thread streams the file in large blocks (pread / gzread); T workers index the
+// newlines of a block in parallel, then parse whole records in parallel: barcode name -> dense id through a
+// sharded concurrent dictionary (parseName, classify.cpp:112-119), bases copied straight into the pinned
+// staging buffer the GPU library handed out (hast_batch_begin).  Record order inside a batch is preserved,
+// although nothing downstream depends on it (counts are sums).
+#pragma once
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include "../../include/hast.h"
+
+namespace hast {
+
+// ------------------------------------------------------------------------------------------------
+// minimal fork-join pool: run(fn) executes fn(worker_index) on every worker and waits
+// ------------------------------------------------------------------------------------------------
+class WorkerPool {
+  public:
+    explicit WorkerPool(int n) : n_(n < 1 ? 1 : n) {
+        for (int i = 1; i < n_; ++i) threads_.emplace_back([this, i] { loop(i); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    int size() const { return n_; }
+    void run(const std::function<void(int)> &fn) {
+        if (n_ == 1) { fn(0); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn;
+            pending_ = n_ - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+  private:
+    void loop(int idx) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)(idx);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    int n_;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    uint64_t gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+
+// ------------------------------------------------------------------------------------------------
+// barcode dictionary: BarcodeCache keys (classify.cpp:51) -> dense ids, concurrent
+// ------------------------------------------------------------------------------------------------
+class BarcodeDict {
+  public:
+    BarcodeDict() : shards_(kShards) {}
+    static uint64_t hash(std::string_view s) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (s.size() * 0xff51afd7ed558ccdull);
+        size_t i = 0;
+        for (; i + 8 <= s.size(); i += 8) {
+            uint64_t w;
+            memcpy(&w, s.data() + i, 8);
+            h = (h ^ w) * 0x9FB21C651E98DF25ull;
+            h ^= h >> 29;
+        }
+        uint64_t w = 0;
+        memcpy(&w, s.data() + i, s.size() - i);
+        h = (h ^ w) * 0x9FB21C651E98DF25ull;
+        return h ^ (h >> 32);
+    }
+    // thread-safe; `cache` is a per-thread front cache (hot barcodes such as 0_0_0 never touch a lock)
+    struct Cache {
+        struct E { uint64_t h = 0; const char *p = nullptr; uint32_t len = 0, id = 0; };
+        std::vector<E> e = std::vector<E>(4096);
+    };
+    uint32_t get(std::string_view bc, Cache &cache) {
+        const uint64_t h = hash(bc);
+        Cache::E &ce = cache.e[h & 4095];
+        if (ce.p && ce.h == h && ce.len == bc.size() && memcmp(ce.p, bc.data(), bc.size()) == 0) return ce.id;
+        Shard &s = shards_[(h >> 40) & (kShards - 1)];
+        std::lock_guard<std::mutex> g(s.mu);
+        if (s.slots.empty()) s.slots.resize(64);
+        size_t mask = s.slots.size() - 1, i = (size_t)h & mask;
+        for (;;) {
+            Slot &sl = s.slots[i];
+            if (!sl.p) break;
+            if (sl.h == h && sl.len == bc.size() && memcmp(sl.p, bc.data(), bc.size()) == 0) {
+                ce = {h, sl.p, sl.len, sl.id};
+                return sl.id;
+            }
+            i = (i + 1) & mask;
+        }
+        // insert
+        const char *p = s.store(bc);
+        const uint32_t id = next_id_.fetch_add(1, std::memory_order_relaxed);
+        s.slots[i] = {h, p, (uint32_t)bc.size(), id};
+        if (++s.n * 2 > s.slots.size()) s.grow();
+        ce = {h, p, (uint32_t)bc.size(), id};
+        return id;
+    }
+    size_t size() const { return next_id_.load(std::memory_order_relaxed); }
+    // names by id (call when no thread is inserting)
+    std::vector<std::string_view> names() const {
+        std::vector<std::string_view> out(size());
+        for (const Shard &s : shards_)
+            for (const Slot &sl : s.slots)
+                if (sl.p) out[sl.id] = std::string_view(sl.p, sl.len);
+        return out;
+    }
+
+  private:
+    static constexpr size_t kShards = 4096;
+    struct Slot { uint64_t h = 0; const char *p = nullptr; uint32_t len = 0, id = 0; };
+    struct Shard {
+        std::mutex mu;
+        std::vector<Slot> slots;
+        size_t n = 0;
+        std::vector<std::unique_ptr<char[]>> arena;
+        size_t arena_used = 0, arena_cap = 0;
+        const char *store(std::string_view s) {
+            if (arena_used + s.size() + 1 > arena_cap) {
+                arena_cap = std::max<size_t>(1 << 14, s.size() + 1);
+                arena.emplace_back(new char[arena_cap]);
+                arena_used = 0;
+            }
+            char *p = arena.back().get() + arena_used;
+            memcpy(p, s.data(), s.size());
+            p[s.size()] = 0;
+            arena_used += s.size() + 1;
+            return p;
+        }
+        void grow() {
+            std::vector<Slot> old;
+            old.swap(slots);
+            slots.resize(old.size() * 2);
+            size_t mask = slots.size() - 1;
+            for (const Slot &o : old)
+                if (o.p) {
+                    size_t i = (size_t)o.h & mask;
+                    while (slots[i].p) i = (i + 1) & mask;
+                    slots[i] = o;
+                }
+        }
+    };
+    std::vector<Shard> shards_;
+    std::atomic<uint32_t> next_id_{0};
+};
+
+// ------------------------------------------------------------------------------------------------
+// block source: raw or gz bytes in large blocks, produced by a background reader thread
+// ------------------------------------------------------------------------------------------------
+class BlockSource {
+  public:
+    ~BlockSource() { close(); }
+    bool open(const std::string &path, size_t block_bytes) {
+        close();
+        const size_t n = path.size();
+        gz_mode_ = n > 3 && path.compare(n - 3, 3, ".gz") == 0;               // classify.cpp:245-249
+        if (gz_mode_) {
+            gz_ = gzopen(path.c_str(), "rb");
+            if (!gz_) return false;
+            gzbuffer(gz_, 4u << 20);
+        } else {
+            fp_ = fopen(path.c_str(), "rb");
+            if (!fp_) return false;
+        }
+        block_bytes_ = block_bytes;
+        eof_ = false;
+        stop_ = false;
+        reader_ = std::thread([this] { pump(); });
+        return true;
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (reader_.joinable()) reader_.join();
+        if (gz_) gzclose(gz_);
+        if (fp_) fclose(fp_);
+        gz_ = nullptr;
+        fp_ = nullptr;
+        ready_.clear();
+        free_.clear();
+    }
+    // Every block starts with kFrontPad free bytes so that the tail of the previous block (an incomplete
+    // record) can be put in front of the new data without copying the block.
+    static constexpr size_t kFrontPad = 1u << 20;
+    // Next block: kFrontPad free bytes + raw data (empty vector at end of input).  Return a finished block
+    // with recycle().
+    std::vector<char> next() {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return !ready_.empty() || eof_; });
+        if (ready_.empty()) return {};
+        std::vector<char> b = std::move(ready_.front());
+        ready_.erase(ready_.begin());
+        cv_.notify_all();
+        return b;
+    }
+    void recycle(std::vector<char> &&b) {
+        std::lock_guard<std::mutex> g(mu_);
+        free_.push_back(std::move(b));
+    }
+
+  private:
+    void pump() {
+        for (;;) {
+            std::vector<char> b;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return stop_ || ready_.size() < 3; });
+                if (stop_) return;
+                if (!free_.empty()) {
+                    b = std::move(free_.back());
+                    free_.pop_back();
+                }
+            }
+            b.resize(kFrontPad + block_bytes_);
+            char *dst = b.data() + kFrontPad;
+            size_t got = 0;
+            while (got < block_bytes_) {
+                long r = gz_mode_ ? (long)gzread(gz_, dst + got, (unsigned)std::min<size_t>(block_bytes_ - got, 1u << 30))
+                                  : (long)fread(dst + got, 1, block_bytes_ - got, fp_);
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            b.resize(kFrontPad + got);
+            std::lock_guard<std::mutex> g(mu_);
+            if (got == 0) {
+                eof_ = true;
+                cv_.notify_all();
+                return;
+            }
+            ready_.push_back(std::move(b));
+            cv_.notify_all();
+        }
+    }
+    bool gz_mode_ = false;
+    gzFile gz_ = nullptr;
+    FILE *fp_ = nullptr;
+    size_t block_bytes_ = 0;
+    std::thread reader_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::vector<char>> ready_, free_;
+    bool eof_ = false, stop_ = false;
+};
+
+}  // namespace hast

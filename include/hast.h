@@ -137,6 +137,14 @@ hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t base
 hast_status hast_classify_batch(hast_ctx *, const uint8_t *bases, const uint64_t *offsets,
                                 const uint32_t *barcode_ids, size_t n_reads, uint32_t max_read_len);
 
+/* Zero-copy variant for host-fed callers (the CLI's parser threads write straight into pinned memory):
+ * hast_batch_begin hands out the pinned staging arrays of the next batch (waiting for that buffer's previous
+ * batch to finish on the GPU); the caller fills bases back to back, offsets[0..n_reads] and barcode ids, then
+ * hast_batch_submit enqueues H2D + classification.  Capacities: bases_capacity bytes, reads_capacity reads. */
+hast_status hast_batch_begin(hast_ctx *, size_t bases_capacity, size_t reads_capacity,
+                             uint8_t **bases, uint64_t **offsets, uint32_t **barcode_ids);
+hast_status hast_batch_submit(hast_ctx *, size_t n_reads, uint32_t max_read_len);
+
 /* ---- host-side pieces of the path (no device work) ---------------------------------------- */
 /* parseName (classify.cpp:112-119): barcode = head[last '#' + 1 .. last '/'). */
 void     hast_parse_barcode(const char *head, size_t len, size_t *start, size_t *n);

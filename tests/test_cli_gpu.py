@@ -34,7 +34,7 @@ def test_cli_small_batches_and_counter_growth(exe, golden_workdir):
     """Tiny batches force many launches and the counter-array regrowth path; output unchanged."""
     meta = load_case("rand_k21")["runs"]["pair_w104"]
     d = golden_workdir / "rand_k21"
-    res = subprocess.run([exe] + meta["argv"] + ["--batch-reads", "257", "--stats"], cwd=d,
+    res = subprocess.run([exe] + meta["argv"] + ["--batch-reads", "257", "--initial-barcodes", "3", "--stats"], cwd=d,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()
@@ -56,3 +56,55 @@ def test_cli_usage_and_errors(exe, golden_workdir, tmp_path):
     r = subprocess.run([exe, "--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", str(short)], cwd=d,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 3                           # the reference aborts (kmer.h:171)
+
+
+def _write_case(tmp_path, n_records, seed, gz):
+    """A FASTQ the oracle and the CLI both read: ragged lengths, odd headers, N reads, last line unterminated."""
+    import gzip
+    import random
+    import numpy as np
+    from hast_amd.binding import make_params
+    rng = random.Random(seed)
+    k, n_keys = 21, 4000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    tostr = lambda key: "".join("ACTG"[(int(key) >> (2 * (k - 1 - j))) & 3] for j in range(k))
+    for h in (0, 1):
+        (tmp_path / ("hap%d.mer" % h)).write_text("".join(tostr(x) + "\n" for x in keys[h]))
+    allk = np.concatenate(keys)
+    recs = []
+    for i in range(n_records):
+        L = rng.choice([k, 30, 100, 100, 100, 150, rng.randint(k, 400)])
+        s = [rng.choice("ACGT") for _ in range(L)]
+        for _ in range(rng.randint(0, 2)):
+            o = rng.randint(0, L - k)
+            s[o:o + k] = tostr(rng.choice(allk))
+        if rng.random() < 0.02:
+            s[rng.randrange(L)] = "N"
+        bc = "0_0_0" if rng.random() < 0.15 else "%d_%d_%d" % (rng.randint(1, 40), rng.randint(1, 40), rng.randint(1, 3))
+        head = "@R%07d#%s/%d\tx%d" % (i, bc, 1 + (i & 1), i) if rng.random() < 0.9 else "@odd%d/%s#%s" % (i, "y" * rng.randint(0, 5), bc)
+        recs.append("%s\n%s\n+\n%s\n" % (head, "".join(s), "#@+\t"[0:1] * L))
+    text = "".join(recs)[:-1]                                   # last quality line unterminated
+    path = tmp_path / ("reads.fq.gz" if gz else "reads.fq")
+    if gz:
+        with gzip.open(path, "wb", compresslevel=1) as f:
+            f.write(text.encode())
+    else:
+        path.write_text(text)
+    return path
+
+
+@pytest.mark.parametrize("gz,threads,batch", [(False, 1, 0), (False, 7, 900), (True, 4, 2500), (False, 16, 64)])
+def test_cli_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path, gz, threads, batch):
+    """Multi-threaded block ingest (carry across blocks, tail record, sharded barcode dictionary, counter
+    regrowth) against the oracle's line-by-line reader on the same file."""
+    path = _write_case(tmp_path, 30000, seed=threads * 10 + batch, gz=gz)
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", path.name, "--read", path.name, "--weight0", "1.04"]
+    ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args, cwd=tmp_path, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert ref.returncode == 0, ref.stderr.decode()[-500:]
+    extra = ["-t", str(threads), "--initial-barcodes", "16"] + (["--batch-reads", str(batch)] if batch else [])
+    got = subprocess.run([exe] + args + extra, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert got.returncode == 0, got.stderr.decode()[-2000:]
+    assert got.stdout == ref.stdout
+    assert len(got.stdout.splitlines()) > 1000
