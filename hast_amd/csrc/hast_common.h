@@ -106,10 +106,8 @@ HAST_HD uint32_t synth_barcode(const SynthParams &p, uint64_t read) {
 // One read: uniform random ACGT, then n in {0..3} planted parental k-mers (80 % from the
 // barcode's true haplotype = id&1, random strand, random offset), then with p = 1/200 one 'N'.
 // Writes read_len ASCII bytes.
-HAST_HD void synth_read(const SynthParams &p, uint64_t read, uint8_t *out, uint32_t *barcode_out) {
+HAST_HD void synth_read_bc(const SynthParams &p, uint64_t read, uint32_t bc, uint8_t *out) {
     const uint32_t L = p.read_len, K = p.k;
-    const uint32_t bc = synth_barcode(p, read);
-    *barcode_out = bc;
     for (uint32_t j0 = 0; j0 < L; j0 += 32) {
         uint64_t w = synth_rand(p.seed_r, read, j0 >> 5);
         uint32_t n = (L - j0 < 32) ? (L - j0) : 32;
@@ -130,6 +128,11 @@ HAST_HD void synth_read(const SynthParams &p, uint64_t read, uint8_t *out, uint3
     }
     uint64_t w = synth_rand(p.seed_r, read, 2000);
     if (w % 200 == 0) out[(uint32_t)(w >> 16) % L] = 'N';
+}
+HAST_HD void synth_read(const SynthParams &p, uint64_t read, uint8_t *out, uint32_t *barcode_out) {
+    const uint32_t bc = synth_barcode(p, read);
+    *barcode_out = bc;
+    synth_read_bc(p, read, bc, out);
 }
 
 }  // namespace hast
