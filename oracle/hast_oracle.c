@@ -692,3 +692,216 @@ int ho_classify_ids(const ho_classifier *c, const uint8_t *bases, const uint64_t
     free(jobs);
     return 0;
 }
+
+/* ==========================================================================================
+ * Secondary oracle: stage-03 per-read classifier (03.mkoutput_by_fabulous2.0/src_main/classify.cpp,
+ * cited s03:N).  Strings, not 2-bit codes -- restated as such.
+ * ======================================================================================== */
+typedef struct {
+    char *arena;      /* n strings of k bytes back to back */
+    size_t n, cap;
+    uint32_t *index;  /* open addressing: idx+1 */
+    size_t icap;
+} strset;
+
+struct ho_s03 {
+    int k;
+    strset set[2];
+    uint64_t lines[2];
+    unsigned char oppo[256]; /* g_oppo s03:24-36; absent keys default-construct to '\0' (std::map::operator[]) */
+};
+
+static int strset_find_or_add(strset *s, const char *key, int k, int add) {
+    if (s->icap == 0) {
+        s->icap = 1 << 16;
+        s->index = (uint32_t *)calloc(s->icap, sizeof(uint32_t));
+    }
+    size_t i = hash_bytes(key, (size_t)k) & (s->icap - 1);
+    while (s->index[i]) {
+        if (memcmp(s->arena + (size_t)(s->index[i] - 1) * (size_t)k, key, (size_t)k) == 0) return 1;
+        i = (i + 1) & (s->icap - 1);
+    }
+    if (!add) return 0;
+    if (s->n == s->cap) {
+        s->cap = s->cap ? s->cap * 2 : 4096;
+        s->arena = (char *)realloc(s->arena, s->cap * (size_t)k);
+    }
+    memcpy(s->arena + s->n * (size_t)k, key, (size_t)k);
+    s->n++;
+    s->index[i] = (uint32_t)s->n;
+    if (s->n * 2 > s->icap) {
+        size_t ncap = s->icap * 2;
+        uint32_t *ni = (uint32_t *)calloc(ncap, sizeof(uint32_t));
+        for (size_t e = 0; e < s->n; e++) {
+            size_t j = hash_bytes(s->arena + e * (size_t)k, (size_t)k) & (ncap - 1);
+            while (ni[j]) j = (j + 1) & (ncap - 1);
+            ni[j] = (uint32_t)(e + 1);
+        }
+        free(s->index);
+        s->index = ni;
+        s->icap = ncap;
+    }
+    return 0;
+}
+
+ho_s03 *ho_s03_new(void) {
+    ho_s03 *c = (ho_s03 *)calloc(1, sizeof(*c));
+    const char *from = "aAgGcCtTnN", *to = "TTCCGGAANN"; /* s03:26-35 */
+    for (int i = 0; from[i]; i++) c->oppo[(unsigned char)from[i]] = (unsigned char)to[i];
+    return c;
+}
+void ho_s03_free(ho_s03 *c) {
+    if (!c) return;
+    for (int h = 0; h < 2; h++) {
+        free(c->set[h].arena);
+        free(c->set[h].index);
+    }
+    free(c);
+}
+int ho_s03_k(const ho_s03 *c) { return c->k; }
+uint64_t ho_s03_lines(const ho_s03 *c, int hap) { return c->lines[hap & 1]; }
+
+static void s03_insert_line(ho_s03 *c, int hap, const char *line, size_t len) {
+    /* s03:59-60 / 64-65: insert(line); insert(reverse_complement(line)) -- strings of the LINE's length.
+     * Only lines of exactly K bytes can ever match a K-byte window, so others are counted but not stored. */
+    if ((int)len != c->k) return;
+    char rc[64];
+    for (size_t i = 0; i < len; i++) rc[len - i - 1] = (char)c->oppo[(unsigned char)line[i]]; /* s03:37-42 */
+    strset_find_or_add(&c->set[hap], line, c->k, 1);
+    strset_find_or_add(&c->set[hap], rc, c->k, 1);
+}
+
+int ho_s03_load_text(ho_s03 *c, const char *text, size_t nbytes, int hap) { /* s03:51-70 */
+    size_t pos = 0;
+    uint64_t total = 0;
+    if (hap == 0) {
+        const char *nl = (const char *)memchr(text, '\n', nbytes);
+        size_t l = nl ? (size_t)(nl - text) : nbytes;
+        if (l < 1 || l > 63) return -2;
+        c->k = (int)l; /* s03:58 */
+        s03_insert_line(c, hap, text, l);
+        total++;
+        pos = nl ? l + 1 : nbytes;
+    }
+    while (pos < nbytes) {
+        const char *nl = (const char *)memchr(text + pos, '\n', nbytes - pos);
+        if (!nl) break; /* s03:63 eof() => dropped */
+        s03_insert_line(c, hap, text + pos, (size_t)(nl - (text + pos)));
+        total++;
+        pos = (size_t)(nl - text) + 1;
+    }
+    c->lines[hap] = total; /* s03:68 */
+    return 0;
+}
+
+int ho_s03_load_file(ho_s03 *c, const char *path, int hap) {
+    size_t n = 0;
+    char *buf = slurp(path, &n);
+    if (!buf) return -1;
+    int rc = ho_s03_load_text(c, buf, n, hap);
+    free(buf);
+    return rc;
+}
+
+void ho_s03_read_hits(const ho_s03 *c, const char *seq, size_t slen, uint32_t *h0, uint32_t *h1) { /* s03:209-214 */
+    *h0 = *h1 = 0;
+    if ((long)slen - c->k + 1 <= 0) return;
+    for (size_t i = 0; i + (size_t)c->k <= slen; i++) {
+        *h0 += (uint32_t)strset_find_or_add((strset *)&c->set[0], seq + i, c->k, 0);
+        *h1 += (uint32_t)strset_find_or_add((strset *)&c->set[1], seq + i, c->k, 0);
+    }
+}
+
+int ho_s03_format_row(const ho_s03 *c, const char *name, size_t nlen, uint32_t h0, uint32_t h1, char *out) {
+    /* s03:215-216 then s03:104-135 */
+    double hc[2] = {(double)h0, (double)h1};
+    for (int j = 0; j < 2; j++) hc[j] /= (double)(int)c->lines[j]; /* total_kmers is int (s03:50) */
+    double readHapCount = 0, secondBest = 0;
+    int readHap = -1;
+    for (int i = 0; i < 2; i++) {
+        if (hc[i] > 0 && hc[i] < readHapCount && hc[i] > secondBest) secondBest = hc[i];
+        if (hc[i] > 0 && hc[i] > readHapCount) {
+            readHap = i;
+            secondBest = readHapCount;
+            readHapCount = hc[i];
+        }
+    }
+    memcpy(out, name, nlen);
+    char *p = out + nlen;
+    if (secondBest == 0 && readHapCount != 0) return (int)nlen + sprintf(p, "\thaplotype%d\t%0.6f\n", readHap, readHapCount);
+    if (readHapCount == 0 && secondBest == 0) return (int)nlen + sprintf(p, "\tambiguous\t0.0\n");
+    if (readHapCount / secondBest > 1) return (int)nlen + sprintf(p, "\thaplotype%d\t%0.6f\n", readHap, readHapCount);
+    return (int)nlen + sprintf(p, "\tambiguous\t%0.6f\n", readHapCount);
+}
+
+static void s03_emit(const ho_s03 *c, const char *head, size_t hlen, const char *seq, size_t slen, FILE *out) {
+    uint32_t h0, h1;
+    ho_s03_read_hits(c, seq, slen, &h0, &h1);
+    char *row = (char *)malloc(hlen + 96);
+    /* name = head.substr(1) (s03:207); an empty header would throw in the reference */
+    int n = ho_s03_format_row(c, hlen ? head + 1 : head, hlen ? hlen - 1 : 0, h0, h1, row);
+    fwrite(row, 1, (size_t)n, out);
+    free(row);
+}
+
+int ho_s03_process_file(const ho_s03 *c, const char *path, int format, FILE *out) {
+    lreader r;
+    memset(&r, 0, sizeof(r));
+    size_t plen = strlen(path);
+    if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0) { /* s03:235-242 */
+        r.gz = gzopen(path, "rb");
+        if (!r.gz) return -1;
+    } else {
+        r.fp = fopen(path, "rb");
+        if (!r.fp) return -1;
+    }
+    r.cap = 1 << 20;
+    r.buf = (char *)malloc(r.cap);
+    char *head = NULL, *seq = NULL;
+    size_t hcap = 0, hlen = 0, scap = 0, slen = 0;
+    int rc = 0;
+    if (format == 1) { /* processFastq s03:248-270: ids from 0, one record = 4 getlines */
+        for (;;) {
+            size_t n, sn, tn;
+            int eof;
+            const char *h = lr_getline(&r, &n, &eof);
+            if (eof) break;
+            if (n && h[0] == '>') { rc = -7; break; } /* s03:256-259 */
+            if (n + 1 > hcap) { hcap = (n + 1) * 2; head = (char *)realloc(head, hcap); }
+            memcpy(head, h, n);
+            const char *s = lr_getline(&r, &sn, &eof);
+            s03_emit(c, head, n, s, sn, out);
+            lr_getline(&r, &tn, &eof);
+            lr_getline(&r, &tn, &eof);
+        }
+    } else { /* processFasta s03:272-302: multi-line sequences, ids from 1, empty lines skipped */
+        long long id = 0;
+        for (;;) {
+            size_t n;
+            int eof;
+            const char *t = lr_getline(&r, &n, &eof);
+            if (eof) break; /* s03:279: a last line without '\n' is dropped */
+            if (n == 0) continue;
+            if (t[0] == '@' || t[0] == '+') { rc = -7; break; }
+            if (t[0] == '>') {
+                if (id > 0) s03_emit(c, head, hlen, seq ? seq : "", slen, out);
+                if (n + 1 > hcap) { hcap = (n + 1) * 2; head = (char *)realloc(head, hcap); }
+                memcpy(head, t, n);
+                hlen = n;
+                slen = 0;
+                id++;
+            } else {
+                if (slen + n + 1 > scap) { scap = (slen + n + 1) * 2; seq = (char *)realloc(seq, scap); }
+                memcpy(seq + slen, t, n);
+                slen += n;
+            }
+        }
+        if (rc == 0) s03_emit(c, head ? head : "", hlen, seq ? seq : "", slen, out); /* s03:297 unconditional submit */
+    }
+    free(head);
+    free(seq);
+    free(r.buf);
+    if (r.gz) gzclose(r.gz);
+    if (r.fp) fclose(r.fp);
+    return rc;
+}

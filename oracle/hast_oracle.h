@@ -86,6 +86,25 @@ int      ho_classify_ids(const ho_classifier *, const uint8_t *bases, const uint
                          const uint32_t *barcode_ids, size_t n_reads,
                          uint32_t *c0, uint32_t *c1, uint32_t *neg, uint32_t *seen, int threads);
 
+/* ---- secondary oracle: the per-read classifier of stage 03 (BASELINE config 5) ------------------
+ * Restatement of /root/reference/03.mkoutput_by_fabulous2.0/src_main/classify.cpp (cited s03:N):
+ * k-mers are raw case-sensitive STRINGS; each set holds every line and its reverse complement
+ * (s03:59-60,64-65, complement map s03:25-36, unknown bytes map to '\0'); every window of a read is looked
+ * up as a substring (s03:209-214), no N handling at all; density = hits / line count (s03:68,216). */
+typedef struct ho_s03 ho_s03;
+ho_s03  *ho_s03_new(void);
+void     ho_s03_free(ho_s03 *);
+int      ho_s03_load_text(ho_s03 *, const char *text, size_t nbytes, int hap);   /* s03:51-70 load_kmers    */
+int      ho_s03_load_file(ho_s03 *, const char *path, int hap);
+int      ho_s03_k(const ho_s03 *);
+uint64_t ho_s03_lines(const ho_s03 *, int hap);                                  /* total_kmers[hap]        */
+/* s03:203-214: integer hit counts of one read (the parity quantity; densities are host-side doubles) */
+void     ho_s03_read_hits(const ho_s03 *, const char *seq, size_t slen, uint32_t *h0, uint32_t *h1);
+/* s03:104-135 PrintOutput row for one read: writes "name\tlabel\tvalue\n" into out (>= nlen+64 bytes) */
+int      ho_s03_format_row(const ho_s03 *, const char *name, size_t nlen, uint32_t h0, uint32_t h1, char *out);
+/* s03:248-302 processFastq / processFasta into `out` (rows ordered by read id). format: 0 fasta, 1 fastq */
+int      ho_s03_process_file(const ho_s03 *, const char *path, int format, FILE *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ def _make(target_dir, *targets):
 def oracle_dir():
     """oracle/ with liboracle.so + oracle_classify built (test infrastructure)."""
     d = os.path.join(ROOT, "oracle")
-    _make(d, "liboracle.so", "oracle_classify")
+    _make(d, "liboracle.so", "oracle_classify", "oracle_classify_s03")
     return d
 
 
@@ -37,14 +37,16 @@ def oracle_lib(oracle_dir):
     return oracle_binding.load(os.path.join(oracle_dir, "liboracle.so"))
 
 
-def golden_cases():
+def golden_cases(program=None):
+    """(case, run) pairs; program: None = all, "s01" = stage-01 classify runs, "s03" = per-read classifier runs"""
     out = []
     for name in sorted(os.listdir(GOLDEN)):
         cj = os.path.join(GOLDEN, name, "case.json")
         if os.path.exists(cj):
             meta = json.load(open(cj))
             for run in sorted(meta["runs"]):
-                out.append((name, run))
+                if program is None or meta["runs"][run].get("program", "s01") == program:
+                    out.append((name, run))
     return out
 
 
@@ -59,7 +61,7 @@ def golden_workdir(tmp_path_factory):
             continue
         dst = base / name
         shutil.copytree(src, dst)
-        for fn in ("hap0.mer", "hap1.mer"):
+        for fn in ("hap0.mer", "hap1.mer", "reads.fa"):
             gzp = dst / (fn + ".gz")
             if gzp.exists():
                 with gzip.open(gzp, "rb") as f, open(dst / fn, "wb") as g:

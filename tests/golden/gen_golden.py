@@ -201,6 +201,55 @@ def random_case(name, k, n_keys, n_pairs, n_barcodes, seed, read_len=100, extra_
             os.remove(p)
 
 
+def case_s03(name, k, n_keys, seed, max_len):
+    """Per-read classifier of stage 03 (config 5 analogue): FASTA (multi-line) and FASTQ, long reads."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "classify_s03")
+    rng = random.Random(seed)
+    keys = [[rand_seq(rng, k) for _ in range(n_keys)] for _ in range(2)]
+    keys[1][:3] = [rc(s) for s in keys[0][:3]]                    # shared between the sets (via reverse complement)
+    keys[0] += keys[0][:4]                                        # duplicate lines count in the denominator
+    reads = []
+    for i in range(40):
+        L = rng.choice([k - 1, k, 50, 300, 2000, max_len]) if i > 5 else max_len
+        s = list(rand_seq(rng, L))
+        favoured = rng.randint(0, 1)
+        for _ in range(rng.randint(0, 12)):
+            if L < k:
+                break
+            h = favoured if rng.random() < 0.7 else 1 - favoured
+            km = rng.choice(keys[h])
+            km = rc(km) if rng.random() < 0.5 else km
+            o = rng.randint(0, L - k)
+            s[o:o + k] = list(km)
+        for _ in range(rng.randint(0, 3)):
+            if L:
+                s[rng.randrange(L)] = rng.choice("NnacgtR")        # windows over these bytes simply miss
+        reads.append(("read%d some text/%d" % (i, i), "".join(s)))
+    fa = "".join(">%s\n%s\n\n" % (h, "\n".join(q[j:j + 70] for j in range(0, len(q), 70))) for h, q in reads)
+    fqs = "".join("@%s\n%s\n+\n%s\n" % (h, q, "I" * len(q)) for h, q in reads if len(q) >= 1)
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    write(os.path.join(d, "hap0.mer"), "\n".join(keys[0]) + "\n")
+    write(os.path.join(d, "hap1.mer"), "\n".join(keys[1]) + "\n" + "ACGT")   # unterminated tail dropped
+    write(os.path.join(d, "reads.fa"), fa)
+    write(os.path.join(d, "reads.fq.gz"), fqs, gz=True)
+    meta = {"runs": {}}
+    for rn, argv in {"fasta": ["--hap", "hap0.mer", "--hap", "hap1.mer", "--read", "reads.fa", "--thread", "3"],
+                     "fastq_gz": ["--hap", "hap0.mer", "--hap", "hap1.mer", "--read", "reads.fq.gz", "--format", "fastq",
+                                  "--read", "reads.fq.gz"]}.items():
+        out = subprocess.run([ref] + argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        write(os.path.join(d, "expected.%s.tsv" % rn), out.stdout.decode())
+        meta["runs"][rn] = {"argv": argv, "expected": "expected.%s.tsv" % rn, "program": "s03"}
+    with open(os.path.join(d, "case.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    for fn in ("hap0.mer", "hap1.mer", "reads.fa"):
+        pth = os.path.join(d, fn)
+        write(pth + ".gz", open(pth).read(), gz=True)
+        os.remove(pth)
+    print("wrote", name)
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
@@ -209,6 +258,8 @@ def main():
     random_case("rand_k31", 31, 1500, 600, 40, seed=31, extra_runs=False)
     random_case("rand_k11", 11, 2000, 600, 40, seed=11, read_len=80, extra_runs=False)
     random_case("rand_k32", 32, 500, 200, 20, seed=32, read_len=120, extra_runs=False)
+    case_s03("s03_k21", 21, 300, seed=521, max_len=20000)
+    case_s03("s03_k31", 31, 300, seed=531, max_len=9000)
 
 
 if __name__ == "__main__":

@@ -72,11 +72,14 @@ def test_get_hap(oracle_lib):
 def test_oracle_matches_reference_golden(oracle_dir, golden_workdir, case, run):
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case
-    res = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + meta["argv"], cwd=d,
+    s03 = meta.get("program") == "s03"
+    res = subprocess.run([os.path.join(oracle_dir, "oracle_classify_s03" if s03 else "oracle_classify")] + meta["argv"], cwd=d,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert res.returncode == 0, res.stderr.decode()[-1000:]
     expected = open(d / meta["expected"], "rb").read()
     assert res.stdout == expected
+    if s03:
+        return
     # set-size / adaptor-erase log lines agree with the reference's (classify.cpp:45,321-336)
     mine = [l for l in res.stderr.decode().splitlines() if l.startswith("Recorded") or "erase a adaptor" in l]
     assert mine == meta["ref_log"]
@@ -86,12 +89,12 @@ def test_golden_reference_binary_still_agrees(golden_workdir):
     """When the real reference binary is present (build container), re-run it: the committed
     expected files must be exactly what it prints today."""
     from tests.conftest import ROOT
-    ref = os.path.join(ROOT, "oracle", "_ref", "classify")
-    if not os.path.exists(ref):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "classify")):
         pytest.skip("oracle/_ref/classify not built here")
     for case, run in golden_cases():
         meta = load_case(case)["runs"][run]
         d = golden_workdir / case
+        ref = os.path.join(ROOT, "oracle", "_ref", "classify_s03" if meta.get("program") == "s03" else "classify")
         res = subprocess.run([ref] + meta["argv"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert res.returncode == 0
         assert res.stdout == open(d / meta["expected"], "rb").read(), (case, run)
