@@ -51,6 +51,8 @@ ABI_SYMBOLS = {
     "hast_counts_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
     "hast_classify_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
     "hast_classify_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
+    "hast_classify_perread_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp]),
+    "hast_classify_perread": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "hast_batch_begin": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "hast_batch_submit": (C.c_int, [vp, C.c_size_t, C.c_uint32]),
     "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -297,6 +299,18 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         _ck(self._lib.hast_classify_batch(self._h, _ptr(bases), _ptr(offsets), _ptr(ids), ids.size, max_read_len))
+
+    def classify_perread(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        """per-read (hits0, hits1), stage-03 string semantics, any read length"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        votes = np.zeros((offsets.size - 1, 2), dtype=np.uint32)
+        _ck(self._lib.hast_classify_perread(self._h, _ptr(bases), _ptr(offsets), offsets.size - 1, _ptr(votes)))
+        return votes
+
+    def classify_perread_device(self, d_bases, bases_bytes, d_offsets, n_reads, d_votes, stream=None):
+        _ck(self._lib.hast_classify_perread_device(self._h, C.c_void_p(d_bases), bases_bytes, C.c_void_p(d_offsets),
+                                                   n_reads, C.c_void_p(d_votes), stream))
 
     # synthetic
     def synth_keys_device(self, p, hap, first, n, d_out, stream=None):

@@ -69,6 +69,9 @@ struct hast_ctx {
     size_t scratch_bytes = 0;
     Staging stage[2];
     unsigned batch_no = 0;
+    // per-read mode: segment table of long reads
+    void *d_seg = nullptr;
+    size_t seg_bytes = 0;
 };
 
 namespace {
@@ -195,6 +198,7 @@ void hast_ctx_destroy(hast_ctx *c) {
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_seg) (void)hipFree(c->d_seg);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -468,9 +472,9 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
-                                 uint32_t read_len, const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads,
-                                 hast_stream s) {
+static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                 const uint32_t *d_lens, const uint32_t *d_seg_read, int strict, uint32_t read_len,
+                                 const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads, hast_stream s) {
     if (hast_status st = need_table(c, 0)) return st;
     if (n_reads == 0) return HAST_OK;
     if (!d_bases) return fail(HAST_ERR_INVALID, "d_bases is null");
@@ -482,6 +486,9 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.bases = d_bases;
     a.bases_bytes = bases_bytes;
     a.offsets = d_offsets;
+    a.lens = d_lens;
+    a.seg_read = d_seg_read;
+    a.strict = strict;
     a.barcode_ids = d_barcode_ids;
     a.votes = d_votes;
     a.counts = c->d_counts;
@@ -499,8 +506,9 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     // 4 waves x 2 blocks per iteration: 150-bp reads => 31 reads = 4030 windows = 63 of 64 block slots).
     // The m-mer hash array is padded by W entries so window-min reads past a read's last window stay in bounds.
     const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
-    const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4;
-    const size_t pad = (size_t)wlen * 4 + 64;
+    const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 +
+                            (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
+    const size_t pad = (size_t)wlen * 4 + 64 + 64;
     const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, ((size_t)19968 - pad) / per_read));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
@@ -525,6 +533,70 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     const uint64_t n_tiles = (n_reads + tr - 1) / tr;
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
     HIP_TRY(launch_classify(a, grid, smem, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                 uint32_t read_len, const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads,
+                                 hast_stream s) {
+    return classify_rows(c, d_bases, bases_bytes, d_offsets, nullptr, nullptr, 0, read_len, d_barcode_ids, d_votes, n_reads, s);
+}
+
+// Per-read mode with the string semantics of the stage-03 classifier; reads of any length are cut into
+// segments of kSegWindows windows on the device so that a kernel row always fits LDS.
+static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 512 bases per row for K <= 31
+
+hast_status hast_classify_perread_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                         size_t n_reads, uint32_t *d_votes, hast_stream s) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n_reads == 0) return HAST_OK;
+    if (!d_bases || !d_offsets || !d_votes) return fail(HAST_ERR_INVALID, "null argument");
+    hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    const size_t max_seg = n_reads + bases_bytes / kSegWindows + 1;
+    const size_t need = max_seg * (sizeof(uint64_t) + 2 * sizeof(uint32_t)) + 64;
+    if (c->seg_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(hs));
+        if (c->d_seg) HIP_TRY(hipFree(c->d_seg));
+        c->d_seg = nullptr;
+        c->seg_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_seg, need + need / 4));
+        c->seg_bytes = need + need / 4;
+    }
+    const size_t cap = (c->seg_bytes - 64) / (sizeof(uint64_t) + 2 * sizeof(uint32_t));
+    uint64_t *seg_off = (uint64_t *)c->d_seg;
+    uint32_t *seg_len = (uint32_t *)(seg_off + cap);
+    uint32_t *seg_read = seg_len + cap;
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), hs));
+    HIP_TRY(hipMemsetAsync(d_votes, 0, n_reads * 2 * sizeof(uint32_t), hs));
+    HIP_TRY(launch_build_segments(d_offsets, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt, hs));
+    unsigned long long n_seg = 0;
+    HIP_TRY(hipMemcpyAsync(&n_seg, c->d_cnt, sizeof(n_seg), hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
+    if (n_seg > cap) return fail(HAST_ERR_INVALID, "segment table overflow (%llu > %zu)", n_seg, cap);
+    return classify_rows(c, d_bases, bases_bytes, seg_off, seg_len, seg_read, 1, kSegWindows + (uint32_t)c->k - 1, nullptr,
+                         d_votes, (size_t)n_seg, hs);
+}
+
+hast_status hast_classify_perread(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, size_t n_reads,
+                                  uint32_t *votes_out) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n_reads == 0) return HAST_OK;
+    if (!bases || !offsets || !votes_out) return fail(HAST_ERR_INVALID, "null argument");
+    const size_t nbytes = offsets[n_reads] - offsets[0];
+    const size_t ob = (n_reads + 1) * sizeof(uint64_t), vb = n_reads * 2 * sizeof(uint32_t);
+    const size_t total = ((nbytes + 255) & ~(size_t)255) + ((ob + 255) & ~(size_t)255) + vb + 256;
+    if (hast_status st = ensure_scratch(c, total)) return st;
+    uint8_t *d_b = (uint8_t *)c->d_scratch;
+    uint64_t *d_o = (uint64_t *)(d_b + ((nbytes + 255) & ~(size_t)255));
+    uint32_t *d_v = (uint32_t *)((uint8_t *)d_o + ((ob + 255) & ~(size_t)255));
+    std::vector<uint64_t> rel(n_reads + 1);
+    for (size_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - offsets[0];
+    if (nbytes) HIP_TRY(hipMemcpyAsync(d_b, bases + offsets[0], nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_o, rel.data(), ob, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));        // rel is a local
+    if (hast_status st = hast_classify_perread_device(c, d_b, nbytes ? nbytes : 1, d_o, n_reads, d_v, c->stream)) return st;
+    HIP_TRY(hipMemcpyAsync(votes_out, d_v, vb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return HAST_OK;
 }
 

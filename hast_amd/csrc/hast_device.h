@@ -16,7 +16,9 @@ struct TableGeom {
 struct ClassifyArgs {
     const uint8_t *bases;        // ASCII bases, reads back to back
     uint64_t bases_bytes;        // readable bytes at `bases`
-    const uint64_t *offsets;     // n_reads+1 offsets or nullptr (fixed length)
+    const uint64_t *offsets;     // n_reads+1 offsets or nullptr (fixed length); with `lens`: n_reads start offsets
+    const uint32_t *lens;        // per-row length (rows = segments of long reads) or nullptr
+    const uint32_t *seg_read;    // row -> output read index (votes are atomically added) or nullptr
     const uint32_t *barcode_ids; // per read, or nullptr
     uint32_t *votes;             // [n_reads][2] or nullptr
     uint32_t *counts;            // [n_barcodes][4] = {c0,c1,neg,reserved}
@@ -33,6 +35,7 @@ struct ClassifyArgs {
     uint32_t div_hw;             // same trick for 2*w64 (16-base half-words per read)
     int k;
     int m;                       // minimizer length
+    int strict;                  // per-window validity (stage-03 string semantics) instead of the whole-read N skip
 };
 
 hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t tag,
@@ -43,6 +46,8 @@ hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_key
 hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
 hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
+hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, hipStream_t s);
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
 hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);
 

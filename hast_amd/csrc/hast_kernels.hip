@@ -167,6 +167,16 @@ __device__ __forceinline__ uint32_t has_byte_N(uint32_t x) {
     uint32_t y = x ^ 0x4E4E4E4Eu;                       // 'N' -> 0
     return (y - 0x01010101u) & ~y & 0x80808080u;        // != 0 iff some byte of y is 0
 }
+// 4 ASCII bytes -> 4 bits (first base = bit 3): 1 where the byte is not one of 'A','C','G','T'
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {            // 0x80 in every zero byte, exact
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t not_acgt4(uint32_t x) {
+    const uint32_t ok = zero_bytes(x ^ 0x41414141u) | zero_bytes(x ^ 0x43434343u) | zero_bytes(x ^ 0x47474747u) |
+                        zero_bytes(x ^ 0x54545454u);
+    const uint32_t t = (~ok & 0x80808080u) >> 7;                         // bits 0,8,16,24
+    return ((t * 0x08040201u) >> 24) & 0xFu;                             // -> bits 3,2,1,0
+}
 // bases [p, p+n) of a packed read (n <= 31), right-aligned
 __device__ __forceinline__ uint64_t window_bits(const unsigned long long *words, uint32_t p, uint32_t shift_out) {
     const unsigned long long w0 = words[p >> 5], w1 = words[(p >> 5) + 1];
@@ -181,7 +191,10 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 
 // WT  = number of m-mers per window (K-m+1) when known at compile time, 0 = runtime loop
 // FAST = all index divisions are exact multiply-high (host-checked); false = plain division
-template <int WT, bool FAST>
+// STRICT = per-window validity instead of the whole-read N skip: a window counts only when all its K bytes
+//          are upper-case A/C/G/T (the string semantics of the stage-03 per-read classifier,
+//          03.mkoutput_by_fabulous2.0/src_main/classify.cpp:209-214); rows may then be SEGMENTS of long reads
+template <int WT, bool FAST, bool STRICT>
 __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
@@ -193,6 +206,8 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
     uint32_t *s_flag = s_len + TR;                                                         // [TR]
     uint32_t *s_mh = s_flag + TR;                                                          // [TR][MS] (+ W pad)
+    const uint32_t IW = 2 * a.w64 + 1;                                                     // invalid-byte mask words per read
+    uint32_t *s_inv = s_mh + (size_t)TR * MS + 16;                                         // [TR][IW], STRICT only
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -216,7 +231,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
         // ---- per-read header --------------------------------------------------------------
         if (tid < tra) {
             uint64_t off, len;
-            if (a.offsets) { off = a.offsets[r0 + tid]; len = a.offsets[r0 + tid + 1] - off; }
+            if (a.offsets) { off = a.offsets[r0 + tid]; len = a.lens ? a.lens[r0 + tid] : a.offsets[r0 + tid + 1] - off; }
             else           { off = (r0 + tid) * (uint64_t)a.read_len; len = a.read_len; }
             if (len > a.read_len) len = a.read_len;          // contract: read_len bounds every read
             s_off[tid] = off;
@@ -243,7 +258,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                 uintptr_t p = a4 + 4 * i;
                 d[i] = (p < end_addr) ? *reinterpret_cast<const uint32_t *>(p) : 0x41414141u;
             }
-            uint32_t packed = 0, nflag = 0;
+            uint32_t packed = 0, nflag = 0, invalid = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], bsh);   // bytes addr+4i .. +4i+3
@@ -252,14 +267,19 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                     uint32_t m = (vb <= 0) ? 0u : ((1u << (8 * vb)) - 1u);
                     x = (x & m) | (0x41414141u & ~m);                            // pad with 'A'
                 }
-                nflag |= has_byte_N(x);
+                if (STRICT) invalid = (invalid << 4) | not_acgt4(x);
+                else nflag |= has_byte_N(x);
                 packed = (packed << 8) | pack4(x);
             }
             // 64-bit LDS word w = bases 32w..32w+31, first base most significant: the even
             // half-word is the HIGH 32 bits (little-endian: +4 bytes)
             uint32_t *dst = reinterpret_cast<uint32_t *>(s_pack + (size_t)r * WS + (j >> 1)) + (1 - (j & 1));
             *dst = packed;
-            if (nflag) atomicOr(&s_flag[r], 1u);
+            if (STRICT) {
+                // 32-bit mask word w = bases 32w..32w+31, first base most significant: even half-word = HIGH 16 bits
+                uint16_t *di = reinterpret_cast<uint16_t *>(s_inv + (size_t)r * IW + (j >> 1)) + (1 - (j & 1));
+                *di = (uint16_t)invalid;
+            } else if (nflag) atomicOr(&s_flag[r], 1u);
         }
         __syncthreads();
 
@@ -272,8 +292,10 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             s_mh[t] = (q + M <= s_len[r]) ? h : 0xFFFFFFFFu;
         }
         __syncthreads();
-        if (tid < tra && s_flag[tid]) s_len[tid] = 0;
-        __syncthreads();
+        if (!STRICT) {
+            if (tid < tra && s_flag[tid]) s_len[tid] = 0;
+            __syncthreads();
+        }
 
         // ---- B: probe.  Each wave walks 64-window blocks b = wave, wave+4, ... two at a time -------
         const uint32_t P = a.max_pos;                                 // windows per read (stride)
@@ -288,7 +310,12 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                 const bool inq = q < Q;
                 r = inq ? r : 0;
                 const uint32_t p = inq ? q - r * P : 0;
-                const bool ok = inq && (p + K <= s_len[r]);
+                bool ok = inq && (p + K <= s_len[r]);
+                if (STRICT) {       // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
+                    const uint32_t *iw = s_inv + r * IW + (p >> 5);
+                    const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
+                    ok = ok && (bits >> (64 - K)) == 0;
+                }
                 const uint64_t ck = kmer_canon(window_bits(s_pack + (size_t)r * WS, p, kshift), K);
                 const uint32_t *mh = s_mh + r * MS + p;
                 uint32_t mn = mh[0];
@@ -381,8 +408,14 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
         if (tid < tra) {
             const unsigned long long v = s_vote[tid];
             if (a.votes) {
-                a.votes[2 * (r0 + tid)] = (uint32_t)v;
-                a.votes[2 * (r0 + tid) + 1] = (uint32_t)(v >> 32);
+                if (a.seg_read) {                 // rows are segments of long reads: add into the read's (zeroed) row
+                    uint32_t *row = a.votes + 2 * (size_t)a.seg_read[r0 + tid];
+                    if ((uint32_t)v) atomicAdd(row, (uint32_t)v);
+                    if ((uint32_t)(v >> 32)) atomicAdd(row + 1, (uint32_t)(v >> 32));
+                } else {
+                    a.votes[2 * (r0 + tid)] = (uint32_t)v;
+                    a.votes[2 * (r0 + tid) + 1] = (uint32_t)(v >> 32);
+                }
             }
             if (a.barcode_ids) {
                 uint32_t *rec = a.counts + 4 * (size_t)a.barcode_ids[r0 + tid];
@@ -446,35 +479,69 @@ hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long
     hipLaunchKernelGGL(k_count_tags, dim3(grid_for(nslots / 2, 256, 256 * 8)), dim3(256), 0, s, slots, nslots, d_out);
     return hipGetLastError();
 }
-template <int WT, bool FAST>
+template <int WT, bool FAST, bool STRICT>
 static hipError_t launch_classify_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<WT, FAST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<WT, FAST, STRICT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_classify<WT, FAST>), dim3(grid), dim3(kThreads), smem, s, a);
+    hipLaunchKernelGGL((k_classify<WT, FAST, STRICT>), dim3(grid), dim3(kThreads), smem, s, a);
     return hipGetLastError();
+}
+
+template <bool STRICT>
+static hipError_t launch_classify_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+    const int w = a.k - a.m + 1;
+    const bool fast = a.div_magic && a.div_mh && a.div_hw;
+    if (!fast) return launch_classify_t<0, false, STRICT>(a, grid, smem, s);
+    switch (w) {
+    case 1: return launch_classify_t<1, true, STRICT>(a, grid, smem, s);
+    case 2: return launch_classify_t<2, true, STRICT>(a, grid, smem, s);
+    case 3: return launch_classify_t<3, true, STRICT>(a, grid, smem, s);
+    case 4: return launch_classify_t<4, true, STRICT>(a, grid, smem, s);
+    case 5: return launch_classify_t<5, true, STRICT>(a, grid, smem, s);
+    case 6: return launch_classify_t<6, true, STRICT>(a, grid, smem, s);
+    case 7: return launch_classify_t<7, true, STRICT>(a, grid, smem, s);
+    case 8: return launch_classify_t<8, true, STRICT>(a, grid, smem, s);
+    case 9: return launch_classify_t<9, true, STRICT>(a, grid, smem, s);
+    default: return launch_classify_t<0, true, STRICT>(a, grid, smem, s);
+    }
 }
 
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (a.n_reads == 0) return hipSuccess;
-    const int w = a.k - a.m + 1;
-    const bool fast = a.div_magic && a.div_mh && a.div_hw;
-    if (!fast) return launch_classify_t<0, false>(a, grid, smem, s);
-    switch (w) {
-    case 1: return launch_classify_t<1, true>(a, grid, smem, s);
-    case 2: return launch_classify_t<2, true>(a, grid, smem, s);
-    case 3: return launch_classify_t<3, true>(a, grid, smem, s);
-    case 4: return launch_classify_t<4, true>(a, grid, smem, s);
-    case 5: return launch_classify_t<5, true>(a, grid, smem, s);
-    case 6: return launch_classify_t<6, true>(a, grid, smem, s);
-    case 7: return launch_classify_t<7, true>(a, grid, smem, s);
-    case 8: return launch_classify_t<8, true>(a, grid, smem, s);
-    case 9: return launch_classify_t<9, true>(a, grid, smem, s);
-    default: return launch_classify_t<0, true>(a, grid, smem, s);
+    return a.strict ? launch_classify_s<true>(a, grid, smem, s) : launch_classify_s<false>(a, grid, smem, s);
+}
+
+// Long reads -> segments of at most seg_windows windows (consecutive segments overlap by K-1 bases), so that a
+// row of the classify kernel always fits LDS.  One thread per read; segment rows are handed out with one atomic.
+__global__ void k_build_segments(const uint64_t *offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    const uint64_t off = offsets[i], len = offsets[i + 1] - off;
+    const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
+    const uint64_t nseg = nwin ? (nwin + seg_windows - 1) / seg_windows : 1;
+    const unsigned long long base = atomicAdd(counter, (unsigned long long)nseg);
+    for (uint64_t j = 0; j < nseg; ++j) {
+        const uint64_t start = j * seg_windows;
+        const uint64_t rest = len - start;
+        const uint64_t sl = rest < (uint64_t)seg_windows + k - 1 ? rest : (uint64_t)seg_windows + k - 1;
+        seg_off[base + j] = off + start;
+        seg_len[base + j] = (uint32_t)sl;
+        seg_read[base + j] = (uint32_t)i;
     }
 }
+
+hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, hipStream_t s) {
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_segments, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_offsets, n_reads, k,
+                       seg_windows, seg_off, seg_len, seg_read, d_counter);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_keys, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, p, hap, first, n, d_out);

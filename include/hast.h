@@ -137,6 +137,18 @@ hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t base
 hast_status hast_classify_batch(hast_ctx *, const uint8_t *bases, const uint64_t *offsets,
                                 const uint32_t *barcode_ids, size_t n_reads, uint32_t max_read_len);
 
+/* Per-read mode (BASELINE config 5; reference: the per-read classifier of stage 03,
+ * 03.mkoutput_by_fabulous2.0/src_main/classify.cpp:203-218): no barcodes, no whole-read N skip; a window
+ * counts for haplotype h when its K bytes are upper-case A/C/G/T and its canonical k-mer is in set h (== the
+ * reference's string lookup of the window against every k-mer line and its reverse complement, given
+ * upper-case ACGT k-mer lines).  Reads may have any length (20 kb PacBio-style reads are cut into segments on
+ * the device).  d_votes[n_reads][2] is overwritten with (hits0, hits1). */
+hast_status hast_classify_perread_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
+                                         const uint64_t *d_offsets, size_t n_reads, uint32_t *d_votes, hast_stream);
+/* Same with host buffers, synchronous (H2D, classify, D2H of the votes). */
+hast_status hast_classify_perread(hast_ctx *, const uint8_t *bases, const uint64_t *offsets, size_t n_reads,
+                                  uint32_t *votes_out);
+
 /* Zero-copy variant for host-fed callers (the CLI's parser threads write straight into pinned memory):
  * hast_batch_begin hands out the pinned staging arrays of the next batch (waiting for that buffer's previous
  * batch to finish on the GPU); the caller fills bases back to back, offsets[0..n_reads] and barcode ids, then

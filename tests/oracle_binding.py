@@ -37,6 +37,16 @@ def load(path):
         "ho_classify_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     }
+    sig.update({
+        "ho_s03_new": (C.c_void_p, []),
+        "ho_s03_free": (None, [C.c_void_p]),
+        "ho_s03_load_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]),
+        "ho_s03_load_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+        "ho_s03_k": (C.c_int, [C.c_void_p]),
+        "ho_s03_lines": (C.c_uint64, [C.c_void_p, C.c_int]),
+        "ho_s03_read_hits": (None, [C.c_void_p, C.c_char_p, C.c_size_t, u32p, u32p]),
+        "ho_s03_format_row": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char_p]),
+    })
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args

@@ -329,3 +329,98 @@ def test_minimizer_length_does_not_change_results(built, oracle_lib, k, m):
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
     oracle_lib.ho_free(oc)
+
+
+# ---- per-read mode (BASELINE config 5; secondary oracle = stage-03 per-read classifier) ----------------
+def _s03_oracle(o, lines0, lines1):
+    oc = o.ho_s03_new()
+    for h, lines in ((0, lines0), (1, lines1)):
+        t = ("\n".join(lines) + "\n").encode()
+        assert o.ho_s03_load_text(oc, t, len(t), h) == 0
+    return oc
+
+
+def _kmer_str(key, k):
+    return "".join("ACTG"[(int(key) >> (2 * (k - 1 - j))) & 3] for j in range(k))
+
+
+@pytest.mark.parametrize("k,max_len", [(21, 3000), (31, 30000), (11, 600), (27, 100)])
+def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len):
+    """Integer hits per read == the stage-03 reference's string lookups: windows containing N / lower-case /
+    IUPAC bytes miss (no whole-read skip), reads far longer than an LDS row are segmented on the device."""
+    rng = random.Random(k + max_len)
+    n_keys = 2000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    lines = [[_kmer_str(x, k) for x in keys[h]] for h in (0, 1)]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    lines[0][:50] = ["".join(comp[c] for c in reversed(s)) for s in lines[0][:50]]   # files need not be canonical
+    oc = _s03_oracle(oracle_lib, lines[0], lines[1])
+    allk = lines[0] + lines[1]
+    seqs = []
+    for i in range(300 if max_len < 5000 else 60):
+        L = rng.choice([0, 1, k - 1, k, k + 1, 100, max_len // 3, max_len]) if i > 3 else max_len
+        s = [rng.choice("ACGT") for _ in range(L)]
+        for _ in range(rng.randint(0, 1 + L // 150)):
+            if L >= k:
+                km = rng.choice(allk)
+                o = rng.randint(0, L - k)
+                s[o:o + k] = km if rng.random() < 0.5 else "".join(comp[c] for c in reversed(km))
+        for _ in range(rng.randint(0, 1 + L // 400)):
+            if L:
+                s[rng.randrange(L)] = rng.choice("NnacgtRYK-")
+        seqs.append("".join(s).encode())
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_text(0, ("\n".join(lines[0]) + "\n").encode())
+        ctx.table_insert_text(1, ("\n".join(lines[1]) + "\n").encode())
+        votes = ctx.classify_perread(bases, off)
+        votes2 = ctx.classify_perread(bases, off)                 # idempotent: the output rows are overwritten
+    exp = np.zeros_like(votes)
+    h0, h1 = C.c_uint32(), C.c_uint32()
+    for i, sq in enumerate(seqs):
+        oracle_lib.ho_s03_read_hits(oc, sq, len(sq), C.byref(h0), C.byref(h1))
+        exp[i] = (h0.value, h1.value)
+    oracle_lib.ho_s03_free(oc)
+    assert np.array_equal(votes, exp)
+    assert np.array_equal(votes2, exp)
+    assert exp.sum() > 0
+
+
+@pytest.mark.parametrize("case", ["s03_k21", "s03_k31"])
+def test_perread_rows_match_s03_reference_golden(built, oracle_lib, golden_workdir, case):
+    """Hits from the GPU, formatted as the stage-03 program prints them, reproduce the real reference binary's
+    stdout for the committed FASTA input (multi-line records, ids, ambiguous/haplotype calls, %0.6f densities)."""
+    d = golden_workdir / case
+    t0, t1 = open(d / "hap0.mer", "rb").read(), open(d / "hap1.mer", "rb").read()
+    k = t0.index(b"\n")
+    oc = oracle_lib.ho_s03_new()
+    assert oracle_lib.ho_s03_load_text(oc, t0, len(t0), 0) == 0 and oracle_lib.ho_s03_load_text(oc, t1, len(t1), 1) == 0
+    names, seqs = [], []
+    for line in open(d / "reads.fa", "rb").read().split(b"\n"):
+        if not line:
+            continue
+        if line.startswith(b">"):
+            names.append(line[1:])
+            seqs.append(b"")
+        else:
+            seqs[-1] += line
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(len(t0) // (k + 1) + len(t1) // (k + 1) + 2)
+        ctx.table_insert_text(0, t0)
+        # the library follows load_kmers' framing: the unterminated tail of hap1.mer is dropped
+        ctx.table_insert_text(1, t1[:t1.rindex(b"\n") + 1])
+        votes = ctx.classify_perread(bases, off)
+    out = b""
+    buf = C.create_string_buffer(4096)
+    for name, v in zip(names, votes):
+        n = oracle_lib.ho_s03_format_row(oc, name, len(name), int(v[0]), int(v[1]), buf)
+        out += buf.raw[:n]
+    oracle_lib.ho_s03_free(oc)
+    assert out == open(d / "expected.fasta.tsv", "rb").read()
