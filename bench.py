@@ -32,6 +32,9 @@ WORKLOADS = {
     "c3": (200_000_000, 10_000_000, "C3 human-trio scale: 200M+200M synthetic 21-mers, 10M barcodes, 150bp reads"),
     "c2": (50_000_000, 1_000_000, "C2: 50M+50M synthetic 21-mers, 1M barcodes, 150bp reads"),
     "c1": (1_000_000, 10_000, "C1 plumbing: 1M+1M synthetic 21-mers, 10k barcodes, 150bp reads"),
+    # config 5: K=31, 400M+400M keys, PacBio-style 20 kb reads, barcode-free per-read (hits0, hits1) output
+    # (string semantics of the stage-03 per-read classifier); pass --k 31 --read-len 20000 --batch-reads 120000
+    "c5": (400_000_000, 1, "C5 HAST4TGS-style: 400M+400M synthetic 31-mers, 20kb reads, per-read assignment"),
 }
 ADAPTOR_F = b"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA"   # classify.cpp:312
 ADAPTOR_R = b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"   # classify.cpp:313
@@ -81,6 +84,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n_keys, n_bc, wl_desc = WORKLOADS[args.workload]
+    perread = args.workload == "c5"
+    if perread:                       # config 5 geometry unless overridden on the command line
+        if args.k == 21: args.k = 31
+        if args.read_len == 150: args.read_len = 20000
+        if args.batch_reads == 16_000_000: args.batch_reads = 120_000
+        args.cpu_seconds = 0          # the port's CPU leg restates stage 01 only
     K, L, R = args.k, args.read_len, args.batch_reads
     p = make_params(K, L, n_keys, n_bc)
     ctx = hast_amd.Context(K, local_rank, minimizer=args.minimizer or None)
@@ -123,9 +132,17 @@ def main():
     if rank == 0:
         log("%d resident batches x %d reads (%.2f GB) generated in %.1f s" % (n_res, R, n_res * per_batch / 1e9, time.time() - t0))
 
+    votes = offsets = None
+    if perread:
+        votes = torch.zeros((R, 2), dtype=torch.int32, device=dev)
+        offsets = (torch.arange(R + 1, dtype=torch.int64, device=dev) * L)
+
     def step(j):
         b, ids = batches[j % n_res]
-        ctx.classify_device(b.data_ptr(), R * L, R, L, d_barcode_ids=ids.data_ptr(), stream=hs)
+        if perread:
+            ctx.classify_perread_device(b.data_ptr(), R * L, offsets.data_ptr(), R, votes.data_ptr(), stream=hs)
+        else:
+            ctx.classify_device(b.data_ptr(), R * L, R, L, d_barcode_ids=ids.data_ptr(), stream=hs)
 
     def barrier():
         if world > 1:
@@ -149,9 +166,10 @@ def main():
             ev0[s].record(stream)
             step(args.warmup + s)
             ev1[s].record(stream)
-        if world > 1:
+        if world > 1 and not perread:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)          # RCCL, uint32-as-int32 sums
-        counts_host = counts.cpu() if rank == 0 else None
+        # per-read mode needs no reduction: every rank returns its own reads' (hits0, hits1)
+        counts_host = (votes.cpu() if perread else counts.cpu()) if (rank == 0 or perread) else None
     stream.synchronize()
     torch.cuda.synchronize()
     barrier()
@@ -171,6 +189,8 @@ def main():
     result = None
     if rank == 0:
         ch = counts_host.numpy().view(np.uint32)
+        if perread:
+            ch = np.concatenate([ch, np.zeros((ch.shape[0], 1), np.uint32)], axis=1)
         result = {
             "metric": "classified read-bp/sec at k=%d, %dbp reads, %dM unique-mers/hap" % (K, L, n_keys // 1_000_000),
             "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,6 +201,7 @@ def main():
                        "load_factor": args.load_factor, "minimizer": ctx.minimizer, "set_sizes": list(set_sizes), "sharding": "reads by index, tables replicated",
                        "collective": "1x all_reduce(sum,u32[%d]) + D2H in timed region" % (n_bc * 4) if world > 1 else "none (D2H of counters in timed region)",
                        "resident_batches": n_res},
+            "mode": "per-read votes (stage-03 semantics)" if perread else "per-barcode counts (stage-01 semantics)",
             "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": kern_avg_ms,
