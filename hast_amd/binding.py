@@ -87,6 +87,10 @@ def classify_exe():
     return os.path.join(_HERE, "classify")
 
 
+def classify_read_exe():
+    return os.path.join(_HERE, "classify_read")
+
+
 def build(verbose=False):
     """Compile libhast.so + classify for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     res = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

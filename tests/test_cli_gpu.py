@@ -108,3 +108,16 @@ def test_cli_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path, gz, threa
     assert got.returncode == 0, got.stderr.decode()[-2000:]
     assert got.stdout == ref.stdout
     assert len(got.stdout.splitlines()) > 1000
+
+
+@pytest.mark.parametrize("case,run", golden_cases("s03"))
+def test_classify_read_cli_matches_s03_reference_golden(exe, golden_workdir, case, run):
+    """Drop-in for the per-read classifier of stage 03 (config 5 analogue): stdout identical to the real reference
+    binary's on FASTA (multi-line) and gz FASTQ inputs with reads up to 20 kb."""
+    meta = load_case(case)["runs"][run]
+    d = golden_workdir / case
+    # our loader drops the unterminated tail exactly like the reference; the fixture's hap1.mer has one
+    res = subprocess.run([hast_amd.classify_read_exe()] + meta["argv"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert res.stdout == open(d / meta["expected"], "rb").read()
