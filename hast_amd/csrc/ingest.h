@@ -204,6 +204,8 @@ class BlockSource {
             gz_ = gzopen(path.c_str(), "rb");
             if (!gz_) return false;
             gzbuffer(gz_, 4u << 20);
+        } else if (path == "-") {
+            fp_ = stdin;
         } else {
             fp_ = fopen(path.c_str(), "rb");
             if (!fp_) return false;
@@ -222,7 +224,7 @@ class BlockSource {
         cv_.notify_all();
         if (reader_.joinable()) reader_.join();
         if (gz_) gzclose(gz_);
-        if (fp_) fclose(fp_);
+        if (fp_ && fp_ != stdin) fclose(fp_);
         gz_ = nullptr;
         fp_ = nullptr;
         ready_.clear();

@@ -250,6 +250,66 @@ def case_s03(name, k, n_keys, seed, max_len):
     print("wrote", name)
 
 
+def case_quartering():
+    """Step 10-11 of classify_stlfr_reads.sh (:155-190) run with the reference's own awk program on the rand_k21
+    inputs: barcode lists from the reference's phased.barcodes, then quartering_fastq.awk.  Stored: md5 + size of
+    each routed FASTQ and the text appended to filter_reads.log (the routed files are as large as the input)."""
+    import hashlib
+    import shutil
+    import tempfile
+    awk_prog = "/root/reference/01.classify_stlfr_reads/quartering_fastq.awk"
+    src = os.path.join(HERE, "rand_k21")
+    tmp = tempfile.mkdtemp()
+    try:
+        phased = open(os.path.join(src, "expected.pair_w104.tsv")).read()
+        # add rows the FASTQ never mentions + make one FASTQ barcode unclassified (exercises the ERROR path)
+        lines = phased.splitlines()
+        dropped = lines.pop(7).split("\t")[0]
+        open(os.path.join(tmp, "phased.barcodes"), "w").write("\n".join(lines) + "\n")
+        for name, val in (("paternal", "0"), ("maternal", "1"), ("homozygous", "-1")):
+            subprocess.run("awk '{if($2 == %s) print $1;}' phased.barcodes > %s.unique.barcodes"
+                           % (val if val != "-1" else '"-1"', name), shell=True, cwd=tmp, check=True)
+        out = {"dropped_barcode": dropped, "files": {}}
+        for fq_name in ("r1.fq", "r2.fq"):
+            data = gzip.open(os.path.join(src, fq_name + ".gz")).read()
+            if fq_name == "r2.fq":
+                data = data[:-1] + b"\n@tail#%s/2\nACGT" % lines[3].split("\t")[0].encode()   # partial last record, unterminated
+            open(os.path.join(tmp, fq_name), "wb").write(data)
+            r = subprocess.run(["awk", "-v", "prefix=" + fq_name, "-F", "#|/", "-f", awk_prog, "paternal.unique.barcodes",
+                                "maternal.unique.barcodes", "homozygous.unique.barcodes", fq_name], cwd=tmp,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+            out["files"][fq_name] = {"stderr_lines": len(r.stderr.decode().splitlines()),
+                                     "stderr_md5": hashlib.md5(r.stderr).hexdigest()}
+            for cls in ("paternal", "maternal", "homozygous", "nobarcode"):
+                pth = os.path.join(tmp, "%s.%s.fastq" % (fq_name, cls))
+                if os.path.exists(pth):
+                    b = open(pth, "rb").read()
+                    out["files"][fq_name][cls] = {"md5": hashlib.md5(b).hexdigest(), "bytes": len(b)}
+        out["filter_reads_log"] = open(os.path.join(tmp, "filter_reads.log")).read()
+        # tiny hand-made case with every branch of the awk program; inputs and outputs stored in full
+        e = os.path.join(tmp, "edge")
+        os.makedirs(e)
+        edge_in = {"p.bc": "1_1_1\n2_2_2\n", "m.bc": "3_3_3\n1_1_1\n", "h.bc": "4_4_4\n\n5_5_5/x\n",
+                   "e.fq": "@r1#1_1_1/1\tx\nACGT\n+\nFFFF\n@r2#3_3_3/2\nAC\n+\nFF\n@r3#0_0_0/1\nA\n+\nF\n@r4#9_9_9/1\nA\n+\nF\n"
+                           "@r5\nA\n+\nF\n@r6#4_4_4\nAA\n+\nFF\n@r7##/1\nA\n+\nF\n@r8/5_5_5#z\nC\n+\nF\n@r9#2_2_2/1\nG\n+"}
+        for fn, txt in edge_in.items():
+            open(os.path.join(e, fn), "w").write(txt)
+        r = subprocess.run(["awk", "-v", "prefix=e.fq", "-F", "#|/", "-f", awk_prog, "p.bc", "m.bc", "h.bc", "e.fq"], cwd=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        out["edge"] = {"inputs": edge_in, "stderr": r.stderr.decode(),
+                       "outputs": {fn: open(os.path.join(e, fn)).read() for fn in sorted(os.listdir(e)) if fn not in edge_in}}
+        out["r2_tail"] = "@tail#%s/2\nACGT" % lines[3].split("\t")[0]
+        d = os.path.join(HERE, "quartering")
+        os.makedirs(d, exist_ok=True)
+        for name in ("paternal", "maternal", "homozygous"):
+            shutil.copy(os.path.join(tmp, name + ".unique.barcodes"), os.path.join(d, name + ".unique.barcodes"))
+        with open(os.path.join(d, "expected.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        print("wrote quartering", {k: sorted(v) for k, v in out["files"].items()})
+    finally:
+        shutil.rmtree(tmp)
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
@@ -260,6 +320,7 @@ def main():
     random_case("rand_k32", 32, 500, 200, 20, seed=32, read_len=120, extra_runs=False)
     case_s03("s03_k21", 21, 300, seed=521, max_len=20000)
     case_s03("s03_k31", 31, 300, seed=531, max_len=9000)
+    case_quartering()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,75 @@
+"""CPU test of hast_amd/quartering_fastq: byte-identical outputs to the reference's awk program
+(01.classify_stlfr_reads/quartering_fastq.awk under mawk, fixtures made by tests/golden/gen_golden.py)."""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import hast_amd
+from tests.conftest import GOLDEN, ROOT
+
+EXE = os.path.join(ROOT, "hast_amd", "quartering_fastq")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    hast_amd.build()
+    return EXE
+
+
+def test_edge_case_all_branches(exe, tmp_path):
+    exp = json.load(open(os.path.join(GOLDEN, "quartering", "expected.json")))["edge"]
+    for fn, txt in exp["inputs"].items():
+        (tmp_path / fn).write_text(txt)
+    for threads in (1, 5):
+        for fn in exp["outputs"]:
+            (tmp_path / fn).unlink(missing_ok=True)
+        r = subprocess.run([exe, "-t", str(threads), "--prefix", "e.fq", "p.bc", "m.bc", "h.bc", "e.fq"], cwd=tmp_path,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == b""
+        assert r.stderr.decode() == exp["stderr"]
+        got = {fn: (tmp_path / fn).read_text() for fn in exp["outputs"]}
+        assert got == exp["outputs"]
+        assert sorted(os.listdir(tmp_path)) == sorted(list(exp["inputs"]) + list(exp["outputs"]))
+
+
+@pytest.mark.parametrize("threads,block_mb,via", [(1, 64, "file"), (8, 1, "file"), (3, 1, "gz"), (4, 64, "stdin")])
+def test_rand_k21_matches_reference_awk(exe, tmp_path, threads, block_mb, via):
+    exp = json.load(open(os.path.join(GOLDEN, "quartering", "expected.json")))
+    for name in ("paternal", "maternal", "homozygous"):
+        shutil.copy(os.path.join(GOLDEN, "quartering", name + ".unique.barcodes"), tmp_path)
+    lists = ["paternal.unique.barcodes", "maternal.unique.barcodes", "homozygous.unique.barcodes"]
+    for fq in ("r1.fq", "r2.fq"):
+        data = gzip.open(os.path.join(GOLDEN, "rand_k21", fq + ".gz")).read()
+        if fq == "r2.fq":
+            data = data[:-1] + b"\n" + exp["r2_tail"].encode()
+        cmd = [exe, "-t", str(threads), "--block-mb", str(block_mb), "--prefix", fq] + lists
+        if via == "gz":
+            with gzip.open(tmp_path / (fq + ".gz"), "wb") as f:
+                f.write(data)
+            r = subprocess.run(cmd + [fq + ".gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        elif via == "stdin":
+            r = subprocess.run(cmd + ["-"], cwd=tmp_path, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        else:
+            (tmp_path / fq).write_bytes(data)
+            r = subprocess.run(cmd + [fq], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-500:]
+        e = exp["files"][fq]
+        assert hashlib.md5(r.stderr).hexdigest() == e["stderr_md5"]
+        for cls in ("paternal", "maternal", "homozygous", "nobarcode"):
+            p = tmp_path / ("%s.%s.fastq" % (fq, cls))
+            if cls in e:
+                b = p.read_bytes()
+                assert (len(b), hashlib.md5(b).hexdigest()) == (e[cls]["bytes"], e[cls]["md5"]), (fq, cls)
+            else:
+                assert not p.exists()
+    log = (tmp_path / "filter_reads.log").read_text()
+    if via == "file":
+        assert log == exp["filter_reads_log"]
+    else:   # the FILENAME line is whatever was given (awk prints "-" behind gzip -dc); the counters are the same
+        strip = lambda t: [l for l in t.splitlines() if l.startswith("#")]
+        assert strip(log) == strip(exp["filter_reads_log"])
