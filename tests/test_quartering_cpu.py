@@ -73,3 +73,28 @@ def test_rand_k21_matches_reference_awk(exe, tmp_path, threads, block_mb, via):
     else:   # the FILENAME line is whatever was given (awk prints "-" behind gzip -dc); the counters are the same
         strip = lambda t: [l for l in t.splitlines() if l.startswith("#")]
         assert strip(log) == strip(exp["filter_reads_log"])
+
+
+def test_merge_counts_equals_single_run(oracle_dir, golden_workdir, tmp_path):
+    """8(f)#3: merging the TSVs of two shards (r1 alone, r2 alone) reproduces the reference's output for both files
+    together (rand_k21 golden, weight0 1.04).  Shard TSVs come from the oracle (CPU); set sizes from its log."""
+    hast_amd.build()
+    d = golden_workdir / "rand_k21"
+    base = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--weight0", "1.04"]
+    sizes = None
+    for i, fq in enumerate(("r1.fq.gz", "r2.fq.gz")):
+        r = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + base + ["--read", fq], cwd=d, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, check=True)
+        (tmp_path / ("shard%d.tsv" % i)).write_bytes(r.stdout)
+    # |S_0|, |S_1| after adaptor scrub: unique canonical keys, from the oracle library
+    from tests import oracle_binding as ob
+    o = ob.load(os.path.join(oracle_dir, "liboracle.so"))
+    oc = o.ho_new()
+    for h in (0, 1):
+        assert o.ho_load_kmers_file(oc, str(d / ("hap%d.mer" % h)).encode(), h) == 0
+    o.ho_init_adaptor(oc, b"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA", b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG", None)
+    sizes = (o.ho_set_size(oc, 0), o.ho_set_size(oc, 1))
+    o.ho_free(oc)
+    r = subprocess.run([os.path.join(ROOT, "hast_amd", "merge_counts"), "--set0", str(sizes[0]), "--set1", str(sizes[1]),
+                        "--weight0", "1.04", "shard0.tsv", "shard1.tsv"], cwd=tmp_path, stdout=subprocess.PIPE, check=True)
+    assert r.stdout == open(d / "expected.pair_w104.tsv", "rb").read()
