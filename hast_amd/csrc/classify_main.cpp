@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -271,138 +272,167 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> allnl;
     std::vector<uint64_t> part_bytes(T + 1);
     std::vector<uint32_t> part_max(T), part_err(T);
-    for (const auto &r : read) {
-        fprintf(stderr, "__process read: %s\n", r.c_str());
-        hast::BlockSource src;
-        if (!src.open(r, block_bytes)) die(2, ("cannot open " + r).c_str());
+    // Several --read files are streamed CONCURRENTLY (each has its own reader thread, so .gz files inflate in
+    // parallel -- zlib is the serial bottleneck of real inputs) and their blocks are parsed round-robin.  Counts are
+    // sums, so the interleaving cannot change the output; the reference handles the files one after the other.
+    struct FileState {
+        std::string name;
+        std::unique_ptr<hast::BlockSource> src;
         std::vector<char> carry;                       // bytes of an incomplete record at the end of a block
-        uint64_t file_records = 0;
-        // parse `n_rec` complete records whose newline positions are in allnl (4 per record) from `data`
-        auto parse_records = [&](const char *data, size_t n_rec) {
-            if (n_rec == 0) return;
-            uint8_t *hb;
-            uint64_t *ho;
-            uint32_t *hi;
-            const size_t span = (size_t)allnl[4 * n_rec - 1] + 1;
-            CK(hast_batch_begin(ctx, span, n_rec, &hb, &ho, &hi), "staging a batch");
-            auto rec_range = [&](int t, size_t &lo, size_t &hi_) { lo = n_rec * (size_t)t / T; hi_ = n_rec * (size_t)(t + 1) / T; };
-            pool.run([&](int t) {                          // pass 1: bytes of bases per worker
-                size_t lo, hi_;
-                rec_range(t, lo, hi_);
-                uint64_t sum = 0;
-                uint32_t mx = 0;
-                for (size_t i = lo; i < hi_; i++) {
-                    uint32_t len = allnl[4 * i + 1] - allnl[4 * i] - 1;
-                    sum += len;
-                    mx = std::max(mx, len);
-                }
-                part_bytes[t + 1] = sum;
-                part_max[t] = mx;
-            });
-            part_bytes[0] = 0;
-            for (int t = 0; t < T; t++) part_bytes[t + 1] += part_bytes[t];
-            pool.run([&](int t) {                          // pass 2: barcode ids + bases into pinned staging
-                size_t lo, hi_;
-                rec_range(t, lo, hi_);
-                uint64_t off = part_bytes[t];
-                uint32_t err = 0;
-                for (size_t i = lo; i < hi_; i++) {
-                    const size_t h0 = i ? (size_t)allnl[4 * i - 1] + 1 : 0, h1 = allnl[4 * i], s1 = allnl[4 * i + 1];
-                    size_t bs, bn;
-                    hast_parse_barcode(data + h0, h1 - h0, &bs, &bn);                          // classify.cpp:189
-                    hi[i] = dict.get(std::string_view(data + h0 + bs, bn), caches[t]);
-                    const size_t len = s1 - h1 - 1;
-                    ho[i] = off;
-                    memcpy(hb + off, data + h1 + 1, len);
-                    if (len < K && !memchr(data + h1 + 1, 'N', len)) err = 1;                  // kmer.h:171
-                    off += len;
-                }
-                part_err[t] = err;
-            });
-            ho[n_rec] = part_bytes[T];
+    };
+    const std::string *cur_name = nullptr;
+    // parse `n_rec` complete records whose newline positions are in allnl (4 per record) from `data`
+    auto parse_records = [&](const char *data, size_t n_rec) {
+        if (n_rec == 0) return;
+        uint8_t *hb;
+        uint64_t *ho;
+        uint32_t *hi;
+        const size_t span = (size_t)allnl[4 * n_rec - 1] + 1;
+        CK(hast_batch_begin(ctx, span, n_rec, &hb, &ho, &hi), "staging a batch");
+        auto rec_range = [&](int t, size_t &lo, size_t &hi_) { lo = n_rec * (size_t)t / T; hi_ = n_rec * (size_t)(t + 1) / T; };
+        pool.run([&](int t) {                          // pass 1: bytes of bases per worker
+            size_t lo, hi_;
+            rec_range(t, lo, hi_);
+            uint64_t sum = 0;
             uint32_t mx = 0;
-            for (int t = 0; t < T; t++) {
-                mx = std::max(mx, part_max[t]);
-                if (part_err[t]) {
-                    fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, r.c_str());
-                    exit(3);                                                                   // reference: assert abort
-                }
+            for (size_t i = lo; i < hi_; i++) {
+                uint32_t len = allnl[4 * i + 1] - allnl[4 * i] - 1;
+                sum += len;
+                mx = std::max(mx, len);
             }
-            if (dict.size() > acc.device_cap) flush_counts(ctx, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
-            CK(hast_batch_submit(ctx, n_rec, mx), "classifying a batch");
-            total_reads += n_rec;
-            total_bases += part_bytes[T];
-            file_records += n_rec;
-        };
-        for (;;) {
-            std::vector<char> blk = src.next();
-            const bool last = blk.empty();
-            constexpr size_t kPad = hast::BlockSource::kFrontPad;
-            // work area = carry (incomplete record of the previous block) + this block's data
-            const char *data;
-            size_t len;
-            if (last) {
-                data = carry.data();
-                len = carry.size();
-            } else if (carry.size() <= kPad) {
-                memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());   // in front, no block copy
-                data = blk.data() + kPad - carry.size();
-                len = blk.size() - kPad + carry.size();
-            } else {                                                                     // giant record: slow path
-                carry.insert(carry.end(), blk.begin() + kPad, blk.end());
-                data = carry.data();
-                len = carry.size();
+            part_bytes[t + 1] = sum;
+            part_max[t] = mx;
+        });
+        part_bytes[0] = 0;
+        for (int t = 0; t < T; t++) part_bytes[t + 1] += part_bytes[t];
+        pool.run([&](int t) {                          // pass 2: barcode ids + bases into pinned staging
+            size_t lo, hi_;
+            rec_range(t, lo, hi_);
+            uint64_t off = part_bytes[t];
+            uint32_t err = 0;
+            for (size_t i = lo; i < hi_; i++) {
+                const size_t h0 = i ? (size_t)allnl[4 * i - 1] + 1 : 0, h1 = allnl[4 * i], s1 = allnl[4 * i + 1];
+                size_t bs, bn;
+                hast_parse_barcode(data + h0, h1 - h0, &bs, &bn);                          // classify.cpp:189
+                hi[i] = dict.get(std::string_view(data + h0 + bs, bn), caches[t]);
+                const size_t len = s1 - h1 - 1;
+                ho[i] = off;
+                memcpy(hb + off, data + h1 + 1, len);
+                if (len < K && !memchr(data + h1 + 1, 'N', len)) err = 1;                  // kmer.h:171
+                off += len;
             }
-            if (len == 0) break;
-            if (len >= (1ull << 32)) die(3, "a single FASTQ record spans more than 4 GB");
-            // newline index, in parallel
-            pool.run([&](int t) {
-                auto &v = nl[t];
-                v.clear();
-                const size_t lo = len * (size_t)t / T, hi_ = len * (size_t)(t + 1) / T;
-                const char *p = data + lo, *e = data + hi_;
-                while (p < e && (p = (const char *)memchr(p, '\n', (size_t)(e - p)))) {
-                    v.push_back((uint32_t)(p - data));
-                    ++p;
-                }
-            });
-            size_t total_nl = 0;
-            std::vector<size_t> cum(T + 1, 0);
-            for (int t = 0; t < T; t++) cum[t + 1] = cum[t] + nl[t].size();
-            total_nl = cum[T];
-            allnl.resize(total_nl);
-            pool.run([&](int t) { if (!nl[t].empty()) memcpy(allnl.data() + cum[t], nl[t].data(), nl[t].size() * 4); });
-            const size_t n_rec = total_nl / 4;
-            parse_records(data, n_rec);
-            const size_t consumed = n_rec ? (size_t)allnl[4 * n_rec - 1] + 1 : 0;
-            if (last) {
-                // end of input: what is left holds < 4 newlines.  Reference framing (classify.cpp:257-268): the
-                // header must be newline-terminated; bases are whatever follows up to the next newline or EOF.
-                const char *p = data + consumed, *e = data + len;
-                const char *h_end = (const char *)memchr(p, '\n', (size_t)(e - p));
-                if (h_end) {
-                    const char *s0 = h_end + 1;
-                    const char *s_end = (const char *)memchr(s0, '\n', (size_t)(e - s0));
-                    if (!s_end) s_end = e;
-                    std::string tail(p, (size_t)(h_end - p));
-                    tail.push_back('\n');
-                    tail.append(s0, (size_t)(s_end - s0));
-                    tail.append("\n+\n\n");
-                    allnl.clear();
-                    for (size_t i = 0; i < tail.size(); i++)
-                        if (tail[i] == '\n') allnl.push_back((uint32_t)i);
-                    parse_records(tail.data(), 1);
-                }
-                break;
+            part_err[t] = err;
+        });
+        ho[n_rec] = part_bytes[T];
+        uint32_t mx = 0;
+        for (int t = 0; t < T; t++) {
+            mx = std::max(mx, part_max[t]);
+            if (part_err[t]) {
+                fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, cur_name->c_str());
+                exit(3);                                                                   // reference: assert abort
             }
-            // keep the incomplete record for the next block
-            std::vector<char> rest(data + consumed, data + len);
-            carry.swap(rest);
-            src.recycle(std::move(blk));
         }
-        logtime();
-        fprintf(stderr, "__process read done__\n");
-        (void)file_records;
+        if (dict.size() > acc.device_cap) flush_counts(ctx, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
+        CK(hast_batch_submit(ctx, n_rec, mx), "classifying a batch");
+        total_reads += n_rec;
+        total_bases += part_bytes[T];
+    };
+    // one block of one file; returns false when that file is finished
+    auto process_block = [&](FileState &fs) -> bool {
+        cur_name = &fs.name;
+        hast::BlockSource &src = *fs.src;
+        std::vector<char> &carry = fs.carry;
+        std::vector<char> blk = src.next();
+        const bool last = blk.empty();
+        constexpr size_t kPad = hast::BlockSource::kFrontPad;
+        // work area = carry (incomplete record of the previous block) + this block's data
+        const char *data;
+        size_t len;
+        if (last) {
+            data = carry.data();
+            len = carry.size();
+        } else if (carry.size() <= kPad) {
+            memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());   // in front, no block copy
+            data = blk.data() + kPad - carry.size();
+            len = blk.size() - kPad + carry.size();
+        } else {                                                                     // giant record: slow path
+            carry.insert(carry.end(), blk.begin() + kPad, blk.end());
+            data = carry.data();
+            len = carry.size();
+        }
+        if (len == 0) return false;
+        if (len >= (1ull << 32)) die(3, "a single FASTQ record spans more than 4 GB");
+        // newline index, in parallel
+        pool.run([&](int t) {
+            auto &v = nl[t];
+            v.clear();
+            const size_t lo = len * (size_t)t / T, hi_ = len * (size_t)(t + 1) / T;
+            const char *p = data + lo, *e = data + hi_;
+            while (p < e && (p = (const char *)memchr(p, '\n', (size_t)(e - p)))) {
+                v.push_back((uint32_t)(p - data));
+                ++p;
+            }
+        });
+        std::vector<size_t> cum(T + 1, 0);
+        for (int t = 0; t < T; t++) cum[t + 1] = cum[t] + nl[t].size();
+        const size_t total_nl = cum[T];
+        allnl.resize(total_nl);
+        pool.run([&](int t) { if (!nl[t].empty()) memcpy(allnl.data() + cum[t], nl[t].data(), nl[t].size() * 4); });
+        const size_t n_rec = total_nl / 4;
+        parse_records(data, n_rec);
+        const size_t consumed = n_rec ? (size_t)allnl[4 * n_rec - 1] + 1 : 0;
+        if (last) {
+            // end of input: what is left holds < 4 newlines.  Reference framing (classify.cpp:257-268): the
+            // header must be newline-terminated; bases are whatever follows up to the next newline or EOF.
+            const char *p = data + consumed, *e = data + len;
+            const char *h_end = (const char *)memchr(p, '\n', (size_t)(e - p));
+            if (h_end) {
+                const char *s0 = h_end + 1;
+                const char *s_end = (const char *)memchr(s0, '\n', (size_t)(e - s0));
+                if (!s_end) s_end = e;
+                std::string tail(p, (size_t)(h_end - p));
+                tail.push_back('\n');
+                tail.append(s0, (size_t)(s_end - s0));
+                tail.append("\n+\n\n");
+                allnl.clear();
+                for (size_t i = 0; i < tail.size(); i++)
+                    if (tail[i] == '\n') allnl.push_back((uint32_t)i);
+                parse_records(tail.data(), 1);
+            }
+            return false;
+        }
+        // keep the incomplete record for the next block
+        std::vector<char> rest(data + consumed, data + len);
+        carry.swap(rest);
+        src.recycle(std::move(blk));
+        return true;
+    };
+    {
+        const size_t max_active = 4;                   // concurrent reader threads (3 prefetched blocks each)
+        std::vector<FileState> active;
+        size_t next_file = 0;
+        auto open_next = [&]() {
+            const std::string &r = read[next_file++];
+            fprintf(stderr, "__process read: %s\n", r.c_str());
+            FileState fs;
+            fs.name = r;
+            fs.src.reset(new hast::BlockSource());
+            if (!fs.src->open(r, block_bytes)) die(2, ("cannot open " + r).c_str());
+            active.push_back(std::move(fs));
+        };
+        while (next_file < read.size() && active.size() < max_active) open_next();
+        while (!active.empty()) {
+            for (size_t i = 0; i < active.size();) {
+                if (process_block(active[i])) {
+                    ++i;
+                    continue;
+                }
+                logtime();
+                fprintf(stderr, "__process read done__\n");
+                active.erase(active.begin() + (long)i);
+                if (next_file < read.size()) open_next();
+            }
+        }
     }
     flush_counts(ctx, acc, dict.size(), 1);
     const double t_classified = now_s();

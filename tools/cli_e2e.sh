@@ -29,6 +29,18 @@ if [ -x oracle/_ref/classify_O2 ]; then
 fi
 for T in 1 8 32 64; do run hast_t$T hast_amd/classify $ARGS -t $T --stats; echo ","; done
 run hast_t64_again hast_amd/classify $ARGS -t 64 --stats
+if [ "${GZ:-0}" = 1 ]; then
+  (gzip -1 -k $D/r1.fq & gzip -1 -k $D/r2.fq & wait)
+  GZARGS="--hap0 $D/hap0.mer --hap1 $D/hap1.mer --read $D/r1.fq.gz --read $D/r2.fq.gz --weight0 1.04"
+  echo ","; run hast_gz_t32 hast_amd/classify $GZARGS -t 32 --stats
+  [ -x oracle/_ref/classify_O2 ] && { echo ","; run ref_O2_gz_t32 timeout 1800 oracle/_ref/classify_O2 $GZARGS -t 32; }
+fi
+if [ "${QUARTER:-0}" = 1 ]; then
+  # the step after classify with OUR partitioner (the reference's awk program does not travel to this box;
+  # its timing is taken in the build container)
+  ( cd $D && awk '{if($2 == 0) print $1;}' out.hast_t64 > p.bc && awk '{if($2 == 1) print $1;}' out.hast_t64 > m.bc && awk '{if($2 == "-1") print $1;}' out.hast_t64 > h.bc )
+  for T in 1 8 32; do echo ","; ( cd $D && rm -f r1.fq.*.fastq; run quarter_t$T $OLDPWD/hast_amd/quartering_fastq -t $T --prefix r1.fq p.bc m.bc h.bc r1.fq ); done
+fi
 echo "]}"
 } > $OUT
 grep -h "__stats__" $D/err.hast_t* | tail -5
