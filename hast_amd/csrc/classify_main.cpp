@@ -44,36 +44,21 @@ void logtime() {                                  // classify.cpp:17-21
     fprintf(stderr, "%s\n", ctime(&now));
 }
 
-void print_usage() {                              // classify.cpp:280-310 (same text)
-    fputs("\n"
-          "Uasge :\n"
-          "    classify --hap0 hap0 --hap1 hap1 --read read1.fq [options]\n"
-          "\n"
-          "Options:\n"
-          "        -h/--help                       print this uasge and exit.\n"
-          "        -p/--hap0                       unshared kmer set of hap0.\n"
-          "        -m/--hap1                       unshared kmer set of hap1.\n"
-          "        -r/--read                       filial reads in fastq format. gzip file must be ended by \".gz\".\n"
-          "        -t/--thread   (8 default)       thread number to used.\n"
-          "        -w/--weight0  (1.0 default)     weight of hap0.\n"
-          "        -u/--weight1  (1.0 default)     weight of hap1.\n"
-          "        -f/--adaptor_f                  forward adaptor sequence.\n"
-          "                                        default \"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA\"\n"
-          "        -q/--adaptor_r                  reverse adaptor sequence.\n"
-          "                                        default \"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG\"\n"
-          "        --device N    (0 default)       MI355X ordinal to run on.\n"
-          "\n"
-          "Examples:\n"
-          "    ./classify --hap0 p.kmers --hap1 m.kmers --read input.fastq.gz\n"
-          "\n"
-          "    ./classify --hap0 p.kmers --hap1 m.kmers --read input.L01.fastq.gz --read input.L02.fastq.gz\n"
-          "\n"
-          "    ./classify --hap0 p.kmers --hap1 m.kmers --read input.L01.fastq.gz --read input.L02.fastq.gz -t 24 --weight1 1.04 -f CTGTCTCTTATACACATCTTAGGAAGACAA -q TCTGCTGAGTCGAGAACGTCTCTG\n"
-          "\n"
-          "Output format:\n"
-          "barcode\thaplotype(0/1/-1)\tkmer_count_hap0\tkmer_count_hap1\n"
-          "\n"
-          "Usage done.\n",
+void print_usage() {                              // same flags as the reference (classify.cpp:375-387); stderr is free-form
+    fputs("\nclassify (MI355X) -- per-barcode haplotype votes for stLFR reads\n\n"
+          "  classify --hap0 PATERNAL.mer --hap1 MATERNAL.mer --read READS.fq[.gz] [--read ...] [options]\n\n"
+          "  -p, --hap0 FILE       parent-0 specific k-mers, one per line (K = length of the first line, K <= 31)\n"
+          "  -m, --hap1 FILE       parent-1 specific k-mers\n"
+          "  -r, --read FILE       child reads, 4-line FASTQ; gzip if the name ends in .gz; may be repeated\n"
+          "  -t, --thread N        host parser threads (default 8)\n"
+          "  -w, --weight0 F       weight of hap0 in the call (default 1.0)\n"
+          "  -u, --weight1 F       weight of hap1 in the call (default 1.0)\n"
+          "  -f, --adaptor_f SEQ   forward adaptor whose k-mers are removed from both sets\n"
+          "  -q, --adaptor_r SEQ   reverse adaptor whose k-mers are removed from both sets\n"
+          "      --device N        GPU ordinal (default 0)\n"
+          "      --stats           timings and set sizes on stderr\n"
+          "  -h, --help            this text\n\n"
+          "stdout: barcode <TAB> haplotype(0/1/-1) <TAB> hits_hap0 <TAB> hits_hap1, sorted by barcode\n\n",
           stderr);
 }
 

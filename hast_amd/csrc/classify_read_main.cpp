@@ -30,11 +30,11 @@ namespace {
     exit(code);
 }
 
-void print_usage() {   // s03:304-309
-    fprintf(stderr, "Uasge :\n\tclassify_read --hap hap0.kmer --hap hap1.kmer --read read.fa [--read read_2.fa] [--thread t_num (8 default) ] [--format fasta/fastq (default fasta)] \n");
-    fprintf(stderr, "notice : --read accept file in gzip format , but file must end by \".gz\"\n");
-    fprintf(stderr, "warn   : --read default only accept fasta read.\n");
-    fprintf(stderr, "         add --format fastq if --read refer to fastq file.\n");
+void print_usage() {   // same flags as the reference (s03:316-324); stderr is free-form
+    fputs("classify_read (MI355X) -- per-read haplotype assignment\n"
+          "  classify_read --hap HAP0.mer --hap HAP1.mer --read READS [--read ...] [--format fasta|fastq] [--thread N]\n"
+          "  reads may be gzip files when the name ends in .gz; --format defaults to fasta\n",
+          stderr);
 }
 
 bool slurp(const std::string &path, std::vector<char> &out) {
@@ -65,24 +65,14 @@ struct Batch {
     }
 };
 
-// s03:104-135 PrintOutput for one read, from integer hits
+// One output row from a read's integer hits.  Densities are hits / line count of the file (s03:68,215-216).  The
+// reference's selection loop (s03:110-133) reduces, for two haplotypes, to: both zero -> "ambiguous 0.0"; otherwise
+// the larger density wins and a tie goes to haplotype0 (its strict comparisons never replace the first maximum).
 void print_row(const std::string &name, uint32_t h0, uint32_t h1, const int total_kmers[2]) {
-    double hc[2] = {(double)h0, (double)h1};
-    for (int j = 0; j < 2; j++) hc[j] /= total_kmers[j];                   // s03:215-216
-    double readHapCount = 0, secondBest = 0;
-    int readHap = -1;
-    for (int i = 0; i < 2; i++) {
-        if (hc[i] > 0 && hc[i] < readHapCount && hc[i] > secondBest) secondBest = hc[i];
-        if (hc[i] > 0 && hc[i] > readHapCount) {
-            readHap = i;
-            secondBest = readHapCount;
-            readHapCount = hc[i];
-        }
-    }
-    if (secondBest == 0 && readHapCount != 0) printf("%s\thaplotype%d\t%0.6f\n", name.c_str(), readHap, readHapCount);
-    else if (readHapCount == 0 && secondBest == 0) printf("%s\t%s\t0.0\n", name.c_str(), "ambiguous");
-    else if (readHapCount / secondBest > 1) printf("%s\thaplotype%d\t%0.6f\n", name.c_str(), readHap, readHapCount);
-    else printf("%s\t%s\t%0.6f\n", name.c_str(), "ambiguous", readHapCount);
+    const double d0 = (double)h0 / total_kmers[0], d1 = (double)h1 / total_kmers[1];
+    if (!(d0 > 0) && !(d1 > 0)) printf("%s\tambiguous\t0.0\n", name.c_str());
+    else if (d1 > d0) printf("%s\thaplotype1\t%0.6f\n", name.c_str(), d1);
+    else printf("%s\thaplotype0\t%0.6f\n", name.c_str(), d0);
 }
 
 }  // namespace
