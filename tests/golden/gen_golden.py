@@ -250,6 +250,29 @@ def case_s03(name, k, n_keys, seed, max_len):
     print("wrote", name)
 
 
+def case_s03_edge():
+    """Corner cases of the stage-03 call logic from the real binary: exact tie, no hits, one-sided hits, read shorter
+    than K, lower-case read, empty FASTA lines, shared k-mer."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "classify_s03")
+    a, b, c, d = "ACGTTGCATCGATTGCAAGTT", "GGATCCATTAGGCATCGATCA", "TTTGACCAGTAGGCATGCATG", "CATGCATGCCCGGGAAATTTA"
+    pad = "AAAAAAAAAAAAAAAAAAAAAAAAA"
+    reads = [("tie", pad + a + pad + b + pad), ("tie_rc", pad + rc(a) + pad + rc(d) + pad), ("none", pad * 3),
+             ("only1", pad + d + pad), ("only0", c), ("short", "ACGT"), ("two0_one1", a + pad + c + pad + b),
+             ("lower", (pad + a).lower()), ("withN", pad + a[:10] + "N" + a[11:] + pad + b)]
+    d_ = os.path.join(HERE, "s03_edge")
+    os.makedirs(d_, exist_ok=True)
+    write(os.path.join(d_, "hap0.mer"), a + "\n" + c + "\n")
+    write(os.path.join(d_, "hap1.mer"), b + "\n" + d + "\n")
+    write(os.path.join(d_, "reads.fa"), "".join(">%s desc\n%s\n\n%s\n" % (n, q[:30], q[30:]) for n, q in reads))
+    argv = ["--hap", "hap0.mer", "--hap", "hap1.mer", "--read", "reads.fa"]
+    out = subprocess.run([ref] + argv, cwd=d_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert out.returncode == 0
+    write(os.path.join(d_, "expected.fasta.tsv"), out.stdout.decode())
+    with open(os.path.join(d_, "case.json"), "w") as f:
+        json.dump({"runs": {"fasta": {"argv": argv, "expected": "expected.fasta.tsv", "program": "s03"}}}, f, indent=1, sort_keys=True)
+    print("wrote s03_edge:", out.stdout.decode().replace("\n", " | "))
+
+
 def case_quartering():
     """Step 10-11 of classify_stlfr_reads.sh (:155-190) run with the reference's own awk program on the rand_k21
     inputs: barcode lists from the reference's phased.barcodes, then quartering_fastq.awk.  Stored: md5 + size of
@@ -320,6 +343,7 @@ def main():
     random_case("rand_k32", 32, 500, 200, 20, seed=32, read_len=120, extra_runs=False)
     case_s03("s03_k21", 21, 300, seed=521, max_len=20000)
     case_s03("s03_k31", 31, 300, seed=531, max_len=9000)
+    case_s03_edge()
     case_quartering()
 
 

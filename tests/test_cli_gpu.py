@@ -121,22 +121,3 @@ def test_classify_read_cli_matches_s03_reference_golden(exe, golden_workdir, cas
                          timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()
-
-
-def test_classify_read_ties_and_zeroes_vs_oracle(exe, oracle_dir, tmp_path):
-    """Call logic of the per-read program on the corner cases: equal densities (the reference's strict comparisons
-    keep haplotype0), no hits (ambiguous 0.0), only one haplotype hit, read shorter than K, empty FASTA lines."""
-    k = 21
-    a, b, c, d = "ACGTTGCAACGTTGCAACGTT", "GGATCCATTAGGCATCGATCA", "TTTGACCAGTAGGCATGCATG", "CATGCATGCCCGGGAAATTTA"
-    (tmp_path / "h0.mer").write_text(a + "\n" + c + "\n")
-    (tmp_path / "h1.mer").write_text(b + "\n" + d + "\n")
-    pad = "AAAAAAAAAAAAAAAAAAAAAAAAA"
-    reads = [("tie", pad + a + pad + b + pad), ("none", pad + pad + pad), ("only1", pad + d + pad), ("only0", c),
-             ("short", "ACGT"), ("two0_one1", a + pad + c + pad + b), ("lower", (pad + a).lower())]
-    (tmp_path / "r.fa").write_text("".join(">%s desc\n%s\n\n%s\n" % (n, s[:30], s[30:]) for n, s in reads))
-    args = ["--hap", "h0.mer", "--hap", "h1.mer", "--read", "r.fa"]
-    ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify_s03")] + args, cwd=tmp_path, stdout=subprocess.PIPE, check=True)
-    got = subprocess.run([hast_amd.classify_read_exe()] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert got.returncode == 0, got.stderr.decode()[-1000:]
-    assert got.stdout == ref.stdout
-    assert b"tie desc\thaplotype0" in got.stdout and b"none desc\tambiguous\t0.0" in got.stdout
