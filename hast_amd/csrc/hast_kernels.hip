@@ -137,11 +137,11 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 //               (hast_common.h), so consecutive windows mostly probe the same 64-B line.
 //   B  probe  : (read, offset) windows are flattened; every LANE owns one window: funnel-shift it out
 //               of two LDS words (no rolling state), canonicalise (v_bfrev), window-min of the m-mer
-//               hashes.  Then 4 rounds: in round j each QUAD takes the window of its lane j (DPP
-//               quad broadcast) and its 4 lanes load the 4 x 16 B of that window's bucket, i.e. one
-//               global_load_dwordx4 wave-instruction = 16 buckets, lanes of a quad coalesced into one
-//               64-B line, adjacent quads = consecutive windows (same line when they share a
-//               minimizer).  kBlocks x 4 loads are in flight per lane.  A bucket is full iff its last
+//               hashes.  Then kLPB rounds: in round j each GROUP of kLPB lanes (a pair by default, a quad
+//               with -DHAST_LPB=4) takes the window of its lane j (DPP quad_perm broadcast) and its lanes
+//               load the 4 x 16 B of that window's bucket between them, i.e. the 64-B line is fetched
+//               once, by adjacent lanes, and adjacent groups = consecutive windows (same line when they
+//               share a minimizer).  kBlocks x 4 loads are in flight per lane.  A bucket is full iff its last
 //               slot is taken (slots fill in order), so "no match and slot.y of some lane empty"
 //               ends the probe; full buckets without a match (rare at load factor 0.25) take the
 //               chain walk.  Hits (about 1 % of windows) go to per-read LDS counters.
@@ -155,7 +155,14 @@ constexpr int kThreads = 256;
 #ifndef HAST_MINWAVES
 #define HAST_MINWAVES 1
 #endif
+#ifndef HAST_LPB
+#define HAST_LPB 2        // measured on C3: pairs 15.4 ms vs quads 16.2 ms per 16M reads (fewer DPP/compare rounds)
+#endif
 constexpr int kBlocks = HAST_KBLOCKS;         // 64-window blocks per wave in flight together
+constexpr int kLPB = HAST_LPB;                // lanes that share one bucket (4: 16 B each, 2: 32 B each)
+constexpr int kRounds = kLPB;                 // rounds per 64-window block (64/kLPB windows per round)
+constexpr int kNLd = 4 / kLPB;                // 16-B loads per lane per round
+constexpr uint32_t kGrpMask = (1u << kLPB) - 1;
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack4(uint32_t x) {
@@ -184,9 +191,11 @@ __device__ __forceinline__ uint64_t window_bits(const unsigned long long *words,
     const unsigned long long x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));       // sh == 0 safe
     return x >> shift_out;
 }
+// value of lane J of my group of kLPB lanes (DPP quad_perm: [J,J,J,J] for quads, [J,J,2+J,2+J] for pairs)
 template <int J>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);   // quad_perm [J,J,J,J]
+    constexpr int ctrl = kLPB == 4 ? J * 0x55 : (J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6));
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xF, 0xF, true);
 }
 
 // WT  = number of m-mers per window (K-m+1) when known at compile time, 0 = runtime loop
@@ -212,9 +221,10 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const uint32_t wave = tid >> 6;
-    const uint32_t sub = tid & 3;                // which 16 B of a bucket this lane loads
+    const uint32_t sub = tid & (kLPB - 1);       // which 16-B piece(s) of a bucket this lane loads: sub, sub+kLPB, ..
     // lane -> window inside a 64-window block, so that in round j quad g holds window 16j+g
-    const uint32_t wofs = 16 * sub + (lane >> 2);
+    const uint32_t wofs = (64 / kLPB) * sub + (lane / kLPB);
+    const uint32_t gsh = lane & ~(uint32_t)(kLPB - 1);               // first lane of my group
     const int K = a.k, M = a.m;
     const uint32_t W = WT ? (uint32_t)WT : (uint32_t)(K - M + 1);
     const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
@@ -222,7 +232,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
-    const u64x2 *tab = reinterpret_cast<const u64x2 *>(a.slots) + sub;     // this lane's 16 B of bucket 0
+    const u64x2 *tab = reinterpret_cast<const u64x2 *>(a.slots) + sub;     // this lane's first 16-B piece of bucket 0
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t r0 = tile * TR;
@@ -330,36 +340,56 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                 o_bkt[u] = ok ? bucket_of_minhash(mn, nb) : 0;       // invalid windows read bucket 0 (harmless)
                 o_meta[u] = r | (ok ? 0x80000000u : 0u);
             }
-            u64x2 sl[kBlocks][4];
+            u64x2 sl[kBlocks][kRounds][kNLd];
 #pragma unroll
             for (int u = 0; u < kBlocks; ++u) {
-                sl[u][0] = tab[(size_t)quad_bcast<0>(o_bkt[u]) * 4];
-                sl[u][1] = tab[(size_t)quad_bcast<1>(o_bkt[u]) * 4];
-                sl[u][2] = tab[(size_t)quad_bcast<2>(o_bkt[u]) * 4];
-                sl[u][3] = tab[(size_t)quad_bcast<3>(o_bkt[u]) * 4];
+                uint32_t bk[kRounds];
+                bk[0] = quad_bcast<0>(o_bkt[u]);
+                bk[1] = quad_bcast<1>(o_bkt[u]);
+                if (kRounds == 4) {
+                    bk[kRounds - 2] = quad_bcast<kRounds == 4 ? 2 : 0>(o_bkt[u]);
+                    bk[kRounds - 1] = quad_bcast<kRounds == 4 ? 3 : 1>(o_bkt[u]);
+                }
+#pragma unroll
+                for (int j = 0; j < kRounds; ++j)
+#pragma unroll
+                    for (int l = 0; l < kNLd; ++l) sl[u][j][l] = tab[(size_t)bk[j] * 4 + l * kLPB];
             }
 #pragma unroll
             for (int u = 0; u < kBlocks; ++u) {
                 // the window's key and read are re-broadcast here rather than kept live across the loads
-                const uint32_t kl[4] = {quad_bcast<0>(o_klo[u]), quad_bcast<1>(o_klo[u]), quad_bcast<2>(o_klo[u]), quad_bcast<3>(o_klo[u])};
-                const uint32_t kh[4] = {quad_bcast<0>(o_khi[u]), quad_bcast<1>(o_khi[u]), quad_bcast<2>(o_khi[u]), quad_bcast<3>(o_khi[u])};
-                const uint32_t mt[4] = {quad_bcast<0>(o_meta[u]), quad_bcast<1>(o_meta[u]), quad_bcast<2>(o_meta[u]), quad_bcast<3>(o_meta[u])};
+                uint32_t kl[kRounds], kh[kRounds], mt[kRounds];
+                kl[0] = quad_bcast<0>(o_klo[u]); kh[0] = quad_bcast<0>(o_khi[u]); mt[0] = quad_bcast<0>(o_meta[u]);
+                kl[1] = quad_bcast<1>(o_klo[u]); kh[1] = quad_bcast<1>(o_khi[u]); mt[1] = quad_bcast<1>(o_meta[u]);
+                if (kRounds == 4) {
+                    constexpr int J2 = kRounds == 4 ? 2 : 0, J3 = kRounds == 4 ? 3 : 1;
+                    kl[kRounds - 2] = quad_bcast<J2>(o_klo[u]); kh[kRounds - 2] = quad_bcast<J2>(o_khi[u]); mt[kRounds - 2] = quad_bcast<J2>(o_meta[u]);
+                    kl[kRounds - 1] = quad_bcast<J3>(o_klo[u]); kh[kRounds - 1] = quad_bcast<J3>(o_khi[u]); mt[kRounds - 1] = quad_bcast<J3>(o_meta[u]);
+                }
                 uint32_t hitmask = 0, fullmask = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < kRounds; ++j) {
                     const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
                     const bool valid = (int)mt[j] < 0;
-                    const bool mx = (sl[u][j].x & ~3ull) == kq, my = (sl[u][j].y & ~3ull) == kq;
-                    if (valid && (mx || my)) hitmask |= 1u << j;
-                    // bucket full <=> its last slot (lane 3's .y) is taken, because slots fill in order
-                    if (valid && sl[u][j].y != kEmptySlot && sub == 3) fullmask |= 1u << j;
+                    bool m = false;
+#pragma unroll
+                    for (int l = 0; l < kNLd; ++l) m = m || (sl[u][j][l].x & ~3ull) == kq || (sl[u][j][l].y & ~3ull) == kq;
+                    if (valid && m) hitmask |= 1u << j;
+                    // bucket full <=> its last slot (last lane of the group, last piece, .y) is taken: slots fill in order
+                    if (valid && sl[u][j][kNLd - 1].y != kEmptySlot && sub == kLPB - 1) fullmask |= 1u << j;
                 }
                 if (hitmask) {                                  // ~1 % of windows
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < kRounds; ++j)
                         if (hitmask & (1u << j)) {
                             const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
-                            const uint32_t tags = (uint32_t)(((sl[u][j].x & ~3ull) == kq ? sl[u][j].x : sl[u][j].y) & 3);
+                            unsigned long long hit_slot = 0;
+#pragma unroll
+                            for (int l = 0; l < kNLd; ++l) {
+                                if ((sl[u][j][l].x & ~3ull) == kq) hit_slot = sl[u][j][l].x;
+                                if ((sl[u][j][l].y & ~3ull) == kq) hit_slot = sl[u][j][l].y;
+                            }
+                            const uint32_t tags = (uint32_t)(hit_slot & 3);
                             atomicAdd(&s_vote[mt[j] & 0xFFFF],
                                       (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
                         }
@@ -368,34 +398,43 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                     // quad-uniform masks: a full bucket needs the chain walk unless some lane of the quad hit
                     uint32_t moremask = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < kRounds; ++j) {
                         const unsigned long long f = __ballot((fullmask >> j) & 1), h = __ballot((hitmask >> j) & 1);
-                        const uint32_t sh = lane & 60;
-                        if (((f >> sh) & 0xF) != 0 && ((h >> sh) & 0xF) == 0) moremask |= 1u << j;
+                        if (((f >> gsh) & kGrpMask) != 0 && ((h >> gsh) & kGrpMask) == 0) moremask |= 1u << j;
                     }
                     while (__any(moremask != 0)) {
                         const bool act = moremask != 0;
                         const uint32_t j = act ? (uint32_t)__ffs(moremask) - 1 : 0;
-                        const int src = (int)((lane & 60) | j);
+                        const int src = (int)(gsh | j);
                         const unsigned long long kq = ((unsigned long long)__shfl((int)o_khi[u], src) << 32) | (uint32_t)__shfl((int)o_klo[u], src);
                         uint32_t b = (uint32_t)__shfl((int)o_bkt[u], src);
                         const uint32_t rd = (uint32_t)__shfl((int)o_meta[u], src) & 0xFFFF;
                         bool pending = act;
                         uint32_t guard = 0;
                         while (__any(pending)) {
-                            u64x2 s2 = {kEmptySlot, kEmptySlot};
+                            u64x2 s2[kNLd];
+#pragma unroll
+                            for (int l = 0; l < kNLd; ++l) s2[l] = u64x2{kEmptySlot, kEmptySlot};
                             if (pending) {
                                 b = (b + 1 == nb) ? 0 : b + 1;
-                                s2 = tab[(size_t)b * 4];
+#pragma unroll
+                                for (int l = 0; l < kNLd; ++l) s2[l] = tab[(size_t)b * 4 + l * kLPB];
                             }
-                            const bool nx = (s2.x & ~3ull) == kq, ny = (s2.y & ~3ull) == kq;
-                            const bool h2 = pending && (nx || ny);
-                            const unsigned long long m2 = __ballot(h2 || (pending && s2.y == kEmptySlot));
+                            unsigned long long hit_slot = 0;
+                            bool h2 = false;
+#pragma unroll
+                            for (int l = 0; l < kNLd; ++l) {
+                                if ((s2[l].x & ~3ull) == kq) { hit_slot = s2[l].x; h2 = true; }
+                                if ((s2[l].y & ~3ull) == kq) { hit_slot = s2[l].y; h2 = true; }
+                            }
+                            h2 = h2 && pending;
+                            // the bucket is not full iff its last slot is empty; any empty .y of the last piece implies it
+                            const unsigned long long m2 = __ballot(h2 || (pending && s2[kNLd - 1].y == kEmptySlot));
                             if (h2) {
-                                const uint32_t tags = (uint32_t)((nx ? s2.x : s2.y) & 3);
+                                const uint32_t tags = (uint32_t)(hit_slot & 3);
                                 atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
                             }
-                            if (((m2 >> (lane & 60)) & 0xF) != 0 || ++guard >= nb) pending = false;
+                            if (((m2 >> gsh) & kGrpMask) != 0 || ++guard >= nb) pending = false;
                         }
                         moremask &= moremask - 1;
                     }
