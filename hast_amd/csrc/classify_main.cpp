@@ -337,7 +337,7 @@ int main(int argc, char **argv) {
             data = carry.data();
             len = carry.size();
         } else if (carry.size() <= kPad) {
-            memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());   // in front, no block copy
+            if (!carry.empty()) memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());   // in front, no block copy
             data = blk.data() + kPad - carry.size();
             len = blk.size() - kPad + carry.size();
         } else {                                                                     // giant record: slow path

@@ -134,7 +134,7 @@ int main(int argc, char **argv) {
         size_t len;
         if (last) { data = carry.data(); len = carry.size(); }
         else if (carry.size() <= kPad) {
-            memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());
+            if (!carry.empty()) memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());
             data = blk.data() + kPad - carry.size();
             len = blk.size() - kPad + carry.size();
         } else {

@@ -12,7 +12,7 @@ import pytest
 import hast_amd
 from tests.conftest import GOLDEN, ROOT
 
-EXE = os.path.join(ROOT, "hast_amd", "quartering_fastq")
+EXE = os.environ.get("HAST_QUARTERING_EXE") or os.path.join(ROOT, "hast_amd", "quartering_fastq")
 
 
 @pytest.fixture(scope="module")
