@@ -431,7 +431,9 @@ hast_status hast_counts_read(hast_ctx *c, uint32_t *c0, uint32_t *c1, uint32_t *
 // RCCL, resolved lazily so that single-GPU users never load it.
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
     if (!ctxs || n < 1) return fail(HAST_ERR_INVALID, "no contexts");
-    if (n == 1) return HAST_OK;
+    // a single context needs no exchange; HAST_FORCE_RCCL=1 still runs the RCCL path (1-rank communicator), which
+    // is how a 1-GPU box checks the library loading, symbols and enum values used for N > 1
+    if (n == 1 && !getenv("HAST_FORCE_RCCL")) return HAST_OK;
     typedef void *comm_t;
     typedef int (*init_all_t)(comm_t *, int, const int *);
     typedef int (*allreduce_t)(const void *, void *, size_t, int, int, comm_t, hipStream_t);

@@ -424,3 +424,26 @@ def test_perread_rows_match_s03_reference_golden(built, oracle_lib, golden_workd
         out += buf.raw[:n]
     oracle_lib.ho_s03_free(oc)
     assert out == open(d / "expected.fasta.tsv", "rb").read()
+
+
+def test_counts_allreduce_rccl_path_single_rank(built, monkeypatch):
+    """hast_counts_allreduce over RCCL with a 1-rank communicator (HAST_FORCE_RCCL=1): checks dlopen of librccl, the
+    symbols and the ncclUint32/ncclSum enum values used by the N>1 merge; the sum over one rank is the identity."""
+    monkeypatch.setenv("HAST_FORCE_RCCL", "1")
+    k, L, n_keys, n_bc, n = 21, 150, 5000, 64, 4000
+    p = make_params(k, L, n_keys, n_bc)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.synth_table_build(p)
+        ctx.counts_resize(n_bc)
+        d_b, d_i = ctx.alloc(n * L), ctx.alloc(n * 4)
+        ctx.synth_reads_device(p, 0, n, d_b, d_i)
+        ctx.classify_device(d_b, n * L, n, L, d_barcode_ids=d_i)
+        before = ctx.counts_read(n_bc)
+        arr = (C.c_void_p * 1)(ctx._h)
+        st = hast_amd.lib().hast_counts_allreduce(arr, 1)
+        assert st == 0, hast_amd.lib().hast_last_error()
+        after = ctx.counts_read(n_bc)
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+    assert int(before[0].sum()) > 0
