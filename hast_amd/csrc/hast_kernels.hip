@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 //               with -DHAST_LPB=4) takes the window of its lane j (DPP quad_perm broadcast) and its lanes
 //               load the 4 x 16 B of that window's bucket between them, i.e. the 64-B line is fetched
 //               once, by adjacent lanes, and adjacent groups = consecutive windows (same line when they
-//               share a minimizer).  kBlocks x 4 loads are in flight per lane.  A bucket is full iff its last
+//               share a minimizer).  Blocks are software-pipelined: 4..8 loads in flight per lane.  A bucket is full iff its last
 //               slot is taken (slots fill in order), so "no match and slot.y of some lane empty"
 //               ends the probe; full buckets without a match (rare at load factor 0.25) take the
 //               chain walk.  Hits (about 1 % of windows) go to per-read LDS counters.
@@ -149,16 +149,12 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 //               ({c0,c1} as a single u64 add, or neg++; classify.cpp:203-208).
 // ------------------------------------------------------------------------------------------
 constexpr int kThreads = 256;
-#ifndef HAST_KBLOCKS
-#define HAST_KBLOCKS 2
-#endif
 #ifndef HAST_MINWAVES
 #define HAST_MINWAVES 1
 #endif
 #ifndef HAST_LPB
 #define HAST_LPB 2        // measured on C3: pairs 15.4 ms vs quads 16.2 ms per 16M reads (fewer DPP/compare rounds)
 #endif
-constexpr int kBlocks = HAST_KBLOCKS;         // 64-window blocks per wave in flight together
 constexpr int kLPB = HAST_LPB;                // lanes that share one bucket (4: 16 B each, 2: 32 B each)
 constexpr int kRounds = kLPB;                 // rounds per 64-window block (64/kLPB windows per round)
 constexpr int kNLd = 4 / kLPB;                // 16-B loads per lane per round
@@ -307,138 +303,153 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             __syncthreads();
         }
 
-        // ---- B: probe.  Each wave walks 64-window blocks b = wave, wave+4, ... two at a time -------
+        // ---- B: probe.  Each wave walks the 64-window blocks wave, wave+4, ... -----------------------
         const uint32_t P = a.max_pos;                                 // windows per read (stride)
         const uint32_t Q = tra * P;
         const uint32_t nblk = (Q + 63) >> 6;
-        for (uint32_t b0 = wave; b0 < nblk; b0 += 4 * kBlocks) {
-            uint32_t o_klo[kBlocks], o_khi[kBlocks], o_bkt[kBlocks], o_meta[kBlocks];   // this lane's own window
-#pragma unroll
-            for (int u = 0; u < kBlocks; ++u) {
-                const uint32_t q = (b0 + 4 * u) * 64 + wofs;
-                uint32_t r = FAST ? __umulhi(q, a.div_magic) : (q / P);
-                const bool inq = q < Q;
-                r = inq ? r : 0;
-                const uint32_t p = inq ? q - r * P : 0;
-                bool ok = inq && (p + K <= s_len[r]);
-                if (STRICT) {       // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
-                    const uint32_t *iw = s_inv + r * IW + (p >> 5);
-                    const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
-                    ok = ok && (bits >> (64 - K)) == 0;
-                }
-                const uint64_t ck = kmer_canon(window_bits(s_pack + (size_t)r * WS, p, kshift), K);
-                const uint32_t *mh = s_mh + r * MS + p;
-                uint32_t mn = mh[0];
-                if (WT) {
-#pragma unroll
-                    for (int j = 1; j < (WT ? WT : 1); ++j) mn = min(mn, mh[j]);
-                } else {
-                    for (uint32_t j = 1; j < W; ++j) mn = min(mn, mh[j]);
-                }
-                o_klo[u] = (uint32_t)(ck << 2);
-                o_khi[u] = (uint32_t)(ck >> 30);
-                o_bkt[u] = ok ? bucket_of_minhash(mn, nb) : 0;       // invalid windows read bucket 0 (harmless)
-                o_meta[u] = r | (ok ? 0x80000000u : 0u);
+        // Software pipeline over the wave's blocks: the loads of block i+1 are issued (after its windows are
+        // computed) BEFORE block i is compared, so a wave always has 4..8 bucket loads in flight while it does
+        // VALU work, instead of alternating "compute with nothing in flight" and "wait".
+        struct Blk {
+            uint32_t klo, khi, bkt, meta;               // this lane's own window
+            u64x2 sl[kRounds][kNLd];                    // the bucket pieces this lane loaded, per round
+        };
+        auto start = [&](Blk &B, uint32_t blk) {
+            const uint32_t q = blk * 64 + wofs;
+            uint32_t r = FAST ? __umulhi(q, a.div_magic) : (q / P);
+            const bool inq = q < Q;
+            r = inq ? r : 0;
+            const uint32_t p = inq ? q - r * P : 0;
+            bool ok = inq && (p + K <= s_len[r]);
+            if (STRICT) {           // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
+                const uint32_t *iw = s_inv + r * IW + (p >> 5);
+                const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
+                ok = ok && (bits >> (64 - K)) == 0;
             }
-            u64x2 sl[kBlocks][kRounds][kNLd];
+            const uint64_t ck = kmer_canon(window_bits(s_pack + (size_t)r * WS, p, kshift), K);
+            const uint32_t *mh = s_mh + r * MS + p;
+            uint32_t mn = mh[0];
+            if (WT) {
 #pragma unroll
-            for (int u = 0; u < kBlocks; ++u) {
-                uint32_t bk[kRounds];
-                bk[0] = quad_bcast<0>(o_bkt[u]);
-                bk[1] = quad_bcast<1>(o_bkt[u]);
-                if (kRounds == 4) {
-                    bk[kRounds - 2] = quad_bcast<kRounds == 4 ? 2 : 0>(o_bkt[u]);
-                    bk[kRounds - 1] = quad_bcast<kRounds == 4 ? 3 : 1>(o_bkt[u]);
-                }
+                for (int j = 1; j < (WT ? WT : 1); ++j) mn = min(mn, mh[j]);
+            } else {
+                for (uint32_t j = 1; j < W; ++j) mn = min(mn, mh[j]);
+            }
+            B.klo = (uint32_t)(ck << 2);
+            B.khi = (uint32_t)(ck >> 30);
+            B.bkt = ok ? bucket_of_minhash(mn, nb) : 0;              // invalid windows read bucket 0 (harmless)
+            B.meta = r | (ok ? 0x80000000u : 0u);
+            uint32_t bk[kRounds];
+            bk[0] = quad_bcast<0>(B.bkt);
+            bk[1] = quad_bcast<1>(B.bkt);
+            if (kRounds == 4) {
+                bk[kRounds - 2] = quad_bcast<kRounds == 4 ? 2 : 0>(B.bkt);
+                bk[kRounds - 1] = quad_bcast<kRounds == 4 ? 3 : 1>(B.bkt);
+            }
+#pragma unroll
+            for (int j = 0; j < kRounds; ++j)
+#pragma unroll
+                for (int l = 0; l < kNLd; ++l) B.sl[j][l] = tab[(size_t)bk[j] * 4 + l * kLPB];
+        };
+        auto finish = [&](Blk &B) {
+            // the window's key and read are re-broadcast here rather than kept live across the loads
+            uint32_t kl[kRounds], kh[kRounds], mt[kRounds];
+            kl[0] = quad_bcast<0>(B.klo); kh[0] = quad_bcast<0>(B.khi); mt[0] = quad_bcast<0>(B.meta);
+            kl[1] = quad_bcast<1>(B.klo); kh[1] = quad_bcast<1>(B.khi); mt[1] = quad_bcast<1>(B.meta);
+            if (kRounds == 4) {
+                constexpr int J2 = kRounds == 4 ? 2 : 0, J3 = kRounds == 4 ? 3 : 1;
+                kl[kRounds - 2] = quad_bcast<J2>(B.klo); kh[kRounds - 2] = quad_bcast<J2>(B.khi); mt[kRounds - 2] = quad_bcast<J2>(B.meta);
+                kl[kRounds - 1] = quad_bcast<J3>(B.klo); kh[kRounds - 1] = quad_bcast<J3>(B.khi); mt[kRounds - 1] = quad_bcast<J3>(B.meta);
+            }
+            uint32_t hitmask = 0, fullmask = 0;
+#pragma unroll
+            for (int j = 0; j < kRounds; ++j) {
+                const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
+                const bool valid = (int)mt[j] < 0;
+                bool m = false;
+#pragma unroll
+                for (int l = 0; l < kNLd; ++l) m = m || (B.sl[j][l].x & ~3ull) == kq || (B.sl[j][l].y & ~3ull) == kq;
+                if (valid && m) hitmask |= 1u << j;
+                // bucket full <=> its last slot (last lane of the group, last piece, .y) is taken: slots fill in order
+                if (valid && B.sl[j][kNLd - 1].y != kEmptySlot && sub == kLPB - 1) fullmask |= 1u << j;
+            }
+            if (hitmask) {                                      // ~1 % of windows
 #pragma unroll
                 for (int j = 0; j < kRounds; ++j)
+                    if (hitmask & (1u << j)) {
+                        const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
+                        unsigned long long hit_slot = 0;
 #pragma unroll
-                    for (int l = 0; l < kNLd; ++l) sl[u][j][l] = tab[(size_t)bk[j] * 4 + l * kLPB];
+                        for (int l = 0; l < kNLd; ++l) {
+                            if ((B.sl[j][l].x & ~3ull) == kq) hit_slot = B.sl[j][l].x;
+                            if ((B.sl[j][l].y & ~3ull) == kq) hit_slot = B.sl[j][l].y;
+                        }
+                        const uint32_t tags = (uint32_t)(hit_slot & 3);
+                        atomicAdd(&s_vote[mt[j] & 0xFFFF], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+                    }
             }
-#pragma unroll
-            for (int u = 0; u < kBlocks; ++u) {
-                // the window's key and read are re-broadcast here rather than kept live across the loads
-                uint32_t kl[kRounds], kh[kRounds], mt[kRounds];
-                kl[0] = quad_bcast<0>(o_klo[u]); kh[0] = quad_bcast<0>(o_khi[u]); mt[0] = quad_bcast<0>(o_meta[u]);
-                kl[1] = quad_bcast<1>(o_klo[u]); kh[1] = quad_bcast<1>(o_khi[u]); mt[1] = quad_bcast<1>(o_meta[u]);
-                if (kRounds == 4) {
-                    constexpr int J2 = kRounds == 4 ? 2 : 0, J3 = kRounds == 4 ? 3 : 1;
-                    kl[kRounds - 2] = quad_bcast<J2>(o_klo[u]); kh[kRounds - 2] = quad_bcast<J2>(o_khi[u]); mt[kRounds - 2] = quad_bcast<J2>(o_meta[u]);
-                    kl[kRounds - 1] = quad_bcast<J3>(o_klo[u]); kh[kRounds - 1] = quad_bcast<J3>(o_khi[u]); mt[kRounds - 1] = quad_bcast<J3>(o_meta[u]);
-                }
-                uint32_t hitmask = 0, fullmask = 0;
+            if (__any(fullmask != 0)) {                         // some bucket of this block is full (rare at LF 0.2)
+                // group-uniform masks: a full bucket needs the chain walk unless some lane of the group hit
+                uint32_t moremask = 0;
 #pragma unroll
                 for (int j = 0; j < kRounds; ++j) {
-                    const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
-                    const bool valid = (int)mt[j] < 0;
-                    bool m = false;
-#pragma unroll
-                    for (int l = 0; l < kNLd; ++l) m = m || (sl[u][j][l].x & ~3ull) == kq || (sl[u][j][l].y & ~3ull) == kq;
-                    if (valid && m) hitmask |= 1u << j;
-                    // bucket full <=> its last slot (last lane of the group, last piece, .y) is taken: slots fill in order
-                    if (valid && sl[u][j][kNLd - 1].y != kEmptySlot && sub == kLPB - 1) fullmask |= 1u << j;
+                    const unsigned long long f = __ballot((fullmask >> j) & 1), h = __ballot((hitmask >> j) & 1);
+                    if (((f >> gsh) & kGrpMask) != 0 && ((h >> gsh) & kGrpMask) == 0) moremask |= 1u << j;
                 }
-                if (hitmask) {                                  // ~1 % of windows
+                while (__any(moremask != 0)) {
+                    const bool act = moremask != 0;
+                    const uint32_t j = act ? (uint32_t)__ffs(moremask) - 1 : 0;
+                    const int src = (int)(gsh | j);
+                    const unsigned long long kq = ((unsigned long long)__shfl((int)B.khi, src) << 32) | (uint32_t)__shfl((int)B.klo, src);
+                    uint32_t b = (uint32_t)__shfl((int)B.bkt, src);
+                    const uint32_t rd = (uint32_t)__shfl((int)B.meta, src) & 0xFFFF;
+                    bool pending = act;
+                    uint32_t guard = 0;
+                    while (__any(pending)) {
+                        u64x2 s2[kNLd];
 #pragma unroll
-                    for (int j = 0; j < kRounds; ++j)
-                        if (hitmask & (1u << j)) {
-                            const unsigned long long kq = ((unsigned long long)kh[j] << 32) | kl[j];
-                            unsigned long long hit_slot = 0;
+                        for (int l = 0; l < kNLd; ++l) s2[l] = u64x2{kEmptySlot, kEmptySlot};
+                        if (pending) {
+                            b = (b + 1 == nb) ? 0 : b + 1;
 #pragma unroll
-                            for (int l = 0; l < kNLd; ++l) {
-                                if ((sl[u][j][l].x & ~3ull) == kq) hit_slot = sl[u][j][l].x;
-                                if ((sl[u][j][l].y & ~3ull) == kq) hit_slot = sl[u][j][l].y;
-                            }
+                            for (int l = 0; l < kNLd; ++l) s2[l] = tab[(size_t)b * 4 + l * kLPB];
+                        }
+                        unsigned long long hit_slot = 0;
+                        bool h2 = false;
+#pragma unroll
+                        for (int l = 0; l < kNLd; ++l) {
+                            if ((s2[l].x & ~3ull) == kq) { hit_slot = s2[l].x; h2 = true; }
+                            if ((s2[l].y & ~3ull) == kq) { hit_slot = s2[l].y; h2 = true; }
+                        }
+                        h2 = h2 && pending;
+                        // the bucket is not full iff its last slot is empty; any empty .y of the last piece implies it
+                        const unsigned long long m2 = __ballot(h2 || (pending && s2[kNLd - 1].y == kEmptySlot));
+                        if (h2) {
                             const uint32_t tags = (uint32_t)(hit_slot & 3);
-                            atomicAdd(&s_vote[mt[j] & 0xFFFF],
-                                      (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+                            atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
                         }
-                }
-                if (__any(fullmask != 0)) {                     // some bucket of this block is full (rare at LF 0.25)
-                    // quad-uniform masks: a full bucket needs the chain walk unless some lane of the quad hit
-                    uint32_t moremask = 0;
-#pragma unroll
-                    for (int j = 0; j < kRounds; ++j) {
-                        const unsigned long long f = __ballot((fullmask >> j) & 1), h = __ballot((hitmask >> j) & 1);
-                        if (((f >> gsh) & kGrpMask) != 0 && ((h >> gsh) & kGrpMask) == 0) moremask |= 1u << j;
+                        if (((m2 >> gsh) & kGrpMask) != 0 || ++guard >= nb) pending = false;
                     }
-                    while (__any(moremask != 0)) {
-                        const bool act = moremask != 0;
-                        const uint32_t j = act ? (uint32_t)__ffs(moremask) - 1 : 0;
-                        const int src = (int)(gsh | j);
-                        const unsigned long long kq = ((unsigned long long)__shfl((int)o_khi[u], src) << 32) | (uint32_t)__shfl((int)o_klo[u], src);
-                        uint32_t b = (uint32_t)__shfl((int)o_bkt[u], src);
-                        const uint32_t rd = (uint32_t)__shfl((int)o_meta[u], src) & 0xFFFF;
-                        bool pending = act;
-                        uint32_t guard = 0;
-                        while (__any(pending)) {
-                            u64x2 s2[kNLd];
-#pragma unroll
-                            for (int l = 0; l < kNLd; ++l) s2[l] = u64x2{kEmptySlot, kEmptySlot};
-                            if (pending) {
-                                b = (b + 1 == nb) ? 0 : b + 1;
-#pragma unroll
-                                for (int l = 0; l < kNLd; ++l) s2[l] = tab[(size_t)b * 4 + l * kLPB];
-                            }
-                            unsigned long long hit_slot = 0;
-                            bool h2 = false;
-#pragma unroll
-                            for (int l = 0; l < kNLd; ++l) {
-                                if ((s2[l].x & ~3ull) == kq) { hit_slot = s2[l].x; h2 = true; }
-                                if ((s2[l].y & ~3ull) == kq) { hit_slot = s2[l].y; h2 = true; }
-                            }
-                            h2 = h2 && pending;
-                            // the bucket is not full iff its last slot is empty; any empty .y of the last piece implies it
-                            const unsigned long long m2 = __ballot(h2 || (pending && s2[kNLd - 1].y == kEmptySlot));
-                            if (h2) {
-                                const uint32_t tags = (uint32_t)(hit_slot & 3);
-                                atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
-                            }
-                            if (((m2 >> gsh) & kGrpMask) != 0 || ++guard >= nb) pending = false;
-                        }
-                        moremask &= moremask - 1;
-                    }
+                    moremask &= moremask - 1;
                 }
+            }
+        };
+        {
+            Blk A, B;
+            uint32_t blk = wave;
+            bool va = blk < nblk;
+            if (va) start(A, blk);
+            blk += 4;
+            while (va) {
+                const bool vb = blk < nblk;
+                if (vb) start(B, blk);
+                blk += 4;
+                finish(A);
+                if (!vb) break;
+                va = blk < nblk;
+                if (va) start(A, blk);
+                blk += 4;
+                finish(B);
             }
         }
         __syncthreads();
