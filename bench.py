@@ -219,7 +219,15 @@ def main():
         }
         traffic = _committed_traffic(args, R)
         if traffic:
-            result["roofline"].update(traffic)
+            rf = result["roofline"]
+            rf.update(traffic)
+            # what the kernel really moves, next to the algorithmic figure: bytes/s of HBM traffic, and 64-B
+            # requests/s against the measured random-line ceiling of this chip (tools/hbm_randread: ~48 G lines/s)
+            rf["traffic_GBps"] = traffic["traffic"] / (kern_avg_ms * 1e-3) / 1e9
+            if traffic.get("hbm_read_requests_per_launch"):
+                rf["hbm_lines_per_s"] = traffic["hbm_read_requests_per_launch"] / (kern_avg_ms * 1e-3)
+                rf["hbm_line_rate_ceiling"] = 48e9
+                rf["hbm_line_rate_frac"] = rf["hbm_lines_per_s"] / 48e9
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle's port on this box's host cores -----------------
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -244,7 +252,10 @@ def _committed_traffic(args, R):
         return None
     if d.get("workload") != args.workload or d.get("batch_reads") != R:
         return None
-    return {"traffic": d.get("hbm_bytes_per_launch"), "traffic_source": d.get("source")}
+    out = {"traffic": d.get("hbm_bytes_per_launch"), "traffic_source": d.get("source")}
+    if d.get("hbm_read_requests_per_launch"):
+        out["hbm_read_requests_per_launch"] = d["hbm_read_requests_per_launch"]
+    return out
 
 
 def cpu_baseline(args, ctx, p, batch0, set_sizes, hs, stream):

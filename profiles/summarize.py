@@ -58,6 +58,7 @@ summary = {
 }
 json.dump(summary, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 json.dump({"workload": "c3", "batch_reads": bench["config"]["batch_reads"], "hbm_bytes_per_launch": fetch + write,
+           "hbm_read_requests_per_launch": pmc[kc].get("TCC_EA0_RDREQ_sum"),
            "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on tools/hbm_randread)" % tag},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 if os.path.exists("gpurun_out/randread.jsonl"):
