@@ -447,3 +447,43 @@ def test_counts_allreduce_rccl_path_single_rank(built, monkeypatch):
     for a, b in zip(before, after):
         assert np.array_equal(a, b)
     assert int(before[0].sum()) > 0
+
+
+@pytest.mark.parametrize("k,n_keys,L,n_reads", [(21, 200_000_000, 150, 2_000_000), (31, 400_000_000, 5000, 40_000)])
+def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
+    """BASELINE-size tables (C3: 200M+200M 21-mers, 16 GB; C5: 400M+400M 31-mers, 32 GB -- slot indices beyond 2^32
+    bytes and 2^31 slots): results must not depend on where keys live.  The same reads are classified against a table
+    placed by the default minimizer and against one placed by plain hashing of the key (m = K), in one batch and
+    split in two; set sizes, per-read votes and per-barcode counts must be identical, and hits must exist."""
+    n_bc = 100_000
+    p = make_params(k, L, n_keys, n_bc)
+    results = []
+    for m in (None, k):
+        with hast_amd.Context(k, minimizer=m) as ctx:
+            ctx.table_reserve(2 * n_keys)
+            ctx.synth_table_build(p)
+            sizes = ctx.table_sizes()
+            ctx.counts_resize(n_bc)
+            d_b, d_i, d_v = ctx.alloc(n_reads * L), ctx.alloc(n_reads * 4), ctx.alloc(n_reads * 8)
+            ctx.synth_reads_device(p, 777, n_reads, d_b, d_i)
+            ctx.classify_device(d_b, n_reads * L, n_reads, L, d_barcode_ids=d_i, d_votes=d_v)
+            whole = ctx.counts_read(n_bc)
+            votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+            ctx.counts_zero()
+            h = n_reads // 3
+            ctx.classify_device(d_b, n_reads * L, h, L, d_barcode_ids=d_i)
+            ctx.classify_device(d_b + h * L, (n_reads - h) * L, n_reads - h, L, d_barcode_ids=d_i + 4 * h)
+            parts = ctx.counts_read(n_bc)
+            for w, q in zip(whole, parts):
+                assert np.array_equal(w, q)
+            ids = ctx.to_host(d_i, (n_reads,), np.uint32)
+            for f in (d_b, d_i, d_v):
+                ctx.free(f)
+        assert np.array_equal(np.bincount(ids, weights=votes[:, 0], minlength=n_bc).astype(np.uint32), whole[0])
+        results.append((sizes, votes, whole))
+    (s0, v0, w0), (s1, v1, w1) = results
+    assert s0 == s1 and abs(s0[0] - n_keys) < n_keys // 1000
+    assert np.array_equal(v0, v1)
+    for a, b in zip(w0, w1):
+        assert np.array_equal(a, b)
+    assert int(v0.sum()) > n_reads // 2
