@@ -1,6 +1,6 @@
 #!/bin/bash
-# End-to-end (M2) measurement of the drop-in CLI against the REAL reference binary on the same files,
-# run on the GPU box through gpurun:   bash tools/cli_e2e.sh [n_pairs] [keys_per_hap] [barcodes] [tag]
+# TEST INFRASTRUCTURE (it executes oracle/_ref, the real reference binaries): end-to-end (M2) measurement of the drop-in CLI against the REAL reference binary on the same files,
+# run on the GPU box through gpurun:   bash tests/e2e/cli_e2e.sh [n_pairs] [keys_per_hap] [barcodes] [tag]
 # Generates the synthetic C1-style inputs (tools/gen_fastq), runs oracle/_ref/classify (as shipped, -g) and
 # classify_O2 on the host cores, then hast_amd/classify at several -t, compares stdout md5, and writes
 # gpurun_out/cli_e2e_<tag>.json.  File I/O + parse + H2D are inside every timing (this is not the bench metric).
