@@ -487,3 +487,50 @@ def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
     for a, b in zip(w0, w1):
         assert np.array_equal(a, b)
     assert int(v0.sum()) > n_reads // 2
+
+
+def test_randomized_configurations_vs_oracle(built, oracle_lib):
+    """Differential fuzz over the kernel's configuration space: K, minimizer length (incl. W > 9 -> runtime-loop
+    instantiation), load factor (chain walks), fixed lengths down to L == K (plain-division instantiation), ragged
+    lengths, tile tails.  Per-read votes and per-barcode counts must equal the oracle's in every configuration."""
+    rng = random.Random(20261003)
+    for it in range(36):
+        k = rng.choice([3, 8, 12, 16, 19, 21, 24, 28, 31])
+        m = rng.choice([1, max(1, k - 12), max(1, k - 5), k - 1 if k > 1 else 1, k])
+        lf = rng.choice([0.2, 0.5, 0.85])
+        fixed = rng.random() < 0.5
+        L = rng.choice([k, k + 1, k + 7, 64, 100, 151, 257]) if fixed else rng.randint(k + 1, 400)
+        n_keys = rng.choice([50, 2000, 20000]) if k >= 8 else 20
+        n_bc = rng.choice([1, 7, 300])
+        n_reads = rng.choice([1, 63, 64, 1000, 4097])
+        p = make_params(k, L, n_keys, n_bc, seed_k=rng.getrandbits(40) | 1, seed_r=rng.getrandbits(40) | 1, seed_b=rng.getrandbits(40) | 1)
+        keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+        oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+        if fixed:
+            bases, ids = hast_amd.synth_reads_host(p, rng.randrange(10 ** 6), n_reads)
+            off = np.arange(n_reads + 1, dtype=np.uint64) * L
+        else:
+            seqs = ragged_reads(rng, k, np.concatenate(keys), n_reads, L)
+            lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            bases = np.frombuffer(b"".join(seqs) + b"A", dtype=np.uint8)[:-1].copy()
+            ids = np.array([rng.randrange(n_bc) for _ in seqs], dtype=np.uint32)
+            L = max(1, int(lens.max())) if len(seqs) else 1
+        cfg = dict(it=it, k=k, m=m, lf=lf, fixed=fixed, L=L, n_keys=n_keys, n_bc=n_bc, n_reads=n_reads)
+        with hast_amd.Context(k, minimizer=m) as ctx:
+            ctx.table_reserve(2 * n_keys, lf)
+            ctx.table_insert_keys(0, keys[0])
+            ctx.table_insert_keys(1, keys[1])
+            assert ctx.table_sizes() == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1)), cfg
+            ctx.counts_resize(n_bc)
+            d_b, d_i, d_v = ctx.to_device(bases), ctx.to_device(ids), ctx.alloc(max(1, n_reads) * 8)
+            d_o = None if fixed else ctx.to_device(off)
+            ctx.classify_device(d_b, bases.size, n_reads, L, d_offsets=d_o, d_barcode_ids=d_i, d_votes=d_v)
+            ctx.sync()
+            got = ctx.counts_read(n_bc)
+            votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+        exp = oracle_counts(oracle_lib, oc, bases if bases.size else np.zeros(1, np.uint8), off, ids, n_bc, threads=2)
+        assert np.array_equal(votes, oracle_votes(oracle_lib, oc, bases, off)), cfg
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e), cfg
+        oracle_lib.ho_free(oc)
