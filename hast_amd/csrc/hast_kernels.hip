@@ -218,8 +218,9 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint32_t lane = tid & 63;
     const uint32_t wave = tid >> 6;
     const uint32_t sub = tid & (kLPB - 1);       // which 16-B piece(s) of a bucket this lane loads: sub, sub+kLPB, ..
-    // lane -> window inside a 64-window block, so that in round j quad g holds window 16j+g
-    const uint32_t wofs = (64 / kLPB) * sub + (lane / kLPB);
+    // lane -> window inside a 64-window block, so that in round j adjacent groups hold consecutive windows
+    // (each half-wave owns 32 CONSECUTIVE windows, so its ds_read_b32 of the m-mer hashes hit 32 different banks)
+    const uint32_t wofs = 32 * (lane >> 5) + (32 / kLPB) * sub + ((lane & 31) / kLPB);
     const uint32_t gsh = lane & ~(uint32_t)(kLPB - 1);               // first lane of my group
     const int K = a.k, M = a.m;
     const uint32_t W = WT ? (uint32_t)WT : (uint32_t)(K - M + 1);
