@@ -43,6 +43,9 @@ ABI_SYMBOLS = {
     "hast_table_erase": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "hast_table_sizes": (C.c_int, [vp, u64p, u64p]),
     "hast_table_lookup": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "hast_table_save": (C.c_int, [vp, C.c_char_p]),
+    "hast_table_load": (C.c_int, [vp, C.c_char_p, C.c_double]),
+    "hast_table_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), u64p]),
     "hast_table_info": (C.c_int, [vp, u64p, u64p]),
     "hast_counts_resize": (C.c_int, [vp, C.c_size_t]),
     "hast_counts_bind": (C.c_int, [vp, vp, C.c_size_t]),
@@ -267,6 +270,12 @@ class Context:
         tags = np.zeros(keys.size, dtype=np.uint8)
         _ck(self._lib.hast_table_lookup(self._h, _ptr(keys), keys.size, _ptr(tags)))
         return tags
+
+    def table_save(self, path):
+        _ck(self._lib.hast_table_save(self._h, os.fsencode(path)))
+
+    def table_load(self, path, load_factor=0.0):
+        _ck(self._lib.hast_table_load(self._h, os.fsencode(path), load_factor))
 
     def table_info(self):
         a, b = C.c_uint64(), C.c_uint64()

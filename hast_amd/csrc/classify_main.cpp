@@ -56,6 +56,8 @@ void print_usage() {                              // same flags as the reference
           "  -f, --adaptor_f SEQ   forward adaptor whose k-mers are removed from both sets\n"
           "  -q, --adaptor_r SEQ   reverse adaptor whose k-mers are removed from both sets\n"
           "      --device N        GPU ordinal (default 0)\n"
+          "      --save-table FILE write the built k-mer table (after the adaptor scrub) as a binary key set\n"
+          "      --load-table FILE use such a file instead of --hap0/--hap1\n"
           "      --stats           timings and set sizes on stderr\n"
           "  -h, --help            this text\n\n"
           "stdout: barcode <TAB> haplotype(0/1/-1) <TAB> hits_hap0 <TAB> hits_hap1, sorted by barcode\n\n",
@@ -140,9 +142,10 @@ int main(int argc, char **argv) {
         {"help", no_argument, NULL, 'h'},            {"device", required_argument, NULL, 1001},
         {"batch-reads", required_argument, NULL, 1002}, {"stats", no_argument, NULL, 1003},
         {"block-mb", required_argument, NULL, 1004},    {"initial-barcodes", required_argument, NULL, 1005},
+        {"save-table", required_argument, NULL, 1006},  {"load-table", required_argument, NULL, 1007},
         {0, 0, 0, 0}};
     static char optstring[] = "p:m:l:r:t:w:u:f:q:h";             // classify.cpp:387
-    std::string hap0, hap1;
+    std::string hap0, hap1, save_table, load_table;
     std::string r1("CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA");   // classify.cpp:312
     std::string r2("TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG");   // classify.cpp:313
     std::vector<std::string> read;
@@ -167,11 +170,13 @@ int main(int argc, char **argv) {
         case 1003: stats = true; break;
         case 1004: block_mb = (size_t)std::max(1L, atol(optarg)); break;
         case 1005: initial_barcodes = (size_t)std::max(1L, atol(optarg)); break;
+        case 1006: save_table = optarg; break;
+        case 1007: load_table = optarg; break;
         case 'h':
         default: print_usage(); return -1;
         }
     }
-    if (hap0.empty() || hap1.empty() || read.empty() || t_num < 1) {   // classify.cpp:425-428
+    if (((hap0.empty() || hap1.empty()) && load_table.empty()) || read.empty() || t_num < 1) {   // classify.cpp:425-428
         print_usage();
         return -1;
     }
@@ -182,16 +187,28 @@ int main(int argc, char **argv) {
     const double t_start = now_s();
 
     // ---- load_kmers (classify.cpp:30-46): both files to memory, table built on the GPU --------
+    size_t K = 0;
+    hast_ctx *ctx = nullptr;
+    double t_loaded = 0;
+    if (!load_table.empty()) {
+        // binary key-set cache written by --save-table (both sets, after the adaptor scrub of that run)
+        int kk = 0;
+        if (hast_table_file_info(load_table.c_str(), &kk, nullptr) != HAST_OK) die(2, "cannot use --load-table file");
+        K = (size_t)kk;
+        if (hast_ctx_create(device, kk, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+        fprintf(stderr, "__load kmer table %s__\n", load_table.c_str());
+        CK(hast_table_load(ctx, load_table.c_str(), 0.0), "loading the k-mer table");
+        t_loaded = now_s();
+    } else {
     std::vector<char> txt[2];
     if (!slurp(hap0, txt[0])) die(2, ("cannot read " + hap0).c_str());
     if (!slurp(hap1, txt[1])) die(2, ("cannot read " + hap1).c_str());
     const void *nl0 = memchr(txt[0].data(), '\n', txt[0].size());
-    const size_t K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // :35-36
+    K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // :35-36
     if (K < 1 || K > 31) {
         fprintf(stderr, "classify: ERROR: K=%zu (length of the first line of %s) is outside [1,31]\n", K, hap0.c_str());
         return 3;
     }
-    hast_ctx *ctx = nullptr;
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
     CK(hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.0), "allocating the k-mer table");
     for (int h = 0; h < 2; h++) {
@@ -209,7 +226,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "Recorded %llu haplotype %d specific %zu-mers\n", (unsigned long long)lines, h, K);   // :45
         std::vector<char>().swap(txt[h]);
     }
-    const double t_loaded = now_s();
+    t_loaded = now_s();
+    }
 
     // ---- InitAdaptor (classify.cpp:314-339) ---------------------------------------------------
     fprintf(stderr, "Adaptor forward :%s\n", r1.c_str());
@@ -238,6 +256,7 @@ int main(int argc, char **argv) {
     }
     uint64_t n_set[2] = {0, 0};
     CK(hast_table_sizes(ctx, &n_set[0], &n_set[1]), "counting set sizes");
+    if (!save_table.empty()) CK(hast_table_save(ctx, save_table.c_str()), "writing --save-table file");
     logtime();
 
     // ---- processFastq (classify.cpp:238-278) for each --read, in order ------------------------

@@ -370,6 +370,96 @@ hast_status hast_table_sizes(hast_ctx *c, uint64_t *n0, uint64_t *n1) {
     return HAST_OK;
 }
 
+// ---- binary key-set cache: file = 32-byte header + live slots (key<<2|tags), 8 B per distinct key
+namespace {
+struct CacheHeader {
+    char magic[8];          // "HASTKEYS"
+    uint32_t version, k;
+    uint64_t n_slots;
+    uint64_t reserved;
+};
+}  // namespace
+
+hast_status hast_table_save(hast_ctx *c, const char *path) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (!path) return fail(HAST_ERR_INVALID, "path is null");
+    uint64_t n0 = 0, n1 = 0;
+    if (hast_status st = hast_table_sizes(c, &n0, &n1)) return st;
+    const size_t cap = (size_t)(n0 + n1) + 16;                    // distinct live keys <= n0 + n1
+    uint64_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, cap * sizeof(uint64_t)));
+    unsigned long long n = 0;
+    hipError_t e = hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_export_slots(c->d_slots, (size_t)c->nbuckets * kSlotsPerBucket, d_out, cap, c->d_cnt, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, c->d_cnt, sizeof(n), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    std::vector<uint64_t> host;
+    if (e == hipSuccess && n <= cap) {
+        host.resize((size_t)n);
+        if (n) e = hipMemcpy(host.data(), d_out, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(HAST_ERR_HIP, "table export: %s", hipGetErrorString(e));
+    if (n > cap) return fail(HAST_ERR_INVALID, "table export overflow");
+    std::sort(host.begin(), host.end());                          // deterministic file for a given key set
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(HAST_ERR_IO, "cannot write %s", path);
+    CacheHeader h;
+    memcpy(h.magic, "HASTKEYS", 8);
+    h.version = 1;
+    h.k = (uint32_t)c->k;
+    h.n_slots = n;
+    h.reserved = 0;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (n == 0 || fwrite(host.data(), sizeof(uint64_t), (size_t)n, f) == (size_t)n);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(HAST_ERR_IO, "short write to %s", path);
+    return HAST_OK;
+}
+
+hast_status hast_table_file_info(const char *path, int *k_out, uint64_t *n_keys_out) {
+    if (!path) return fail(HAST_ERR_INVALID, "path is null");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(HAST_ERR_IO, "cannot read %s", path);
+    CacheHeader h;
+    const bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "HASTKEYS", 8) == 0 && h.version == 1;
+    fclose(f);
+    if (!ok) return fail(HAST_ERR_FORMAT, "%s is not a HASTKEYS v1 file", path);
+    if (k_out) *k_out = (int)h.k;
+    if (n_keys_out) *n_keys_out = h.n_slots;
+    return HAST_OK;
+}
+
+hast_status hast_table_load(hast_ctx *c, const char *path, double load_factor) {
+    if (hast_status st = use(c)) return st;
+    if (!path) return fail(HAST_ERR_INVALID, "path is null");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(HAST_ERR_IO, "cannot read %s", path);
+    CacheHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "HASTKEYS", 8) != 0 || h.version != 1) {
+        fclose(f);
+        return fail(HAST_ERR_FORMAT, "%s is not a HASTKEYS v1 file", path);
+    }
+    if ((int)h.k != c->k) {
+        fclose(f);
+        return fail(HAST_ERR_INVALID, "%s holds %u-mers, the context is K=%d", path, h.k, c->k);
+    }
+    hast_status st = hast_table_reserve(c, h.n_slots + 1, load_factor);
+    const size_t per = kChunkBytes / sizeof(uint64_t);
+    std::vector<uint64_t> buf(std::min<uint64_t>(per, h.n_slots ? h.n_slots : 1));
+    if (st == HAST_OK) st = ensure_scratch(c, buf.size() * sizeof(uint64_t) + 16);
+    for (uint64_t i = 0; st == HAST_OK && i < h.n_slots; i += per) {
+        const size_t m = (size_t)std::min<uint64_t>(per, h.n_slots - i);
+        if (fread(buf.data(), sizeof(uint64_t), m, f) != m) { st = fail(HAST_ERR_IO, "%s is truncated", path); break; }
+        hipError_t e = hipMemcpyAsync(c->d_scratch, buf.data(), m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_import_slots(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, c->d_err, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(HAST_ERR_HIP, "table import: %s", hipGetErrorString(e));
+    }
+    fclose(f);
+    if (st != HAST_OK) return st;
+    return check_err_word(c, c->stream);
+}
+
 hast_status hast_table_info(const hast_ctx *c, uint64_t *n_buckets, uint64_t *bytes) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
     if (n_buckets) *n_buckets = c->nbuckets;

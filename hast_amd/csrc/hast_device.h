@@ -44,6 +44,8 @@ hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, 
                               uint32_t tag, uint32_t *d_err, hipStream_t s);
 hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s);
 hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
+hipError_t launch_export_slots(const uint64_t *slots, size_t nslots, uint64_t *d_out, size_t cap, unsigned long long *d_counter, hipStream_t s);
+hipError_t launch_import_slots(uint64_t *slots, TableGeom g, const uint64_t *d_in, size_t n, uint32_t *d_err, hipStream_t s);
 hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
 hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,

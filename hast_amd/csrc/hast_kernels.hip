@@ -105,6 +105,26 @@ __global__ void k_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *keys
     tags[i] = p ? (uint8_t)(*p & 3) : 0;
 }
 
+// Table export/import (binary key-set cache): the live slots (key<<2|tags, tags != 0) are compacted
+// into a dense array; importing re-inserts them (placement is recomputed, so K, not the geometry, must match).
+__global__ void __launch_bounds__(256) k_export_slots(const uint64_t *slots, size_t nslots, uint64_t *out, size_t cap,
+                                                      unsigned long long *counter) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nslots; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t s = slots[i];
+        if (s != kEmptySlot && (s & 3)) {
+            const unsigned long long at = atomicAdd(counter, 1ull);
+            if (at < cap) out[at] = s;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_import_slots(uint64_t *slots, TableGeom g, const uint64_t *in, size_t n, uint32_t *err) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t s = in[i];
+        if ((s & 3) == 0 || (s >> 2) >> (2 * g.k)) { atomicOr(&err[0], 2u); continue; }     // not a slot image for this K
+        if (!table_insert(slots, g, s >> 2, (uint32_t)(s & 3))) atomicOr(&err[0], 1u);
+    }
+}
+
 // g_kmers[h].size(): number of slots with tag bit h.  Streaming 16 B/lane.
 __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *out) {
     unsigned long long c0 = 0, c1 = 0;
@@ -524,6 +544,15 @@ hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_key
 hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_lookup_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slots, g, d_keys, n, d_tags);
+    return hipGetLastError();
+}
+hipError_t launch_export_slots(const uint64_t *slots, size_t nslots, uint64_t *d_out, size_t cap, unsigned long long *d_counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_export_slots, dim3(grid_for(nslots, 256, 256 * 16)), dim3(256), 0, s, slots, nslots, d_out, cap, d_counter);
+    return hipGetLastError();
+}
+hipError_t launch_import_slots(uint64_t *slots, TableGeom g, const uint64_t *d_in, size_t n, uint32_t *d_err, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_import_slots, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_in, n, d_err);
     return hipGetLastError();
 }
 hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s) {

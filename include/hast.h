@@ -99,6 +99,13 @@ hast_status hast_table_sizes(hast_ctx *, uint64_t *n_hap0, uint64_t *n_hap1);
 /* Membership of host keys (test/diagnostic entry): out_tags[i] = tag bits of key i (0 = absent). */
 hast_status hast_table_lookup(hast_ctx *, const uint64_t *canon_keys, size_t n, uint8_t *out_tags);
 
+/* Binary key-set cache (so the multi-GB k-mer text files are parsed once): hast_table_save writes the live keys
+ * with their tag bits (8 B per distinct key, sorted; both sets, after any erase) to `path`; hast_table_load sizes a
+ * new table for them (load factor as in hast_table_reserve) and re-inserts them.  K must match the context. */
+hast_status hast_table_save(hast_ctx *, const char *path);
+hast_status hast_table_load(hast_ctx *, const char *path, double load_factor);
+hast_status hast_table_file_info(const char *path, int *k_out, uint64_t *n_keys_out);   /* no GPU needed */
+
 /* geometry, for roofline accounting */
 hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *bytes);
 

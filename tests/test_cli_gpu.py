@@ -121,3 +121,19 @@ def test_classify_read_cli_matches_s03_reference_golden(exe, golden_workdir, cas
                          timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()
+
+
+def test_cli_save_and_load_table(exe, golden_workdir, tmp_path):
+    """--save-table / --load-table: the cached key set reproduces the reference's output without the k-mer text files."""
+    meta = load_case("rand_k21")["runs"]["pair_w104"]
+    d = golden_workdir / "rand_k21"
+    cache = str(tmp_path / "rand_k21.keys")
+    r = subprocess.run([exe] + meta["argv"] + ["--save-table", cache], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and r.stdout == open(d / meta["expected"], "rb").read()
+    argv = [a for a in meta["argv"]]
+    for flag in ("--hap0", "--hap1"):
+        i = argv.index(flag)
+        del argv[i:i + 2]
+    r = subprocess.run([exe] + argv + ["--load-table", cache], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert r.stdout == open(d / meta["expected"], "rb").read()

@@ -534,3 +534,48 @@ def test_randomized_configurations_vs_oracle(built, oracle_lib):
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), cfg
         oracle_lib.ho_free(oc)
+
+
+def test_table_save_load_roundtrip(built, oracle_lib, tmp_path):
+    """Binary key-set cache (8(f)#4): save after build + erase, load into a new context with a different minimizer
+    and load factor: same set sizes, same membership/tags, same classification; the file is deterministic."""
+    k, n_keys, n_bc, L, n = 21, 30000, 50, 150, 5000
+    p = make_params(k, L, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    keys[1][:200] = keys[0][:200]
+    bases, ids = hast_amd.synth_reads_host(p, 0, n)
+    off = np.arange(n + 1, dtype=np.uint64) * L
+    f1, f2 = str(tmp_path / "t1.keys"), str(tmp_path / "t2.keys")
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        ctx.table_erase(np.concatenate([keys[0][:50], keys[1][300:320]]))
+        sizes = ctx.table_sizes()
+        ctx.counts_resize(n_bc)
+        ctx.classify_batch(bases, off, ids, L)
+        want = ctx.counts_read(n_bc)
+        probe = np.concatenate([keys[0][:1000], keys[1][:1000]])
+        tags = ctx.table_lookup(probe)
+        ctx.table_save(f1)
+    kk, nn = C.c_int(), C.c_uint64()
+    assert hast_amd.lib().hast_table_file_info(f1.encode(), C.byref(kk), C.byref(nn)) == 0 and kk.value == k
+    assert os.path.getsize(f1) == 32 + 8 * nn.value
+    with hast_amd.Context(k, minimizer=11) as ctx:
+        ctx.table_load(f1, 0.6)
+        assert ctx.table_sizes() == sizes
+        assert np.array_equal(ctx.table_lookup(probe), tags)
+        ctx.counts_resize(n_bc)
+        ctx.classify_batch(bases, off, ids, L)
+        got = ctx.counts_read(n_bc)
+        ctx.table_save(f2)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert open(f1, "rb").read() == open(f2, "rb").read()
+    with hast_amd.Context(15) as ctx:
+        with pytest.raises(hast_amd.HastError):
+            ctx.table_load(f1)                       # K mismatch
+    (tmp_path / "junk").write_bytes(b"not a table")
+    with hast_amd.Context(k) as ctx:
+        with pytest.raises(hast_amd.HastError):
+            ctx.table_load(str(tmp_path / "junk"))
