@@ -64,7 +64,7 @@ struct hast_ctx {
     bool counts_owned = false;
     // small scratch
     uint32_t *d_err = nullptr;              // [4]
-    unsigned long long *d_cnt = nullptr;    // [2]
+    unsigned long long *d_cnt = nullptr;    // [4]: [0..1] set sizes / segment counter, [3] tile queue of k_classify
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
     Staging stage[2];
@@ -167,7 +167,7 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     };
     bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
     bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
-    bail(hipMalloc(&c->d_cnt, 2 * sizeof(unsigned long long)), "hipMalloc(cnt)");
+    bail(hipMalloc(&c->d_cnt, 4 * sizeof(unsigned long long)), "hipMalloc(cnt)");
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
     if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     for (auto &s : c->stage)
@@ -600,8 +600,9 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
     const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 +
                             (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
-    const size_t pad = (size_t)wlen * 4 + 64 + 64;
-    const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, ((size_t)19968 - pad) / per_read));
+    const size_t pad = (size_t)wlen * 4 + 64 + 64 + 16;
+    static const size_t lds_budget = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)19968; }();
+    const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (lds_budget - pad) / per_read));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
         double best = -1;
@@ -624,6 +625,8 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.div_hw = magic((uint64_t)tr * a.w64 * 2 + 1024, a.w64 * 2);
     const uint64_t n_tiles = (n_reads + tr - 1) / tr;
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
+    a.tile_queue = c->d_cnt + 3;
+    HIP_TRY(hipMemsetAsync(a.tile_queue, 0, sizeof(unsigned long long), s ? (hipStream_t)s : c->stream));
     HIP_TRY(launch_classify(a, grid, smem, s ? (hipStream_t)s : c->stream));
     return HAST_OK;
 }

@@ -22,6 +22,7 @@ struct ClassifyArgs {
     const uint32_t *barcode_ids; // per read, or nullptr
     uint32_t *votes;             // [n_reads][2] or nullptr
     uint32_t *counts;            // [n_barcodes][4] = {c0,c1,neg,reserved}
+    unsigned long long *tile_queue; // zeroed before the launch: next tile index (dynamic load balance)
     const uint64_t *slots;       // table
     uint64_t n_reads;
     uint32_t nbuckets;

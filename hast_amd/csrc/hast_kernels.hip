@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint32_t TR = a.tile_reads;
     const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
     const uint32_t MS = a.mh_stride;                                 // m-mer positions per read (stride)
-    unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(smem);            // [TR][WS]
+    unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);            // next tile of this workgroup
+    unsigned long long *s_pack = s_tile + 2;                                               // [TR][WS]
     unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
     unsigned long long *s_off = s_vote + TR;                                               // [TR]
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
@@ -251,7 +252,13 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
     const u64x2 *tab = reinterpret_cast<const u64x2 *>(a.slots) + sub;     // this lane's first 16-B piece of bucket 0
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Tiles are handed out by a global queue (one atomic per tile), so the load stays balanced whatever the
+    // residency of the grid is (the grid may be larger than what fits the chip at once).
+    if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
+    __syncthreads();
+    for (;;) {
+        const uint64_t tile = *s_tile;
+        if (tile >= n_tiles) break;
         const uint64_t r0 = tile * TR;
         const uint32_t tra = (uint32_t)((a.n_reads - r0 < TR) ? (a.n_reads - r0) : TR);
 
@@ -267,6 +274,8 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             s_vote[tid] = 0;
         }
         __syncthreads();
+        // everyone has read `tile`: fetch the next one now; the barriers below publish it before the loop top reads it
+        if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
 
         // ---- A: pack ----------------------------------------------------------------------
         const uint32_t HW = a.w64 * 2;                                // 16-base half-words per read
