@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 // ------------------------------------------------------------------------------------------
 constexpr int kThreads = 256;
 #ifndef HAST_MINWAVES
-#define HAST_MINWAVES 1
+#define HAST_MINWAVES 5   // 96 VGPRs: 5 waves/SIMD = 5 workgroups per CU (measured best of 4/5/6/8 with the tile queue)
 #endif
 #ifndef HAST_LPB
 #define HAST_LPB 2        // measured on C3: pairs 15.4 ms vs quads 16.2 ms per 16M reads (fewer DPP/compare rounds)
