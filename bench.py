@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores of this process")
     ap.add_argument("--minimizer", type=int, default=0, help="minimizer length for bucket placement (0 = library default)")
+    ap.add_argument("--clustered", action="store_true", help="keys in runs of K around variant sites (real-data structure) instead of independent random keys")
+    ap.add_argument("--no-plants", action="store_true", help="reads without planted parental k-mers (isolates table effects)")
     ap.add_argument("--max-resident-gb", type=float, default=96.0, help="HBM budget for resident read batches")
     args = ap.parse_args()
 
@@ -95,7 +97,7 @@ def main():
         if args.batch_reads == 16_000_000: args.batch_reads = 120_000
         args.cpu_seconds = 0          # the port's CPU leg restates stage 01 only
     K, L, R = args.k, args.read_len, args.batch_reads
-    p = make_params(K, L, n_keys, n_bc)
+    p = make_params(K, L, n_keys, n_bc, clustered=args.clustered, no_plants=args.no_plants)
     ctx = hast_amd.Context(K, local_rank, minimizer=args.minimizer or None)
     stream = torch.cuda.Stream(device=dev)
     hs = C.c_void_p(stream.cuda_stream)
@@ -206,7 +208,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": wl_desc, "k": K, "read_len": L, "keys_per_hap": n_keys, "barcodes": n_bc,
                        "batch_reads": R, "reads_total": world * args.steps * R, "table_gb": round(table_bytes / 1e9, 3),
-                       "load_factor": args.load_factor, "minimizer": ctx.minimizer, "set_sizes": list(set_sizes), "sharding": "reads by index, tables replicated",
+                       "load_factor": args.load_factor, "minimizer": ctx.minimizer, "keys": "clustered" if args.clustered else "random", "set_sizes": list(set_sizes), "sharding": "reads by index, tables replicated",
                        "collective": "1x all_reduce(sum,u32[%d]) + D2H in timed region" % (n_bc * 4) if use_dist else "none (D2H of counters in timed region)",
                        "resident_batches": n_res},
             "mode": "per-read votes (stage-03 semantics)" if perread else "per-barcode counts (stage-01 semantics)",

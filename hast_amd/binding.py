@@ -157,8 +157,8 @@ def chop_read(seq: bytes, k: int):
     return [out[i] for i in range(got)]
 
 
-def make_params(k, read_len=150, n_keys_per_hap=0, n_barcodes=1, seed_k=0, seed_r=0, seed_b=0):
-    return SynthParams(seed_k, seed_r, seed_b, n_keys_per_hap, n_barcodes, read_len, k, 0)
+def make_params(k, read_len=150, n_keys_per_hap=0, n_barcodes=1, seed_k=0, seed_r=0, seed_b=0, clustered=False, no_plants=False):
+    return SynthParams(seed_k, seed_r, seed_b, n_keys_per_hap, n_barcodes, read_len, k, (1 if clustered else 0) | (2 if no_plants else 0))
 
 
 def synth_keys_host(p: SynthParams, hap, first, n):

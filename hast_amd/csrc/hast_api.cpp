@@ -126,7 +126,7 @@ SynthParams resolve(const hast_synth_params *p) {
     r.n_barcodes = p->n_barcodes ? p->n_barcodes : 1;
     r.read_len = p->read_len;
     r.k = p->k;
-    r.reserved = 0;
+    r.reserved = p->reserved;      // 0 = random keys, 1 = clustered keys (runs of K around variant sites)
     return r;
 }
 
@@ -259,6 +259,7 @@ hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     double want = (double)(max_keys ? max_keys : 1) / lf / kSlotsPerBucket;
     uint64_t nb = (uint64_t)want + 1;
     if (nb < 64) nb = 64;
+    nb += nb & 1;                                   // even: buckets may be used in pairs
     if (nb >= (1ull << 32)) return fail(HAST_ERR_INVALID, "table of %llu buckets exceeds 2^32", (unsigned long long)nb);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_slots) HIP_TRY(hipFree(c->d_slots));

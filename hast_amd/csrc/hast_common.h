@@ -47,7 +47,11 @@ HAST_HD uint64_t kmer_pack(const char *s, int k) {                             /
 }
 
 // ---- table geometry ---------------------------------------------------------------------------
-constexpr int      kSlotsPerBucket = 8;            // 8 x 8 B = one 64-B line
+#ifndef HAST_SLOTS
+#define HAST_SLOTS 8
+#endif
+constexpr int      kSlotsPerBucket = HAST_SLOTS;   // 8 x 8 B = one 64-B line (16: one 128-B line)
+constexpr int      kPieces = kSlotsPerBucket / 2;  // 16-B pieces per bucket
 constexpr uint64_t kEmptySlot = ~0ull;             // (key<<2|tags) can never be all ones: the
                                                    // all-G k-mer is never canonical (all-C is smaller)
 
@@ -73,8 +77,17 @@ HAST_HD uint32_t minimizer_hash(uint64_t kmer, int k, int m) {
 HAST_HD uint32_t bucket_of_minhash(uint32_t minh, uint32_t nbuckets) {
     return (uint32_t)(((uint64_t)(minh * 0x9E3779B1u) * nbuckets) >> 32);
 }
+// A minimizer owns a PAIR of adjacent buckets (one aligned 128-B block) and the key's last bit picks the half.  Real
+// parent-specific k-mers come in runs of K windows around a variant site, for both alleles, so up to a dozen keys share
+// a minimizer; spreading them over 16 slots keeps buckets from filling up, while every probe still loads only its own
+// 64 B.  The windows of a read that share a minimizer now touch two lines of one 128-B block instead of one line, which
+// costs no extra HBM requests (measured: TCC_EA0_RDREQ unchanged, same kernel time on random keys, -10 % time on
+// clustered keys).  nbuckets is even.
+HAST_HD uint32_t bucket_of(uint32_t minh, uint64_t key, uint32_t nbuckets) {
+    return (bucket_of_minhash(minh, nbuckets >> 1) << 1) | (uint32_t)(key & 1);
+}
 HAST_HD uint32_t home_bucket(uint64_t key, int k, int m, uint32_t nbuckets) {
-    return bucket_of_minhash(minimizer_hash(key, k, m), nbuckets);
+    return bucket_of(minimizer_hash(key, k, m), key, nbuckets);
 }
 
 // ---- synthetic workload ----------------------------------------------------------
@@ -94,8 +107,27 @@ struct SynthParams {          // mirrors hast_synth_params with defaults resolve
     uint32_t n_barcodes, read_len, k, reserved;
 };
 
-// key j of haplotype h: canonical(random 2K bits).  Duplicates / keys in both sets occur by chance.
+// key j of haplotype h.
+//   reserved == 0: canonical(random 2K bits); duplicates / keys in both sets occur by chance.
+//   reserved == 1 ("clustered", the structure of REAL parent-specific k-mers): keys come in runs of K overlapping
+//     windows around a variant site.  Site s = j / K has a random context of 2K-1 bases whose middle base is the
+//     haplotype's allele (hap 1 = hap 0's allele + 1 mod 4); key j is window j % K of that context.  Neighbouring
+//     keys then share minimizers, within and across the two haplotypes -- the hard case for bucket placement.
+HAST_HD uint64_t synth_context_window(const SynthParams &p, int hap, uint64_t site, uint32_t t) {
+    // context bases c[0 .. 2K-2], 2 bits each, drawn from two 64-bit words (62 + 62 bits hold up to 61 bases)
+    const uint32_t K = p.k;
+    const uint64_t w0 = synth_rand(p.seed_k, 0x5173ull, 2 * site), w1 = synth_rand(p.seed_k, 0x5173ull, 2 * site + 1);
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < K; ++i) {
+        const uint32_t pos = t + i;                                   // 0 .. 2K-2
+        uint32_t base = (uint32_t)(((pos < 31) ? (w0 >> (2 * pos)) : (w1 >> (2 * (pos - 31)))) & 3);
+        if (pos == K - 1) base = (base + (uint32_t)hap) & 3;          // the variant: different allele per haplotype
+        v = (v << 2) | base;
+    }
+    return v;
+}
 HAST_HD uint64_t synth_key(const SynthParams &p, int hap, uint64_t j) {
+    if (p.reserved & 1) return kmer_canon(synth_context_window(p, hap, j / p.k, (uint32_t)(j % p.k)), (int)p.k);
     return kmer_canon(synth_rand(p.seed_k, (uint64_t)hap, j) & kmer_mask((int)p.k), (int)p.k);
 }
 
@@ -113,12 +145,22 @@ HAST_HD void synth_read_bc(const SynthParams &p, uint64_t read, uint32_t bc, uin
         uint32_t n = (L - j0 < 32) ? (L - j0) : 32;
         for (uint32_t j = 0; j < n; j++) out[j0 + j] = (uint8_t)"ACGT"[(w >> (2 * j)) & 3];
     }
-    if (L >= K && p.n_keys_per_hap > 0) {
+    if (L >= K && p.n_keys_per_hap > 0 && !(p.reserved & 2)) {        // reserved bit 1: reads without planted k-mers
         const uint32_t nplant = (uint32_t)(synth_rand(p.seed_r, read, 1000) & 3);
         for (uint32_t t = 0; t < nplant; t++) {
             uint64_t w = synth_rand(p.seed_r, read, 1001 + t);
             int truth = (int)(bc & 1u);
             int hap = ((w & 0xFF) < 205) ? truth : 1 - truth;
+            if ((p.reserved & 1) && L >= 2 * K - 1) {
+                // clustered mode: plant a site's whole context with this haplotype's allele (up to K consecutive hits)
+                const uint64_t site = ((w >> 32) % p.n_keys_per_hap) / K;
+                const uint32_t off = (uint32_t)((w >> 16) & 0xFFFF) % (L - (2 * K - 1) + 1);
+                for (uint32_t tt = 0; tt < K; tt += K - 1) {           // two windows cover the 2K-1 bases: t=0 and t=K-1
+                    const uint64_t v = synth_context_window(p, hap, site, tt);
+                    for (uint32_t j = 0; j < K; j++) out[off + tt + j] = (uint8_t)"ACTG"[(v >> (2 * (K - 1 - j))) & 3];
+                }
+                continue;
+            }
             uint32_t off = (uint32_t)((w >> 16) & 0xFFFF) % (L - K + 1);
             uint64_t key = synth_key(p, hap, (w >> 32) % p.n_keys_per_hap);
             if ((w >> 8) & 1) key = kmer_revcomp(key, (int)K);

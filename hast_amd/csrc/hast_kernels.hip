@@ -177,7 +177,7 @@ constexpr int kThreads = 256;
 #endif
 constexpr int kLPB = HAST_LPB;                // lanes that share one bucket (4: 16 B each, 2: 32 B each)
 constexpr int kRounds = kLPB;                 // rounds per 64-window block (64/kLPB windows per round)
-constexpr int kNLd = 4 / kLPB;                // 16-B loads per lane per round
+constexpr int kNLd = kPieces / kLPB;          // 16-B loads per lane per round
 constexpr uint32_t kGrpMask = (1u << kLPB) - 1;
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             }
             B.klo = (uint32_t)(ck << 2);
             B.khi = (uint32_t)(ck >> 30);
-            B.bkt = ok ? bucket_of_minhash(mn, nb) : 0;              // invalid windows read bucket 0 (harmless)
+            B.bkt = ok ? bucket_of(mn, ck, nb) : 0;                  // invalid windows read bucket 0 (harmless)
             B.meta = r | (ok ? 0x80000000u : 0u);
             uint32_t bk[kRounds];
             bk[0] = quad_bcast<0>(B.bkt);
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
 #pragma unroll
             for (int j = 0; j < kRounds; ++j)
 #pragma unroll
-                for (int l = 0; l < kNLd; ++l) B.sl[j][l] = tab[(size_t)bk[j] * 4 + l * kLPB];
+                for (int l = 0; l < kNLd; ++l) B.sl[j][l] = tab[(size_t)bk[j] * kPieces + l * kLPB];
         };
         auto finish = [&](Blk &B) {
             // the window's key and read are re-broadcast here rather than kept live across the loads
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                         if (pending) {
                             b = (b + 1 == nb) ? 0 : b + 1;
 #pragma unroll
-                            for (int l = 0; l < kNLd; ++l) s2[l] = tab[(size_t)b * 4 + l * kLPB];
+                            for (int l = 0; l < kNLd; ++l) s2[l] = tab[(size_t)b * kPieces + l * kLPB];
                         }
                         unsigned long long hit_slot = 0;
                         bool h2 = false;

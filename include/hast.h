@@ -183,7 +183,8 @@ typedef struct {
     uint32_t n_barcodes;
     uint32_t read_len;
     uint32_t k;
-    uint32_t reserved;
+    uint32_t reserved;               /* 0 = independent random keys; 1 = clustered keys: runs of K
+                                        overlapping windows around variant sites, like real parent-specific k-mers */
 } hast_synth_params;
 
 hast_status hast_synth_keys_host(const hast_synth_params *, int hap, uint64_t first, size_t n, uint64_t *out);

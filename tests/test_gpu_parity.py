@@ -153,8 +153,9 @@ def test_insert_text_rejects_ragged_lines(built):
 
 
 # ------------------------------------------------------------------------------------------------
-def test_synth_generators_agree(built):
-    p = make_params(21, 150, 5000, 100)
+@pytest.mark.parametrize("clustered", [False, True])
+def test_synth_generators_agree(built, clustered):
+    p = make_params(21, 150, 5000, 100, clustered=clustered)
     with hast_amd.Context(21) as ctx:
         n = 3000
         d_b, d_i, d_k = ctx.alloc(n * 150), ctx.alloc(n * 4), ctx.alloc(n * 8)
