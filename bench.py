@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--minimizer", type=int, default=0, help="minimizer length for bucket placement (0 = library default)")
     ap.add_argument("--clustered", action="store_true", help="keys in runs of K around variant sites (real-data structure) instead of independent random keys")
     ap.add_argument("--no-plants", action="store_true", help="reads without planted parental k-mers (isolates table effects)")
+    ap.add_argument("--barcodes", type=int, default=0, help="override the workload's barcode count")
+    ap.add_argument("--keys-per-hap", type=int, default=0, help="override the workload's key count per haplotype")
     ap.add_argument("--max-resident-gb", type=float, default=96.0, help="HBM budget for resident read batches")
     args = ap.parse_args()
 
@@ -90,6 +92,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n_keys, n_bc, wl_desc = WORKLOADS[args.workload]
+    if args.barcodes or args.keys_per_hap:
+        n_bc, n_keys = args.barcodes or n_bc, args.keys_per_hap or n_keys
+        wl_desc += " (overridden: %d keys/hap, %d barcodes)" % (n_keys, n_bc)
     perread = args.workload == "c5"
     if perread:                       # config 5 geometry unless overridden on the command line
         if args.k == 21: args.k = 31
