@@ -65,6 +65,12 @@ def main():
     ap.add_argument("--max-resident-gb", type=float, default=96.0, help="HBM budget for resident read batches")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries chat on fd 1 (RCCL prints its version banner there under
+    # NCCL_DEBUG=VERSION), so fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch                      # first: libhast then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
@@ -243,7 +249,8 @@ def main():
         except Exception as e:                                       # the baseline never gates the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "bp/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
