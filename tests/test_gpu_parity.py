@@ -580,3 +580,42 @@ def test_table_save_load_roundtrip(built, oracle_lib, tmp_path):
     with hast_amd.Context(k) as ctx:
         with pytest.raises(hast_amd.HastError):
             ctx.table_load(str(tmp_path / "junk"))
+
+
+def test_poly_a_key_zero_and_hot_read(built, oracle_lib):
+    """Canonical key 0 (poly-A / poly-T) is a legal key: slot value (0<<2)|tags must not look empty, erasing it must
+    leave a tombstone rather than an empty slot, and reads made only of that k-mer (every window a hit, all on one
+    LDS counter) count correctly."""
+    k = 21
+    polyA, polyT = b"A" * k, b"T" * k
+    other = b"ACGTTGCATCGATTGCAAGTT"
+    text0 = polyA + b"\n" + other + b"\n"
+    text1 = polyT + b"\n"                                  # same canonical key as poly-A => key in both sets
+    oc = oracle_lib.ho_new()
+    assert oracle_lib.ho_load_kmers_text(oc, text0, len(text0), 0) == 0 and oracle_lib.ho_load_kmers_text(oc, text1, len(text1), 1) == 0
+    seqs = [b"A" * 150, b"T" * 150, b"A" * 70 + b"C" + b"T" * 79, other * 3, b"A" * 20]
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    ids = np.arange(len(seqs), dtype=np.uint32)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(16)
+        assert ctx.table_insert_text(0, text0) == 2 and ctx.table_insert_text(1, text1) == 1
+        assert ctx.table_sizes() == (2, 1)
+        assert list(ctx.table_lookup(np.array([0], dtype=np.uint64))) == [3]
+        ctx.counts_resize(len(seqs))
+        ctx.classify_batch(bases, off, ids, 150)
+        got = ctx.counts_read(len(seqs))
+        exp = oracle_counts(oracle_lib, oc, bases, off, ids, len(seqs), threads=1)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)
+        assert got[0][0] == 130 and got[1][0] == 130          # every window of the poly-A read hits, in both sets
+        # erase key 0 (as InitAdaptor would for a poly-A adaptor): reported in both sets, then gone, sizes drop
+        assert list(ctx.table_erase(np.array([0], dtype=np.uint64))) == [3]
+        assert ctx.table_sizes() == (1, 0)
+        assert list(ctx.table_lookup(np.array([0], dtype=np.uint64))) == [0]
+        ctx.counts_zero()
+        ctx.classify_batch(bases, off, ids, 150)
+        got = ctx.counts_read(len(seqs))
+        assert got[0][0] == 0 and got[1][0] == 0 and got[0][3] > 0
+    oracle_lib.ho_free(oc)
