@@ -10,7 +10,7 @@ NP=${1:-1000000}; NK=${2:-1000000}; NB=${3:-10000}; TAG=${4:-c1}
 D=$(mktemp -d /tmp/hast_e2e.XXXXXX)
 OUT=gpurun_out/cli_e2e_$TAG.json
 mkdir -p gpurun_out
-tools/gen_fastq $D $NP $NK $NB 21 150 32 || exit 1
+tools/gen_fastq $D $NP $NK $NB 21 150 32 ${CLUSTERED:-0} || exit 1
 BYTES=$(stat -c %s $D/r1.fq); READS=$((NP*2)); BP=$((READS*150))
 ARGS="--hap0 $D/hap0.mer --hap1 $D/hap1.mer --read $D/r1.fq --read $D/r2.fq --weight0 1.04"
 now() { date +%s.%N; }

@@ -1,6 +1,6 @@
 // gen_fastq.cpp -- measurement tool: writes the SURVEY 8(d) synthetic workload as FILES (k-mer text files +
 // paired stLFR-style FASTQ) so the drop-in `classify` CLI and the real reference binary can be run and
-// timed on the same inputs.   gen_fastq <out_dir> <n_pairs> <keys_per_hap> <n_barcodes> [K=21] [L=150] [threads=8]
+// timed on the same inputs.   gen_fastq <out_dir> <n_pairs> <keys_per_hap> <n_barcodes> [K=21] [L=150] [threads=8] [clustered=0]
 // Header shape: @V300R%09d#<barcode>/<mate>\t<id>\t1 ; barcode id 0 -> 0_0_0, else a_b_c with a,b,c in [1,1536].
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +29,7 @@ int main(int argc, char **argv) {
     SynthParams p{0x4841535401ull, 0x4841535402ull, 0x4841535403ull, n_keys, (uint32_t)strtoul(argv[4], 0, 10),
                   argc > 6 ? (uint32_t)atoi(argv[6]) : 150u, argc > 5 ? (uint32_t)atoi(argv[5]) : 21u, 0};
     const int threads = argc > 7 ? atoi(argv[7]) : 8;
+    if (argc > 8 && atoi(argv[8])) p.reserved = 1;            // clustered keys (runs of K windows around variant sites)
     for (int h = 0; h < 2; h++) {
         FILE *f = fopen((dir + "/hap" + std::to_string(h) + ".mer").c_str(), "wb");
         if (!f) return 2;
