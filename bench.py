@@ -87,6 +87,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU path)")
+    # test switches for boxes with ONE GPU: HAST_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # HAST_BENCH_BACKEND=gloo moves the collectives to the CPU, so the N>1 control flow (sharding by rank, barrier,
+    # max-over-ranks timing, rank-0 output) can be run end to end with 2 processes on a 1-GPU box
+    if os.environ.get("HAST_BENCH_SHARE_GPU"):
+        local_rank = 0
+    backend = os.environ.get("HAST_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # HAST_BENCH_FORCE_DIST=1 runs the RCCL init / barrier / all-reduce path even at world size 1 (a check of the
@@ -95,7 +101,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_keys, n_bc, wl_desc = WORKLOADS[args.workload]
     if args.barcodes or args.keys_per_hap:
@@ -163,7 +172,10 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     host_out = torch.empty((R, 2) if perread else (n_bc, 4), dtype=torch.int32, pin_memory=True)
 
@@ -186,7 +198,13 @@ def main():
             step(args.warmup + s)
             ev1[s].record(stream)
         if use_dist and not perread:
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)          # RCCL, uint32-as-int32 sums
+            if backend == "nccl":
+                dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # RCCL, uint32-as-int32 sums
+            else:                                                  # test backend: reduce on the host
+                stream.synchronize()
+                tmp = counts.cpu()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+                counts.copy_(tmp)
         # per-read mode needs no reduction: every rank returns its own reads' (hits0, hits1)
         counts_host = None
         if rank == 0 or perread:
@@ -196,7 +214,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
