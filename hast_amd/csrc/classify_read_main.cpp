@@ -19,6 +19,7 @@
 
 #include "../../include/hast.h"
 #include "fastq_reader.h"
+#include "ingest.h"
 
 namespace {
 
@@ -47,32 +48,6 @@ bool slurp(const std::string &path, std::vector<char> &out) {
     bool ok = sz <= 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
     fclose(f);
     return ok;
-}
-
-struct Batch {
-    std::vector<std::string> names;
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> offsets{0};
-    void add(std::string_view head, std::string_view seq) {
-        names.emplace_back(head.empty() ? head : head.substr(1));          // s03:207 head.substr(1)
-        bases.insert(bases.end(), seq.begin(), seq.end());
-        offsets.push_back(bases.size());
-    }
-    void clear() {
-        names.clear();
-        bases.clear();
-        offsets.assign(1, 0);
-    }
-};
-
-// One output row from a read's integer hits.  Densities are hits / line count of the file (s03:68,215-216).  The
-// reference's selection loop (s03:110-133) reduces, for two haplotypes, to: both zero -> "ambiguous 0.0"; otherwise
-// the larger density wins and a tie goes to haplotype0 (its strict comparisons never replace the first maximum).
-void print_row(const std::string &name, uint32_t h0, uint32_t h1, const int total_kmers[2]) {
-    const double d0 = (double)h0 / total_kmers[0], d1 = (double)h1 / total_kmers[1];
-    if (!(d0 > 0) && !(d1 > 0)) printf("%s\tambiguous\t0.0\n", name.c_str());
-    else if (d1 > d0) printf("%s\thaplotype1\t%0.6f\n", name.c_str(), d1);
-    else printf("%s\thaplotype0\t%0.6f\n", name.c_str(), d0);
 }
 
 }  // namespace
@@ -138,63 +113,175 @@ int main(int argc, char **argv) {
         total_kmers[h] = (int)lines;
         fprintf(stderr, "Recorded %d haplotype %d specific %zu-mers\n", total_kmers[h], h, K);
     }
-    // ---- reads ------------------------------------------------------------------------------------------
-    Batch batch;
+    // ---- reads: block ingest with t_num parser threads (ingest.h), one GPU batch per block ------------------------
+    // Framing as in the reference: FASTQ = 4 getlines per record, the header must be newline-terminated (s03:255-263);
+    // FASTA = '>' lines start a record, other non-empty lines are appended, a last line without '\n' is dropped
+    // (s03:279-296).  Rows of a file are printed when the file is done, like PrintOutput after the loop (s03:269,301).
+    hast::WorkerPool pool(t_num);
+    const int T = pool.size();
+    std::vector<std::vector<uint32_t>> nl(T);
+    std::vector<uint32_t> allnl;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets;
+    std::vector<std::string> names;
     std::vector<uint32_t> votes;
-    auto flush = [&]() {
-        if (batch.names.empty()) return;
-        votes.assign(batch.names.size() * 2, 0);
-        if (hast_classify_perread(ctx, batch.bases.data(), batch.offsets.data(), batch.names.size(), votes.data()) != HAST_OK)
-            die(4, "classifying a batch");
-        for (size_t i = 0; i < batch.names.size(); i++) print_row(batch.names[i], votes[2 * i], votes[2 * i + 1], total_kmers);
-        batch.clear();
+    std::vector<uint64_t> part(T + 1);
+    std::vector<int> bad(T);
+    std::string out_rows;
+    const bool fastq = format == "fastq";
+    // classify the parsed batch (names/offsets/bases) and append its rows
+    auto classify_batch = [&]() {
+        if (names.empty()) return;
+        votes.assign(names.size() * 2, 0);
+        if (hast_classify_perread(ctx, bases.data(), offsets.data(), names.size(), votes.data()) != HAST_OK) die(4, "classifying a batch");
+        char row[96];
+        for (size_t i = 0; i < names.size(); i++) {
+            const double d0 = (double)votes[2 * i] / total_kmers[0], d1 = (double)votes[2 * i + 1] / total_kmers[1];   // s03:215-216
+            // s03:110-133 for two haplotypes: both zero -> ambiguous 0.0; else the larger density, ties to haplotype0
+            if (!(d0 > 0) && !(d1 > 0)) snprintf(row, sizeof(row), "\tambiguous\t0.0\n");
+            else if (d1 > d0) snprintf(row, sizeof(row), "\thaplotype1\t%0.6f\n", d1);
+            else snprintf(row, sizeof(row), "\thaplotype0\t%0.6f\n", d0);
+            out_rows += names[i];
+            out_rows += row;
+        }
     };
-    const size_t kBatchBytes = 256u << 20;
+    // records = [first, last) pairs of line indices: header line, then sequence lines; fills names/offsets/bases in parallel
+    struct RecSpan { uint32_t head, seq_first, seq_end; };             // line indices; sequence lines [seq_first, seq_end)
+    std::vector<RecSpan> recs;
+    auto line_start = [&](size_t i) -> size_t { return i ? (size_t)allnl[i - 1] + 1 : 0; };
+    auto build_batch = [&](const char *data) {
+        const size_t n = recs.size();
+        names.assign(n, std::string());
+        offsets.assign(n + 1, 0);
+        if (n == 0) { bases.clear(); return; }
+        std::vector<uint64_t> len(n);
+        pool.run([&](int t) {
+            uint64_t sum = 0;
+            for (size_t i = n * (size_t)t / T; i < n * (size_t)(t + 1) / T; i++) {
+                const RecSpan &r = recs[i];
+                uint64_t l = 0;
+                if (r.seq_end > r.seq_first) l = ((uint64_t)allnl[r.seq_end - 1] - line_start(r.seq_first)) - (r.seq_end - r.seq_first - 1);
+                len[i] = l;
+                sum += l;
+            }
+            part[t + 1] = sum;
+        });
+        part[0] = 0;
+        for (int t = 0; t < T; t++) part[t + 1] += part[t];
+        bases.resize(part[T] + 16);
+        pool.run([&](int t) {
+            uint64_t off = part[t];
+            for (size_t i = n * (size_t)t / T; i < n * (size_t)(t + 1) / T; i++) {
+                const RecSpan &r = recs[i];
+                const size_t hs = line_start(r.head), he = allnl[r.head];
+                names[i].assign(data + hs + (he > hs ? 1 : 0), data + he);               // head.substr(1), s03:207
+                offsets[i] = off;
+                for (uint32_t li = r.seq_first; li < r.seq_end; li++) {
+                    const size_t ls = line_start(li), le = allnl[li];
+                    memcpy(bases.data() + off, data + ls, le - ls);
+                    off += le - ls;
+                }
+            }
+        });
+        offsets[n] = part[T];
+    };
+    const size_t block_bytes = (size_t)std::max(1L, getenv("HAST_READ_BLOCK_BYTES") ? atol(getenv("HAST_READ_BLOCK_BYTES")) : (256L << 20));
     for (const auto &r : read) {
         fprintf(stderr, "__process read: %s\n", r.c_str());
-        hast::LineSource in;
-        if (!in.open(r)) die(2, "cannot open " + r);
-        bool eof;
-        if (format == "fastq") {                                             // s03:248-270
-            for (;;) {
-                std::string head(in.getline(eof));
-                if (eof) break;
-                if (!head.empty() && head[0] == '>') {
-                    fprintf(stderr, "fasta detected . ERROR . please use \"--format fasta\". exit ... \n");
-                    return 1;
-                }
-                std::string_view seq = in.getline(eof);
-                batch.add(head, seq);
-                in.getline(eof);
-                in.getline(eof);
-                if (batch.bases.size() >= kBatchBytes) flush();
+        hast::BlockSource src;
+        if (!src.open(r, block_bytes)) die(2, "cannot open " + r);
+        std::vector<char> carry;
+        out_rows.clear();
+        bool seen_header = false;                       // FASTA: lines before the first '>' belong to no record (s03:286-292)
+        for (;;) {
+            std::vector<char> blk = src.next();
+            const bool last = blk.empty();
+            constexpr size_t kPad = hast::BlockSource::kFrontPad;
+            const char *data;
+            size_t len;
+            if (last) { data = carry.data(); len = carry.size(); }
+            else if (carry.size() <= kPad) {
+                if (!carry.empty()) memcpy(blk.data() + kPad - carry.size(), carry.data(), carry.size());
+                data = blk.data() + kPad - carry.size();
+                len = blk.size() - kPad + carry.size();
+            } else {
+                carry.insert(carry.end(), blk.begin() + kPad, blk.end());
+                data = carry.data();
+                len = carry.size();
             }
-        } else {                                                             // s03:272-302
-            std::string head, seq;
-            long long id = 0;
-            for (;;) {
-                std::string_view tmp = in.getline(eof);
-                if (eof) break;
-                if (tmp.empty()) continue;
-                if (tmp[0] == '@' || tmp[0] == '+') {
-                    fprintf(stderr, "fasta detected . ERROR . please use \"--format fastq\". exit ... \n");
-                    return 1;
+            if (len >= (1ull << 32)) die(3, "a single record spans more than 4 GB");
+            pool.run([&](int t) {
+                auto &v = nl[t];
+                v.clear();
+                const char *p = data + len * (size_t)t / T, *e = data + len * (size_t)(t + 1) / T;
+                while (p < e && (p = (const char *)memchr(p, '\n', (size_t)(e - p)))) { v.push_back((uint32_t)(p - data)); ++p; }
+            });
+            allnl.clear();
+            for (int t = 0; t < T; t++) allnl.insert(allnl.end(), nl[t].begin(), nl[t].end());
+            const size_t n_lines = allnl.size();                 // complete ('\n'-terminated) lines in the work area
+            recs.clear();
+            size_t consumed = 0;
+            if (fastq) {
+                const size_t n_rec = n_lines / 4;
+                for (size_t i = 0; i < n_rec; i++) recs.push_back({(uint32_t)(4 * i), (uint32_t)(4 * i + 1), (uint32_t)(4 * i + 2)});
+                consumed = n_rec ? (size_t)allnl[4 * n_rec - 1] + 1 : 0;
+                if (last && n_lines % 4 >= 1) {
+                    // tail: header terminated; bases = next piece, terminated or not (s03:260); make the tail a full record
+                    std::string tail(data + consumed, len - consumed);
+                    size_t he = tail.find('\n');
+                    std::string head = tail.substr(0, he), seq;
+                    size_t s0 = he + 1, se = tail.find('\n', s0);
+                    seq = tail.substr(s0, se == std::string::npos ? std::string::npos : se - s0);
+                    // handled after the block's records, as a one-record batch below
+                    for (const RecSpan &x : recs)
+                        if (data[line_start(x.head)] == '>') { fprintf(stderr, "fasta detected . ERROR . please use \"--format fasta\". exit ... \n"); return 1; }
+                    build_batch(data);
+                    classify_batch();
+                    if (!head.empty() && head[0] == '>') { fprintf(stderr, "fasta detected . ERROR . please use \"--format fasta\". exit ... \n"); return 1; }
+                    names.assign(1, head.empty() ? head : head.substr(1));
+                    bases.assign(seq.begin(), seq.end());
+                    bases.resize(bases.size() + 16);
+                    offsets.assign({0, (uint64_t)seq.size()});
+                    classify_batch();
+                    break;
                 }
-                if (tmp[0] == '>') {
-                    if (id > 0) {
-                        batch.add(head, seq);
-                        if (batch.bases.size() >= kBatchBytes) flush();
+                for (const RecSpan &x : recs)
+                    if (len && data[line_start(x.head)] == '>') { fprintf(stderr, "fasta detected . ERROR . please use \"--format fasta\". exit ... \n"); return 1; }
+            } else {
+                // header lines (first byte '>'); '@'/'+' at the start of a non-empty line is the reference's format error
+                std::vector<std::vector<uint32_t>> hl(T);
+                pool.run([&](int t) {
+                    bad[t] = 0;
+                    hl[t].clear();
+                    for (size_t i = n_lines * (size_t)t / T; i < n_lines * (size_t)(t + 1) / T; i++) {
+                        const size_t ls = line_start(i);
+                        if (allnl[i] == ls) continue;                                       // empty line: skipped (s03:280)
+                        const char c = data[ls];
+                        if (c == '>') hl[t].push_back((uint32_t)i);
+                        else if (c == '@' || c == '+') bad[t] = 1;
                     }
-                    head.assign(tmp);
-                    seq.clear();
-                    id++;
-                } else {
-                    seq.append(tmp);
+                });
+                std::vector<uint32_t> heads;
+                for (int t = 0; t < T; t++) {
+                    if (bad[t]) { fprintf(stderr, "fasta detected . ERROR . please use \"--format fastq\". exit ... \n"); return 1; }
+                    heads.insert(heads.end(), hl[t].begin(), hl[t].end());
                 }
+                // complete records: header j .. header j+1; at EOF the last header's record ends at the last complete line
+                for (size_t j = 0; j + 1 < heads.size(); j++) recs.push_back({heads[j], heads[j] + 1, heads[j + 1]});
+                if (last && !heads.empty()) recs.push_back({heads.back(), heads.back() + 1, (uint32_t)n_lines});
+                if (!heads.empty()) seen_header = true;
+                if (last) consumed = len;
+                else if (!heads.empty()) consumed = line_start(heads.back());      // carry the (possibly incomplete) last record
+                else consumed = seen_header ? 0 : (n_lines ? (size_t)allnl[n_lines - 1] + 1 : 0);   // no header yet: drop complete lines
             }
-            if (id > 0) batch.add(head, seq);                                // s03:297 (the reference crashes on an empty file)
+            build_batch(data);
+            classify_batch();
+            if (last) break;
+            std::vector<char> keep(data + consumed, data + len);
+            carry.swap(keep);
+            src.recycle(std::move(blk));
         }
-        flush();                                                             // rows of one file are printed before the next (s03:269,301)
+        fwrite(out_rows.data(), 1, out_rows.size(), stdout);
         fprintf(stderr, "__process read done__\n");
     }
     fflush(stdout);

@@ -137,3 +137,52 @@ def test_cli_save_and_load_table(exe, golden_workdir, tmp_path):
     r = subprocess.run([exe] + argv + ["--load-table", cache], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-1000:]
     assert r.stdout == open(d / meta["expected"], "rb").read()
+
+
+@pytest.mark.parametrize("fmt,gz,threads,block", [("fasta", False, 1, 0), ("fasta", False, 6, 70000), ("fasta", True, 3, 9000),
+                                                  ("fastq", False, 5, 50000), ("fastq", True, 2, 0)])
+def test_classify_read_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path, fmt, gz, threads, block):
+    """classify_read's block ingest (records spanning blocks, multi-line FASTA, junk before the first header, empty
+    lines, unterminated last line, tail FASTQ record) against the stage-03 oracle's line-by-line reader."""
+    import gzip
+    import random
+    rng = random.Random(threads * 1000 + block)
+    k = 21
+    keys = [["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(300)] for _ in range(2)]
+    for h in (0, 1):
+        (tmp_path / ("h%d.mer" % h)).write_text("\n".join(keys[h]) + "\n")
+    recs = []
+    for i in range(1500):
+        L = rng.choice([0, 5, k, 60, 300, 3000, 12000]) if i % 7 else rng.randint(0, 400)
+        s = [rng.choice("ACGT") for _ in range(L)]
+        for _ in range(rng.randint(0, 1 + L // 200)):
+            if L >= k:
+                o = rng.randint(0, L - k)
+                s[o:o + k] = rng.choice(keys[rng.randint(0, 1)])
+        if L and rng.random() < 0.1:
+            s[rng.randrange(L)] = rng.choice("Nn")
+        recs.append(("r%d some/desc %d" % (i, i), "".join(s)))
+    if fmt == "fasta":
+        text = "junk line before any header\nACGT\n"
+        for n, s in recs:
+            w = rng.choice([60, 70, 1000000])
+            text += ">" + n + "\n" + "".join(s[j:j + w] + "\n" + ("\n" if rng.random() < 0.05 else "") for j in range(0, len(s), w))
+        text += ">last\nACGTACGTACGTACGTACGTACGT\nTTTT"                      # unterminated last line is dropped
+    else:
+        text = "".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in recs) + "@tail x\nACGTACGTACGTACGTACGTACGTA"
+    name = "reads." + ("fa" if fmt == "fasta" else "fq") + (".gz" if gz else "")
+    if gz:
+        with gzip.open(tmp_path / name, "wb", compresslevel=1) as f:
+            f.write(text.encode())
+    else:
+        (tmp_path / name).write_text(text)
+    args = ["--hap", "h0.mer", "--hap", "h1.mer", "--read", name, "--read", name, "--format", fmt]
+    ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify_s03")] + args, cwd=tmp_path, stdout=subprocess.PIPE, check=True)
+    env = dict(os.environ)
+    if block:
+        env["HAST_READ_BLOCK_BYTES"] = str(block)
+    got = subprocess.run([hast_amd.classify_read_exe()] + args + ["--thread", str(threads)], cwd=tmp_path, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert got.returncode == 0, got.stderr.decode()[-2000:]
+    assert got.stdout == ref.stdout
+    assert len(ref.stdout.splitlines()) == 2 * (len(recs) + 1)
