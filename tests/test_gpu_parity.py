@@ -494,8 +494,8 @@ def test_randomized_configurations_vs_oracle(built, oracle_lib):
     """Differential fuzz over the kernel's configuration space: K, minimizer length (incl. W > 9 -> runtime-loop
     instantiation), load factor (chain walks), fixed lengths down to L == K (plain-division instantiation), ragged
     lengths, tile tails.  Per-read votes and per-barcode counts must equal the oracle's in every configuration."""
-    rng = random.Random(20261003)
-    for it in range(36):
+    rng = random.Random(int(os.environ.get("HAST_FUZZ_SEED", "20261003")))
+    for it in range(int(os.environ.get("HAST_FUZZ_ITERS", "36"))):
         k = rng.choice([3, 8, 12, 16, 19, 21, 24, 28, 31])
         m = rng.choice([1, max(1, k - 12), max(1, k - 5), k - 1 if k > 1 else 1, k])
         lf = rng.choice([0.2, 0.5, 0.85])

@@ -111,7 +111,7 @@ int main(int argc, char **argv) {
         return 0;
     }
 #define CASE(L, U) if (line == L && unroll == U) ms = run<L, U>(tab, nlines, iters, blocks, sink, share);
-    CASE(64, 1) CASE(64, 2) CASE(64, 4) CASE(64, 8) CASE(128, 1) CASE(128, 2) CASE(128, 4) CASE(128, 8)
+    CASE(64, 1) CASE(64, 2) CASE(64, 4) CASE(64, 8) CASE(128, 1) CASE(128, 2) CASE(128, 4) CASE(128, 8) CASE(256, 1) CASE(256, 2) CASE(256, 4) CASE(512, 2)
     if (ms == 0) { fprintf(stderr, "unsupported line/unroll\n"); return 1; }
     double groups = (double)blocks * 256 / (line / 16);
     double lines = groups * iters * unroll;
