@@ -18,7 +18,6 @@
 #include <vector>
 
 #include "../../include/hast.h"
-#include "fastq_reader.h"
 #include "ingest.h"
 
 namespace {

@@ -209,7 +209,7 @@ __device__ __forceinline__ uint64_t window_bits(const unsigned long long *words,
 }
 // value of lane J of my group of kLPB lanes (DPP quad_perm: [J,J,J,J] for quads, [J,J,2+J,2+J] for pairs)
 template <int J>
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) {
     constexpr int ctrl = kLPB == 4 ? J * 0x55 : (J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6));
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xF, 0xF, true);
 }
@@ -370,11 +370,11 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             B.bkt = ok ? bucket_of(mn, ck, nb) : 0;                  // invalid windows read bucket 0 (harmless)
             B.meta = r | (ok ? 0x80000000u : 0u);
             uint32_t bk[kRounds];
-            bk[0] = quad_bcast<0>(B.bkt);
-            bk[1] = quad_bcast<1>(B.bkt);
+            bk[0] = group_bcast<0>(B.bkt);
+            bk[1] = group_bcast<1>(B.bkt);
             if (kRounds == 4) {
-                bk[kRounds - 2] = quad_bcast<kRounds == 4 ? 2 : 0>(B.bkt);
-                bk[kRounds - 1] = quad_bcast<kRounds == 4 ? 3 : 1>(B.bkt);
+                bk[kRounds - 2] = group_bcast<kRounds == 4 ? 2 : 0>(B.bkt);
+                bk[kRounds - 1] = group_bcast<kRounds == 4 ? 3 : 1>(B.bkt);
             }
 #pragma unroll
             for (int j = 0; j < kRounds; ++j)
@@ -384,12 +384,12 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
         auto finish = [&](Blk &B) {
             // the window's key and read are re-broadcast here rather than kept live across the loads
             uint32_t kl[kRounds], kh[kRounds], mt[kRounds];
-            kl[0] = quad_bcast<0>(B.klo); kh[0] = quad_bcast<0>(B.khi); mt[0] = quad_bcast<0>(B.meta);
-            kl[1] = quad_bcast<1>(B.klo); kh[1] = quad_bcast<1>(B.khi); mt[1] = quad_bcast<1>(B.meta);
+            kl[0] = group_bcast<0>(B.klo); kh[0] = group_bcast<0>(B.khi); mt[0] = group_bcast<0>(B.meta);
+            kl[1] = group_bcast<1>(B.klo); kh[1] = group_bcast<1>(B.khi); mt[1] = group_bcast<1>(B.meta);
             if (kRounds == 4) {
                 constexpr int J2 = kRounds == 4 ? 2 : 0, J3 = kRounds == 4 ? 3 : 1;
-                kl[kRounds - 2] = quad_bcast<J2>(B.klo); kh[kRounds - 2] = quad_bcast<J2>(B.khi); mt[kRounds - 2] = quad_bcast<J2>(B.meta);
-                kl[kRounds - 1] = quad_bcast<J3>(B.klo); kh[kRounds - 1] = quad_bcast<J3>(B.khi); mt[kRounds - 1] = quad_bcast<J3>(B.meta);
+                kl[kRounds - 2] = group_bcast<J2>(B.klo); kh[kRounds - 2] = group_bcast<J2>(B.khi); mt[kRounds - 2] = group_bcast<J2>(B.meta);
+                kl[kRounds - 1] = group_bcast<J3>(B.klo); kh[kRounds - 1] = group_bcast<J3>(B.khi); mt[kRounds - 1] = group_bcast<J3>(B.meta);
             }
             uint32_t hitmask = 0, fullmask = 0;
 #pragma unroll
