@@ -11,7 +11,7 @@
 //   * unopenable k-mer/read file: error + exit 2 (the reference loops forever, classify.cpp:41);
 //   * ragged k-mer line / read shorter than K: error + exit 3 (the reference assert-aborts,
 //     kmer.h:154,171);
-//   * K must be in [1,31] (the reference is correct up to 32 and silently wrong above).
+//   * K must be in [1,32] like the reference's correct range (it is silently wrong above 32).
 // Additive flags: --device N (GPU ordinal, default 0), --block-mb N (ingest block size), --batch-reads N
 // (approximate records per GPU batch, for tests), --initial-barcodes N, --stats (timings on stderr).
 // -t/--thread N is honoured as the number of host parser threads.
@@ -46,7 +46,7 @@ void logtime() {                                  // classify.cpp:17-21
 void print_usage() {                              // same flags as the reference (classify.cpp:375-387); stderr is free-form
     fputs("\nclassify (MI355X) -- per-barcode haplotype votes for stLFR reads\n\n"
           "  classify --hap0 PATERNAL.mer --hap1 MATERNAL.mer --read READS.fq[.gz] [--read ...] [options]\n\n"
-          "  -p, --hap0 FILE       parent-0 specific k-mers, one per line (K = length of the first line, K <= 31)\n"
+          "  -p, --hap0 FILE       parent-0 specific k-mers, one per line (K = length of the first line, K <= 32)\n"
           "  -m, --hap1 FILE       parent-1 specific k-mers\n"
           "  -r, --read FILE       child reads, 4-line FASTQ; gzip if the name ends in .gz; may be repeated\n"
           "  -t, --thread N        host parser threads (default 8)\n"
@@ -204,8 +204,8 @@ int main(int argc, char **argv) {
     if (!slurp(hap1, txt[1])) die(2, ("cannot read " + hap1).c_str());
     const void *nl0 = memchr(txt[0].data(), '\n', txt[0].size());
     K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // :35-36
-    if (K < 1 || K > 31) {
-        fprintf(stderr, "classify: ERROR: K=%zu (length of the first line of %s) is outside [1,31]\n", K, hap0.c_str());
+    if (K < 1 || K > 32) {
+        fprintf(stderr, "classify: ERROR: K=%zu (length of the first line of %s) is outside [1,32]\n", K, hap0.c_str());
         return 3;
     }
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");

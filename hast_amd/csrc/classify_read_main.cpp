@@ -6,7 +6,7 @@
 // reference does on the host around them: flag parsing, FASTA/FASTQ framing (s03:248-302), the density and
 // the call (s03:110-133, 215-216).
 //
-// Requirement (deviation): k-mer lines must be upper-case A/C/G/T of one length K <= 31 -- what jellyfish/meryl
+// Requirement (deviation): k-mer lines must be upper-case A/C/G/T of one length K <= 32 -- what jellyfish/meryl
 // dumps are.  The reference would also store other bytes literally (s03:59-65); we stop with exit 3 instead.
 #include <getopt.h>
 
@@ -87,7 +87,7 @@ int main(int argc, char **argv) {
         if (!slurp(haps[h], txt[h])) die(2, "cannot read " + haps[h]);
     const void *nl0 = memchr(txt[0].data(), '\n', txt[0].size());
     const size_t K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // s03:57-58
-    if (K < 1 || K > 31) die(3, "K (length of the first k-mer line) must be in [1,31]");
+    if (K < 1 || K > 32) die(3, "K (length of the first k-mer line) must be in [1,32]");
     for (int h = 0; h < 2; h++)
         for (char ch : txt[h])
             if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != '\n') die(3, "k-mer files must hold upper-case A/C/G/T lines only");

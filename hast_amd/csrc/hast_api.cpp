@@ -76,7 +76,8 @@ struct hast_ctx {
 
 namespace {
 
-TableGeom geom(const hast_ctx *c) { return TableGeom{c->nbuckets, c->k, c->m}; }
+TableGeom geom(const hast_ctx *c) { return TableGeom{c->nbuckets, c->k, c->m, c->k == 32}; }
+size_t table_slots(const hast_ctx *c) { return (size_t)c->nbuckets * kSlotsPerBucket * (c->k == 32 ? 2 : 1); }
 
 // default minimizer length: w = K-m+1 consecutive windows can share a bucket line; m stays >= 16 so that
 // the minimizer space (4^m/2 = 2.1 G) is well above human-scale key counts (4e8) and buckets stay evenly
@@ -132,7 +133,7 @@ SynthParams resolve(const hast_synth_params *p) {
 
 hast_status check_synth(const hast_synth_params *p) {
     if (!p) return fail(HAST_ERR_INVALID, "null synth params");
-    if (p->k < 1 || p->k > 31) return fail(HAST_ERR_INVALID, "synth k=%u out of [1,31]", p->k);
+    if (p->k < 1 || p->k > 32) return fail(HAST_ERR_INVALID, "synth k=%u out of [1,32]", p->k);
     return HAST_OK;
 }
 
@@ -147,7 +148,7 @@ const char *hast_last_error(void) { return g_err; }
 hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     if (!out) return fail(HAST_ERR_INVALID, "out is null");
     *out = nullptr;
-    if (k < 1 || k > 31) return fail(HAST_ERR_INVALID, "K=%d out of [1,31]", k);
+    if (k < 1 || k > 32) return fail(HAST_ERR_INVALID, "K=%d out of [1,32]", k);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -265,7 +266,8 @@ hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     if (c->d_slots) HIP_TRY(hipFree(c->d_slots));
     c->d_slots = nullptr;
     c->nbuckets = 0;
-    size_t bytes = (size_t)nb * kSlotsPerBucket * sizeof(uint64_t);
+    // K == 32: two tag-less tables (one per haplotype) back to back, each sized for all the keys
+    size_t bytes = (size_t)nb * kSlotsPerBucket * sizeof(uint64_t) * (c->k == 32 ? 2 : 1);
     HIP_TRY(hipMalloc(&c->d_slots, bytes));
     HIP_TRY(hipMemsetAsync(c->d_slots, 0xFF, bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -283,7 +285,7 @@ static hast_status need_table(hast_ctx *c, int hap) {
 hast_status hast_table_insert_keys_device(hast_ctx *c, int hap, const uint64_t *d_keys, size_t n, hast_stream s) {
     if (hast_status st = need_table(c, hap)) return st;
     hipStream_t hs = s ? (hipStream_t)s : c->stream;
-    HIP_TRY(launch_insert_keys(c->d_slots, geom(c), d_keys, n, 1u << hap, c->d_err, hs));
+    HIP_TRY(launch_insert_keys(c->d_slots, geom(c), d_keys, n, (uint32_t)hap, c->d_err, hs));
     return check_err_word(c, hs);
 }
 
@@ -295,7 +297,7 @@ hast_status hast_table_insert_keys(hast_ctx *c, int hap, const uint64_t *keys, s
     for (size_t i = 0; i < n; i += per) {
         size_t m = std::min(per, n - i);
         HIP_TRY(hipMemcpyAsync(c->d_scratch, keys + i, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_insert_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+        HIP_TRY(launch_insert_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, (uint32_t)hap, c->d_err, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return check_err_word(c, c->stream);
@@ -318,7 +320,7 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
     for (size_t i = 0; i < n_lines; i += per) {
         size_t m = std::min(per, n_lines - i);
         HIP_TRY(hipMemcpyAsync(c->d_scratch, text + i * stride, m * stride, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_insert_text(c->d_slots, geom(c), (const char *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+        HIP_TRY(launch_insert_text(c->d_slots, geom(c), (const char *)c->d_scratch, m, (uint32_t)hap, c->d_err, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (hast_status st = check_err_word(c, c->stream)) return st;
@@ -363,7 +365,7 @@ hast_status hast_table_sizes(hast_ctx *c, uint64_t *n0, uint64_t *n1) {
     if (hast_status st = need_table(c, 0)) return st;
     unsigned long long h[2] = {0, 0};
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(h), c->stream));
-    HIP_TRY(launch_count_tags(c->d_slots, (size_t)c->nbuckets * kSlotsPerBucket, c->d_cnt, c->stream));
+    HIP_TRY(launch_count_tags(c->d_slots, geom(c), c->d_cnt, c->stream));
     HIP_TRY(hipMemcpyAsync(h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (n0) *n0 = h[0];
@@ -383,6 +385,7 @@ struct CacheHeader {
 
 hast_status hast_table_save(hast_ctx *c, const char *path) {
     if (hast_status st = need_table(c, 0)) return st;
+    if (c->k == 32) return fail(HAST_ERR_INVALID, "the key-set cache stores tag bits next to the key: not available for K=32");
     if (!path) return fail(HAST_ERR_INVALID, "path is null");
     uint64_t n0 = 0, n1 = 0;
     if (hast_status st = hast_table_sizes(c, &n0, &n1)) return st;
@@ -440,7 +443,7 @@ hast_status hast_table_load(hast_ctx *c, const char *path, double load_factor) {
         fclose(f);
         return fail(HAST_ERR_FORMAT, "%s is not a HASTKEYS v1 file", path);
     }
-    if ((int)h.k != c->k) {
+    if (h.k == 32 || (int)h.k != c->k) {
         fclose(f);
         return fail(HAST_ERR_INVALID, "%s holds %u-mers, the context is K=%d", path, h.k, c->k);
     }
@@ -464,7 +467,7 @@ hast_status hast_table_load(hast_ctx *c, const char *path, double load_factor) {
 hast_status hast_table_info(const hast_ctx *c, uint64_t *n_buckets, uint64_t *bytes) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
     if (n_buckets) *n_buckets = c->nbuckets;
-    if (bytes) *bytes = (uint64_t)c->nbuckets * kSlotsPerBucket * sizeof(uint64_t);
+    if (bytes) *bytes = (uint64_t)table_slots(c) * sizeof(uint64_t);
     return HAST_OK;
 }
 
@@ -590,6 +593,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.nbuckets = c->nbuckets;
     a.read_len = read_len;
     a.k = c->k;
+    a.wide = c->k == 32;
     a.m = c->m;
     a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
     a.mh_stride = read_len >= (uint32_t)c->m ? read_len - c->m + 1 : 0;
@@ -815,7 +819,7 @@ int hast_get_hap(const char *bc, size_t blen, uint32_t c0, uint32_t c1, uint64_t
 uint64_t hast_canon_kmer(const char *s, int k) { return kmer_canon(kmer_pack(s, k), k); }
 
 size_t hast_chop_read(const char *seq, size_t len, int k, uint64_t *out) {
-    if (k < 1 || k > 31 || len < (size_t)k) return 0;
+    if (k < 1 || k > 32 || len < (size_t)k) return 0;
     const uint64_t mask = kmer_mask(k);
     uint64_t w = kmer_pack(seq, k);
     size_t n = 0;
@@ -883,7 +887,7 @@ hast_status hast_synth_table_build(hast_ctx *c, const hast_synth_params *p) {
         for (uint64_t i = 0; i < sp.n_keys_per_hap; i += per) {
             size_t m = (size_t)std::min<uint64_t>(per, sp.n_keys_per_hap - i);
             HIP_TRY(launch_synth_keys(sp, hap, i, m, (uint64_t *)c->d_scratch, c->stream));
-            HIP_TRY(launch_insert_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, 1u << hap, c->d_err, c->stream));
+            HIP_TRY(launch_insert_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, (uint32_t)hap, c->d_err, c->stream));
         }
     return check_err_word(c, c->stream);
 }

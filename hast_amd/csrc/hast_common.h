@@ -18,7 +18,7 @@ namespace hast {
 
 // ---- 2-bit k-mers (kmer.h:11-13, 129-166, 196-210) -----------------------------------------
 HAST_HD uint32_t base_code(uint32_t c) { return (c & 6u) >> 1; }              // kmer.h:11
-HAST_HD uint64_t kmer_mask(int k) { return (1ull << (2 * k)) - 1; }            // k <= 31
+HAST_HD uint64_t kmer_mask(int k) { return k >= 32 ? ~0ull : (1ull << (2 * k)) - 1; }   // k <= 32
 
 // reverse complement of a 2K-bit value: complement = code^2 (kmer.h:13), then reverse the order
 // of the 2-bit groups and right-align (kmer.h:196-210).
@@ -54,6 +54,10 @@ constexpr int      kSlotsPerBucket = HAST_SLOTS;   // 8 x 8 B = one 64-B line (1
 constexpr int      kPieces = kSlotsPerBucket / 2;  // 16-B pieces per bucket
 constexpr uint64_t kEmptySlot = ~0ull;             // (key<<2|tags) can never be all ones: the
                                                    // all-G k-mer is never canonical (all-C is smaller)
+// K = 32 ("wide"): a key needs all 64 bits, so there is no room for tag bits.  The table is then TWO tables back to
+// back, one per haplotype, whose slots hold the bare key; empty = all ones (G^32, never canonical) and an erased slot
+// becomes kTombSlot = G^31 T, never canonical either (its reverse complement starts with A).
+constexpr uint64_t kTombSlot = ~0ull - 1;
 
 // Home bucket of a canonical key = f(minimizer of the key), so that the K-m+1.. consecutive windows of a
 // read that share a minimizer probe the SAME 64-B line (the memory system merges them: one HBM request

@@ -11,6 +11,7 @@ struct TableGeom {
     uint32_t nbuckets;
     int k;          // k-mer length
     int m;          // minimizer length (m == k: plain hashing of the key)
+    int wide;       // k == 32: two tag-less tables back to back (hap h at slots + h * nbuckets * 8)
 };
 
 struct ClassifyArgs {
@@ -36,18 +37,19 @@ struct ClassifyArgs {
     uint32_t div_hw;             // same trick for 2*w64 (16-base half-words per read)
     int k;
     int m;                       // minimizer length
+    int wide;                    // K == 32: probe the two per-haplotype tables (slots, slots + nbuckets*8)
     int strict;                  // per-window validity (stage-03 string semantics) instead of the whole-read N skip
 };
 
-hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t tag,
+hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t hap,
                               uint32_t *d_err, hipStream_t s);
 hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, size_t n_lines,
-                              uint32_t tag, uint32_t *d_err, hipStream_t s);
+                              uint32_t hap, uint32_t *d_err, hipStream_t s);
 hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s);
 hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
 hipError_t launch_export_slots(const uint64_t *slots, size_t nslots, uint64_t *d_out, size_t cap, unsigned long long *d_counter, hipStream_t s);
 hipError_t launch_import_slots(uint64_t *slots, TableGeom g, const uint64_t *d_in, size_t n, uint32_t *d_err, hipStream_t s);
-hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s);
+hipError_t launch_count_tags(const uint64_t *slots, TableGeom g, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
 hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
                                  uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, hipStream_t s);

@@ -19,12 +19,21 @@ namespace hast {
 // probe order from its home bucket, that had a free slot when it was inserted; slots never become
 // empty again (erase only clears tag bits), so lookups may stop at the first bucket with an empty slot.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool table_insert(uint64_t *slots, const TableGeom g, uint64_t key, uint32_t tag) {
+__device__ __forceinline__ uint64_t *hap_table(uint64_t *slots, const TableGeom g, uint32_t hap) {
+    return g.wide ? slots + (size_t)hap * g.nbuckets * kSlotsPerBucket : slots;
+}
+__device__ __forceinline__ bool slot_has_key(unsigned long long slot, uint64_t key, int wide) {
+    return wide ? slot == key : (slot >> 2) == key;      // a canonical key never equals the empty/tombstone patterns
+}
+
+__device__ __forceinline__ bool table_insert(uint64_t *slots, const TableGeom g, uint64_t key, uint32_t hap) {
     const uint32_t nbuckets = g.nbuckets;
-    const uint64_t want = (key << 2) | tag;
+    const uint32_t tag = 1u << hap;
+    const uint64_t want = g.wide ? key : ((key << 2) | tag);
+    uint64_t *tab = hap_table(slots, g, hap);
     uint32_t b = home_bucket(key, g.k, g.m, nbuckets);
     for (uint32_t probe = 0; probe < nbuckets; ++probe) {
-        unsigned long long *bs = reinterpret_cast<unsigned long long *>(slots) + (size_t)b * kSlotsPerBucket;
+        unsigned long long *bs = reinterpret_cast<unsigned long long *>(tab) + (size_t)b * kSlotsPerBucket;
         for (int i = 0; i < kSlotsPerBucket; ++i) {
             unsigned long long cur = __hip_atomic_load(&bs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
@@ -34,8 +43,8 @@ __device__ __forceinline__ bool table_insert(uint64_t *slots, const TableGeom g,
                     cur = old;               // someone else took the slot: look at what they wrote
                     continue;
                 }
-                if ((cur >> 2) == key) {
-                    if ((cur & tag) == 0) atomicOr(&bs[i], (unsigned long long)tag);
+                if (slot_has_key(cur, key, g.wide)) {
+                    if (!g.wide && (cur & tag) == 0) atomicOr(&bs[i], (unsigned long long)tag);
                     return true;
                 }
                 break;
@@ -46,17 +55,17 @@ __device__ __forceinline__ bool table_insert(uint64_t *slots, const TableGeom g,
     return false;
 }
 
-// returns the address of the slot holding `key`, or nullptr
-__device__ __forceinline__ unsigned long long *table_find(uint64_t *slots, const TableGeom g, uint64_t key) {
+// returns the address of the slot holding `key` in table `tab`, or nullptr
+__device__ __forceinline__ unsigned long long *table_find(uint64_t *tab, const TableGeom g, uint64_t key) {
     const uint32_t nbuckets = g.nbuckets;
     uint32_t b = home_bucket(key, g.k, g.m, nbuckets);
     for (uint32_t probe = 0; probe < nbuckets; ++probe) {
-        unsigned long long *bs = reinterpret_cast<unsigned long long *>(slots) + (size_t)b * kSlotsPerBucket;
+        unsigned long long *bs = reinterpret_cast<unsigned long long *>(tab) + (size_t)b * kSlotsPerBucket;
         bool any_empty = false;
         for (int i = 0; i < kSlotsPerBucket; ++i) {
             unsigned long long cur = bs[i];
             if (cur == kEmptySlot) any_empty = true;
-            else if ((cur >> 2) == key) return &bs[i];
+            else if (slot_has_key(cur, key, g.wide)) return &bs[i];
         }
         if (any_empty) return nullptr;
         b = (b + 1 == nbuckets) ? 0 : b + 1;
@@ -65,15 +74,15 @@ __device__ __forceinline__ unsigned long long *table_find(uint64_t *slots, const
 }
 
 __global__ void __launch_bounds__(256) k_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *keys,
-                                                     size_t n, uint32_t tag, uint32_t *err) {
+                                                     size_t n, uint32_t hap, uint32_t *err) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        if (!table_insert(slots, g, keys[i], tag)) atomicOr(&err[0], 1u);
+        if (!table_insert(slots, g, keys[i], hap)) atomicOr(&err[0], 1u);
 }
 
 // load_kmers (classify.cpp:30-46): line i = text[i*(K+1) .. +K), text[i*(K+1)+K] must be '\n'.
 // err bit0: table full, bit1: a line is not exactly K bytes.
 __global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, TableGeom g, const char *text,
-                                                     size_t n_lines, uint32_t tag, uint32_t *err) {
+                                                     size_t n_lines, uint32_t hap, uint32_t *err) {
     const int k = g.k;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_lines; i += (size_t)gridDim.x * blockDim.x) {
         const char *s = text + i * (size_t)(k + 1);
@@ -85,24 +94,40 @@ __global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, TableGeom 
             w = (w << 2) | base_code(c);
         }
         if (bad) { atomicOr(&err[0], 2u); continue; }
-        if (!table_insert(slots, g, kmer_canon(w, k), tag)) atomicOr(&err[0], 1u);
+        if (!table_insert(slots, g, kmer_canon(w, k), hap)) atomicOr(&err[0], 1u);
     }
 }
 
-// InitAdaptor (classify.cpp:314-339): clear both tag bits of each key; report which were set.
+// InitAdaptor (classify.cpp:314-339): remove each key from both sets; report which sets had it.
 __global__ void k_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *keys, size_t n, uint8_t *hit) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long *p = table_find(slots, g, keys[i]);
-    unsigned long long old = p ? atomicAnd(p, ~3ull) : 0ull;
-    hit[i] = (uint8_t)(old & 3);
+    if (!g.wide) {
+        unsigned long long *p = table_find(slots, g, keys[i]);
+        unsigned long long old = p ? atomicAnd(p, ~3ull) : 0ull;
+        hit[i] = (uint8_t)(old & 3);
+        return;
+    }
+    uint32_t h = 0;
+    for (uint32_t hap = 0; hap < 2; ++hap) {
+        unsigned long long *p = table_find(hap_table(slots, g, hap), g, keys[i]);
+        if (p && atomicCAS(p, (unsigned long long)keys[i], (unsigned long long)kTombSlot) == keys[i]) h |= 1u << hap;
+    }
+    hit[i] = (uint8_t)h;
 }
 
 __global__ void k_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *keys, size_t n, uint8_t *tags) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long *p = table_find(slots, g, keys[i]);
-    tags[i] = p ? (uint8_t)(*p & 3) : 0;
+    if (!g.wide) {
+        unsigned long long *p = table_find(slots, g, keys[i]);
+        tags[i] = p ? (uint8_t)(*p & 3) : 0;
+        return;
+    }
+    uint32_t t = 0;
+    for (uint32_t hap = 0; hap < 2; ++hap)
+        if (table_find(hap_table(slots, g, hap), g, keys[i])) t |= 1u << hap;
+    tags[i] = (uint8_t)t;
 }
 
 // Table export/import (binary key-set cache): the live slots (key<<2|tags, tags != 0) are compacted
@@ -121,17 +146,25 @@ __global__ void __launch_bounds__(256) k_import_slots(uint64_t *slots, TableGeom
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint64_t s = in[i];
         if ((s & 3) == 0 || (s >> 2) >> (2 * g.k)) { atomicOr(&err[0], 2u); continue; }     // not a slot image for this K
-        if (!table_insert(slots, g, s >> 2, (uint32_t)(s & 3))) atomicOr(&err[0], 1u);
+        bool ok = true;
+        if (s & 1) ok = table_insert(slots, g, s >> 2, 0);
+        if (ok && (s & 2)) ok = table_insert(slots, g, s >> 2, 1);
+        if (!ok) atomicOr(&err[0], 1u);
     }
 }
 
 // g_kmers[h].size(): number of slots with tag bit h.  Streaming 16 B/lane.
-__global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *out) {
+__global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *out, int wide) {
     unsigned long long c0 = 0, c1 = 0;
     const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(slots);
     size_t n2 = nslots / 2;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
         ulonglong2 s = v[i];
+        if (wide) {        // tag-less tables: hap 0 in the first half of the slots, hap 1 in the second; count live slots
+            const unsigned long long live = (unsigned long long)(s.x < kTombSlot) + (unsigned long long)(s.y < kTombSlot);
+            if (2 * i < nslots / 2) c0 += live; else c1 += live;
+            continue;
+        }
         if (s.x != kEmptySlot) { c0 += s.x & 1; c1 += (s.x >> 1) & 1; }
         if (s.y != kEmptySlot) { c0 += s.y & 1; c1 += (s.y >> 1) & 1; }
     }
@@ -219,7 +252,8 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v) {
 // STRICT = per-window validity instead of the whole-read N skip: a window counts only when all its K bytes
 //          are upper-case A/C/G/T (the string semantics of the stage-03 per-read classifier,
 //          03.mkoutput_by_fabulous2.0/src_main/classify.cpp:209-214); rows may then be SEGMENTS of long reads
-template <int WT, bool FAST, bool STRICT>
+// WIDE = K == 32: bare 64-bit keys in two per-haplotype tables, probed one after the other
+template <int WT, bool FAST, bool STRICT, bool WIDE>
 __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
@@ -250,7 +284,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
-    const u64x2 *tab = reinterpret_cast<const u64x2 *>(a.slots) + sub;     // this lane's first 16-B piece of bucket 0
+    const u64x2 *tab0 = reinterpret_cast<const u64x2 *>(a.slots) + sub;    // this lane's first 16-B piece of bucket 0
 
     // Tiles are handed out by a global queue (one atomic per tile), so the load stays balanced whatever the
     // residency of the grid is (the grid may be larger than what fits the chip at once).
@@ -340,6 +374,8 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
         // Software pipeline over the wave's blocks: the loads of block i+1 are issued (after its windows are
         // computed) BEFORE block i is compared, so a wave always has 4..8 bucket loads in flight while it does
         // VALU work, instead of alternating "compute with nothing in flight" and "wait".
+        const u64x2 *tab = tab0;                        // table probed in this pass (WIDE: one pass per haplotype)
+        uint32_t pass_tags = 0;                         // WIDE: the tag a match in this pass stands for
         struct Blk {
             uint32_t klo, khi, bkt, meta;               // this lane's own window
             u64x2 sl[kRounds][kNLd];                    // the bucket pieces this lane loaded, per round
@@ -365,8 +401,8 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             } else {
                 for (uint32_t j = 1; j < W; ++j) mn = min(mn, mh[j]);
             }
-            B.klo = (uint32_t)(ck << 2);
-            B.khi = (uint32_t)(ck >> 30);
+            B.klo = WIDE ? (uint32_t)ck : (uint32_t)(ck << 2);        // the slot value without tags (WIDE: the bare key)
+            B.khi = WIDE ? (uint32_t)(ck >> 32) : (uint32_t)(ck >> 30);
             B.bkt = ok ? bucket_of(mn, ck, nb) : 0;                  // invalid windows read bucket 0 (harmless)
             B.meta = r | (ok ? 0x80000000u : 0u);
             uint32_t bk[kRounds];
@@ -398,7 +434,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                 const bool valid = (int)mt[j] < 0;
                 bool m = false;
 #pragma unroll
-                for (int l = 0; l < kNLd; ++l) m = m || (B.sl[j][l].x & ~3ull) == kq || (B.sl[j][l].y & ~3ull) == kq;
+                for (int l = 0; l < kNLd; ++l) m = m || (WIDE ? B.sl[j][l].x : (B.sl[j][l].x & ~3ull)) == kq || (WIDE ? B.sl[j][l].y : (B.sl[j][l].y & ~3ull)) == kq;
                 if (valid && m) hitmask |= 1u << j;
                 // bucket full <=> its last slot (last lane of the group, last piece, .y) is taken: slots fill in order
                 if (valid && B.sl[j][kNLd - 1].y != kEmptySlot && sub == kLPB - 1) fullmask |= 1u << j;
@@ -411,10 +447,10 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                         unsigned long long hit_slot = 0;
 #pragma unroll
                         for (int l = 0; l < kNLd; ++l) {
-                            if ((B.sl[j][l].x & ~3ull) == kq) hit_slot = B.sl[j][l].x;
-                            if ((B.sl[j][l].y & ~3ull) == kq) hit_slot = B.sl[j][l].y;
+                            if ((WIDE ? B.sl[j][l].x : (B.sl[j][l].x & ~3ull)) == kq) hit_slot = B.sl[j][l].x;
+                            if ((WIDE ? B.sl[j][l].y : (B.sl[j][l].y & ~3ull)) == kq) hit_slot = B.sl[j][l].y;
                         }
-                        const uint32_t tags = (uint32_t)(hit_slot & 3);
+                        const uint32_t tags = WIDE ? pass_tags : (uint32_t)(hit_slot & 3);
                         atomicAdd(&s_vote[mt[j] & 0xFFFF], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
                     }
             }
@@ -448,14 +484,14 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                         bool h2 = false;
 #pragma unroll
                         for (int l = 0; l < kNLd; ++l) {
-                            if ((s2[l].x & ~3ull) == kq) { hit_slot = s2[l].x; h2 = true; }
-                            if ((s2[l].y & ~3ull) == kq) { hit_slot = s2[l].y; h2 = true; }
+                            if ((WIDE ? s2[l].x : (s2[l].x & ~3ull)) == kq) { hit_slot = s2[l].x; h2 = true; }
+                            if ((WIDE ? s2[l].y : (s2[l].y & ~3ull)) == kq) { hit_slot = s2[l].y; h2 = true; }
                         }
                         h2 = h2 && pending;
                         // the bucket is not full iff its last slot is empty; any empty .y of the last piece implies it
                         const unsigned long long m2 = __ballot(h2 || (pending && s2[kNLd - 1].y == kEmptySlot));
                         if (h2) {
-                            const uint32_t tags = (uint32_t)(hit_slot & 3);
+                            const uint32_t tags = WIDE ? pass_tags : (uint32_t)(hit_slot & 3);
                             atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
                         }
                         if (((m2 >> gsh) & kGrpMask) != 0 || ++guard >= nb) pending = false;
@@ -464,7 +500,11 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                 }
             }
         };
-        {
+        for (int pass = 0; pass < (WIDE ? 2 : 1); ++pass) {
+            if (WIDE) {
+                tab = tab0 + (size_t)pass * nb * kPieces;
+                pass_tags = 1u << pass;
+            }
             Blk A, B;
             uint32_t blk = wave;
             bool va = blk < nblk;
@@ -533,16 +573,16 @@ static inline int grid_for(size_t n, int block, int cap) {
     return (int)(g > (size_t)cap ? (size_t)cap : g);
 }
 
-hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t tag,
+hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t hap,
                               uint32_t *d_err, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_keys, n, tag, d_err);
+    hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_keys, n, hap, d_err);
     return hipGetLastError();
 }
 hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, size_t n_lines,
-                              uint32_t tag, uint32_t *d_err, hipStream_t s) {
+                              uint32_t hap, uint32_t *d_err, hipStream_t s) {
     if (n_lines == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_text, n_lines, tag, d_err);
+    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_text, n_lines, hap, d_err);
     return hipGetLastError();
 }
 hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s) {
@@ -564,18 +604,19 @@ hipError_t launch_import_slots(uint64_t *slots, TableGeom g, const uint64_t *d_i
     hipLaunchKernelGGL(k_import_slots, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_in, n, d_err);
     return hipGetLastError();
 }
-hipError_t launch_count_tags(const uint64_t *slots, size_t nslots, unsigned long long *d_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_count_tags, dim3(grid_for(nslots / 2, 256, 256 * 8)), dim3(256), 0, s, slots, nslots, d_out);
+hipError_t launch_count_tags(const uint64_t *slots, TableGeom g, unsigned long long *d_out, hipStream_t s) {
+    const size_t nslots = (size_t)g.nbuckets * kSlotsPerBucket * (g.wide ? 2 : 1);
+    hipLaunchKernelGGL(k_count_tags, dim3(grid_for(nslots / 2, 256, 256 * 8)), dim3(256), 0, s, slots, nslots, d_out, g.wide);
     return hipGetLastError();
 }
-template <int WT, bool FAST, bool STRICT>
+template <int WT, bool FAST, bool STRICT, bool WIDE = false>
 static hipError_t launch_classify_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<WT, FAST, STRICT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify<WT, FAST, STRICT, WIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_classify<WT, FAST, STRICT>), dim3(grid), dim3(kThreads), smem, s, a);
+    hipLaunchKernelGGL((k_classify<WT, FAST, STRICT, WIDE>), dim3(grid), dim3(kThreads), smem, s, a);
     return hipGetLastError();
 }
 
@@ -583,6 +624,7 @@ template <bool STRICT>
 static hipError_t launch_classify_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     const int w = a.k - a.m + 1;
     const bool fast = a.div_magic && a.div_mh && a.div_hw;
+    if (a.wide) return fast ? launch_classify_t<0, true, STRICT, true>(a, grid, smem, s) : launch_classify_t<0, false, STRICT, true>(a, grid, smem, s);
     if (!fast) return launch_classify_t<0, false, STRICT>(a, grid, smem, s);
     switch (w) {
     case 1: return launch_classify_t<1, true, STRICT>(a, grid, smem, s);

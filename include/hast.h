@@ -29,7 +29,7 @@ extern "C" {
 
 typedef enum {
     HAST_OK = 0,
-    HAST_ERR_INVALID = 1,    /* bad argument / K out of [1,31] / wrong call order            */
+    HAST_ERR_INVALID = 1,    /* bad argument / K out of [1,32] / wrong call order            */
     HAST_ERR_NO_DEVICE = 2,  /* no HIP device, or the device is not usable                  */
     HAST_ERR_HIP = 3,        /* a HIP runtime call failed (message in hast_last_error)      */
     HAST_ERR_OOM = 4,        /* host or device allocation failed                            */
@@ -48,7 +48,8 @@ const char *hast_last_error(void);
 /* ---- context ------------------------------------------------------------------------------
  * Holds what the reference keeps in process globals: g_K (classify.cpp:29), g_kmers[2]
  * (classify.cpp:27) as ONE merged open-addressed table in HBM, and the per-barcode counters
- * (BarcodeCache, classify.cpp:50-64).  k in [1,31]. */
+ * (BarcodeCache, classify.cpp:50-64).  k in [1,32] (the reference's correct range; at k = 32 a key
+ * fills the 64-bit slot, so the table is two tag-less per-haplotype tables and every window is probed twice). */
 hast_status hast_ctx_create(int device_ordinal, int k, hast_ctx **out);
 void        hast_ctx_destroy(hast_ctx *);
 int         hast_ctx_k(const hast_ctx *);

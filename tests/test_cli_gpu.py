@@ -19,7 +19,7 @@ def exe():
     return hast_amd.classify_exe()
 
 
-@pytest.mark.parametrize("case,run", [c for c in golden_cases("s01") if c[0] != "rand_k32"])
+@pytest.mark.parametrize("case,run", golden_cases("s01"))
 def test_cli_matches_reference_golden(exe, golden_workdir, case, run):
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case

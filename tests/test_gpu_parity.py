@@ -52,8 +52,8 @@ def oracle_votes(o, oc, bases, offsets):
 
 
 # ------------------------------------------------------------------------------------------------
-def test_table_build_sizes_lookup_erase(built, oracle_lib):
-    k = 21
+@pytest.mark.parametrize("k", [21, 32])
+def test_table_build_sizes_lookup_erase(built, oracle_lib, k):
     rng = np.random.default_rng(1)
     mask = (1 << (2 * k)) - 1
     raw0 = rng.integers(0, mask, 40000, dtype=np.uint64)
@@ -129,7 +129,7 @@ def test_table_full_is_reported(built):
 
 
 def test_insert_text_matches_reference_set_sizes(built, oracle_lib, golden_workdir):
-    for case in ("edge_k7", "rand_k21", "rand_k31", "rand_k11"):
+    for case in ("edge_k7", "rand_k21", "rand_k31", "rand_k32", "rand_k11"):
         d = golden_workdir / case
         t0, t1 = open(d / "hap0.mer", "rb").read(), open(d / "hap1.mer", "rb").read()
         k = t0.index(b"\n")
@@ -168,7 +168,7 @@ def test_synth_generators_agree(built, clustered):
         assert np.array_equal(ctx.to_host(d_k, (n,), np.uint64), hast_amd.synth_keys_host(p, 1, 77, n))
 
 
-@pytest.mark.parametrize("k,L", [(21, 150), (31, 150), (11, 100), (5, 64), (27, 151), (1, 40)])
+@pytest.mark.parametrize("k,L", [(21, 150), (31, 150), (32, 150), (11, 100), (5, 64), (27, 151), (1, 40)])
 def test_classify_fixed_length_vs_oracle(built, oracle_lib, k, L):
     n_keys, n_reads, n_bc = 20000, 20011, 333
     if k <= 5:
@@ -228,7 +228,7 @@ def ragged_reads(rng, k, keys, n, max_len):
     return seqs
 
 
-@pytest.mark.parametrize("k,max_len", [(21, 180), (31, 97), (7, 300), (13, 2500)])
+@pytest.mark.parametrize("k,max_len", [(21, 180), (31, 97), (32, 140), (7, 300), (13, 2500)])
 def test_classify_ragged_reads_vs_oracle(built, oracle_lib, k, max_len):
     """Variable-length reads through offsets: empty, shorter than K (the reference aborts; we define
     0 windows), len==K, N / n / lower-case / IUPAC bytes, unaligned starts."""
@@ -295,7 +295,7 @@ def test_classify_votes_only_and_linearity(built, oracle_lib):
     assert np.array_equal(np.bincount(ids, weights=(votes.sum(1) == 0), minlength=n_bc).astype(np.uint32), whole[2])
 
 
-@pytest.mark.parametrize("k,m", [(21, 1), (21, 5), (21, 11), (21, 16), (21, 20), (21, 21), (31, 9), (31, 31), (12, 7)])
+@pytest.mark.parametrize("k,m", [(21, 1), (21, 5), (21, 11), (21, 16), (21, 20), (21, 21), (31, 9), (31, 31), (32, 32), (32, 20), (12, 7)])
 def test_minimizer_length_does_not_change_results(built, oracle_lib, k, m):
     """Bucket placement by minimizer (any m in [1,K]) is invisible in the results: table sizes, lookups,
     per-read votes and per-barcode counts stay bit-exact against the oracle; ragged reads included."""
@@ -345,7 +345,7 @@ def _kmer_str(key, k):
     return "".join("ACTG"[(int(key) >> (2 * (k - 1 - j))) & 3] for j in range(k))
 
 
-@pytest.mark.parametrize("k,max_len", [(21, 3000), (31, 30000), (11, 600), (27, 100)])
+@pytest.mark.parametrize("k,max_len", [(21, 3000), (31, 30000), (32, 2000), (11, 600), (27, 100)])
 def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len):
     """Integer hits per read == the stage-03 reference's string lookups: windows containing N / lower-case /
     IUPAC bytes miss (no whole-read skip), reads far longer than an LDS row are segmented on the device."""
@@ -496,7 +496,7 @@ def test_randomized_configurations_vs_oracle(built, oracle_lib):
     lengths, tile tails.  Per-read votes and per-barcode counts must equal the oracle's in every configuration."""
     rng = random.Random(int(os.environ.get("HAST_FUZZ_SEED", "20261003")))
     for it in range(int(os.environ.get("HAST_FUZZ_ITERS", "36"))):
-        k = rng.choice([3, 8, 12, 16, 19, 21, 24, 28, 31])
+        k = rng.choice([3, 8, 12, 16, 19, 21, 24, 28, 31, 32])
         m = rng.choice([1, max(1, k - 12), max(1, k - 5), k - 1 if k > 1 else 1, k])
         lf = rng.choice([0.2, 0.5, 0.85])
         fixed = rng.random() < 0.5
