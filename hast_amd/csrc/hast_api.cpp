@@ -636,24 +636,34 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     return HAST_OK;
 }
 
+static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                      size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
+                                      hipStream_t hs);
+static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
+static constexpr uint32_t kLongRead = 4096;      // longer reads (with offsets) go through the segmented path
+
 hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  uint32_t read_len, const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads,
                                  hast_stream s) {
+    if (read_len > kLongRead && d_offsets && c && c->d_slots && n_reads) {
+        // stage-01 semantics on long reads: whole-read N skip by a pre-pass, windows through segments
+        if (d_barcode_ids && !c->d_counts) return fail(HAST_ERR_INVALID, "barcode ids given but no counters bound");
+        if (hast_status st = use(c)) return st;
+        return classify_segmented(c, d_bases, bases_bytes, d_offsets, n_reads, 0, d_barcode_ids, d_votes, s ? (hipStream_t)s : c->stream);
+    }
     return classify_rows(c, d_bases, bases_bytes, d_offsets, nullptr, nullptr, 0, read_len, d_barcode_ids, d_votes, n_reads, s);
 }
 
-// Per-read mode with the string semantics of the stage-03 classifier; reads of any length are cut into
-// segments of kSegWindows windows on the device so that a kernel row always fits LDS.
-static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 512 bases per row for K <= 31
-
-hast_status hast_classify_perread_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
-                                         size_t n_reads, uint32_t *d_votes, hast_stream s) {
-    if (hast_status st = need_table(c, 0)) return st;
-    if (n_reads == 0) return HAST_OK;
-    if (!d_bases || !d_offsets || !d_votes) return fail(HAST_ERR_INVALID, "null argument");
-    hipStream_t hs = s ? (hipStream_t)s : c->stream;
+// Reads of any length: cut into segments on the device, classify the segments, add their votes per read.
+//   strict = 1: stage-03 semantics (per-window validity), votes written to d_votes_out.
+//   strict = 0: stage-01 semantics (a read holding 'N' is skipped as a whole: found by a pre-pass, such reads get no
+//               windows), then per-read bookkeeping into the barcode counters and/or d_votes_out.
+static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                      size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
+                                      hipStream_t hs) {
     const size_t max_seg = n_reads + bases_bytes / kSegWindows + 1;
-    const size_t need = max_seg * (sizeof(uint64_t) + 2 * sizeof(uint32_t)) + 64;
+    const size_t votes_b = ((n_reads * 2 * sizeof(uint32_t) + 255) & ~(size_t)255), flags_b = ((n_reads + 255) & ~(size_t)255);
+    const size_t need = max_seg * (sizeof(uint64_t) + 2 * sizeof(uint32_t)) + votes_b + flags_b + 256;
     if (c->seg_bytes < need) {
         HIP_TRY(hipStreamSynchronize(hs));
         if (c->d_seg) HIP_TRY(hipFree(c->d_seg));
@@ -662,19 +672,36 @@ hast_status hast_classify_perread_device(hast_ctx *c, const uint8_t *d_bases, si
         HIP_TRY(hipMalloc(&c->d_seg, need + need / 4));
         c->seg_bytes = need + need / 4;
     }
-    const size_t cap = (c->seg_bytes - 64) / (sizeof(uint64_t) + 2 * sizeof(uint32_t));
-    uint64_t *seg_off = (uint64_t *)c->d_seg;
+    uint32_t *acc = (uint32_t *)c->d_seg;                                  // per-read vote accumulator
+    uint8_t *has_n = (uint8_t *)c->d_seg + votes_b;
+    const size_t cap = (c->seg_bytes - votes_b - flags_b - 256) / (sizeof(uint64_t) + 2 * sizeof(uint32_t));
+    uint64_t *seg_off = (uint64_t *)((uint8_t *)c->d_seg + votes_b + flags_b);
     uint32_t *seg_len = (uint32_t *)(seg_off + cap);
     uint32_t *seg_read = seg_len + cap;
+    // strict callers own an output row per read; otherwise accumulate privately and commit afterwards
+    uint32_t *target = strict ? d_votes_out : acc;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), hs));
-    HIP_TRY(hipMemsetAsync(d_votes, 0, n_reads * 2 * sizeof(uint32_t), hs));
-    HIP_TRY(launch_build_segments(d_offsets, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt, hs));
+    HIP_TRY(hipMemsetAsync(target, 0, n_reads * 2 * sizeof(uint32_t), hs));
+    if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, n_reads, has_n, hs));
+    HIP_TRY(launch_build_segments(d_offsets, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt,
+                                  strict ? nullptr : has_n, hs));
     unsigned long long n_seg = 0;
     HIP_TRY(hipMemcpyAsync(&n_seg, c->d_cnt, sizeof(n_seg), hipMemcpyDeviceToHost, hs));
     HIP_TRY(hipStreamSynchronize(hs));
     if (n_seg > cap) return fail(HAST_ERR_INVALID, "segment table overflow (%llu > %zu)", n_seg, cap);
-    return classify_rows(c, d_bases, bases_bytes, seg_off, seg_len, seg_read, 1, kSegWindows + (uint32_t)c->k - 1, nullptr,
-                         d_votes, (size_t)n_seg, hs);
+    if (hast_status st = classify_rows(c, d_bases, bases_bytes, seg_off, seg_len, seg_read, strict, kSegWindows + (uint32_t)c->k - 1,
+                                       nullptr, target, (size_t)n_seg, hs))
+        return st;
+    if (!strict) HIP_TRY(launch_commit_votes(acc, d_barcode_ids, c->d_counts, d_votes_out, n_reads, hs));
+    return HAST_OK;
+}
+
+hast_status hast_classify_perread_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+                                         size_t n_reads, uint32_t *d_votes, hast_stream s) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n_reads == 0) return HAST_OK;
+    if (!d_bases || !d_offsets || !d_votes) return fail(HAST_ERR_INVALID, "null argument");
+    return classify_segmented(c, d_bases, bases_bytes, d_offsets, n_reads, 1, nullptr, d_votes, s ? (hipStream_t)s : c->stream);
 }
 
 hast_status hast_classify_perread(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, size_t n_reads,

@@ -52,7 +52,11 @@ hipError_t launch_import_slots(uint64_t *slots, TableGeom g, const uint64_t *d_i
 hipError_t launch_count_tags(const uint64_t *slots, TableGeom g, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
 hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
-                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, hipStream_t s);
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
+                                 hipStream_t s);
+hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, size_t n_reads, uint8_t *d_has_n, hipStream_t s);
+hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
+                               size_t n_reads, hipStream_t s);
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
 hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);
 

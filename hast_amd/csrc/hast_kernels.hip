@@ -648,10 +648,10 @@ hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStre
 // Long reads -> segments of at most seg_windows windows (consecutive segments overlap by K-1 bases), so that a
 // row of the classify kernel always fits LDS.  One thread per read; segment rows are handed out with one atomic.
 __global__ void k_build_segments(const uint64_t *offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
-                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter) {
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter, const uint8_t *skip) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n_reads) return;
-    const uint64_t off = offsets[i], len = offsets[i + 1] - off;
+    const uint64_t off = offsets[i], len = (skip && skip[i]) ? 0 : offsets[i + 1] - off;   // skipped read: no windows
     const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
     const uint64_t nseg = nwin ? (nwin + seg_windows - 1) / seg_windows : 1;
     const unsigned long long base = atomicAdd(counter, (unsigned long long)nseg);
@@ -665,11 +665,49 @@ __global__ void k_build_segments(const uint64_t *offsets, size_t n_reads, int k,
     }
 }
 
+// containN (classify.cpp:182-185) for reads too long for one kernel row: one wave per read scans its bytes.
+__global__ void __launch_bounds__(256) k_scan_n(const uint8_t *bases, const uint64_t *offsets, size_t n_reads, uint8_t *has_n) {
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (wave >= n_reads) return;
+    const uint64_t off = offsets[wave], len = offsets[wave + 1] - off;
+    bool found = false;
+    for (uint64_t i = lane; i < len && !found; i += 64) found = bases[off + i] == 'N';
+    const bool any = __any(found);
+    if (lane == 0) has_n[wave] = any ? 1 : 0;
+}
+// process_reads' bookkeeping (classify.cpp:203-208) from per-read votes accumulated over segments.
+__global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, const uint32_t *barcode_ids, uint32_t *counts,
+                                                      uint32_t *votes_out, size_t n_reads) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    const uint32_t v0 = votes[2 * i], v1 = votes[2 * i + 1];
+    if (votes_out) { votes_out[2 * i] = v0; votes_out[2 * i + 1] = v1; }
+    if (barcode_ids) {
+        uint32_t *rec = counts + 4 * (size_t)barcode_ids[i];
+        if (v0 | v1) atomicAdd(reinterpret_cast<unsigned long long *>(rec), (unsigned long long)v0 | ((unsigned long long)v1 << 32));
+        else atomicAdd(rec + 2, 1u);
+    }
+}
+hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, size_t n_reads, uint8_t *d_has_n, hipStream_t s) {
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_n, dim3((unsigned)((n_reads * 64 + 255) / 256)), dim3(256), 0, s, d_bases, d_offsets, n_reads, d_has_n);
+    return hipGetLastError();
+}
+hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
+                               size_t n_reads, hipStream_t s) {
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_commit_votes, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_votes, d_barcode_ids, d_counts,
+                       d_votes_out, n_reads);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
-                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, hipStream_t s) {
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
+                                 hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_segments, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_offsets, n_reads, k,
-                       seg_windows, seg_off, seg_len, seg_read, d_counter);
+                       seg_windows, seg_off, seg_len, seg_read, d_counter, d_skip);
     return hipGetLastError();
 }
 

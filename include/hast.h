@@ -135,7 +135,9 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
  *   d_votes        optional [n_reads][2] per-read (vote0, vote1) output (per-read mode), or NULL
  *   bases_bytes    total bytes readable at d_bases (reads never look past it)
  * A read shorter than K has no windows (the reference aborts, kmer.h:171): it votes 0/0.
- * Asynchronous on `stream`. */
+ * Reads of any length: with d_offsets and read_len > 4096 the reads are cut into segments on the device
+ * (same result; the call then waits for one small device->host counter before the main launch).
+ * Otherwise asynchronous on `stream`. */
 hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
                                  const uint64_t *d_offsets, uint32_t read_len,
                                  const uint32_t *d_barcode_ids, uint32_t *d_votes,

@@ -58,7 +58,7 @@ def test_cli_usage_and_errors(exe, golden_workdir, tmp_path):
     assert r.returncode == 3                           # the reference aborts (kmer.h:171)
 
 
-def _write_case(tmp_path, n_records, seed, gz):
+def _write_case(tmp_path, n_records, seed, gz, long_reads=False):
     """A FASTQ the oracle and the CLI both read: ragged lengths, odd headers, N reads, last line unterminated."""
     import gzip
     import random
@@ -75,11 +75,13 @@ def _write_case(tmp_path, n_records, seed, gz):
     recs = []
     for i in range(n_records):
         L = rng.choice([k, 30, 100, 100, 100, 150, rng.randint(k, 400)])
+        if long_reads and rng.random() < 0.05:
+            L = rng.randint(4000, 90000)                       # beyond one kernel row: segmented path
         s = [rng.choice("ACGT") for _ in range(L)]
         for _ in range(rng.randint(0, 2)):
             o = rng.randint(0, L - k)
             s[o:o + k] = tostr(rng.choice(allk))
-        if rng.random() < 0.02:
+        if rng.random() < (0.3 if L > 4000 else 0.02):
             s[rng.randrange(L)] = "N"
         bc = "0_0_0" if rng.random() < 0.15 else "%d_%d_%d" % (rng.randint(1, 40), rng.randint(1, 40), rng.randint(1, 3))
         head = "@R%07d#%s/%d\tx%d" % (i, bc, 1 + (i & 1), i) if rng.random() < 0.9 else "@odd%d/%s#%s" % (i, "y" * rng.randint(0, 5), bc)
@@ -108,6 +110,19 @@ def test_cli_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path, gz, threa
     assert got.returncode == 0, got.stderr.decode()[-2000:]
     assert got.stdout == ref.stdout
     assert len(got.stdout.splitlines()) > 1000
+
+
+def test_cli_long_reads_stage01_semantics(exe, oracle_dir, tmp_path):
+    """Reads far longer than one kernel row (segments + whole-read N skip by a pre-pass) mixed with short ones."""
+    path = _write_case(tmp_path, 1500, seed=77, gz=False, long_reads=True)
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", path.name]
+    ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args, cwd=tmp_path, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert ref.returncode == 0, ref.stderr.decode()[-500:]
+    for extra in (["-t", "4"], ["-t", "3", "--batch-reads", "100"]):
+        got = subprocess.run([exe] + args + extra, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert got.returncode == 0, got.stderr.decode()[-2000:]
+        assert got.stdout == ref.stdout
 
 
 @pytest.mark.parametrize("case,run", golden_cases("s03"))

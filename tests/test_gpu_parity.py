@@ -228,16 +228,17 @@ def ragged_reads(rng, k, keys, n, max_len):
     return seqs
 
 
-@pytest.mark.parametrize("k,max_len", [(21, 180), (31, 97), (32, 140), (7, 300), (13, 2500)])
+@pytest.mark.parametrize("k,max_len", [(21, 180), (31, 97), (32, 140), (7, 300), (13, 2500), (21, 70000), (32, 9000)])
 def test_classify_ragged_reads_vs_oracle(built, oracle_lib, k, max_len):
     """Variable-length reads through offsets: empty, shorter than K (the reference aborts; we define
-    0 windows), len==K, N / n / lower-case / IUPAC bytes, unaligned starts."""
+    0 windows), len==K, N / n / lower-case / IUPAC bytes, unaligned starts.  max_len > 4096 goes through the
+    segmented path (whole-read N skip by a pre-pass, votes summed over segments)."""
     rng = random.Random(k * 1000 + max_len)
     n_keys, n_bc = 3000, 50
     p = make_params(k, 100, n_keys, n_bc)
     keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
     oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
-    seqs = ragged_reads(rng, k, np.concatenate(keys), 6000 if max_len < 1000 else 700, max_len)
+    seqs = ragged_reads(rng, k, np.concatenate(keys), 6000 if max_len < 1000 else 700 if max_len < 4096 else 160, max_len)
     lens = np.array([len(s) for s in seqs], dtype=np.uint64)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
