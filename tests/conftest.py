@@ -71,3 +71,20 @@ def golden_workdir(tmp_path_factory):
 
 def load_case(name):
     return json.load(open(os.path.join(GOLDEN, name, "case.json")))
+
+
+def run_s00_case(exe, golden_workdir, tmp_path, case, run, extra_args=()):
+    """Run a build_unshared_kmers.sh replacement (the oracle's or the product's) on a stage-00 golden case in a scratch
+    directory and compare every product the reference script left behind (.mer files as sorted line sets)."""
+    import subprocess
+    meta = load_case(case)["runs"][run]
+    work = tmp_path / ("%s_%s" % (case, run))
+    shutil.copytree(golden_workdir / case, work)
+    res = subprocess.run([exe] + meta["argv"] + list(extra_args), cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, (res.stdout.decode()[-1000:], res.stderr.decode()[-2000:])
+    for prod, rec in meta["products"].items():
+        got = open(work / prod, "rb").read()
+        if rec["sorted"]:
+            got = b"".join(sorted(got.splitlines(keepends=True)))
+        assert got == open(work / rec["expected"], "rb").read(), (case, run, prod)
+    return res

@@ -333,7 +333,179 @@ def case_quartering():
         shutil.rmtree(tmp)
 
 
+# ------------------------------------------------------------------------------------------
+# stage 00: parent-unique k-mer sets.  The REAL reference script is run where it lies (it calls the jellyfish binary
+# vendored next to it); stored: our inputs, and its final products with the .mer lines SORTED (their order in the
+# reference is jellyfish's hash order, which nothing downstream depends on).
+S00_SCRIPT = "/root/reference/00.build_unshare_kmers_by_jellyfish/build_unshared_kmers.sh"
+
+
+def mutate(rng, g, rate):
+    g = list(g)
+    for i in range(len(g)):
+        if rng.random() < rate:
+            g[i] = rng.choice([c for c in "ACGT" if c != g[i]])
+    return "".join(g)
+
+
+def sample_reads(rng, genome, cov, L, err, n_rate=0.02, lower_rate=0.03):
+    out = []
+    for i in range(int(len(genome) * cov / L)):
+        s = rng.randrange(len(genome) - L)
+        q = [(rng.choice("ACGT") if rng.random() < err else c) for c in genome[s:s + L]]
+        q = "".join(q)
+        if rng.random() < 0.5:
+            q = rc(q)
+        if rng.random() < n_rate:
+            j = rng.randrange(L)
+            q = q[:j] + "N" + q[j + 1:]
+        if rng.random() < lower_rate:
+            q = q.lower()
+        out.append(q)
+    return out
+
+
+def s00_finish(name, files, runs):
+    """files: {fname: (text, gz?)}; runs: {run: argv}.  Runs the reference script in a scratch copy."""
+    import shutil
+    import tempfile
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    for fn, (text, gz) in files.items():
+        write(os.path.join(d, fn), text, gz)
+    meta = {"runs": {}}
+    for rn, argv in runs.items():
+        tmp = tempfile.mkdtemp()
+        try:
+            for fn in files:
+                shutil.copy(os.path.join(d, fn), tmp)
+            r = subprocess.run(["bash", S00_SCRIPT] + argv, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=3600)
+            assert r.returncode == 0, r.stdout.decode()[-3000:]
+            rec = {"argv": argv, "program": "s00", "products": {}}
+            for prod in ("paternal.unique.filter.mer", "maternal.unique.filter.mer"):
+                lines = sorted(open(os.path.join(tmp, prod)).read().splitlines())
+                exp = "expected.%s.%s" % (rn, prod)
+                write(os.path.join(d, exp), "".join(l + "\n" for l in lines))
+                rec["products"][prod] = {"expected": exp, "sorted": True, "lines": len(lines)}
+            for prod in ("maternal.histo", "paternal.histo", "maternal.bounds.txt", "paternal.bounds.txt"):
+                pth = os.path.join(tmp, prod)
+                if os.path.exists(pth):
+                    exp = "expected.%s.%s" % (rn, prod)
+                    shutil.copy(pth, os.path.join(d, exp))
+                    rec["products"][prod] = {"expected": exp, "sorted": False}
+            rec["ref_log"] = [l for l in r.stdout.decode().splitlines() if "bounds of" in l]
+            meta["runs"][rn] = rec
+        finally:
+            shutil.rmtree(tmp)
+    with open(os.path.join(d, "case.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote", name, {rn: {k: v.get("lines") for k, v in rec["products"].items() if "lines" in v} for rn, rec in meta["runs"].items()})
+
+
+def case_s00_trio():
+    rng = random.Random(2100)
+    base = rand_seq(rng, 2500)
+    mat, pat = mutate(rng, base, 0.012), mutate(rng, base, 0.012)
+    m = sample_reads(rng, mat, 30, 100, 0.006)
+    p = sample_reads(rng, pat, 28, 100, 0.006)
+    h = len(p) // 3
+    files = {"m.fq": (fq([("@m%d some text" % i, q) for i, q in enumerate(m)]), False),
+             "p1.fq": (fq([("@p%d/1" % i, q) for i, q in enumerate(p[:h])]), False),
+             "p2.fq": (fq([("@p%d/2" % i, q) for i, q in enumerate(p[h:])]), False)}
+    common = ["--paternal", "p1.fq", "--paternal", "p2.fq", "--maternal", "m.fq", "--thread", "2", "--memory", "1"]
+    s00_finish("s00_trio_k21", files, {
+        "auto": common + ["--auto_bounds"],
+        "default_bounds": common + ["--mer", "21"],
+        "k17_bounds": common + ["--mer", "17", "--p-lower", "2", "--p-upper", "40", "--m-lower", "1", "--m-upper", "25"]})
+
+
+def case_s00_gz():
+    rng = random.Random(2500)
+    base = rand_seq(rng, 1800)
+    mat, pat = mutate(rng, base, 0.02), mutate(rng, base, 0.02)
+    m = sample_reads(rng, mat, 20, 80, 0.004)
+    p = sample_reads(rng, pat, 20, 80, 0.004)
+    hm, hp = len(m) // 2, len(p) // 2
+    files = {"m_a.fq.gz": (fq([("@a%d" % i, q) for i, q in enumerate(m[:hm])]), True),
+             "m_b.fq.gz": (fq([("@b%d" % i, q) for i, q in enumerate(m[hm:])]), True),
+             "p_a.fq.gz": (fq([("@a%d" % i, q) for i, q in enumerate(p[:hp])]), True),
+             "p_b.fq.gz": (fq([("@b%d" % i, q) for i, q in enumerate(p[hp:])]), True)}
+    argv = ["--maternal", "m_a.fq.gz", "--maternal", "m_b.fq.gz", "--paternal", "p_a.fq.gz", "--paternal", "p_b.fq.gz",
+            "--mer", "25", "--thread", "3", "--memory", "1", "--p-lower", "3", "--p-upper", "60", "--m-lower", "3", "--m-upper", "60"]
+    s00_finish("s00_gz_k25", files, {"gz": argv})
+
+
+def case_s00_fasta():
+    """multi-line FASTA, blank lines, lower case, N runs, CRLF; K = 11 (the script's minimum) on a tiny genome so that
+    many k-mers are shared between the parents and repeated inside one"""
+    rng = random.Random(1100)
+    base = rand_seq(rng, 900)
+    def fasta(genome, seed, crlf):
+        r = random.Random(seed)
+        recs = []
+        for i in range(25):
+            s = r.randrange(len(genome) - 300)
+            q = genome[s:s + r.randint(5, 300)]
+            if r.random() < 0.3:
+                q = rc(q)
+            if r.random() < 0.3:
+                j = r.randrange(len(q))
+                q = q[:j] + "N" * r.randint(1, 4) + q[j:]
+            if r.random() < 0.2:
+                q = q.lower()
+            if r.random() < 0.2:
+                j = r.randrange(len(q))
+                q = q[:j] + r.choice("RYKMSW") + q[j + 1:]
+            w = r.choice([7, 60, 70, 1000])
+            lines = [q[k:k + w] for k in range(0, len(q), w)]
+            if r.random() < 0.2:
+                lines.insert(r.randrange(len(lines) + 1), "")
+            recs.append(">rec%d len=%d\n" % (i, len(q)) + "\n".join(lines) + "\n")
+        text = "".join(recs)
+        return text.replace("\n", "\r\n") if crlf else text
+    files = {"m.fa": (fasta(mutate(rng, base, 0.01), 1, False), False),
+             "p.fa": (fasta(mutate(rng, base, 0.01), 2, False)[:-1], False),          # last line unterminated
+             "p_crlf.fa": (fasta(mutate(rng, base, 0.01), 3, True), False)}
+    s00_finish("s00_fasta_k11", files, {
+        "all": ["--maternal", "m.fa", "--paternal", "p.fa", "--paternal", "p_crlf.fa", "--mer", "11", "--memory", "1",
+                "--p-lower", "1", "--p-upper", "100000000", "--m-lower", "1", "--m-upper", "100000000"],
+        "ge2": ["--maternal", "m.fa", "--paternal", "p.fa", "--mer", "11", "--memory", "1",
+                "--p-lower", "2", "--p-upper", "3", "--m-lower", "2", "--m-upper", "1000"]})
+
+
+def case_s00_edge():
+    """multi-line FASTQ, quality lines that start with '@' or '+', reads shorter than K, one k-mer counted more than
+    10000 times (jellyfish histo lumps counts > 10000 into row 10001), K = 31 and 32"""
+    rng = random.Random(3100)
+    g = rand_seq(rng, 700)
+    def recs(seed, extra):
+        r = random.Random(seed)
+        out = []
+        for i in range(60):
+            s = r.randrange(len(g) - 150)
+            q = g[s:s + r.randint(10, 150)]
+            if r.random() < 0.1:
+                q = q[:5] + "n" + q[6:]
+            qual = "".join(r.choice("@+>FI#") for _ in q)
+            if r.random() < 0.4 and len(q) > 40:                              # sequence and quality over several lines
+                c = r.randint(1, len(q) - 1)
+                out.append("@e%d\n%s\n%s\n+e%d\n%s\n%s\n" % (i, q[:c], q[c:], i, qual[:c + 3], qual[c + 3:]))
+            else:
+                out.append("@e%d\n%s\n+\n%s\n" % (i, q, qual))
+        return "".join(out) + extra
+    polya = "@polyA\n%s\n+\n%s\n" % ("A" * 10150, "I" * 10150)
+    files = {"m.fq": (recs(1, polya), False), "p.fq": (recs(2, "@tail\nACGTTGCATGCATGCATTTAGCAGCATCAGCATCAGCAGGGAT\n+\n" + "I" * 43 + "\n\n"), False)}
+    base = ["--maternal", "m.fq", "--paternal", "p.fq", "--memory", "1", "--thread", "1"]
+    s00_finish("s00_edge_k31", files, {
+        "k31_auto": base + ["--mer", "31", "--auto_bounds"],
+        "k32": base + ["--mer", "32", "--p-lower", "1", "--p-upper", "99999", "--m-lower", "1", "--m-upper", "100000000"]})
+
+
 def main():
+    if len(sys.argv) > 1:                     # e.g. `gen_golden.py case_s00_trio case_s00_gz`: only these
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        return
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
     case_edge()
@@ -345,6 +517,10 @@ def main():
     case_s03("s03_k31", 31, 300, seed=531, max_len=9000)
     case_s03_edge()
     case_quartering()
+    case_s00_trio()
+    case_s00_gz()
+    case_s00_fasta()
+    case_s00_edge()
 
 
 if __name__ == "__main__":

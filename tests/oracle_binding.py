@@ -47,6 +47,23 @@ def load(path):
         "ho_s03_read_hits": (None, [C.c_void_p, C.c_char_p, C.c_size_t, u32p, u32p]),
         "ho_s03_format_row": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char_p]),
     })
+    lp = C.POINTER(C.c_long)
+    sig.update({          # stage 00 (oracle/s00_oracle.h)
+        "ho_s00_new": (C.c_void_p, [C.c_int]),
+        "ho_s00_free": (None, [C.c_void_p]),
+        "ho_s00_k": (C.c_int, [C.c_void_p]),
+        "ho_s00_canon_str": (C.c_uint64, [C.c_char_p, C.c_int]),
+        "ho_s00_key_to_str": (None, [C.c_uint64, C.c_int, C.c_char_p]),
+        "ho_s00_add_seq": (None, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),
+        "ho_s00_add_stream": (None, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+        "ho_s00_add_files": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int]),
+        "ho_s00_distinct": (C.c_uint64, [C.c_void_p, C.c_int]),
+        "ho_s00_total": (C.c_uint64, [C.c_void_p, C.c_int]),
+        "ho_s00_count": (C.c_uint32, [C.c_void_p, C.c_int, C.c_uint64]),
+        "ho_s00_histo": (None, [C.c_void_p, C.c_int, u64p]),
+        "ho_s00_find_bounds": (None, [u64p, lp, lp, lp, lp]),
+        "ho_s00_select": (C.c_size_t, [C.c_void_p, C.c_int, C.c_long, C.c_long, u64p]),
+    })
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args

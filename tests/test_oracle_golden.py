@@ -68,7 +68,7 @@ def test_get_hap(oracle_lib):
 
 
 # ---- (ii) golden outputs of the real reference binary --------------------------------------
-@pytest.mark.parametrize("case,run", golden_cases())
+@pytest.mark.parametrize("case,run", golden_cases("s01") + golden_cases("s03"))
 def test_oracle_matches_reference_golden(oracle_dir, golden_workdir, case, run):
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case
@@ -91,10 +91,32 @@ def test_golden_reference_binary_still_agrees(golden_workdir):
     from tests.conftest import ROOT
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "classify")):
         pytest.skip("oracle/_ref/classify not built here")
-    for case, run in golden_cases():
+    for case, run in golden_cases("s01") + golden_cases("s03"):
         meta = load_case(case)["runs"][run]
         d = golden_workdir / case
         ref = os.path.join(ROOT, "oracle", "_ref", "classify_s03" if meta.get("program") == "s03" else "classify")
         res = subprocess.run([ref] + meta["argv"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert res.returncode == 0
         assert res.stdout == open(d / meta["expected"], "rb").read(), (case, run)
+
+
+# ---- stage 00: the reference script (+ its vendored jellyfish) run on our inputs ---------------------------
+@pytest.mark.parametrize("case,run", golden_cases("s00"))
+def test_s00_oracle_matches_reference_script_golden(oracle_dir, golden_workdir, tmp_path, case, run):
+    from tests.conftest import run_s00_case
+    run_s00_case(os.path.join(oracle_dir, "oracle_unshared"), golden_workdir, tmp_path, case, run)
+
+
+def test_s00_known_answers(oracle_lib):
+    """canonical form and counting rules probed on jellyfish 2.3.0 (count -m 5 -C on hand-made records)"""
+    o = oracle_lib
+    assert o.ho_s00_canon_str(b"TACGT", 5) == o.ho_s00_canon_str(b"ACGTA", 5)        # a k-mer and its reverse complement
+    assert o.ho_s00_canon_str(b"acgta", 5) == o.ho_s00_canon_str(b"ACGTA", 5)        # case-insensitive
+    c = o.ho_s00_new(5)
+    for rec in (b"ACGTACGTAC", b"acgtNACGTAcgtt", b"AC", b"TTTTTRAAAAACCCC"):
+        o.ho_s00_add_seq(c, 0, rec, len(rec))
+    exp = {b"AAAAA": 2, b"AAAAC": 1, b"AAACC": 1, b"AACCC": 1, b"AACGT": 1, b"ACCCC": 1, b"ACGTA": 5, b"CGTAC": 5}
+    for kmer, n in exp.items():
+        assert o.ho_s00_count(c, 0, o.ho_s00_canon_str(kmer, 5)) == n
+    assert o.ho_s00_distinct(c, 0) == len(exp) and o.ho_s00_distinct(c, 1) == 0
+    o.ho_s00_free(c)
