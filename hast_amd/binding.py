@@ -19,6 +19,13 @@ class SynthParams(C.Structure):
                 ("k", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class KcSynth(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("genome_len", C.c_uint64), ("read_len", C.c_uint32), ("snp_per_1024", C.c_uint32),
+                ("err_per_4096", C.c_uint32), ("n_per_4096", C.c_uint32)]
+
+
+KC_HISTO_HIGH = 10000
+
 # every symbol include/hast.h declares: name -> (restype, argtypes)
 ABI_SYMBOLS = {
     "hast_version": (C.c_char_p, []),
@@ -68,6 +75,24 @@ ABI_SYMBOLS = {
     "hast_synth_keys_device": (C.c_int, [vp, C.POINTER(SynthParams), C.c_int, C.c_uint64, C.c_size_t, vp, vp]),
     "hast_synth_reads_device": (C.c_int, [vp, C.POINTER(SynthParams), C.c_uint64, C.c_size_t, vp, vp, vp]),
     "hast_synth_table_build": (C.c_int, [vp, C.POINTER(SynthParams)]),
+    # stage 00: parent-unique k-mer sets
+    "hast_kc_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "hast_kc_destroy": (None, [vp]),
+    "hast_kc_stream": (vp, [vp]),
+    "hast_kc_set_slice": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+    "hast_kc_count_device": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "hast_kc_count": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "hast_kc_sync": (C.c_int, [vp]),
+    "hast_kc_stats": (C.c_int, [vp, u64p]),
+    "hast_kc_histo": (C.c_int, [vp, C.c_int, vp]),
+    "hast_kc_find_bounds": (None, [vp, C.POINTER(C.c_long)]),
+    "hast_kc_select": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
+    "hast_kc_release_table": (C.c_int, [vp]),
+    "hast_kc_selection_sort": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
+    "hast_kc_selection_text": (C.c_int, [vp, C.c_int, C.c_size_t, C.c_size_t, vp]),
+    "hast_kc_selection_keys": (C.c_int, [vp, C.c_int, C.c_size_t, C.c_size_t, vp]),
+    "hast_kc_synth_host": (C.c_int, [C.POINTER(KcSynth), C.c_int, C.c_uint64, C.c_size_t, vp]),
+    "hast_kc_synth_device": (C.c_int, [vp, C.POINTER(KcSynth), C.c_int, C.c_uint64, C.c_size_t, vp]),
 }
 
 
@@ -92,6 +117,10 @@ def classify_exe():
 
 def classify_read_exe():
     return os.path.join(_HERE, "classify_read")
+
+
+def unshared_kmers_exe():
+    return os.path.join(_HERE, "unshared_kmers")
 
 
 def build(verbose=False):
@@ -335,3 +364,90 @@ class Context:
 
     def synth_table_build(self, p):
         _ck(self._lib.hast_synth_table_build(self._h, C.byref(p)))
+
+
+# ---- stage 00: parent-unique k-mer sets ---------------------------------------------------------------------
+def kc_find_bounds(histo: np.ndarray):
+    """(MIN_INDEX, MAX_INDEX, LOWER_INDEX, UPPER_INDEX) of find_bounds.awk; host arithmetic only"""
+    histo = np.ascontiguousarray(histo, dtype=np.uint64)
+    assert histo.size == KC_HISTO_HIGH + 2
+    out = (C.c_long * 4)()
+    lib().hast_kc_find_bounds(_ptr(histo), out)
+    return tuple(out)
+
+
+def kc_synth_host(p: KcSynth, parent, first, n_reads):
+    out = np.empty(n_reads * (p.read_len + 1), dtype=np.uint8)
+    _ck(lib().hast_kc_synth_host(C.byref(p), parent, first, n_reads, _ptr(out)))
+    return out
+
+
+class KmerCounter:
+    """One count table of both parents' canonical k-mers in HBM (hast_kc_*)."""
+
+    def __init__(self, k, table_bytes=0, device=0):
+        self._lib = lib()
+        h = C.c_void_p()
+        _ck(self._lib.hast_kc_create(device, k, table_bytes, C.byref(h)))
+        self._h = h
+        self.k = k
+
+    def close(self):
+        if self._h:
+            self._lib.hast_kc_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_slice(self, slice_, n_slices):
+        _ck(self._lib.hast_kc_set_slice(self._h, slice_, n_slices))
+
+    def count(self, parent, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        _ck(self._lib.hast_kc_count(self._h, parent, _ptr(data), data.size))
+
+    def count_device(self, parent, d_bytes, n_bytes):
+        _ck(self._lib.hast_kc_count_device(self._h, parent, C.c_void_p(d_bytes), n_bytes))
+
+    def sync(self):
+        _ck(self._lib.hast_kc_sync(self._h))
+
+    def stats(self):
+        out = np.zeros(6, dtype=np.uint64)
+        _ck(self._lib.hast_kc_stats(self._h, out.ctypes.data_as(u64p)))
+        return dict(distinct=(int(out[0]), int(out[1])), keys=int(out[2]), capacity=int(out[3]), total=(int(out[4]), int(out[5])))
+
+    def histo(self, parent, into=None):
+        h = np.zeros(KC_HISTO_HIGH + 2, dtype=np.uint64) if into is None else into
+        _ck(self._lib.hast_kc_histo(self._h, parent, _ptr(h)))
+        return h
+
+    def select(self, parent, lower, upper):
+        n = C.c_size_t()
+        _ck(self._lib.hast_kc_select(self._h, parent, lower, upper, C.byref(n)))
+        return n.value
+
+    def release_table(self):
+        _ck(self._lib.hast_kc_release_table(self._h))
+
+    def selection_sort(self, parent):
+        n = C.c_size_t()
+        _ck(self._lib.hast_kc_selection_sort(self._h, parent, C.byref(n)))
+        return n.value
+
+    def selection_text(self, parent, first, count) -> bytes:
+        out = np.empty(count * (self.k + 1), dtype=np.uint8)
+        _ck(self._lib.hast_kc_selection_text(self._h, parent, first, count, _ptr(out)))
+        return out.tobytes()
+
+    def selection_keys(self, parent, first, count):
+        out = np.empty(count, dtype=np.uint64)
+        _ck(self._lib.hast_kc_selection_keys(self._h, parent, first, count, _ptr(out)))
+        return out
+
+    def synth_device(self, p: KcSynth, parent, first, n_reads, d_out):
+        _ck(self._lib.hast_kc_synth_device(self._h, C.byref(p), parent, first, n_reads, C.c_void_p(d_out)))

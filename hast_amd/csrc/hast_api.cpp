@@ -15,6 +15,7 @@
 #include "../../include/hast.h"
 #include "hast_common.h"
 #include "hast_device.h"
+#include "hast_internal.h"
 
 using namespace hast;
 
@@ -139,10 +140,23 @@ hast_status check_synth(const hast_synth_params *p) {
 
 }  // namespace
 
+// hooks for the other translation units of the library (hast_internal.h)
+namespace hast {
+hast_status set_error(hast_status st, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return st;
+}
+int default_minimizer_for(int k) { return default_minimizer(k); }
+}  // namespace hast
+
 extern "C" {
 
 const char *hast_version(void) { return "hast-mi355x 0.1 (gfx950)"; }
 const char *hast_last_error(void) { return g_err; }
+
 
 // ---------------------------------------------------------------------------------------------
 hast_status hast_ctx_create(int device, int k, hast_ctx **out) {

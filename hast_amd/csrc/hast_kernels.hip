@@ -11,6 +11,7 @@
 //   kmer/kmer.h:11,153-166,169-194 (coding, str2Kmer, chopRead2Kmer).
 #include "hast_common.h"
 #include "hast_device.h"
+#include "hast_devutil.h"
 
 namespace hast {
 
@@ -214,32 +215,6 @@ constexpr int kNLd = kPieces / kLPB;          // 16-B loads per lane per round
 constexpr uint32_t kGrpMask = (1u << kLPB) - 1;
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack4(uint32_t x) {
-    // four ASCII bytes (first base = lowest byte) -> 8 bits, first base in the top pair
-    uint32_t t = (x >> 1) & 0x03030303u;
-    return (t * 0x40100401u) >> 24;
-}
-__device__ __forceinline__ uint32_t has_byte_N(uint32_t x) {
-    uint32_t y = x ^ 0x4E4E4E4Eu;                       // 'N' -> 0
-    return (y - 0x01010101u) & ~y & 0x80808080u;        // != 0 iff some byte of y is 0
-}
-// 4 ASCII bytes -> 4 bits (first base = bit 3): 1 where the byte is not one of 'A','C','G','T'
-__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {            // 0x80 in every zero byte, exact
-    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
-}
-__device__ __forceinline__ uint32_t not_acgt4(uint32_t x) {
-    const uint32_t ok = zero_bytes(x ^ 0x41414141u) | zero_bytes(x ^ 0x43434343u) | zero_bytes(x ^ 0x47474747u) |
-                        zero_bytes(x ^ 0x54545454u);
-    const uint32_t t = (~ok & 0x80808080u) >> 7;                         // bits 0,8,16,24
-    return ((t * 0x08040201u) >> 24) & 0xFu;                             // -> bits 3,2,1,0
-}
-// bases [p, p+n) of a packed read (n <= 31), right-aligned
-__device__ __forceinline__ uint64_t window_bits(const unsigned long long *words, uint32_t p, uint32_t shift_out) {
-    const unsigned long long w0 = words[p >> 5], w1 = words[(p >> 5) + 1];
-    const uint32_t sh = (p & 31) * 2;
-    const unsigned long long x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));       // sh == 0 safe
-    return x >> shift_out;
-}
 // value of lane J of my group of kLPB lanes (DPP quad_perm: [J,J,J,J] for quads, [J,J,2+J,2+J] for pairs)
 template <int J>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) {

@@ -1,0 +1,439 @@
+// kc_api.cpp -- the stage-00 part of the C ABI (include/hast.h, hast_kc_*): k-mer count table of both parents in HBM,
+// histograms, parent-unique selections.  Host C++ over the HIP runtime; device work is in kc_kernels.hip.
+// No CPU path: a context needs a GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "hast_internal.h"
+#include "kc_device.h"
+
+using namespace hast;
+
+#define KC_TRY(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return set_error(e_ == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", #expr, \
+                             hipGetErrorString(e_));                                                  \
+    } while (0)
+
+namespace {
+constexpr size_t kStageBytes = 64u << 20;      // one pinned/device staging buffer of hast_kc_count
+struct KcStage {
+    uint8_t *h = nullptr, *d = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+// d_small layout (unsigned long long words)
+enum { kQueue = 0, kTotal = 1 /* ,2 */, kCursor = 3, kStats = 4 /* ,5,6 */, kSmallWords = 8 };
+}  // namespace
+
+struct hast_kc {
+    int device = 0, k = 0, m = 0, n_cu = 256;
+    hipStream_t stream = nullptr;
+    unsigned long long *d_table = nullptr;
+    uint32_t nbuckets = 0;
+    uint32_t slice = 0, n_slices = 1;
+    uint32_t tile_bases = 4096;
+    unsigned long long *d_small = nullptr;
+    uint32_t *d_err = nullptr;
+    unsigned long long *d_histo = nullptr;
+    KcStage stage[2];
+    unsigned turn = 0;
+    std::vector<uint64_t> sel[2];              // print keys selected so far (host side, unsorted)
+    unsigned long long *d_sorted[2] = {nullptr, nullptr};
+    size_t n_sorted[2] = {0, 0};
+};
+
+namespace {
+hast_status use(hast_kc *c) {
+    if (!c) return set_error(HAST_ERR_INVALID, "null k-mer count context");
+    KC_TRY(hipSetDevice(c->device));
+    return HAST_OK;
+}
+hast_status need_table(hast_kc *c) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_table) return set_error(HAST_ERR_INVALID, "the count table has been released");
+    return HAST_OK;
+}
+hast_status check_parent(int parent) {
+    return (parent == 0 || parent == 1) ? HAST_OK : set_error(HAST_ERR_INVALID, "parent %d is not 0 (paternal) or 1 (maternal)", parent);
+}
+KcSynth resolve(const hast_kc_synth *p) {
+    KcSynth g;
+    g.seed = p->seed ? p->seed : 0x4841535400ull;
+    g.genome_len = p->genome_len;
+    g.read_len = p->read_len;
+    g.snp_per_1024 = p->snp_per_1024;
+    g.err_per_4096 = p->err_per_4096;
+    g.n_per_4096 = p->n_per_4096;
+    return g;
+}
+hast_status check_synth(const hast_kc_synth *p) {
+    if (!p) return set_error(HAST_ERR_INVALID, "null synth params");
+    if (p->read_len < 1 || p->genome_len < p->read_len) return set_error(HAST_ERR_INVALID, "synth: genome shorter than a read");
+    return HAST_OK;
+}
+}  // namespace
+
+hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out) {
+    if (!out) return set_error(HAST_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (k < 1 || k > 32) return set_error(HAST_ERR_INVALID, "K=%d out of [1,32]", k);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(HAST_ERR_NO_DEVICE, "no HIP device (%s); libhast has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= n) return set_error(HAST_ERR_NO_DEVICE, "device %d not in [0,%d)", device, n);
+    KC_TRY(hipSetDevice(device));
+    hast_kc *c = new (std::nothrow) hast_kc();
+    if (!c) return set_error(HAST_ERR_OOM, "host allocation failed");
+    c->device = device;
+    c->k = k;
+    c->m = default_minimizer_for(k);
+    if (const char *t = getenv("HAST_KC_TILE")) {
+        const long v = atol(t);
+        if (v >= 256 && v <= 16384) c->tile_bases = (uint32_t)(v & ~31l);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    hast_status st = HAST_OK;
+    auto bail = [&](hipError_t he, const char *what) {
+        if (he != hipSuccess && st == HAST_OK)
+            st = set_error(he == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
+    };
+    bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    bail(hipMalloc(&c->d_small, kSmallWords * sizeof(unsigned long long)), "hipMalloc(small)");
+    bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
+    bail(hipMalloc(&c->d_histo, (HAST_KC_HISTO_HIGH + 2) * sizeof(unsigned long long)), "hipMalloc(histo)");
+    for (auto &s : c->stage) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+    if (st == HAST_OK) {
+        if (table_bytes == 0) {
+            size_t free_b = 0, total_b = 0;
+            bail(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
+            table_bytes = (size_t)((double)free_b * 0.85);
+        }
+        size_t nb = table_bytes / (kKcBucketWords * sizeof(unsigned long long));
+        nb = std::min<size_t>(std::max<size_t>(nb, 64), 0xFFFFFFF0u);
+        c->nbuckets = (uint32_t)nb;
+        bail(hipMalloc(&c->d_table, nb * kKcBucketWords * sizeof(unsigned long long)), "hipMalloc(count table)");
+    }
+    if (st == HAST_OK) bail(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream), "hipMemset");
+    if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
+    if (st == HAST_OK) bail(launch_kc_clear(c->d_table, c->nbuckets, c->stream), "clear table");
+    if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (st != HAST_OK) {
+        hast_kc_destroy(c);
+        return st;
+    }
+    *out = c;
+    return HAST_OK;
+}
+
+void hast_kc_destroy(hast_kc *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->stage) {
+        if (s.h) (void)hipHostFree(s.h);
+        if (s.d) (void)hipFree(s.d);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto *p : c->d_sorted)
+        if (p) (void)hipFree(p);
+    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_histo) (void)hipFree(c->d_histo);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+hast_stream hast_kc_stream(hast_kc *c) { return c ? (hast_stream)c->stream : nullptr; }
+
+hast_status hast_kc_set_slice(hast_kc *c, uint32_t slice, uint32_t n_slices) {
+    if (hast_status st = need_table(c)) return st;
+    if (n_slices < 1 || slice >= n_slices) return set_error(HAST_ERR_INVALID, "slice %u of %u", slice, n_slices);
+    c->slice = slice;
+    c->n_slices = n_slices;
+    KC_TRY(launch_kc_clear(c->d_table, c->nbuckets, c->stream));
+    KC_TRY(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream));
+    KC_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream));
+    return HAST_OK;
+}
+
+static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, size_t n_bytes, size_t n_starts) {
+    if (n_starts == 0) return HAST_OK;
+    KcCountArgs a;
+    a.bytes = d_bytes;
+    a.n_bytes = n_bytes;
+    a.n_starts = n_starts;
+    a.table = c->d_table;
+    a.nbuckets = c->nbuckets;
+    a.k = c->k;
+    a.m = c->m;
+    a.parent = (uint32_t)parent;
+    a.slice = c->slice;
+    a.n_slices = c->n_slices;
+    a.tile_bases = c->tile_bases;
+    a.tile_queue = c->d_small + kQueue;
+    a.total = c->d_small + kTotal;
+    a.err = c->d_err;
+    const size_t n_tiles = (n_starts + a.tile_bases - 1) / a.tile_bases;
+    const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)c->n_cu * 8);
+    KC_TRY(hipMemsetAsync(c->d_small + kQueue, 0, sizeof(unsigned long long), c->stream));
+    KC_TRY(launch_kc_count(a, grid, c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_kc_count_device(hast_kc *c, int parent, const uint8_t *d_bytes, size_t n_bytes) {
+    if (hast_status st = need_table(c)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (n_bytes && !d_bytes) return set_error(HAST_ERR_INVALID, "d_bytes is null");
+    return count_launch(c, parent, d_bytes, n_bytes, n_bytes);
+}
+
+hast_status hast_kc_count(hast_kc *c, int parent, const uint8_t *bytes, size_t n_bytes) {
+    if (hast_status st = need_table(c)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (n_bytes && !bytes) return set_error(HAST_ERR_INVALID, "bytes is null");
+    const size_t overlap = (size_t)c->k - 1, chunk = kStageBytes - 64;
+    for (size_t at = 0; at < n_bytes; at += chunk) {
+        KcStage &s = c->stage[c->turn++ & 1];
+        if (!s.h) {
+            KC_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h), kStageBytes, hipHostMallocDefault));
+            KC_TRY(hipMalloc(reinterpret_cast<void **>(&s.d), kStageBytes));
+        }
+        if (s.busy) {
+            KC_TRY(hipEventSynchronize(s.done));
+            s.busy = false;
+        }
+        const size_t starts = std::min(chunk, n_bytes - at);
+        const size_t avail = std::min(starts + overlap, n_bytes - at);       // windows near the cut need the next K-1 bytes
+        memcpy(s.h, bytes + at, avail);
+        KC_TRY(hipMemcpyAsync(s.d, s.h, avail, hipMemcpyHostToDevice, c->stream));
+        if (hast_status st = count_launch(c, parent, s.d, avail, starts)) return st;
+        KC_TRY(hipEventRecord(s.done, c->stream));
+        s.busy = true;
+    }
+    return HAST_OK;
+}
+
+hast_status hast_kc_sync(hast_kc *c) {
+    if (hast_status st = use(c)) return st;
+    uint32_t e = 0;
+    KC_TRY(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    KC_TRY(hipStreamSynchronize(c->stream));
+    for (auto &s : c->stage) s.busy = false;
+    if (e & 1) return set_error(HAST_ERR_TABLE_FULL, "k-mer count table full (%u buckets of %d keys, slice %u of %u): use more slices",
+                                c->nbuckets, kKcSlots, c->slice, c->n_slices);
+    return HAST_OK;
+}
+
+hast_status hast_kc_stats(hast_kc *c, uint64_t out[6]) {
+    if (hast_status st = need_table(c)) return st;
+    if (!out) return set_error(HAST_ERR_INVALID, "out is null");
+    unsigned long long h[kSmallWords];
+    KC_TRY(hipMemsetAsync(c->d_small + kStats, 0, 3 * sizeof(unsigned long long), c->stream));
+    KC_TRY(launch_kc_stats(c->d_table, c->nbuckets, c->d_small + kStats, c->stream));
+    KC_TRY(hipMemcpyAsync(h, c->d_small, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    KC_TRY(hipStreamSynchronize(c->stream));
+    out[0] = h[kStats];
+    out[1] = h[kStats + 1];
+    out[2] = h[kStats + 2];
+    out[3] = (uint64_t)c->nbuckets * kKcSlots;
+    out[4] = h[kTotal];
+    out[5] = h[kTotal + 1];
+    return HAST_OK;
+}
+
+hast_status hast_kc_histo(hast_kc *c, int parent, uint64_t *histo) {
+    if (hast_status st = need_table(c)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (!histo) return set_error(HAST_ERR_INVALID, "histo is null");
+    const size_t n = HAST_KC_HISTO_HIGH + 2;
+    std::vector<unsigned long long> h(n);
+    KC_TRY(hipMemsetAsync(c->d_histo, 0, n * sizeof(unsigned long long), c->stream));
+    KC_TRY(launch_kc_histo(c->d_table, c->nbuckets, (uint32_t)parent, c->d_histo, c->stream));
+    KC_TRY(hipMemcpyAsync(h.data(), c->d_histo, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    KC_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; ++i) histo[i] += h[i];
+    return HAST_OK;
+}
+
+void hast_kc_find_bounds(const uint64_t *histo, long out[4]) {
+    // find_bounds.awk:8-25 over the rows `jellyfish histo` prints (ascending count, empty rows absent).  The awk program
+    // tests a variable it never assigns (so: 0) until the descent ends; the row that ends the descent is not a
+    // candidate for the maximum.  awk compares numbers as doubles.
+    double lowest = 0, highest = 0;
+    long min_index = 0, max_index = 0;
+    bool descending = true;
+    for (long i = 1; i <= (long)HAST_KC_HISTO_HIGH + 1; ++i) {
+        if (!histo[i]) continue;
+        const double c = (double)histo[i];
+        if (descending) {
+            if (lowest == 0 || c < lowest) {
+                lowest = c;
+                min_index = i;
+            } else descending = false;
+        } else if (highest == 0 || c > highest) {
+            highest = c;
+            max_index = i;
+        }
+    }
+    out[0] = min_index;
+    out[1] = max_index;
+    out[2] = min_index + 1;                              // LOWER_INDEX (find_bounds.awk:29)
+    out[3] = 3 * max_index - 2 * min_index - 1;          // UPPER_INDEX (find_bounds.awk:28,30)
+}
+
+hast_status hast_kc_select(hast_kc *c, int parent, uint32_t lower, uint32_t upper, size_t *n_added) {
+    if (hast_status st = need_table(c)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (n_added) *n_added = 0;
+    unsigned long long n = 0;
+    unsigned long long *cur = c->d_small + kCursor;
+    KC_TRY(hipMemsetAsync(cur, 0, sizeof(unsigned long long), c->stream));
+    KC_TRY(launch_kc_select(c->d_table, c->nbuckets, (uint32_t)parent, lower, upper, c->k, nullptr, 0, cur, c->stream));
+    KC_TRY(hipMemcpyAsync(&n, cur, sizeof(n), hipMemcpyDeviceToHost, c->stream));
+    KC_TRY(hipStreamSynchronize(c->stream));
+    if (n == 0) return HAST_OK;
+    unsigned long long *d_out = nullptr;
+    KC_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long)));
+    hast_status st = HAST_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && st == HAST_OK) st = set_error(HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    step(hipMemsetAsync(cur, 0, sizeof(unsigned long long), c->stream), "hipMemset");
+    step(launch_kc_select(c->d_table, c->nbuckets, (uint32_t)parent, lower, upper, c->k, d_out, (size_t)n, cur, c->stream), "select");
+    std::vector<uint64_t> &v = c->sel[parent];
+    const size_t old = v.size();
+    if (st == HAST_OK) {
+        v.resize(old + n);
+        step(hipMemcpyAsync(v.data() + old, d_out, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream), "D2H");
+        step(hipStreamSynchronize(c->stream), "sync");
+    }
+    (void)hipFree(d_out);
+    if (st != HAST_OK) {
+        v.resize(old);
+        return st;
+    }
+    if (n_added) *n_added = (size_t)n;
+    return HAST_OK;
+}
+
+hast_status hast_kc_release_table(hast_kc *c) {
+    if (hast_status st = use(c)) return st;
+    KC_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_table) KC_TRY(hipFree(c->d_table));
+    c->d_table = nullptr;
+    for (auto &s : c->stage) {
+        if (s.d) KC_TRY(hipFree(s.d));
+        s.d = nullptr;
+        if (s.h) KC_TRY(hipHostFree(s.h));
+        s.h = nullptr;
+    }
+    return HAST_OK;
+}
+
+hast_status hast_kc_selection_sort(hast_kc *c, int parent, size_t *n_out) {
+    if (hast_status st = use(c)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    std::vector<uint64_t> &v = c->sel[parent];
+    if (c->d_sorted[parent]) {
+        KC_TRY(hipFree(c->d_sorted[parent]));
+        c->d_sorted[parent] = nullptr;
+        c->n_sorted[parent] = 0;
+    }
+    const size_t n = v.size();
+    if (n_out) *n_out = n;
+    if (n == 0) return HAST_OK;
+    unsigned long long *d_in = nullptr, *d_out = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hast_status st = HAST_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && st == HAST_OK)
+            st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    step(hipMalloc(reinterpret_cast<void **>(&d_in), n * sizeof(unsigned long long)), "hipMalloc(sort in)");
+    if (st == HAST_OK) step(hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long)), "hipMalloc(sort out)");
+    if (st == HAST_OK) step(hipMemcpyAsync(d_in, v.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream), "H2D");
+    if (st == HAST_OK) step(kc_sort_keys(nullptr, &tmp_bytes, d_in, d_out, n, c->k, c->stream), "sort (size query)");
+    if (st == HAST_OK) step(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16), "hipMalloc(sort temp)");
+    if (st == HAST_OK) step(kc_sort_keys(d_tmp, &tmp_bytes, d_in, d_out, n, c->k, c->stream), "sort");
+    if (st == HAST_OK) step(hipStreamSynchronize(c->stream), "sync");
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_in) (void)hipFree(d_in);
+    if (st != HAST_OK) {
+        if (d_out) (void)hipFree(d_out);
+        return st;
+    }
+    c->d_sorted[parent] = d_out;
+    c->n_sorted[parent] = n;
+    std::vector<uint64_t>().swap(v);
+    return HAST_OK;
+}
+
+static hast_status selection_rows(hast_kc *c, int parent, size_t first, size_t count) {
+    if (hast_status st = use(c)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (first + count > c->n_sorted[parent] || first + count < first)
+        return set_error(HAST_ERR_INVALID, "rows [%zu, %zu) outside the sorted selection of %zu", first, first + count, c->n_sorted[parent]);
+    return HAST_OK;
+}
+
+hast_status hast_kc_selection_text(hast_kc *c, int parent, size_t first, size_t count, char *out) {
+    if (hast_status st = selection_rows(c, parent, first, count)) return st;
+    if (count == 0) return HAST_OK;
+    if (!out) return set_error(HAST_ERR_INVALID, "out is null");
+    const size_t bytes = count * (size_t)(c->k + 1);
+    char *d_text = nullptr;
+    KC_TRY(hipMalloc(reinterpret_cast<void **>(&d_text), bytes));
+    hipError_t e = launch_kc_format(c->d_sorted[parent] + first, count, c->k, d_text, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_text, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_text);
+    if (e != hipSuccess) return set_error(HAST_ERR_HIP, "formatting the selection: %s", hipGetErrorString(e));
+    return HAST_OK;
+}
+
+hast_status hast_kc_selection_keys(hast_kc *c, int parent, size_t first, size_t count, uint64_t *out) {
+    if (hast_status st = selection_rows(c, parent, first, count)) return st;
+    if (count == 0) return HAST_OK;
+    if (!out) return set_error(HAST_ERR_INVALID, "out is null");
+    unsigned long long *d_keys = nullptr;
+    KC_TRY(hipMalloc(reinterpret_cast<void **>(&d_keys), count * sizeof(unsigned long long)));
+    hipError_t e = launch_kc_to_table_keys(c->d_sorted[parent] + first, count, c->k, d_keys, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_keys, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_keys);
+    if (e != hipSuccess) return set_error(HAST_ERR_HIP, "converting the selection: %s", hipGetErrorString(e));
+    return HAST_OK;
+}
+
+hast_status hast_kc_synth_host(const hast_kc_synth *p, int parent, uint64_t first_read, size_t n_reads, uint8_t *out) {
+    if (hast_status st = check_synth(p)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (n_reads && !out) return set_error(HAST_ERR_INVALID, "out is null");
+    const KcSynth g = resolve(p);
+    const size_t rec = (size_t)g.read_len + 1;
+    for (size_t i = 0; i < n_reads; ++i)
+        for (uint32_t j = 0; j < rec; ++j) out[i * rec + j] = kc_synth_byte(g, parent, first_read + i, j);
+    return HAST_OK;
+}
+
+hast_status hast_kc_synth_device(hast_kc *c, const hast_kc_synth *p, int parent, uint64_t first_read, size_t n_reads, uint8_t *d_out) {
+    if (hast_status st = use(c)) return st;
+    if (hast_status st = check_synth(p)) return st;
+    if (hast_status st = check_parent(parent)) return st;
+    if (n_reads && !d_out) return set_error(HAST_ERR_INVALID, "d_out is null");
+    KC_TRY(launch_kc_synth(resolve(p), parent, first_read, n_reads * ((size_t)p->read_len + 1), d_out, c->stream));
+    return HAST_OK;
+}

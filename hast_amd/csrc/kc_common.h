@@ -1,0 +1,67 @@
+// kc_common.h -- stage 00 (parent-unique k-mer sets): integer helpers shared by host C++ and gfx950 device code.
+//
+// The count table works on the SAME canonical keys as the stage-01 table (hast_common.h: A0 C1 T2 G3, canonical =
+// numeric min of k-mer and reverse complement).  The reference's stage 00 prints what jellyfish prints
+// (build_unshared_kmers.sh:283-284): the representative that is smaller in the order A<C<G<T.  The set {k-mer,
+// reverse complement} is the same under both conventions, only the printed member may differ, so keys are converted
+// when they leave the table (kc_to_print_key).
+#pragma once
+#include "hast_common.h"
+
+namespace hast {
+
+constexpr int kKcSlots = 8;                       // keys per bucket
+constexpr int kKcBucketWords = 16;                // 8 keys (64 B) + 8 x {u32 paternal, u32 maternal} (64 B) = 128 B
+constexpr uint32_t kKcHistoHigh = 10000;          // jellyfish histo default --high (analysis_kmercount.sh:7-9)
+
+// 2-bit codes A0 C1 T2 G3 -> A0 C1 G2 T3 (swap codes 2 and 3: low bit ^= high bit)
+HAST_HD uint64_t kc_recode(uint64_t x) { return x ^ ((x >> 1) & 0x5555555555555555ull); }
+// table key -> the key jellyfish would print: min over both strands in the order A<C<G<T, in that coding
+HAST_HD uint64_t kc_to_print_key(uint64_t key, int k) {
+    const uint64_t a = kc_recode(key), b = kc_recode(kmer_revcomp(key, k));
+    return a < b ? a : b;
+}
+// and back: printed key -> table key
+HAST_HD uint64_t kc_from_print_key(uint64_t pk, int k) { return kmer_canon(kc_recode(pk), k); }   // the recoding is an involution
+
+// slice of the key space a window belongs to (decided by its minimizer, so a bucket never mixes slices)
+HAST_HD uint32_t kc_slice_of(uint32_t minh, uint32_t n_slices) {
+    uint32_t h = minh * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return (uint32_t)(((uint64_t)h * n_slices) >> 32);
+}
+
+// ---- synthetic trio (bench + tests): two parental genomes that differ from a common random genome by SNPs -------
+// Reads are sampled at random positions of the parent's genome, random strand, with substitution errors; the byte
+// stream holds the reads back to back, each followed by '\n'.
+struct KcSynth {
+    uint64_t seed;
+    uint64_t genome_len;      // bases
+    uint32_t read_len;
+    uint32_t snp_per_1024;    // parent-specific SNP rate (per 1024 bases)
+    uint32_t err_per_4096;    // sequencing substitution errors (per 4096 bases)
+    uint32_t n_per_4096;      // reads that get one 'N' (per 4096 reads)
+};
+HAST_HD uint32_t kc_genome_base(const KcSynth &g, int parent, uint64_t x) {
+    uint32_t b = (uint32_t)(synth_rand(g.seed, 0x67656E6Full, x >> 5) >> (2 * (x & 31))) & 3;
+    const uint64_t h = synth_rand(g.seed, 0x736E7000ull + (uint64_t)parent, x);
+    if ((h & 1023) < g.snp_per_1024) b = (b + 1 + (uint32_t)((h >> 10) % 3)) & 3;       // a different base
+    return b;
+}
+// byte j (0 .. read_len) of read i of `parent`; byte read_len is the separator
+HAST_HD uint8_t kc_synth_byte(const KcSynth &g, int parent, uint64_t i, uint32_t j) {
+    if (j >= g.read_len) return (uint8_t)'\n';
+    const uint64_t r = synth_rand(g.seed, 0x72656164ull + (uint64_t)parent, i);
+    const uint64_t start = (r >> 1) % (g.genome_len - g.read_len + 1);
+    const bool rev = r & 1;
+    uint32_t b = rev ? 3 - kc_genome_base(g, parent, start + (g.read_len - 1 - j)) : kc_genome_base(g, parent, start + j);
+    const uint64_t e = synth_rand(g.seed, 0x65727200ull + (uint64_t)parent, i * 4096 + j);
+    if ((e & 4095) < g.err_per_4096) b = (b + 1 + (uint32_t)((e >> 12) % 3)) & 3;
+    const uint64_t nn = synth_rand(g.seed, 0x6E6E6E00ull + (uint64_t)parent, i);
+    if ((nn & 4095) < g.n_per_4096 && (uint32_t)((nn >> 12) % g.read_len) == j) return (uint8_t)'N';
+    return (uint8_t)"ACGT"[b];
+}
+
+}  // namespace hast

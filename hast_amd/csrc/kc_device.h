@@ -1,0 +1,38 @@
+// kc_device.h -- launch interface of kc_kernels.hip (stage 00 k-mer counting) for kc_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "kc_common.h"
+
+namespace hast {
+
+struct KcCountArgs {
+    const uint8_t *bytes;            // sequence bytes; any byte outside ACGTacgt separates runs of bases
+    size_t n_bytes;                  // readable bytes
+    size_t n_starts;                 // windows start at positions [0, n_starts)
+    unsigned long long *table;       // nbuckets x 128 B
+    uint32_t nbuckets;
+    int k, m;
+    uint32_t parent;                 // 0 paternal, 1 maternal
+    uint32_t slice, n_slices;        // only windows whose minimizer falls into this slice of the key space are counted
+    uint32_t tile_bases;             // window starts per tile (multiple of 32)
+    unsigned long long *tile_queue;  // zeroed before the launch
+    unsigned long long *total;       // [2] windows counted per parent
+    uint32_t *err;                   // bit 0: table full
+};
+
+size_t kc_count_smem(uint32_t tile_bases, int k, int m);
+hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s);
+hipError_t launch_kc_clear(unsigned long long *table, size_t nbuckets, hipStream_t s);
+hipError_t launch_kc_stats(const unsigned long long *table, size_t nbuckets, unsigned long long *d_out3, hipStream_t s);
+hipError_t launch_kc_histo(const unsigned long long *table, size_t nbuckets, uint32_t parent, unsigned long long *d_out, hipStream_t s);
+hipError_t launch_kc_select(const unsigned long long *table, size_t nbuckets, uint32_t parent, uint32_t lower, uint32_t upper, int k,
+                            unsigned long long *d_out, size_t cap, unsigned long long *d_cursor, hipStream_t s);
+hipError_t launch_kc_format(const unsigned long long *d_keys, size_t n, int k, char *d_text, hipStream_t s);
+hipError_t launch_kc_to_table_keys(const unsigned long long *d_keys, size_t n, int k, unsigned long long *d_out, hipStream_t s);
+hipError_t launch_kc_synth(const KcSynth &g, int parent, uint64_t first_read, size_t n_bytes, uint8_t *d_out, hipStream_t s);
+hipError_t kc_sort_keys(void *d_tmp, size_t *tmp_bytes, unsigned long long *d_in, unsigned long long *d_out, size_t n, int k, hipStream_t s);
+
+}  // namespace hast

@@ -200,6 +200,70 @@ hast_status hast_synth_reads_device(hast_ctx *, const hast_synth_params *, uint6
 /* generate + insert both haplotypes' keys on the device (no host copy of the keys) */
 hast_status hast_synth_table_build(hast_ctx *, const hast_synth_params *);
 
+/* ==== stage 00: parent-unique k-mer sets ======================================
+ * Replaces the compute of 00.build_unshare_kmers_by_jellyfish/build_unshared_kmers.sh:165-291, which drives a
+ * third-party CPU hash counter (jellyfish 2.3.0, vendored there as a binary) through seven count/dump passes over text
+ * files.  Here ONE table in HBM holds, for every canonical k-mer of either parent, its paternal and its maternal count;
+ * the histograms (analysis_kmercount.sh:7-9), and the two final sets (script lines 246-291)
+ *     paternal.unique.filter = { x : p_lower <= count_pat(x) <= p_upper and count_mat(x) == 0 }   (and vice versa)
+ * are read out of it directly.  Counting rules = `jellyfish count -m K -C`: every window of K consecutive bases,
+ * both cases of ACGT are bases, any other byte ends the run; a k-mer and its reverse complement are one key.
+ * parent: 0 = paternal, 1 = maternal.
+ *
+ * Key space slices: when the table cannot hold every distinct k-mer, hast_kc_sync reports HAST_ERR_TABLE_FULL;
+ * the caller then processes the key space in n_slices passes over the input (hast_kc_set_slice), each pass
+ * counting only the k-mers of its slice; histograms add up and selections concatenate over the slices.  The
+ * same call shards the key space over several GPUs (one context per GPU, disjoint slices, no collective). */
+typedef struct hast_kc hast_kc;
+#define HAST_KC_HISTO_HIGH 10000u          /* counts above are lumped into bin HIGH+1 (jellyfish histo default) */
+
+/* table_bytes == 0: 85 % of the free device memory.  k in [1,32]. */
+hast_status hast_kc_create(int device_ordinal, int k, size_t table_bytes, hast_kc **out);
+void        hast_kc_destroy(hast_kc *);
+hast_stream hast_kc_stream(hast_kc *);
+/* empties the table and restricts counting to slice `slice` of `n_slices` (1 slice = everything) */
+hast_status hast_kc_set_slice(hast_kc *, uint32_t slice, uint32_t n_slices);
+/* Count the k-mers of a byte stream for one parent.  The stream is a sequence of records' bases with at least one
+ * non-base byte (e.g. '\n') between records; windows start at [0, n_bytes).  _device: bytes already in HBM,
+ * asynchronous on the context's stream.  Host variant: copies through pinned staging, double-buffered. */
+hast_status hast_kc_count_device(hast_kc *, int parent, const uint8_t *d_bytes, size_t n_bytes);
+hast_status hast_kc_count(hast_kc *, int parent, const uint8_t *bytes, size_t n_bytes);
+/* wait for all counting submitted so far; HAST_ERR_TABLE_FULL when some k-mer found no slot */
+hast_status hast_kc_sync(hast_kc *);
+/* out[0..1] distinct k-mers per parent, out[2] keys in the table, out[3] table capacity (slots),
+ * out[4..5] k-mer occurrences counted per parent */
+hast_status hast_kc_stats(hast_kc *, uint64_t out[6]);
+/* ADDS the count histogram of one parent to histo[0 .. HAST_KC_HISTO_HIGH+1] (`jellyfish histo`) */
+hast_status hast_kc_histo(hast_kc *, int parent, uint64_t *histo);
+/* find_bounds.awk:1-33 over the non-empty rows of a histogram: out = MIN_INDEX, MAX_INDEX, LOWER_INDEX, UPPER_INDEX.
+ * Host-only arithmetic (no GPU needed). */
+void        hast_kc_find_bounds(const uint64_t *histo, long out[4]);
+/* Append to the context's selection of `parent` the keys of the current table with lower <= count <= upper that the
+ * other parent does not have.  n_added may be NULL. */
+hast_status hast_kc_select(hast_kc *, int parent, uint32_t lower, uint32_t upper, size_t *n_added);
+/* free the table (the selections stay) */
+hast_status hast_kc_release_table(hast_kc *);
+/* sort the selection of `parent` (ascending = lexicographic order of the printed k-mers) and keep it on the device */
+hast_status hast_kc_selection_sort(hast_kc *, int parent, size_t *n);
+/* rows [first, first+count) of the sorted selection as text: count lines of K upper-case letters + '\n', the member of
+ * {k-mer, reverse complement} that comes first in the order A<C<G<T (what the reference's .mer files hold) */
+hast_status hast_kc_selection_text(hast_kc *, int parent, size_t first, size_t count, char *out);
+/* the same rows as stage-01 table keys (hast_table_insert_keys), no text round trip */
+hast_status hast_kc_selection_keys(hast_kc *, int parent, size_t first, size_t count, uint64_t *out);
+
+/* synthetic trio for benches and tests: two parental genomes = one random genome + parent-specific SNPs; reads are
+ * sampled with substitution errors on a random strand; the stream is read_len bases + '\n' per read */
+typedef struct hast_kc_synth {
+    uint64_t seed;            /* 0 => default */
+    uint64_t genome_len;
+    uint32_t read_len;
+    uint32_t snp_per_1024;    /* parent-specific SNPs per 1024 bases */
+    uint32_t err_per_4096;    /* substitution errors per 4096 bases */
+    uint32_t n_per_4096;      /* reads with one 'N' per 4096 reads */
+} hast_kc_synth;
+hast_status hast_kc_synth_host(const hast_kc_synth *, int parent, uint64_t first_read, size_t n_reads, uint8_t *out);
+hast_status hast_kc_synth_device(hast_kc *, const hast_kc_synth *, int parent, uint64_t first_read, size_t n_reads, uint8_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,7 @@ def run_s00_case(exe, golden_workdir, tmp_path, case, run, extra_args=()):
     import subprocess
     meta = load_case(case)["runs"][run]
     work = tmp_path / ("%s_%s" % (case, run))
+    os.makedirs(tmp_path, exist_ok=True)
     shutil.copytree(golden_workdir / case, work)
     res = subprocess.run([exe] + meta["argv"] + list(extra_args), cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert res.returncode == 0, (res.stdout.decode()[-1000:], res.stderr.decode()[-2000:])

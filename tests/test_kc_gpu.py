@@ -1,0 +1,247 @@
+"""GPU parity of stage 00 (parent-unique k-mer sets): hast_kc_* and the unshared_kmers program against the oracle
+(oracle/s00_oracle.c, pinned on the reference script's own outputs) and against those committed outputs."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import hast_amd
+from hast_amd import KcSynth, KmerCounter
+from tests.conftest import golden_cases, run_s00_case
+
+pytestmark = pytest.mark.gpu
+U64P = C.POINTER(C.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def built():
+    hast_amd.build()
+    return hast_amd.lib()
+
+
+def random_stream(rng, n, k):
+    """bases with everything the counting rules distinguish: both cases, N/n, IUPAC, separators, CR, repeats"""
+    out = bytearray()
+    motifs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(k, 3 * k))) for _ in range(40)]
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.35:
+            s = rng.choice(motifs)
+            if rng.random() < 0.5:
+                s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        elif r < 0.40:
+            s = rng.choice("ACGT") * rng.randint(1, 4 * k)
+        else:
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 200)))
+        if rng.random() < 0.2:
+            s = s.lower()
+        out += s.encode()
+        r = rng.random()
+        if r < 0.25:
+            out += b"\n"
+        elif r < 0.35:
+            out += rng.choice([b"N", b"n", b"R", b"\r", b"NNNN", b"-", b"\x00", b"\xff", b"@", b">"])
+    return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+
+
+def oracle_table(o, k, streams):
+    c = o.ho_s00_new(k)
+    for parent, data in streams:
+        o.ho_s00_add_stream(c, parent, data.ctypes.data, data.size)
+    return c
+
+
+def oracle_select(o, c, parent, lo, hi):
+    n = o.ho_s00_select(c, parent, lo, hi, None)
+    keys = np.zeros(max(n, 1), dtype=np.uint64)
+    o.ho_s00_select(c, parent, lo, hi, keys.ctypes.data_as(U64P))
+    return keys[:n]
+
+
+def oracle_histo(o, c, parent):
+    h = np.zeros(hast_amd.KC_HISTO_HIGH + 2, dtype=np.uint64)
+    o.ho_s00_histo(c, parent, h.ctypes.data_as(U64P))
+    return h
+
+
+def key_text(o, keys, k):
+    buf = C.create_string_buffer(k + 1)
+    out = []
+    for x in keys:
+        o.ho_s00_key_to_str(int(x), k, buf)
+        out.append(buf.value + b"\n")
+    return b"".join(out)
+
+
+def check_against_oracle(o, kc, c, k, bounds):
+    st = kc.stats()
+    assert st["distinct"] == (o.ho_s00_distinct(c, 0), o.ho_s00_distinct(c, 1))
+    assert st["total"] == (o.ho_s00_total(c, 0), o.ho_s00_total(c, 1))
+    for p in (0, 1):
+        assert np.array_equal(kc.histo(p), oracle_histo(o, c, p)), p
+
+
+@pytest.mark.parametrize("k", [21, 31, 32, 11, 5, 1, 16])
+def test_counts_histograms_selections_vs_oracle(built, oracle_lib, k):
+    o = oracle_lib
+    rng = random.Random(100 + k)
+    pat, mat = random_stream(rng, 300_000, k), random_stream(rng, 260_000, k)
+    shared = random_stream(rng, 150_000, k)                      # k-mers both parents have
+    c = oracle_table(o, k, [(0, pat), (0, shared), (1, mat), (1, shared)])
+    bounds = [(1, 1 << 30), (2, 5), (1, 1), (3, 3), (7, 2)]
+    with KmerCounter(k, table_bytes=64 << 20) as kc:
+        kc.count(0, pat)
+        kc.count(1, mat)
+        for p in (0, 1):
+            kc.count(p, shared)
+        kc.sync()
+        check_against_oracle(o, kc, c, k, bounds)
+        for lo, hi in bounds:
+            got = [kc.select(p, lo, hi) for p in (0, 1)]
+            want = [oracle_select(o, c, p, lo, hi) for p in (0, 1)]
+            assert got == [w.size for w in want], (lo, hi)
+        # the selections accumulate: what has been appended so far, sorted, is the sorted union with multiplicity
+        kc.release_table()
+        for p in (0, 1):
+            allw = np.sort(np.concatenate([oracle_select(o, c, p, lo, hi) for lo, hi in bounds]))
+            n = kc.selection_sort(p)
+            assert n == allw.size
+            assert kc.selection_text(p, 0, n) == key_text(o, allw, k)
+            if n > 10:
+                assert kc.selection_text(p, 3, 5) == key_text(o, allw[3:8], k)
+            # the same rows as stage-01 table keys
+            tk = kc.selection_keys(p, 0, n)
+            txt = key_text(o, allw, k).split(b"\n")[:-1]
+            assert [int(x) for x in tk[:200]] == [hast_amd.canon_kmer(t) for t in txt[:200]]
+    o.ho_s00_free(c)
+
+
+def test_slices_partition_the_key_space(built, oracle_lib):
+    o, k = oracle_lib, 21
+    rng = random.Random(7)
+    pat, mat = random_stream(rng, 400_000, k), random_stream(rng, 400_000, k)
+    c = oracle_table(o, k, [(0, pat), (1, mat), (1, pat[:100_000])])
+    want = [oracle_select(o, c, p, 1, 50) for p in (0, 1)]
+    with KmerCounter(k, table_bytes=32 << 20) as kc:
+        for n_slices in (3, 1):
+            h = [np.zeros(hast_amd.KC_HISTO_HIGH + 2, dtype=np.uint64) for _ in (0, 1)]
+            distinct = [0, 0]
+            for s in range(n_slices):
+                kc.set_slice(s, n_slices)
+                kc.count(0, pat)
+                kc.count(1, mat)
+                kc.count(1, pat[:100_000])
+                kc.sync()
+                st = kc.stats()
+                for p in (0, 1):
+                    kc.histo(p, into=h[p])
+                    distinct[p] += st["distinct"][p]
+                    kc.select(p, 1, 50)
+                if n_slices > 1:
+                    assert 0 < st["keys"] < o.ho_s00_distinct(c, 0) + o.ho_s00_distinct(c, 1)
+            for p in (0, 1):
+                assert np.array_equal(h[p], oracle_histo(o, c, p))
+                assert distinct[p] == o.ho_s00_distinct(c, p)
+        kc.release_table()
+        for p in (0, 1):                                           # both rounds appended: every key twice
+            n = kc.selection_sort(p)
+            assert kc.selection_text(p, 0, n) == key_text(o, np.repeat(want[p], 2), k)
+    o.ho_s00_free(c)
+
+
+def test_full_table_is_reported_and_high_load_is_exact(built, oracle_lib):
+    o, k = oracle_lib, 21
+    rng = random.Random(11)
+    data = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(200_000)), dtype=np.uint8).copy()     # ~200k distinct
+    with KmerCounter(k, table_bytes=64 * 128) as kc:               # 512 slots
+        kc.count(0, data)
+        with pytest.raises(hast_amd.HastError) as ei:
+            kc.sync()
+        assert ei.value.status == 5
+    c = oracle_table(o, k, [(0, data), (1, data[50_000:])])
+    n_keys = o.ho_s00_distinct(c, 0)
+    with KmerCounter(k, table_bytes=int(n_keys / 0.92) // 8 * 128) as kc:   # load factor 0.92: long overflow chains
+        kc.count(0, data)
+        kc.count(1, data[50_000:])
+        kc.sync()
+        st = kc.stats()
+        assert st["keys"] == n_keys and st["keys"] / st["capacity"] > 0.9
+        check_against_oracle(o, kc, c, k, None)
+        assert kc.select(0, 1, 10) == oracle_select(o, c, 0, 1, 10).size
+    o.ho_s00_free(c)
+
+
+def test_streams_longer_than_a_staging_buffer_and_device_input(built, oracle_lib):
+    """host streams are cut into 64-MB pieces (windows across a cut counted once); device-resident streams; the
+    device generator equals the host generator"""
+    o, k = oracle_lib, 21
+    g = KcSynth(0, 300_000, 100, 12, 25, 30)
+    n_reads = 700_000                                              # 70.7 MB per parent: two staging pieces
+    host = [hast_amd.kc_synth_host(g, p, 0, n_reads) for p in (0, 1)]
+    # make the cut fall inside a run of bases: one long record instead of reads around the 64-MB mark
+    cut = (64 << 20) - 64
+    host[0][cut - 3000:cut + 3000][host[0][cut - 3000:cut + 3000] == 10] = ord("A")
+    c = oracle_table(o, k, [(0, host[0]), (1, host[1])])
+    with hast_amd.Context(k) as ctx, KmerCounter(k, table_bytes=1 << 30) as kc:
+        kc.count(0, host[0])
+        d = ctx.alloc(host[1].size)
+        kc.synth_device(g, 1, 0, n_reads, d)
+        kc.count_device(1, d, host[1].size)
+        kc.sync()
+        assert np.array_equal(ctx.to_host(d, (host[1].size,), np.uint8), host[1])
+        check_against_oracle(o, kc, c, k, None)
+        h = kc.histo(0)
+        lo, hi = hast_amd.kc_find_bounds(h)[2:]
+        assert kc.select(0, lo, hi) == oracle_select(o, c, 0, lo, hi).size
+        assert kc.select(1, 2, 10_000) == oracle_select(o, c, 1, 2, 10_000).size
+    o.ho_s00_free(c)
+
+
+# ---- the program ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,run", golden_cases("s00"))
+def test_unshared_kmers_matches_reference_script_golden(built, golden_workdir, tmp_path, case, run):
+    res = run_s00_case(hast_amd.unshared_kmers_exe(), golden_workdir, tmp_path, case, run, extra_args=["--table-gb", "0.25", "--stats"])
+    assert b"[stats]" in res.stderr
+
+
+def test_unshared_kmers_default_table_size(built, golden_workdir, tmp_path):
+    """no --table-gb: the table takes 85 % of the free HBM"""
+    run_s00_case(hast_amd.unshared_kmers_exe(), golden_workdir, tmp_path, "s00_fasta_k11", "ge2")
+
+
+def test_unshared_kmers_slices_overflow_retry_and_table_handoff(built, oracle_dir, golden_workdir, tmp_path):
+    """a table too small for the input: the program starts over with more slices and still writes the same sets;
+    --save-table gives classify the same table as the text files do"""
+    exe = hast_amd.unshared_kmers_exe()
+    case, run = "s00_trio_k21", "auto"
+    run_s00_case(exe, golden_workdir, tmp_path / "a", case, run, extra_args=["--table-gb", "0.0002", "--slices", "3"])
+    res = run_s00_case(exe, golden_workdir, tmp_path / "b", case, run, extra_args=["--table-gb", "0.00005", "--save-table", "sets.hastkeys"])
+    assert b"starting over" in res.stderr
+    work = tmp_path / "b" / ("%s_%s" % (case, run))
+    args = ["--read", "m.fq", "--read", "p1.fq"]
+    a = subprocess.run([hast_amd.classify_exe(), "--hap0", "paternal.unique.filter.mer", "--hap1", "maternal.unique.filter.mer"] + args,
+                       cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([hast_amd.classify_exe(), "--load-table", "sets.hastkeys"] + args, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-500:], b.stderr[-500:])
+    assert a.stdout == b.stdout and len(a.stdout) > 0
+
+
+def test_unshared_kmers_argument_checks(built, golden_workdir, tmp_path):
+    exe = hast_amd.unshared_kmers_exe()
+    d = golden_workdir / "s00_gz_k25"
+    run = lambda *a: subprocess.run([exe] + list(a), cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run().returncode == 0 and b"Usage" in run().stdout                        # build_unshared_kmers.sh:57-60
+    assert run("--help").returncode == 0
+    assert run("--bogus").returncode == 0                                                # :113-116 (bare `exit`)
+    assert run("--paternal", "p_a.fq.gz").returncode == 1                                # no maternal
+    assert run("--paternal", "p_a.fq.gz", "--maternal", "m_a.fq.gz", "--mer", "10").returncode == 1
+    assert run("--paternal", "p_a.fq.gz", "--maternal", "m_a.fq.gz", "--p-lower", "0").returncode == 1
+    assert run("--paternal", "p_a.fq.gz", "--maternal", "nope.fq.gz").returncode == 1
+    (d / "plain.fq").write_bytes(b"@r\nACGT\n+\nIIII\n")
+    assert run("--paternal", "p_a.fq.gz", "--paternal", "plain.fq", "--maternal", "m_a.fq.gz").returncode == 1      # :166-185
+    (d / "bad.fq").write_bytes(b"@r\nACGTACGTACGTACGTACGTACGTAAA\n+\nIII\n")
+    r = run("--paternal", "bad.fq", "--maternal", "plain.fq", "--table-gb", "0.01")
+    assert r.returncode == 1 and b"quality" in r.stdout
