@@ -114,11 +114,10 @@ hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out)
     bail(hipMalloc(&c->d_histo, (HAST_KC_HISTO_HIGH + 2) * sizeof(unsigned long long)), "hipMalloc(histo)");
     for (auto &s : c->stage) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
     if (st == HAST_OK) {
-        if (table_bytes == 0) {
-            size_t free_b = 0, total_b = 0;
-            bail(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
-            table_bytes = (size_t)((double)free_b * 0.85);
-        }
+        size_t free_b = 0, total_b = 0;
+        bail(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
+        const size_t most = (size_t)((double)free_b * 0.85);
+        if (table_bytes == 0 || table_bytes > most) table_bytes = most;      // never more than 85 % of what is free
         size_t nb = table_bytes / (kKcBucketWords * sizeof(unsigned long long));
         nb = std::min<size_t>(std::max<size_t>(nb, 64), 0xFFFFFFF0u);
         c->nbuckets = (uint32_t)nb;
@@ -325,6 +324,17 @@ hast_status hast_kc_select(hast_kc *c, int parent, uint32_t lower, uint32_t uppe
         return st;
     }
     if (n_added) *n_added = (size_t)n;
+    return HAST_OK;
+}
+
+hast_status hast_kc_selection_clear(hast_kc *c) {
+    if (hast_status st = use(c)) return st;
+    for (int p = 0; p < 2; ++p) {
+        std::vector<uint64_t>().swap(c->sel[p]);
+        if (c->d_sorted[p]) KC_TRY(hipFree(c->d_sorted[p]));
+        c->d_sorted[p] = nullptr;
+        c->n_sorted[p] = 0;
+    }
     return HAST_OK;
 }
 

@@ -11,7 +11,7 @@
 namespace hast {
 
 constexpr int kKcSlots = 8;                       // keys per bucket
-constexpr int kKcBucketWords = 16;                // 8 keys (64 B) + 8 x {u32 paternal, u32 maternal} (64 B) = 128 B
+constexpr int kKcBucketWords = 16;                // 8 keys (64 B) + 8 x u32 paternal (32 B) + 8 x u32 maternal (32 B) = 128 B
 constexpr uint32_t kKcHistoHigh = 10000;          // jellyfish histo default --high (analysis_kmercount.sh:7-9)
 
 // 2-bit codes A0 C1 T2 G3 -> A0 C1 G2 T3 (swap codes 2 and 3: low bit ^= high bit)

@@ -5,7 +5,7 @@
 //
 // Integer + HBM work only (no MFMA by design):
 //   k_kc_count   : byte stream -> 2-bit codes + validity mask in LDS -> canonical k-mer per window -> find-or-insert in
-//                  the window's minimizer bucket (128-B line: 8 keys + 8 counter pairs) -> one atomic add
+//                  the window's minimizer bucket (128-B line: 8 keys + 8 paternal + 8 maternal counters) -> one atomic add
 //   k_kc_stats / k_kc_histo / k_kc_select : streaming passes over the table
 //   k_kc_format  : selected keys -> text lines
 #include <cstring>
@@ -28,7 +28,7 @@ __device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, 
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (uint32_t probe = 0; probe < nb; ++probe) {
         unsigned long long *bk = table + (size_t)b * kKcBucketWords;
-        uint32_t *cnt = reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent;
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots;   // this parent's 8 counters: one 32-B sector
         const u64x2 *v = reinterpret_cast<const u64x2 *>(bk);
         unsigned long long s[kKcSlots];
 #pragma unroll
@@ -37,21 +37,22 @@ __device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, 
             s[2 * i] = t.x;
             s[2 * i + 1] = t.y;
         }
-        int first_empty = kKcSlots;
+        // ONE atomic site for every lane that found its key: the lanes of a wave are consecutive windows, mostly of the
+        // same bucket, and their adds to one 64-B counter line leave the CU as a single request only when they come
+        // from the same instruction
+        int idx = -1, first_empty = kKcSlots;
 #pragma unroll
         for (int i = kKcSlots - 1; i >= 0; --i) {
-            if (s[i] == key) {
-                atomicAdd(cnt + 2 * i, 1u);
-                return true;
-            }
+            if (s[i] == key) idx = i;
             if (s[i] == kEmptySlot) first_empty = i;
         }
-        for (int i = first_empty; i < kKcSlots; ++i) {
+        for (int i = first_empty; idx < 0 && i < kKcSlots; ++i) {
             const unsigned long long old = atomicCAS(&bk[i], (unsigned long long)kEmptySlot, (unsigned long long)key);
-            if (old == kEmptySlot || old == key) {
-                atomicAdd(cnt + 2 * i, 1u);
-                return true;
-            }
+            if (old == kEmptySlot || old == key) idx = i;
+        }
+        if (idx >= 0) {
+            atomicAdd(cnt + idx, 1u);
+            return true;
         }
         b = (b + 1 == nb) ? 0 : b + 1;                       // bucket full: next bucket (same 4-KB page mostly)
     }
@@ -193,10 +194,10 @@ __global__ void __launch_bounds__(256) k_kc_stats(const unsigned long long *tabl
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nslots; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned long long *bk = table + (i / kKcSlots) * kKcBucketWords;
         if (bk[i % kKcSlots] == kEmptySlot) continue;
-        const unsigned long long c = bk[kKcSlots + i % kKcSlots];
+        const uint32_t *c = reinterpret_cast<const uint32_t *>(bk + kKcSlots) + i % kKcSlots;
         cu++;
-        c0 += (uint32_t)c != 0;
-        c1 += (uint32_t)(c >> 32) != 0;
+        c0 += c[0] != 0;
+        c1 += c[kKcSlots] != 0;
     }
     for (int off = 32; off > 0; off >>= 1) {
         c0 += __shfl_down(c0, off, 64);
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(256) k_kc_histo(const unsigned long long *tabl
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nslots; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned long long *bk = table + (i / kKcSlots) * kKcBucketWords;
         if (bk[i % kKcSlots] == kEmptySlot) continue;
-        const uint32_t c = reinterpret_cast<const uint32_t *>(bk + kKcSlots)[2 * (i % kKcSlots) + parent];
+        const uint32_t c = reinterpret_cast<const uint32_t *>(bk + kKcSlots)[parent * kKcSlots + i % kKcSlots];
         if (c == 1) n1++;
         else if (c == 2) n2++;
         else if (c) atomicAdd(&h[c > kKcHistoHigh ? kKcHistoHigh + 1 : c], 1u);
@@ -250,8 +251,9 @@ __global__ void __launch_bounds__(256) k_kc_select(const unsigned long long *tab
             const unsigned long long *bk = table + (i / kKcSlots) * kKcBucketWords;
             key = bk[i % kKcSlots];
             if (key != kEmptySlot) {
-                const uint32_t *c = reinterpret_cast<const uint32_t *>(bk + kKcSlots) + 2 * (i % kKcSlots);
-                take = c[parent] >= lower && c[parent] <= upper && c[1 - parent] == 0;
+                const uint32_t *c = reinterpret_cast<const uint32_t *>(bk + kKcSlots) + i % kKcSlots;
+                const uint32_t mine = c[parent * kKcSlots], other = c[(1 - parent) * kKcSlots];
+                take = mine >= lower && mine <= upper && other == 0;
             }
         }
         // one atomic per wave

@@ -31,6 +31,7 @@ class SeqParser {
         const char *end = p + n;
         if (n && fmt_ == kUnknown) {
             const char first = carry_.empty() ? *p : carry_[0];
+            first_ = first;
             fmt_ = first == '>' ? kFasta : first == '@' ? kFastq : kBad;
             if (fmt_ == kBad) return fail("unsupported format: the input starts with neither '>' nor '@'");
         }
@@ -52,6 +53,13 @@ class SeqParser {
         }
         return true;
     }
+    // true when the input seen so far ends exactly between two records: appending another input to it (`zcat a b`)
+    // then parses like the two inputs one by one
+    bool at_record_boundary() const {
+        if (!carry_.empty()) return false;
+        return fmt_ == kUnknown || fmt_ == kFasta || (state_ == kHeader && !in_record_);
+    }
+    char first_byte() const { return first_; }
     // end of this input: the unterminated last line, and the record in progress
     bool finish() {
         if (!carry_.empty()) {
@@ -122,6 +130,7 @@ class SeqParser {
     std::string carry_, err_;
     size_t seq_len_ = 0, qual_len_ = 0, records_ = 0;
     bool in_record_ = false;
+    char first_ = 0;
 };
 
 }  // namespace hast

@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "../../include/hast.h"
@@ -121,9 +122,11 @@ class ChunkSink {
 struct IngestResult {
     std::string error;
     size_t bases = 0, records = 0, bytes = 0;
+    bool clean_end = true;           // the stream ended exactly between two records
+    char first = 0;                  // its first byte
 };
 
-// one `jellyfish count` input stream: the files one after the other, either as separate inputs (plain) or as one
+// one input stream of the counter: the files one after the other, either as separate inputs (plain) or as one
 // concatenated stream (gz: `zcat files | ...`, s00:187-188)
 void ingest_stream(Gpu &gpu, int parent, int k, const std::vector<std::string> &paths, bool concatenated, IngestResult &res) {
     ChunkSink sink(gpu, parent, k);
@@ -143,37 +146,59 @@ void ingest_stream(Gpu &gpu, int parent, int k, const std::vector<std::string> &
             src.recycle(std::move(b));
             if (!res.error.empty() || !gpu.ok()) break;
         }
-        if (res.error.empty() && (!concatenated || i + 1 == paths.size()) && !parser.finish()) res.error = paths[i] + ": " + parser.error();
+        if (res.error.empty() && (!concatenated || i + 1 == paths.size())) {
+            res.clean_end = parser.at_record_boundary();
+            res.first = parser.first_byte();
+            if (!parser.finish()) res.error = paths[i] + ": " + parser.error();
+        }
     }
     sink.flush(true);
     res.bases = sink.bases();
     res.records = parser.records();
 }
 
-// all files of one parent; plain files are independent inputs and are read by up to `threads` workers at once
-bool ingest_parent(Gpu &gpu, int parent, const Options &o, std::string &err, size_t &bases, size_t &records, size_t &bytes) {
-    std::vector<std::string> order(o.files[parent].rbegin(), o.files[parent].rend());   // s00:105,109: each new file is put in front
-    const bool gz = ends_gz(order[0]);
-    std::vector<IngestResult> results;
-    if (gz) {
-        results.resize(1);
-        ingest_stream(gpu, parent, (int)o.mer, order, true, results[0]);
-    } else {
-        results.resize(order.size());
-        std::atomic<size_t> next{0};
-        const int nt = (int)std::max<long>(1, std::min<long>(o.cpu, (long)order.size()));
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t)
-            th.emplace_back([&] {
-                for (size_t i; (i = next.fetch_add(1)) < order.size();) ingest_stream(gpu, parent, (int)o.mer, {order[i]}, false, results[i]);
-            });
-        for (auto &t : th) t.join();
+// Both parents' files, read and parsed by up to --thread workers at once.  Plain files are independent inputs of the
+// counter (s00:190).  The gz files of a parent are ONE concatenated stream in the reference (s00:187-188); they are
+// still read in parallel, which gives the same result whenever every file ends exactly between two records and all
+// start with the same byte -- if not (gz_in_order comes back true), the caller starts over and reads them in order.
+struct ParentTotals { size_t bases = 0, records = 0, bytes = 0; };
+bool ingest_all(Gpu &gpu, const Options &o, bool &gz_in_order, std::string &err, ParentTotals tot[2]) {
+    struct Job { int parent; std::vector<std::string> paths; bool concatenated, check; IngestResult res; };
+    std::vector<Job> jobs;
+    for (int p = 1; p >= 0; --p) {                                              // maternal first, as the script does
+        std::vector<std::string> order(o.files[p].rbegin(), o.files[p].rend());   // s00:105,109: each new file is put in front
+        const bool gz = ends_gz(order[0]);
+        if (gz && gz_in_order) jobs.push_back({p, order, true, false, {}});
+        else
+            for (size_t i = 0; i < order.size(); ++i) jobs.push_back({p, {order[i]}, false, gz && order.size() > 1, {}});
     }
-    for (const auto &r : results) {
-        if (!r.error.empty() && err.empty()) err = r.error;
-        bases += r.bases;
-        records += r.records;
-        bytes += r.bytes;
+    std::atomic<size_t> next{0};
+    const int nt = (int)std::max<long>(1, std::min<long>(o.cpu, (long)jobs.size()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            for (size_t i; (i = next.fetch_add(1)) < jobs.size();) ingest_stream(gpu, jobs[i].parent, (int)o.mer, jobs[i].paths, jobs[i].concatenated, jobs[i].res);
+        });
+    for (auto &t : th) t.join();
+    bool redo = false;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        const Job &j = jobs[i];
+        if (j.check) {
+            const bool last = i + 1 == jobs.size() || jobs[i + 1].parent != j.parent;
+            const bool first = i == 0 || jobs[i - 1].parent != j.parent;
+            if ((!last && !j.res.clean_end) || (!first && j.res.first != jobs[i - 1].res.first && j.res.first && jobs[i - 1].res.first)) redo = true;
+            if (!j.res.error.empty() && !first) redo = true;                    // may parse differently as part of the whole stream
+        }
+    }
+    if (redo && !gz_in_order) {
+        gz_in_order = true;
+        return false;
+    }
+    for (const auto &j : jobs) {
+        if (!j.res.error.empty() && err.empty()) err = j.res.error;
+        tot[j.parent].bases += j.res.bases;
+        tot[j.parent].records += j.res.records;
+        tot[j.parent].bytes += j.res.bytes;
     }
     if (err.empty() && !gpu.ok()) err = gpu.error;
     return err.empty();
@@ -245,12 +270,35 @@ int main(int argc, char **argv) {
             }
     const char *pname[2] = {"paternal", "maternal"};
     const double t_start = now();
+    double t_ingest = 0;
 
+    // Table size when not given: room for every window of the input being a different k-mer at load factor 1/2 (an
+    // upper bound from the file sizes: about half the bytes of a FASTQ are bases, a gz file holds at most ~3 bases per
+    // byte), capped by the library at 85 % of the free HBM.  Too small a guess only costs a restart with more slices.
+    size_t table_bytes = (size_t)(o.table_gb * (double)(1ull << 30));
+    if (table_bytes == 0) {
+        double windows = 0;
+        for (int p = 0; p < 2; ++p)
+            for (const auto &f : o.files[p]) {
+                struct stat sb;
+                if (stat(f.c_str(), &sb) != 0) continue;
+                bool fasta = false;
+                if (!ends_gz(f)) {
+                    if (FILE *fp = fopen(f.c_str(), "rb")) {
+                        fasta = fgetc(fp) == '>';
+                        fclose(fp);
+                    }
+                }
+                windows += ends_gz(f) ? 3.0 * (double)sb.st_size : fasta ? (double)sb.st_size : 0.55 * (double)sb.st_size;
+            }
+        table_bytes = (size_t)std::max(256.0 * (1 << 20), windows * 2.0 * 16.0);
+    }
     Gpu gpu;
-    if (hast_kc_create(o.device, (int)o.mer, (size_t)(o.table_gb * (double)(1ull << 30)), &gpu.kc) != HAST_OK) {
+    if (hast_kc_create(o.device, (int)o.mer, table_bytes, &gpu.kc) != HAST_OK) {
         fprintf(stderr, "unshared_kmers: %s\n", hast_last_error());
         return 4;
     }
+    const double t_table = now();
     auto gpu_fail = [&](const char *what) {
         fprintf(stderr, "unshared_kmers: %s: %s\n", what, hast_last_error());
         hast_kc_destroy(gpu.kc);
@@ -259,30 +307,39 @@ int main(int argc, char **argv) {
 
     std::vector<uint64_t> histo[2];
     long slices = o.slices;
+    bool gz_in_order = false;
     uint64_t stats_sum[6] = {0, 0, 0, 0, 0, 0};
     size_t bases[2] = {0, 0}, records[2] = {0, 0}, bytes[2] = {0, 0};
     // One sweep = every slice of the key space: count both parents, then take what this sweep is for.
-    // Returns 0 ok, 1 input error, 4 GPU error, -1 table full (caller retries with more slices).
+    // Returns 0 ok, 1 input error, 4 GPU error, -1 table full (caller retries with more slices), -2 read the gz files in order.
     auto sweep = [&](bool take_histo, bool take_sets) -> int {
         for (int p = 0; p < 2; ++p) {
             if (take_histo) histo[p].assign(HAST_KC_HISTO_HIGH + 2, 0);
             bases[p] = records[p] = bytes[p] = 0;
         }
         for (auto &x : stats_sum) x = 0;
+        if (take_sets && hast_kc_selection_clear(gpu.kc) != HAST_OK) return 4;      // a sweep that starts over starts from nothing
         for (long s = 0; s < slices; ++s) {
             if (hast_kc_set_slice(gpu.kc, (uint32_t)s, (uint32_t)slices) != HAST_OK) return 4;
-            for (int p = 1; p >= 0; --p) {                                      // maternal first, as the script does
+            {
                 std::string err;
-                size_t b = 0, r = 0, by = 0;
-                if (!ingest_parent(gpu, p, o, err, b, r, by)) {
+                ParentTotals tot[2];
+                const bool was_in_order = gz_in_order;
+                const double t_in = now();
+                const bool ok = ingest_all(gpu, o, gz_in_order, err, tot);
+                t_ingest += now() - t_in;
+                if (!ok) {
+                    if (gz_in_order && !was_in_order) return -2;               // a gz file ends inside a record: read them in order
                     const bool gpu_side = !gpu.error.empty();
                     if (gpu_side && hast_kc_sync(gpu.kc) == HAST_ERR_TABLE_FULL) return -1;
                     fprintf(gpu_side ? stderr : stdout, "ERROR: %s\n", err.c_str());
                     return gpu_side ? 4 : 1;
                 }
-                bases[p] = b;
-                records[p] = r;
-                bytes[p] = by;
+                for (int p = 0; p < 2; ++p) {
+                    bases[p] = tot[p].bases;
+                    records[p] = tot[p].records;
+                    bytes[p] = tot[p].bytes;
+                }
             }
             const hast_status st = hast_kc_sync(gpu.kc);
             if (st == HAST_ERR_TABLE_FULL) return -1;
@@ -308,6 +365,11 @@ int main(int argc, char **argv) {
         for (;;) {
             gpu.error.clear();
             const int rc = sweep(take_histo, take_sets);
+            if (rc == -2) {
+                fprintf(stderr, "a gz input ends inside a record: reading each parent's gz files in order, as one stream\n");
+                hast_kc_sync(gpu.kc);
+                continue;
+            }
             if (rc != -1) return rc;
             if (slices >= 4096) {
                 fprintf(stderr, "unshared_kmers: the count table is too small even with %ld slices\n", slices);
@@ -417,7 +479,8 @@ int main(int argc, char **argv) {
         for (int p = 0; p < 2; ++p)
             fprintf(stderr, "[stats] %s: %zu input bytes, %zu records, %zu bases, %llu k-mers counted, %llu distinct, %zu selected\n", pname[p],
                     bytes[p], records[p], bases[p], (unsigned long long)stats_sum[4 + p], (unsigned long long)stats_sum[p], n_sel[p]);
-        fprintf(stderr, "[stats] count %.3f s, output %.3f s, total %.3f s\n", t_count - t_start, t_end - t_count, t_end - t_start);
+        fprintf(stderr, "[stats] table %.3f s, read+parse+count %.3f s, table passes %.3f s, output %.3f s, total %.3f s\n", t_table - t_start, t_ingest,
+                t_count - t_table - t_ingest, t_end - t_count, t_end - t_start);
     }
     hast_kc_destroy(gpu.kc);
     return 0;

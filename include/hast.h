@@ -217,7 +217,7 @@ hast_status hast_synth_table_build(hast_ctx *, const hast_synth_params *);
 typedef struct hast_kc hast_kc;
 #define HAST_KC_HISTO_HIGH 10000u          /* counts above are lumped into bin HIGH+1 (jellyfish histo default) */
 
-/* table_bytes == 0: 85 % of the free device memory.  k in [1,32]. */
+/* table_bytes == 0 (or more than that): 85 % of the free device memory.  k in [1,32]. */
 hast_status hast_kc_create(int device_ordinal, int k, size_t table_bytes, hast_kc **out);
 void        hast_kc_destroy(hast_kc *);
 hast_stream hast_kc_stream(hast_kc *);
@@ -241,6 +241,8 @@ void        hast_kc_find_bounds(const uint64_t *histo, long out[4]);
 /* Append to the context's selection of `parent` the keys of the current table with lower <= count <= upper that the
  * other parent does not have.  n_added may be NULL. */
 hast_status hast_kc_select(hast_kc *, int parent, uint32_t lower, uint32_t upper, size_t *n_added);
+/* forget what has been selected so far (e.g. before starting over with more slices) */
+hast_status hast_kc_selection_clear(hast_kc *);
 /* free the table (the selections stay) */
 hast_status hast_kc_release_table(hast_kc *);
 /* sort the selection of `parent` (ascending = lexicographic order of the printed k-mers) and keep it on the device */

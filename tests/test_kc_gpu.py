@@ -229,6 +229,31 @@ def test_unshared_kmers_slices_overflow_retry_and_table_handoff(built, oracle_di
     assert a.stdout == b.stdout and len(a.stdout) > 0
 
 
+def test_unshared_kmers_gz_files_cut_inside_a_record(built, golden_workdir, tmp_path):
+    """`zcat a b | counter` (build_unshared_kmers.sh:187-188): the gz files of a parent are one stream.  The program reads
+    them in parallel and must notice when that is not the same thing: re-cut the golden case's files mid-record."""
+    import gzip
+    import shutil
+    from tests.conftest import load_case
+    case, run = "s00_gz_k25", "gz"
+    src = golden_workdir / case
+    work = tmp_path / "recut"
+    shutil.copytree(src, work)
+    for parent in "mp":
+        # the script puts each new file in FRONT of the list (:105,109): the stream is b then a
+        whole = gzip.open(work / ("%s_b.fq.gz" % parent)).read() + gzip.open(work / ("%s_a.fq.gz" % parent)).read()
+        cut = len(whole) // 3 + (17 if parent == "m" else 140)                 # inside a sequence / a quality line
+        for name, part in (("b", whole[:cut]), ("a", whole[cut:])):
+            with gzip.GzipFile(work / ("%s_%s.fq.gz" % (parent, name)), "wb", mtime=0) as f:
+                f.write(part)
+    meta = load_case(case)["runs"][run]
+    res = subprocess.run([hast_amd.unshared_kmers_exe()] + meta["argv"] + ["--table-gb", "0.1"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert res.returncode == 0, res.stderr[-1000:]
+    assert b"in order" in res.stderr
+    for prod, rec in meta["products"].items():
+        assert open(work / prod, "rb").read() == open(work / rec["expected"], "rb").read(), prod     # our rows are sorted already
+
+
 def test_unshared_kmers_argument_checks(built, golden_workdir, tmp_path):
     exe = hast_amd.unshared_kmers_exe()
     d = golden_workdir / "s00_gz_k25"
