@@ -88,6 +88,7 @@ ABI_SYMBOLS = {
     "hast_kc_find_bounds": (None, [vp, C.POINTER(C.c_long)]),
     "hast_kc_select": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t)]),
     "hast_kc_selection_clear": (C.c_int, [vp]),
+    "hast_kc_selection_adopt": (C.c_int, [vp, vp]),
     "hast_kc_release_table": (C.c_int, [vp]),
     "hast_kc_selection_sort": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
     "hast_kc_selection_text": (C.c_int, [vp, C.c_int, C.c_size_t, C.c_size_t, vp]),

@@ -338,6 +338,16 @@ hast_status hast_kc_selection_clear(hast_kc *c) {
     return HAST_OK;
 }
 
+hast_status hast_kc_selection_adopt(hast_kc *dst, hast_kc *src) {
+    if (!dst || !src || dst == src) return set_error(HAST_ERR_INVALID, "selection_adopt needs two different contexts");
+    if (dst->k != src->k) return set_error(HAST_ERR_INVALID, "selection_adopt: K differs (%d vs %d)", dst->k, src->k);
+    for (int p = 0; p < 2; ++p) {
+        dst->sel[p].insert(dst->sel[p].end(), src->sel[p].begin(), src->sel[p].end());
+        std::vector<uint64_t>().swap(src->sel[p]);
+    }
+    return HAST_OK;
+}
+
 hast_status hast_kc_release_table(hast_kc *c) {
     if (hast_status st = use(c)) return st;
     KC_TRY(hipStreamSynchronize(c->stream));

@@ -9,7 +9,7 @@
 // (*.jf, *.mer.fa, *.mer.filter.fa, *.mer.unique.fa, step_NN_done markers) have no counterpart: one count table in
 // HBM holds both parents' counts and the products are read out of it (include/hast.h, hast_kc_*).
 //
-// Extra options: --device N, --table-gb X (size of the count table; default 85 % of the free HBM), --slices S (process
+// Extra options: --device N (repeat it, or --devices a,b,c, to split the key space over several GPUs), --table-gb X (size of the count table per GPU; default: from the input size, at most 85 % of the free HBM), --slices S (process
 // the key space in S passes over the input; doubled automatically when the table overflows), --save-table FILE (the
 // two sets as a binary stage-01 table for `classify --load-table`), --stats.
 // Exit status: 0 ok / usage; 1 bad arguments, missing or malformed input (the script: exit 1); 4 GPU trouble.
@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -46,7 +47,8 @@ void usage(FILE *f) {
           "    --m-lower N / --m-upper N   keep maternal k-mers seen N..N times (default 9 / 33)\n"
           "    --p-lower N / --p-upper N   the same for paternal k-mers (default 9 / 33)\n"
           "    --auto_bounds     derive the four bounds from the count histograms (also writes *.histo, *.bounds.txt)\n"
-          "    --device N  --table-gb X  --slices S  --save-table FILE  --stats\n",
+          "    --device N (repeatable) / --devices a,b,c   GPUs; the k-mer space is split between them\n"
+          "    --table-gb X  --slices S  --save-table FILE  --stats\n",
           f);
 }
 
@@ -56,20 +58,34 @@ struct Options {
     long mer = 21, cpu = 8, memory = 10, lower[2] = {9, 9}, upper[2] = {33, 33};     // s00:44-55; [0] paternal, [1] maternal
     std::vector<std::string> files[2];
     bool auto_bounds = false, stats = false;
-    int device = 0;
+    std::vector<int> devices;        // --device N (repeatable) or --devices a,b,c; default: device 0
     double table_gb = 0;
     long slices = 1;
     std::string save_table;
 };
 
 // ---- ingest: files -> byte stream of bases -> GPU ---------------------------------------------------------------
+// One count table per GPU.  With several GPUs the KEY SPACE is split between them (device d of D owns the slices
+// d, d+D, ... of the minimizer hash): every GPU sees every chunk of bases and counts only its own k-mers, so there is no
+// exchange between the GPUs at all; histograms add up and selections concatenate on the host.
 struct Gpu {
-    hast_kc *kc = nullptr;
+    std::vector<hast_kc *> all;
+    hast_kc *kc = nullptr;           // all[0]: also sorts and formats the output
+    std::vector<std::unique_ptr<std::mutex>> dev_mu;
     std::mutex mu;
     std::string error;               // first failure of a submit
     bool ok() {
         std::lock_guard<std::mutex> g(mu);
         return error.empty();
+    }
+    void fail(const char *what) {
+        std::lock_guard<std::mutex> g(mu);
+        if (error.empty()) error = what;
+    }
+    void destroy() {
+        for (hast_kc *k : all) hast_kc_destroy(k);
+        all.clear();
+        kc = nullptr;
     }
 };
 
@@ -94,11 +110,14 @@ class ChunkSink {
         if (buf_.size() >= kChunk) flush(false);
     }
     void flush(bool last) {
-        if (buf_.size() > (fresh_from_ ? fresh_from_ : 0)) {
-            std::lock_guard<std::mutex> g(gpu_.mu);
-            if (gpu_.error.empty() && hast_kc_count(gpu_.kc, parent_, reinterpret_cast<const uint8_t *>(buf_.data()), buf_.size()) != HAST_OK)
-                gpu_.error = hast_last_error();
-        }
+        if (buf_.size() > fresh_from_ && gpu_.ok())
+            for (size_t d = 0; d < gpu_.all.size(); ++d) {
+                std::lock_guard<std::mutex> g(*gpu_.dev_mu[d]);
+                if (hast_kc_count(gpu_.all[d], parent_, reinterpret_cast<const uint8_t *>(buf_.data()), buf_.size()) != HAST_OK) {
+                    gpu_.fail(hast_last_error());
+                    break;
+                }
+            }
         if (last) {
             buf_.clear();
             fresh_from_ = 0;
@@ -237,7 +256,14 @@ int main(int argc, char **argv) {
         else if (a == "--auto_bounds") o.auto_bounds = true;
         else if (a == "--paternal") o.files[0].push_back(val());
         else if (a == "--maternal") o.files[1].push_back(val());
-        else if (a == "--device") o.device = atoi(val());
+        else if (a == "--device") o.devices.push_back(atoi(val()));
+        else if (a == "--devices") {
+            for (const char *q = val(); *q;) {
+                o.devices.push_back(atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
         else if (a == "--table-gb") o.table_gb = atof(val());
         else if (a == "--slices") o.slices = atol(val());
         else if (a == "--save-table") o.save_table = val();
@@ -293,15 +319,26 @@ int main(int argc, char **argv) {
             }
         table_bytes = (size_t)std::max(256.0 * (1 << 20), windows * 2.0 * 16.0);
     }
+    if (o.devices.empty()) o.devices.push_back(0);
+    const long n_dev = (long)o.devices.size();
     Gpu gpu;
-    if (hast_kc_create(o.device, (int)o.mer, table_bytes, &gpu.kc) != HAST_OK) {
-        fprintf(stderr, "unshared_kmers: %s\n", hast_last_error());
-        return 4;
+    for (int dev : o.devices) {
+        hast_kc *k = nullptr;
+        // --table-gb is per GPU; the automatic size is for the whole key space, i.e. divided between the GPUs
+        const size_t per_dev = o.table_gb > 0 ? table_bytes : table_bytes / (size_t)n_dev + 1;
+        if (hast_kc_create(dev, (int)o.mer, per_dev, &k) != HAST_OK) {
+            fprintf(stderr, "unshared_kmers: device %d: %s\n", dev, hast_last_error());
+            gpu.destroy();
+            return 4;
+        }
+        gpu.all.push_back(k);
+        gpu.dev_mu.emplace_back(new std::mutex());
     }
+    gpu.kc = gpu.all[0];
     const double t_table = now();
     auto gpu_fail = [&](const char *what) {
         fprintf(stderr, "unshared_kmers: %s: %s\n", what, hast_last_error());
-        hast_kc_destroy(gpu.kc);
+        gpu.destroy();
         return 4;
     };
 
@@ -312,15 +349,38 @@ int main(int argc, char **argv) {
     size_t bases[2] = {0, 0}, records[2] = {0, 0}, bytes[2] = {0, 0};
     // One sweep = every slice of the key space: count both parents, then take what this sweep is for.
     // Returns 0 ok, 1 input error, 4 GPU error, -1 table full (caller retries with more slices), -2 read the gz files in order.
+    // the sets of the tables as they stand, appended to the first GPU's selection
+    auto select_all = [&]() -> bool {
+        for (hast_kc *k : gpu.all) {
+            for (int p = 0; p < 2; ++p) {
+                // a bound pair that selects nothing (upper < lower, e.g. from an empty histogram) is an empty set
+                if (o.upper[p] < o.lower[p] || o.upper[p] < 1) continue;
+                if (hast_kc_select(k, p, (uint32_t)o.lower[p], (uint32_t)std::min<long>(o.upper[p], 0xFFFFFFFFl), nullptr) != HAST_OK) return false;
+            }
+            if (k != gpu.kc && hast_kc_selection_adopt(gpu.kc, k) != HAST_OK) return false;
+        }
+        return true;
+    };
     auto sweep = [&](bool take_histo, bool take_sets) -> int {
         for (int p = 0; p < 2; ++p) {
             if (take_histo) histo[p].assign(HAST_KC_HISTO_HIGH + 2, 0);
             bases[p] = records[p] = bytes[p] = 0;
         }
         for (auto &x : stats_sum) x = 0;
-        if (take_sets && hast_kc_selection_clear(gpu.kc) != HAST_OK) return 4;      // a sweep that starts over starts from nothing
+        if (take_sets)                                                          // a sweep that starts over starts from nothing
+            for (hast_kc *k : gpu.all)
+                if (hast_kc_selection_clear(k) != HAST_OK) return 4;
         for (long s = 0; s < slices; ++s) {
-            if (hast_kc_set_slice(gpu.kc, (uint32_t)s, (uint32_t)slices) != HAST_OK) return 4;
+            for (long d = 0; d < n_dev; ++d)
+                if (hast_kc_set_slice(gpu.all[d], (uint32_t)(s * n_dev + d), (uint32_t)(slices * n_dev)) != HAST_OK) return 4;
+            auto sync_all = [&]() -> hast_status {                              // table-full on any device wins
+                hast_status worst = HAST_OK;
+                for (hast_kc *k : gpu.all) {
+                    const hast_status st = hast_kc_sync(k);
+                    if (st == HAST_ERR_TABLE_FULL || (st != HAST_OK && worst == HAST_OK)) worst = st;
+                }
+                return worst;
+            };
             {
                 std::string err;
                 ParentTotals tot[2];
@@ -331,7 +391,7 @@ int main(int argc, char **argv) {
                 if (!ok) {
                     if (gz_in_order && !was_in_order) return -2;               // a gz file ends inside a record: read them in order
                     const bool gpu_side = !gpu.error.empty();
-                    if (gpu_side && hast_kc_sync(gpu.kc) == HAST_ERR_TABLE_FULL) return -1;
+                    if (gpu_side && sync_all() == HAST_ERR_TABLE_FULL) return -1;
                     fprintf(gpu_side ? stderr : stdout, "ERROR: %s\n", err.c_str());
                     return gpu_side ? 4 : 1;
                 }
@@ -341,23 +401,19 @@ int main(int argc, char **argv) {
                     bytes[p] = tot[p].bytes;
                 }
             }
-            const hast_status st = hast_kc_sync(gpu.kc);
+            const hast_status st = sync_all();
             if (st == HAST_ERR_TABLE_FULL) return -1;
             if (st != HAST_OK) return 4;
-            uint64_t stt[6];
-            if (hast_kc_stats(gpu.kc, stt) != HAST_OK) return 4;
-            for (int i = 0; i < 6; ++i) stats_sum[i] += (i == 3) ? 0 : stt[i];
-            stats_sum[3] = stt[3];
-            if (take_histo)
-                for (int p = 0; p < 2; ++p)
-                    if (hast_kc_histo(gpu.kc, p, histo[p].data()) != HAST_OK) return 4;
-            if (take_sets)
-                for (int p = 0; p < 2; ++p) {
-                    // a bound pair that selects nothing (upper < lower, e.g. from an empty histogram) is an empty set
-                    if (o.upper[p] < o.lower[p] || o.upper[p] < 1) continue;
-                    if (hast_kc_select(gpu.kc, p, (uint32_t)o.lower[p], (uint32_t)std::min<long>(o.upper[p], 0xFFFFFFFFl), nullptr) != HAST_OK)
-                        return 4;
-                }
+            stats_sum[3] = 0;
+            for (hast_kc *k : gpu.all) {
+                uint64_t stt[6];
+                if (hast_kc_stats(k, stt) != HAST_OK) return 4;
+                for (int i = 0; i < 6; ++i) stats_sum[i] += stt[i];
+                if (take_histo)
+                    for (int p = 0; p < 2; ++p)
+                        if (hast_kc_histo(k, p, histo[p].data()) != HAST_OK) return 4;
+            }
+            if (take_sets && !select_all()) return 4;
         }
         return 0;
     };
@@ -367,7 +423,7 @@ int main(int argc, char **argv) {
             const int rc = sweep(take_histo, take_sets);
             if (rc == -2) {
                 fprintf(stderr, "a gz input ends inside a record: reading each parent's gz files in order, as one stream\n");
-                hast_kc_sync(gpu.kc);
+                for (hast_kc *k : gpu.all) hast_kc_sync(k);
                 continue;
             }
             if (rc != -1) return rc;
@@ -396,30 +452,28 @@ int main(int argc, char **argv) {
                 FILE *f = write_histo(hp.c_str(), histo[p]) ? fopen(bp.c_str(), "w") : nullptr;
                 if (!f) {
                     printf("ERROR: cannot write %s / %s\n", hp.c_str(), bp.c_str());
-                    hast_kc_destroy(gpu.kc);
+                    gpu.destroy();
                     return 1;
                 }
                 fprintf(f, "MIN_INDEX=%ld\nMAX_INDEX=%ld\nLOWER_INDEX=%ld\nUPPER_INDEX=%ld\n", b[0], b[1], b[2], b[3]);   // find_bounds.awk:31
                 fclose(f);
             }
-            if (slices == 1) {                                                  // the table still holds everything
-                for (int p = 0; p < 2 && rc == 0; ++p)
-                    if (o.upper[p] >= o.lower[p] && o.upper[p] >= 1 &&
-                        hast_kc_select(gpu.kc, p, (uint32_t)o.lower[p], (uint32_t)std::min<long>(o.upper[p], 0xFFFFFFFFl), nullptr) != HAST_OK)
-                        rc = 4;
+            if (slices == 1) {                                                  // the tables still hold everything
+                if (!select_all()) rc = 4;
             } else rc = run(false, true);
         }
     }
     if (rc == 4) return gpu_fail("counting");
     if (rc != 0) {
-        hast_kc_destroy(gpu.kc);
+        gpu.destroy();
         return rc;
     }
     const double t_count = now();
     printf("bounds used for maternal: [%ld, %ld]\n", o.lower[1], o.upper[1]);   // s00:254-255
     printf("bounds used for paternal: [%ld, %ld]\n", o.lower[0], o.upper[0]);
 
-    if (hast_kc_release_table(gpu.kc) != HAST_OK) return gpu_fail("releasing the table");
+    for (hast_kc *k : gpu.all)
+        if (hast_kc_release_table(k) != HAST_OK) return gpu_fail("releasing the table");
     size_t n_sel[2] = {0, 0};
     for (int p = 0; p < 2; ++p) {
         if (hast_kc_selection_sort(gpu.kc, p, &n_sel[p]) != HAST_OK) return gpu_fail("sorting the selection");
@@ -427,7 +481,7 @@ int main(int argc, char **argv) {
         FILE *f = fopen(path.c_str(), "w");
         if (!f) {
             printf("ERROR: cannot write %s\n", path.c_str());
-            hast_kc_destroy(gpu.kc);
+            gpu.destroy();
             return 1;
         }
         const size_t rows = 4u << 20, width = (size_t)o.mer + 1;
@@ -441,19 +495,19 @@ int main(int argc, char **argv) {
             if (fwrite(text.data(), 1, n * width, f) != n * width) {
                 printf("ERROR: short write to %s\n", path.c_str());
                 fclose(f);
-                hast_kc_destroy(gpu.kc);
+                gpu.destroy();
                 return 1;
             }
         }
         if (fclose(f) != 0) {
             printf("ERROR: cannot write %s\n", path.c_str());
-            hast_kc_destroy(gpu.kc);
+            gpu.destroy();
             return 1;
         }
     }
     if (!o.save_table.empty()) {                                                // hap 0 = paternal, hap 1 = maternal (classify -p / -m)
         hast_ctx *ctx = nullptr;
-        if (hast_ctx_create(o.device, (int)o.mer, &ctx) != HAST_OK) return gpu_fail("--save-table");
+        if (hast_ctx_create(o.devices[0], (int)o.mer, &ctx) != HAST_OK) return gpu_fail("--save-table");
         bool ok = hast_table_reserve(ctx, n_sel[0] + n_sel[1] + 64, 0.0) == HAST_OK;
         std::vector<uint64_t> keys;
         for (int p = 0; p < 2 && ok; ++p)
@@ -466,7 +520,7 @@ int main(int argc, char **argv) {
         if (!ok) fprintf(stderr, "unshared_kmers: --save-table: %s\n", hast_last_error());
         hast_ctx_destroy(ctx);
         if (!ok) {
-            hast_kc_destroy(gpu.kc);
+            gpu.destroy();
             return 4;
         }
     }
@@ -474,7 +528,7 @@ int main(int argc, char **argv) {
     printf("maternal-unique k-mers kept: %zu (maternal.unique.filter.mer)\n", n_sel[1]);
     const double t_end = now();
     if (o.stats) {
-        fprintf(stderr, "[stats] K=%ld slices=%ld table_slots=%llu keys_in_table=%llu\n", o.mer, slices,
+        fprintf(stderr, "[stats] K=%ld gpus=%ld slices=%ld table_slots=%llu keys_in_table=%llu\n", o.mer, n_dev, slices * n_dev,
                 (unsigned long long)stats_sum[3], (unsigned long long)stats_sum[2]);
         for (int p = 0; p < 2; ++p)
             fprintf(stderr, "[stats] %s: %zu input bytes, %zu records, %zu bases, %llu k-mers counted, %llu distinct, %zu selected\n", pname[p],
@@ -482,6 +536,6 @@ int main(int argc, char **argv) {
         fprintf(stderr, "[stats] table %.3f s, read+parse+count %.3f s, table passes %.3f s, output %.3f s, total %.3f s\n", t_table - t_start, t_ingest,
                 t_count - t_table - t_ingest, t_end - t_count, t_end - t_start);
     }
-    hast_kc_destroy(gpu.kc);
+    gpu.destroy();
     return 0;
 }

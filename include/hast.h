@@ -243,6 +243,8 @@ void        hast_kc_find_bounds(const uint64_t *histo, long out[4]);
 hast_status hast_kc_select(hast_kc *, int parent, uint32_t lower, uint32_t upper, size_t *n_added);
 /* forget what has been selected so far (e.g. before starting over with more slices) */
 hast_status hast_kc_selection_clear(hast_kc *);
+/* move what `src` has selected so far to the end of `dst`'s selections (key space split over several contexts) */
+hast_status hast_kc_selection_adopt(hast_kc *dst, hast_kc *src);
 /* free the table (the selections stay) */
 hast_status hast_kc_release_table(hast_kc *);
 /* sort the selection of `parent` (ascending = lexicographic order of the printed k-mers) and keep it on the device */

@@ -23,6 +23,10 @@ echo "{\"genome\": $G, \"coverage\": $COV, \"bp\": $BP, \"files_per_parent\": $N
 run oracle_cpu_1thread timeout 3000 $PWD/oracle/oracle_unshared $ARGS --thread 1 --auto_bounds; echo ","
 for T in 1 8; do run hast_t$T $PWD/hast_amd/unshared_kmers $ARGS --thread $T --auto_bounds --stats; echo ","; done
 run hast_t8_again $PWD/hast_amd/unshared_kmers $ARGS --thread 8 --auto_bounds --stats
+if [ "${GZ:-1}" = 1 ]; then
+  for f in $D/*.fq; do gzip -1 -k $f & done; wait
+  echo ","; run hast_gz_t8 $PWD/hast_amd/unshared_kmers ${ARGS//.fq/.fq.gz} --thread 8 --auto_bounds --stats
+fi
 echo "]}"
 } > $OUT
 cat $OUT

@@ -229,6 +229,17 @@ def test_unshared_kmers_slices_overflow_retry_and_table_handoff(built, oracle_di
     assert a.stdout == b.stdout and len(a.stdout) > 0
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_unshared_kmers_key_space_split_over_several_tables(built, golden_workdir, tmp_path, devices):
+    """--devices a,b,..: one table per GPU, each owning a share of the minimizer space (here: several tables on the one
+    GPU of the test box); with --slices on top and a table that overflows"""
+    exe = hast_amd.unshared_kmers_exe()
+    run_s00_case(exe, golden_workdir, tmp_path / "a", "s00_trio_k21", "auto", extra_args=["--table-gb", "0.05", "--devices", devices])
+    run_s00_case(exe, golden_workdir, tmp_path / "b", "s00_gz_k25", "gz", extra_args=["--table-gb", "0.01", "--devices", devices, "--slices", "2"])
+    res = run_s00_case(exe, golden_workdir, tmp_path / "c", "s00_trio_k21", "k17_bounds", extra_args=["--table-gb", "0.00003", "--devices", devices])
+    assert b"starting over" in res.stderr
+
+
 def test_unshared_kmers_gz_files_cut_inside_a_record(built, golden_workdir, tmp_path):
     """`zcat a b | counter` (build_unshared_kmers.sh:187-188): the gz files of a parent are one stream.  The program reads
     them in parallel and must notice when that is not the same thing: re-cut the golden case's files mid-record."""
