@@ -99,6 +99,16 @@ def main():
                      "frac": alg_bytes / t_count / 1e9 / 8000.0, "traffic": None,
                      "algorithmic_bytes": alg_bytes, "windows_per_s": windows / t_count},
     }
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic_s00.json")
+    if os.path.exists(tf):                       # measured HBM traffic of the count kernel (rocprofv3 PMC), scaled per read
+        t = json.load(open(tf))
+        rf = out["roofline"]
+        rf["traffic"] = t["hbm_bytes_per_read"] * 2 * n_reads
+        rf["traffic_source"] = t["source"]
+        tx = (t["hbm_read_requests_per_read"] + t["hbm_write_requests_per_read"]) * 2 * n_reads / t_count
+        rf["hbm_transactions_per_s"] = tx
+        rf["hbm_line_rate_ceiling"] = 48e9      # tools/hbm_randread: random 64-B lines per second this part sustains
+        rf["hbm_line_rate_frac"] = tx / 48e9
     assert st["total"][0] + st["total"][1] <= windows
     # CPU baseline: the oracle's counter on a sample of the maternal stream (1 thread)
     if a.cpu_seconds > 0:
