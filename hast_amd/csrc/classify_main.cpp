@@ -347,6 +347,7 @@ int main(int argc, char **argv) {
         std::vector<char> &carry = fs.carry;
         std::vector<char> blk = src.next();
         const bool last = blk.empty();
+        if (last && !src.error().empty()) die(2, (fs.name + ": " + src.error()).c_str());
         constexpr size_t kPad = hast::BlockSource::kFrontPad;
         // work area = carry (incomplete record of the previous block) + this block's data
         const char *data;

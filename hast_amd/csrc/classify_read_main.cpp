@@ -195,6 +195,7 @@ int main(int argc, char **argv) {
         for (;;) {
             std::vector<char> blk = src.next();
             const bool last = blk.empty();
+            if (last && !src.error().empty()) die(2, r + ": " + src.error());
             constexpr size_t kPad = hast::BlockSource::kFrontPad;
             const char *data;
             size_t len;

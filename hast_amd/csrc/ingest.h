@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/hast.h"
+#include "fast_inflate.h"
 
 namespace hast {
 
@@ -191,7 +192,9 @@ class BarcodeDict {
 };
 
 // ------------------------------------------------------------------------------------------------
-// block source: raw or gz bytes in large blocks, produced by a background reader thread
+// block source: raw or gz bytes in large blocks, produced by a background reader thread.  gz files go through the
+// in-tree decoder (fast_inflate.h: about twice zlib's speed on FASTQ, members CRC-checked); HAST_INFLATE=zlib in the
+// environment switches back to zlib's gzread.  A damaged gz file ends the stream early and sets error().
 // ------------------------------------------------------------------------------------------------
 class BlockSource {
   public:
@@ -200,10 +203,17 @@ class BlockSource {
         close();
         const size_t n = path.size();
         gz_mode_ = n > 3 && path.compare(n - 3, 3, ".gz") == 0;               // classify.cpp:245-249
-        if (gz_mode_) {
+        const char *which = getenv("HAST_INFLATE");
+        use_zlib_ = which && strcmp(which, "zlib") == 0;
+        error_.clear();
+        if (gz_mode_ && use_zlib_) {
             gz_ = gzopen(path.c_str(), "rb");
             if (!gz_) return false;
             gzbuffer(gz_, 4u << 20);
+        } else if (gz_mode_) {
+            fp_ = fopen(path.c_str(), "rb");
+            if (!fp_) return false;
+            inflater_.open(fp_, 4u << 20);
         } else if (path == "-") {
             fp_ = stdin;
         } else {
@@ -244,6 +254,11 @@ class BlockSource {
         cv_.notify_all();
         return b;
     }
+    // after next() has returned an empty block: empty = clean end of input, otherwise what went wrong
+    std::string error() {
+        std::lock_guard<std::mutex> g(mu_);
+        return error_;
+    }
     void recycle(std::vector<char> &&b) {
         std::lock_guard<std::mutex> g(mu_);
         free_.push_back(std::move(b));
@@ -265,25 +280,39 @@ class BlockSource {
             b.resize(kFrontPad + block_bytes_);
             char *dst = b.data() + kFrontPad;
             size_t got = 0;
+            std::string trouble;
             while (got < block_bytes_) {
-                long r = gz_mode_ ? (long)gzread(gz_, dst + got, (unsigned)std::min<size_t>(block_bytes_ - got, 1u << 30))
-                                  : (long)fread(dst + got, 1, block_bytes_ - got, fp_);
+                long r;
+                if (gz_mode_ && use_zlib_) {
+                    r = (long)gzread(gz_, dst + got, (unsigned)std::min<size_t>(block_bytes_ - got, 1u << 30));
+                    if (r <= 0) {                      // 0 is also what a stream that ends too early gives: ask
+                        int en = 0;
+                        const char *msg = gzerror(gz_, &en);
+                        if (en != Z_OK && en != Z_STREAM_END) trouble = std::string("gz: ") + msg;
+                    }
+                } else if (gz_mode_) {
+                    r = inflater_.read(reinterpret_cast<uint8_t *>(dst + got), block_bytes_ - got);
+                    if (r < 0) trouble = inflater_.error();
+                } else r = (long)fread(dst + got, 1, block_bytes_ - got, fp_);
                 if (r <= 0) break;
                 got += (size_t)r;
             }
             b.resize(kFrontPad + got);
             std::lock_guard<std::mutex> g(mu_);
-            if (got == 0) {
+            if (!trouble.empty()) error_ = trouble;
+            if (got) ready_.push_back(std::move(b));
+            if (got == 0 || !trouble.empty()) {
                 eof_ = true;
                 cv_.notify_all();
                 return;
             }
-            ready_.push_back(std::move(b));
             cv_.notify_all();
         }
     }
-    bool gz_mode_ = false;
+    bool gz_mode_ = false, use_zlib_ = false;
     gzFile gz_ = nullptr;
+    GzInflater inflater_;
+    std::string error_;
     FILE *fp_ = nullptr;
     size_t block_bytes_ = 0;
     std::thread reader_;

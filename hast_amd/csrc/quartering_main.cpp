@@ -129,6 +129,10 @@ int main(int argc, char **argv) {
     for (;;) {
         std::vector<char> blk = src.next();
         const bool last = blk.empty();
+        if (last && !src.error().empty()) {
+            fprintf(stderr, "quartering_fastq: %s\n", src.error().c_str());
+            exit(2);
+        }
         constexpr size_t kPad = hast::BlockSource::kFrontPad;
         const char *data;
         size_t len;

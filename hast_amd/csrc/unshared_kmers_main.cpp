@@ -158,7 +158,10 @@ void ingest_stream(Gpu &gpu, int parent, int k, const std::vector<std::string> &
         }
         for (;;) {
             std::vector<char> b = src.next();
-            if (b.empty()) break;
+            if (b.empty()) {
+                if (!src.error().empty()) res.error = paths[i] + ": " + src.error();
+                break;
+            }
             const size_t n = b.size() - hast::BlockSource::kFrontPad;
             res.bytes += n;
             if (!parser.feed(b.data() + hast::BlockSource::kFrontPad, n)) res.error = paths[i] + ": " + parser.error();

@@ -1,0 +1,58 @@
+// Host-only driver for hast_amd/csrc/fast_inflate.h (test infrastructure): decodes the file given on the command line in
+// read() calls of `piece` bytes with an input buffer of `inbuf` bytes and writes the result to stdout;
+// with "-z" it uses zlib's gzread instead (the behaviour to match).  Exit 3 + message on a decoding error.
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../hast_amd/csrc/fast_inflate.h"
+
+int main(int argc, char **argv) {
+    bool use_zlib = false, quiet = false;
+    size_t piece = 1 << 20, inbuf = 1 << 20;
+    const char *path = nullptr;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-z")) use_zlib = true;
+        else if (!strcmp(argv[i], "-q")) quiet = true;
+        else if (!strcmp(argv[i], "-p")) piece = (size_t)atol(argv[++i]);
+        else if (!strcmp(argv[i], "-i")) inbuf = (size_t)atol(argv[++i]);
+        else path = argv[i];
+    }
+    std::vector<uint8_t> buf(piece);
+    size_t total = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (use_zlib) {
+        gzFile f = gzopen(path, "rb");
+        if (!f) return 2;
+        gzbuffer(f, 4u << 20);
+        int n;
+        while ((n = gzread(f, buf.data(), (unsigned)piece)) > 0) {
+            if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
+            total += (size_t)n;
+        }
+        if (n < 0) return 3;
+        gzclose(f);
+    } else {
+        FILE *f = fopen(path, "rb");
+        if (!f) return 2;
+        hast::GzInflater z;
+        z.open(f, inbuf);
+        long n;
+        while ((n = z.read(buf.data(), piece)) > 0) {
+            if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
+            total += (size_t)n;
+        }
+        if (n < 0) {
+            fprintf(stderr, "%s\n", z.error().c_str());
+            return 3;
+        }
+        fclose(f);
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "%zu bytes in %.3f s = %.1f MB/s\n", total, dt, total / dt / 1e6);
+    return 0;
+}

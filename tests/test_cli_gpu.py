@@ -112,6 +112,23 @@ def test_cli_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path, gz, threa
     assert len(got.stdout.splitlines()) > 1000
 
 
+def test_cli_gz_decoders_agree_and_damaged_gz_is_an_error(exe, golden_workdir, tmp_path):
+    """the in-tree gzip decoder vs zlib (HAST_INFLATE=zlib) on a golden case with gz reads; a truncated gz file must not
+    pass as a shorter input"""
+    import shutil
+    d = tmp_path / "gz"
+    shutil.copytree(golden_workdir / "rand_k21", d)
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "r1.fq.gz", "--read", "r2.fq.gz"]
+    a = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_INFLATE="zlib"))
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 100
+    whole = (d / "r2.fq.gz").read_bytes()
+    (d / "r2.fq.gz").write_bytes(whole[:len(whole) // 2])
+    for env in (None, dict(os.environ, HAST_INFLATE="zlib")):
+        r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 2 and r.stdout == b"", r.stderr[-300:]
+
+
 def test_cli_long_reads_stage01_semantics(exe, oracle_dir, tmp_path):
     """Reads far longer than one kernel row (segments + whole-read N skip by a pre-pass) mixed with short ones."""
     path = _write_case(tmp_path, 1500, seed=77, gz=False, long_reads=True)

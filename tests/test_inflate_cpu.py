@@ -1,0 +1,119 @@
+"""Host-only test of the ingest's gzip decoder (hast_amd/csrc/fast_inflate.h) against zlib: same bytes out for every kind of
+deflate block, member layout, buffer size and call size; errors for truncated / damaged input.  Built with ASAN + UBSAN."""
+import gzip
+import os
+import random
+import struct
+import subprocess
+import zlib
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("inflate") / "test_inflate"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "test_inflate.cpp"), "-lz"], check=True)
+    return str(exe)
+
+
+def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, flags=0, extra=b""):
+    if flags == 0:
+        c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+        return c.compress(data) + c.flush()
+    # hand-made header with optional fields (RFC 1952): FEXTRA 4, FNAME 8, FCOMMENT 16, FHCRC 2
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    raw = c.compress(data) + c.flush()
+    head = b"\x1f\x8b\x08" + bytes([flags]) + b"\x00\x00\x00\x00\x00\x03"
+    if flags & 4:
+        head += struct.pack("<H", len(extra)) + extra
+    if flags & 8:
+        head += b"file name.fq\x00"
+    if flags & 16:
+        head += b"a comment\x00"
+    if flags & 2:
+        head += struct.pack("<H", zlib.crc32(head) & 0xFFFF)
+    return head + raw + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def fastq(rng, n):
+    out = []
+    for i in range(n):
+        L = rng.choice([100, 150, 150, 37])
+        out.append("@V300R%09d#%d_%d_%d/1\n%s\n+\n%s\n" % (i, i % 1536, i % 977, i % 3, "".join(rng.choice("ACGT") for _ in range(L)),
+                                                           "".join(rng.choice("FFFFFF:,F#") for _ in range(L))))
+    return "".join(out).encode()
+
+
+def corpus():
+    rng = random.Random(5)
+    fq = fastq(rng, 6000)
+    rnd = bytes(rng.getrandbits(8) for _ in range(300_000))
+    rep = (b"ACGT" * 50 + b"\n") * 4000 + b"A" * 100_000 + bytes(range(256)) * 300
+    cases = {
+        "fastq_l6": member(fq), "fastq_l1": member(fq, 1), "fastq_l9": member(fq, 9),
+        "fastq_fixed": member(fq, 6, zlib.Z_FIXED), "fastq_huffman_only": member(fq, 6, zlib.Z_HUFFMAN_ONLY), "fastq_rle": member(fq, 6, zlib.Z_RLE),
+        "stored": member(fq[:200_000], 0), "random_l6": member(rnd), "random_l0": member(rnd, 0), "repeats": member(rep, 9),
+        "empty_member": member(b""), "one_byte": member(b"A"), "no_input": b"",
+        "members": member(fq[:70_000]) + member(b"") + member(fq[70_000:140_000], 1) + member(rnd[:5000], 0) + member(fq[140_000:], 9),
+        "header_fields": member(fq[:50_000], flags=4 | 8 | 16 | 2, extra=b"xx\x03\x00abc") + member(fq[50_000:90_000], flags=8),
+        "small_window": member(fq[:100_000], 6, wbits=16 + 9),
+        "trailing_garbage": member(fq[:30_000]) + b"\x00\x00\x00garbage that is not a member",
+        "not_gzip": fq[:40_000],
+    }
+    return cases, fq
+
+
+CASES, FQ = corpus()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_same_bytes_as_zlib(driver, tmp_path, name):
+    p = tmp_path / (name + ".gz")
+    p.write_bytes(CASES[name])
+    want = subprocess.run([driver, "-z", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0
+    for piece, inbuf in ((1 << 20, 1 << 20), (65536, 4096), (7, 64), (1, 333), (1000, 100)):
+        if piece < 100 and len(want.stdout) > 400_000:
+            continue
+        got = subprocess.run([driver, "-p", str(piece), "-i", str(inbuf), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, (name, piece, inbuf, got.stderr[-300:])
+        assert got.stdout == want.stdout, (name, piece, inbuf)
+
+
+def test_big_stream_and_python_gzip_writer(driver, tmp_path):
+    rng = random.Random(9)
+    data = fastq(rng, 40_000) + b"\x00" * 3_000_000 + fastq(rng, 20_000)
+    p = tmp_path / "big.gz"
+    with gzip.open(p, "wb", compresslevel=4) as f:
+        f.write(data)
+    got = subprocess.run([driver, "-p", "16777216", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0 and got.stdout == data
+
+
+def test_damaged_input_is_an_error(driver, tmp_path):
+    good = member(FQ[:120_000]) + member(FQ[120_000:200_000], 1)
+    rng = random.Random(3)
+    for cut in (5, 11, 100, len(good) // 3, len(good) - 9, len(good) - 1):
+        p = tmp_path / ("cut%d.gz" % cut)
+        p.write_bytes(good[:cut])
+        r = subprocess.run([driver, "-q", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 3, (cut, r.stderr)
+    flipped = 0
+    for _ in range(40):
+        b = bytearray(good)
+        i = rng.randrange(12, len(b))
+        b[i] ^= 1 << rng.randrange(8)
+        p = tmp_path / "flip.gz"
+        p.write_bytes(bytes(b))
+        r = subprocess.run([driver, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode in (0, 3)
+        assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr
+        if r.returncode == 0:                      # a flip can only go unnoticed if it did not change the data (header bytes)
+            assert r.stdout == FQ[:200_000]
+        else:
+            flipped += 1
+    assert flipped > 30
