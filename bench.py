@@ -48,9 +48,13 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (s00: 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (s00: 1)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["s00"], default="c3",
+                    help="c1/c2/c3/c5: stage-01 classification (the BASELINE metric); s00: stage-00 k-mer counting (SURVEY 8(f) #4)")
+    ap.add_argument("--genome", type=float, default=200e6, help="s00: genome length of the synthetic trio")
+    ap.add_argument("--coverage", type=float, default=30, help="s00: coverage per parent")
+    ap.add_argument("--table-gb", type=float, default=60, help="s00: size of the count table (0 = 85 %% of the free HBM)")
     ap.add_argument("--batch-reads", type=int, default=16_000_000)
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--read-len", type=int, default=150)
@@ -64,6 +68,9 @@ def main():
     ap.add_argument("--keys-per-hap", type=int, default=0, help="override the workload's key count per haplotype")
     ap.add_argument("--max-resident-gb", type=float, default=96.0, help="HBM budget for resident read batches")
     args = ap.parse_args()
+    s00 = args.workload == "s00"
+    args.steps = args.steps if args.steps is not None else (3 if s00 else 20)
+    args.warmup = args.warmup if args.warmup is not None else (1 if s00 else 3)
 
     # The contract is ONE JSON line on stdout.  Libraries chat on fd 1 (RCCL prints its version banner there under
     # NCCL_DEBUG=VERSION), so fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved stdout.
@@ -71,6 +78,8 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    if s00:
+        return bench_s00(args, real_stdout)
     import numpy as np
     import torch                      # first: libhast then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
@@ -272,6 +281,110 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+
+def bench_s00(args, real_stdout):
+    """Stage 00 (not the BASELINE metric): a "step" is one whole counting job -- every read of both parents
+    of a synthetic trio, resident in HBM, counted once into the emptied table (k_kc_count); value = bases counted per
+    second.  Roofline: HBM transactions; algorithmic bytes per window = 256 (one 128-B bucket line read + written back).
+    cpu_baseline = the oracle's counter (oracle/s00_oracle.c, one thread) on a sample of the same stream."""
+    import numpy as np
+    import hast_amd
+    from hast_amd import KcSynth, KmerCounter
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        sys.exit("bench.py --workload s00 measures one GPU (several GPUs split the key space: DESIGN.md section 9)")
+    hast_amd.build()
+    L, k = args.read_len, args.k
+    g = KcSynth(0, int(args.genome), L, 1, 20, 20)
+    n_reads = int(args.genome * args.coverage / L)
+    batch = min(args.batch_reads, 8_000_000)
+    n_batches = (n_reads + batch - 1) // batch
+    rec = L + 1
+    with hast_amd.Context(k) as ctx:
+        bufs = []
+        gen = KmerCounter(k, table_bytes=1 << 20)
+        for p in (1, 0):                                   # maternal first, as the reference script does
+            for b in range(n_batches):
+                n = min(batch, n_reads - b * batch)
+                d = ctx.alloc(n * rec)
+                gen.synth_device(g, p, b * batch, n, d)
+                bufs.append((p, d, n))
+        gen.sync()
+        sample = ctx.to_host(bufs[0][1], (min(bufs[0][2], 400_000) * rec,), np.uint8)
+        gen.close()
+        kc = KmerCounter(k, table_bytes=int(args.table_gb * (1 << 30)))
+        times = []
+        for it in range(args.warmup + args.steps):
+            kc.sync()
+            t0 = time.perf_counter()
+            kc.set_slice(0, 1)                             # empty table
+            for p, d, n in bufs:
+                kc.count_device(p, d, n * rec)
+            kc.sync()
+            if it >= args.warmup:
+                times.append(time.perf_counter() - t0)
+        t_count = sum(times) / len(times)
+        st = kc.stats()
+        t0 = time.perf_counter()
+        h = [kc.histo(p) for p in (0, 1)]
+        t_histo = time.perf_counter() - t0
+        bounds = [hast_amd.kc_find_bounds(x) for x in h]
+        t0 = time.perf_counter()
+        n_sel = [kc.select(p, max(1, bounds[p][2]), max(1, bounds[p][3])) for p in (0, 1)]
+        t_select = time.perf_counter() - t0
+        kc.release_table()
+        t0 = time.perf_counter()
+        n_sorted = [kc.selection_sort(p) for p in (0, 1)]
+        text0 = kc.selection_text(0, 0, min(n_sorted[0], 1 << 20))
+        t_sort = time.perf_counter() - t0
+        kc.close()
+    bases = 2 * n_reads * L
+    windows = 2 * n_reads * (L - k + 1)
+    alg_bytes = 2 * n_reads * (rec + (L - k + 1) * 256)
+    assert st["total"][0] + st["total"][1] <= windows
+    out = {
+        "metric": "parental read-bp/sec counted into the k-mer table at k=%d, %dbp reads" % (k, L),
+        "value": bases / t_count, "unit": "bp/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_count * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "S00 synthetic trio: %.0f Mbp genome, %gx coverage per parent, %d-bp reads, K=%d" % (args.genome / 1e6, args.coverage, L, k),
+                   "reads_per_parent": n_reads, "batch_reads": batch, "table_slots": st["capacity"], "table_gb": st["capacity"] * 16 / 2**30,
+                   "load_factor": st["keys"] / st["capacity"]},
+        "seconds": {"count": t_count, "count_min": min(times), "count_max": max(times), "histo_x2": t_histo, "select_x2": t_select, "sort_format": t_sort},
+        "kmers": {"counted": list(st["total"]), "distinct": list(st["distinct"]), "union": st["keys"], "bounds": [list(b) for b in bounds],
+                  "selected": n_sel, "first_row": text0[:k].decode()},
+        "roofline": {"bound": "hbm", "kernel": "k_kc_count", "achieved": alg_bytes / t_count / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / t_count / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                     "windows_per_s": windows / t_count},
+    }
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic_s00.json")
+    if os.path.exists(tf):                       # measured HBM traffic of the count kernel (rocprofv3 PMC), scaled per read
+        t = json.load(open(tf))
+        rf = out["roofline"]
+        rf["traffic"] = t["hbm_bytes_per_read"] * 2 * n_reads
+        rf["traffic_source"] = t["source"]
+        tx = (t["hbm_read_requests_per_read"] + t["hbm_write_requests_per_read"]) * 2 * n_reads / t_count
+        rf["hbm_transactions_per_s"] = tx
+        rf["hbm_line_rate_ceiling"] = 48e9      # tools/hbm_randread: random 64-B lines per second this part sustains
+        rf["hbm_line_rate_frac"] = tx / 48e9
+    if args.cpu_seconds > 0:
+        import subprocess
+        from tests import oracle_binding
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL, check=True)
+        o = oracle_binding.load(os.path.join(ROOT, "oracle", "liboracle.so"))
+        c = o.ho_s00_new(k)
+        done, t0 = 0, time.perf_counter()
+        step = 20_000 * rec
+        while done < sample.size and time.perf_counter() - t0 < args.cpu_seconds:
+            part = sample[done:done + step]
+            o.ho_s00_add_stream(c, 1, part.ctypes.data, part.size)
+            done += part.size
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": done / rec * L / dt, "unit": "bp/s", "cores": 1, "kind": "port",
+                               "sample": "first %d reads of the maternal stream (%.1f s), oracle/s00_oracle.c -O2" % (done // rec, dt)}
+        o.ho_s00_free(c)
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
 
 
 def _committed_traffic(args, R):

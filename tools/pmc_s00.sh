@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for the stage-00 count kernel (run through gpurun from the repo root): kernel stats, then PMC passes
-# (each in its own run, --kernel-trace only) of tools/bench_s00.py on a 50-Mbp trio with the table at load factor ~0.5.
+# (each in its own run, --kernel-trace only) of bench.py --workload s00 on a 50-Mbp trio with the table at load factor ~0.5.
 set -u
 TAG=${1:-s00}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python3 tools/bench_s00.py --genome 50e6 --table-gb 9.5 --cpu-seconds 0"
+CMD="python3 bench.py --workload s00 --genome 50e6 --table-gb 9.5 --cpu-seconds 0 --steps 1 --warmup 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats_bench.json 2> $OUT/stats_bench.err
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_ATOMIC_sum TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum" \
             "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES" \
