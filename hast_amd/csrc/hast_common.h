@@ -93,6 +93,22 @@ HAST_HD uint32_t bucket_of(uint32_t minh, uint64_t key, uint32_t nbuckets) {
 HAST_HD uint32_t home_bucket(uint64_t key, int k, int m, uint32_t nbuckets) {
     return bucket_of(minimizer_hash(key, k, m), key, nbuckets);
 }
+// Probe sequence of a key: its home bucket (by minimizer), then -- only when that one is full -- a bucket chosen by the
+// KEY's own hash, then the buckets after that one.  The jump matters for minimizers that very many keys share (in real
+// genomes: poly-A and other low-complexity m-mers): walking on from the home bucket would put all their keys into ONE run
+// of full buckets that every one of those keys has to cross (quadratic); after the jump they are spread over the whole
+// table and a lookup that overflows costs one more random line.
+HAST_HD uint32_t overflow_bucket(uint64_t key, uint32_t nbuckets) {
+    const uint32_t h = (uint32_t)((key * 0xD6E8FEB86659FD93ull) >> 32);
+    return (uint32_t)(((uint64_t)h * nbuckets) >> 32);
+}
+// bucket after `b` in the probe sequence of `key`; `step` = number of buckets probed so far (>= 1)
+HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t nbuckets) {
+#ifndef HAST_LINEAR_OVERFLOW           // (experiments only: the old walk-on-from-home behaviour)
+    if (step == 1) return overflow_bucket(key, nbuckets);
+#endif
+    return b + 1 == nbuckets ? 0 : b + 1;
+}
 
 // ---- synthetic workload ----------------------------------------------------------
 HAST_HD uint64_t splitmix64(uint64_t x) {

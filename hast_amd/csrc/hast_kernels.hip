@@ -51,7 +51,7 @@ __device__ __forceinline__ bool table_insert(uint64_t *slots, const TableGeom g,
                 break;
             }
         }
-        b = (b + 1 == nbuckets) ? 0 : b + 1;
+        b = next_bucket(b, probe + 1, key, nbuckets);
     }
     return false;
 }
@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned long long *table_find(uint64_t *tab, const T
             else if (slot_has_key(cur, key, g.wide)) return &bs[i];
         }
         if (any_empty) return nullptr;
-        b = (b + 1 == nbuckets) ? 0 : b + 1;
+        b = next_bucket(b, probe + 1, key, nbuckets);
     }
     return nullptr;
 }
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
 #pragma unroll
                         for (int l = 0; l < kNLd; ++l) s2[l] = u64x2{kEmptySlot, kEmptySlot};
                         if (pending) {
-                            b = (b + 1 == nb) ? 0 : b + 1;
+                            b = next_bucket(b, guard + 1, WIDE ? kq : (kq >> 2), nb);
 #pragma unroll
                             for (int l = 0; l < kNLd; ++l) s2[l] = tab[(size_t)b * kPieces + l * kLPB];
                         }

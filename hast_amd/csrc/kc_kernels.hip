@@ -21,10 +21,10 @@ namespace hast {
 
 constexpr int kKcThreads = 256;
 
-// find-or-insert `key` starting at bucket b, then count it for `parent`.  Slots never change once written and fill in
+// find-or-insert `key` starting at bucket b, then add `add` to its count for `parent`.  Slots never change once written and fill in
 // order, so a (possibly stale) plain read can only show a PREFIX of the real bucket: a key seen is there for good, and
 // "not seen" is settled by the compare-and-swap on the first slot that looked empty.
-__device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, uint32_t b, uint64_t key, uint32_t parent) {
+__device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, uint32_t b, uint64_t key, uint32_t parent, uint32_t add) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (uint32_t probe = 0; probe < nb; ++probe) {
         unsigned long long *bk = table + (size_t)b * kKcBucketWords;
@@ -51,10 +51,10 @@ __device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, 
             if (old == kEmptySlot || old == key) idx = i;
         }
         if (idx >= 0) {
-            atomicAdd(cnt + idx, 1u);
+            atomicAdd(cnt + idx, add);
             return true;
         }
-        b = (b + 1 == nb) ? 0 : b + 1;                       // bucket full: next bucket (same 4-KB page mostly)
+        b = next_bucket(b, probe + 1, key, nb);              // bucket full: jump to the key's own overflow bucket, then walk on
     }
     return false;
 }
@@ -129,12 +129,17 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
         __syncthreads();
 
         // ---- B: one lane per window --------------------------------------------------------------------
+        // Consecutive windows with the SAME key (homopolymers, short tandem repeats of period 1) are counted by the first
+        // of them with the run length: real reads hold poly-A k-mers by the million, and every one of them would
+        // otherwise be an atomic on the same counter.
         const uint64_t left = a.n_starts - t0;
         const uint32_t nwin = left < TB ? (uint32_t)left : TB;
-        for (uint32_t p = tid; p < nwin; p += kKcThreads) {
+        const uint32_t lane = tid & 63;
+        for (uint32_t base = tid - lane; base < nwin; base += kKcThreads) {       // wave-uniform trip count
+            const uint32_t p = base + lane;
             const uint32_t *iw = s_inv + (p >> 5);
             const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
-            if ((bits >> (64 - K)) != 0) continue;                   // some byte of the window is not a base
+            bool valid = p < nwin && (bits >> (64 - K)) == 0;       // every byte of the window is a base
             const uint64_t key = kmer_canon(window_bits(s_pack, p, kshift), K);
             uint32_t mn = s_mh[p];
             if (WT) {
@@ -143,9 +148,17 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             } else {
                 for (uint32_t j = 1; j < W; ++j) mn = min(mn, s_mh[p + j]);
             }
-            if (a.n_slices > 1 && kc_slice_of(mn, a.n_slices) != a.slice) continue;
-            if (!kc_bump(a.table, a.nbuckets, bucket_of_minhash(mn, a.nbuckets), key, a.parent)) atomicOr(a.err, 1u);
-            ++counted;
+            if (a.n_slices > 1 && kc_slice_of(mn, a.n_slices) != a.slice) valid = false;
+            const uint64_t prev_key = __shfl_up(key, 1, 64);
+            const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
+            const bool follower = valid && lane > 0 && prev_valid && prev_key == key;
+            const unsigned long long fmask = __ballot(follower);
+            if (valid) ++counted;
+            if (!valid || follower) continue;
+            // run length = 1 + the followers right after this lane
+            const unsigned long long after = lane == 63 ? 0ull : (fmask >> (lane + 1));
+            const uint32_t run = 1 + (uint32_t)__builtin_ctzll(~after);
+            if (!kc_bump(a.table, a.nbuckets, bucket_of_minhash(mn, a.nbuckets), key, a.parent, run)) atomicOr(a.err, 1u);
         }
         __syncthreads();
     }

@@ -620,3 +620,51 @@ def test_poly_a_key_zero_and_hot_read(built, oracle_lib):
         got = ctx.counts_read(len(seqs))
         assert got[0][0] == 0 and got[1][0] == 0 and got[0][3] > 0
     oracle_lib.ho_free(oc)
+
+
+def test_keys_piled_on_one_minimizer(built, oracle_lib):
+    """Real genomes have m-mers that very many k-mers share (poly-A, low complexity): thousands of keys whose minimizer
+    is A^16, and reads full of windows with that minimizer.  Results must match the oracle and the run must not crawl
+    (overflowing keys jump to a bucket chosen by the key itself instead of piling up behind the home bucket)."""
+    import time
+    k, n_bc = 21, 16
+    rng = random.Random(77)
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    def kmer_with_poly_a():
+        left = rng.randint(0, 5)
+        s = [rng.choice("ACGT") for _ in range(left)] + ["A"] * 16 + [rng.choice("ACGT") for _ in range(5 - left)]
+        return "".join(s)
+    texts = [[kmer_with_poly_a() for _ in range(20000)] + ["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(3000)] for _ in (0, 1)]
+    keys = [np.array(sorted({hast_amd.canon_kmer(t.encode()) for t in ts}), dtype=np.uint64) for ts in texts]
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    seqs = []
+    for i in range(30000):
+        s = [rng.choice("ACGT") for _ in range(150)]
+        if i % 3:
+            o = rng.randint(0, 100)
+            s[o:o + 30] = "A" * 30                               # ~40 windows of this read have the A^16 minimizer
+        if i % 5 == 0:
+            o = rng.randint(0, 129)
+            s[o:o + k] = rng.choice(texts[i & 1])
+        seqs.append("".join(s).encode())
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    ids = np.array([rng.randrange(n_bc) for _ in seqs], dtype=np.uint32)
+    for lf in (0.2, 0.8):
+        with hast_amd.Context(k) as ctx:
+            ctx.table_reserve(int(keys[0].size + keys[1].size), lf)
+            t0 = time.time()
+            ctx.table_insert_keys(0, keys[0])
+            ctx.table_insert_keys(1, keys[1])
+            assert ctx.table_sizes() == (keys[0].size, keys[1].size)
+            ctx.counts_resize(n_bc)
+            ctx.classify_batch(bases, off, ids, 150)
+            got = ctx.counts_read(n_bc)
+            dt = time.time() - t0
+        exp = oracle_counts(oracle_lib, oc, bases, off, ids, n_bc)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)
+        assert int(exp[0].sum()) > 1000
+        assert dt < 5, "piled-up keys: %.1f s" % dt
+    oracle_lib.ho_free(oc)

@@ -200,6 +200,29 @@ def test_streams_longer_than_a_staging_buffer_and_device_input(built, oracle_lib
     o.ho_s00_free(c)
 
 
+def test_kmers_piled_on_one_minimizer(built, oracle_lib):
+    """poly-A cores with random flanks: hundreds of thousands of distinct k-mers share the minimizer A^16"""
+    import time
+    o, k = oracle_lib, 21
+    rng = np.random.default_rng(5)
+    n, L = 150_000, 100
+    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L + 1))]
+    reads[:, L] = 10
+    reads[rng.random(n) < 0.4, 30:70] = ord("A")
+    data = reads.reshape(-1).copy()
+    c = oracle_table(o, k, [(0, data), (1, data[: data.size // 3])])
+    with KmerCounter(k, table_bytes=1 << 30) as kc:
+        t0 = time.time()
+        kc.count(0, data)
+        kc.count(1, data[: data.size // 3])
+        kc.sync()
+        dt = time.time() - t0
+        check_against_oracle(o, kc, c, k, None)
+        assert kc.select(0, 1, 3) == oracle_select(o, c, 0, 1, 3).size
+    assert dt < 5, "piled-up k-mers: %.1f s" % dt
+    o.ho_s00_free(c)
+
+
 # ---- the program ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case,run", golden_cases("s00"))
 def test_unshared_kmers_matches_reference_script_golden(built, golden_workdir, tmp_path, case, run):
