@@ -612,15 +612,15 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
     a.mh_stride = read_len >= (uint32_t)c->m ? read_len - c->m + 1 : 0;
     a.w64 = (read_len + 31) / 32;
-    // Reads per tile: at most what fits ~19.5 KB of LDS (8 workgroups per CU) and at most 64; among the
+    // Reads per tile: at most what fits ~20.5 KB of LDS (7 workgroups per CU by LDS; registers allow 5) and at most 64; among the
     // candidates take the one whose windows fill the waves' 64-window blocks best (a workgroup walks
     // 4 waves x 2 blocks per iteration: 150-bp reads => 31 reads = 4030 windows = 63 of 64 block slots).
     // The m-mer hash array is padded by W entries so window-min reads past a read's last window stay in bounds.
     const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
     const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 +
                             (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
-    const size_t pad = (size_t)wlen * 4 + 64 + 64 + 16;
-    static const size_t lds_budget = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)19968; }();
+    const size_t pad = (size_t)wlen * 4 + 64 + 64 + 16 + 64 * 16;          // + the commit cache (kCommitSlots x 16 B)
+    static const size_t lds_budget = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)20992; }();
     const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (lds_budget - pad) / per_read));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
