@@ -46,6 +46,10 @@ struct hast_kc {
     unsigned long long *d_histo = nullptr;
     KcStage stage[2];
     unsigned turn = 0;
+    // early word on a full table: the error word is copied to pinned memory every few chunks and looked at without waiting
+    uint32_t *h_err = nullptr;
+    hipEvent_t err_ev = nullptr;
+    bool err_pending = false;
     std::vector<uint64_t> sel[2];              // print keys selected so far (host side, unsorted)
     unsigned long long *d_sorted[2] = {nullptr, nullptr};
     size_t n_sorted[2] = {0, 0};
@@ -113,6 +117,9 @@ hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out)
     bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
     bail(hipMalloc(&c->d_histo, (HAST_KC_HISTO_HIGH + 2) * sizeof(unsigned long long)), "hipMalloc(histo)");
     for (auto &s : c->stage) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+    bail(hipEventCreateWithFlags(&c->err_ev, hipEventDisableTiming), "hipEventCreate");
+    bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc(err)");
+    if (c->h_err) *c->h_err = 0;
     if (st == HAST_OK) {
         size_t free_b = 0, total_b = 0;
         bail(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
@@ -144,6 +151,8 @@ void hast_kc_destroy(hast_kc *c) {
         if (s.d) (void)hipFree(s.d);
         if (s.done) (void)hipEventDestroy(s.done);
     }
+    if (c->err_ev) (void)hipEventDestroy(c->err_ev);
+    if (c->h_err) (void)hipHostFree(c->h_err);
     for (auto *p : c->d_sorted)
         if (p) (void)hipFree(p);
     if (c->d_table) (void)hipFree(c->d_table);
@@ -164,6 +173,11 @@ hast_status hast_kc_set_slice(hast_kc *c, uint32_t slice, uint32_t n_slices) {
     KC_TRY(launch_kc_clear(c->d_table, c->nbuckets, c->stream));
     KC_TRY(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream));
     KC_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream));
+    if (c->err_pending) {                          // a copy of the old word may still be in flight
+        KC_TRY(hipEventSynchronize(c->err_ev));
+        c->err_pending = false;
+    }
+    *c->h_err = 0;
     return HAST_OK;
 }
 
@@ -203,6 +217,12 @@ hast_status hast_kc_count(hast_kc *c, int parent, const uint8_t *bytes, size_t n
     if (hast_status st = check_parent(parent)) return st;
     if (n_bytes && !bytes) return set_error(HAST_ERR_INVALID, "bytes is null");
     const size_t overlap = (size_t)c->k - 1, chunk = kStageBytes - 64;
+    // a table that is already full makes the rest of the pass pointless: say so as soon as the device's word has arrived
+    if (c->err_pending && hipEventQuery(c->err_ev) == hipSuccess) {
+        c->err_pending = false;
+        if (*c->h_err & 1) return set_error(HAST_ERR_TABLE_FULL, "k-mer count table full (%u buckets of %d keys, slice %u of %u): use more slices",
+                                            c->nbuckets, kKcSlots, c->slice, c->n_slices);
+    }
     for (size_t at = 0; at < n_bytes; at += chunk) {
         KcStage &s = c->stage[c->turn++ & 1];
         if (!s.h) {
@@ -221,6 +241,11 @@ hast_status hast_kc_count(hast_kc *c, int parent, const uint8_t *bytes, size_t n
         KC_TRY(hipEventRecord(s.done, c->stream));
         s.busy = true;
     }
+    if (!c->err_pending && (c->turn & 7) == 0) {
+        KC_TRY(hipMemcpyAsync(c->h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        KC_TRY(hipEventRecord(c->err_ev, c->stream));
+        c->err_pending = true;
+    }
     return HAST_OK;
 }
 
@@ -230,6 +255,7 @@ hast_status hast_kc_sync(hast_kc *c) {
     KC_TRY(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     KC_TRY(hipStreamSynchronize(c->stream));
     for (auto &s : c->stage) s.busy = false;
+    c->err_pending = false;
     if (e & 1) return set_error(HAST_ERR_TABLE_FULL, "k-mer count table full (%u buckets of %d keys, slice %u of %u): use more slices",
                                 c->nbuckets, kKcSlots, c->slice, c->n_slices);
     return HAST_OK;

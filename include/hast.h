@@ -225,7 +225,8 @@ hast_stream hast_kc_stream(hast_kc *);
 hast_status hast_kc_set_slice(hast_kc *, uint32_t slice, uint32_t n_slices);
 /* Count the k-mers of a byte stream for one parent.  The stream is a sequence of records' bases with at least one
  * non-base byte (e.g. '\n') between records; windows start at [0, n_bytes).  _device: bytes already in HBM,
- * asynchronous on the context's stream.  Host variant: copies through pinned staging, double-buffered. */
+ * asynchronous on the context's stream.  Host variant: copies through pinned staging, double-buffered; it may
+ * return HAST_ERR_TABLE_FULL early (the device's word is polled without waiting), hast_kc_sync reports it for sure. */
 hast_status hast_kc_count_device(hast_kc *, int parent, const uint8_t *d_bytes, size_t n_bytes);
 hast_status hast_kc_count(hast_kc *, int parent, const uint8_t *bytes, size_t n_bytes);
 /* wait for all counting submitted so far; HAST_ERR_TABLE_FULL when some k-mer found no slot */
