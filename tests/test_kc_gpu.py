@@ -200,6 +200,54 @@ def test_streams_longer_than_a_staging_buffer_and_device_input(built, oracle_lib
     o.ho_s00_free(c)
 
 
+def test_randomized_configurations_vs_oracle(built, oracle_lib):
+    """fuzz: K, stream make-up, table size (load factor up to ~0.95), slices, call pattern; HAST_FUZZ_SEED / HAST_FUZZ_ITERS"""
+    o = oracle_lib
+    rng = random.Random(int(os.environ.get("HAST_FUZZ_SEED", "20261004")))
+    for it in range(int(os.environ.get("HAST_FUZZ_ITERS", "24"))):
+        k = rng.choice([1, 2, 7, 11, 15, 16, 17, 21, 21, 25, 31, 32])
+        n = rng.choice([0, 1, k - 1, k, 1000, 40_000, 200_000])
+        streams = [(p, random_stream(rng, max(n, 1), k)[:n]) for p in (0, 1, rng.randrange(2))]
+        if rng.random() < 0.3 and n > 100:                          # a popular minimizer + a hot k-mer
+            s = streams[0][1]
+            s[: n // 2] = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(it).integers(0, 4, n // 2)]
+            s[np.arange(0, n // 2 - 40, 97)[:, None] + np.arange(20, 20 + rng.choice([16, 30]))] = ord("A")
+        c = oracle_table(o, k, streams)
+        n_keys = max(1, sum(1 for _ in range(1)) * (o.ho_s00_distinct(c, 0) + o.ho_s00_distinct(c, 1)))
+        lf = rng.choice([0.05, 0.5, 0.9, 0.95])
+        n_slices = rng.choice([1, 1, 2, 5])
+        table_bytes = max(64 * 128, int(n_keys / lf / n_slices * 1.3) // 8 * 128)
+        lo, hi = rng.choice([(1, 1 << 31), (1, 1), (2, 40), (3, 3)])
+        with KmerCounter(k, table_bytes=table_bytes) as kc:
+            h = [np.zeros(hast_amd.KC_HISTO_HIGH + 2, dtype=np.uint64) for _ in (0, 1)]
+            try:
+                for sl in range(n_slices):
+                    kc.set_slice(sl, n_slices)
+                    for p, data in streams:
+                        if rng.random() < 0.5 and data.size > 10:   # one stream in two calls must be cut at a separator...
+                            cut = int(np.argmax(data[data.size // 2:] == 10)) + data.size // 2
+                            if data[cut] == 10:
+                                kc.count(p, data[:cut + 1])
+                                kc.count(p, data[cut + 1:])
+                                continue
+                        kc.count(p, data)
+                    kc.sync()
+                    for p in (0, 1):
+                        kc.histo(p, into=h[p])
+                        kc.select(p, lo, hi)
+            except hast_amd.HastError as e:                         # uneven slices can overflow a tight table: that must be SAID
+                assert e.status == 5, e
+                continue
+            kc.release_table()
+            for p in (0, 1):
+                assert np.array_equal(h[p], oracle_histo(o, c, p)), (it, k, p)
+                want = oracle_select(o, c, p, lo, hi)
+                nsel = kc.selection_sort(p)
+                assert nsel == want.size, (it, k, p, lf, n_slices)
+                assert kc.selection_text(p, 0, nsel) == key_text(o, want, k), (it, k, p)
+        o.ho_s00_free(c)
+
+
 def test_kmers_piled_on_one_minimizer(built, oracle_lib):
     """poly-A cores with random flanks: hundreds of thousands of distinct k-mers share the minimizer A^16"""
     import time
