@@ -198,6 +198,7 @@ def main():
     # ---- timed region: K steps + ONE all-reduce + D2H of the counters -------------------------------
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ctx.classify_timing(args.steps)          # HIP events around k_classify and k_commit_votes, on the launch stream, inside the library
     barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -226,7 +227,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    call_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]           # the whole hast_classify_device call
+    kern_ms, commit_ms = ctx.classify_times(args.steps)                # k_classify alone / k_commit_votes alone
+    ctx.classify_timing(0)
+    if len(kern_ms) != args.steps:
+        kern_ms, commit_ms = call_ms, [0.0] * len(call_ms)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     total_bp = world * args.steps * R * L
@@ -253,7 +258,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": kern_avg_ms,
-                         "kernel_ms_min": min(kern_ms), "kernel_ms_max": max(kern_ms)},
+                         "kernel_ms_min": min(kern_ms), "kernel_ms_max": max(kern_ms),
+                         "commit_kernel_ms_avg": sum(commit_ms) / len(commit_ms), "call_ms_avg": sum(call_ms) / len(call_ms)},
             "hits": {"c0": int(ch[:, 0].sum(dtype=np.uint64)), "c1": int(ch[:, 1].sum(dtype=np.uint64)),
                      "neg_reads": int(ch[:, 2].sum(dtype=np.uint64))},
         }

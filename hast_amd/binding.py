@@ -59,6 +59,8 @@ ABI_SYMBOLS = {
     "hast_counts_zero": (C.c_int, [vp, vp]),
     "hast_counts_read": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
     "hast_counts_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "hast_classify_timing": (C.c_int, [vp, C.c_int]),
+    "hast_classify_times": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "hast_classify_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
     "hast_classify_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
     "hast_classify_perread_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp]),
@@ -337,6 +339,14 @@ class Context:
                                            C.c_void_p(d_offsets) if d_offsets else None, read_len,
                                            C.c_void_p(d_barcode_ids) if d_barcode_ids else None,
                                            C.c_void_p(d_votes) if d_votes else None, n_reads, stream))
+
+    def classify_timing(self, n_slots):
+        _ck(self._lib.hast_classify_timing(self._h, n_slots))
+
+    def classify_times(self, max_n=4096):
+        a, b, n = (C.c_float * max_n)(), (C.c_float * max_n)(), C.c_int()
+        _ck(self._lib.hast_classify_times(self._h, a, b, max_n, C.byref(n)))
+        return list(a[:n.value]), list(b[:n.value])
 
     def classify_batch(self, bases: np.ndarray, offsets: np.ndarray, ids: np.ndarray, max_read_len):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

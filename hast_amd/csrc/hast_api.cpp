@@ -73,6 +73,12 @@ struct hast_ctx {
     // per-read mode: segment table of long reads
     void *d_seg = nullptr;
     size_t seg_bytes = 0;
+    // optional kernel timing (hast_classify_timing): ring of event triplets {before k_classify, between, after k_commit_votes}
+    std::vector<hipEvent_t> t_ev;
+    size_t t_slots = 0, t_next = 0, t_count = 0;
+    // per-read votes of the last barcode-mode launch when the caller gave no buffer for them
+    uint32_t *d_votes_scratch = nullptr;
+    size_t votes_bytes = 0;
 };
 
 namespace {
@@ -214,6 +220,8 @@ void hast_ctx_destroy(hast_ctx *c) {
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_seg) (void)hipFree(c->d_seg);
+    if (c->d_votes_scratch) (void)hipFree(c->d_votes_scratch);
+    for (hipEvent_t e : c->t_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -599,8 +607,24 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.lens = d_lens;
     a.seg_read = d_seg_read;
     a.strict = strict;
-    a.barcode_ids = d_barcode_ids;
-    a.votes = d_votes;
+    // The kernel only writes per-read votes; the per-barcode bookkeeping runs as a kernel of its own afterwards (its random
+    // read-modify-writes cost 4x as much when they are interleaved with the probes' reads).  Without a votes buffer from
+    // the caller the votes go to library scratch.
+    uint32_t *votes_buf = d_votes;
+    if (d_barcode_ids && !votes_buf) {
+        const size_t need = n_reads * 2 * sizeof(uint32_t);
+        if (c->votes_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(s ? (hipStream_t)s : c->stream));
+            if (c->d_votes_scratch) HIP_TRY(hipFree(c->d_votes_scratch));
+            c->d_votes_scratch = nullptr;
+            c->votes_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_votes_scratch), need + need / 8));
+            c->votes_bytes = need + need / 8;
+        }
+        votes_buf = c->d_votes_scratch;
+    }
+    a.barcode_ids = nullptr;
+    a.votes = votes_buf;
     a.counts = c->d_counts;
     a.slots = c->d_slots;
     a.n_reads = n_reads;
@@ -612,15 +636,15 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
     a.mh_stride = read_len >= (uint32_t)c->m ? read_len - c->m + 1 : 0;
     a.w64 = (read_len + 31) / 32;
-    // Reads per tile: at most what fits ~20.5 KB of LDS (7 workgroups per CU by LDS; registers allow 5) and at most 64; among the
+    // Reads per tile: at most what fits ~19.5 KB of LDS (8 workgroups per CU) and at most 64; among the
     // candidates take the one whose windows fill the waves' 64-window blocks best (a workgroup walks
     // 4 waves x 2 blocks per iteration: 150-bp reads => 31 reads = 4030 windows = 63 of 64 block slots).
     // The m-mer hash array is padded by W entries so window-min reads past a read's last window stay in bounds.
     const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
     const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 +
                             (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
-    const size_t pad = (size_t)wlen * 4 + 64 + 64 + 16 + 64 * 16;          // + the commit cache (kCommitSlots x 16 B)
-    static const size_t lds_budget = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)20992; }();
+    const size_t pad = (size_t)wlen * 4 + 64 + 64 + 16;
+    static const size_t lds_budget = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)19968; }();
     const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (lds_budget - pad) / per_read));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
@@ -646,7 +670,17 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
     a.tile_queue = c->d_cnt + 3;
     HIP_TRY(hipMemsetAsync(a.tile_queue, 0, sizeof(unsigned long long), s ? (hipStream_t)s : c->stream));
-    HIP_TRY(launch_classify(a, grid, smem, s ? (hipStream_t)s : c->stream));
+    hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    hipEvent_t *ev = c->t_slots ? &c->t_ev[3 * (c->t_next % c->t_slots)] : nullptr;
+    if (ev) HIP_TRY(hipEventRecord(ev[0], hs));
+    HIP_TRY(launch_classify(a, grid, smem, hs));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], hs));
+    if (d_barcode_ids) HIP_TRY(launch_commit_votes(votes_buf, d_barcode_ids, c->d_counts, nullptr, n_reads, hs));
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev[2], hs));
+        c->t_next++;
+        c->t_count = std::min(c->t_count + 1, c->t_slots);
+    }
     return HAST_OK;
 }
 
@@ -655,6 +689,33 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
                                       hipStream_t hs);
 static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
 static constexpr uint32_t kLongRead = 4096;      // longer reads (with offsets) go through the segmented path
+
+hast_status hast_classify_timing(hast_ctx *c, int n_slots) {
+    if (hast_status st = use(c)) return st;
+    for (hipEvent_t e : c->t_ev) (void)hipEventDestroy(e);
+    c->t_ev.clear();
+    c->t_slots = c->t_next = c->t_count = 0;
+    if (n_slots <= 0) return HAST_OK;
+    c->t_ev.resize(3 * (size_t)n_slots);
+    for (hipEvent_t &e : c->t_ev) HIP_TRY(hipEventCreate(&e));
+    c->t_slots = (size_t)n_slots;
+    return HAST_OK;
+}
+hast_status hast_classify_times(hast_ctx *c, float *classify_ms, float *commit_ms, int max, int *n_out) {
+    if (hast_status st = use(c)) return st;
+    if (!n_out || (max > 0 && (!classify_ms || !commit_ms))) return fail(HAST_ERR_INVALID, "null argument");
+    int n = 0;
+    const size_t first = c->t_next - c->t_count;
+    for (size_t i = 0; i < c->t_count && n < max; ++i, ++n) {
+        hipEvent_t *ev = &c->t_ev[3 * ((first + i) % c->t_slots)];
+        HIP_TRY(hipEventSynchronize(ev[2]));
+        HIP_TRY(hipEventElapsedTime(&classify_ms[n], ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&commit_ms[n], ev[1], ev[2]));
+    }
+    *n_out = n;
+    c->t_count = 0;
+    return HAST_OK;
+}
 
 hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  uint32_t read_len, const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads,

@@ -199,13 +199,12 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 //               slot is taken (slots fill in order), so "no match and slot.y of some lane empty"
 //               ends the probe; full buckets without a match (rare at load factor 0.25) take the
 //               chain walk.  Hits (about 1 % of windows) go to per-read LDS counters.
-//   C  commit : one lane per read does ONE global atomic on the read's barcode record
-//               ({c0,c1} as a single u64 add, or neg++; classify.cpp:203-208).
+//   C  votes  : one lane per read stores the read's {vote0, vote1} (8 B, coalesced).  The per-barcode bookkeeping
+//               (classify.cpp:203-208) is a kernel of its own, k_commit_votes: random read-modify-writes that are
+//               interleaved with the probes' random reads cost 4x what they cost on their own (DRAM bus turnaround;
+//               tools/atomics_probe.hip: 16M updates beside 640M line reads +2.7 ms, alone 0.7 ms).
 // ------------------------------------------------------------------------------------------
 constexpr int kThreads = 256;
-constexpr int kCommitSlots = 64;              // LDS commit cache entries (power of two), 16 B each: see k_classify
-constexpr uint32_t kCommitEpoch = 64;         // tiles between two write-outs of the cache
-constexpr uint32_t kNoBarcode = 0xFFFFFFFFu;
 #ifndef HAST_MINWAVES
 #define HAST_MINWAVES 5   // 96 VGPRs: 5 waves/SIMD = 5 workgroups per CU (measured best of 4/5/6/8 with the tile queue)
 #endif
@@ -238,14 +237,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
     const uint32_t MS = a.mh_stride;                                 // m-mer positions per read (stride)
     unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);            // next tile of this workgroup
-    // commit cache (barcode mode): kCommitSlots x {votes u64, neg u32, id u32}.  Real stLFR data has barcodes that
-    // own a large share of the reads ("0_0_0" = no barcode: 10-20 %); one global atomic per read on their record would
-    // serialise in the memory system (measured: 16 barcodes -> 3x, 1 barcode -> 12x the kernel time).  Reads whose barcode
-    // holds a slot are summed in LDS and written out every kCommitEpoch tiles; everyone else goes straight to HBM.
-    unsigned long long *s_cvote = s_tile + 2;                                              // [kCommitSlots]
-    uint32_t *s_cneg = reinterpret_cast<uint32_t *>(s_cvote + kCommitSlots);               // [kCommitSlots]
-    uint32_t *s_cid = s_cneg + kCommitSlots;                                               // [kCommitSlots]
-    unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(s_cid + kCommitSlots);   // [TR][WS]
+    unsigned long long *s_pack = s_tile + 2;                                               // [TR][WS]
     unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
     unsigned long long *s_off = s_vote + TR;                                               // [TR]
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
@@ -274,22 +266,6 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     // Tiles are handed out by a global queue (one atomic per tile), so the load stays balanced whatever the
     // residency of the grid is (the grid may be larger than what fits the chip at once).
     if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
-    if (tid < kCommitSlots) {
-        s_cid[tid] = kNoBarcode;
-        s_cvote[tid] = 0;
-        s_cneg[tid] = 0;
-    }
-    auto flush_commits = [&]() {                   // all threads; barriers are the caller's business
-        if (tid < kCommitSlots && s_cid[tid] != kNoBarcode) {
-            uint32_t *rec = a.counts + 4 * (size_t)s_cid[tid];
-            if (s_cvote[tid]) atomicAdd(reinterpret_cast<unsigned long long *>(rec), s_cvote[tid]);
-            if (s_cneg[tid]) atomicAdd(rec + 2, s_cneg[tid]);
-            s_cid[tid] = kNoBarcode;
-            s_cvote[tid] = 0;
-            s_cneg[tid] = 0;
-        }
-    };
-    uint32_t tiles_done = 0;
     __syncthreads();
     for (;;) {
         const uint64_t tile = *s_tile;
@@ -525,7 +501,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
         }
         __syncthreads();
 
-        // ---- C: commit (classify.cpp:203-208) ------------------------------------------------
+        // ---- C: the read's votes out (the per-barcode bookkeeping is k_commit_votes' job) ----------------
         if (tid < tra) {
             const unsigned long long v = s_vote[tid];
             if (a.votes) {
@@ -534,35 +510,12 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
                     if ((uint32_t)v) atomicAdd(row, (uint32_t)v);
                     if ((uint32_t)(v >> 32)) atomicAdd(row + 1, (uint32_t)(v >> 32));
                 } else {
-                    a.votes[2 * (r0 + tid)] = (uint32_t)v;
-                    a.votes[2 * (r0 + tid) + 1] = (uint32_t)(v >> 32);
-                }
-            }
-            if (a.barcode_ids) {
-                const uint32_t id = a.barcode_ids[r0 + tid];
-                const uint32_t slot = (id * 0x9E3779B1u) >> (32 - 6);                  // log2(kCommitSlots) = 6
-                const uint32_t owner = atomicCAS(&s_cid[slot], kNoBarcode, id);
-                if (owner == kNoBarcode || owner == id) {                           // this barcode holds the slot: sum in LDS
-                    if (v) atomicAdd(&s_cvote[slot], v);
-                    else atomicAdd(&s_cneg[slot], 1u);
-                } else {
-                    uint32_t *rec = a.counts + 4 * (size_t)id;
-                    if (v) atomicAdd(reinterpret_cast<unsigned long long *>(rec), v);   // {c0,c1} in one add
-                    else atomicAdd(rec + 2, 1u);                                        // key -1
+                    reinterpret_cast<unsigned long long *>(a.votes)[r0 + tid] = v;       // {vote0, vote1}: one coalesced 8-byte store
                 }
             }
         }
-        // no barrier needed before the next tile: its header only touches this lane's own s_* entries
+        // no barrier needed here: the next tile's header only touches this lane's own s_* entries
         // and is followed by a barrier before anyone else reads them.
-        if (a.barcode_ids && ++tiles_done % kCommitEpoch == 0) {                    // give other barcodes a chance at the slots
-            __syncthreads();
-            flush_commits();
-            __syncthreads();
-        }
-    }
-    if (a.barcode_ids) {
-        __syncthreads();
-        flush_commits();
     }
 }
 
@@ -694,17 +647,68 @@ __global__ void __launch_bounds__(256) k_scan_n(const uint8_t *bases, const uint
     const bool any = __any(found);
     if (lane == 0) has_n[wave] = any ? 1 : 0;
 }
-// process_reads' bookkeeping (classify.cpp:203-208) from per-read votes accumulated over segments.
+// process_reads' bookkeeping (classify.cpp:203-208) from per-read votes: barcode[0] += vote0, barcode[1] += vote1 (one u64
+// add) or barcode[-1] += 1 when both are zero.  A workgroup takes a span of kCommitSpan consecutive reads.  Real stLFR
+// data has barcodes that own a large share of the reads ("0_0_0" = no barcode: 10-20 %), and agent-scope atomics execute
+// at the memory side on this part, so a million adds to ONE record serialise (measured inside k_classify before the
+// split: 16 barcodes -> 3x, 1 barcode -> 12x the kernel time).  Hence a small LDS cache keyed by barcode id: a barcode
+// that holds one of its two candidate slots is summed in LDS and written out at the end of every kCommitFlush reads;
+// everyone else does its one global atomic.
+constexpr int kCommitSlots = 128;              // power of two
+constexpr uint32_t kCommitSpan = 8192, kCommitFlush = 2048, kNoBarcode = 0xFFFFFFFFu;
 __global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, const uint32_t *barcode_ids, uint32_t *counts,
                                                       uint32_t *votes_out, size_t n_reads) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
-    const uint32_t v0 = votes[2 * i], v1 = votes[2 * i + 1];
-    if (votes_out) { votes_out[2 * i] = v0; votes_out[2 * i + 1] = v1; }
-    if (barcode_ids) {
-        uint32_t *rec = counts + 4 * (size_t)barcode_ids[i];
-        if (v0 | v1) atomicAdd(reinterpret_cast<unsigned long long *>(rec), (unsigned long long)v0 | ((unsigned long long)v1 << 32));
-        else atomicAdd(rec + 2, 1u);
+    __shared__ unsigned long long s_vote[kCommitSlots];
+    __shared__ uint32_t s_neg[kCommitSlots], s_id[kCommitSlots];
+    const uint32_t tid = threadIdx.x;
+    auto flush = [&]() {
+        if (tid < kCommitSlots) {
+            if (s_id[tid] != kNoBarcode) {
+                uint32_t *rec = counts + 4 * (size_t)s_id[tid];
+                if (s_vote[tid]) atomicAdd(reinterpret_cast<unsigned long long *>(rec), s_vote[tid]);
+                if (s_neg[tid]) atomicAdd(rec + 2, s_neg[tid]);
+            }
+            s_id[tid] = kNoBarcode;
+            s_vote[tid] = 0;
+            s_neg[tid] = 0;
+        }
+    };
+    if (tid < kCommitSlots) {                  // (LDS starts out undefined: never flush before this)
+        s_id[tid] = kNoBarcode;
+        s_vote[tid] = 0;
+        s_neg[tid] = 0;
+    }
+    __syncthreads();
+    const size_t span0 = (size_t)blockIdx.x * kCommitSpan;
+    for (uint32_t j = 0; j < kCommitSpan; j += 256) {
+        const size_t i = span0 + j + tid;
+        if (i < n_reads) {
+            const unsigned long long v = reinterpret_cast<const unsigned long long *>(votes)[i];
+            if (votes_out) reinterpret_cast<unsigned long long *>(votes_out)[i] = v;
+            if (barcode_ids) {
+                const uint32_t id = barcode_ids[i];
+                const uint32_t h = id * 0x9E3779B1u;
+                uint32_t slot = h >> (32 - 7);                                   // log2(kCommitSlots) = 7
+                uint32_t owner = atomicCAS(&s_id[slot], kNoBarcode, id);
+                if (owner != kNoBarcode && owner != id) {                        // second candidate
+                    slot = (h >> 11) & (kCommitSlots - 1);
+                    owner = atomicCAS(&s_id[slot], kNoBarcode, id);
+                }
+                if (owner == kNoBarcode || owner == id) {
+                    if (v) atomicAdd(&s_vote[slot], v);
+                    else atomicAdd(&s_neg[slot], 1u);
+                } else {
+                    uint32_t *rec = counts + 4 * (size_t)id;
+                    if (v) atomicAdd(reinterpret_cast<unsigned long long *>(rec), v);
+                    else atomicAdd(rec + 2, 1u);
+                }
+            }
+        }
+        if (barcode_ids && (j + 256) % kCommitFlush == 0) {                      // give other barcodes a chance at the slots
+            __syncthreads();
+            flush();
+            __syncthreads();
+        }
     }
 }
 hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, size_t n_reads, uint8_t *d_has_n, hipStream_t s) {
@@ -715,8 +719,8 @@ hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, size
 hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
                                size_t n_reads, hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_commit_votes, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_votes, d_barcode_ids, d_counts,
-                       d_votes_out, n_reads);
+    hipLaunchKernelGGL(k_commit_votes, dim3((unsigned)((n_reads + kCommitSpan - 1) / kCommitSpan)), dim3(256), 0, s, d_votes, d_barcode_ids,
+                       d_counts, d_votes_out, n_reads);
     return hipGetLastError();
 }
 

@@ -138,6 +138,11 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
  * Reads of any length: with d_offsets and read_len > 4096 the reads are cut into segments on the device
  * (same result; the call then waits for one small device->host counter before the main launch).
  * Otherwise asynchronous on `stream`. */
+/* Kernel timing for measurements (bench.py's roofline): with n_slots > 0 every hast_classify_device call records HIP
+ * events around its two kernels (k_classify, k_commit_votes) on the launch stream, for the last n_slots calls;
+ * hast_classify_times waits for them and returns the durations in call order (ms), oldest first, and forgets them. */
+hast_status hast_classify_timing(hast_ctx *, int n_slots);
+hast_status hast_classify_times(hast_ctx *, float *classify_ms, float *commit_ms, int max, int *n_out);
 hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
                                  const uint64_t *d_offsets, uint32_t read_len,
                                  const uint32_t *d_barcode_ids, uint32_t *d_votes,
