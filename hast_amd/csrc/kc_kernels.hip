@@ -21,10 +21,14 @@ namespace hast {
 
 constexpr int kKcThreads = 256;
 
-// find-or-insert `key` starting at bucket b, then add `add` to its count for `parent`.  Slots never change once written and fill in
-// order, so a (possibly stale) plain read can only show a PREFIX of the real bucket: a key seen is there for good, and
-// "not seen" is settled by the compare-and-swap on the first slot that looked empty.
-__device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, uint32_t b, uint64_t key, uint32_t parent, uint32_t add) {
+// find-or-insert `key` starting at bucket b; returns the address of its counter for `parent`, or nullptr when the table is
+// full.  Slots never change once written and fill in order, so a (possibly stale) plain read can only show a PREFIX of
+// the real bucket: a key seen is there for good, and "not seen" is settled by the compare-and-swap on the first slot that
+// looked empty.  The ADD itself is the caller's, after the lanes of the wave have come back together: the lanes of a
+// wave are consecutive windows, mostly of the same bucket, and their adds to one 32-B counter sector leave the CU as a
+// single request only when they come from the same instruction (tools/atomic_merge_probe.hip; an instrumented build
+// counted 48 distinct counter sectors per 150-bp read with the add inside the probe loop, against ~37 minimizer runs).
+__device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t nb, uint32_t b, uint64_t key, uint32_t parent) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (uint32_t probe = 0; probe < nb; ++probe) {
         unsigned long long *bk = table + (size_t)b * kKcBucketWords;
@@ -37,9 +41,6 @@ __device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, 
             s[2 * i] = t.x;
             s[2 * i + 1] = t.y;
         }
-        // ONE atomic site for every lane that found its key: the lanes of a wave are consecutive windows, mostly of the
-        // same bucket, and their adds to one 64-B counter line leave the CU as a single request only when they come
-        // from the same instruction
         int idx = -1, first_empty = kKcSlots;
 #pragma unroll
         for (int i = kKcSlots - 1; i >= 0; --i) {
@@ -50,13 +51,10 @@ __device__ __forceinline__ bool kc_bump(unsigned long long *table, uint32_t nb, 
             const unsigned long long old = atomicCAS(&bk[i], (unsigned long long)kEmptySlot, (unsigned long long)key);
             if (old == kEmptySlot || old == key) idx = i;
         }
-        if (idx >= 0) {
-            atomicAdd(cnt + idx, add);
-            return true;
-        }
+        if (idx >= 0) return cnt + idx;
         b = next_bucket(b, probe + 1, key, nb);              // bucket full: jump to the key's own overflow bucket, then walk on
     }
-    return false;
+    return nullptr;
 }
 
 // One workgroup walks tiles of `tile_bases` window starts (+ K-1 bytes of overlap) of the byte stream.
@@ -154,11 +152,17 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             const bool follower = valid && lane > 0 && prev_valid && prev_key == key;
             const unsigned long long fmask = __ballot(follower);
             if (valid) ++counted;
-            if (!valid || follower) continue;
+            const bool active = valid && !follower;
             // run length = 1 + the followers right after this lane
             const unsigned long long after = lane == 63 ? 0ull : (fmask >> (lane + 1));
             const uint32_t run = 1 + (uint32_t)__builtin_ctzll(~after);
-            if (!kc_bump(a.table, a.nbuckets, bucket_of_minhash(mn, a.nbuckets), key, a.parent, run)) atomicOr(a.err, 1u);
+            uint32_t *counter = nullptr;
+            if (active) counter = kc_slot(a.table, a.nbuckets, bucket_of_minhash(mn, a.nbuckets), key, a.parent);
+            // everyone is back together here: ONE add instruction for the whole wave
+            if (active) {
+                if (counter) atomicAdd(counter, run);
+                else atomicOr(a.err, 1u);
+            }
         }
         __syncthreads();
     }
