@@ -623,9 +623,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
         }
         votes_buf = c->d_votes_scratch;
     }
-    a.barcode_ids = nullptr;
     a.votes = votes_buf;
-    a.counts = c->d_counts;
     a.slots = c->d_slots;
     a.n_reads = n_reads;
     a.nbuckets = c->nbuckets;

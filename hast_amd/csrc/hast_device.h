@@ -20,9 +20,7 @@ struct ClassifyArgs {
     const uint64_t *offsets;     // n_reads+1 offsets or nullptr (fixed length); with `lens`: n_reads start offsets
     const uint32_t *lens;        // per-row length (rows = segments of long reads) or nullptr
     const uint32_t *seg_read;    // row -> output read index (votes are atomically added) or nullptr
-    const uint32_t *barcode_ids; // per read, or nullptr
     uint32_t *votes;             // [n_reads][2] or nullptr
-    uint32_t *counts;            // [n_barcodes][4] = {c0,c1,neg,reserved}
     unsigned long long *tile_queue; // zeroed before the launch: next tile index (dynamic load balance)
     const uint64_t *slots;       // table
     uint64_t n_reads;
