@@ -39,7 +39,11 @@ cal_line = json.loads(open(os.path.join(src, "cal_FETCH_SIZE.json")).read().stri
 kr = [k for k in pmc if "k_rand" in k][0]
 kc = [k for k in pmc if "k_classify" in k][0]
 cal_factor = cal_line["bytes"] / (pmc[kr]["FETCH_SIZE"] * 1024.0)
-fetch = pmc[kc]["FETCH_SIZE"] * 1024.0 * cal_factor
+# FETCH_SIZE tallies every request at 64 B, but on gfx950 a request is a 128-B block (profiles/fetch_calibration.json):
+# k_classify's requests carry 96.7 B on average (both halves of a minimizer's bucket pair in 51 % of them)
+req_bytes = json.load(open(os.path.join(dst, "fetch_calibration.json")))["bytes_per_read_request"]
+fetch_tallied = pmc[kc]["FETCH_SIZE"] * 1024.0 * cal_factor
+fetch = fetch_tallied * req_bytes / 64.0
 write = pmc[kc]["WRITE_SIZE"] * 1024.0
 summary = {
     "tag": tag,
@@ -51,7 +55,7 @@ summary = {
                     "note": "FETCH_SIZE (KB) x 1024 reads the random-line bytes exactly (factor ~1.00); the gfx950 x2 "
                             "correction applies to wide coalesced streams only (here: the 2.4 GB of read bases, <2 % of traffic)"},
     "hbm_bytes_per_launch": fetch + write,
-    "fetch_bytes": fetch, "write_bytes": write,
+    "fetch_bytes": fetch, "fetch_bytes_as_tallied_at_64B_per_request": fetch_tallied, "write_bytes": write,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     "traffic_over_algorithmic": (fetch + write) / bench["roofline"]["algorithmic_bytes_per_launch"],
     "l2_hit_rate": pmc[kc]["TCC_HIT_sum"] / (pmc[kc]["TCC_HIT_sum"] + pmc[kc]["TCC_MISS_sum"]),
@@ -59,7 +63,8 @@ summary = {
 json.dump(summary, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 json.dump({"workload": "c3", "batch_reads": bench["config"]["batch_reads"], "hbm_bytes_per_launch": fetch + write,
            "hbm_read_requests_per_launch": pmc[kc].get("TCC_EA0_RDREQ_sum"),
-           "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on tools/hbm_randread)" % tag},
+           "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE tallies a request at 64 B, "
+                     "k_classify's 128-B-block requests carry 96.7 B: profiles/fetch_calibration.json)" % tag},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 if os.path.exists("gpurun_out/randread.jsonl"):
     shutil.copy("gpurun_out/randread.jsonl", os.path.join(dst, tag + "_hbm_randread.jsonl"))
