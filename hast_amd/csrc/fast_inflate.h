@@ -26,7 +26,7 @@ class GzInflater {
   public:
     bool open(FILE *f, size_t in_buf_bytes = 1u << 20) {
         fp_ = f;
-        in_.assign(in_buf_bytes + kPad, 0);
+        in_.assign(std::max<size_t>(in_buf_bytes, 64) + kBack + kPad, 0);
         in_pos_ = in_end_ = 0;
         in_eof_ = false;
         out_.assign(kWindow + kOutChunk + kSlack, 0);
@@ -70,7 +70,7 @@ class GzInflater {
     const std::string &error() const { return err_; }
 
   private:
-    static constexpr size_t kWindow = 32768, kOutChunk = 1u << 20, kSlack = 512, kPad = 64;
+    static constexpr size_t kWindow = 32768, kOutChunk = 1u << 20, kSlack = 512, kPad = 64, kBack = 8;
     static constexpr int kLitBits = 11, kDistBits = 8;
     // table entry: bits 0-7 codeword bits to drop, 8-12 extra-bit count (or sub-table index bits), 13 literal, 14 end of block,
     // 15 sub-table pointer, 16-31 value (literal byte / base length / base distance / sub-table start)
@@ -86,9 +86,12 @@ class GzInflater {
     // make at least `want` (<= kPad) real or padded bytes readable at in_pos_; real bytes come first
     void fill_input() {
         if (in_eof_) return;
-        const size_t keep = in_end_ - in_pos_;
-        if (keep && in_pos_) memmove(in_.data(), in_.data() + in_pos_, keep);
-        in_pos_ = 0;
+        // Keep kBack bytes of history in front of the read position: the bit buffer may still hold up to 7 whole bytes
+        // that align_to_byte() hands back by stepping in_pos_ backwards.
+        const size_t back = std::min(in_pos_, kBack);
+        const size_t from = in_pos_ - back, keep = in_end_ - from;
+        if (keep && from) memmove(in_.data(), in_.data() + from, keep);
+        in_pos_ = back;
         in_end_ = keep;
         const size_t room = in_.size() - kPad - in_end_;
         const size_t n = room ? fread(in_.data() + in_end_, 1, room, fp_) : 0;

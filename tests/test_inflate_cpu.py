@@ -94,6 +94,49 @@ def test_big_stream_and_python_gzip_writer(driver, tmp_path):
     assert got.returncode == 0 and got.stdout == data
 
 
+def test_thousands_of_tiny_members_with_tiny_input_buffers(driver, tmp_path):
+    """BGZF-like input: every member ends with a byte-aligned trailer right after the last bits of its data, so the decoder
+    keeps handing whole bytes back from its bit buffer -- also across refills of the input buffer (this once stepped
+    in front of the buffer)"""
+    rng = random.Random(1)
+    data, blob = b"", b""
+    for _ in range(3000):
+        d = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 400)))
+        data += d
+        blob += member(d, rng.choice([0, 1, 6, 9]))
+    p = tmp_path / "many.gz"
+    p.write_bytes(blob)
+    for inbuf in (40, 64, 77, 128, 1000, 1 << 20):
+        for piece in (1 << 20, 4096, 13):
+            r = subprocess.run([driver, "-i", str(inbuf), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == data, (inbuf, piece, r.stderr[-300:])
+
+
+def test_random_streams_with_flush_points(driver, tmp_path):
+    """members written with sync / full flushes at random places (empty stored blocks in mid-stream, as pigz and bgzip
+    emit them), random levels and strategies, decoded with random buffer and call sizes"""
+    rng = random.Random(11)
+    for it in range(12):
+        data, blob = b"", b""
+        for _ in range(rng.randint(1, 6)):
+            c = zlib.compressobj(rng.choice([1, 4, 6, 9]), zlib.DEFLATED, 31, 9, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED]))
+            for _ in range(rng.randint(1, 30)):
+                kind = rng.random()
+                d = (bytes(rng.choice(b"ACGTN\n") for _ in range(rng.randint(0, 3000))) if kind < 0.6 else
+                     bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 500))) if kind < 0.8 else b"A" * rng.randint(0, 70000))
+                data += d
+                blob += c.compress(d)
+                if rng.random() < 0.5:
+                    blob += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            blob += c.flush()
+        p = tmp_path / ("r%d.gz" % it)
+        p.write_bytes(blob)
+        for _ in range(3):
+            inbuf, piece = rng.choice([33, 64, 200, 4096, 1 << 20]), rng.choice([1 << 20, 5000, 97])
+            r = subprocess.run([driver, "-i", str(inbuf), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == data, (it, inbuf, piece, r.stderr[-300:])
+
+
 def test_damaged_input_is_an_error(driver, tmp_path):
     good = member(FQ[:120_000]) + member(FQ[120_000:200_000], 1)
     rng = random.Random(3)
