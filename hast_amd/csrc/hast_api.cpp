@@ -610,6 +610,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     // The kernel only writes per-read votes; the per-barcode bookkeeping runs as a kernel of its own afterwards (its random
     // read-modify-writes cost 4x as much when they are interleaved with the probes' reads).  Without a votes buffer from
     // the caller the votes go to library scratch.
+    if (reinterpret_cast<uintptr_t>(d_votes) & 7) return fail(HAST_ERR_INVALID, "d_votes must be 8-byte aligned (a row is stored as one 64-bit word)");
     uint32_t *votes_buf = d_votes;
     if (d_barcode_ids && !votes_buf) {
         const size_t need = n_reads * 2 * sizeof(uint32_t);

@@ -132,7 +132,7 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
  *   d_offsets      n_reads+1 byte offsets into d_bases, or NULL => fixed length: read i at i*read_len
  *   read_len       fixed read length (d_offsets==NULL) or an upper bound on every read's length
  *   d_barcode_ids  per-read dense barcode id (< n_barcodes), or NULL => counters untouched
- *   d_votes        optional [n_reads][2] per-read (vote0, vote1) output (per-read mode), or NULL
+ *   d_votes        optional [n_reads][2] per-read (vote0, vote1) output (per-read mode), 8-byte aligned, or NULL
  *   bases_bytes    total bytes readable at d_bases (reads never look past it)
  * A read shorter than K has no windows (the reference aborts, kmer.h:171): it votes 0/0.
  * Reads of any length: with d_offsets and read_len > 4096 the reads are cut into segments on the device
