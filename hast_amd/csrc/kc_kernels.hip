@@ -181,7 +181,8 @@ static hipError_t launch_kc_count_t(const KcCountArgs &a, unsigned grid, size_t 
 }
 size_t kc_count_smem(uint32_t tile_bases, int k, int m) {
     const uint32_t span = tile_bases + (uint32_t)k - 1, nw = (span + 31) / 32 + 2, w = (uint32_t)(k - m + 1);
-    return 16 + (size_t)nw * 8 + (size_t)nw * 4 + (size_t)(tile_bases + w) * 4 + 16;
+    // + 64 entries: the last wave-block of a tile looks up to 63 window starts past the tile (those lanes are masked off afterwards)
+    return 16 + (size_t)nw * 8 + (size_t)nw * 4 + (size_t)(tile_bases + w + 64) * 4 + 16;
 }
 hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s) {
     const size_t smem = kc_count_smem(a.tile_bases, a.k, a.m);
