@@ -102,3 +102,39 @@ def test_synth_host_generator_properties(lib, oracle_lib):
     hits = int(e[0].sum() + e[1].sum())
     assert 1500 < hits < 4000                                     # ~1.5 planted k-mers per read
     assert 0 < (a == ord("N")).sum() < 40
+
+
+def test_find_bounds_matches_oracle_and_the_awk_program(lib, oracle_lib, tmp_path):
+    """hast_kc_find_bounds (host arithmetic of find_bounds.awk) against the oracle's restatement on random histograms and, in the
+    build container, against the reference's own awk program run on the printed rows"""
+    import ctypes as C
+    import random
+    rng = random.Random(5)
+    awk = "/root/reference/00.build_unshare_kmers_by_jellyfish/find_bounds.awk"
+    for it in range(60):
+        h = np.zeros(hast_amd.KC_HISTO_HIGH + 2, dtype=np.uint64)
+        shape = rng.choice(["typical", "sparse", "flat", "empty", "rising", "tail"])
+        if shape == "typical":                      # error peak at 1, valley, coverage peak
+            peak = rng.randint(8, 60)
+            for c in range(1, 4 * peak):
+                h[c] = int(1e6 / c ** 3 + 5e4 * np.exp(-((c - peak) ** 2) / (2.0 * peak))) + rng.randint(0, 3)
+        elif shape == "sparse":
+            for c in rng.sample(range(1, 10002), rng.randint(1, 12)):
+                h[c] = rng.randint(1, 1000)
+        elif shape == "flat":
+            h[1:rng.randint(2, 50)] = 7
+        elif shape == "rising":
+            for c in range(1, 30):
+                h[c] = c * 10
+        elif shape == "tail":
+            h[1], h[2], h[10001] = 100, 50, rng.randint(1, 500)
+        got = hast_amd.kc_find_bounds(h)
+        out = [C.c_long() for _ in range(4)]
+        oracle_lib.ho_s00_find_bounds(h.ctypes.data_as(C.POINTER(C.c_uint64)), *[C.byref(x) for x in out])
+        assert got == tuple(x.value for x in out), (shape, got)
+        if os.path.exists(awk):
+            rows = "".join("%d %d\n" % (c, h[c]) for c in range(1, 10002) if h[c])
+            (tmp_path / "h.histo").write_text(rows)
+            r = subprocess.run(["awk", "-f", awk, str(tmp_path / "h.histo")], stdout=subprocess.PIPE, check=True).stdout.decode()
+            ref = tuple(int(l.split("=")[1]) for l in r.splitlines())
+            assert got == ref, (shape, got, ref)
