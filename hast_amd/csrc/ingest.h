@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/hast.h"
+#include "bgzf_reader.h"
 #include "fast_inflate.h"
 
 namespace hast {
@@ -194,7 +195,8 @@ class BarcodeDict {
 // ------------------------------------------------------------------------------------------------
 // block source: raw or gz bytes in large blocks, produced by a background reader thread.  gz files go through the
 // in-tree decoder (fast_inflate.h: about twice zlib's speed on FASTQ, members CRC-checked); HAST_INFLATE=zlib in the
-// environment switches back to zlib's gzread.  A damaged gz file ends the stream early and sets error().
+// environment switches back to zlib's gzread.  Blocked gzip (BGZF) is recognised by its first member and inflated by several
+// threads at once (bgzf_reader.h; HAST_BGZF_THREADS).  A damaged gz file ends the stream early and sets error().
 // ------------------------------------------------------------------------------------------------
 class BlockSource {
   public:
@@ -213,7 +215,13 @@ class BlockSource {
         } else if (gz_mode_) {
             fp_ = fopen(path.c_str(), "rb");
             if (!fp_) return false;
-            inflater_.open(fp_, 4u << 20);
+            // blocked gzip (BGZF) is inflated by several threads at once; anything else is one serial stream
+            bgzf_ = BgzfReader::probe(fp_);
+            if (bgzf_) {
+                const unsigned hw = std::thread::hardware_concurrency();
+                const char *e = getenv("HAST_BGZF_THREADS");
+                bgzf_reader_.open(fp_, e ? atoi(e) : (int)std::min(16u, std::max(2u, hw / 8)));
+            } else inflater_.open(fp_, 4u << 20);
         } else if (path == "-") {
             fp_ = stdin;
         } else {
@@ -290,6 +298,17 @@ class BlockSource {
                         const char *msg = gzerror(gz_, &en);
                         if (en != Z_OK && en != Z_STREAM_END) trouble = std::string("gz: ") + msg;
                     }
+                } else if (gz_mode_ && bgzf_) {
+                    r = bgzf_reader_.read(reinterpret_cast<uint8_t *>(dst + got), block_bytes_ - got);
+                    if (r == -2) {                     // a member that is not BGZF: the serial decoder takes over from there
+                        bgzf_ = false;
+                        if (fseek(fp_, (long)bgzf_reader_.resume_offset(), SEEK_SET) != 0) trouble = "gz: cannot seek";
+                        else {
+                            inflater_.open(fp_, 4u << 20);
+                            continue;
+                        }
+                    }
+                    if (r == -1) trouble = bgzf_reader_.error();
                 } else if (gz_mode_) {
                     r = inflater_.read(reinterpret_cast<uint8_t *>(dst + got), block_bytes_ - got);
                     if (r < 0) trouble = inflater_.error();
@@ -309,7 +328,8 @@ class BlockSource {
             cv_.notify_all();
         }
     }
-    bool gz_mode_ = false, use_zlib_ = false;
+    bool gz_mode_ = false, use_zlib_ = false, bgzf_ = false;
+    BgzfReader bgzf_reader_;
     gzFile gz_ = nullptr;
     GzInflater inflater_;
     std::string error_;

@@ -9,15 +9,19 @@
 #include <cstring>
 #include <vector>
 
+#include "../../hast_amd/csrc/bgzf_reader.h"
 #include "../../hast_amd/csrc/fast_inflate.h"
 
 int main(int argc, char **argv) {
-    bool use_zlib = false, quiet = false;
+    bool use_zlib = false, quiet = false, bgzf = false;
+    int threads = 4;
     size_t piece = 1 << 20, inbuf = 1 << 20;
     const char *path = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-z")) use_zlib = true;
         else if (!strcmp(argv[i], "-q")) quiet = true;
+        else if (!strcmp(argv[i], "-b")) bgzf = true;                 // BgzfReader (+ hand-over to the serial decoder), as BlockSource does
+        else if (!strcmp(argv[i], "-t")) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-p")) piece = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-i")) inbuf = (size_t)atol(argv[++i]);
         else path = argv[i];
@@ -40,8 +44,23 @@ int main(int argc, char **argv) {
         FILE *f = fopen(path, "rb");
         if (!f) return 2;
         hast::GzInflater z;
-        z.open(f, inbuf);
         long n;
+        if (bgzf) {
+            if (!hast::BgzfReader::probe(f)) return 4;
+            hast::BgzfReader b;
+            b.open(f, threads);
+            while ((n = b.read(buf.data(), piece)) > 0) {
+                if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
+                total += (size_t)n;
+            }
+            if (n == -1) {
+                fprintf(stderr, "%s\n", b.error().c_str());
+                return 3;
+            }
+            if (n == 0) return 0;
+            fseek(f, (long)b.resume_offset(), SEEK_SET);            // -2: an ordinary member follows
+        }
+        z.open(f, inbuf);
         while ((n = z.read(buf.data(), piece)) > 0) {
             if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
             total += (size_t)n;

@@ -16,7 +16,7 @@ from tests.conftest import ROOT
 def driver(tmp_path_factory):
     exe = tmp_path_factory.mktemp("inflate") / "test_inflate"
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
-                    os.path.join(ROOT, "tests", "native", "test_inflate.cpp"), "-lz"], check=True)
+                    os.path.join(ROOT, "tests", "native", "test_inflate.cpp"), "-lz", "-pthread"], check=True)
     return str(exe)
 
 
@@ -135,6 +135,45 @@ def test_random_streams_with_flush_points(driver, tmp_path):
             inbuf, piece = rng.choice([33, 64, 200, 4096, 1 << 20]), rng.choice([1 << 20, 5000, 97])
             r = subprocess.run([driver, "-i", str(inbuf), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0 and r.stdout == data, (it, inbuf, piece, r.stderr[-300:])
+
+
+def bgzf(data, tail=b""):
+    def block(d):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = c.compress(d) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+                struct.pack("<II", zlib.crc32(d) & 0xFFFFFFFF, len(d)))
+    out = b"".join(block(data[i:i + 65280]) for i in range(0, len(data), 65280))
+    return out + (member(tail) if tail else block(b""))
+
+
+def test_blocked_gzip_is_inflated_in_parallel_and_checked(driver, tmp_path):
+    rng = random.Random(21)
+    data = fastq(rng, 9000) + bytes(rng.getrandbits(8) for _ in range(100_000))
+    p = tmp_path / "b.gz"
+    p.write_bytes(bgzf(data))
+    want = subprocess.run([driver, "-z", str(p)], stdout=subprocess.PIPE).stdout
+    assert want == data                                            # zlib reads the same file as ordinary multi-member gzip
+    for piece, threads in ((1 << 24, 8), (200_000, 3), (70_000, 1), (65_536, 2), (9000, 4), (1, 2)):
+        r = subprocess.run([driver, "-b", "-p", str(piece), "-t", str(threads), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == data, (piece, threads, r.stderr[-300:])
+    # an ordinary gzip member behind the blocks: the serial decoder takes over
+    p.write_bytes(bgzf(data[:500_000], tail=data[500_000:]))
+    r = subprocess.run([driver, "-b", "-p", "300000", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == data, r.stderr[-300:]
+    whole = bgzf(data)
+    for damage in ("flip", "cut", "cut_in_header"):
+        b = bytearray(whole)
+        if damage == "flip":
+            b[len(b) // 2] ^= 0x20
+        elif damage == "cut":
+            b = b[: len(b) // 2]
+        else:
+            b = b[: len(b) - 28 - 20 + 7] if False else b[:7]
+        p.write_bytes(bytes(b))
+        r = subprocess.run([driver, "-b", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode in (3, 4), (damage, r.returncode)      # 4: too short to be recognised as BGZF at all
+        assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr
 
 
 def test_damaged_input_is_an_error(driver, tmp_path):

@@ -37,7 +37,25 @@ def test_edge_case_all_branches(exe, tmp_path):
         assert sorted(os.listdir(tmp_path)) == sorted(list(exp["inputs"]) + list(exp["outputs"]))
 
 
-@pytest.mark.parametrize("threads,block_mb,via", [(1, 64, "file"), (8, 1, "file"), (3, 1, "gz"), (4, 64, "stdin")])
+def _bgzf(data, tail=b""):
+    """blocked gzip as bgzip writes it (members of <= 64 KB with a BC extra field + the empty end-of-file member),
+    optionally followed by an ordinary gzip member"""
+    import struct
+    import zlib
+    def block(d):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = c.compress(d) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+                struct.pack("<II", zlib.crc32(d) & 0xFFFFFFFF, len(d)))
+    out = b"".join(block(data[i:i + 65280]) for i in range(0, len(data), 65280))
+    if tail:
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        return out + c.compress(tail) + c.flush()
+    return out + block(b"")
+
+
+@pytest.mark.parametrize("threads,block_mb,via", [(1, 64, "file"), (8, 1, "file"), (3, 1, "gz"), (4, 64, "stdin"), (2, 1, "bgzf"), (5, 64, "bgzf+gz"),
+                                                  (2, 1, "gz-zlib")])
 def test_rand_k21_matches_reference_awk(exe, tmp_path, threads, block_mb, via):
     exp = json.load(open(os.path.join(GOLDEN, "quartering", "expected.json")))
     for name in ("paternal", "maternal", "homozygous"):
@@ -48,10 +66,16 @@ def test_rand_k21_matches_reference_awk(exe, tmp_path, threads, block_mb, via):
         if fq == "r2.fq":
             data = data[:-1] + b"\n" + exp["r2_tail"].encode()
         cmd = [exe, "-t", str(threads), "--block-mb", str(block_mb), "--prefix", fq] + lists
-        if via == "gz":
+        if via in ("gz", "gz-zlib"):
             with gzip.open(tmp_path / (fq + ".gz"), "wb") as f:
                 f.write(data)
-            r = subprocess.run(cmd + [fq + ".gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            env = dict(os.environ, HAST_INFLATE="zlib") if via == "gz-zlib" else None
+            r = subprocess.run(cmd + [fq + ".gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        elif via.startswith("bgzf"):                 # blocked gzip: inflated by several threads; "+gz": an ordinary member appended
+            cut = len(data) * 2 // 3 if via == "bgzf+gz" else len(data)
+            (tmp_path / (fq + ".gz")).write_bytes(_bgzf(data[:cut], data[cut:]))
+            r = subprocess.run(cmd + [fq + ".gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, HAST_BGZF_THREADS="3"))
         elif via == "stdin":
             r = subprocess.run(cmd + ["-"], cwd=tmp_path, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         else:
