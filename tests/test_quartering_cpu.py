@@ -122,3 +122,29 @@ def test_merge_counts_equals_single_run(oracle_dir, golden_workdir, tmp_path):
     r = subprocess.run([os.path.join(ROOT, "hast_amd", "merge_counts"), "--set0", str(sizes[0]), "--set1", str(sizes[1]),
                         "--weight0", "1.04", "shard0.tsv", "shard1.tsv"], cwd=tmp_path, stdout=subprocess.PIPE, check=True)
     assert r.stdout == open(d / "expected.pair_w104.tsv", "rb").read()
+
+
+def test_block_reads_by_several_readers_equal_a_single_reader(exe, tmp_path):
+    """blocks >= 32 MB of a regular file are filled by four pread() workers; smaller ones by one fread: same outputs, also
+    when the file ends inside a share and when a block ends inside a record"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = 330_000
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 100))]
+    ids = rng.integers(0, 40, size=n)
+    recs = []
+    for i in range(n):
+        recs.append(b"@r%d#%d_%d_%d/1\n" % (i, ids[i], ids[i], ids[i] % 3 + 1) + seqs[i].tobytes() + b"\n+\n" + b"F" * 100 + b"\n")
+    (tmp_path / "big.fq").write_bytes(b"".join(recs))                      # ~73 MB
+    (tmp_path / "p.bc").write_text("".join("%d_%d_%d\n" % (i, i, i % 3 + 1) for i in range(0, 13)))
+    (tmp_path / "m.bc").write_text("".join("%d_%d_%d\n" % (i, i, i % 3 + 1) for i in range(13, 27)))
+    (tmp_path / "h.bc").write_text("".join("%d_%d_%d\n" % (i, i, i % 3 + 1) for i in range(27, 33)))
+    sums = []
+    for block_mb in (64, 40, 8):
+        r = subprocess.run([exe, "-t", "4", "--block-mb", str(block_mb), "--prefix", "b%d" % block_mb, "p.bc", "m.bc", "h.bc", "big.fq"],
+                           cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr[-300:]
+        outs = [tmp_path / ("b%d.%s.fastq" % (block_mb, c)) for c in ("paternal", "maternal", "homozygous", "nobarcode")]
+        sums.append([hashlib.md5(o.read_bytes()).hexdigest() if o.exists() else None for o in outs] + [hashlib.md5(r.stderr).hexdigest()])
+        assert sums[-1][0] is not None and outs[0].stat().st_size > 10_000_000
+    assert sums[0] == sums[1] == sums[2]
