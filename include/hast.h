@@ -137,16 +137,18 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
  * A read shorter than K has no windows (the reference aborts, kmer.h:171): it votes 0/0.
  * Reads of any length: with d_offsets and read_len > 4096 the reads are cut into segments on the device
  * (same result; the call then waits for one small device->host counter before the main launch).
- * Otherwise asynchronous on `stream`. */
+ * Otherwise asynchronous on `stream`.  Two kernels run per call: the probes (k_classify) write per-read votes -- to d_votes, or
+ * to library scratch that grows on demand (a larger batch than ever before synchronises once) -- and k_commit_votes turns
+ * them into the per-barcode counters (updates interleaved with the probes' reads cost four times as much). */
+hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
+                                 const uint64_t *d_offsets, uint32_t read_len,
+                                 const uint32_t *d_barcode_ids, uint32_t *d_votes,
+                                 size_t n_reads, hast_stream);
 /* Kernel timing for measurements (bench.py's roofline): with n_slots > 0 every hast_classify_device call records HIP
  * events around its two kernels (k_classify, k_commit_votes) on the launch stream, for the last n_slots calls;
  * hast_classify_times waits for them and returns the durations in call order (ms), oldest first, and forgets them. */
 hast_status hast_classify_timing(hast_ctx *, int n_slots);
 hast_status hast_classify_times(hast_ctx *, float *classify_ms, float *commit_ms, int max, int *n_out);
-hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
-                                 const uint64_t *d_offsets, uint32_t read_len,
-                                 const uint32_t *d_barcode_ids, uint32_t *d_votes,
-                                 size_t n_reads, hast_stream);
 /* Same with HOST buffers: staged to the device through the context's pinned double buffer
  * (what the classify CLI uses).  Returns once the batch is enqueued; buffers may be reused on return. */
 hast_status hast_classify_batch(hast_ctx *, const uint8_t *bases, const uint64_t *offsets,
