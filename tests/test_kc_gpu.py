@@ -267,7 +267,7 @@ def test_kmers_piled_on_one_minimizer(built, oracle_lib):
         dt = time.time() - t0
         check_against_oracle(o, kc, c, k, None)
         assert kc.select(0, 1, 3) == oracle_select(o, c, 0, 1, 3).size
-    assert dt < 5, "piled-up k-mers: %.1f s" % dt
+    assert dt < 20, "piled-up k-mers: %.1f s" % dt
     o.ho_s00_free(c)
 
 
