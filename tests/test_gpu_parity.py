@@ -668,3 +668,28 @@ def test_keys_piled_on_one_minimizer(built, oracle_lib):
         assert int(exp[0].sum()) > 1000
         assert dt < 20, "piled-up keys: %.1f s" % dt
     oracle_lib.ho_free(oc)
+
+
+def test_kernel_timing_ring(built):
+    """hast_classify_timing / hast_classify_times (bench.py's roofline clock): the last n calls, oldest first, both kernels"""
+    k, L, n = 21, 150, 200_000
+    p = make_params(k, L, 5000, 50)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(10000)
+        ctx.synth_table_build(p)
+        ctx.counts_resize(50)
+        d_b, d_i = ctx.alloc(n * L), ctx.alloc(n * 4)
+        ctx.synth_reads_device(p, 0, n, d_b, d_i)
+        ctx.classify_timing(4)
+        for _ in range(6):
+            ctx.classify_device(d_b, n * L, n, L, d_barcode_ids=d_i)
+        a, b = ctx.classify_times()
+        assert len(a) == 4 and len(b) == 4 and all(0 < x < 1000 for x in a) and all(0 < x < 1000 for x in b)
+        assert ctx.classify_times() == ([], [])                      # forgotten once read
+        ctx.classify_device(d_b, n * L, n, L, d_votes=ctx.alloc(n * 8))   # votes only: no bookkeeping kernel
+        a, b = ctx.classify_times()
+        assert len(a) == 1 and a[0] > 0 and b[0] < a[0]
+        ctx.classify_timing(0)
+        ctx.classify_device(d_b, n * L, n, L, d_barcode_ids=d_i)
+        assert ctx.classify_times() == ([], [])
+        ctx.sync()
