@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_count_tags(const uint64_t *slots, size_
 //               once, by adjacent lanes, and adjacent groups = consecutive windows (same line when they
 //               share a minimizer).  Blocks are software-pipelined: 4..8 loads in flight per lane.  A bucket is full iff its last
 //               slot is taken (slots fill in order), so "no match and slot.y of some lane empty"
-//               ends the probe; full buckets without a match (rare at load factor 0.25) take the
+//               ends the probe; full buckets without a match (rare at load factor 0.2) take the
 //               chain walk.  Hits (about 1 % of windows) go to per-read LDS counters.
 //   C  votes  : one lane per read stores the read's {vote0, vote1} (8 B, coalesced).  The per-barcode bookkeeping
 //               (classify.cpp:203-208) is a kernel of its own, k_commit_votes: random read-modify-writes that are

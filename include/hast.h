@@ -71,7 +71,8 @@ hast_status hast_memset_d(hast_ctx *, void *d_dst, int byte, size_t bytes, hast_
 /* ---- the k-mer table: g_kmers[0], g_kmers[1] (classify.cpp:27) -----------------------------
  * One table, slot = (canonical_key << 2) | tags, tag bit h set <=> key in haplotype h's set.
  * Buckets of 8 slots = 64 B; home bucket from the hash of the key's minimizer (consecutive windows of
- * a read then mostly share a bucket line); overflow to the next bucket. */
+ * a read then mostly share a bucket line); a key whose home bucket is full goes to a bucket chosen by the key's own
+ * hash and walks on from there (hast_common.h: overflow_bucket / next_bucket). */
 
 /* Size the table for up to `max_keys` distinct keys (both haplotypes together) at the given
  * load factor (0 => 0.2: 288 GB of HBM make a sparse table free, and full buckets rare).  Discards
