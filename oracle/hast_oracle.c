@@ -655,6 +655,7 @@ typedef struct {
     const uint32_t *ids;
     size_t lo, hi;
     uint32_t *c0, *c1, *neg, *seen;
+    uint32_t *votes;   /* optional [n_reads][2]: the read's own (vote0, vote1), classify.cpp:195-202 */
 } bulk_job;
 
 static void *bulk_worker(void *arg) {
@@ -665,6 +666,10 @@ static void *bulk_worker(void *arg) {
         uint32_t v0, v1, id = j->ids[r];
         int has_n;
         ho_read_votes(j->c, seq, slen, &v0, &v1, &has_n);
+        if (j->votes) {
+            j->votes[2 * r] = v0;
+            j->votes[2 * r + 1] = v1;
+        }
         if (j->seen) __atomic_fetch_add(&j->seen[id], 1u, __ATOMIC_RELAXED);
         if (v0) __atomic_fetch_add(&j->c0[id], v0, __ATOMIC_RELAXED);
         if (v1) __atomic_fetch_add(&j->c1[id], v1, __ATOMIC_RELAXED);
@@ -676,13 +681,19 @@ static void *bulk_worker(void *arg) {
 int ho_classify_ids(const ho_classifier *c, const uint8_t *bases, const uint64_t *offsets,
                     const uint32_t *ids, size_t n_reads, uint32_t *c0, uint32_t *c1,
                     uint32_t *neg, uint32_t *seen, int threads) {
+    return ho_classify_ids_votes(c, bases, offsets, ids, n_reads, c0, c1, neg, seen, NULL, threads);
+}
+
+int ho_classify_ids_votes(const ho_classifier *c, const uint8_t *bases, const uint64_t *offsets,
+                          const uint32_t *ids, size_t n_reads, uint32_t *c0, uint32_t *c1,
+                          uint32_t *neg, uint32_t *seen, uint32_t *votes, int threads) {
     if (threads < 1) threads = 1;
     if ((size_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     bulk_job *jobs = (bulk_job *)malloc(sizeof(bulk_job) * (size_t)threads);
     for (int t = 0; t < threads; t++) {
         jobs[t] = (bulk_job){c, bases, offsets, ids, n_reads * (size_t)t / (size_t)threads,
-                             n_reads * (size_t)(t + 1) / (size_t)threads, c0, c1, neg, seen};
+                             n_reads * (size_t)(t + 1) / (size_t)threads, c0, c1, neg, seen, votes};
         if (threads == 1) bulk_worker(&jobs[t]);
         else pthread_create(&th[t], NULL, bulk_worker, &jobs[t]);
     }

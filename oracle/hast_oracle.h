@@ -85,6 +85,10 @@ void     ho_read_votes(const ho_classifier *, const char *seq, size_t slen,
 int      ho_classify_ids(const ho_classifier *, const uint8_t *bases, const uint64_t *offsets,
                          const uint32_t *barcode_ids, size_t n_reads,
                          uint32_t *c0, uint32_t *c1, uint32_t *neg, uint32_t *seen, int threads);
+/* same, and votes[2r], votes[2r+1] (optional) get read r's own (vote0, vote1) */
+int      ho_classify_ids_votes(const ho_classifier *, const uint8_t *bases, const uint64_t *offsets,
+                               const uint32_t *barcode_ids, size_t n_reads, uint32_t *c0, uint32_t *c1,
+                               uint32_t *neg, uint32_t *seen, uint32_t *votes, int threads);
 
 /* ---- secondary oracle: the per-read classifier of stage 03 (BASELINE config 5) ------------------
  * Restatement of /root/reference/03.mkoutput_by_fabulous2.0/src_main/classify.cpp (cited s03:N):

@@ -1,71 +1,130 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_<tag>/ (written by profiles/collect.sh on the GPU box) into the small tracked
-summaries under profiles/:  <tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json, <tag>_pmc.json and
-pmc_traffic.json (the per-launch HBM traffic bench.py reports in roofline.traffic)."""
+"""Turn gpurun_out/prof_<tag>/ (written by profiles/collect.sh on the GPU box) into the small tracked summaries under
+profiles/:  <tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json, <tag>_pmc.json, and the per-launch HBM traffic of
+k_classify that bench.py reports as roofline.traffic / roofline.frac: pmc_traffic.json (default command) or
+pmc_traffic_<flags>.json (e.g. --clustered).
+
+HBM read bytes of a launch, from counters only (no constants from elsewhere):
+    by_size  = 32 * RDREQ_32B + 64 * RDREQ_64B + 128 * RDREQ_128B          (TCC_EA0_RDREQ_*_sum, pass "rdsize")
+    dram_32B = 32 * TCC_EA0_RDREQ_DRAM_32B_sum                              (pass "rddram")
+    fetch    = FETCH_SIZE * 1024                                            (tallies 128-B requests at 64 B on gfx950)
+Each is checked on tools/hbm_randread runs of KNOWN byte count (random 64-B lines, random 128-B blocks); the first method
+whose two calibration factors are both within 3 % of 1 is used, and its factors are recorded next to the result.
+"""
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join("gpurun_out", "prof_" + tag)
-dst = "profiles"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
 
 
-def counters(d):
+def kernel_source_id():
+    h = hashlib.sha256()
+    for f in ("hast_kernels.hip", "hast_common.h", "hast_devutil.h", "hast_device.h"):
+        h.update(open(os.path.join(ROOT, "hast_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters(d, want):
+    """last dispatch's value of every counter of the first kernel whose name contains `want`"""
     f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     out = {}
     if not f:
         return out
     for r in csv.DictReader(open(f[0])):
-        out.setdefault(r["Kernel_Name"].split("(")[0], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if want in r["Kernel_Name"]:
+            out.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: v[-1] for k, v in out.items()}
+
+
+def read_bytes(c):
+    out = {}
+    if "TCC_EA0_RDREQ_64B_sum" in c:
+        out["by_size"] = 32 * c.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 128 * c.get("TCC_EA0_RDREQ_128B_sum", 0)
+    if "TCC_EA0_RDREQ_DRAM_32B_sum" in c:
+        out["dram_32B"] = 32 * c["TCC_EA0_RDREQ_DRAM_32B_sum"]
+    if "FETCH_SIZE" in c:
+        out["fetch"] = 1024 * c["FETCH_SIZE"]
     return out
 
 
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, tag + "_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "stats_bench.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
-bench = json.load(open(os.path.join(src, "stats_bench.json")))
-pmc = {}
+flags = open(os.path.join(src, "flags.txt")).read().strip() if os.path.exists(os.path.join(src, "flags.txt")) else ""
+suffix = "".join(ch for ch in flags.replace("--", "_").replace(" ", "") if ch.isalnum() or ch == "_")
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(src, "stats_bench.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
+
+kc = {}
 for d in sorted(os.listdir(src)):
-    if d.startswith(("pmc_", "cal_")) and os.path.isdir(os.path.join(src, d)):
-        for kern, cs in counters(d).items():
-            if "k_classify" in kern or "k_rand" in kern:
-                for c, v in cs.items():
-                    # last dispatch of the run (k_rand: the 256-iteration launch; k_classify: a timed step)
-                    pmc.setdefault(kern, {})[c] = v[-1]
-cal_line = json.loads(open(os.path.join(src, "cal_FETCH_SIZE.json")).read().strip().splitlines()[-1])
-kr = [k for k in pmc if "k_rand" in k][0]
-kc = [k for k in pmc if "k_classify" in k][0]
-cal_factor = cal_line["bytes"] / (pmc[kr]["FETCH_SIZE"] * 1024.0)
-# FETCH_SIZE tallies every request at 64 B, but on gfx950 a request is a 128-B block (profiles/fetch_calibration.json):
-# k_classify's requests carry 96.7 B on average (both halves of a minimizer's bucket pair in 51 % of them)
-req_bytes = json.load(open(os.path.join(dst, "fetch_calibration.json")))["bytes_per_read_request"]
-fetch_tallied = pmc[kc]["FETCH_SIZE"] * 1024.0 * cal_factor
-fetch = fetch_tallied * req_bytes / 64.0
-write = pmc[kc]["WRITE_SIZE"] * 1024.0
+    if d.startswith("pmc_") and os.path.isdir(os.path.join(src, d)):
+        kc.update(counters(d, "k_classify"))
+cal = {}
+for line in (64, 128):
+    c = {}
+    known = None
+    for d in sorted(os.listdir(src)):
+        if d.startswith("cal%d_" % line) and os.path.isdir(os.path.join(src, d)):
+            c.update(counters(d, "k_rand"))
+            js = os.path.join(src, d + ".json")
+            if os.path.exists(js) and open(js).read().strip():
+                known = json.loads(open(js).read().strip().splitlines()[-1])["bytes"]
+    if c and known:
+        cal[str(line)] = {"known_bytes": known, "counters": c,
+                          "factor_known_over_counter": {m: known / v for m, v in read_bytes(c).items() if v}}
+if not cal:            # flag runs (--clustered ...) reuse the default run's calibration of the same tag family
+    base = os.path.join(dst, tag.rstrip("abcdefghijklmnopqrstuvwxyz_") + "_pmc.json")
+    for cand in (os.path.join(dst, "pmc_calibration.json"), base):
+        if os.path.exists(cand):
+            cal = json.load(open(cand)).get("calibration", {})
+            if cal:
+                break
+rb = read_bytes(kc)
+method = None
+for m in ("by_size", "dram_32B", "fetch"):
+    fs = [cal[l]["factor_known_over_counter"].get(m) for l in cal]
+    if m in rb and rb[m] and fs and all(f and abs(f - 1) < 0.03 for f in fs):
+        method = m
+        break
+write = 1024 * kc.get("WRITE_SIZE", 0)
 summary = {
-    "tag": tag,
-    "command": "python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 (one PMC pass per counter group, --kernel-trace only)",
-    "k_classify_per_launch": pmc[kc],
-    "calibration": {"tool": "tools/hbm_randread 6.4 64 4 256 2048 (random 64-B lines, 4 lanes x 16 B, same shape as k_classify)",
-                    "known_bytes": cal_line["bytes"], "FETCH_SIZE_KB": pmc[kr]["FETCH_SIZE"],
-                    "factor_known_over_counter": cal_factor, "TCC_EA0_RDREQ": pmc[kr].get("TCC_EA0_RDREQ_sum"),
-                    "note": "FETCH_SIZE (KB) x 1024 reads the random-line bytes exactly (factor ~1.00); the gfx950 x2 "
-                            "correction applies to wide coalesced streams only (here: the 2.4 GB of read bases, <2 % of traffic)"},
-    "hbm_bytes_per_launch": fetch + write,
-    "fetch_bytes": fetch, "fetch_bytes_as_tallied_at_64B_per_request": fetch_tallied, "write_bytes": write,
-    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-    "traffic_over_algorithmic": (fetch + write) / bench["roofline"]["algorithmic_bytes_per_launch"],
-    "l2_hit_rate": pmc[kc]["TCC_HIT_sum"] / (pmc[kc]["TCC_HIT_sum"] + pmc[kc]["TCC_MISS_sum"]),
+    "tag": tag, "bench_flags": flags, "kernel_source_id": kernel_source_id(),
+    "command": "python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 %s (one PMC pass per counter group, --kernel-trace only)" % flags,
+    "k_classify_per_launch": kc,
+    "read_bytes_by_method": rb, "method_used": method, "calibration": cal,
+    "write_bytes": write,
+    "batch_reads": bench["config"]["batch_reads"],
 }
+if method:
+    fetch = rb[method]
+    req = kc.get("TCC_EA0_RDREQ_sum")
+    summary.update({
+        "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch,
+        "hbm_read_requests_per_launch": req, "bytes_per_read_request": fetch / req if req else None,
+        "requests_per_read": req / bench["config"]["batch_reads"] if req else None,
+        "algorithmic_bytes_per_launch": bench["roofline"].get("algorithmic_bytes_per_launch") or bench["roofline"].get("algorithmic_equiv", {}).get("bytes_per_launch"),
+    })
+    if "TCC_HIT_sum" in kc:
+        summary["l2_hit_rate"] = kc["TCC_HIT_sum"] / (kc["TCC_HIT_sum"] + kc["TCC_MISS_sum"])
+    if "SQ_INSTS_VALU" in kc:
+        L, K = bench["config"]["read_len"], bench["config"]["k"]
+        summary["valu_lane_instructions_per_window"] = kc["SQ_INSTS_VALU"] * 64 / (bench["config"]["batch_reads"] * (L - K + 1))
+    json.dump({"workload": "c3", "bench_flags": flags, "batch_reads": bench["config"]["batch_reads"],
+               "kernel_source_id": summary["kernel_source_id"],
+               "hbm_bytes_per_launch": fetch + write, "hbm_read_requests_per_launch": req,
+               "bytes_per_read_request": summary["bytes_per_read_request"],
+               "source": "profiles/%s_pmc.json: rocprofv3 --pmc, separate passes; read bytes by method '%s' (calibrated on tools/hbm_randread: "
+                         "factors %s), + WRITE_SIZE" % (tag, method, {l: round(cal[l]["factor_known_over_counter"][method], 4) for l in cal})},
+              open(os.path.join(dst, "pmc_traffic%s.json" % (("_" + suffix.strip("_")) if suffix else "")), "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
-json.dump({"workload": "c3", "batch_reads": bench["config"]["batch_reads"], "hbm_bytes_per_launch": fetch + write,
-           "hbm_read_requests_per_launch": pmc[kc].get("TCC_EA0_RDREQ_sum"),
-           "source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE tallies a request at 64 B, "
-                     "k_classify's 128-B-block requests carry 96.7 B: profiles/fetch_calibration.json)" % tag},
-          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-if os.path.exists("gpurun_out/randread.jsonl"):
-    shutil.copy("gpurun_out/randread.jsonl", os.path.join(dst, tag + "_hbm_randread.jsonl"))
-print(json.dumps(summary, indent=1))
+if cal and not flags:
+    json.dump({"tag": tag, "calibration": cal}, open(os.path.join(dst, "pmc_calibration.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k not in ("calibration",)}, indent=1))

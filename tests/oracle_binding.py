@@ -36,6 +36,8 @@ def load(path):
         "ho_read_votes": (None, [C.c_void_p, C.c_char_p, C.c_size_t, u32p, u32p, C.POINTER(C.c_int)]),
         "ho_classify_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+        "ho_classify_ids_votes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     }
     sig.update({
         "ho_s03_new": (C.c_void_p, []),

@@ -34,3 +34,22 @@ def test_two_ranks_equal_one_process():
     assert two["config"]["reads_total"] == one["config"]["reads_total"] == 6 * 300000
     assert two["hits"] == one["hits"] and two["hits"]["c0"] > 0
     assert two["scaling"] == "weak" and "all_reduce" in two["config"]["collective"]
+
+
+def _n_gpus():
+    import ctypes
+    try:
+        n = ctypes.c_int(0)
+        return n.value if ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: one rank per GPU, all-reduce over RCCL/xGMI")
+def test_two_ranks_over_rccl_equal_one_process():
+    """the driver's N=2 launch, as is: one rank per GPU, nccl(=RCCL) backend, ONE all_reduce(sum,u32) of the counters"""
+    common = ["--workload", "c1", "--batch-reads", "300000", "--cpu-seconds", "0"]
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + common, {})
+    one = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"] + common, {})
+    assert two["n_gpus"] == 2 and two["hits"] == one["hits"] and two["hits"]["c0"] > 0

@@ -491,6 +491,116 @@ def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
     assert int(v0.sum()) > n_reads // 2
 
 
+ADAPTOR_F = b"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA"   # classify.cpp:312
+ADAPTOR_R = b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"   # classify.cpp:313
+
+
+@pytest.mark.parametrize("name,n_keys,n_bc,n_reads,clustered", [
+    ("C2", 50_000_000, 1_000_000, 2_000_000, False),
+    ("C3", 200_000_000, 10_000_000, 2_000_000, False),
+    ("C3-clustered-keys", 200_000_000, 10_000_000, 1_000_000, True),
+])
+def test_baseline_size_configs_vs_oracle(built, oracle_lib, name, n_keys, n_bc, n_reads, clustered):
+    """BASELINE configs 2 and 3 at their full table and barcode sizes (50M+50M keys / 1M barcodes; 200M+200M keys / 10M
+    barcodes, K=21, 150-bp reads): the GPU classifies n_reads synthetic reads against the full-size merged table and the
+    CPU oracle classifies the SAME reads against its own two full-size sets built from the same keys (load_kmers +
+    InitAdaptor, classify.cpp:30-46,314-339; process_reads :186-209).  Set sizes after the adaptor scrub, per-read
+    votes and all n_bc per-barcode (c0, c1, neg) counters must be identical."""
+    k, L = 21, 150
+    threads = len(os.sched_getaffinity(0))
+    p = make_params(k, L, n_keys, n_bc, clustered=clustered)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys, 0.2)
+        ctx.synth_table_build(p)
+        akeys = []
+        for ad in (ADAPTOR_F, ADAPTOR_R):
+            for km in hast_amd.chop_read(ad, k):
+                if km not in akeys:
+                    akeys.append(km)
+        ctx.table_erase(np.array(akeys, dtype=np.uint64))
+        sizes = ctx.table_sizes()
+        ctx.counts_resize(n_bc)
+        d_b, d_i, d_v = ctx.alloc(n_reads * L + 64), ctx.alloc(n_reads * 4), ctx.alloc(n_reads * 8)
+        first = 123_456_789
+        ctx.synth_reads_device(p, first, n_reads, d_b, d_i)
+        ctx.classify_device(d_b, n_reads * L, n_reads, L, d_barcode_ids=d_i, d_votes=d_v)
+        got = ctx.counts_read(n_bc)
+        votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+        bases = ctx.to_host(d_b, (n_reads * L,), np.uint8)
+        ids = ctx.to_host(d_i, (n_reads,), np.uint32)
+        # the oracle's sets from the same keys (device generator == host generator is a test of its own)
+        oc = oracle_lib.ho_new()
+        d_k = ctx.alloc(n_keys * 8)
+        for h in (0, 1):
+            ctx.synth_keys_device(p, h, 0, n_keys, d_k)
+            ctx.sync()
+            keys = ctx.to_host(d_k, (n_keys,), np.uint64)
+            assert oracle_lib.ho_load_keys_mt(oc, keys.ctypes.data, keys.size, h, k, threads) == 0
+            del keys
+        for f in (d_b, d_i, d_v, d_k):
+            ctx.free(f)
+    oracle_lib.ho_init_adaptor(oc, ADAPTOR_F, ADAPTOR_R, None)
+    assert sizes == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1)), name
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    exp_votes = np.zeros((n_reads, 2), np.uint32)
+    e = [np.zeros(n_bc, np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids_votes(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, n_reads, e[0].ctypes.data,
+                                     e[1].ctypes.data, e[2].ctypes.data, None, exp_votes.ctypes.data, threads)
+    oracle_lib.ho_free(oc)
+    assert np.array_equal(votes, exp_votes), name
+    for a, b in zip(got, e):
+        assert np.array_equal(a, b), name
+    assert int(e[0].sum()) + int(e[1].sum()) > n_reads // 2 and int(e[2].sum()) > 0
+
+
+def _n_gpus():
+    import ctypes
+    try:
+        n = ctypes.c_int(0)
+        hip = ctypes.CDLL("libamdhip64.so")
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (RCCL over xGMI between two contexts of one process)")
+def test_counts_allreduce_two_devices(built):
+    """collectBarcodes / BarcodeCache::Add (classify.cpp:57-63,226-229) across two GPUs of one process: each context
+    classifies its half of the reads, hast_counts_allreduce sums the counters in place over RCCL, and both contexts must
+    then hold exactly what one context holds after classifying all the reads."""
+    k, L, n_keys, n_bc, n = 21, 150, 200_000, 5000, 400_000
+    p = make_params(k, L, n_keys, n_bc)
+    ctxs = [hast_amd.Context(k, d) for d in (0, 1)]
+    try:
+        bufs = []
+        for r, ctx in enumerate(ctxs):
+            ctx.table_reserve(2 * n_keys)
+            ctx.synth_table_build(p)
+            ctx.counts_resize(n_bc)
+            h = n // 2
+            d_b, d_i = ctx.alloc(h * L + 64), ctx.alloc(h * 4)
+            ctx.synth_reads_device(p, r * h, h, d_b, d_i)
+            ctx.classify_device(d_b, h * L, h, L, d_barcode_ids=d_i)
+            bufs.append((d_b, d_i))
+        arr = (C.c_void_p * 2)(ctxs[0]._h, ctxs[1]._h)
+        st = hast_amd.lib().hast_counts_allreduce(arr, 2)
+        assert st == 0, hast_amd.lib().hast_last_error()
+        merged = [ctx.counts_read(n_bc) for ctx in ctxs]
+        ctx = ctxs[0]
+        ctx.counts_zero()
+        d_b, d_i = ctx.alloc(n * L + 64), ctx.alloc(n * 4)
+        ctx.synth_reads_device(p, 0, n, d_b, d_i)
+        ctx.classify_device(d_b, n * L, n, L, d_barcode_ids=d_i)
+        single = ctx.counts_read(n_bc)
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+    for m in merged:
+        for a, b in zip(m, single):
+            assert np.array_equal(a, b)
+    assert int(single[0].sum()) > 0
+
+
 def test_randomized_configurations_vs_oracle(built, oracle_lib):
     """Differential fuzz over the kernel's configuration space: K, minimizer length (incl. W > 9 -> runtime-loop
     instantiation), load factor (chain walks), fixed lengths down to L == K (plain-division instantiation), ragged
