@@ -79,6 +79,14 @@ struct hast_ctx {
     // per-read votes of the last barcode-mode launch when the caller gave no buffer for them
     uint32_t *d_votes_scratch = nullptr;
     size_t votes_bytes = 0;
+    // fingerprint filter in front of the table (hast_common.h): rebuilt from the table's live keys before the first
+    // classification after the table gained keys
+    void *d_filter = nullptr;
+    size_t filter_bytes = 0;
+    FilterGeom fg{};
+    bool filter_valid = false;
+    bool use_filter = true;                 // HAST_CLASSIFY=exact: probe the exact table directly (the round-1 kernel)
+    int filter_m = 0, filter_t = 0;         // overrides (0 = by key count)
 };
 
 namespace {
@@ -180,6 +188,9 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     c->device = device;
     c->k = k;
     c->m = default_minimizer(k);
+    if (const char *e = getenv("HAST_CLASSIFY")) c->use_filter = strcmp(e, "exact") != 0;
+    if (const char *e = getenv("HAST_FILTER_M")) c->filter_m = atoi(e);
+    if (const char *e = getenv("HAST_FILTER_T")) c->filter_t = atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     hast_status st = HAST_OK;
@@ -221,6 +232,7 @@ void hast_ctx_destroy(hast_ctx *c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_seg) (void)hipFree(c->d_seg);
     if (c->d_votes_scratch) (void)hipFree(c->d_votes_scratch);
+    if (c->d_filter) (void)hipFree(c->d_filter);
     for (hipEvent_t e : c->t_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -288,6 +300,7 @@ hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     if (c->d_slots) HIP_TRY(hipFree(c->d_slots));
     c->d_slots = nullptr;
     c->nbuckets = 0;
+    c->filter_valid = false;
     // K == 32: two tag-less tables (one per haplotype) back to back, each sized for all the keys
     size_t bytes = (size_t)nb * kSlotsPerBucket * sizeof(uint64_t) * (c->k == 32 ? 2 : 1);
     HIP_TRY(hipMalloc(&c->d_slots, bytes));
@@ -296,6 +309,9 @@ hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     c->nbuckets = (uint32_t)nb;
     return HAST_OK;
 }
+
+// every entry point that adds keys calls this: the filter no longer covers the table
+static void table_changed(hast_ctx *c) { c->filter_valid = false; }
 
 static hast_status need_table(hast_ctx *c, int hap) {
     if (hast_status st = use(c)) return st;
@@ -307,6 +323,7 @@ static hast_status need_table(hast_ctx *c, int hap) {
 hast_status hast_table_insert_keys_device(hast_ctx *c, int hap, const uint64_t *d_keys, size_t n, hast_stream s) {
     if (hast_status st = need_table(c, hap)) return st;
     hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    table_changed(c);
     HIP_TRY(launch_insert_keys(c->d_slots, geom(c), d_keys, n, (uint32_t)hap, c->d_err, hs));
     return check_err_word(c, hs);
 }
@@ -314,6 +331,7 @@ hast_status hast_table_insert_keys_device(hast_ctx *c, int hap, const uint64_t *
 hast_status hast_table_insert_keys(hast_ctx *c, int hap, const uint64_t *keys, size_t n) {
     if (hast_status st = need_table(c, hap)) return st;
     if (n && !keys) return fail(HAST_ERR_INVALID, "keys is null");
+    table_changed(c);
     const size_t per = kChunkBytes / sizeof(uint64_t);
     if (hast_status st = ensure_scratch(c, std::min(n, per) * sizeof(uint64_t) + 16)) return st;
     for (size_t i = 0; i < n; i += per) {
@@ -329,6 +347,7 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
     if (hast_status st = need_table(c, hap)) return st;
     if (lines_out) *lines_out = 0;
     if (nbytes && !text) return fail(HAST_ERR_INVALID, "text is null");
+    table_changed(c);
     const size_t stride = (size_t)c->k + 1;
     // classify.cpp:41: pieces are '\n'-terminated lines; a trailing piece without '\n' is dropped.
     // With fixed-width lines that is floor(nbytes/stride) lines, provided every line really is K bytes
@@ -590,6 +609,30 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The fingerprint filter (hast_common.h): sized from the number of live keys, rebuilt from the table's live slots.
+static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
+    if (c->filter_valid) return HAST_OK;
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(h), hs));
+    HIP_TRY(launch_count_tags(c->d_slots, geom(c), c->d_cnt, hs));
+    HIP_TRY(hipMemcpyAsync(h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
+    const FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t);
+    const size_t bytes = (size_t)filter_nblocks(fg) * 128;
+    if (bytes != c->filter_bytes) {
+        if (c->d_filter) HIP_TRY(hipFree(c->d_filter));
+        c->d_filter = nullptr;
+        c->filter_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_filter, bytes));
+        c->filter_bytes = bytes;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_filter, 0, bytes, hs));
+    HIP_TRY(launch_filter_build(c->d_slots, geom(c), c->d_filter, fg, hs));
+    c->fg = fg;
+    c->filter_valid = true;
+    return HAST_OK;
+}
+
 static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  const uint32_t *d_lens, const uint32_t *d_seg_read, int strict, uint32_t read_len,
                                  const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads, hast_stream s) {
@@ -635,16 +678,31 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.max_pos = read_len >= (uint32_t)c->k ? read_len - c->k + 1 : 0;
     a.mh_stride = read_len >= (uint32_t)c->m ? read_len - c->m + 1 : 0;
     a.w64 = (read_len + 31) / 32;
-    // Reads per tile: at most what fits ~19.5 KB of LDS (8 workgroups per CU) and at most 64; among the
+    // Reads per tile: at most what fits the LDS budget of a workgroup and at most 64; among the
     // candidates take the one whose windows fill the waves' 64-window blocks best (a workgroup walks
     // 4 waves x 2 blocks per iteration: 150-bp reads => 31 reads = 4030 windows = 63 of 64 block slots).
-    // The m-mer hash array is padded by W entries so window-min reads past a read's last window stay in bounds.
-    const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
-    const size_t per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 +
-                            (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
-    const size_t pad = (size_t)wlen * 4 + 64 + 64 + 16;
-    static const size_t lds_budget = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)19968; }();
-    const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (lds_budget - pad) / per_read));
+    hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    const bool filt = c->use_filter;
+    size_t per_read, pad;
+    if (filt) {
+        if (hast_status st = ensure_filter(c, hs)) return st;
+        a.filter = c->d_filter;
+        a.fg = c->fg;
+        a.l1_stride = (read_len >= (uint32_t)c->fg.t ? read_len - (uint32_t)c->fg.t + 1 : 0) + 1;
+        per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.l1_stride * 4 + (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
+        pad = 16 + classify_f_queue_bytes() + 64 * 4 + 64;
+    } else {
+        // The m-mer hash array is padded by W entries so window-min reads past a read's last window stay in bounds.
+        const uint32_t wlen = (uint32_t)(c->k - c->m + 1);
+        a.filter = nullptr;
+        a.fg = FilterGeom{};
+        a.l1_stride = 0;
+        per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 + (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
+        pad = (size_t)wlen * 4 + 64 + 64 + 16;
+    }
+    static const size_t lds_env = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)0; }();
+    const size_t lds_budget = lds_env ? lds_env : (filt ? (size_t)26624 : (size_t)19968);      // 6 / 8 workgroups per CU
+    const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, lds_budget > pad + per_read ? (lds_budget - pad) / per_read : 1));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
         double best = -1;
@@ -665,14 +723,14 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.div_magic = magic((uint64_t)tr * a.max_pos + 1024, a.max_pos);
     a.div_mh = magic((uint64_t)tr * a.mh_stride + 1024, a.mh_stride);
     a.div_hw = magic((uint64_t)tr * a.w64 * 2 + 1024, a.w64 * 2);
+    a.div_l1 = magic((uint64_t)tr * a.l1_stride + 1024, a.l1_stride);
     const uint64_t n_tiles = (n_reads + tr - 1) / tr;
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
     a.tile_queue = c->d_cnt + 3;
-    HIP_TRY(hipMemsetAsync(a.tile_queue, 0, sizeof(unsigned long long), s ? (hipStream_t)s : c->stream));
-    hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    HIP_TRY(hipMemsetAsync(a.tile_queue, 0, sizeof(unsigned long long), hs));
     hipEvent_t *ev = c->t_slots ? &c->t_ev[3 * (c->t_next % c->t_slots)] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], hs));
-    HIP_TRY(launch_classify(a, grid, smem, hs));
+    HIP_TRY(filt ? launch_classify_f(a, grid, smem, hs) : launch_classify(a, grid, smem, hs));
     if (ev) HIP_TRY(hipEventRecord(ev[1], hs));
     if (d_barcode_ids) HIP_TRY(launch_commit_votes(votes_buf, d_barcode_ids, c->d_counts, nullptr, n_reads, hs));
     if (ev) {
@@ -688,6 +746,34 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
                                       hipStream_t hs);
 static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
 static constexpr uint32_t kLongRead = 4096;      // longer reads (with offsets) go through the segmented path
+
+hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t) {
+    if (!c) return fail(HAST_ERR_INVALID, "null context");
+    if (m < 0 || m > c->k || m > kFilterMaxM) return fail(HAST_ERR_INVALID, "filter m=%d out of [0,%d]", m, std::min(c->k, kFilterMaxM));
+    if (t < 0 || (m && t > m)) return fail(HAST_ERR_INVALID, "filter t=%d out of [0,m]", t);
+    c->use_filter = enable != 0;
+    c->filter_m = m;
+    c->filter_t = t;
+    c->filter_valid = false;
+    return HAST_OK;
+}
+
+hast_status hast_filter_build(hast_ctx *c) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (!c->use_filter) return HAST_OK;
+    if (hast_status st = ensure_filter(c, c->stream)) return st;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HAST_OK;
+}
+
+hast_status hast_filter_info(const hast_ctx *c, int *enabled, int *m, int *t, uint64_t *bytes) {
+    if (!c) return fail(HAST_ERR_INVALID, "null context");
+    if (enabled) *enabled = c->use_filter ? 1 : 0;
+    if (m) *m = c->filter_valid ? c->fg.m : 0;
+    if (t) *t = c->filter_valid ? c->fg.t : 0;
+    if (bytes) *bytes = c->filter_valid ? c->filter_bytes : 0;
+    return HAST_OK;
+}
 
 hast_status hast_classify_timing(hast_ctx *c, int n_slots) {
     if (hast_status st = use(c)) return st;
@@ -981,6 +1067,7 @@ hast_status hast_synth_table_build(hast_ctx *c, const hast_synth_params *p) {
     if (hast_status st = need_table(c, 0)) return st;
     if (hast_status st = check_synth(p)) return st;
     if ((int)p->k != c->k) return fail(HAST_ERR_INVALID, "synth k=%u != context K=%d", p->k, c->k);
+    table_changed(c);
     SynthParams sp = resolve(p);
     const size_t per = kChunkBytes / sizeof(uint64_t);
     if (hast_status st = ensure_scratch(c, std::min<uint64_t>(sp.n_keys_per_hap, per) * sizeof(uint64_t) + 16)) return st;

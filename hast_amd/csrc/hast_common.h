@@ -110,6 +110,85 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
     return b + 1 == nbuckets ? 0 : b + 1;
 }
 
+// ---- fingerprint filter (the structure k_classify probes; the exact table above is only consulted for its positives) ----
+//
+// Why: the probe kernel runs at the HBM random-request rate of the part, so the only way to get faster is
+// fewer requests per read.  A request brings a 128-B block whatever is used of it; the exact table spends 8 B per key,
+// so a block can only answer for ~3 keys and the placement function needs m = 16 (W = K-m+1 = 6 consecutive windows
+// share a block at best).  The filter spends 2 B per key, so a block answers for dozens of keys, m can be 13 and the
+// sampling function can be any FORWARD-strand scheme, because every key is filed twice -- under the sampled m-mer of
+// its own string and under that of its reverse complement -- and a read window is looked up under the m-mer sampled
+// from the window as it stands (no canonical m-mers anywhere):
+//     block(window)      = scramble(sampled m-mer of the window's forward string)            (4^m blocks of 128 B)
+//     sub-bucket, print  = from a hash of the window's CANONICAL k-mer                        (8 x 16 B, 8 prints each)
+//   sampling = mod-minimizer (Groot Koerkamp & Pibiri 2024): the window's smallest t-mer (leftmost on ties), position x
+//   among its K-t+1 t-mers, names the m-mer at position x mod W.  With t = r + (m-r) mod W, r = 4, the sampled m-mer stays
+//   put for W consecutive windows and then jumps by W: density ~0.165 at K=21, m=13 (W=9, t=4) against 0.287 for the
+//   exact table's random minimizers (m=16, W=6): 23 instead of 39 blocks per 150-bp read (tools/sim/modmin_filter_sim.py).
+//   When the formula gives t = m the scheme IS the plain forward minimizer (large W).
+// A window whose print is in its sub-bucket, or whose sub-bucket is full (8 prints: then a key may not have found room),
+// is a POSITIVE and is looked up in the exact table, which alone decides hits and tag bits; everything else is a proven
+// miss.  So the filter can only cost time, never change a result.
+struct FilterGeom {
+    int k, m, t;            // k-mer, sampled m-mer (m <= 14, 4^m blocks), ordering t-mer (t <= m)
+    int g;                  // entries per first-level minimum of the kernel's sliding window: min(4, K-t+1)
+    uint32_t wdiv;          // floor(2^16 / W) + 1: x / W for x < 64 by multiply-shift
+};
+constexpr int kFilterSubs = 8;                    // 16-B sub-buckets per 128-B block
+constexpr int kFilterPrints = 8;                  // 16-bit prints per sub-bucket
+constexpr int kFilterMaxM = 14;                   // 4^14 blocks = 34 GB
+HAST_HD uint32_t filter_w(const FilterGeom &g) { return (uint32_t)(g.k - g.m + 1); }
+HAST_HD uint32_t filter_nt(const FilterGeom &g) { return (uint32_t)(g.k - g.t + 1); }
+HAST_HD uint64_t filter_nblocks(const FilterGeom &g) { return 1ull << (2 * g.m); }
+// order of a t-mer: 20 hash bits above 12 position bits; smaller wins, equal t-mers (or equal hashes) -> the leftmost
+HAST_HD uint32_t tmer_order(uint32_t tmer, uint32_t pos) { return ((((tmer + 1u) * 0x9E3779B1u) >> 12) << 12) | pos; }
+// position (0 .. W-1) of the m-mer that names the block of the K-mer string `fwd` (2K bits, first base most significant)
+HAST_HD uint32_t filter_sample_pos(uint64_t fwd, const FilterGeom &g) {
+    const uint32_t nt = filter_nt(g), tmask = (uint32_t)kmer_mask(g.t);
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t j = 0; j < nt; ++j) {
+        const uint32_t e = tmer_order((uint32_t)(fwd >> (2 * (g.k - g.t - (int)j))) & tmask, j);
+        best = e < best ? e : best;
+    }
+    const uint32_t x = best & 0xFFFu;
+    return x - ((x * g.wdiv) >> 16) * filter_w(g);
+}
+// block of an m-mer: a bijective scramble of its 2m bits (odd multiplier mod 4^m), so no two m-mers share a block
+HAST_HD uint32_t filter_block_of(uint32_t mmer, int m) { return (mmer * 0x9E3779B1u) & (uint32_t)kmer_mask(m); }
+HAST_HD uint32_t filter_block_of_string(uint64_t fwd, const FilterGeom &g) {
+    const uint32_t p = filter_sample_pos(fwd, g);
+    return filter_block_of((uint32_t)(fwd >> (2 * (g.k - g.m - (int)p))) & (uint32_t)kmer_mask(g.m), g.m);
+}
+// hash of the canonical key: sub-bucket = top 3 bits, print = 16 bits from the middle, never 0 (0 = free slot)
+HAST_HD uint32_t filter_keyhash(uint64_t canon_key) {
+    uint32_t h = (uint32_t)canon_key * 0x85EBCA6Bu ^ (uint32_t)(canon_key >> 32) * 0xC2B2AE35u;
+    h ^= h >> 15;
+    return h * 0x9E3779B1u;
+}
+HAST_HD uint32_t filter_sub_of(uint32_t keyhash) { return keyhash >> 29; }
+HAST_HD uint32_t filter_print_of(uint32_t keyhash) {
+    const uint32_t f = (keyhash >> 8) & 0xFFFFu;
+    return f ? f : 1u;
+}
+// geometry for K and a key count: the smallest m (>= 8, <= 14, <= K) whose 4^m blocks keep the average block at <= 12
+// of its 64 prints (two prints per key), and the t the mod-minimizer wants for that m
+HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t_override) {
+    FilterGeom g;
+    g.k = k;
+    int m = k < 8 ? k : 8;
+    while (m < k && m < kFilterMaxM && (1ull << (2 * m)) * 6 < n_keys) ++m;
+    if (m_override >= 1 && m_override <= k && m_override <= kFilterMaxM) m = m_override;
+    g.m = m;
+    const int w = k - m + 1, r = m < 4 ? m : 4;
+    int t = r + (m - r) % w;
+    if (t_override >= 1 && t_override <= m) t = t_override;
+    g.t = t;
+    const int nt = k - t + 1;
+    g.g = nt < 4 ? nt : 4;
+    g.wdiv = (65536u / (uint32_t)w) + 1u;
+    return g;
+}
+
 // ---- synthetic workload ----------------------------------------------------------
 HAST_HD uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;

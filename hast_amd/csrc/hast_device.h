@@ -37,6 +37,11 @@ struct ClassifyArgs {
     int m;                       // minimizer length
     int wide;                    // K == 32: probe the two per-haplotype tables (slots, slots + nbuckets*8)
     int strict;                  // per-window validity (stage-03 string semantics) instead of the whole-read N skip
+    // ---- filter front end (k_classify_f); unused by the exact-table kernel
+    const void *filter;          // 4^fg.m blocks of 128 B
+    FilterGeom fg;
+    uint32_t l1_stride;          // first-level sliding-minimum entries per read (row stride)
+    uint32_t div_l1;             // exact multiply-high division by l1_stride, or 0
 };
 
 hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t hap,
@@ -49,6 +54,10 @@ hipError_t launch_export_slots(const uint64_t *slots, size_t nslots, uint64_t *d
 hipError_t launch_import_slots(uint64_t *slots, TableGeom g, const uint64_t *d_in, size_t n, uint32_t *d_err, hipStream_t s);
 hipError_t launch_count_tags(const uint64_t *slots, TableGeom g, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
+// filter front end: builds the filter from the live slots of the exact table; classify through it
+hipError_t launch_filter_build(const uint64_t *slots, TableGeom g, void *filter, FilterGeom fg, hipStream_t s);
+hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
+size_t classify_f_queue_bytes();      // LDS the kernel needs besides the per-read arrays
 hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
                                  uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
                                  hipStream_t s);

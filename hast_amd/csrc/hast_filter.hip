@@ -1,0 +1,395 @@
+// hast_filter.hip -- gfx950 (MI355X, CDNA4) device code: the fingerprint filter in front of the exact k-mer table and the
+// classify kernel that probes it (k_classify_f).  See hast_common.h ("fingerprint filter") for the structure and why it
+// exists: the probe is bound by the HBM random-request rate, and this front end needs 23 instead of 39 requests per
+// 150-bp read while doing less arithmetic per window.  Results are decided by the exact table alone (every positive of
+// the filter is looked up there), so the reference semantics implemented are exactly those of hast_kernels.hip:
+//   classify.cpp:182-209 (containN + process_reads), kmer/kmer.h:11,153-166,169-194 (coding, canonical k-mers).
+#include "hast_common.h"
+#include "hast_device.h"
+#include "hast_devutil.h"
+
+namespace hast {
+
+// ------------------------------------------------------------------------------------------
+// Filter build: every live key of the exact table is filed under the block of its own string and under the block of its
+// reverse complement (a read window is looked up under the block of the window as it stands).  A sub-bucket holds 8
+// 16-bit prints that fill in order (0 = free); a key that finds its sub-bucket full is simply not filed: lookups treat a
+// full sub-bucket as "ask the exact table".
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void filter_insert(uint32_t *filt, const FilterGeom g, uint64_t key) {
+    const uint32_t h = filter_keyhash(key), sub = filter_sub_of(h), fp = filter_print_of(h);
+    uint32_t first_blk = 0xFFFFFFFFu;
+    for (int o = 0; o < 2; ++o) {
+        const uint64_t s = o ? kmer_revcomp(key, g.k) : key;
+        if (o && s == key) break;                                    // its own reverse complement
+        const uint32_t blk = filter_block_of_string(s, g);
+        if (blk == first_blk) break;                                 // both strands name the same block
+        first_blk = blk;
+        uint32_t *w = filt + (size_t)blk * (kFilterSubs * kFilterPrints / 2) + sub * (kFilterPrints / 2);
+        for (int i = 0; i < kFilterPrints / 2;) {
+            const uint32_t v = __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+            if (lo == fp || hi == fp) break;                         // an equal print is already there
+            uint32_t nv;
+            if (lo == 0) nv = v | fp;
+            else if (hi == 0) nv = v | (fp << 16);
+            else { ++i; continue; }
+            if (atomicCAS(&w[i], v, nv) == v) break;                 // else: someone else wrote this word, look again
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_filter_build(const uint64_t *slots, size_t nslots, uint32_t *filt, FilterGeom g, int wide) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nslots; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t s = slots[i];
+        if (wide) {
+            if (s < kTombSlot) filter_insert(filt, g, s);
+        } else if (s != kEmptySlot && (s & 3)) filter_insert(filt, g, s >> 2);
+    }
+}
+
+hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter, FilterGeom fg, hipStream_t s) {
+    const size_t nslots = (size_t)tg.nbuckets * kSlotsPerBucket * (tg.wide ? 2 : 1);
+    size_t grid = (nslots + 255) / 256;
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(k_filter_build, dim3((unsigned)grid), dim3(256), 0, s, slots, nslots, (uint32_t *)filter, fg, tg.wide);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_classify_f.  Workgroup = 256 threads = 4 wave64; tiles of TR reads go through LDS:
+//   A  pack   : as hast_kernels.hip: 16 ASCII bases per lane -> 32 bits of 2-bit codes; 'N' flag / invalid-byte mask.
+//   M  order  : one lane per t-mer position: e = tmer_order(t-mer, position); the first level of the sliding minimum,
+//               L1[q] = min(e[q .. q+g-1]) (g = 4), is formed in registers with two wave shuffles and stored.  A window's
+//               smallest t-mer (leftmost on ties) is then the minimum of ceil((K-t+1)/4) L1 entries.
+//   B  probe  : every LANE owns one window: forward K-mer by funnel shift out of the packed LDS words, canonical key
+//               (v_bfrev), smallest t-mer -> position x -> the m-mer at x mod W names the 128-B block, the key's hash the
+//               16-B sub-bucket and the 16-bit print.  ONE 16-B load per window; consecutive windows (adjacent lanes)
+//               mostly name the same block, which the memory system fetches once.  Blocks of 64 windows are software-
+//               pipelined (loads of block i+1 are in flight while block i is compared).  Compare = 4 xor + 3 v_pk_min_u16
+//               + has-zero-halfword.  Positives (print found, or sub-bucket full) -- the real hits, about 1 % of the
+//               windows, plus a few in 10^5 false ones -- go to the wave's own queue in LDS.
+//   V  verify : when a wave's queue holds 64 positives (and at the end of the tile) each lane takes one, finds it in the
+//               exact table (home bucket by the table's own minimizer, then the chain) and adds its tag bits to the
+//               read's votes in LDS.
+//   C  votes  : one lane per read stores {vote0, vote1}; k_commit_votes does the per-barcode bookkeeping.
+// ------------------------------------------------------------------------------------------
+constexpr int kThreadsF = 256;
+constexpr int kQCap = 128;                                    // queue entries per wave: < 64 waiting + <= 64 new
+#ifndef HAST_F_MINWAVES
+#define HAST_F_MINWAVES 6
+#endif
+typedef unsigned long long u64x2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2f __attribute__((ext_vector_type(2)));
+
+size_t classify_f_queue_bytes() { return (size_t)4 * kQCap * 3 * sizeof(uint32_t); }
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    const u16x2f r = __builtin_elementwise_min(__builtin_bit_cast(u16x2f, a), __builtin_bit_cast(u16x2f, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {          // set bits of mask below my lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// NTC = first-level minima per window, ceil((K-t+1)/g), when known at compile time (0 = runtime loop)
+template <int NTC, bool FAST, bool STRICT, bool WIDE>
+__global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(ClassifyArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t TR = a.tile_reads;
+    const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
+    const uint32_t L1S = a.l1_stride;
+    unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);            // next tile of this workgroup
+    unsigned long long *s_pack = s_tile + 2;                                               // [TR][WS]
+    unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
+    unsigned long long *s_off = s_vote + TR;                                               // [TR]
+    uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
+    uint32_t *s_flag = s_len + TR;                                                         // [TR]
+    uint32_t *s_q = s_flag + TR;                                                           // [4][3][kQCap]
+    uint32_t *s_l1 = s_q + 4 * 3 * kQCap;                                                  // [TR][L1S] (+ 64 pad)
+    const uint32_t IW = 2 * a.w64 + 1;                                                     // invalid-byte mask words per read
+    uint32_t *s_inv = s_l1 + (size_t)TR * L1S + 64;                                        // [TR][IW], STRICT only
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = tid >> 6;
+    uint32_t *q_lo = s_q + wave * 3 * kQCap, *q_hi = q_lo + kQCap, *q_rd = q_hi + kQCap;
+    const FilterGeom fg = a.fg;
+    const int K = a.k, M = fg.m, T = fg.t;
+    const uint32_t G = (uint32_t)fg.g, W = filter_w(fg), NT = filter_nt(fg);
+    const uint32_t ntc = NTC ? (uint32_t)NTC : (NT + G - 1) / G;
+    const uint32_t kshift = 64 - 2 * K, tshift = 64 - 2 * T;
+    const uint32_t mmask = (uint32_t)kmer_mask(M);
+    const uint32_t nb = a.nbuckets;
+    const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
+    const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
+    const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
+    const u32x4f *filt = reinterpret_cast<const u32x4f *>(a.filter);
+    const u64x2f *tab0 = reinterpret_cast<const u64x2f *>(a.slots);
+
+    if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
+    __syncthreads();
+    for (;;) {
+        const uint64_t tile = *s_tile;
+        if (tile >= n_tiles) break;
+        const uint64_t r0 = tile * TR;
+        const uint32_t tra = (uint32_t)((a.n_reads - r0 < TR) ? (a.n_reads - r0) : TR);
+
+        // ---- per-read header --------------------------------------------------------------
+        if (tid < tra) {
+            uint64_t off, len;
+            if (a.offsets) { off = a.offsets[r0 + tid]; len = a.lens ? a.lens[r0 + tid] : a.offsets[r0 + tid + 1] - off; }
+            else           { off = (r0 + tid) * (uint64_t)a.read_len; len = a.read_len; }
+            if (len > a.read_len) len = a.read_len;          // contract: read_len bounds every read
+            s_off[tid] = off;
+            s_len[tid] = (uint32_t)len;
+            s_flag[tid] = 0;
+            s_vote[tid] = 0;
+        }
+        __syncthreads();
+        // everyone has read `tile`: fetch the next one now; the barriers below publish it before the loop top reads it
+        if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
+
+        // ---- A: pack ----------------------------------------------------------------------
+        const uint32_t HW = a.w64 * 2;                                // 16-base half-words per read
+        for (uint32_t t = tid; t < tra * HW; t += kThreadsF) {
+            const uint32_t r = FAST ? __umulhi(t, a.div_hw) : (t / HW);
+            const uint32_t j = t - r * HW;
+            const uint32_t len = s_len[r];
+            if (16 * j >= len) continue;
+            const uint32_t nbases = (len - 16 * j < 16) ? (len - 16 * j) : 16;
+            const uintptr_t addr = base_addr + s_off[r] + 16 * j;
+            const uintptr_t a4 = addr & ~(uintptr_t)3;
+            const uint32_t bsh = (uint32_t)(addr & 3);
+            uint32_t d[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                uintptr_t p = a4 + 4 * i;
+                d[i] = (p < end_addr) ? *reinterpret_cast<const uint32_t *>(p) : 0x41414141u;
+            }
+            uint32_t packed = 0, nflag = 0, invalid = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], bsh);   // bytes addr+4i .. +4i+3
+                int vb = (int)nbases - 4 * i;                                    // valid bytes in x
+                if (vb < 4) {
+                    uint32_t m = (vb <= 0) ? 0u : ((1u << (8 * vb)) - 1u);
+                    x = (x & m) | (0x41414141u & ~m);                            // pad with 'A'
+                }
+                if (STRICT) invalid = (invalid << 4) | not_acgt4(x);
+                else nflag |= has_byte_N(x);
+                packed = (packed << 8) | pack4(x);
+            }
+            // 64-bit LDS word w = bases 32w..32w+31, first base most significant: even half-word = HIGH 32 bits
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_pack + (size_t)r * WS + (j >> 1)) + (1 - (j & 1));
+            *dst = packed;
+            if (STRICT) {
+                uint16_t *di = reinterpret_cast<uint16_t *>(s_inv + (size_t)r * IW + (j >> 1)) + (1 - (j & 1));
+                *di = (uint16_t)invalid;
+            } else if (nflag) atomicOr(&s_flag[r], 1u);
+        }
+        __syncthreads();
+
+        // ---- M: t-mer order, first level of the sliding minimum (in registers, two shuffles) ----------------
+        {
+            const uint32_t total = tra * L1S, step = 64 - (G - 1);
+            for (uint32_t b0 = wave * step; b0 < total; b0 += 4 * step) {
+                const uint32_t idx = b0 + lane;
+                uint32_t r = FAST ? __umulhi(idx, a.div_l1) : (idx / L1S);
+                uint32_t q = idx - r * L1S;
+                const bool in = idx < total;
+                r = in ? r : 0;
+                const bool valid = in && (q + T <= s_len[r]);
+                q = valid ? q : 0;
+                const uint32_t tm = (uint32_t)window_bits(s_pack + (size_t)r * WS, q, tshift);
+                const uint32_t e = valid ? tmer_order(tm, q) : 0xFFFFFFFFu;
+                uint32_t mn = e;
+                if (G == 4) {
+                    const uint32_t m2 = min(e, (uint32_t)__shfl_down((int)e, 1));
+                    mn = min(m2, (uint32_t)__shfl_down((int)m2, 2));
+                } else {
+                    if (G >= 2) mn = min(mn, (uint32_t)__shfl_down((int)e, 1));
+                    if (G >= 3) mn = min(mn, (uint32_t)__shfl_down((int)e, 2));
+                }
+                if (lane < step && in) s_l1[idx] = mn;
+            }
+        }
+        __syncthreads();
+        if (!STRICT) {          // reads with 'N' get length 0 (whole-read skip, classify.cpp:190-193)
+            if (tid < tra && s_flag[tid]) s_len[tid] = 0;
+            __syncthreads();
+        }
+
+        // ---- B: probe.  Each wave walks the 64-window blocks wave, wave+4, ... ---------------------------------
+        const uint32_t P = a.max_pos;                                 // windows per read (stride)
+        const uint32_t Q = tra * P;
+        const uint32_t nblk = (Q + 63) >> 6;
+        uint32_t qn = 0;                                              // positives waiting in this wave's queue
+        // V: the last `cnt` queue entries, one per lane, against the exact table
+        auto drain = [&](uint32_t cnt) {
+            const bool act = lane < cnt;
+            const uint32_t e = act ? qn - cnt + lane : 0;
+            const unsigned long long key = ((unsigned long long)q_hi[e] << 32) | q_lo[e];
+            const uint32_t rd = q_rd[e];
+            qn -= cnt;
+            for (int pass = 0; pass < (WIDE ? 2 : 1); ++pass) {
+                const u64x2f *tab = tab0 + (WIDE ? (size_t)pass * nb * kPieces : 0);
+                const unsigned long long want = WIDE ? key : (key << 2);
+                uint32_t b = act ? home_bucket(key, K, a.m, nb) : 0;
+                bool pending = act;
+                uint32_t step = 0;
+                while (__any(pending)) {
+                    u64x2f s[kPieces];
+#pragma unroll
+                    for (int l = 0; l < kPieces; ++l) s[l] = u64x2f{kEmptySlot, kEmptySlot};
+                    if (pending) {
+#pragma unroll
+                        for (int l = 0; l < kPieces; ++l) s[l] = tab[(size_t)b * kPieces + l];
+                    }
+                    unsigned long long hit_slot = 0;
+                    bool hit = false;
+#pragma unroll
+                    for (int l = 0; l < kPieces; ++l) {
+                        if ((WIDE ? s[l].x : (s[l].x & ~3ull)) == want) { hit_slot = s[l].x; hit = true; }
+                        if ((WIDE ? s[l].y : (s[l].y & ~3ull)) == want) { hit_slot = s[l].y; hit = true; }
+                    }
+                    hit = hit && pending;
+                    if (hit) {
+                        const uint32_t tags = WIDE ? (1u << pass) : (uint32_t)(hit_slot & 3);
+                        if (tags) atomicAdd(&s_vote[rd], (unsigned long long)(tags & 1) | ((unsigned long long)(tags >> 1) << 32));
+                    }
+                    // slots fill in order: the bucket is full iff its last slot is taken; only then the chain goes on
+                    if (pending && (hit || s[kPieces - 1].y == kEmptySlot || ++step >= nb)) pending = false;
+                    if (pending) b = next_bucket(b, step, key, nb);
+                }
+            }
+        };
+        struct Blk {
+            u32x4f v;                                   // the 8 prints of this lane's window's sub-bucket
+            uint32_t klo, khi, fpw, meta;               // canonical key, print in both halves, read | valid << 31
+        };
+        auto start = [&](Blk &B, uint32_t blk) {
+            const uint32_t q = blk * 64 + lane;
+            uint32_t r = FAST ? __umulhi(q, a.div_magic) : (q / P);
+            const bool inq = q < Q;
+            r = inq ? r : 0;
+            const uint32_t p = inq ? q - r * P : 0;
+            bool ok = inq && (p + K <= s_len[r]);
+            if (STRICT) {           // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
+                const uint32_t *iw = s_inv + r * IW + (p >> 5);
+                const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
+                ok = ok && (bits >> (64 - K)) == 0;
+            }
+            const unsigned long long fwd = window_bits(s_pack + (size_t)r * WS, p, kshift);
+            const unsigned long long ck = kmer_canon(fwd, K);
+            const uint32_t *l1 = s_l1 + r * L1S + p;
+            uint32_t x = l1[0];
+            if (NTC) {
+#pragma unroll
+                for (int c = 1; c + 1 < (NTC ? NTC : 1); ++c) x = min(x, l1[c * 4]);
+            } else {
+                for (uint32_t c = 1; c + 1 < ntc; ++c) x = min(x, l1[c * G]);
+            }
+            if (ntc > 1) x = min(x, l1[NT - G]);
+            const uint32_t xr = ((x & 0xFFFu) - p) & 63u;             // position of the smallest t-mer inside the window
+            uint32_t pm = xr - ((xr * fg.wdiv) >> 16) * W;            // ... mod W = position of the sampled m-mer
+            pm = ok ? pm : 0;
+            const uint32_t mm = (uint32_t)(fwd >> (2 * ((uint32_t)(K - M) - pm))) & mmask;
+            const uint32_t fb = filter_block_of(mm, M);
+            const uint32_t h = filter_keyhash(ck);
+            B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
+            B.klo = (uint32_t)ck;
+            B.khi = (uint32_t)(ck >> 32);
+            B.fpw = filter_print_of(h) * 0x00010001u;
+            B.meta = r | (ok ? 0x80000000u : 0u);
+        };
+        auto finish = [&](Blk &B) {
+            const uint32_t acc = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
+            const bool match = ((acc - 0x00010001u) & ~acc & 0x80008000u) != 0;      // some halfword of acc is zero
+            const bool full = (B.v.w >> 16) != 0;
+            const bool pos = (int)B.meta < 0 && (match || full);
+            const unsigned long long pmask = __ballot(pos);
+            if (pmask) {
+                const uint32_t at = qn + lanes_below(pmask);
+                if (pos) {
+                    q_lo[at] = B.klo;
+                    q_hi[at] = B.khi;
+                    q_rd[at] = B.meta & 0xFFFFu;
+                }
+                qn += (uint32_t)__popcll(pmask);
+                if (qn >= 64) drain(64);
+            }
+        };
+        {
+            Blk A, B;
+            uint32_t blk = wave;
+            bool va = blk < nblk;
+            if (va) start(A, blk);
+            blk += 4;
+            while (va) {
+                const bool vb = blk < nblk;
+                if (vb) start(B, blk);
+                blk += 4;
+                finish(A);
+                if (!vb) break;
+                va = blk < nblk;
+                if (va) start(A, blk);
+                blk += 4;
+                finish(B);
+            }
+            while (qn) drain(qn < 64 ? qn : 64);
+        }
+        __syncthreads();
+
+        // ---- C: the read's votes out (the per-barcode bookkeeping is k_commit_votes' job) ----------------
+        if (tid < tra) {
+            const unsigned long long v = s_vote[tid];
+            if (a.votes) {
+                if (a.seg_read) {                 // rows are segments of long reads: add into the read's (zeroed) row
+                    uint32_t *row = a.votes + 2 * (size_t)a.seg_read[r0 + tid];
+                    if ((uint32_t)v) atomicAdd(row, (uint32_t)v);
+                    if ((uint32_t)(v >> 32)) atomicAdd(row + 1, (uint32_t)(v >> 32));
+                } else {
+                    reinterpret_cast<unsigned long long *>(a.votes)[r0 + tid] = v;       // {vote0, vote1}: one coalesced 8-byte store
+                }
+            }
+        }
+        // no barrier needed here: the next tile's header only touches this lane's own s_* entries
+        // and is followed by a barrier before anyone else reads them.
+    }
+}
+
+template <int NTC, bool FAST, bool STRICT, bool WIDE = false>
+static hipError_t launch_f_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+    if (smem > (48u << 10)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE>), dim3(grid), dim3(kThreadsF), smem, s, a);
+    return hipGetLastError();
+}
+
+template <bool STRICT>
+static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+    const bool fast = a.div_magic && a.div_l1 && a.div_hw;
+    if (a.wide) return fast ? launch_f_t<0, true, STRICT, true>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true>(a, grid, smem, s);
+    if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT>(a, grid, smem, s) : launch_f_t<0, false, STRICT>(a, grid, smem, s);
+    switch ((filter_nt(a.fg) + 3) / 4) {
+    case 1: return launch_f_t<1, true, STRICT>(a, grid, smem, s);
+    case 2: return launch_f_t<2, true, STRICT>(a, grid, smem, s);
+    case 3: return launch_f_t<3, true, STRICT>(a, grid, smem, s);
+    case 4: return launch_f_t<4, true, STRICT>(a, grid, smem, s);
+    case 5: return launch_f_t<5, true, STRICT>(a, grid, smem, s);
+    case 6: return launch_f_t<6, true, STRICT>(a, grid, smem, s);
+    default: return launch_f_t<0, true, STRICT>(a, grid, smem, s);
+    }
+}
+
+hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+    if (a.n_reads == 0) return hipSuccess;
+    return a.strict ? launch_f_s<true>(a, grid, smem, s) : launch_f_s<false>(a, grid, smem, s);
+}
+
+}  // namespace hast

@@ -111,6 +111,18 @@ hast_status hast_table_file_info(const char *path, int *k_out, uint64_t *n_keys_
 /* geometry, for roofline accounting */
 hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *bytes);
 
+/* ---- the fingerprint filter in front of the table ----------------------------------------------
+ * What hast_classify_* actually probes (hast_amd/csrc/hast_common.h): 16-bit prints of every key,
+ * in 128-B blocks named by a forward mod-minimizer of the key's string and of its reverse complement, so that the
+ * consecutive windows of a read ask for few blocks.  A window the filter cannot rule out is looked up in the table
+ * above, which alone decides hits, so results never depend on the filter.  It is (re)built from the table's live keys
+ * by the first classification after keys were added, or explicitly by hast_filter_build (e.g. outside a timed region).
+ * hast_ctx_set_filter: enable = 0 probes the table directly (the round-1 kernel; also HAST_CLASSIFY=exact in the
+ * environment); m, t = 0 picks the geometry from K and the key count. */
+hast_status hast_ctx_set_filter(hast_ctx *, int enable, int m, int t);
+hast_status hast_filter_build(hast_ctx *);
+hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, uint64_t *bytes);
+
 /* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
  * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:
  *   c0/c1 = sum of per-read votes for key 0/1 (classify.cpp:203-206), neg = key -1 (:191,:207-208).

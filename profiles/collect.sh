@@ -21,6 +21,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 echo "$FLAGS" > $OUT/flags.txt
+python3 -c "import bench; print(bench.kernel_source_id())" > $OUT/kernel_source_id.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $FLAGS > $OUT/stats_bench.json 2> $OUT/stats_bench.err
 declare -A PASS
 PASS[rdsize]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"

@@ -8,8 +8,13 @@ HBM read bytes of a launch, from counters only (no constants from elsewhere):
     by_size  = 32 * RDREQ_32B + 64 * RDREQ_64B + 128 * RDREQ_128B          (TCC_EA0_RDREQ_*_sum, pass "rdsize")
     dram_32B = 32 * TCC_EA0_RDREQ_DRAM_32B_sum                              (pass "rddram")
     fetch    = FETCH_SIZE * 1024                                            (tallies 128-B requests at 64 B on gfx950)
-Each is checked on tools/hbm_randread runs of KNOWN byte count (random 64-B lines, random 128-B blocks); the first method
-whose two calibration factors are both within 3 % of 1 is used, and its factors are recorded next to the result.
+Each is checked on tools/hbm_randread runs of KNOWN byte count: random 128-B blocks (every byte of a request is asked
+for) and random 64-B lines.  What the counters show on gfx950 (profiles/pmc_calibration.json): EVERY L2->fabric read
+request is a 128-B request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ, RDREQ_DRAM_32B == 4 per request) -- a random 64-B line
+costs a 128-B fetch, so for the 64-B run the counters read exactly twice the bytes the kernel asked for, and FETCH_SIZE
+(which prices a request at 64 B) reads half of what moved.  HBM traffic = bytes MOVED = the first method whose factor on the
+128-B run is within 3 % of 1 and which agrees with the DRAM-side count; the 64-B run's factor is recorded as the evidence
+for the fetch granule.
 """
 import csv
 import glob
@@ -27,7 +32,7 @@ dst = os.path.join(ROOT, "profiles")
 
 def kernel_source_id():
     h = hashlib.sha256()
-    for f in ("hast_kernels.hip", "hast_common.h", "hast_devutil.h", "hast_device.h"):
+    for f in ("hast_kernels.hip", "hast_filter.hip", "hast_common.h", "hast_devutil.h", "hast_device.h"):
         h.update(open(os.path.join(ROOT, "hast_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -90,13 +95,18 @@ if not cal:            # flag runs (--clustered ...) reuse the default run's cal
 rb = read_bytes(kc)
 method = None
 for m in ("by_size", "dram_32B", "fetch"):
-    fs = [cal[l]["factor_known_over_counter"].get(m) for l in cal]
-    if m in rb and rb[m] and fs and all(f and abs(f - 1) < 0.03 for f in fs):
+    f128 = cal.get("128", {}).get("factor_known_over_counter", {}).get(m)
+    if m in rb and rb[m] and f128 and abs(f128 - 1) < 0.03:
+        if m == "by_size" and "dram_32B" in rb and abs(rb["by_size"] / rb["dram_32B"] - 1) > 0.01:
+            continue
         method = m
         break
 write = 1024 * kc.get("WRITE_SIZE", 0)
 summary = {
-    "tag": tag, "bench_flags": flags, "kernel_source_id": kernel_source_id(),
+    "tag": tag, "bench_flags": flags,
+    # identifies the device code the box ran (written there by collect.sh); the local tree's id when that file is missing
+    "kernel_source_id": (open(os.path.join(src, "kernel_source_id.txt")).read().strip()
+                         if os.path.exists(os.path.join(src, "kernel_source_id.txt")) else kernel_source_id()),
     "command": "python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 %s (one PMC pass per counter group, --kernel-trace only)" % flags,
     "k_classify_per_launch": kc,
     "read_bytes_by_method": rb, "method_used": method, "calibration": cal,
@@ -122,7 +132,7 @@ if method:
                "hbm_bytes_per_launch": fetch + write, "hbm_read_requests_per_launch": req,
                "bytes_per_read_request": summary["bytes_per_read_request"],
                "source": "profiles/%s_pmc.json: rocprofv3 --pmc, separate passes; read bytes by method '%s' (calibrated on tools/hbm_randread: "
-                         "factors %s), + WRITE_SIZE" % (tag, method, {l: round(cal[l]["factor_known_over_counter"][method], 4) for l in cal})},
+                         "known/counted = %s; every read request on gfx950 is a 128-B fetch), + WRITE_SIZE" % (tag, method, {l + "-B run": round(cal[l]["factor_known_over_counter"][method], 4) for l in cal})},
               open(os.path.join(dst, "pmc_traffic%s.json" % (("_" + suffix.strip("_")) if suffix else "")), "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 if cal and not flags:

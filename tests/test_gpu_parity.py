@@ -491,6 +491,108 @@ def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
     assert int(v0.sum()) > n_reads // 2
 
 
+@pytest.mark.parametrize("k,fm,ft,n_keys,lf", [
+    (21, 0, 0, 30000, 0.2),       # geometry by key count
+    (21, 8, 0, 400000, 0.2),      # 4^8 blocks for 800k prints: most sub-buckets FULL -> everything is verified in the table
+    (21, 13, 4, 30000, 0.2),      # the BASELINE geometry (mod-minimizer, W=9, t=4) on a small table
+    (21, 14, 6, 30000, 0.85),     # other sweet spot; exact table with overflow chains
+    (21, 12, 3, 30000, 0.2),      # t not congruent to m: still exact, only denser
+    (31, 14, 0, 30000, 0.2),      # plain forward minimizer, W=18
+    (32, 10, 5, 30000, 0.2),      # wide keys
+    (9, 9, 9, 3000, 0.2), (6, 3, 2, 1500, 0.2), (2, 2, 1, 10, 0.2), (1, 1, 1, 2, 0.2),
+])
+def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, ft, n_keys, lf):
+    """The fingerprint filter may only cost time: for every geometry (incl. overfull filters, t-mers that do not fit the
+    mod-minimizer rule, plain minimizers, W = 1) per-read votes and per-barcode counts must equal the oracle's, and equal
+    what the exact table gives when probed directly (hast_ctx_set_filter(enable = 0))."""
+    L, n_bc, n_reads = 150 if k <= 21 else 400, 500, 20000
+    p = make_params(k, L, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    bases, ids = hast_amd.synth_reads_host(p, 5, n_reads)
+    # ragged lengths incl. reads shorter than K, and a few reads with N / lower case
+    rng = np.random.default_rng(k * 131 + fm)
+    lens = rng.integers(max(1, k - 2), L + 1, n_reads).astype(np.uint64)
+    lens[::7] = L
+    off = np.zeros(n_reads + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    rag = np.concatenate([bases[i * L:i * L + int(lens[i])] for i in range(n_reads)])
+    for i in range(0, n_reads, 97):
+        rag[int(off[i])] |= 0x20
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    exp_votes = np.zeros((n_reads, 2), np.uint32)
+    e = [np.zeros(n_bc, np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids_votes(oc, rag.ctypes.data, off.ctypes.data, ids.ctypes.data, n_reads, e[0].ctypes.data,
+                                     e[1].ctypes.data, e[2].ctypes.data, None, exp_votes.ctypes.data, 4)
+    oracle_lib.ho_free(oc)
+    for enable in (True, False):
+        with hast_amd.Context(k) as ctx:
+            ctx.set_filter(enable, fm if enable else 0, ft if enable else 0)
+            ctx.table_reserve(2 * n_keys, lf)
+            ctx.table_insert_keys(0, keys[0])
+            ctx.table_insert_keys(1, keys[1])
+            ctx.counts_resize(n_bc)
+            d_b, d_o, d_i, d_v = ctx.to_device(rag), ctx.to_device(off), ctx.to_device(ids), ctx.alloc(n_reads * 8)
+            ctx.classify_device(d_b, rag.size, n_reads, L, d_offsets=d_o, d_barcode_ids=d_i, d_votes=d_v)
+            got = ctx.counts_read(n_bc)
+            votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+            en, m, t, nbytes = ctx.filter_info()
+            assert en == enable
+            if enable:
+                assert nbytes == 128 * 4 ** m and 1 <= t <= m <= min(k, 14)
+                if fm:
+                    assert m == fm
+                if ft:
+                    assert t == ft
+        assert np.array_equal(votes, exp_votes), (k, fm, ft, enable)
+        for a, b in zip(got, e):
+            assert np.array_equal(a, b), (k, fm, ft, enable)
+    assert k < 6 or int(exp_votes.sum()) > 0
+
+
+def test_filter_follows_the_table(built, oracle_lib):
+    """Keys added after a classification must be seen by the next one (the filter is rebuilt), erased keys must stop
+    counting (the table decides), and a second table in the same context must not see the first one's prints."""
+    k, L, n_keys, n_bc, n_reads = 21, 150, 20000, 50, 8000
+    p = make_params(k, L, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    bases, ids = hast_amd.synth_reads_host(p, 0, n_reads)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+
+    def expect(k0, k1):
+        oc = oracle_from_keys(oracle_lib, k, k0, k1)
+        r = oracle_counts(oracle_lib, oc, bases, off, ids, n_bc)
+        oracle_lib.ho_free(oc)
+        return r
+
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.counts_resize(n_bc)
+        d_b, d_i = ctx.to_device(bases), ctx.to_device(ids)
+
+        def run():
+            ctx.counts_zero()
+            ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i)
+            return ctx.counts_read(n_bc)
+
+        ctx.table_insert_keys(0, keys[0][:n_keys // 2])
+        for a, b in zip(run(), expect(keys[0][:n_keys // 2], keys[1][:0])):
+            assert np.array_equal(a, b)
+        ctx.table_insert_keys(0, keys[0][n_keys // 2:])                 # more keys: the filter must follow
+        ctx.table_insert_keys(1, keys[1])
+        full = expect(keys[0], keys[1])
+        for a, b in zip(run(), full):
+            assert np.array_equal(a, b)
+        assert int(full[0].sum()) > 0 and int(full[1].sum()) > 0
+        gone = keys[1][:n_keys // 2]                                    # erased keys: the table says no (InitAdaptor removes
+        ctx.table_erase(gone)                                           # a key from BOTH sets, classify.cpp:314-339)
+        for a, b in zip(run(), expect(keys[0][~np.isin(keys[0], gone)], keys[1][~np.isin(keys[1], gone)])):
+            assert np.array_equal(a, b)
+        ctx.table_reserve(2 * n_keys)                                   # a new, empty table
+        ctx.table_insert_keys(1, keys[1][:100])
+        for a, b in zip(run(), expect(keys[0][:0], keys[1][:100])):
+            assert np.array_equal(a, b)
+
+
 ADAPTOR_F = b"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA"   # classify.cpp:312
 ADAPTOR_R = b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"   # classify.cpp:313
 
