@@ -54,6 +54,7 @@ ABI_SYMBOLS = {
     "hast_table_load": (C.c_int, [vp, C.c_char_p, C.c_double]),
     "hast_table_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), u64p]),
     "hast_table_info": (C.c_int, [vp, u64p, u64p]),
+    "hast_table_clone": (C.c_int, [vp, vp]),
     "hast_ctx_set_filter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     "hast_filter_build": (C.c_int, [vp]),
     "hast_filter_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), u64p]),
@@ -324,6 +325,9 @@ class Context:
 
     def table_load(self, path, load_factor=0.0):
         _ck(self._lib.hast_table_load(self._h, os.fsencode(path), load_factor))
+
+    def table_clone_from(self, src):
+        _ck(self._lib.hast_table_clone(self._h, src._h))
 
     def table_info(self):
         a, b = C.c_uint64(), C.c_uint64()

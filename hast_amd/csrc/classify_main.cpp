@@ -12,7 +12,10 @@
 //   * ragged k-mer line / read shorter than K: error + exit 3 (the reference assert-aborts,
 //     kmer.h:154,171);
 //   * K must be in [1,32] like the reference's correct range (it is silently wrong above 32).
-// Additive flags: --device N (GPU ordinal, default 0), --block-mb N (ingest block size), --batch-reads N
+// Additive flags: --device N (GPU ordinal, default 0), --devices A,B,... (several GPUs of this node: the table is built
+// on the first one and copied to the others over xGMI, parsed batches are dealt round-robin, the per-barcode counters are
+// summed with ONE RCCL all-reduce at the end -- the thread merge of classify.cpp:226-229,276-277 across GPUs; integer sums,
+// so stdout is byte-identical to a single-GPU run), --block-mb N (ingest block size), --batch-reads N
 // (approximate records per GPU batch, for tests), --initial-barcodes N, --stats (timings on stderr).
 // -t/--thread N is honoured as the number of host parser threads.
 #include <getopt.h>
@@ -55,6 +58,7 @@ void print_usage() {                              // same flags as the reference
           "  -f, --adaptor_f SEQ   forward adaptor whose k-mers are removed from both sets\n"
           "  -q, --adaptor_r SEQ   reverse adaptor whose k-mers are removed from both sets\n"
           "      --device N        GPU ordinal (default 0)\n"
+          "      --devices A,B,..  classify on several GPUs of this node (reads are dealt out, counts summed over RCCL)\n"
           "      --save-table FILE write the built k-mer table (after the adaptor scrub) as a binary key set\n"
           "      --load-table FILE use such a file instead of --hap0/--hap1\n"
           "      --stats           timings and set sizes on stderr\n"
@@ -105,9 +109,12 @@ struct Counts {                                    // host accumulators behind t
     size_t device_cap = 0;
 };
 
-void flush_counts(hast_ctx *ctx, Counts &acc, size_t n_known, size_t new_cap) {
-    // fold what the device has counted so far into the host sums, then (re)size the device array
+void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, size_t n_known, size_t new_cap) {
+    // fold what the devices have counted so far into the host sums, then (re)size the device arrays.  Several GPUs: ONE
+    // all-reduce(sum,u32) over RCCL/xGMI leaves the totals on every device (collectBarcodes + data.Add, classify.cpp:226-229,277)
+    hast_ctx *ctx = ctxs[0];
     if (acc.device_cap) {
+        if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
         std::vector<uint32_t> a(acc.device_cap), b(acc.device_cap), c(acc.device_cap);
         CK(hast_counts_read(ctx, a.data(), b.data(), c.data(), acc.device_cap), "reading counters");
         if (acc.c0.size() < acc.device_cap) {
@@ -122,7 +129,7 @@ void flush_counts(hast_ctx *ctx, Counts &acc, size_t n_known, size_t new_cap) {
         }
     }
     (void)n_known;
-    CK(hast_counts_resize(ctx, new_cap), "allocating counters");
+    for (hast_ctx *c : ctxs) CK(hast_counts_resize(c, new_cap), "allocating counters");
     acc.device_cap = new_cap;
 }
 
@@ -142,6 +149,7 @@ int main(int argc, char **argv) {
         {"batch-reads", required_argument, NULL, 1002}, {"stats", no_argument, NULL, 1003},
         {"block-mb", required_argument, NULL, 1004},    {"initial-barcodes", required_argument, NULL, 1005},
         {"save-table", required_argument, NULL, 1006},  {"load-table", required_argument, NULL, 1007},
+        {"devices", required_argument, NULL, 1008},
         {0, 0, 0, 0}};
     static char optstring[] = "p:m:l:r:t:w:u:f:q:h";             // classify.cpp:387
     std::string hap0, hap1, save_table, load_table;
@@ -149,6 +157,7 @@ int main(int argc, char **argv) {
     std::string r2("TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG");   // classify.cpp:313
     std::vector<std::string> read;
     int t_num = 8, device = 0;
+    std::vector<int> devices;
     size_t batch_reads = 0, block_mb = 256, initial_barcodes = 1u << 20;
     bool stats = false;
     double w0 = 1.0, w1 = 1.0;
@@ -171,6 +180,16 @@ int main(int argc, char **argv) {
         case 1005: initial_barcodes = (size_t)std::max(1L, atol(optarg)); break;
         case 1006: save_table = optarg; break;
         case 1007: load_table = optarg; break;
+        case 1008:
+            for (const char *q = optarg; *q;) {
+                char *end;
+                const long v = strtol(q, &end, 10);
+                if (end == q || v < 0) { print_usage(); return -1; }
+                devices.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') { print_usage(); return -1; }
+            }
+            break;
         case 'h':
         default: print_usage(); return -1;
         }
@@ -179,6 +198,8 @@ int main(int argc, char **argv) {
         print_usage();
         return -1;
     }
+    if (devices.empty()) devices.push_back(device);
+    device = devices[0];
     fprintf(stderr, "__START__\n");
     fprintf(stderr, " use hap0 weight %g\n", w0);
     fprintf(stderr, " use hap1 weight %g\n", w1);
@@ -256,6 +277,15 @@ int main(int argc, char **argv) {
     uint64_t n_set[2] = {0, 0};
     CK(hast_table_sizes(ctx, &n_set[0], &n_set[1]), "counting set sizes");
     if (!save_table.empty()) CK(hast_table_save(ctx, save_table.c_str()), "writing --save-table file");
+    // the other GPUs get a copy of the finished table (after the adaptor scrub), peer to peer
+    std::vector<hast_ctx *> ctxs{ctx};
+    for (size_t i = 1; i < devices.size(); i++) {
+        hast_ctx *c2 = nullptr;
+        if (hast_ctx_create(devices[i], (int)K, &c2) != HAST_OK) die(4, "cannot create GPU context");
+        CK(hast_table_clone(c2, ctx), "copying the k-mer table to another GPU");
+        ctxs.push_back(c2);
+    }
+    size_t next_ctx = 0;
     logtime();
 
     // ---- processFastq (classify.cpp:238-278) for each --read, in order ------------------------
@@ -265,7 +295,7 @@ int main(int argc, char **argv) {
     hast::BarcodeDict dict;
     std::vector<hast::BarcodeDict::Cache> caches(pool.size());
     Counts acc;
-    flush_counts(ctx, acc, 0, initial_barcodes);
+    flush_counts(ctxs, acc, 0, initial_barcodes);
     const int T = pool.size();
     // --batch-reads N (tests / small inputs): shrink the blocks so that a batch holds about N records
     size_t block_bytes = block_mb << 20;
@@ -291,7 +321,8 @@ int main(int argc, char **argv) {
         uint64_t *ho;
         uint32_t *hi;
         const size_t span = (size_t)allnl[4 * n_rec - 1] + 1;
-        CK(hast_batch_begin(ctx, span, n_rec, &hb, &ho, &hi), "staging a batch");
+        hast_ctx *bctx = ctxs[next_ctx++ % ctxs.size()];                               // batches are dealt round-robin to the GPUs
+        CK(hast_batch_begin(bctx, span, n_rec, &hb, &ho, &hi), "staging a batch");
         auto rec_range = [&](int t, size_t &lo, size_t &hi_) { lo = n_rec * (size_t)t / T; hi_ = n_rec * (size_t)(t + 1) / T; };
         pool.run([&](int t) {                          // pass 1: bytes of bases per worker
             size_t lo, hi_;
@@ -335,8 +366,8 @@ int main(int argc, char **argv) {
                 exit(3);                                                                   // reference: assert abort
             }
         }
-        if (dict.size() > acc.device_cap) flush_counts(ctx, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
-        CK(hast_batch_submit(ctx, n_rec, mx), "classifying a batch");
+        if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
+        CK(hast_batch_submit(bctx, n_rec, mx), "classifying a batch");
         total_reads += n_rec;
         total_bases += part_bytes[T];
     };
@@ -438,7 +469,7 @@ int main(int argc, char **argv) {
             }
         }
     }
-    flush_counts(ctx, acc, dict.size(), 1);
+    flush_counts(ctxs, acc, dict.size(), 1);
     const double t_classified = now_s();
     const std::vector<std::string_view> names = dict.names();
 
@@ -472,6 +503,6 @@ int main(int argc, char **argv) {
                 (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
     fprintf(stderr, "__END__\n");
-    hast_ctx_destroy(ctx);
+    for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     return 0;
 }

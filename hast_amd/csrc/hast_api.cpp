@@ -310,6 +310,7 @@ hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     return HAST_OK;
 }
 
+static hast_status ensure_filter(hast_ctx *c, hipStream_t hs);
 // every entry point that adds keys calls this: the filter no longer covers the table
 static void table_changed(hast_ctx *c) { c->filter_valid = false; }
 
@@ -505,6 +506,43 @@ hast_status hast_table_load(hast_ctx *c, const char *path, double load_factor) {
     return check_err_word(c, c->stream);
 }
 
+// Replicate a finished table (and its filter) onto another context's device: one peer copy over xGMI instead of parsing
+// and inserting the k-mer text once per GPU.
+hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
+    if (!dst || !src || dst == src) return fail(HAST_ERR_INVALID, "clone needs two different contexts");
+    if (dst->k != src->k) return fail(HAST_ERR_INVALID, "clone: K differs (%d vs %d)", dst->k, src->k);
+    if (hast_status st = need_table(src, 0)) return st;
+    if (src->use_filter)
+        if (hast_status st = ensure_filter(src, src->stream)) return st;
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    if (hast_status st = use(dst)) return st;
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    if (dst->d_slots) HIP_TRY(hipFree(dst->d_slots));
+    dst->d_slots = nullptr;
+    dst->nbuckets = 0;
+    dst->filter_valid = false;
+    dst->m = src->m;
+    const size_t bytes = table_slots(src) * sizeof(uint64_t);
+    HIP_TRY(hipMalloc(&dst->d_slots, bytes));
+    HIP_TRY(hipMemcpyPeer(dst->d_slots, dst->device, src->d_slots, src->device, bytes));
+    dst->nbuckets = src->nbuckets;
+    if (src->filter_valid && dst->use_filter) {
+        if (dst->filter_bytes != src->filter_bytes) {
+            if (dst->d_filter) HIP_TRY(hipFree(dst->d_filter));
+            dst->d_filter = nullptr;
+            dst->filter_bytes = 0;
+            HIP_TRY(hipMalloc(&dst->d_filter, src->filter_bytes));
+            dst->filter_bytes = src->filter_bytes;
+        }
+        HIP_TRY(hipMemcpyPeer(dst->d_filter, dst->device, src->d_filter, src->device, src->filter_bytes));
+        dst->fg = src->fg;
+        dst->filter_m = src->filter_m;
+        dst->filter_t = src->filter_t;
+        dst->filter_valid = true;
+    }
+    return HAST_OK;
+}
+
 hast_status hast_table_info(const hast_ctx *c, uint64_t *n_buckets, uint64_t *bytes) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
     if (n_buckets) *n_buckets = c->nbuckets;
@@ -566,6 +604,25 @@ hast_status hast_counts_read(hast_ctx *c, uint32_t *c0, uint32_t *c1, uint32_t *
 // RCCL, resolved lazily so that single-GPU users never load it.
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
     if (!ctxs || n < 1) return fail(HAST_ERR_INVALID, "no contexts");
+    // contexts that all sit on ONE device (a logical split, e.g. classify --devices 0,0 on a single-GPU box) need no
+    // exchange between GPUs: their counters are summed by a kernel on that device
+    if (n > 1 && ctxs[0]) {
+        bool same = true;
+        for (int i = 1; i < n; i++) same = same && ctxs[i] && ctxs[i]->device == ctxs[0]->device;
+        if (same) {
+            if (hast_status st = use(ctxs[0])) return st;
+            for (int i = 0; i < n; i++) {
+                if (!ctxs[i]->d_counts || ctxs[i]->n_barcodes != ctxs[0]->n_barcodes) return fail(HAST_ERR_INVALID, "contexts need equal-size counters");
+                HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+            }
+            const size_t nw = ctxs[0]->n_barcodes * 4;
+            for (int i = 1; i < n; i++) HIP_TRY(launch_add_u32(ctxs[0]->d_counts, ctxs[i]->d_counts, nw, ctxs[0]->stream));
+            for (int i = 1; i < n; i++)
+                HIP_TRY(hipMemcpyAsync(ctxs[i]->d_counts, ctxs[0]->d_counts, nw * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctxs[0]->stream));
+            HIP_TRY(hipStreamSynchronize(ctxs[0]->stream));
+            return HAST_OK;
+        }
+    }
     // a single context needs no exchange; HAST_FORCE_RCCL=1 still runs the RCCL path (1-rank communicator), which
     // is how a 1-GPU box checks the library loading, symbols and enum values used for N > 1
     if (n == 1 && !getenv("HAST_FORCE_RCCL")) return HAST_OK;
@@ -589,6 +646,12 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
         if (!ctxs[i] || !ctxs[i]->d_counts || ctxs[i]->n_barcodes != ctxs[0]->n_barcodes)
             return fail(HAST_ERR_INVALID, "contexts need equal-size counters");
         devs[i] = ctxs[i]->device;
+    }
+    {
+        std::vector<int> sorted(devs);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return fail(HAST_ERR_INVALID, "hast_counts_allreduce: two contexts on one device (a communicator has one rank per GPU)");
     }
     std::vector<comm_t> comms(n);
     if (int rc = init_all(comms.data(), n, devs.data())) return fail(HAST_ERR_RCCL, "ncclCommInitAll failed (%d)", rc);

@@ -64,6 +64,7 @@ hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int 
 hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, size_t n_reads, uint8_t *d_has_n, hipStream_t s);
 hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
                                size_t n_reads, hipStream_t s);
+hipError_t launch_add_u32(uint32_t *d_dst, const uint32_t *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
 hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);
 

@@ -733,6 +733,15 @@ hipError_t launch_build_segments(const uint64_t *d_offsets, size_t n_reads, int 
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) k_add_u32(uint32_t *dst, const uint32_t *src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+hipError_t launch_add_u32(uint32_t *d_dst, const uint32_t *d_src, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_u32, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_dst, d_src, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_keys, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, p, hap, first, n, d_out);

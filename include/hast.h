@@ -108,6 +108,11 @@ hast_status hast_table_save(hast_ctx *, const char *path);
 hast_status hast_table_load(hast_ctx *, const char *path, double load_factor);
 hast_status hast_table_file_info(const char *path, int *k_out, uint64_t *n_keys_out);   /* no GPU needed */
 
+/* Replicate src's finished table (and its filter) onto dst's device with one peer copy (xGMI), instead of building it
+ * once per GPU: what the multi-GPU classify CLI does after building the table on its first device.  Same K required;
+ * dst's previous table is discarded. */
+hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src);
+
 /* geometry, for roofline accounting */
 hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *bytes);
 
@@ -133,7 +138,8 @@ hast_status hast_counts_zero(hast_ctx *, hast_stream);
 hast_status hast_counts_read(hast_ctx *, uint32_t *c0, uint32_t *c1, uint32_t *neg, size_t n_barcodes);
 /* Thread-merge of the reference (collectBarcodes/BarcodeCache::Add, classify.cpp:57-63,226-229)
  * across the GPUs of ONE process: a single in-place RCCL all-reduce(sum,u32) over the counters of
- * n_ctx contexts (one per device, same n_barcodes). */
+ * n_ctx contexts (one per device, same n_barcodes).  Contexts that all share ONE device (a logical split) are summed
+ * by a kernel on that device instead; a mix of shared and distinct devices is refused. */
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
 
 /* ---- classification: MultiThread::process_reads (classify.cpp:186-209) ---------------------

@@ -30,6 +30,30 @@ def test_cli_matches_reference_golden(exe, golden_workdir, case, run):
     assert mine == meta["ref_log"]
 
 
+def _n_gpus():
+    import ctypes
+    try:
+        n = ctypes.c_int(0)
+        return n.value if ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", pytest.param("0,1", marks=pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs"))])
+@pytest.mark.parametrize("case,run", golden_cases("s01"))
+def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, devices):
+    """--devices: the table is built once and copied to the other contexts, batches are dealt round-robin, the counters
+    are summed once at the end (classify.cpp:226-229,276-277 across GPUs).  Integer sums: stdout must be byte-identical
+    to the real reference's.  "0,0" = several contexts on the one GPU of the test box (same code path up to the sum:
+    a kernel instead of RCCL); "0,1" = two GPUs over RCCL."""
+    meta = load_case(case)["runs"][run]
+    d = golden_workdir / case
+    res = subprocess.run([exe] + meta["argv"] + ["--devices", devices, "--batch-reads", "700", "--initial-barcodes", "50"], cwd=d,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert res.stdout == open(d / meta["expected"], "rb").read()
+
+
 def test_cli_small_batches_and_counter_growth(exe, golden_workdir):
     """Tiny batches force many launches and the counter-array regrowth path; output unchanged."""
     meta = load_case("rand_k21")["runs"]["pair_w104"]
