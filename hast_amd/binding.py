@@ -55,9 +55,9 @@ ABI_SYMBOLS = {
     "hast_table_file_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), u64p]),
     "hast_table_info": (C.c_int, [vp, u64p, u64p]),
     "hast_table_clone": (C.c_int, [vp, vp]),
-    "hast_ctx_set_filter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "hast_ctx_set_filter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hast_filter_build": (C.c_int, [vp]),
-    "hast_filter_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), u64p]),
+    "hast_filter_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), u64p]),
     "hast_counts_resize": (C.c_int, [vp, C.c_size_t]),
     "hast_counts_bind": (C.c_int, [vp, vp, C.c_size_t]),
     "hast_counts_zero": (C.c_int, [vp, vp]),
@@ -228,17 +228,17 @@ class Context:
     def minimizer(self):
         return self._lib.hast_ctx_minimizer(self._h)
 
-    def set_filter(self, enable=True, m=0, t=0):
-        _ck(self._lib.hast_ctx_set_filter(self._h, 1 if enable else 0, m, t))
+    def set_filter(self, enable=True, m=0, t=0, kp=0):
+        _ck(self._lib.hast_ctx_set_filter(self._h, 1 if enable else 0, m, t, kp))
 
     def filter_build(self):
         _ck(self._lib.hast_filter_build(self._h))
 
     def filter_info(self):
-        """(enabled, m, t, bytes); m = t = bytes = 0 until the filter has been built for the current table"""
-        en, m, t, b = C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
-        _ck(self._lib.hast_filter_info(self._h, C.byref(en), C.byref(m), C.byref(t), C.byref(b)))
-        return bool(en.value), m.value, t.value, b.value
+        """(enabled, m, t, kp, bytes); m = t = kp = bytes = 0 until the filter has been built for the current table"""
+        en, m, t, kp, b = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
+        _ck(self._lib.hast_filter_info(self._h, C.byref(en), C.byref(m), C.byref(t), C.byref(kp), C.byref(b)))
+        return bool(en.value), m.value, t.value, kp.value, b.value
 
     def close(self):
         if self._h:

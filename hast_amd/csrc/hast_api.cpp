@@ -86,7 +86,7 @@ struct hast_ctx {
     FilterGeom fg{};
     bool filter_valid = false;
     bool use_filter = true;                 // HAST_CLASSIFY=exact: probe the exact table directly (the round-1 kernel)
-    int filter_m = 0, filter_t = 0;         // overrides (0 = by key count)
+    int filter_m = 0, filter_t = 0, filter_kp = 0;   // overrides (0 = by K and key count)
 };
 
 namespace {
@@ -191,6 +191,7 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     if (const char *e = getenv("HAST_CLASSIFY")) c->use_filter = strcmp(e, "exact") != 0;
     if (const char *e = getenv("HAST_FILTER_M")) c->filter_m = atoi(e);
     if (const char *e = getenv("HAST_FILTER_T")) c->filter_t = atoi(e);
+    if (const char *e = getenv("HAST_FILTER_KP")) c->filter_kp = atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     hast_status st = HAST_OK;
@@ -538,6 +539,7 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
         dst->fg = src->fg;
         dst->filter_m = src->filter_m;
         dst->filter_t = src->filter_t;
+        dst->filter_kp = src->filter_kp;
         dst->filter_valid = true;
     }
     return HAST_OK;
@@ -680,7 +682,7 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
     HIP_TRY(launch_count_tags(c->d_slots, geom(c), c->d_cnt, hs));
     HIP_TRY(hipMemcpyAsync(h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, hs));
     HIP_TRY(hipStreamSynchronize(hs));
-    const FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t);
+    const FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t, c->filter_kp);
     const size_t bytes = (size_t)filter_nblocks(fg) * 128;
     if (bytes != c->filter_bytes) {
         if (c->d_filter) HIP_TRY(hipFree(c->d_filter));
@@ -810,13 +812,15 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
 static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
 static constexpr uint32_t kLongRead = 4096;      // longer reads (with offsets) go through the segmented path
 
-hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t) {
+hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t, int kp) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
     if (m < 0 || m > c->k || m > kFilterMaxM) return fail(HAST_ERR_INVALID, "filter m=%d out of [0,%d]", m, std::min(c->k, kFilterMaxM));
     if (t < 0 || (m && t > m)) return fail(HAST_ERR_INVALID, "filter t=%d out of [0,m]", t);
+    if (kp < 0 || kp > c->k || (kp && m && (kp < m || kp - m >= 32))) return fail(HAST_ERR_INVALID, "filter kp=%d out of [m,K]", kp);
     c->use_filter = enable != 0;
     c->filter_m = m;
     c->filter_t = t;
+    c->filter_kp = kp;
     c->filter_valid = false;
     return HAST_OK;
 }
@@ -829,11 +833,12 @@ hast_status hast_filter_build(hast_ctx *c) {
     return HAST_OK;
 }
 
-hast_status hast_filter_info(const hast_ctx *c, int *enabled, int *m, int *t, uint64_t *bytes) {
+hast_status hast_filter_info(const hast_ctx *c, int *enabled, int *m, int *t, int *kp, uint64_t *bytes) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
     if (enabled) *enabled = c->use_filter ? 1 : 0;
     if (m) *m = c->filter_valid ? c->fg.m : 0;
     if (t) *t = c->filter_valid ? c->fg.t : 0;
+    if (kp) *kp = c->filter_valid ? c->fg.kp : 0;
     if (bytes) *bytes = c->filter_valid ? c->filter_bytes : 0;
     return HAST_OK;
 }

@@ -131,14 +131,15 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
 // miss.  So the filter can only cost time, never change a result.
 struct FilterGeom {
     int k, m, t;            // k-mer, sampled m-mer (m <= 14, 4^m blocks), ordering t-mer (t <= m)
-    int g;                  // entries per first-level minimum of the kernel's sliding window: min(4, K-t+1)
+    int kp;                 // the sampling only looks at the first kp bases of a window (kp <= k): W = kp-m+1 candidates
+    int g;                  // entries per first-level minimum of the kernel's sliding window: min(4, kp-t+1)
     uint32_t wdiv;          // floor(2^16 / W) + 1: x / W for x < 64 by multiply-shift
 };
 constexpr int kFilterSubs = 8;                    // 16-B sub-buckets per 128-B block
 constexpr int kFilterPrints = 8;                  // 16-bit prints per sub-bucket
 constexpr int kFilterMaxM = 14;                   // 4^14 blocks = 34 GB
-HAST_HD uint32_t filter_w(const FilterGeom &g) { return (uint32_t)(g.k - g.m + 1); }
-HAST_HD uint32_t filter_nt(const FilterGeom &g) { return (uint32_t)(g.k - g.t + 1); }
+HAST_HD uint32_t filter_w(const FilterGeom &g) { return (uint32_t)(g.kp - g.m + 1); }
+HAST_HD uint32_t filter_nt(const FilterGeom &g) { return (uint32_t)(g.kp - g.t + 1); }
 HAST_HD uint64_t filter_nblocks(const FilterGeom &g) { return 1ull << (2 * g.m); }
 // order of a t-mer: 20 hash bits above 12 position bits; smaller wins, equal t-mers (or equal hashes) -> the leftmost
 HAST_HD uint32_t tmer_order(uint32_t tmer, uint32_t pos) { return ((((tmer + 1u) * 0x9E3779B1u) >> 12) << 12) | pos; }
@@ -170,20 +171,29 @@ HAST_HD uint32_t filter_print_of(uint32_t keyhash) {
     const uint32_t f = (keyhash >> 8) & 0xFFFFu;
     return f ? f : 1u;
 }
-// geometry for K and a key count: the smallest m (>= 8, <= 14, <= K) whose 4^m blocks keep the average block at <= 12
-// of its 64 prints (two prints per key), and the t the mod-minimizer wants for that m
-HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t_override) {
+// Geometry for K and a key count.  Measured with tools/sim/filter_load_sim.cpp (unscaled: 400M keys, both strands filed):
+// what limits m from below is not the average load of a block but the skew of the sampling -- the sampled m-mers all hold
+// one of the window's lowest-ordered t-mers, so a fraction of the blocks takes most of the keys.  4^m >= 0.67 N keeps the
+// windows that land in a full sub-bucket (and must ask the table) under ~0.5 per 150-bp read:
+//     N = 400M: m = 14, kp = 21 -> W = 8, t = 6: 25.5 blocks + 0.5 forced look-ups per read (m = 13, t = 4: 23 + 77)
+//     N = 100M: m = 13, kp = 21 -> W = 9, t = 4: 23.4 + 0.9
+// kp = min(K, m + 8): longer windows (K = 31) are sampled on their first kp bases only -- more candidates would lower the
+// density further but pile the keys on even fewer blocks.
+HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t_override, int kp_override = 0) {
     FilterGeom g;
     g.k = k;
     int m = k < 8 ? k : 8;
-    while (m < k && m < kFilterMaxM && (1ull << (2 * m)) * 6 < n_keys) ++m;
+    while (m < k && m < kFilterMaxM && (1ull << (2 * m)) * 3 < 2 * n_keys) ++m;
     if (m_override >= 1 && m_override <= k && m_override <= kFilterMaxM) m = m_override;
     g.m = m;
-    const int w = k - m + 1, r = m < 4 ? m : 4;
+    int kp = k < m + 8 ? k : m + 8;
+    if (kp_override >= m && kp_override <= k && kp_override - m < 32) kp = kp_override;
+    g.kp = kp;
+    const int w = kp - m + 1, r = m < 4 ? m : 4;
     int t = r + (m - r) % w;
     if (t_override >= 1 && t_override <= m) t = t_override;
     g.t = t;
-    const int nt = k - t + 1;
+    const int nt = kp - t + 1;
     g.g = nt < 4 ? nt : 4;
     g.wdiv = (65536u / (uint32_t)w) + 1u;
     return g;

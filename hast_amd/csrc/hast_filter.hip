@@ -61,7 +61,7 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 //   A  pack   : as hast_kernels.hip: 16 ASCII bases per lane -> 32 bits of 2-bit codes; 'N' flag / invalid-byte mask.
 //   M  order  : one lane per t-mer position: e = tmer_order(t-mer, position); the first level of the sliding minimum,
 //               L1[q] = min(e[q .. q+g-1]) (g = 4), is formed in registers with two wave shuffles and stored.  A window's
-//               smallest t-mer (leftmost on ties) is then the minimum of ceil((K-t+1)/4) L1 entries.
+//               smallest t-mer (leftmost on ties) is then the minimum of ceil((kp-t+1)/4) L1 entries.
 //   B  probe  : every LANE owns one window: forward K-mer by funnel shift out of the packed LDS words, canonical key
 //               (v_bfrev), smallest t-mer -> position x -> the m-mer at x mod W names the 128-B block, the key's hash the
 //               16-B sub-bucket and the 16-bit print.  ONE 16-B load per window; consecutive windows (adjacent lanes)
@@ -322,21 +322,27 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             }
         };
         {
-            Blk A, B;
-            uint32_t blk = wave;
-            bool va = blk < nblk;
-            if (va) start(A, blk);
-            blk += 4;
-            while (va) {
-                const bool vb = blk < nblk;
-                if (vb) start(B, blk);
-                blk += 4;
-                finish(A);
-                if (!vb) break;
-                va = blk < nblk;
-                if (va) start(A, blk);
-                blk += 4;
-                finish(B);
+            // Software pipeline, two blocks deep.  Every start() sits in straight-line code (no branch around it), so the
+            // compiler can count the loads in flight and wait for block i with vmcnt(1) while block i+1's load is still
+            // out; a start() under an `if` makes it fall back to vmcnt(0), i.e. no overlap at all.
+            const uint32_t n_my = nblk > wave ? (nblk - wave + 3) >> 2 : 0;      // blocks wave, wave+4, ... of this tile
+            if (n_my) {
+                Blk A, B;
+                uint32_t blk = wave;
+                start(A, blk);
+                uint32_t i = 1;
+                for (; i + 1 < n_my; i += 2) {
+                    start(B, blk + 4);
+                    finish(A);
+                    blk += 8;
+                    start(A, blk);
+                    finish(B);
+                }
+                if (i < n_my) {
+                    start(B, blk + 4);
+                    finish(A);
+                    finish(B);
+                } else finish(A);
             }
             while (qn) drain(qn < 64 ? qn : 64);
         }

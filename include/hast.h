@@ -123,10 +123,11 @@ hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *byt
  * above, which alone decides hits, so results never depend on the filter.  It is (re)built from the table's live keys
  * by the first classification after keys were added, or explicitly by hast_filter_build (e.g. outside a timed region).
  * hast_ctx_set_filter: enable = 0 probes the table directly (the round-1 kernel; also HAST_CLASSIFY=exact in the
- * environment); m, t = 0 picks the geometry from K and the key count. */
-hast_status hast_ctx_set_filter(hast_ctx *, int enable, int m, int t);
+ * environment); m (sampled m-mer, 4^m blocks), t (ordering t-mer), kp (bases of a window the sampling looks at) = 0 picks
+ * the geometry from K and the key count. */
+hast_status hast_ctx_set_filter(hast_ctx *, int enable, int m, int t, int kp);
 hast_status hast_filter_build(hast_ctx *);
-hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, uint64_t *bytes);
+hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, int *kp, uint64_t *bytes);
 
 /* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
  * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:

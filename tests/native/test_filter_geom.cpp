@@ -28,7 +28,8 @@ int main() {
         const int k = 1 + (int)(rnd() % 32);
         int m = 1 + (int)(rnd() % (uint64_t)(k < kFilterMaxM ? k : kFilterMaxM));
         int t = (rnd() & 1) ? 0 : 1 + (int)(rnd() % (uint64_t)m);
-        const FilterGeom g = filter_geom_for(k, 0, m, t);
+        const int kpo = (rnd() & 1) ? 0 : m + (int)(rnd() % (uint64_t)(k - m + 1));
+        const FilterGeom g = filter_geom_for(k, 0, m, t, kpo);
         if (g.m != m || (t && g.t != t) || g.t > g.m || g.t < 1) { printf("geom: k=%d m=%d t=%d -> m=%d t=%d\n", k, m, t, g.m, g.t); return 1; }
         const uint32_t W = filter_w(g), NT = filter_nt(g), G = (uint32_t)g.g;
         const uint32_t L = (uint32_t)k + (uint32_t)(rnd() % 200);
@@ -66,11 +67,11 @@ int main() {
             if (filter_sub_of(h) >= (uint32_t)kFilterSubs || filter_print_of(h) == 0 || filter_print_of(h) > 0xFFFF) { printf("print\n"); return 1; }
         }
     }
-    struct { int k; uint64_t n; int m, t; } want[] = {{21, 400000000ull, 13, 4}, {21, 100000000ull, 12, 12}, {31, 800000000ull, 14, 14},
-                                                      {21, 40000ull, 8, 8}, {5, 10ull, 5, 4}, {32, 2000000000ull, 14, 14}};
+    struct { int k; uint64_t n; int m, t, kp; } want[] = {{21, 400000000ull, 14, 6, 21}, {21, 100000000ull, 13, 4, 21}, {31, 800000000ull, 14, 5, 22},
+                                                          {21, 40000ull, 8, 8, 16}, {5, 10ull, 5, 4, 5}, {32, 2000000000ull, 14, 5, 22}};
     for (auto &w : want) {
         const FilterGeom g = filter_geom_for(w.k, w.n, 0, 0);
-        if (g.m != w.m || g.t != w.t) { printf("pick: K=%d n=%llu -> m=%d t=%d (want %d %d)\n", w.k, (unsigned long long)w.n, g.m, g.t, w.m, w.t); return 1; }
+        if (g.m != w.m || g.t != w.t || g.kp != w.kp) { printf("pick: K=%d n=%llu -> m=%d t=%d kp=%d (want %d %d %d)\n", w.k, (unsigned long long)w.n, g.m, g.t, g.kp, w.m, w.t, w.kp); return 1; }
     }
     printf("ok %ld windows\n", windows);
     return 0;

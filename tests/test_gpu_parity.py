@@ -491,17 +491,18 @@ def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
     assert int(v0.sum()) > n_reads // 2
 
 
-@pytest.mark.parametrize("k,fm,ft,n_keys,lf", [
-    (21, 0, 0, 30000, 0.2),       # geometry by key count
-    (21, 8, 0, 400000, 0.2),      # 4^8 blocks for 800k prints: most sub-buckets FULL -> everything is verified in the table
-    (21, 13, 4, 30000, 0.2),      # the BASELINE geometry (mod-minimizer, W=9, t=4) on a small table
-    (21, 14, 6, 30000, 0.85),     # other sweet spot; exact table with overflow chains
-    (21, 12, 3, 30000, 0.2),      # t not congruent to m: still exact, only denser
-    (31, 14, 0, 30000, 0.2),      # plain forward minimizer, W=18
-    (32, 10, 5, 30000, 0.2),      # wide keys
-    (9, 9, 9, 3000, 0.2), (6, 3, 2, 1500, 0.2), (2, 2, 1, 10, 0.2), (1, 1, 1, 2, 0.2),
+@pytest.mark.parametrize("k,fm,ft,fkp,n_keys,lf", [
+    (21, 0, 0, 0, 30000, 0.2),        # geometry by key count
+    (21, 8, 0, 0, 400000, 0.2),       # 4^8 blocks for 800k prints: most sub-buckets FULL -> everything is verified in the table
+    (21, 14, 6, 21, 30000, 0.85),     # the BASELINE geometry (mod-minimizer, W=8, t=6) on a small table with overflow chains
+    (21, 13, 4, 0, 30000, 0.2),       # the C2 geometry (W=9, t=4)
+    (21, 12, 3, 0, 30000, 0.2),       # t not congruent to m: still exact, only denser
+    (31, 14, 0, 0, 30000, 0.2),       # long windows sampled on their first 22 bases
+    (31, 14, 14, 31, 30000, 0.2),     # plain forward minimizer over the whole window, W=18
+    (32, 10, 5, 27, 30000, 0.2),      # wide keys
+    (9, 9, 9, 0, 3000, 0.2), (6, 3, 2, 0, 1500, 0.2), (2, 2, 1, 0, 10, 0.2), (1, 1, 1, 0, 2, 0.2),
 ])
-def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, ft, n_keys, lf):
+def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, ft, fkp, n_keys, lf):
     """The fingerprint filter may only cost time: for every geometry (incl. overfull filters, t-mers that do not fit the
     mod-minimizer rule, plain minimizers, W = 1) per-read votes and per-barcode counts must equal the oracle's, and equal
     what the exact table gives when probed directly (hast_ctx_set_filter(enable = 0))."""
@@ -526,7 +527,7 @@ def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, f
     oracle_lib.ho_free(oc)
     for enable in (True, False):
         with hast_amd.Context(k) as ctx:
-            ctx.set_filter(enable, fm if enable else 0, ft if enable else 0)
+            ctx.set_filter(enable, fm if enable else 0, ft if enable else 0, fkp if enable else 0)
             ctx.table_reserve(2 * n_keys, lf)
             ctx.table_insert_keys(0, keys[0])
             ctx.table_insert_keys(1, keys[1])
@@ -535,10 +536,12 @@ def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, f
             ctx.classify_device(d_b, rag.size, n_reads, L, d_offsets=d_o, d_barcode_ids=d_i, d_votes=d_v)
             got = ctx.counts_read(n_bc)
             votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
-            en, m, t, nbytes = ctx.filter_info()
+            en, m, t, kp, nbytes = ctx.filter_info()
             assert en == enable
             if enable:
-                assert nbytes == 128 * 4 ** m and 1 <= t <= m <= min(k, 14)
+                assert nbytes == 128 * 4 ** m and 1 <= t <= m <= min(k, 14) and m <= kp <= k
+                if fkp:
+                    assert kp == fkp
                 if fm:
                     assert m == fm
                 if ft:
