@@ -753,7 +753,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
         if (hast_status st = ensure_filter(c, hs)) return st;
         a.filter = c->d_filter;
         a.fg = c->fg;
-        a.l1_stride = (read_len >= (uint32_t)c->fg.t ? read_len - (uint32_t)c->fg.t + 1 : 0) + 1;
+        a.l1_stride = ((read_len >= (uint32_t)c->fg.t ? read_len - (uint32_t)c->fg.t + 1 : 0) + 1 + 3) & ~3u;
         per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.l1_stride * 4 + (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
         pad = 16 + classify_f_queue_bytes() + 64 * 4 + 64;
     } else {
@@ -788,7 +788,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.div_magic = magic((uint64_t)tr * a.max_pos + 1024, a.max_pos);
     a.div_mh = magic((uint64_t)tr * a.mh_stride + 1024, a.mh_stride);
     a.div_hw = magic((uint64_t)tr * a.w64 * 2 + 1024, a.w64 * 2);
-    a.div_l1 = magic((uint64_t)tr * a.l1_stride + 1024, a.l1_stride);
+    a.div_l1g = magic((uint64_t)tr * (a.l1_stride / 4) + 1024, a.l1_stride / 4);
     const uint64_t n_tiles = (n_reads + tr - 1) / tr;
     const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 8);
     a.tile_queue = c->d_cnt + 3;

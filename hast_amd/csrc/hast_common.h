@@ -120,7 +120,7 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
 // its own string and under that of its reverse complement -- and a read window is looked up under the m-mer sampled
 // from the window as it stands (no canonical m-mers anywhere):
 //     block(window)      = scramble(sampled m-mer of the window's forward string)            (4^m blocks of 128 B)
-//     sub-bucket, print  = from a hash of the window's CANONICAL k-mer                        (8 x 16 B, 8 prints each)
+//     sub-bucket, print  = from a hash of the window's K-mer as it stands                     (8 x 16 B, 8 prints each)
 //   sampling = mod-minimizer (Groot Koerkamp & Pibiri 2024): the window's smallest t-mer (leftmost on ties), position x
 //   among its K-t+1 t-mers, names the m-mer at position x mod W.  With t = r + (m-r) mod W, r = 4, the sampled m-mer stays
 //   put for W consecutive windows and then jumps by W: density ~0.165 at K=21, m=13 (W=9, t=4) against 0.287 for the
@@ -160,9 +160,9 @@ HAST_HD uint32_t filter_block_of_string(uint64_t fwd, const FilterGeom &g) {
     const uint32_t p = filter_sample_pos(fwd, g);
     return filter_block_of((uint32_t)(fwd >> (2 * (g.k - g.m - (int)p))) & (uint32_t)kmer_mask(g.m), g.m);
 }
-// hash of the canonical key: sub-bucket = top 3 bits, print = 16 bits from the middle, never 0 (0 = free slot)
-HAST_HD uint32_t filter_keyhash(uint64_t canon_key) {
-    uint32_t h = (uint32_t)canon_key * 0x85EBCA6Bu ^ (uint32_t)(canon_key >> 32) * 0xC2B2AE35u;
+// hash of a K-mer string (one strand of a key): sub-bucket = top 3 bits, print = 16 bits from the middle, never 0 (0 = free slot)
+HAST_HD uint32_t filter_keyhash(uint64_t kmer) {
+    uint32_t h = (uint32_t)kmer * 0x85EBCA6Bu ^ (uint32_t)(kmer >> 32) * 0xC2B2AE35u;
     h ^= h >> 15;
     return h * 0x9E3779B1u;
 }

@@ -40,8 +40,8 @@ struct ClassifyArgs {
     // ---- filter front end (k_classify_f); unused by the exact-table kernel
     const void *filter;          // 4^fg.m blocks of 128 B
     FilterGeom fg;
-    uint32_t l1_stride;          // first-level sliding-minimum entries per read (row stride)
-    uint32_t div_l1;             // exact multiply-high division by l1_stride, or 0
+    uint32_t l1_stride;          // first-level sliding-minimum entries per read (row stride), a multiple of 4
+    uint32_t div_l1g;            // exact multiply-high division by l1_stride / 4, or 0
 };
 
 hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t hap,

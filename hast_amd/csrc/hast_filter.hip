@@ -17,14 +17,12 @@ namespace hast {
 // full sub-bucket as "ask the exact table".
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void filter_insert(uint32_t *filt, const FilterGeom g, uint64_t key) {
-    const uint32_t h = filter_keyhash(key), sub = filter_sub_of(h), fp = filter_print_of(h);
-    uint32_t first_blk = 0xFFFFFFFFu;
     for (int o = 0; o < 2; ++o) {
         const uint64_t s = o ? kmer_revcomp(key, g.k) : key;
         if (o && s == key) break;                                    // its own reverse complement
+        // block, sub-bucket and print all come from the string AS A READ WOULD SHOW IT: the probe never canonicalises
         const uint32_t blk = filter_block_of_string(s, g);
-        if (blk == first_blk) break;                                 // both strands name the same block
-        first_blk = blk;
+        const uint32_t h = filter_keyhash(s), sub = filter_sub_of(h), fp = filter_print_of(h);
         uint32_t *w = filt + (size_t)blk * (kFilterSubs * kFilterPrints / 2) + sub * (kFilterPrints / 2);
         for (int i = 0; i < kFilterPrints / 2;) {
             const uint32_t v = __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -62,15 +60,15 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 //   M  order  : one lane per t-mer position: e = tmer_order(t-mer, position); the first level of the sliding minimum,
 //               L1[q] = min(e[q .. q+g-1]) (g = 4), is formed in registers with two wave shuffles and stored.  A window's
 //               smallest t-mer (leftmost on ties) is then the minimum of ceil((kp-t+1)/4) L1 entries.
-//   B  probe  : every LANE owns one window: forward K-mer by funnel shift out of the packed LDS words, canonical key
-//               (v_bfrev), smallest t-mer -> position x -> the m-mer at x mod W names the 128-B block, the key's hash the
-//               16-B sub-bucket and the 16-bit print.  ONE 16-B load per window; consecutive windows (adjacent lanes)
+//   B  probe  : every LANE owns one window: its K-mer by funnel shift out of the packed LDS words, smallest t-mer ->
+//               position x -> the m-mer at x mod W names the 128-B block, a hash of the K-mer as it stands the 16-B
+//               sub-bucket and the 16-bit print (no canonical form: every key was filed once per strand).  ONE 16-B load per window; consecutive windows (adjacent lanes)
 //               mostly name the same block, which the memory system fetches once.  Blocks of 64 windows are software-
 //               pipelined (loads of block i+1 are in flight while block i is compared).  Compare = 4 xor + 3 v_pk_min_u16
 //               + has-zero-halfword.  Positives (print found, or sub-bucket full) -- the real hits, about 1 % of the
 //               windows, plus a few in 10^5 false ones -- go to the wave's own queue in LDS.
-//   V  verify : when a wave's queue holds 64 positives (and at the end of the tile) each lane takes one, finds it in the
-//               exact table (home bucket by the table's own minimizer, then the chain) and adds its tag bits to the
+//   V  verify : when a wave's queue holds 64 positives (and at the end of the tile) each lane takes one, canonicalises it
+//               (v_bfrev) and finds it in the exact table (home bucket by the table's own minimizer, then the chain) and adds its tag bits to the
 //               read's votes in LDS.
 //   C  votes  : one lane per read stores {vote0, vote1}; k_commit_votes does the per-barcode bookkeeping.
 // ------------------------------------------------------------------------------------------
@@ -101,19 +99,19 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
     const uint32_t L1S = a.l1_stride;
     unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);            // next tile of this workgroup
-    unsigned long long *s_pack = s_tile + 2;                                               // [TR][WS]
+    uint32_t *s_l1 = reinterpret_cast<uint32_t *>(s_tile + 2);                             // [TR][L1S] (+ 64 pad), 16-B aligned rows
+    unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(s_l1 + (size_t)TR * L1S + 64);   // [TR][WS]
     unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
     unsigned long long *s_off = s_vote + TR;                                               // [TR]
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
     uint32_t *s_flag = s_len + TR;                                                         // [TR]
     uint32_t *s_q = s_flag + TR;                                                           // [4][3][kQCap]
-    uint32_t *s_l1 = s_q + 4 * 3 * kQCap;                                                  // [TR][L1S] (+ 64 pad)
     const uint32_t IW = 2 * a.w64 + 1;                                                     // invalid-byte mask words per read
-    uint32_t *s_inv = s_l1 + (size_t)TR * L1S + 64;                                        // [TR][IW], STRICT only
+    uint32_t *s_inv = s_q + 4 * 3 * kQCap;                                                 // [TR][IW], STRICT only
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t wave = tid >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));      // wave-uniform: loop control stays scalar
     uint32_t *q_lo = s_q + wave * 3 * kQCap, *q_hi = q_lo + kQCap, *q_rd = q_hi + kQCap;
     const FilterGeom fg = a.fg;
     const int K = a.k, M = fg.m, T = fg.t;
@@ -191,12 +189,35 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         }
         __syncthreads();
 
-        // ---- M: t-mer order, first level of the sliding minimum (in registers, two shuffles) ----------------
-        {
+        // ---- M: t-mer order and the first level of the sliding minimum, L1[q] = min(e[q .. q+g-1]) ---------------------
+        if (G == 4) {
+            // a lane takes 4 consecutive positions (one funnel shift, four hashes); L1 of its positions needs its own
+            // suffix minima and the prefix minima of the next lane's four (three shuffles); lane 63 only serves lane 62
+            const uint32_t gpr = L1S >> 2, total = tra * gpr;          // groups of 4 positions per read (L1S % 4 == 0)
+            const uint32_t t3shift = 64 - 2 * ((uint32_t)T + 3), tmask = (uint32_t)kmer_mask(T);
+            for (uint32_t b0 = wave * 63; b0 < total; b0 += 4 * 63) {
+                const uint32_t gi = b0 + lane;
+                const bool in = gi < total;
+                uint32_t r = FAST ? __umulhi(gi, a.div_l1g) : (gi / gpr);
+                r = in ? r : 0;
+                const uint32_t q0 = in ? 4 * (gi - r * gpr) : 0;
+                const int nv = in ? (int)s_len[r] - T + 1 - (int)q0 : 0;                  // e[q0 + i] exists iff i < nv
+                const unsigned long long bits = window_bits(s_pack + (size_t)r * WS, nv > 0 ? q0 : 0, t3shift);   // T+3 bases
+                uint32_t e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    e[i] = i < nv ? tmer_order((uint32_t)(bits >> (2 * (3 - i))) & tmask, q0 + i) : 0xFFFFFFFFu;
+                const uint32_t s2 = min(e[2], e[3]), s1 = min(e[1], s2), s0 = min(e[0], s1);
+                const uint32_t p1 = min(e[0], e[1]), p2 = min(p1, e[2]);
+                const uint32_t n0 = (uint32_t)__shfl_down((int)e[0], 1), n1 = (uint32_t)__shfl_down((int)p1, 1), n2 = (uint32_t)__shfl_down((int)p2, 1);
+                if (lane < 63 && in)
+                    *reinterpret_cast<u32x4f *>(s_l1 + (size_t)r * L1S + q0) = u32x4f{s0, min(s1, n0), min(s2, n1), min(e[3], n2)};
+            }
+        } else {
             const uint32_t total = tra * L1S, step = 64 - (G - 1);
             for (uint32_t b0 = wave * step; b0 < total; b0 += 4 * step) {
                 const uint32_t idx = b0 + lane;
-                uint32_t r = FAST ? __umulhi(idx, a.div_l1) : (idx / L1S);
+                uint32_t r = idx / L1S;
                 uint32_t q = idx - r * L1S;
                 const bool in = idx < total;
                 r = in ? r : 0;
@@ -205,13 +226,8 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
                 const uint32_t tm = (uint32_t)window_bits(s_pack + (size_t)r * WS, q, tshift);
                 const uint32_t e = valid ? tmer_order(tm, q) : 0xFFFFFFFFu;
                 uint32_t mn = e;
-                if (G == 4) {
-                    const uint32_t m2 = min(e, (uint32_t)__shfl_down((int)e, 1));
-                    mn = min(m2, (uint32_t)__shfl_down((int)m2, 2));
-                } else {
-                    if (G >= 2) mn = min(mn, (uint32_t)__shfl_down((int)e, 1));
-                    if (G >= 3) mn = min(mn, (uint32_t)__shfl_down((int)e, 2));
-                }
+                if (G >= 2) mn = min(mn, (uint32_t)__shfl_down((int)e, 1));
+                if (G >= 3) mn = min(mn, (uint32_t)__shfl_down((int)e, 2));
                 if (lane < step && in) s_l1[idx] = mn;
             }
         }
@@ -230,7 +246,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         auto drain = [&](uint32_t cnt) {
             const bool act = lane < cnt;
             const uint32_t e = act ? qn - cnt + lane : 0;
-            const unsigned long long key = ((unsigned long long)q_hi[e] << 32) | q_lo[e];
+            const unsigned long long key = kmer_canon(((unsigned long long)q_hi[e] << 32) | q_lo[e], K);   // queued: the window as read
             const uint32_t rd = q_rd[e];
             qn -= cnt;
             for (int pass = 0; pass < (WIDE ? 2 : 1); ++pass) {
@@ -267,7 +283,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         };
         struct Blk {
             u32x4f v;                                   // the 8 prints of this lane's window's sub-bucket
-            uint32_t klo, khi, fpw, meta;               // canonical key, print in both halves, read | valid << 31
+            uint32_t klo, khi, fpw, meta;               // the window's K-mer, print in both halves, read | valid << 31
         };
         auto start = [&](Blk &B, uint32_t blk) {
             const uint32_t q = blk * 64 + lane;
@@ -282,7 +298,6 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
                 ok = ok && (bits >> (64 - K)) == 0;
             }
             const unsigned long long fwd = window_bits(s_pack + (size_t)r * WS, p, kshift);
-            const unsigned long long ck = kmer_canon(fwd, K);
             const uint32_t *l1 = s_l1 + r * L1S + p;
             uint32_t x = l1[0];
             if (NTC) {
@@ -297,10 +312,10 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             pm = ok ? pm : 0;
             const uint32_t mm = (uint32_t)(fwd >> (2 * ((uint32_t)(K - M) - pm))) & mmask;
             const uint32_t fb = filter_block_of(mm, M);
-            const uint32_t h = filter_keyhash(ck);
+            const uint32_t h = filter_keyhash(fwd);                   // of the window as it stands: no canonical form in the probe
             B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
-            B.klo = (uint32_t)ck;
-            B.khi = (uint32_t)(ck >> 32);
+            B.klo = (uint32_t)fwd;
+            B.khi = (uint32_t)(fwd >> 32);
             B.fpw = filter_print_of(h) * 0x00010001u;
             B.meta = r | (ok ? 0x80000000u : 0u);
         };
@@ -379,7 +394,7 @@ static hipError_t launch_f_t(const ClassifyArgs &a, int grid, size_t smem, hipSt
 
 template <bool STRICT>
 static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
-    const bool fast = a.div_magic && a.div_l1 && a.div_hw;
+    const bool fast = a.div_magic && a.div_l1g && a.div_hw;
     if (a.wide) return fast ? launch_f_t<0, true, STRICT, true>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true>(a, grid, smem, s);
     if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT>(a, grid, smem, s) : launch_f_t<0, false, STRICT>(a, grid, smem, s);
     switch ((filter_nt(a.fg) + 3) / 4) {

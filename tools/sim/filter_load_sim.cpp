@@ -32,13 +32,11 @@ int main(int argc, char **argv) {
         for (uint64_t i = ti; i < N; i += threads) {
             const uint64_t w = synth_rand(77, 1, i) & kmer_mask(K);
             const uint64_t key = kmer_canon(w, K);
-            const uint32_t h = filter_keyhash(key);
-            uint32_t first = ~0u;
             for (int o = 0; o < 2; o++) {
                 const uint64_t s = o ? kmer_revcomp(key, K) : key;
+                if (o && s == key) break;
                 const uint32_t b = block_of(s);
-                if (b == first) break;
-                first = b;
+                const uint32_t h = filter_keyhash(s);
                 if (b % SLICE) continue;
                 const uint64_t base = (uint64_t)(b / SLICE) * 8;
                 uint32_t s1 = filter_sub_of(h), s2 = sub2(h);
@@ -71,7 +69,7 @@ int main(int argc, char **argv) {
                 tot_w++;
                 if (b % SLICE == 0) {
                     in_slice++;
-                    const uint32_t h = filter_keyhash(kmer_canon(fwd, K));
+                    const uint32_t h = filter_keyhash(fwd);
                     const uint64_t base = (uint64_t)(b / SLICE) * 8;
                     bool f = cnt[base + filter_sub_of(h)] >= 8;
                     if (choices == 2) f = f && cnt[base + sub2(h)] >= 8;      // a key may sit in either: only "both full" hides one
