@@ -766,13 +766,13 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
         pad = (size_t)wlen * 4 + 64 + 64 + 16;
     }
     static const size_t lds_env = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)0; }();
-    const size_t lds_budget = lds_env ? lds_env : (filt ? (size_t)26624 : (size_t)19968);      // 6 / 8 workgroups per CU
+    const size_t lds_budget = lds_env ? lds_env : (filt ? (size_t)32000 : (size_t)19968);      // 5 / 8 workgroups per CU
     const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, lds_budget > pad + per_read ? (lds_budget - pad) / per_read : 1));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
         double best = -1;
         for (uint32_t t = tr_max; t >= 1 && t + 8 > tr_max; --t) {
-            const uint64_t q = (uint64_t)t * a.max_pos, blocks = (q + 63) / 64, slots = (blocks + 7) / 8 * 8;
+            const uint64_t q = (uint64_t)t * a.max_pos, blocks = (q + 63) / 64, slots = filt ? (blocks + 3) / 4 * 4 : (blocks + 7) / 8 * 8;
             const double eff = (double)q / (double)(slots * 64);
             if (eff > best + 1e-9) { best = eff; tr = t; }
         }

@@ -60,7 +60,7 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 //   M  order  : one lane per t-mer position: e = tmer_order(t-mer, position); the first level of the sliding minimum,
 //               L1[q] = min(e[q .. q+g-1]) (g = 4), is formed in registers with two wave shuffles and stored.  A window's
 //               smallest t-mer (leftmost on ties) is then the minimum of ceil((kp-t+1)/4) L1 entries.
-//   B  probe  : every LANE owns one window: its K-mer by funnel shift out of the packed LDS words, smallest t-mer ->
+//   B  probe  : each wave walks a contiguous quarter of the tile's 64-window blocks; every LANE owns one window: its K-mer by funnel shift out of the packed LDS words, smallest t-mer ->
 //               position x -> the m-mer at x mod W names the 128-B block, a hash of the K-mer as it stands the 16-B
 //               sub-bucket and the 16-bit print (no canonical form: every key was filed once per strand).  ONE 16-B load per window; consecutive windows (adjacent lanes)
 //               mostly name the same block, which the memory system fetches once.  Blocks of 64 windows are software-
@@ -75,7 +75,7 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 constexpr int kThreadsF = 256;
 constexpr int kQCap = 128;                                    // queue entries per wave: < 64 waiting + <= 64 new
 #ifndef HAST_F_MINWAVES
-#define HAST_F_MINWAVES 6
+#define HAST_F_MINWAVES 5      // 96 VGPRs: measured best of 4/5/6/8 (242 vs 226-228 Gbp/s)
 #endif
 typedef unsigned long long u64x2f __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             __syncthreads();
         }
 
-        // ---- B: probe.  Each wave walks the 64-window blocks wave, wave+4, ... ---------------------------------
+        // ---- B: probe ---------------------------------------------------------------------------------------------
         const uint32_t P = a.max_pos;                                 // windows per read (stride)
         const uint32_t Q = tra * P;
         const uint32_t nblk = (Q + 63) >> 6;
@@ -340,21 +340,24 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             // Software pipeline, two blocks deep.  Every start() sits in straight-line code (no branch around it), so the
             // compiler can count the loads in flight and wait for block i with vmcnt(1) while block i+1's load is still
             // out; a start() under an `if` makes it fall back to vmcnt(0), i.e. no overlap at all.
-            const uint32_t n_my = nblk > wave ? (nblk - wave + 3) >> 2 : 0;      // blocks wave, wave+4, ... of this tile
+            // a wave takes a CONTIGUOUS quarter of the tile's blocks: the run of windows that straddles two blocks then asks
+            // for its 128-B block twice from the same wave in back-to-back instructions (an L1 hit, not a second request)
+            const uint32_t per = (nblk + 3) >> 2, first = wave * per;
+            const uint32_t n_my = first < nblk ? (nblk - first < per ? nblk - first : per) : 0;
             if (n_my) {
                 Blk A, B;
-                uint32_t blk = wave;
+                uint32_t blk = first;
                 start(A, blk);
                 uint32_t i = 1;
                 for (; i + 1 < n_my; i += 2) {
-                    start(B, blk + 4);
+                    start(B, blk + 1);
                     finish(A);
-                    blk += 8;
+                    blk += 2;
                     start(A, blk);
                     finish(B);
                 }
                 if (i < n_my) {
-                    start(B, blk + 4);
+                    start(B, blk + 1);
                     finish(A);
                     finish(B);
                 } else finish(A);
