@@ -1,0 +1,180 @@
+// fq_kernels.hip -- gfx950 device code: FASTQ framing on the GPU (the producer side of the hot path).
+//
+// The reference's producer (processFastq, 01.classify_stlfr_reads/classify.cpp:238-278) reads the file one getline at a
+// time: a record is four '\n'-separated lines counted from the start of the file, line 1 is the header (its barcode is the
+// text between the last '#' and the last '/', parseName :112-119), line 2 the bases; nothing else is looked at.  Here the raw
+// bytes of the file go to HBM as they are and three small kernels do the same framing for a whole block at once:
+//   k_fq_count   newlines per 4-KB tile (16 bytes per lane, has-zero-byte on x ^ '\n\n\n\n')
+//   k_fq_scan    exclusive scan of the tile counts (one workgroup; a block has a few thousand tiles)
+//   k_fq_index   positions of all newlines, in order (each tile re-derives its masks and writes at its scanned base)
+//   k_fq_records one lane per record: header / bases extents, barcode extent, length checks; the bytes after the last
+//                complete record (the "tail") are kept for the next block of the same file.
+// k_classify_f then reads the bases straight out of the raw block (offsets + lengths), the host only maps barcode text to
+// dense ids (the dictionary has to be one per job, not per GPU) and hands them back for k_commit_votes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fq_device.h"
+
+namespace hast {
+
+constexpr int kFqTile = 4096;                    // bytes per tile = 256 lanes x 16 B
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t *p, const uint8_t *lo, const uint8_t *hi) {
+    // bit i set <=> p[i] == '\n', for the 16 bytes at p (16-B aligned); bytes outside [lo, hi) never count
+    uint32_t m = 0;
+    if (p + 16 <= lo || p >= hi) return 0;
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t y = w[i] ^ 0x0A0A0A0Au;
+        const uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;     // 0x80 in every zero byte, exact
+        m |= (((z >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * i);                          // bits 0,8,16,24 -> 4 adjacent bits
+    }
+    if (p < lo) m &= 0xFFFFu << (uint32_t)(lo - p);
+    if (p + 16 > hi) m &= 0xFFFFu >> (uint32_t)(p + 16 - hi);
+    return m & 0xFFFFu;
+}
+
+// tiles are 4-KB aligned pieces of the buffer; `lo`/`hi` bound the bytes that belong to this parse
+__global__ void __launch_bounds__(256) k_fq_count(const uint8_t *buf, const FqState *st, uint32_t *tile_cnt) {
+    const uint64_t lo = st->parse_lo, hi = st->parse_hi;
+    const uint64_t tile = blockIdx.x;                                                      // tiles cover the buffer from byte 0
+    if (tile * kFqTile >= hi || (tile + 1) * kFqTile <= lo) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = 0; return; }
+    const uint8_t *p = buf + tile * kFqTile + threadIdx.x * 16;
+    uint32_t c = __popc(nl_mask16(p, buf + lo, buf + hi));
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    __shared__ uint32_t s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// exclusive scan of n tile counts in place (n <= a few 10^4), total -> st->n_nl; one workgroup of 1024
+__global__ void __launch_bounds__(1024) k_fq_scan(uint32_t *tile_cnt, uint32_t n, FqState *st) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += tile_cnt[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = tile_cnt[i];
+        tile_cnt[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) st->n_nl = s_part[1023];
+}
+
+__global__ void __launch_bounds__(256) k_fq_index(const uint8_t *buf, const FqState *st, const uint32_t *tile_base, uint32_t *nl) {
+    const uint64_t lo = st->parse_lo, hi = st->parse_hi;
+    const uint64_t tile = blockIdx.x;
+    if (tile * kFqTile >= hi || (tile + 1) * kFqTile <= lo) return;
+    const uint64_t at = tile * kFqTile + threadIdx.x * 16;
+    uint32_t m = nl_mask16(buf + at, buf + lo, buf + hi);
+    const uint32_t c = __popc(m);
+    // exclusive prefix of c over the workgroup
+    uint32_t incl = c;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += v;
+    }
+    __shared__ uint32_t s[4];
+    if (lane == 63) s[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = tile_base[blockIdx.x] + incl - c;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += s[w];
+    while (m) {
+        const uint32_t b = __ffs(m) - 1;
+        nl[base++] = (uint32_t)(at + b);
+        m &= m - 1;
+    }
+}
+
+// One lane per complete record i (lines 4i .. 4i+3 of the parse range, which always starts at a record boundary).
+// `last`: the input ends with this block, so a final record whose header line is terminated counts even when its bases /
+// '+' / quality lines lack their newlines (classify.cpp:257-268: a getline that hits EOF still yields the line read).
+__global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
+                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t k, int last) {
+    const uint64_t lo = st->parse_lo, hi = st->parse_hi;
+    const uint32_t n_nl = st->n_nl;
+    uint32_t n_rec = n_nl / 4;
+    // the EOF record without all four newlines: it counts iff its header line is terminated (even with an empty bases line)
+    const bool partial = last && n_nl - 4 * n_rec >= 1;
+    const uint32_t total = n_rec + (partial ? 1 : 0);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        st->n_rec = total;
+        const uint64_t consumed = last ? hi : (n_rec ? (uint64_t)nl[4 * n_rec - 1] + 1 : lo);
+        st->tail_lo = consumed;                               // bytes [consumed, hi) belong to the next block's first record
+    }
+    if (i >= total) return;
+    const uint64_t h0 = i ? (uint64_t)nl[4 * i - 1] + 1 : lo;
+    const uint64_t h1 = nl[4 * i];                            // end of the header line (exists for every counted record)
+    const uint64_t s1 = (4 * i + 1 < n_nl) ? nl[4 * i + 1] : hi;   // end of the bases line, or EOF
+    const uint32_t len = (uint32_t)(s1 - h1 - 1 > 0xFFFFFFFFull ? 0xFFFFFFFFull : s1 - h1 - 1);
+    r_off[i] = h1 + 1;
+    r_len[i] = len;
+    // parseName (classify.cpp:112-119): s = last '#', e = last '/'; barcode = [s+1, e) when e > s, else [s+1, end of header)
+    int64_t s = -1, e = -1;
+    for (int64_t p = (int64_t)h1 - 1; p >= (int64_t)h0; --p) {
+        const uint8_t c = buf[p];
+        if (c == '/' && e < 0) e = p;
+        if (c == '#') { s = p; break; }
+    }
+    const int64_t start = s < 0 ? (int64_t)h0 : s + 1;
+    const int64_t stop = (e > s && e >= 0) ? e : (int64_t)h1;
+    bc_pos[i] = (uint32_t)start;
+    bc_len[i] = (uint32_t)(stop - start);
+    atomicMax(&st->max_len, len);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&st->bases), (unsigned long long)len);
+    if (len < k) {                                            // the reference aborts on such a read unless it holds 'N' (kmer.h:171)
+        bool has_n = false;
+        for (uint64_t p = h1 + 1; p < s1 && !has_n; ++p) has_n = buf[p] == 'N';
+        if (!has_n) atomicOr(&st->flags, 1u);
+    }
+}
+
+// copies the previous block's tail in front of this block's bytes and sets the parse range; one workgroup is plenty
+// (a tail is part of one record).  prev == nullptr: first block of a file.
+__global__ void __launch_bounds__(256) k_fq_begin(uint8_t *buf, FqState *st, const uint8_t *prev_buf, const FqState *prev, uint64_t pad,
+                                                  uint64_t n_bytes) {
+    uint64_t tail = 0;
+    if (prev) {
+        tail = prev->parse_hi - prev->tail_lo;
+        if (tail > pad) { tail = pad; if (threadIdx.x == 0) atomicOr(&st->flags, 2u); }      // a record larger than the pad
+        const uint8_t *src = prev_buf + prev->parse_hi - tail;
+        uint8_t *dst = buf + pad - tail;
+        for (uint64_t i = threadIdx.x; i < tail; i += blockDim.x) dst[i] = src[i];
+    }
+    if (threadIdx.x == 0) {
+        st->parse_lo = pad - tail;
+        st->parse_hi = pad + n_bytes;
+        st->tail_in = tail;
+    }
+}
+
+hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
+                           uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
+                           uint32_t k, int last, uint32_t max_records, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_st, 0, sizeof(FqState), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fq_begin, dim3(1), dim3(256), 0, s, d_buf, d_st, d_prev_buf, d_prev_st, pad, n_bytes);
+    const uint32_t n_tiles = (uint32_t)((pad + n_bytes + kFqTile - 1) / kFqTile);
+    hipLaunchKernelGGL(k_fq_count, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
+    hipLaunchKernelGGL(k_fq_index, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt, d_nl);
+    hipLaunchKernelGGL(k_fq_records, dim3((max_records + 255) / 256), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, k, last);
+    return hipGetLastError();
+}
+
+}  // namespace hast

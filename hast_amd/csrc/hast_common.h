@@ -126,8 +126,8 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
 //   put for W consecutive windows and then jumps by W: density ~0.165 at K=21, m=13 (W=9, t=4) against 0.287 for the
 //   exact table's random minimizers (m=16, W=6): 23 instead of 39 blocks per 150-bp read (tools/sim/modmin_filter_sim.py).
 //   When the formula gives t = m the scheme IS the plain forward minimizer (large W).
-// A window whose print is in its sub-bucket, or whose sub-bucket is full (8 prints: then a key may not have found room),
-// is a POSITIVE and is looked up in the exact table, which alone decides hits and tag bits; everything else is a proven
+// A window whose print is in one of its two sub-buckets, or whose two sub-buckets are both full (then a key may not have
+// found room), is a POSITIVE and is looked up in the exact table, which alone decides hits and tag bits; everything else is a proven
 // miss.  So the filter can only cost time, never change a result.
 struct FilterGeom {
     int k, m, t;            // k-mer, sampled m-mer (m <= 14, 4^m blocks), ordering t-mer (t <= m)
@@ -167,6 +167,11 @@ HAST_HD uint32_t filter_keyhash(uint64_t kmer) {
     return h * 0x9E3779B1u;
 }
 HAST_HD uint32_t filter_sub_of(uint32_t keyhash) { return keyhash >> 29; }
+// Two-choice filing: a print may sit in either of two sub-buckets of its block (the less loaded one at build time; both
+// are in the same 128-B block, so a look-up still costs one request).  Only a window whose TWO sub-buckets are full has to
+// ask the table.  At 400M keys this takes the forced look-ups from 0.54 per read to none, at 800M 31-mers from 11 % of
+// the windows to 1-2 % (tools/sim/filter_load_sim.cpp).
+HAST_HD uint32_t filter_sub2_of(uint32_t keyhash) { return (keyhash >> 26) & 7u; }
 HAST_HD uint32_t filter_print_of(uint32_t keyhash) {
     const uint32_t f = (keyhash >> 8) & 0xFFFFu;
     return f ? f : 1u;

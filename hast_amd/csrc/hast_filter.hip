@@ -16,24 +16,47 @@ namespace hast {
 // 16-bit prints that fill in order (0 = free); a key that finds its sub-bucket full is simply not filed: lookups treat a
 // full sub-bucket as "ask the exact table".
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sub_load(const uint32_t *w) {                 // prints in a sub-bucket (they fill in order)
+    uint32_t n = 0;
+    for (int i = 0; i < kFilterPrints / 2; ++i) {
+        const uint32_t v = __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n += (v & 0xFFFFu) != 0;
+        n += (v >> 16) != 0;
+    }
+    return n;
+}
+// true: the print is in the sub-bucket now (it was there, or it found a free slot); false: the sub-bucket is full
+__device__ __forceinline__ bool sub_insert(uint32_t *w, uint32_t fp) {
+    for (int i = 0; i < kFilterPrints / 2;) {
+        const uint32_t v = __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+        if (lo == fp || hi == fp) return true;                       // an equal print is already there
+        uint32_t nv;
+        if (lo == 0) nv = v | fp;
+        else if (hi == 0) nv = v | (fp << 16);
+        else { ++i; continue; }
+        if (atomicCAS(&w[i], v, nv) == v) return true;               // else: someone else wrote this word, look again
+    }
+    return false;
+}
 __device__ __forceinline__ void filter_insert(uint32_t *filt, const FilterGeom g, uint64_t key) {
     for (int o = 0; o < 2; ++o) {
         const uint64_t s = o ? kmer_revcomp(key, g.k) : key;
         if (o && s == key) break;                                    // its own reverse complement
-        // block, sub-bucket and print all come from the string AS A READ WOULD SHOW IT: the probe never canonicalises
+        // block, sub-buckets and print all come from the string AS A READ WOULD SHOW IT: the probe never canonicalises
         const uint32_t blk = filter_block_of_string(s, g);
-        const uint32_t h = filter_keyhash(s), sub = filter_sub_of(h), fp = filter_print_of(h);
-        uint32_t *w = filt + (size_t)blk * (kFilterSubs * kFilterPrints / 2) + sub * (kFilterPrints / 2);
-        for (int i = 0; i < kFilterPrints / 2;) {
-            const uint32_t v = __hip_atomic_load(&w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-            if (lo == fp || hi == fp) break;                         // an equal print is already there
-            uint32_t nv;
-            if (lo == 0) nv = v | fp;
-            else if (hi == 0) nv = v | (fp << 16);
-            else { ++i; continue; }
-            if (atomicCAS(&w[i], v, nv) == v) break;                 // else: someone else wrote this word, look again
+        const uint32_t h = filter_keyhash(s), fp = filter_print_of(h);
+        uint32_t *b = filt + (size_t)blk * (kFilterSubs * kFilterPrints / 2);
+        uint32_t *w1 = b + filter_sub_of(h) * (kFilterPrints / 2), *w2 = b + filter_sub2_of(h) * (kFilterPrints / 2);
+        // the less loaded of the two first; a print that is already in either one is not filed again
+        bool there = false;
+        for (int i = 0; i < kFilterPrints / 2 && !there; ++i) {
+            const uint32_t v = __hip_atomic_load(&w2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            there = (v & 0xFFFFu) == fp || (v >> 16) == fp;
         }
+        if (there) continue;
+        if (w1 != w2 && sub_load(w2) < sub_load(w1)) { uint32_t *t = w1; w1 = w2; w2 = t; }
+        if (!sub_insert(w1, fp) && w1 != w2) (void)sub_insert(w2, fp);     // both full: not filed; such windows ask the table
     }
 }
 
@@ -57,19 +80,22 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 // ------------------------------------------------------------------------------------------
 // k_classify_f.  Workgroup = 256 threads = 4 wave64; tiles of TR reads go through LDS:
 //   A  pack   : as hast_kernels.hip: 16 ASCII bases per lane -> 32 bits of 2-bit codes; 'N' flag / invalid-byte mask.
-//   M  order  : one lane per t-mer position: e = tmer_order(t-mer, position); the first level of the sliding minimum,
-//               L1[q] = min(e[q .. q+g-1]) (g = 4), is formed in registers with two wave shuffles and stored.  A window's
-//               smallest t-mer (leftmost on ties) is then the minimum of ceil((kp-t+1)/4) L1 entries.
-//   B  probe  : each wave walks a contiguous quarter of the tile's 64-window blocks; every LANE owns one window: its K-mer by funnel shift out of the packed LDS words, smallest t-mer ->
-//               position x -> the m-mer at x mod W names the 128-B block, a hash of the K-mer as it stands the 16-B
-//               sub-bucket and the 16-bit print (no canonical form: every key was filed once per strand).  ONE 16-B load per window; consecutive windows (adjacent lanes)
-//               mostly name the same block, which the memory system fetches once.  Blocks of 64 windows are software-
-//               pipelined (loads of block i+1 are in flight while block i is compared).  Compare = 4 xor + 3 v_pk_min_u16
-//               + has-zero-halfword.  Positives (print found, or sub-bucket full) -- the real hits, about 1 % of the
-//               windows, plus a few in 10^5 false ones -- go to the wave's own queue in LDS.
+//   M  order  : e[q] = tmer_order(t-mer at q, q) for every position, and the first level of the sliding minimum,
+//               L1[q] = min(e[q .. q+3]): a lane takes 4 consecutive positions (one funnel shift, four hashes) and needs
+//               the prefix minima of the next lane's four (three wave shuffles).  A window's smallest t-mer (leftmost on
+//               ties) is then the minimum of ceil((kp-t+1)/4) L1 entries.
+//   B  probe  : each wave walks a contiguous quarter of the tile's 64-window blocks; every LANE owns one window: its
+//               K-mer by funnel shift out of the packed LDS words, smallest t-mer -> position x -> the m-mer at x mod W
+//               names the 128-B block, a hash of the K-mer as it stands names two 16-B sub-buckets and the 16-bit print
+//               (no canonical form anywhere in the probe: every key was filed once per strand).  Two 16-B loads per
+//               window, both in the one block; consecutive windows (adjacent lanes) mostly name the same block, which
+//               the memory system fetches once.  Blocks are software-pipelined: the loads of block i+1 are in flight
+//               while block i is compared (8 xor + 7 v_pk_min_u16 + has-zero-halfword).  Positives (print found, or both
+//               sub-buckets full) -- the real hits, about 1 % of the windows, plus a few in 10^5 false ones -- go to the
+//               wave's own queue in LDS.
 //   V  verify : when a wave's queue holds 64 positives (and at the end of the tile) each lane takes one, canonicalises it
-//               (v_bfrev) and finds it in the exact table (home bucket by the table's own minimizer, then the chain) and adds its tag bits to the
-//               read's votes in LDS.
+//               (v_bfrev) and finds it in the exact table (home bucket by the table's own minimizer, then the chain)
+//               and adds its tag bits to the read's votes in LDS.
 //   C  votes  : one lane per read stores {vote0, vote1}; k_commit_votes does the per-barcode bookkeeping.
 // ------------------------------------------------------------------------------------------
 constexpr int kThreadsF = 256;
@@ -282,7 +308,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             }
         };
         struct Blk {
-            u32x4f v;                                   // the 8 prints of this lane's window's sub-bucket
+            u32x4f v, v2;                               // the 2 x 8 prints of this lane's window's two sub-buckets
             uint32_t klo, khi, fpw, meta;               // the window's K-mer, print in both halves, read | valid << 31
         };
         auto start = [&](Blk &B, uint32_t blk) {
@@ -314,15 +340,18 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             const uint32_t fb = filter_block_of(mm, M);
             const uint32_t h = filter_keyhash(fwd);                   // of the window as it stands: no canonical form in the probe
             B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
+            B.v2 = filt[(size_t)fb * kFilterSubs + filter_sub2_of(h)];
             B.klo = (uint32_t)fwd;
             B.khi = (uint32_t)(fwd >> 32);
             B.fpw = filter_print_of(h) * 0x00010001u;
             B.meta = r | (ok ? 0x80000000u : 0u);
         };
         auto finish = [&](Blk &B) {
-            const uint32_t acc = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
+            const uint32_t a1 = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
+            const uint32_t a2 = pk_min_u16(pk_min_u16(B.v2.x ^ B.fpw, B.v2.y ^ B.fpw), pk_min_u16(B.v2.z ^ B.fpw, B.v2.w ^ B.fpw));
+            const uint32_t acc = pk_min_u16(a1, a2);
             const bool match = ((acc - 0x00010001u) & ~acc & 0x80008000u) != 0;      // some halfword of acc is zero
-            const bool full = (B.v.w >> 16) != 0;
+            const bool full = (B.v.w >> 16) != 0 && (B.v2.w >> 16) != 0;             // a key finds no room only when BOTH are full
             const bool pos = (int)B.meta < 0 && (match || full);
             const unsigned long long pmask = __ballot(pos);
             if (pmask) {
