@@ -24,6 +24,12 @@ class KcSynth(C.Structure):
                 ("err_per_4096", C.c_uint32), ("n_per_4096", C.c_uint32)]
 
 
+class FqBlock(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("max_read_len", C.c_uint32), ("short_read", C.c_uint32),
+                ("bytes", C.POINTER(C.c_uint8)), ("bc_pos", C.POINTER(C.c_uint32)), ("bc_len", C.POINTER(C.c_uint32)),
+                ("ids", C.POINTER(C.c_uint32))]
+
+
 KC_HISTO_HIGH = 10000
 
 # every symbol include/hast.h declares: name -> (restype, argtypes)
@@ -71,6 +77,13 @@ ABI_SYMBOLS = {
     "hast_classify_perread": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "hast_batch_begin": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "hast_batch_submit": (C.c_int, [vp, C.c_size_t, C.c_uint32]),
+    "hast_fq_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
+    "hast_fq_destroy": (None, [vp]),
+    "hast_fq_block_bytes": (C.c_size_t, [vp]),
+    "hast_fq_acquire": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8))]),
+    "hast_fq_submit": (C.c_int, [vp, C.c_size_t, C.c_int]),
+    "hast_fq_next": (C.c_int, [vp, C.POINTER(FqBlock)]),
+    "hast_fq_commit": (C.c_int, [vp]),
     "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hast_get_hap": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
     "hast_canon_kmer": (C.c_uint64, [C.c_char_p, C.c_int]),

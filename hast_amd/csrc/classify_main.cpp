@@ -16,18 +16,23 @@
 // on the first one and copied to the others over xGMI, parsed batches are dealt round-robin, the per-barcode counters are
 // summed with ONE RCCL all-reduce at the end -- the thread merge of classify.cpp:226-229,276-277 across GPUs; integer sums,
 // so stdout is byte-identical to a single-GPU run), --block-mb N (ingest block size), --batch-reads N
-// (approximate records per GPU batch, for tests), --initial-barcodes N, --stats (timings on stderr).
+// (approximate records per GPU batch, for tests), --initial-barcodes N, --stats (timings on stderr), --host-parse (frame the
+// FASTQ records on the host as round 1 did; default: raw file bytes go to the GPU and are framed there, hast_fq_*).
 // -t/--thread N is honoured as the number of host parser threads.
 #include <getopt.h>
 
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <string_view>
 #include <unordered_map>
 #include <vector>
@@ -149,7 +154,7 @@ int main(int argc, char **argv) {
         {"batch-reads", required_argument, NULL, 1002}, {"stats", no_argument, NULL, 1003},
         {"block-mb", required_argument, NULL, 1004},    {"initial-barcodes", required_argument, NULL, 1005},
         {"save-table", required_argument, NULL, 1006},  {"load-table", required_argument, NULL, 1007},
-        {"devices", required_argument, NULL, 1008},
+        {"devices", required_argument, NULL, 1008},     {"host-parse", no_argument, NULL, 1009},
         {0, 0, 0, 0}};
     static char optstring[] = "p:m:l:r:t:w:u:f:q:h";             // classify.cpp:387
     std::string hap0, hap1, save_table, load_table;
@@ -159,7 +164,7 @@ int main(int argc, char **argv) {
     int t_num = 8, device = 0;
     std::vector<int> devices;
     size_t batch_reads = 0, block_mb = 256, initial_barcodes = 1u << 20;
-    bool stats = false;
+    bool stats = false, host_parse = false;
     double w0 = 1.0, w1 = 1.0;
     for (;;) {
         int c = getopt_long(argc, argv, optstring, long_options, NULL);
@@ -180,6 +185,7 @@ int main(int argc, char **argv) {
         case 1005: initial_barcodes = (size_t)std::max(1L, atol(optarg)); break;
         case 1006: save_table = optarg; break;
         case 1007: load_table = optarg; break;
+        case 1009: host_parse = true; break;
         case 1008:
             for (const char *q = optarg; *q;) {
                 char *end;
@@ -442,7 +448,7 @@ int main(int argc, char **argv) {
         src.recycle(std::move(blk));
         return true;
     };
-    {
+    if (host_parse) {
         const size_t max_active = 4;                   // concurrent reader threads (3 prefetched blocks each)
         std::vector<FileState> active;
         size_t next_file = 0;
@@ -466,6 +472,160 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "__process read done__\n");
                 active.erase(active.begin() + (long)i);
                 if (next_file < read.size()) open_next();
+            }
+        }
+    }
+    else {
+        // ---- raw bytes to the GPU, records framed there (hast_fq_*, fq_kernels.hip) -------------------------------------
+        // per file: a reader thread fills the pinned buffers the library hands out (pread / inflate straight into them); this
+        // thread submits them, maps the barcode text of every record to its id (in parallel) and commits.  Files go to the
+        // GPUs round-robin; a file's blocks stay on one GPU (the unfinished record at the end of a block is carried on the device).
+        struct Feed {
+            std::string name;
+            hast::BlockSource src;
+            hast_fq *fq = nullptr;
+            std::thread th;
+            std::mutex mu;
+            std::condition_variable cv;
+            std::deque<uint8_t *> empty;                           // acquired, waiting for the reader
+            struct Filled { size_t n; bool last; std::string err; };
+            std::deque<Filled> filled;                             // filled, in order, waiting for hast_fq_submit
+            bool stop = false, eof_acquired = false;
+            size_t held = 0;                                       // acquired and not yet committed
+            size_t submitted = 0, opened = 0;
+        };
+        const int n_buf = 3;
+        std::mutex wake_mu;
+        std::condition_variable wake_cv;
+        uint64_t wake_gen = 0;
+        std::vector<std::unique_ptr<Feed>> active;
+        size_t next_file = 0;
+        const size_t cap = std::max<size_t>(4096, std::min<size_t>(block_bytes, 64u << 20));
+        auto open_next = [&]() {
+            const std::string &r = read[next_file];
+            fprintf(stderr, "__process read: %s\n", r.c_str());
+            std::unique_ptr<Feed> f(new Feed());
+            f->name = r;
+            if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
+            CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, &f->fq), "creating the FASTQ stream");
+            next_file++;
+            Feed *fp = f.get();
+            f->th = std::thread([fp, cap, &wake_mu, &wake_cv, &wake_gen] {
+                for (;;) {
+                    uint8_t *buf;
+                    {
+                        std::unique_lock<std::mutex> g(fp->mu);
+                        fp->cv.wait(g, [fp] { return fp->stop || !fp->empty.empty(); });
+                        if (fp->stop) return;
+                        buf = fp->empty.front();
+                        fp->empty.pop_front();
+                    }
+                    Feed::Filled fl{0, false, std::string()};
+                    fl.n = fp->src.read_into(reinterpret_cast<char *>(buf), cap, fl.err);
+                    fl.last = fl.n < cap || !fl.err.empty();
+                    {
+                        std::lock_guard<std::mutex> g(fp->mu);
+                        fp->filled.push_back(fl);
+                    }
+                    {
+                        std::lock_guard<std::mutex> g(wake_mu);
+                        ++wake_gen;
+                    }
+                    wake_cv.notify_one();
+                    if (fl.last) return;
+                }
+            });
+            active.push_back(std::move(f));
+        };
+        const size_t max_active = std::max<size_t>(4, 2 * ctxs.size());
+        while (next_file < read.size() && active.size() < max_active) open_next();
+        uint64_t seen_gen = 0;
+        // names the barcodes of the oldest submitted block of a feed and commits it
+        auto open_block = [&](Feed &f) {
+            hast_fq_block b;
+            CK(hast_fq_next(f.fq, &b), "framing a block");
+            if (b.short_read) {
+                fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, f.name.c_str());
+                exit(3);                                                                   // reference: assert abort (kmer.h:171)
+            }
+            const size_t n = (size_t)b.n_records;
+            pool.run([&](int t) {
+                const size_t lo = n * (size_t)t / T, hi_ = n * (size_t)(t + 1) / T;
+                for (size_t i = lo; i < hi_; i++)
+                    b.ids[i] = dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]);
+            });
+            if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
+            CK(hast_fq_commit(f.fq), "classifying a block");
+            f.opened++;
+            f.held--;
+            total_reads += n;
+            total_bases += b.n_bases;
+        };
+        while (!active.empty()) {
+            bool progress = false;
+            for (size_t fi = 0; fi < active.size(); ++fi) {
+                Feed &f = *active[fi];
+                // 1. hand empty buffers to the reader
+                while (!f.eof_acquired && f.held < (size_t)n_buf) {
+                    uint8_t *buf;
+                    CK(hast_fq_acquire(f.fq, &buf), "staging a block");
+                    f.held++;
+                    std::lock_guard<std::mutex> g(f.mu);
+                    f.empty.push_back(buf);
+                    f.cv.notify_one();
+                    progress = true;
+                }
+                // 2. submit what the reader has filled (copy + framing run on the GPU from here on)
+                for (;;) {
+                    Feed::Filled fl;
+                    {
+                        std::lock_guard<std::mutex> g(f.mu);
+                        if (f.filled.empty()) break;
+                        fl = f.filled.front();
+                        f.filled.pop_front();
+                    }
+                    if (!fl.err.empty()) die(2, (f.name + ": " + fl.err).c_str());
+                    CK(hast_fq_submit(f.fq, fl.n, fl.last ? 1 : 0), "framing a block");
+                    f.submitted++;
+                    if (fl.last) f.eof_acquired = true;
+                    progress = true;
+                }
+            }
+            // 3. blocks whose successor is already on its way to the GPU (or the file's last ones): name barcodes, commit
+            for (size_t fi = 0; fi < active.size();) {
+                Feed &f = *active[fi];
+                while (f.opened < f.submitted && (f.submitted - f.opened >= 2 || f.eof_acquired)) {
+                    open_block(f);
+                    progress = true;
+                }
+                if (f.eof_acquired && f.opened == f.submitted) {
+                    {
+                        std::lock_guard<std::mutex> g(f.mu);
+                        f.stop = true;
+                    }
+                    f.cv.notify_all();
+                    f.th.join();
+                    hast_fq_destroy(f.fq);
+                    logtime();
+                    fprintf(stderr, "__process read done__\n");
+                    active.erase(active.begin() + (long)fi);
+                    if (next_file < read.size()) open_next();
+                    progress = true;
+                    continue;
+                }
+                ++fi;
+            }
+            if (!progress)                                         // slow readers (one gz stream): do not sit on a finished block
+                for (auto &fp : active)
+                    if (fp->opened < fp->submitted) {
+                        open_block(*fp);
+                        progress = true;
+                        break;
+                    }
+            if (!progress) {                                       // everything waits for a reader thread
+                std::unique_lock<std::mutex> g(wake_mu);
+                wake_cv.wait_for(g, std::chrono::milliseconds(2), [&] { return wake_gen != seen_gen; });
+                seen_gen = wake_gen;
             }
         }
     }

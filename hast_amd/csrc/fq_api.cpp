@@ -1,0 +1,228 @@
+// fq_api.cpp -- hast_fq_*: a FASTQ stream framed on the GPU (include/hast.h, "FASTQ framing").  The caller puts raw file bytes
+// into pinned buffers; everything the reference's producer thread does per record (classify.cpp:238-278: four getlines,
+// parseName) happens in fq_kernels.hip, the reads are classified where they lie in the raw block, and the host only has to
+// name the barcodes (text -> dense id, one dictionary per job) before the per-barcode bookkeeping runs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/hast.h"
+#include "fq_device.h"
+#include "hast_internal.h"
+
+using namespace hast;
+
+namespace {
+#define FQ_TRY(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return set_error(e_ == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Slot {
+    uint8_t *h_buf = nullptr, *d_buf = nullptr;        // pad + block bytes (+ slack)
+    FqState *d_st = nullptr, *h_st = nullptr;          // h_st pinned
+    uint32_t *d_tile = nullptr, *d_nl = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_len = nullptr, *d_bcpos = nullptr, *d_bclen = nullptr, *d_ids = nullptr, *d_votes = nullptr;
+    uint32_t *h_bc = nullptr, *h_ids = nullptr;        // pinned, grown on demand: h_bc = [pos | len]
+    size_t h_cap = 0;                                  // records the pinned arrays hold
+    size_t n_bytes = 0;
+    int last = 0;
+    hipEvent_t parsed = nullptr, done = nullptr;
+    enum { FREE, ACQUIRED, SUBMITTED, OPEN } state = FREE;
+    bool done_pending = false;
+};
+}  // namespace
+
+struct hast_fq {
+    hast_ctx *ctx = nullptr;
+    int device = 0, k = 0;
+    size_t block = 0, pad = 0, max_rec = 0;
+    std::vector<Slot> slots;
+    size_t n_acquired = 0, n_submitted = 0, n_opened = 0;      // blocks handed out / submitted / returned by hast_fq_next
+    int prev_submitted = -1;                                   // slot of the previous block of this file (device-side tail)
+    std::vector<uint8_t> carry;                                // host copy of the previous block's tail (barcodes may lie in it)
+};
+
+static void free_slot(Slot &s) {
+    if (s.h_buf) (void)hipHostFree(s.h_buf);
+    if (s.h_st) (void)hipHostFree(s.h_st);
+    if (s.h_bc) (void)hipHostFree(s.h_bc);
+    if (s.h_ids) (void)hipHostFree(s.h_ids);
+    for (void *p : {(void *)s.d_buf, (void *)s.d_st, (void *)s.d_tile, (void *)s.d_nl, (void *)s.d_off, (void *)s.d_len, (void *)s.d_bcpos,
+                    (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes})
+        if (p) (void)hipFree(p);
+    if (s.parsed) (void)hipEventDestroy(s.parsed);
+    if (s.done) (void)hipEventDestroy(s.done);
+    s = Slot();
+}
+
+extern "C" {
+
+hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, hast_fq **out) {
+    if (!ctx || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (block_bytes < 4096 || block_bytes > (1ull << 30)) return set_error(HAST_ERR_INVALID, "block_bytes %zu out of [4 KB, 1 GB]", block_bytes);
+    if (n_buffers < 2 || n_buffers > 16) return set_error(HAST_ERR_INVALID, "n_buffers %d out of [2,16]", n_buffers);
+    FQ_TRY(hipSetDevice(hast_ctx_device(ctx)));
+    hast_fq *f = new (std::nothrow) hast_fq();
+    if (!f) return set_error(HAST_ERR_OOM, "host allocation failed");
+    f->ctx = ctx;
+    f->device = hast_ctx_device(ctx);
+    f->k = hast_ctx_k(ctx);
+    f->block = (block_bytes + 4095) & ~(size_t)4095;
+    f->pad = std::min<size_t>(std::max<size_t>(f->block / 8, 64 << 10), 4u << 20);     // room for the largest record that straddles two blocks
+    f->pad = (f->pad + 4095) & ~(size_t)4095;
+    const size_t buf = f->pad + f->block + 4096;
+    f->max_rec = (f->pad + f->block) / 4 + 2;                                           // a record holds at least four newlines
+    f->slots.resize((size_t)n_buffers);
+    hast_status st = HAST_OK;
+    auto ck = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && st == HAST_OK) st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    for (Slot &s : f->slots) {
+        ck(hipHostMalloc((void **)&s.h_buf, buf, hipHostMallocDefault), "pinned block");
+        ck(hipHostMalloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault), "pinned state");
+        ck(hipMalloc((void **)&s.d_buf, buf), "device block");
+        ck(hipMalloc((void **)&s.d_st, sizeof(FqState)), "device state");
+        ck(hipMalloc((void **)&s.d_tile, (buf / 4096 + 2) * sizeof(uint32_t)), "tile counts");
+        ck(hipMalloc((void **)&s.d_nl, (f->pad + f->block + 16) * sizeof(uint32_t)), "newline index");
+        ck(hipMalloc((void **)&s.d_off, f->max_rec * sizeof(uint64_t)), "record offsets");
+        for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) ck(hipMalloc((void **)p, f->max_rec * sizeof(uint32_t)), "record arrays");
+        ck(hipMalloc((void **)&s.d_votes, f->max_rec * 2 * sizeof(uint32_t)), "votes");
+        ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
+        ck(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event");
+        if (st != HAST_OK) break;
+    }
+    if (st != HAST_OK) {
+        hast_fq_destroy(f);
+        return st;
+    }
+    *out = f;
+    return HAST_OK;
+}
+
+void hast_fq_destroy(hast_fq *f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipStreamSynchronize(ctx_stream_of(f->ctx));
+    for (Slot &s : f->slots) free_slot(s);
+    delete f;
+}
+
+size_t hast_fq_block_bytes(const hast_fq *f) { return f ? f->block : 0; }
+
+hast_status hast_fq_acquire(hast_fq *f, uint8_t **host_buf) {
+    if (!f || !host_buf) return set_error(HAST_ERR_INVALID, "null argument");
+    Slot &s = f->slots[f->n_acquired % f->slots.size()];
+    if (s.state != Slot::FREE) return set_error(HAST_ERR_INVALID, "hast_fq_acquire: all %zu buffers are in use (commit the oldest block first)", f->slots.size());
+    FQ_TRY(hipSetDevice(f->device));
+    if (s.done_pending) {
+        FQ_TRY(hipEventSynchronize(s.done));
+        s.done_pending = false;
+    }
+    s.state = Slot::ACQUIRED;
+    f->n_acquired++;
+    *host_buf = s.h_buf + f->pad;
+    return HAST_OK;
+}
+
+hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
+    if (!f) return set_error(HAST_ERR_INVALID, "null argument");
+    if (f->n_submitted >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_submit without hast_fq_acquire");
+    if (n_bytes > f->block) return set_error(HAST_ERR_INVALID, "block of %zu bytes exceeds the capacity %zu", n_bytes, f->block);
+    const int si = (int)(f->n_submitted % f->slots.size());
+    Slot &s = f->slots[(size_t)si];
+    FQ_TRY(hipSetDevice(f->device));
+    hipStream_t hs = ctx_stream_of(f->ctx);
+    s.n_bytes = n_bytes;
+    s.last = last;
+    if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, hs));
+    const Slot *prev = f->prev_submitted >= 0 ? &f->slots[(size_t)f->prev_submitted] : nullptr;
+    FQ_TRY(launch_fq_block(s.d_buf, s.d_st, prev ? prev->d_buf : nullptr, prev ? prev->d_st : nullptr, f->pad, n_bytes, s.d_tile, s.d_nl, s.d_off,
+                           s.d_len, s.d_bcpos, s.d_bclen, (uint32_t)f->k, last, (uint32_t)f->max_rec, hs));
+    FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, hs));
+    FQ_TRY(hipEventRecord(s.parsed, hs));
+    s.state = Slot::SUBMITTED;
+    f->n_submitted++;
+    f->prev_submitted = last ? -1 : si;                       // the next block starts a new file after `last`
+    return HAST_OK;
+}
+
+hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
+    if (!f || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (f->n_opened >= f->n_submitted) return set_error(HAST_ERR_INVALID, "hast_fq_next: no submitted block");
+    Slot &s = f->slots[f->n_opened % f->slots.size()];
+    if (s.state != Slot::SUBMITTED) return set_error(HAST_ERR_INVALID, "hast_fq_next: commit the previous block first");
+    FQ_TRY(hipSetDevice(f->device));
+    hipStream_t hs = ctx_stream_of(f->ctx);
+    FQ_TRY(hipEventSynchronize(s.parsed));
+    const FqState st = *s.h_st;
+    if (st.flags & 2) return set_error(HAST_ERR_FORMAT, "a FASTQ record is larger than %zu bytes", f->pad);
+    if (st.n_rec > f->max_rec) return set_error(HAST_ERR_INVALID, "record table overflow");
+    const size_t n = st.n_rec;
+    if (s.h_cap < n) {
+        if (s.h_bc) FQ_TRY(hipHostFree(s.h_bc));
+        if (s.h_ids) FQ_TRY(hipHostFree(s.h_ids));
+        s.h_bc = s.h_ids = nullptr;
+        s.h_cap = 0;
+        const size_t cap = n + n / 4 + 1024;
+        FQ_TRY(hipHostMalloc((void **)&s.h_bc, 2 * cap * sizeof(uint32_t), hipHostMallocDefault));
+        FQ_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
+        s.h_cap = cap;
+    }
+    if (n) {
+        FQ_TRY(hipMemcpyAsync(s.h_bc, s.d_bcpos, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+        FQ_TRY(hipMemcpyAsync(s.h_bc + s.h_cap, s.d_bclen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+        // the reads are classified where they lie in the raw block while the host names the barcodes
+        if (!(st.flags & 1))
+            if (hast_status c = classify_framed(f->ctx, s.d_buf, f->pad + s.n_bytes, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
+        FQ_TRY(hipEventRecord(s.parsed, hs));
+        FQ_TRY(hipEventSynchronize(s.parsed));                 // (waits for the two small copies; the kernels were enqueued before the record)
+    }
+    // host view of the bytes the barcode extents point into: this block's bytes, preceded by the previous block's tail
+    if (st.tail_in != f->carry.size()) return set_error(HAST_ERR_INVALID, "tail bookkeeping out of step (%llu vs %zu)", (unsigned long long)st.tail_in, f->carry.size());
+    if (!f->carry.empty()) memcpy(s.h_buf + f->pad - f->carry.size(), f->carry.data(), f->carry.size());
+    const size_t tail = s.last ? 0 : (size_t)(st.parse_hi - st.tail_lo);
+    f->carry.assign(s.h_buf + st.parse_hi - tail, s.h_buf + st.parse_hi);
+    out->n_records = n;
+    out->n_bases = st.bases;
+    out->max_read_len = st.max_len;
+    out->short_read = (st.flags & 1) ? 1 : 0;
+    out->bytes = s.h_buf;
+    out->bc_pos = s.h_bc;
+    out->bc_len = s.h_bc + s.h_cap;
+    out->ids = s.h_ids;
+    s.state = Slot::OPEN;
+    f->n_opened++;
+    return HAST_OK;
+}
+
+hast_status hast_fq_commit(hast_fq *f) {
+    if (!f) return set_error(HAST_ERR_INVALID, "null argument");
+    if (f->n_opened == 0) return set_error(HAST_ERR_INVALID, "hast_fq_commit without hast_fq_next");
+    Slot &s = f->slots[(f->n_opened - 1) % f->slots.size()];
+    if (s.state != Slot::OPEN) return set_error(HAST_ERR_INVALID, "hast_fq_commit: no open block");
+    FQ_TRY(hipSetDevice(f->device));
+    hipStream_t hs = ctx_stream_of(f->ctx);
+    const size_t n = s.h_st->n_rec;
+    if (n && !(s.h_st->flags & 1)) {
+        const size_t nbc = ctx_n_barcodes(f->ctx);
+        for (size_t i = 0; i < n; ++i)
+            if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %zu is outside the %zu counters", s.h_ids[i], i, nbc);
+        FQ_TRY(hipMemcpyAsync(s.d_ids, s.h_ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
+        if (hast_status c = commit_framed(f->ctx, s.d_votes, s.d_ids, n, hs)) return c;
+    }
+    FQ_TRY(hipEventRecord(s.done, hs));
+    s.done_pending = true;
+    s.state = Slot::FREE;
+    return HAST_OK;
+}
+
+}  // extern "C"

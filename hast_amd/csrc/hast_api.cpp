@@ -806,7 +806,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     return HAST_OK;
 }
 
-static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets, const uint32_t *d_lens,
                                       size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
                                       hipStream_t hs);
 static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
@@ -877,7 +877,7 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
         // stage-01 semantics on long reads: whole-read N skip by a pre-pass, windows through segments
         if (d_barcode_ids && !c->d_counts) return fail(HAST_ERR_INVALID, "barcode ids given but no counters bound");
         if (hast_status st = use(c)) return st;
-        return classify_segmented(c, d_bases, bases_bytes, d_offsets, n_reads, 0, d_barcode_ids, d_votes, s ? (hipStream_t)s : c->stream);
+        return classify_segmented(c, d_bases, bases_bytes, d_offsets, nullptr, n_reads, 0, d_barcode_ids, d_votes, s ? (hipStream_t)s : c->stream);
     }
     return classify_rows(c, d_bases, bases_bytes, d_offsets, nullptr, nullptr, 0, read_len, d_barcode_ids, d_votes, n_reads, s);
 }
@@ -886,7 +886,7 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
 //   strict = 1: stage-03 semantics (per-window validity), votes written to d_votes_out.
 //   strict = 0: stage-01 semantics (a read holding 'N' is skipped as a whole: found by a pre-pass, such reads get no
 //               windows), then per-read bookkeeping into the barcode counters and/or d_votes_out.
-static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
+static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets, const uint32_t *d_lens,
                                       size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
                                       hipStream_t hs) {
     const size_t max_seg = n_reads + bases_bytes / kSegWindows + 1;
@@ -910,8 +910,8 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
     uint32_t *target = strict ? d_votes_out : acc;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), hs));
     HIP_TRY(hipMemsetAsync(target, 0, n_reads * 2 * sizeof(uint32_t), hs));
-    if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, n_reads, has_n, hs));
-    HIP_TRY(launch_build_segments(d_offsets, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt,
+    if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, d_lens, n_reads, has_n, hs));
+    HIP_TRY(launch_build_segments(d_offsets, d_lens, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt,
                                   strict ? nullptr : has_n, hs));
     unsigned long long n_seg = 0;
     HIP_TRY(hipMemcpyAsync(&n_seg, c->d_cnt, sizeof(n_seg), hipMemcpyDeviceToHost, hs));
@@ -929,7 +929,7 @@ hast_status hast_classify_perread_device(hast_ctx *c, const uint8_t *d_bases, si
     if (hast_status st = need_table(c, 0)) return st;
     if (n_reads == 0) return HAST_OK;
     if (!d_bases || !d_offsets || !d_votes) return fail(HAST_ERR_INVALID, "null argument");
-    return classify_segmented(c, d_bases, bases_bytes, d_offsets, n_reads, 1, nullptr, d_votes, s ? (hipStream_t)s : c->stream);
+    return classify_segmented(c, d_bases, bases_bytes, d_offsets, nullptr, n_reads, 1, nullptr, d_votes, s ? (hipStream_t)s : c->stream);
 }
 
 hast_status hast_classify_perread(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, size_t n_reads,
@@ -1035,6 +1035,29 @@ hast_status hast_classify_batch(hast_ctx *c, const uint8_t *bases, const uint64_
     memcpy(hi, ids, n_reads * sizeof(uint32_t));
     return hast_batch_submit(c, n_reads, max_read_len);
 }
+
+}  // extern "C"
+
+// ---- hooks for fq_api.cpp (hast_internal.h): reads given as starts + lengths inside a raw FASTQ block -----------------
+namespace hast {
+hast_status classify_framed(hast_ctx *c, const uint8_t *d_buf, size_t buf_bytes, const uint64_t *d_off, const uint32_t *d_len, uint32_t max_len,
+                            uint32_t *d_votes, size_t n_reads, hipStream_t hs) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (n_reads == 0) return HAST_OK;
+    if (max_len > kLongRead) return classify_segmented(c, d_buf, buf_bytes, d_off, d_len, n_reads, 0, nullptr, d_votes, hs);
+    return classify_rows(c, d_buf, buf_bytes, d_off, d_len, nullptr, 0, max_len ? max_len : 1, nullptr, d_votes, n_reads, hs);
+}
+hast_status commit_framed(hast_ctx *c, const uint32_t *d_votes, const uint32_t *d_ids, size_t n_reads, hipStream_t hs) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters bound");
+    HIP_TRY(launch_commit_votes(d_votes, d_ids, c->d_counts, nullptr, n_reads, hs));
+    return HAST_OK;
+}
+hipStream_t ctx_stream_of(hast_ctx *c) { return c->stream; }
+size_t ctx_n_barcodes(const hast_ctx *c) { return c->n_barcodes; }
+}  // namespace hast
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------
 // host-side pieces

@@ -202,7 +202,9 @@ class BarcodeDict {
 class BlockSource {
   public:
     ~BlockSource() { close(); }
-    bool open(const std::string &path, size_t block_bytes) {
+    // threaded = false: no background reader; the caller pulls the bytes with read_into() from a thread of its own
+    // (the GPU-framing path reads straight into pinned staging memory)
+    bool open(const std::string &path, size_t block_bytes, bool threaded = true) {
         close();
         const size_t n = path.size();
         gz_mode_ = n > 3 && path.compare(n - 3, 3, ".gz") == 0;               // classify.cpp:245-249
@@ -233,7 +235,7 @@ class BlockSource {
         plain_off_ = -1;
         eof_ = false;
         stop_ = false;
-        reader_ = std::thread([this] { pump(); });
+        if (threaded) reader_ = std::thread([this] { pump(); });
         return true;
     }
     void close() {
@@ -274,7 +276,44 @@ class BlockSource {
         free_.push_back(std::move(b));
     }
 
+    // Next up-to-`want` bytes of the (decompressed) input into dst; fewer than `want` only at the end of the input.  On a
+    // damaged input returns what could be read and sets `trouble`.  Only for sources opened with threaded = false.
+    size_t read_into(char *dst, size_t want, std::string &trouble) { return fill(dst, want, trouble); }
+
   private:
+    size_t fill(char *dst, size_t want, std::string &trouble) {
+        size_t got = 0;
+        while (got < want) {
+            long r;
+            if (gz_mode_ && use_zlib_) {
+                r = (long)gzread(gz_, dst + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
+                if (r <= 0) {                      // 0 is also what a stream that ends too early gives: ask
+                    int en = 0;
+                    const char *msg = gzerror(gz_, &en);
+                    if (en != Z_OK && en != Z_STREAM_END) trouble = std::string("gz: ") + msg;
+                }
+            } else if (gz_mode_ && bgzf_) {
+                r = bgzf_reader_.read(reinterpret_cast<uint8_t *>(dst + got), want - got);
+                if (r == -2) {                     // a member that is not BGZF: the serial decoder takes over from there
+                    bgzf_ = false;
+                    if (fseek(fp_, (long)bgzf_reader_.resume_offset(), SEEK_SET) != 0) trouble = "gz: cannot seek";
+                    else {
+                        inflater_.open(fp_, 4u << 20);
+                        continue;
+                    }
+                }
+                if (r == -1) trouble = bgzf_reader_.error();
+            } else if (gz_mode_) {
+                r = inflater_.read(reinterpret_cast<uint8_t *>(dst + got), want - got);
+                if (r < 0) trouble = inflater_.error();
+            } else if (fp_ != stdin && want >= (32u << 20) && plain_off_ != -2) {
+                r = parallel_pread(dst + got, want - got);     // regular file: several readers per block (never mixed with fread)
+            } else r = (long)fread(dst + got, 1, want - got, fp_);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        return got;
+    }
     void pump() {
         for (;;) {
             std::vector<char> b;
@@ -288,38 +327,8 @@ class BlockSource {
                 }
             }
             b.resize(kFrontPad + block_bytes_);
-            char *dst = b.data() + kFrontPad;
-            size_t got = 0;
             std::string trouble;
-            while (got < block_bytes_) {
-                long r;
-                if (gz_mode_ && use_zlib_) {
-                    r = (long)gzread(gz_, dst + got, (unsigned)std::min<size_t>(block_bytes_ - got, 1u << 30));
-                    if (r <= 0) {                      // 0 is also what a stream that ends too early gives: ask
-                        int en = 0;
-                        const char *msg = gzerror(gz_, &en);
-                        if (en != Z_OK && en != Z_STREAM_END) trouble = std::string("gz: ") + msg;
-                    }
-                } else if (gz_mode_ && bgzf_) {
-                    r = bgzf_reader_.read(reinterpret_cast<uint8_t *>(dst + got), block_bytes_ - got);
-                    if (r == -2) {                     // a member that is not BGZF: the serial decoder takes over from there
-                        bgzf_ = false;
-                        if (fseek(fp_, (long)bgzf_reader_.resume_offset(), SEEK_SET) != 0) trouble = "gz: cannot seek";
-                        else {
-                            inflater_.open(fp_, 4u << 20);
-                            continue;
-                        }
-                    }
-                    if (r == -1) trouble = bgzf_reader_.error();
-                } else if (gz_mode_) {
-                    r = inflater_.read(reinterpret_cast<uint8_t *>(dst + got), block_bytes_ - got);
-                    if (r < 0) trouble = inflater_.error();
-                } else if (fp_ != stdin && block_bytes_ >= (32u << 20) && plain_off_ != -2) {
-                    r = parallel_pread(dst + got, block_bytes_ - got);     // regular file: several readers per block (never mixed with fread)
-                } else r = (long)fread(dst + got, 1, block_bytes_ - got, fp_);
-                if (r <= 0) break;
-                got += (size_t)r;
-            }
+            const size_t got = fill(b.data() + kFrontPad, block_bytes_, trouble);
             b.resize(kFrontPad + got);
             std::lock_guard<std::mutex> g(mu_);
             if (!trouble.empty()) error_ = trouble;

@@ -194,6 +194,42 @@ hast_status hast_batch_begin(hast_ctx *, size_t bases_capacity, size_t reads_cap
                              uint8_t **bases, uint64_t **offsets, uint32_t **barcode_ids);
 hast_status hast_batch_submit(hast_ctx *, size_t n_reads, uint32_t max_read_len);
 
+/* ---- FASTQ framing on the GPU: processFastq (classify.cpp:238-278) --------------------------------
+ * The reference's producer thread reads a record as four getlines (no '@'/'+' validation, no CR stripping), takes the
+ * barcode out of line 1 (parseName, :112-119) and hands line 2 to a worker.  hast_fq does that framing for whole blocks of
+ * raw file bytes on the device: the caller only moves bytes (pread / inflate straight into the pinned buffer it is given)
+ * and names barcodes; the reads are classified where they lie in the raw block.  Per block, in this order:
+ *     hast_fq_acquire   pinned host memory for the next block_bytes of the file (waits until that buffer is free again)
+ *     hast_fq_submit    n_bytes are in it; last != 0: the file ends here (the EOF rules of classify.cpp:257-268 apply:
+ *                       a final record counts when its header line is terminated).  Enqueues the copy and the framing.
+ *     hast_fq_next      oldest submitted block: waits for its record table, starts the classification of its reads, and
+ *                       gives the barcode text extents of its records: record i's barcode = bytes[bc_pos[i] .. +bc_len[i])
+ *     (caller)          ids[i] = dense id of that barcode (one dictionary per job, shared by all GPUs; < n_barcodes of
+ *                       the context's counters)
+ *     hast_fq_commit    copies the ids over and runs the per-barcode bookkeeping (classify.cpp:203-208); frees the buffer
+ * Blocks may be submitted ahead of hast_fq_next (n_buffers of them); records that straddle two blocks are handled on the
+ * device (the unfinished tail of a block is put in front of the next one), up to 4 MB per record.  After a block submitted
+ * with last != 0 the next one starts a new file.  One hast_fq per input stream; several may share a context. */
+typedef struct hast_fq hast_fq;
+typedef struct {
+    uint64_t n_records;        /* records framed in this block */
+    uint64_t n_bases;          /* sum of their base-line lengths */
+    uint32_t max_read_len;
+    uint32_t short_read;       /* != 0: some read is shorter than K and holds no 'N' (the reference aborts, kmer.h:171);
+                                  nothing of this block has been classified */
+    const uint8_t *bytes;      /* host view of the block (with the previous block's tail in front of it) */
+    const uint32_t *bc_pos;    /* [n_records] */
+    const uint32_t *bc_len;    /* [n_records] */
+    uint32_t *ids;             /* [n_records], to be filled by the caller before hast_fq_commit */
+} hast_fq_block;
+hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_fq **out);
+void        hast_fq_destroy(hast_fq *);
+size_t      hast_fq_block_bytes(const hast_fq *);
+hast_status hast_fq_acquire(hast_fq *, uint8_t **host_buf);
+hast_status hast_fq_submit(hast_fq *, size_t n_bytes, int last);
+hast_status hast_fq_next(hast_fq *, hast_fq_block *out);
+hast_status hast_fq_commit(hast_fq *);
+
 /* ---- host-side pieces of the path (no device work) ---------------------------------------- */
 /* parseName (classify.cpp:112-119): barcode = head[last '#' + 1 .. last '/'). */
 void     hast_parse_barcode(const char *head, size_t len, size_t *start, size_t *n);

@@ -19,11 +19,12 @@ def exe():
     return hast_amd.classify_exe()
 
 
+@pytest.mark.parametrize("extra", [[], ["--host-parse"]])
 @pytest.mark.parametrize("case,run", golden_cases("s01"))
-def test_cli_matches_reference_golden(exe, golden_workdir, case, run):
+def test_cli_matches_reference_golden(exe, golden_workdir, case, run, extra):
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case
-    res = subprocess.run([exe] + meta["argv"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    res = subprocess.run([exe] + meta["argv"] + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()
     mine = [l for l in res.stderr.decode().splitlines() if l.startswith("Recorded") or "erase a adaptor" in l]
@@ -54,11 +55,13 @@ def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, 
     assert res.stdout == open(d / meta["expected"], "rb").read()
 
 
-def test_cli_small_batches_and_counter_growth(exe, golden_workdir):
-    """Tiny batches force many launches and the counter-array regrowth path; output unchanged."""
+@pytest.mark.parametrize("extra", [["--batch-reads", "257"], ["--batch-reads", "13"], ["--batch-reads", "257", "--host-parse"]])
+def test_cli_small_batches_and_counter_growth(exe, golden_workdir, extra):
+    """Tiny blocks (82 KB / 4 KB: every other record straddles a block border of the GPU framer) force many launches and the
+    counter-array regrowth path; output unchanged.  --host-parse: the round-1 host framing path."""
     meta = load_case("rand_k21")["runs"]["pair_w104"]
     d = golden_workdir / "rand_k21"
-    res = subprocess.run([exe] + meta["argv"] + ["--batch-reads", "257", "--initial-barcodes", "3", "--stats"], cwd=d,
+    res = subprocess.run([exe] + meta["argv"] + extra + ["--initial-barcodes", "3", "--stats"], cwd=d,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()

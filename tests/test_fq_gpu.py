@@ -1,0 +1,148 @@
+"""FASTQ framing on the GPU (-m gpu): hast_fq_* (fq_kernels.hip) against a plain restatement of the reference's reader
+(processFastq, classify.cpp:257-268: four getlines per record, header must be newline-terminated, the rest may hit EOF;
+parseName :112-119), on byte streams cut into blocks at arbitrary places -- records, headers and barcodes straddle block
+borders all the time -- and the per-barcode counters after the commit against the oracle."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import hast_amd
+from hast_amd.binding import FqBlock, make_params
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_framing(data: bytes, oracle_lib):
+    """[(barcode, bases)] exactly as the reference's producer loop frames `data`"""
+    lines = data.split(b"\n")          # the last piece is what follows the last newline (unterminated or empty)
+    out, i = [], 0
+    while 4 * i < len(lines) - 1:      # a header line that reaches EOF before its newline ends the input
+        head = lines[4 * i]
+        seq = lines[4 * i + 1] if 4 * i + 1 < len(lines) else b""
+        out.append((ob.parse_name(oracle_lib, head), seq))
+        i += 1
+    return out
+
+
+def make_fastq(rng, n, k, keys, tail):
+    recs = []
+    for i in range(n):
+        L = rng.choice([k, k + 1, 60, 100, 150, 150, 150, rng.randint(k, 300)])
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if rng.random() < 0.5:
+            key = int(rng.choice(keys))
+            ks = "".join("ACTG"[(key >> (2 * (k - 1 - j))) & 3] for j in range(k))
+            p = rng.randint(0, L - k)
+            s[p:p + k] = ks
+        if rng.random() < 0.03:
+            s[rng.randrange(L)] = "N"
+        if rng.random() < 0.02:                      # a read shorter than K is only legal with an 'N' in it (kmer.h:171)
+            s = list("ACGN"[:rng.randint(1, 4)]) if k > 4 else s
+            if "N" not in s:
+                s.append("N")
+        bc = rng.choice(["0_0_0", "%d_%d_%d" % (rng.randint(1, 30), rng.randint(1, 3), rng.randint(1, 3))])
+        head = rng.choice(["@r{i}#{bc}/1", "@r{i}#{bc}/2\tx\t1", "@r{i}/x#{bc}", "@r{i}#{bc}", "@#{bc}/1/2", "@nohash{i}", "@r{i}#a#{bc}/1/"]).format(i=i, bc=bc)
+        qual = "".join(rng.choice("@+IF#/") for _ in range(len(s)))     # quality lines may start with '@' or hold '#', '/'
+        recs.append("%s\n%s\n+\n%s\n" % (head, "".join(s), qual))
+    text = "".join(recs)
+    if tail == "no_final_newline":
+        text = text[:-1]
+    elif tail == "header_only":
+        text += "@last#9_9_9/1\n"
+    elif tail == "unterminated_header":
+        text += "@dropped#8_8_8/1"
+    elif tail == "bases_no_newline":
+        text += "@last#7_7_7/1\n" + "ACGT" * 10
+    return text.encode()
+
+
+@pytest.mark.parametrize("tail", ["plain", "no_final_newline", "header_only", "unterminated_header", "bases_no_newline"])
+@pytest.mark.parametrize("chunk", [(700, 4096), (4096, 4096), (50_000, 65536)])
+def test_fq_framing_and_counts(oracle_lib, tail, chunk):
+    lo, hi = chunk
+    rng = random.Random(hash((tail, chunk)) & 0xFFFF)
+    k, n_keys = 21, 3000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    data = make_fastq(rng, 1500, k, np.concatenate(keys), tail)
+    want = reference_framing(data, oracle_lib)
+    lib = hast_amd.lib()
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        ctx.counts_resize(4096)
+        fq = C.c_void_p()
+        assert lib.hast_fq_create(ctx._h, hi, 3, C.byref(fq)) == 0, lib.hast_last_error()
+        names, got, pos, pending = {}, [], 0, 0
+        n_bases = 0
+
+        def drain():
+            nonlocal n_bases
+            b = FqBlock()
+            assert lib.hast_fq_next(fq, C.byref(b)) == 0, lib.hast_last_error()
+            assert not b.short_read
+            for i in range(b.n_records):
+                bc = bytes(b.bytes[b.bc_pos[i]:b.bc_pos[i] + b.bc_len[i]])
+                b.ids[i] = names.setdefault(bc, len(names))
+                got.append(bc)
+            n_bases += b.n_bases
+            assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
+
+        while True:
+            n = min(len(data) - pos, rng.randint(lo, hi))
+            buf = C.POINTER(C.c_uint8)()
+            assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
+            C.memmove(buf, data[pos:pos + n], n)
+            pos += n
+            last = pos >= len(data)
+            assert lib.hast_fq_submit(fq, n, 1 if last else 0) == 0, lib.hast_last_error()
+            pending += 1
+            if pending == 2 or last:                 # keep one block in flight behind the one being named
+                while pending > (0 if last else 1):
+                    drain()
+                    pending -= 1
+            if last:
+                break
+        lib.hast_fq_destroy(fq)
+        counts = ctx.counts_read(len(names))
+    assert got == [bc for bc, _ in want]
+    assert n_bases == sum(len(s) for _, s in want)
+    # counters == oracle on the framed reads
+    oc = oracle_lib.ho_new()
+    for h in (0, 1):
+        assert oracle_lib.ho_load_keys(oc, keys[h].ctypes.data, keys[h].size, h, k) == 0
+    bases = np.frombuffer(b"".join(s for _, s in want), dtype=np.uint8)
+    off = np.zeros(len(want) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for _, s in want])
+    ids = np.array([names[bc] for bc, _ in want], dtype=np.uint32)
+    e = [np.zeros(len(names), np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, ids.size, e[0].ctypes.data, e[1].ctypes.data,
+                               e[2].ctypes.data, None, 2)
+    oracle_lib.ho_free(oc)
+    for a, b in zip(counts, e):
+        assert np.array_equal(a, b)
+    assert int(e[0].sum()) + int(e[1].sum()) > 100
+
+
+def test_fq_short_read_is_reported(oracle_lib):
+    k = 21
+    lib = hast_amd.lib()
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(100)
+        ctx.table_insert_keys(0, np.array([12345], dtype=np.uint64))
+        ctx.counts_resize(16)
+        fq = C.c_void_p()
+        assert lib.hast_fq_create(ctx._h, 4096, 2, C.byref(fq)) == 0
+        data = b"@a#1_1_1/1\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n@b#1_1_1/1\nACGTACGT\n+\nIIIIIIII\n"
+        buf = C.POINTER(C.c_uint8)()
+        assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0
+        C.memmove(buf, data, len(data))
+        assert lib.hast_fq_submit(fq, len(data), 1) == 0
+        b = FqBlock()
+        assert lib.hast_fq_next(fq, C.byref(b)) == 0
+        assert b.n_records == 2 and b.short_read == 1
+        lib.hast_fq_destroy(fq)
