@@ -174,6 +174,10 @@ class BgzfReader {
             }
             if (have >= 18 && !parse_header(in_.data() + scan_, have, hdr, total)) return -2;
             if (eof_) {
+                // fewer than a header's worth of bytes after the last member: padding that does not start a gzip member is
+                // ignored, as gzread and the serial decoder do (fast_inflate.h); the beginning of a member is a truncated file
+                const unsigned char *q = in_.data() + scan_;
+                if (have < 18 && !(have >= 2 && q[0] == 0x1f && q[1] == 0x8b) && !(have == 1 && q[0] == 0x1f)) return 0;
                 err_ = "bgzf: the file ends inside a block";
                 return -1;
             }

@@ -24,7 +24,9 @@ namespace hast {
 
 class GzInflater {
   public:
-    bool open(FILE *f, size_t in_buf_bytes = 1u << 20) {
+    // continuation = true: the stream is the rest of a gzip file whose first members someone else has decoded (the
+    // hand-over from BgzfReader): bytes that do not start a member are then trailing garbage, not a plain file
+    bool open(FILE *f, size_t in_buf_bytes = 1u << 20, bool continuation = false) {
         fp_ = f;
         in_.assign(std::max<size_t>(in_buf_bytes, 64) + kBack + kPad, 0);
         in_pos_ = in_end_ = 0;
@@ -36,7 +38,7 @@ class GzInflater {
         bitbuf_ = 0;
         bitcnt_ = 0;
         err_.clear();
-        first_member_ = true;
+        first_member_ = !continuation;
         (void)crc_state();
         build_fixed();
         return f != nullptr;

@@ -298,7 +298,7 @@ class BlockSource {
                     bgzf_ = false;
                     if (fseek(fp_, (long)bgzf_reader_.resume_offset(), SEEK_SET) != 0) trouble = "gz: cannot seek";
                     else {
-                        inflater_.open(fp_, 4u << 20);
+                        inflater_.open(fp_, 4u << 20, true);
                         continue;
                     }
                 }

@@ -60,7 +60,7 @@ int main(int argc, char **argv) {
             if (n == 0) return 0;
             fseek(f, (long)b.resume_offset(), SEEK_SET);            // -2: an ordinary member follows
         }
-        z.open(f, inbuf);
+        z.open(f, inbuf, bgzf);                                     // after a hand-over the stream is a continuation, as in BlockSource
         while ((n = z.read(buf.data(), piece)) > 0) {
             if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
             total += (size_t)n;

@@ -79,12 +79,13 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk):
         assert lib.hast_fq_create(ctx._h, hi, 3, C.byref(fq)) == 0, lib.hast_last_error()
         names, got, pos, pending = {}, [], 0, 0
         n_bases = 0
+        short = []
 
         def drain():
             nonlocal n_bases
             b = FqBlock()
             assert lib.hast_fq_next(fq, C.byref(b)) == 0, lib.hast_last_error()
-            assert not b.short_read
+            short.append(b.short_read)
             for i in range(b.n_records):
                 bc = bytes(b.bytes[b.bc_pos[i]:b.bc_pos[i] + b.bc_len[i]])
                 b.ids[i] = names.setdefault(bc, len(names))
@@ -111,6 +112,12 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk):
         counts = ctx.counts_read(len(names))
     assert got == [bc for bc, _ in want]
     assert n_bases == sum(len(s) for _, s in want)
+    if tail == "header_only":
+        # a last record with a terminated header and nothing after it is a record with an EMPTY read: the reference frames
+        # it and then aborts on it (kmer.h:171); here the block that holds it reports a short read and is not classified
+        assert short[-1] == 1 and not any(short[:-1])
+        return
+    assert not any(short)
     # counters == oracle on the framed reads
     oc = oracle_lib.ho_new()
     for h in (0, 1):

@@ -162,6 +162,17 @@ def test_blocked_gzip_is_inflated_in_parallel_and_checked(driver, tmp_path):
     r = subprocess.run([driver, "-b", "-p", "300000", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and r.stdout == data, r.stderr[-300:]
     whole = bgzf(data)
+    # padding after the last member: ignored whatever its length, as gzread and the serial decoder do (a few bytes used to be
+    # "the file ends inside a block" while 18 or more were ignored)
+    for pad in (b"\0", b"\0" * 5, b"\n" * 17, b"\0" * 18, b"junk" * 20):
+        p.write_bytes(whole + pad)
+        assert subprocess.run([driver, "-z", str(p)], stdout=subprocess.PIPE).stdout == data          # zlib: ignored
+        r = subprocess.run([driver, "-b", "-p", "300000", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == data, (pad, r.stderr[-300:])
+    # ... but the beginning of another member is a truncated file
+    p.write_bytes(whole + whole[:9])
+    r = subprocess.run([driver, "-b", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 3
     for damage in ("flip", "cut", "cut_in_header"):
         b = bytearray(whole)
         if damage == "flip":
