@@ -76,8 +76,7 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
     f->device = hast_ctx_device(ctx);
     f->k = hast_ctx_k(ctx);
     f->block = (block_bytes + 4095) & ~(size_t)4095;
-    f->pad = std::min<size_t>(std::max<size_t>(f->block / 8, 64 << 10), 4u << 20);     // room for the largest record that straddles two blocks
-    f->pad = (f->pad + 4095) & ~(size_t)4095;
+    f->pad = 4u << 20;                                     // room for the unfinished record(s) carried from block to block: a record may be 4 MB
     const size_t buf = f->pad + f->block + 4096;
     f->max_rec = (f->pad + f->block) / 4 + 2;                                           // a record holds at least four newlines
     f->slots.resize((size_t)n_buffers);
