@@ -127,11 +127,15 @@ void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, size_t n_known, si
             acc.c1.resize(acc.device_cap);
             acc.neg.resize(acc.device_cap);
         }
+        bool past_int = false;
         for (size_t i = 0; i < acc.device_cap; i++) {
+            past_int = past_int || a[i] > 0x7FFFFFFFu || b[i] > 0x7FFFFFFFu;
             acc.c0[i] += a[i];
             acc.c1[i] += b[i];
             acc.neg[i] += c[i];
         }
+        if (past_int)        // the reference's `int` counters (classify.cpp:51) overflow here: its output is undefined from this point on
+            fprintf(stderr, " WARN : a barcode has more than INT_MAX hits; the reference's counters overflow on this input\n");
     }
     (void)n_known;
     for (hast_ctx *c : ctxs) CK(hast_counts_resize(c, new_cap), "allocating counters");
@@ -507,6 +511,7 @@ int main(int argc, char **argv) {
             std::unique_ptr<Feed> f(new Feed());
             f->name = r;
             if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
+            f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
             CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, &f->fq), "creating the FASTQ stream");
             next_file++;
             Feed *fp = f.get();
@@ -540,10 +545,14 @@ int main(int argc, char **argv) {
         const size_t max_active = std::max<size_t>(4, 2 * ctxs.size());
         while (next_file < read.size() && active.size() < max_active) open_next();
         uint64_t seen_gen = 0;
+        double t_gpu_wait = 0, t_names = 0, t_commit = 0, t_idle = 0;
         // names the barcodes of the oldest submitted block of a feed and commits it
         auto open_block = [&](Feed &f) {
             hast_fq_block b;
+            const double t0 = now_s();
             CK(hast_fq_next(f.fq, &b), "framing a block");
+            const double t1 = now_s();
+            t_gpu_wait += t1 - t0;
             if (b.short_read) {
                 fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, f.name.c_str());
                 exit(3);                                                                   // reference: assert abort (kmer.h:171)
@@ -554,8 +563,11 @@ int main(int argc, char **argv) {
                 for (size_t i = lo; i < hi_; i++)
                     b.ids[i] = dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]);
             });
+            const double t2 = now_s();
+            t_names += t2 - t1;
             if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
             CK(hast_fq_commit(f.fq), "classifying a block");
+            t_commit += now_s() - t2;
             f.opened++;
             f.held--;
             total_reads += n;
@@ -623,11 +635,16 @@ int main(int argc, char **argv) {
                         break;
                     }
             if (!progress) {                                       // everything waits for a reader thread
+                const double t0 = now_s();
                 std::unique_lock<std::mutex> g(wake_mu);
                 wake_cv.wait_for(g, std::chrono::milliseconds(2), [&] { return wake_gen != seen_gen; });
                 seen_gen = wake_gen;
+                t_idle += now_s() - t0;
             }
         }
+        if (stats)
+            fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f\n",
+                    t_idle, t_gpu_wait, t_names, t_commit);
     }
     flush_counts(ctxs, acc, dict.size(), 1);
     const double t_classified = now_s();

@@ -15,7 +15,9 @@
  *   - the caller owns host buffers; pointers named d_* are DEVICE pointers (from hast_dev_alloc
  *     or from any other allocator on the same device, e.g. a torch tensor's data_ptr()).
  *   - one context per device; calls on one context are serialised by the caller.
- *   - hast_stream is a hipStream_t passed as void* (NULL = the context's own stream).
+ *   - hast_stream is a hipStream_t passed as void* (NULL = the context's own stream).  A context has ONE set of launch
+ *     scratch (tile queue, segment table, vote scratch): at most one classification of a context may be in flight, i.e. all
+ *     classify calls of a context must go to the same stream (any stream, but one).
  *   - there is NO CPU fallback: with no usable GPU hast_ctx_create fails with HAST_ERR_NO_DEVICE.
  */
 #ifndef HAST_H
@@ -132,7 +134,10 @@ hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, int
 /* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
  * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:
  *   c0/c1 = sum of per-read votes for key 0/1 (classify.cpp:203-206), neg = key -1 (:191,:207-208).
- * A barcode was "seen" (gets an output row, classify.cpp:94) iff c0|c1|neg != 0. */
+ * A barcode was "seen" (gets an output row, classify.cpp:94) iff c0|c1|neg != 0.
+ * A read's two votes are added with one 64-bit atomic, so a c0 that passes 2^32 between two read-backs would carry into c1.
+ * The reference counts in `int` (classify.cpp:51): parity is undefined past INT_MAX there; the classify program warns when a
+ * counter it reads back is above INT_MAX. */
 hast_status hast_counts_resize(hast_ctx *, size_t n_barcodes);                 /* library-owned, zeroed */
 hast_status hast_counts_bind(hast_ctx *, uint32_t *d_counts, size_t n_barcodes); /* caller-owned buffer */
 hast_status hast_counts_zero(hast_ctx *, hast_stream);
@@ -153,7 +158,10 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
  *   read_len       fixed read length (d_offsets==NULL) or an upper bound on every read's length
  *   d_barcode_ids  per-read dense barcode id (< n_barcodes), or NULL => counters untouched
  *   d_votes        optional [n_reads][2] per-read (vote0, vote1) output (per-read mode), 8-byte aligned, or NULL
- *   bases_bytes    total bytes readable at d_bases (reads never look past it)
+ *   bases_bytes    total bytes readable at d_bases.  The kernel loads whole aligned dwords: up to 3 bytes in front of
+ *                  d_bases (when it is not 4-byte aligned) and up to 3 bytes behind d_bases + bases_bytes are loaded and
+ *                  ignored; they must be mapped device memory, which holds for any pointer into an allocation made by
+ *                  hipMalloc or a sub-allocator with >= 4-byte granules (torch's: 512 B).
  * A read shorter than K has no windows (the reference aborts, kmer.h:171): it votes 0/0.
  * Reads of any length: with d_offsets and read_len > 4096 the reads are cut into segments on the device
  * (same result; the call then waits for one small device->host counter before the main launch).
