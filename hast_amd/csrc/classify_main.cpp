@@ -498,13 +498,14 @@ int main(int argc, char **argv) {
             size_t held = 0;                                       // acquired and not yet committed
             size_t submitted = 0, opened = 0;
         };
-        const int n_buf = 3;
+        const int n_buf = 5;                                       // blocks a file may have between the reader and the commit
+        double t_create = 0;
         std::mutex wake_mu;
         std::condition_variable wake_cv;
         uint64_t wake_gen = 0;
         std::vector<std::unique_ptr<Feed>> active;
         size_t next_file = 0;
-        const size_t cap = std::max<size_t>(4096, std::min<size_t>(block_bytes, 64u << 20));
+        const size_t cap = std::max<size_t>(4096, std::min<size_t>(block_bytes, 32u << 20));
         auto open_next = [&]() {
             const std::string &r = read[next_file];
             fprintf(stderr, "__process read: %s\n", r.c_str());
@@ -512,7 +513,9 @@ int main(int argc, char **argv) {
             f->name = r;
             if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
             f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
+            const double tc0 = now_s();
             CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, &f->fq), "creating the FASTQ stream");
+            t_create += now_s() - tc0;
             next_file++;
             Feed *fp = f.get();
             f->th = std::thread([fp, cap, &wake_mu, &wake_cv, &wake_gen] {
@@ -643,8 +646,8 @@ int main(int argc, char **argv) {
             }
         }
         if (stats)
-            fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f\n",
-                    t_idle, t_gpu_wait, t_names, t_commit);
+            fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f\n",
+                    t_idle, t_gpu_wait, t_names, t_commit, t_create);
     }
     flush_counts(ctxs, acc, dict.size(), 1);
     const double t_classified = now_s();

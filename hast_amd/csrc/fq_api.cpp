@@ -179,11 +179,12 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     if (n) {
         FQ_TRY(hipMemcpyAsync(s.h_bc, s.d_bcpos, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipMemcpyAsync(s.h_bc + s.h_cap, s.d_bclen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
-        // the reads are classified where they lie in the raw block while the host names the barcodes
+        FQ_TRY(hipEventRecord(s.parsed, hs));
+        // the reads are classified where they lie in the raw block WHILE the host names the barcodes: enqueue first, then wait
+        // for the two small copies only (the event sits in front of the kernels)
         if (!(st.flags & 1))
             if (hast_status c = classify_framed(f->ctx, s.d_buf, f->pad + s.n_bytes, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
-        FQ_TRY(hipEventRecord(s.parsed, hs));
-        FQ_TRY(hipEventSynchronize(s.parsed));                 // (waits for the two small copies; the kernels were enqueued before the record)
+        FQ_TRY(hipEventSynchronize(s.parsed));
     }
     // host view of the bytes the barcode extents point into: this block's bytes, preceded by the previous block's tail
     if (st.tail_in != f->carry.size()) return set_error(HAST_ERR_INVALID, "tail bookkeeping out of step (%llu vs %zu)", (unsigned long long)st.tail_in, f->carry.size());

@@ -15,9 +15,9 @@ run fq_t64 hast_amd/classify $ARGS -t 64 --stats
 run fq_t8 hast_amd/classify $ARGS -t 8 --stats
 run host_t32 hast_amd/classify $ARGS -t 32 --stats --host-parse
 done
-run fq_mb16 hast_amd/classify $ARGS -t 32 --stats --block-mb 16
+run fq_mb8 hast_amd/classify $ARGS -t 32 --stats --block-mb 8
 run fq_mb32 hast_amd/classify $ARGS -t 32 --stats --block-mb 32
-run fq_mb128 hast_amd/classify $ARGS -t 32 --stats --block-mb 128
+run fq_mb16 hast_amd/classify $ARGS -t 32 --stats --block-mb 16
 
 (gzip -1 -k $D/r1.fq & gzip -1 -k $D/r2.fq & wait)
 GZARGS="--hap0 $D/hap0.mer --hap1 $D/hap1.mer --read $D/r1.fq.gz --read $D/r2.fq.gz --weight0 1.04"
