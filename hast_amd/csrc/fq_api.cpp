@@ -46,6 +46,9 @@ struct hast_fq {
     std::vector<Slot> slots;
     size_t n_acquired = 0, n_submitted = 0, n_opened = 0;      // blocks handed out / submitted / returned by hast_fq_next
     int prev_submitted = -1;                                   // slot of the previous block of this file (device-side tail)
+    // raw bytes + framing run on a stream of their own, so that the copies of the blocks submitted ahead do not queue up in
+    // front of the (short) per-block work hast_fq_next / hast_fq_commit put on the context's stream
+    hipStream_t copy_stream = nullptr;
     std::vector<uint8_t> carry;                                // host copy of the previous block's tail (barcodes may lie in it)
 };
 
@@ -81,6 +84,10 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
     f->max_rec = (f->pad + f->block) / 4 + 2;                                           // a record holds at least four newlines
     f->slots.resize((size_t)n_buffers);
     hast_status st = HAST_OK;
+    if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete f;
+        return set_error(HAST_ERR_HIP, "hipStreamCreate failed");
+    }
     auto ck = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && st == HAST_OK) st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     };
@@ -110,6 +117,10 @@ void hast_fq_destroy(hast_fq *f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipStreamSynchronize(ctx_stream_of(f->ctx));
+    if (f->copy_stream) {
+        (void)hipStreamSynchronize(f->copy_stream);
+        (void)hipStreamDestroy(f->copy_stream);
+    }
     for (Slot &s : f->slots) free_slot(s);
     delete f;
 }
@@ -138,7 +149,7 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     const int si = (int)(f->n_submitted % f->slots.size());
     Slot &s = f->slots[(size_t)si];
     FQ_TRY(hipSetDevice(f->device));
-    hipStream_t hs = ctx_stream_of(f->ctx);
+    hipStream_t hs = f->copy_stream;
     s.n_bytes = n_bytes;
     s.last = last;
     if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, hs));

@@ -116,13 +116,14 @@ class BarcodeDict {
         return h ^ (h >> 32);
     }
     // thread-safe; `cache` is a per-thread front cache (hot barcodes such as 0_0_0 never touch a lock)
+    static constexpr size_t kCacheSlots = 1u << 15;         // 768 KB per thread: most of a core's L2, holds the barcodes in flight
     struct Cache {
         struct E { uint64_t h = 0; const char *p = nullptr; uint32_t len = 0, id = 0; };
-        std::vector<E> e = std::vector<E>(4096);
+        std::vector<E> e = std::vector<E>(kCacheSlots);
     };
     uint32_t get(std::string_view bc, Cache &cache) {
         const uint64_t h = hash(bc);
-        Cache::E &ce = cache.e[h & 4095];
+        Cache::E &ce = cache.e[h & (kCacheSlots - 1)];
         if (ce.p && ce.h == h && ce.len == bc.size() && memcmp(ce.p, bc.data(), bc.size()) == 0) return ce.id;
         Shard &s = shards_[(h >> 40) & (kShards - 1)];
         std::lock_guard<std::mutex> g(s.mu);
