@@ -529,7 +529,9 @@ int main(int argc, char **argv) {
                         fp->empty.pop_front();
                     }
                     Feed::Filled fl{0, false, std::string()};
+                    const double tr0 = now_s();
                     fl.n = fp->src.read_into(reinterpret_cast<char *>(buf), cap, fl.err);
+                    if (getenv("HAST_TRACE_BLOCKS")) fprintf(stderr, "trace %s fill %.3f ms at %.4f\n", fp->name.c_str() + (fp->name.size() > 5 ? fp->name.size() - 5 : 0), (now_s() - tr0) * 1e3, now_s());
                     fl.last = fl.n < cap || !fl.err.empty();
                     {
                         std::lock_guard<std::mutex> g(fp->mu);
@@ -571,6 +573,7 @@ int main(int argc, char **argv) {
             if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
             CK(hast_fq_commit(f.fq), "classifying a block");
             t_commit += now_s() - t2;
+            if (getenv("HAST_TRACE_BLOCKS")) fprintf(stderr, "trace %s open wait %.3f name %.3f commit %.3f ms at %.4f (sub %zu open %zu)\n", f.name.c_str() + (f.name.size() > 5 ? f.name.size() - 5 : 0), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3, now_s(), f.submitted, f.opened);
             f.opened++;
             f.held--;
             total_reads += n;
@@ -601,6 +604,7 @@ int main(int argc, char **argv) {
                     }
                     if (!fl.err.empty()) die(2, (f.name + ": " + fl.err).c_str());
                     CK(hast_fq_submit(f.fq, fl.n, fl.last ? 1 : 0), "framing a block");
+                    if (getenv("HAST_TRACE_BLOCKS")) fprintf(stderr, "trace %s submit at %.4f\n", f.name.c_str() + (f.name.size() > 5 ? f.name.size() - 5 : 0), now_s());
                     f.submitted++;
                     if (fl.last) f.eof_acquired = true;
                     progress = true;
