@@ -33,7 +33,7 @@ struct Slot {
     size_t h_cap = 0;                                  // records the pinned arrays hold
     size_t n_bytes = 0;
     int last = 0;
-    hipEvent_t parsed = nullptr, done = nullptr;
+    hipEvent_t copied = nullptr, parsed = nullptr, done = nullptr;
     enum { FREE, ACQUIRED, SUBMITTED, OPEN } state = FREE;
     bool done_pending = false;
 };
@@ -48,7 +48,7 @@ struct hast_fq {
     int prev_submitted = -1;                                   // slot of the previous block of this file (device-side tail)
     // raw bytes + framing run on a stream of their own, so that the copies of the blocks submitted ahead do not queue up in
     // front of the (short) per-block work hast_fq_next / hast_fq_commit put on the context's stream
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, parse_stream = nullptr;     // H2D of block k+1 runs while block k is framed
     std::vector<uint8_t> carry;                                // host copy of the previous block's tail (barcodes may lie in it)
 };
 
@@ -60,6 +60,7 @@ static void free_slot(Slot &s) {
     for (void *p : {(void *)s.d_buf, (void *)s.d_st, (void *)s.d_tile, (void *)s.d_nl, (void *)s.d_off, (void *)s.d_len, (void *)s.d_bcpos,
                     (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes})
         if (p) (void)hipFree(p);
+    if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.parsed) (void)hipEventDestroy(s.parsed);
     if (s.done) (void)hipEventDestroy(s.done);
     s = Slot();
@@ -84,7 +85,9 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
     f->max_rec = (f->pad + f->block) / 4 + 2;                                           // a record holds at least four newlines
     f->slots.resize((size_t)n_buffers);
     hast_status st = HAST_OK;
-    if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&f->parse_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
         delete f;
         return set_error(HAST_ERR_HIP, "hipStreamCreate failed");
     }
@@ -101,6 +104,7 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
         ck(hipMalloc((void **)&s.d_off, f->max_rec * sizeof(uint64_t)), "record offsets");
         for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) ck(hipMalloc((void **)p, f->max_rec * sizeof(uint32_t)), "record arrays");
         ck(hipMalloc((void **)&s.d_votes, f->max_rec * 2 * sizeof(uint32_t)), "votes");
+        ck(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event");
         if (st != HAST_OK) break;
@@ -117,10 +121,11 @@ void hast_fq_destroy(hast_fq *f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
     (void)hipStreamSynchronize(ctx_stream_of(f->ctx));
-    if (f->copy_stream) {
-        (void)hipStreamSynchronize(f->copy_stream);
-        (void)hipStreamDestroy(f->copy_stream);
-    }
+    for (hipStream_t st : {f->copy_stream, f->parse_stream})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
     for (Slot &s : f->slots) free_slot(s);
     delete f;
 }
@@ -149,10 +154,12 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     const int si = (int)(f->n_submitted % f->slots.size());
     Slot &s = f->slots[(size_t)si];
     FQ_TRY(hipSetDevice(f->device));
-    hipStream_t hs = f->copy_stream;
+    hipStream_t hs = f->parse_stream;
     s.n_bytes = n_bytes;
     s.last = last;
-    if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, hs));
+    if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, f->copy_stream));
+    FQ_TRY(hipEventRecord(s.copied, f->copy_stream));
+    FQ_TRY(hipStreamWaitEvent(hs, s.copied, 0));
     const Slot *prev = f->prev_submitted >= 0 ? &f->slots[(size_t)f->prev_submitted] : nullptr;
     FQ_TRY(launch_fq_block(s.d_buf, s.d_st, prev ? prev->d_buf : nullptr, prev ? prev->d_st : nullptr, f->pad, n_bytes, s.d_tile, s.d_nl, s.d_off,
                            s.d_len, s.d_bcpos, s.d_bclen, (uint32_t)f->k, last, (uint32_t)f->max_rec, hs));

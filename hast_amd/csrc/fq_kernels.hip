@@ -111,13 +111,12 @@ __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState 
     // the EOF record without all four newlines: it counts iff its header line is terminated (even with an empty bases line)
     const bool partial = last && n_nl - 4 * n_rec >= 1;
     const uint32_t total = n_rec + (partial ? 1 : 0);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->n_rec = total;
         const uint64_t consumed = last ? hi : (n_rec ? (uint64_t)nl[4 * n_rec - 1] + 1 : lo);
         st->tail_lo = consumed;                               // bytes [consumed, hi) belong to the next block's first record
     }
-    if (i >= total) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const uint64_t h0 = i ? (uint64_t)nl[4 * i - 1] + 1 : lo;
     const uint64_t h1 = nl[4 * i];                            // end of the header line (exists for every counted record)
     const uint64_t s1 = (4 * i + 1 < n_nl) ? nl[4 * i + 1] : hi;   // end of the bases line, or EOF
@@ -141,6 +140,7 @@ __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState 
         bool has_n = false;
         for (uint64_t p = h1 + 1; p < s1 && !has_n; ++p) has_n = buf[p] == 'N';
         if (!has_n) atomicOr(&st->flags, 1u);
+    }
     }
 }
 
@@ -173,7 +173,8 @@ hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_
     hipLaunchKernelGGL(k_fq_count, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt);
     hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
     hipLaunchKernelGGL(k_fq_index, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt, d_nl);
-    hipLaunchKernelGGL(k_fq_records, dim3((max_records + 255) / 256), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, k, last);
+    (void)max_records;                                        // (capacity of the record arrays; the kernel walks what it finds)
+    hipLaunchKernelGGL(k_fq_records, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, k, last);
     return hipGetLastError();
 }
 
