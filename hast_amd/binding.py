@@ -82,6 +82,7 @@ ABI_SYMBOLS = {
     "hast_fq_block_bytes": (C.c_size_t, [vp]),
     "hast_fq_acquire": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8))]),
     "hast_fq_submit": (C.c_int, [vp, C.c_size_t, C.c_int]),
+    "hast_fq_poll": (C.c_int, [vp]),
     "hast_fq_next": (C.c_int, [vp, C.POINTER(FqBlock)]),
     "hast_fq_commit": (C.c_int, [vp]),
     "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

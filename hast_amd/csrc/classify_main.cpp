@@ -498,7 +498,7 @@ int main(int argc, char **argv) {
             size_t held = 0;                                       // acquired and not yet committed
             size_t submitted = 0, opened = 0;
         };
-        const int n_buf = 5;                                       // blocks a file may have between the reader and the commit
+        const int n_buf = 6;                                       // blocks a file may have between the reader and the commit
         double t_create = 0;
         std::mutex wake_mu;
         std::condition_variable wake_cv;
@@ -610,10 +610,11 @@ int main(int argc, char **argv) {
                     progress = true;
                 }
             }
-            // 3. blocks whose successor is already on its way to the GPU (or the file's last ones): name barcodes, commit
+            // 3. a block whose record table has arrived: name its barcodes, commit.  One block per round, so that what the
+            //    readers have filled meanwhile is submitted between two blocks (the GPU must never run out of queued copies)
             for (size_t fi = 0; fi < active.size();) {
                 Feed &f = *active[fi];
-                while (f.opened < f.submitted && (f.submitted - f.opened >= 2 || f.eof_acquired)) {
+                if (f.opened < f.submitted && hast_fq_poll(f.fq)) {
                     open_block(f);
                     progress = true;
                 }
@@ -634,17 +635,10 @@ int main(int argc, char **argv) {
                 }
                 ++fi;
             }
-            if (!progress)                                         // slow readers (one gz stream): do not sit on a finished block
-                for (auto &fp : active)
-                    if (fp->opened < fp->submitted) {
-                        open_block(*fp);
-                        progress = true;
-                        break;
-                    }
             if (!progress) {                                       // everything waits for a reader thread
                 const double t0 = now_s();
                 std::unique_lock<std::mutex> g(wake_mu);
-                wake_cv.wait_for(g, std::chrono::milliseconds(2), [&] { return wake_gen != seen_gen; });
+                wake_cv.wait_for(g, std::chrono::microseconds(100), [&] { return wake_gen != seen_gen; });   // (a GPU event may be what we wait for)
                 seen_gen = wake_gen;
                 t_idle += now_s() - t0;
             }

@@ -171,6 +171,14 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     return HAST_OK;
 }
 
+int hast_fq_poll(hast_fq *f) {
+    if (!f || f->n_opened >= f->n_submitted) return 0;
+    Slot &s = f->slots[f->n_opened % f->slots.size()];
+    if (s.state != Slot::SUBMITTED) return 0;
+    (void)hipSetDevice(f->device);
+    return hipEventQuery(s.parsed) == hipSuccess ? 1 : 0;
+}
+
 hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     if (!f || !out) return set_error(HAST_ERR_INVALID, "null argument");
     memset(out, 0, sizeof(*out));

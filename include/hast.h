@@ -210,7 +210,7 @@ hast_status hast_batch_submit(hast_ctx *, size_t n_reads, uint32_t max_read_len)
  *     hast_fq_acquire   pinned host memory for the next block_bytes of the file (waits until that buffer is free again)
  *     hast_fq_submit    n_bytes are in it; last != 0: the file ends here (the EOF rules of classify.cpp:257-268 apply:
  *                       a final record counts when its header line is terminated).  Enqueues the copy and the framing.
- *     hast_fq_next      oldest submitted block: waits for its record table, starts the classification of its reads, and
+ *     hast_fq_next      oldest submitted block: waits for its record table (hast_fq_poll tells whether it is there), starts the classification of its reads, and
  *                       gives the barcode text extents of its records: record i's barcode = bytes[bc_pos[i] .. +bc_len[i])
  *     (caller)          ids[i] = dense id of that barcode (one dictionary per job, shared by all GPUs; < n_barcodes of
  *                       the context's counters)
@@ -235,6 +235,7 @@ void        hast_fq_destroy(hast_fq *);
 size_t      hast_fq_block_bytes(const hast_fq *);
 hast_status hast_fq_acquire(hast_fq *, uint8_t **host_buf);
 hast_status hast_fq_submit(hast_fq *, size_t n_bytes, int last);
+int         hast_fq_poll(hast_fq *);      /* 1: hast_fq_next would not have to wait for the framing of the oldest submitted block */
 hast_status hast_fq_next(hast_fq *, hast_fq_block *out);
 hast_status hast_fq_commit(hast_fq *);
 
