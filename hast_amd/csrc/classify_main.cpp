@@ -216,9 +216,40 @@ int main(int argc, char **argv) {
     logtime();
     const double t_start = now_s();
 
+    // --batch-reads N (tests / small inputs): shrink the blocks so that a batch holds about N records
+    size_t block_bytes = block_mb << 20;
+    if (batch_reads) block_bytes = std::max<size_t>(4096, std::min(block_bytes, batch_reads * 320));
+    const bool block_given = block_mb != 256 || batch_reads;
+    // GPU framing: bytes per block of a file, blocks a file may have between its reader and the commit
+    const size_t fq_cap = std::max<size_t>(4096, block_given ? std::min<size_t>(block_bytes, 256u << 20) : (16u << 20));
+    const int fq_bufs = 6;
+
     // ---- load_kmers (classify.cpp:30-46): both files to memory, table built on the GPU --------
     size_t K = 0;
     hast_ctx *ctx = nullptr;
+    std::vector<hast_ctx *> ctxs;
+    // The FASTQ streams of the first files (pinned staging + device buffers: ~0.1 s of page pinning) are set up by a thread
+    // of their own while this one reads the k-mer files and builds the table.
+    std::vector<hast_fq *> pre_fq;
+    std::thread pre_thread;
+    std::string pre_error;
+    auto contexts_ready = [&]() {
+        ctxs.push_back(ctx);
+        for (size_t i = 1; i < devices.size(); i++) {
+            hast_ctx *c2 = nullptr;
+            if (hast_ctx_create(devices[i], (int)K, &c2) != HAST_OK) die(4, "cannot create GPU context");
+            ctxs.push_back(c2);
+        }
+        if (host_parse) return;
+        pre_fq.assign(std::min<size_t>(read.size(), std::max<size_t>(4, 2 * ctxs.size())), nullptr);
+        pre_thread = std::thread([&] {
+            for (size_t i = 0; i < pre_fq.size(); i++)
+                if (hast_fq_create(ctxs[i % ctxs.size()], fq_cap, fq_bufs, &pre_fq[i]) != HAST_OK) {
+                    pre_error = hast_last_error();
+                    return;
+                }
+        });
+    };
     double t_loaded = 0;
     if (!load_table.empty()) {
         // binary key-set cache written by --save-table (both sets, after the adaptor scrub of that run)
@@ -226,6 +257,7 @@ int main(int argc, char **argv) {
         if (hast_table_file_info(load_table.c_str(), &kk, nullptr) != HAST_OK) die(2, "cannot use --load-table file");
         K = (size_t)kk;
         if (hast_ctx_create(device, kk, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+        contexts_ready();
         fprintf(stderr, "__load kmer table %s__\n", load_table.c_str());
         CK(hast_table_load(ctx, load_table.c_str(), 0.0), "loading the k-mer table");
         t_loaded = now_s();
@@ -240,6 +272,7 @@ int main(int argc, char **argv) {
         return 3;
     }
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+    contexts_ready();
     CK(hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.0), "allocating the k-mer table");
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "__load hap%d kmers__\n", h);
@@ -288,14 +321,15 @@ int main(int argc, char **argv) {
     CK(hast_table_sizes(ctx, &n_set[0], &n_set[1]), "counting set sizes");
     if (!save_table.empty()) CK(hast_table_save(ctx, save_table.c_str()), "writing --save-table file");
     // the other GPUs get a copy of the finished table (after the adaptor scrub), peer to peer
-    std::vector<hast_ctx *> ctxs{ctx};
-    for (size_t i = 1; i < devices.size(); i++) {
-        hast_ctx *c2 = nullptr;
-        if (hast_ctx_create(devices[i], (int)K, &c2) != HAST_OK) die(4, "cannot create GPU context");
-        CK(hast_table_clone(c2, ctx), "copying the k-mer table to another GPU");
-        ctxs.push_back(c2);
-    }
+    for (size_t i = 1; i < ctxs.size(); i++) CK(hast_table_clone(ctxs[i], ctx), "copying the k-mer table to another GPU");
     size_t next_ctx = 0;
+    if (pre_thread.joinable()) {
+        pre_thread.join();
+        if (!pre_error.empty()) {
+            fprintf(stderr, "classify: ERROR: creating the FASTQ stream (%s)\n", pre_error.c_str());
+            return 4;
+        }
+    }
     logtime();
 
     // ---- processFastq (classify.cpp:238-278) for each --read, in order ------------------------
@@ -307,9 +341,6 @@ int main(int argc, char **argv) {
     Counts acc;
     flush_counts(ctxs, acc, 0, initial_barcodes);
     const int T = pool.size();
-    // --batch-reads N (tests / small inputs): shrink the blocks so that a batch holds about N records
-    size_t block_bytes = block_mb << 20;
-    if (batch_reads) block_bytes = std::max<size_t>(4096, std::min(block_bytes, batch_reads * 320));
     uint64_t total_reads = 0, total_bases = 0;
     std::vector<std::vector<uint32_t>> nl(T);          // per-worker newline positions of the current block
     std::vector<uint32_t> allnl;
@@ -498,14 +529,14 @@ int main(int argc, char **argv) {
             size_t held = 0;                                       // acquired and not yet committed
             size_t submitted = 0, opened = 0;
         };
-        const int n_buf = 6;                                       // blocks a file may have between the reader and the commit
+        const int n_buf = fq_bufs;
         double t_create = 0;
         std::mutex wake_mu;
         std::condition_variable wake_cv;
         uint64_t wake_gen = 0;
         std::vector<std::unique_ptr<Feed>> active;
         size_t next_file = 0;
-        const size_t cap = std::max<size_t>(4096, std::min<size_t>(block_bytes, 32u << 20));
+        const size_t cap = fq_cap;
         auto open_next = [&]() {
             const std::string &r = read[next_file];
             fprintf(stderr, "__process read: %s\n", r.c_str());
@@ -514,7 +545,8 @@ int main(int argc, char **argv) {
             if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
             f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
             const double tc0 = now_s();
-            CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, &f->fq), "creating the FASTQ stream");
+            if (next_file < pre_fq.size() && pre_fq[next_file]) f->fq = pre_fq[next_file];     // set up while the table was built
+            else CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, &f->fq), "creating the FASTQ stream");
             t_create += now_s() - tc0;
             next_file++;
             Feed *fp = f.get();

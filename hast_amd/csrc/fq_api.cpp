@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -29,8 +30,9 @@ struct Slot {
     uint32_t *d_tile = nullptr, *d_nl = nullptr;
     uint64_t *d_off = nullptr;
     uint32_t *d_len = nullptr, *d_bcpos = nullptr, *d_bclen = nullptr, *d_ids = nullptr, *d_votes = nullptr;
-    uint32_t *h_bc = nullptr, *h_ids = nullptr;        // pinned, grown on demand: h_bc = [pos | len]
-    size_t h_cap = 0;                                  // records the pinned arrays hold
+    uint32_t *h_bc = nullptr, *h_ids = nullptr;        // pinned: h_bc = [pos x h_cap | len x h_cap], written by the records kernel itself
+    size_t h_cap = 0;                                  // records the pinned arrays hold (a block with more: grown, copied)
+    size_t k_cap = 0;                                  // ... the capacity the kernel of the submitted block was given
     size_t n_bytes = 0;
     int last = 0;
     hipEvent_t copied = nullptr, parsed = nullptr, done = nullptr;
@@ -80,7 +82,7 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
     f->device = hast_ctx_device(ctx);
     f->k = hast_ctx_k(ctx);
     f->block = (block_bytes + 4095) & ~(size_t)4095;
-    f->pad = 4u << 20;                                     // room for the unfinished record(s) carried from block to block: a record may be 4 MB
+    f->pad = 1u << 20;                                     // room for the unfinished record(s) carried from block to block: a record may be 1 MB
     const size_t buf = f->pad + f->block + 4096;
     f->max_rec = (f->pad + f->block) / 4 + 2;                                           // a record holds at least four newlines
     f->slots.resize((size_t)n_buffers);
@@ -104,6 +106,10 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
         ck(hipMalloc((void **)&s.d_off, f->max_rec * sizeof(uint64_t)), "record offsets");
         for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) ck(hipMalloc((void **)p, f->max_rec * sizeof(uint32_t)), "record arrays");
         ck(hipMalloc((void **)&s.d_votes, f->max_rec * 2 * sizeof(uint32_t)), "votes");
+        s.h_cap = f->block / 96 + 4096;                    // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
+        if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) s.h_cap = (size_t)std::max(1L, atol(e));       // (tests: force the copy path)
+        ck(hipHostMalloc((void **)&s.h_bc, 2 * s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned barcode extents");
+        ck(hipHostMalloc((void **)&s.h_ids, s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned ids");
         ck(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event");
@@ -162,7 +168,8 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     FQ_TRY(hipStreamWaitEvent(hs, s.copied, 0));
     const Slot *prev = f->prev_submitted >= 0 ? &f->slots[(size_t)f->prev_submitted] : nullptr;
     FQ_TRY(launch_fq_block(s.d_buf, s.d_st, prev ? prev->d_buf : nullptr, prev ? prev->d_st : nullptr, f->pad, n_bytes, s.d_tile, s.d_nl, s.d_off,
-                           s.d_len, s.d_bcpos, s.d_bclen, (uint32_t)f->k, last, (uint32_t)f->max_rec, hs));
+                           s.d_len, s.d_bcpos, s.d_bclen, s.h_bc, (uint32_t)s.h_cap, (uint32_t)f->k, last, hs));
+    s.k_cap = s.h_cap;
     FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, hs));
     FQ_TRY(hipEventRecord(s.parsed, hs));
     s.state = Slot::SUBMITTED;
@@ -192,26 +199,24 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     if (st.flags & 2) return set_error(HAST_ERR_FORMAT, "a FASTQ record is larger than %zu bytes", f->pad);
     if (st.n_rec > f->max_rec) return set_error(HAST_ERR_INVALID, "record table overflow");
     const size_t n = st.n_rec;
-    if (s.h_cap < n) {
-        if (s.h_bc) FQ_TRY(hipHostFree(s.h_bc));
-        if (s.h_ids) FQ_TRY(hipHostFree(s.h_ids));
+    const bool by_copy = n > s.k_cap;          // more (short) records than the kernel could write to the host itself
+    if (by_copy) {
+        FQ_TRY(hipHostFree(s.h_bc));
+        FQ_TRY(hipHostFree(s.h_ids));
         s.h_bc = s.h_ids = nullptr;
         s.h_cap = 0;
         const size_t cap = n + n / 4 + 1024;
         FQ_TRY(hipHostMalloc((void **)&s.h_bc, 2 * cap * sizeof(uint32_t), hipHostMallocDefault));
         FQ_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
         s.h_cap = cap;
-    }
-    if (n) {
         FQ_TRY(hipMemcpyAsync(s.h_bc, s.d_bcpos, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipMemcpyAsync(s.h_bc + s.h_cap, s.d_bclen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipEventRecord(s.parsed, hs));
-        // the reads are classified where they lie in the raw block WHILE the host names the barcodes: enqueue first, then wait
-        // for the two small copies only (the event sits in front of the kernels)
-        if (!(st.flags & 1))
-            if (hast_status c = classify_framed(f->ctx, s.d_buf, f->pad + s.n_bytes, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
-        FQ_TRY(hipEventSynchronize(s.parsed));
     }
+    // the reads are classified where they lie in the raw block WHILE the host names the barcodes
+    if (n && !(st.flags & 1))
+        if (hast_status c = classify_framed(f->ctx, s.d_buf, f->pad + s.n_bytes, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
+    if (by_copy) FQ_TRY(hipEventSynchronize(s.parsed));        // (the event sits in front of the kernels)
     // host view of the bytes the barcode extents point into: this block's bytes, preceded by the previous block's tail
     if (st.tail_in != f->carry.size()) return set_error(HAST_ERR_INVALID, "tail bookkeeping out of step (%llu vs %zu)", (unsigned long long)st.tail_in, f->carry.size());
     if (!f->carry.empty()) memcpy(s.h_buf + f->pad - f->carry.size(), f->carry.data(), f->carry.size());

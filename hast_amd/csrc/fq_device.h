@@ -17,6 +17,6 @@ struct FqState {               // one per buffer slot, in device memory; copied 
 
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
-                           uint32_t k, int last, uint32_t max_records, hipStream_t s);
+                           uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last, hipStream_t s);
 
 }  // namespace hast

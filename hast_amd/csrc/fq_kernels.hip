@@ -103,8 +103,10 @@ __global__ void __launch_bounds__(256) k_fq_index(const uint8_t *buf, const FqSt
 // One lane per complete record i (lines 4i .. 4i+3 of the parse range, which always starts at a record boundary).
 // `last`: the input ends with this block, so a final record whose header line is terminated counts even when its bases /
 // '+' / quality lines lack their newlines (classify.cpp:257-268: a getline that hits EOF still yields the line read).
+// h_bc: pinned HOST memory the kernel writes the first h_cap barcode extents to ([pos x h_cap | len x h_cap]), so that the host
+// needs no device-to-host copy for them (such a copy would queue up behind the next block's 16-MB upload).
 __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
-                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t k, int last) {
+                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last) {
     const uint64_t lo = st->parse_lo, hi = st->parse_hi;
     const uint32_t n_nl = st->n_nl;
     uint32_t n_rec = n_nl / 4;
@@ -134,6 +136,10 @@ __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState 
     const int64_t stop = (e > s && e >= 0) ? e : (int64_t)h1;
     bc_pos[i] = (uint32_t)start;
     bc_len[i] = (uint32_t)(stop - start);
+    if (i < h_cap) {
+        h_bc[i] = (uint32_t)start;
+        h_bc[h_cap + i] = (uint32_t)(stop - start);
+    }
     atomicMax(&st->max_len, len);
     atomicAdd(reinterpret_cast<unsigned long long *>(&st->bases), (unsigned long long)len);
     if (len < k) {                                            // the reference aborts on such a read unless it holds 'N' (kmer.h:171)
@@ -165,7 +171,7 @@ __global__ void __launch_bounds__(256) k_fq_begin(uint8_t *buf, FqState *st, con
 
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
-                           uint32_t k, int last, uint32_t max_records, hipStream_t s) {
+                           uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_st, 0, sizeof(FqState), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_fq_begin, dim3(1), dim3(256), 0, s, d_buf, d_st, d_prev_buf, d_prev_st, pad, n_bytes);
@@ -173,8 +179,7 @@ hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_
     hipLaunchKernelGGL(k_fq_count, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt);
     hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
     hipLaunchKernelGGL(k_fq_index, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt, d_nl);
-    (void)max_records;                                        // (capacity of the record arrays; the kernel walks what it finds)
-    hipLaunchKernelGGL(k_fq_records, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, k, last);
+    hipLaunchKernelGGL(k_fq_records, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, h_bc, h_cap, k, last);
     return hipGetLastError();
 }
 

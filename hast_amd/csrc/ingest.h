@@ -309,7 +309,7 @@ class BlockSource {
             } else if (gz_mode_) {
                 r = inflater_.read(reinterpret_cast<uint8_t *>(dst + got), want - got);
                 if (r < 0) trouble = inflater_.error();
-            } else if (fp_ != stdin && want >= (32u << 20) && plain_off_ != -2) {
+            } else if (fp_ != stdin && want >= (4u << 20) && plain_off_ != -2) {
                 r = parallel_pread(dst + got, want - got);     // regular file: several readers per block (never mixed with fread)
             } else r = (long)fread(dst + got, 1, want - got, fp_);
             if (r <= 0) break;
@@ -353,7 +353,7 @@ class BlockSource {
             if (plain_off_ < 0 || pread(fd, dst, 0, 0) != 0) plain_off_ = -2;
         }
         if (plain_off_ == -2) return (long)fread(dst, 1, want, fp_);      // nothing has been pread yet: fread from here on
-        const int kReaders = readers_;
+        const int kReaders = (int)std::max<size_t>(1, std::min<size_t>((size_t)readers_, want >> 20));     // at least 1 MB per reader
         const size_t share = (want / kReaders + 4095) & ~(size_t)4095;
         size_t got[kMaxReaders] = {0};
         auto work = [&](int t) {

@@ -56,11 +56,13 @@ def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, 
 
 
 @pytest.mark.parametrize("extra", [["--batch-reads", "257"], ["--batch-reads", "13"], ["--batch-reads", "257", "--host-parse"]])
-def test_cli_small_batches_and_counter_growth(exe, golden_workdir, extra):
+def test_cli_small_batches_and_counter_growth(exe, golden_workdir, extra, monkeypatch):
     """Tiny blocks (82 KB / 4 KB: every other record straddles a block border of the GPU framer) force many launches and the
     counter-array regrowth path; output unchanged.  --host-parse: the round-1 host framing path."""
     meta = load_case("rand_k21")["runs"]["pair_w104"]
     d = golden_workdir / "rand_k21"
+    if extra == ["--batch-reads", "257"]:
+        monkeypatch.setenv("HAST_FQ_HOST_RECORDS", "7")        # blocks with more records than the framer wrote to the host itself
     res = subprocess.run([exe] + meta["argv"] + extra + ["--initial-barcodes", "3", "--stats"], cwd=d,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
