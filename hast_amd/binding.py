@@ -27,7 +27,7 @@ class KcSynth(C.Structure):
 class FqBlock(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("max_read_len", C.c_uint32), ("short_read", C.c_uint32),
                 ("bytes", C.POINTER(C.c_uint8)), ("bc_pos", C.POINTER(C.c_uint32)), ("bc_len", C.POINTER(C.c_uint32)),
-                ("ids", C.POINTER(C.c_uint32))]
+                ("bc_text", C.POINTER(C.c_uint8)), ("ids", C.POINTER(C.c_uint32))]
 
 
 KC_HISTO_HIGH = 10000

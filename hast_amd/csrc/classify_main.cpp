@@ -230,7 +230,7 @@ int main(int argc, char **argv) {
     std::vector<hast_ctx *> ctxs;
     // The FASTQ streams of the first files (pinned staging + device buffers: ~0.1 s of page pinning) are set up by a thread
     // of their own while this one reads the k-mer files and builds the table.
-    std::vector<hast_fq *> pre_fq;
+    std::vector<hast_fq *> pre_fq, done_fq;
     std::thread pre_thread;
     std::string pre_error;
     auto contexts_ready = [&]() {
@@ -597,8 +597,13 @@ int main(int argc, char **argv) {
             const size_t n = (size_t)b.n_records;
             pool.run([&](int t) {
                 const size_t lo = n * (size_t)t / T, hi_ = n * (size_t)(t + 1) / T;
-                for (size_t i = lo; i < hi_; i++)
-                    b.ids[i] = dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]);
+                for (size_t i = lo; i < hi_; i++) {
+                    const uint8_t *txt = b.bc_text ? b.bc_text + 16 * i : nullptr;      // the framer's compact copy of the barcode text
+                    if (txt && i + 8 < hi_) __builtin_prefetch(&caches[t].e[hast::BarcodeDict::hash(std::string_view(reinterpret_cast<const char *>(txt) + 128 + 1, txt[128] <= 15 ? txt[128] : 0)) & (hast::BarcodeDict::kCacheSlots - 1)]);
+                    b.ids[i] = txt && txt[0] != 0xFF
+                                   ? dict.get(std::string_view(reinterpret_cast<const char *>(txt) + 1, txt[0]), caches[t])
+                                   : dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]);
+                }
             });
             const double t2 = now_s();
             t_names += t2 - t1;
@@ -657,7 +662,7 @@ int main(int argc, char **argv) {
                     }
                     f.cv.notify_all();
                     f.th.join();
-                    hast_fq_destroy(f.fq);
+                    done_fq.push_back(f.fq);                       // (freed after the output: unpinning costs as much as pinning)
                     logtime();
                     fprintf(stderr, "__process read done__\n");
                     active.erase(active.begin() + (long)fi);
@@ -713,6 +718,7 @@ int main(int argc, char **argv) {
                 (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
     fprintf(stderr, "__END__\n");
+    for (hast_fq *f : done_fq) hast_fq_destroy(f);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     return 0;
 }

@@ -108,7 +108,7 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
         ck(hipMalloc((void **)&s.d_votes, f->max_rec * 2 * sizeof(uint32_t)), "votes");
         s.h_cap = f->block / 96 + 4096;                    // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
         if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) s.h_cap = (size_t)std::max(1L, atol(e));       // (tests: force the copy path)
-        ck(hipHostMalloc((void **)&s.h_bc, 2 * s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned barcode extents");
+        ck(hipHostMalloc((void **)&s.h_bc, (2 + 4) * s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned barcode extents + text");
         ck(hipHostMalloc((void **)&s.h_ids, s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned ids");
         ck(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
@@ -229,6 +229,7 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     out->bytes = s.h_buf;
     out->bc_pos = s.h_bc;
     out->bc_len = s.h_bc + s.h_cap;
+    out->bc_text = by_copy ? nullptr : reinterpret_cast<const uint8_t *>(s.h_bc + 2 * s.h_cap);
     out->ids = s.h_ids;
     s.state = Slot::OPEN;
     f->n_opened++;

@@ -104,7 +104,9 @@ __global__ void __launch_bounds__(256) k_fq_index(const uint8_t *buf, const FqSt
 // `last`: the input ends with this block, so a final record whose header line is terminated counts even when its bases /
 // '+' / quality lines lack their newlines (classify.cpp:257-268: a getline that hits EOF still yields the line read).
 // h_bc: pinned HOST memory the kernel writes the first h_cap barcode extents to ([pos x h_cap | len x h_cap]), so that the host
-// needs no device-to-host copy for them (such a copy would queue up behind the next block's 16-MB upload).
+// needs no device-to-host copy for them (such a copy would queue up behind the next block's 16-MB upload), followed by the
+// barcode TEXT itself, 16 bytes per record: length byte + up to 15 bytes (0xFF: longer, take it from the block).  The host
+// then names a record from one compact, sequentially read array instead of one cache miss per header line.
 __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
                                                     uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last) {
     const uint64_t lo = st->parse_lo, hi = st->parse_hi;
@@ -139,6 +141,13 @@ __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState 
     if (i < h_cap) {
         h_bc[i] = (uint32_t)start;
         h_bc[h_cap + i] = (uint32_t)(stop - start);
+        const uint32_t bl = (uint32_t)(stop - start);
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (bl <= 15) {
+            w[0] = bl;
+            for (uint32_t j = 0; j < bl; ++j) w[(j + 1) >> 2] |= (uint32_t)buf[start + j] << (8 * ((j + 1) & 3));
+        } else w[0] = 0xFF;
+        reinterpret_cast<uint4 *>(h_bc + 2 * (size_t)h_cap)[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     atomicMax(&st->max_len, len);
     atomicAdd(reinterpret_cast<unsigned long long *>(&st->bases), (unsigned long long)len);

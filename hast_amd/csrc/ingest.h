@@ -116,15 +116,16 @@ class BarcodeDict {
         return h ^ (h >> 32);
     }
     // thread-safe; `cache` is a per-thread front cache (hot barcodes such as 0_0_0 never touch a lock)
-    static constexpr size_t kCacheSlots = 1u << 15;         // 768 KB per thread: most of a core's L2, holds the barcodes in flight
+    static constexpr size_t kCacheSlots = 1u << 15;         // 1.5 MB per thread: holds the barcodes in flight
     struct Cache {
-        struct E { uint64_t h = 0; const char *p = nullptr; uint32_t len = 0, id = 0; };
+        // the text of short barcodes sits IN the entry (no second cache miss for the comparison)
+        struct E { uint64_t h = 0; const char *p = nullptr; uint32_t len = 0, id = 0; char inl[16] = {0}; };
         std::vector<E> e = std::vector<E>(kCacheSlots);
     };
     uint32_t get(std::string_view bc, Cache &cache) {
         const uint64_t h = hash(bc);
         Cache::E &ce = cache.e[h & (kCacheSlots - 1)];
-        if (ce.p && ce.h == h && ce.len == bc.size() && memcmp(ce.p, bc.data(), bc.size()) == 0) return ce.id;
+        if (ce.p && ce.h == h && ce.len == bc.size() && memcmp(bc.size() <= 16 ? ce.inl : ce.p, bc.data(), bc.size()) == 0) return ce.id;
         Shard &s = shards_[(h >> 40) & (kShards - 1)];
         std::lock_guard<std::mutex> g(s.mu);
         if (s.slots.empty()) s.slots.resize(64);
@@ -133,7 +134,7 @@ class BarcodeDict {
             Slot &sl = s.slots[i];
             if (!sl.p) break;
             if (sl.h == h && sl.len == bc.size() && memcmp(sl.p, bc.data(), bc.size()) == 0) {
-                ce = {h, sl.p, sl.len, sl.id};
+                fill(ce, h, sl.p, sl.len, sl.id);
                 return sl.id;
             }
             i = (i + 1) & mask;
@@ -143,8 +144,15 @@ class BarcodeDict {
         const uint32_t id = next_id_.fetch_add(1, std::memory_order_relaxed);
         s.slots[i] = {h, p, (uint32_t)bc.size(), id};
         if (++s.n * 2 > s.slots.size()) s.grow();
-        ce = {h, p, (uint32_t)bc.size(), id};
+        fill(ce, h, p, (uint32_t)bc.size(), id);
         return id;
+    }
+    static void fill(Cache::E &ce, uint64_t h, const char *p, uint32_t len, uint32_t id) {
+        ce.h = h;
+        ce.p = p;
+        ce.len = len;
+        ce.id = id;
+        if (len <= 16) memcpy(ce.inl, p, len);
     }
     size_t size() const { return next_id_.load(std::memory_order_relaxed); }
     // names by id (call when no thread is inserting)

@@ -228,6 +228,8 @@ typedef struct {
     const uint8_t *bytes;      /* host view of the block (with the previous block's tail in front of it) */
     const uint32_t *bc_pos;    /* [n_records] */
     const uint32_t *bc_len;    /* [n_records] */
+    const uint8_t *bc_text;    /* [n_records][16] or NULL: the barcode text itself, byte 0 = its length, bytes 1.. = the text;
+                                  length byte 0xFF = longer than 15 bytes, take it from bytes[bc_pos ..) */
     uint32_t *ids;             /* [n_records], to be filled by the caller before hast_fq_commit */
 } hast_fq_block;
 hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_fq **out);

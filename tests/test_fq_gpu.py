@@ -43,7 +43,7 @@ def make_fastq(rng, n, k, keys, tail):
             s = list("ACGN"[:rng.randint(1, 4)]) if k > 4 else s
             if "N" not in s:
                 s.append("N")
-        bc = rng.choice(["0_0_0", "%d_%d_%d" % (rng.randint(1, 30), rng.randint(1, 3), rng.randint(1, 3))])
+        bc = rng.choice(["0_0_0", "%d_%d_%d" % (rng.randint(1, 30), rng.randint(1, 3), rng.randint(1, 3)), "lib7_%d_222222_3333" % rng.randint(1, 9), ""])
         head = rng.choice(["@r{i}#{bc}/1", "@r{i}#{bc}/2\tx\t1", "@r{i}/x#{bc}", "@r{i}#{bc}", "@#{bc}/1/2", "@nohash{i}", "@r{i}#a#{bc}/1/"]).format(i=i, bc=bc)
         qual = "".join(rng.choice("@+IF#/") for _ in range(len(s)))     # quality lines may start with '@' or hold '#', '/'
         recs.append("%s\n%s\n+\n%s\n" % (head, "".join(s), qual))
@@ -88,6 +88,9 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk):
             short.append(b.short_read)
             for i in range(b.n_records):
                 bc = bytes(b.bytes[b.bc_pos[i]:b.bc_pos[i] + b.bc_len[i]])
+                if b.bc_text:                            # the framer's compact copy of the text: length byte + up to 15 bytes
+                    t = bytes(b.bc_text[16 * i:16 * i + 16])
+                    assert (t[0] == 0xFF and len(bc) > 15) or (t[0] == len(bc) and t[1:1 + t[0]] == bc), (bc, t)
                 b.ids[i] = names.setdefault(bc, len(names))
                 got.append(bc)
             n_bases += b.n_bases
