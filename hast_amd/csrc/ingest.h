@@ -374,10 +374,9 @@ class BlockSource {
             }
             got[t] = done;
         };
-        std::thread th[kMaxReaders - 1];
-        for (int t = 1; t < kReaders; ++t) th[t - 1] = std::thread(work, t);
-        work(0);
-        for (int t = 1; t < kReaders; ++t) th[t - 1].join();
+        // a persistent pool: spawning the readers anew for every 16-MB block costs as much as the copy itself
+        if (!pread_pool_ || pread_pool_->size() != readers_) pread_pool_.reset(new WorkerPool(readers_));
+        pread_pool_->run([&](int t) { if (t < kReaders) work(t); });
         size_t total = 0;                            // contiguous bytes from the start: a short share ends the data
         for (int t = 0; t < kReaders; ++t) {
             const size_t from = std::min(want, share * (size_t)t), to = std::min(want, from + share);
@@ -389,6 +388,7 @@ class BlockSource {
     }
     static constexpr int kMaxReaders = 32;
     int readers_ = 4;
+    std::unique_ptr<WorkerPool> pread_pool_;
     off_t plain_off_ = -1;
     bool gz_mode_ = false, use_zlib_ = false, bgzf_ = false;
     BgzfReader bgzf_reader_;
