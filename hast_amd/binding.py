@@ -27,7 +27,8 @@ class KcSynth(C.Structure):
 class FqBlock(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("max_read_len", C.c_uint32), ("short_read", C.c_uint32),
                 ("bytes", C.POINTER(C.c_uint8)), ("bc_pos", C.POINTER(C.c_uint32)), ("bc_len", C.POINTER(C.c_uint32)),
-                ("bc_text", C.POINTER(C.c_uint8)), ("ids", C.POINTER(C.c_uint32))]
+                ("bc_text", C.POINTER(C.c_uint8)), ("ids", C.POINTER(C.c_uint32)), ("unknown", C.POINTER(C.c_uint32)),
+                ("n_unknown", C.c_uint64)]
 
 
 KC_HISTO_HIGH = 10000
@@ -77,7 +78,9 @@ ABI_SYMBOLS = {
     "hast_classify_perread": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "hast_batch_begin": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "hast_batch_submit": (C.c_int, [vp, C.c_size_t, C.c_uint32]),
-    "hast_fq_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
+    "hast_names_create": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "hast_names_destroy": (None, [vp]),
+    "hast_fq_create": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(vp)]),
     "hast_fq_destroy": (None, [vp]),
     "hast_fq_block_bytes": (C.c_size_t, [vp]),
     "hast_fq_acquire": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8))]),

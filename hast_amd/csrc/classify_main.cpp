@@ -231,6 +231,7 @@ int main(int argc, char **argv) {
     // The FASTQ streams of the first files (pinned staging + device buffers: ~0.1 s of page pinning) are set up by a thread
     // of their own while this one reads the k-mer files and builds the table.
     std::vector<hast_fq *> pre_fq, done_fq;
+    std::vector<hast_names *> name_caches;                 // per GPU: device-side cache barcode text -> id
     std::thread pre_thread;
     std::string pre_error;
     auto contexts_ready = [&]() {
@@ -241,10 +242,17 @@ int main(int argc, char **argv) {
             ctxs.push_back(c2);
         }
         if (host_parse) return;
+        size_t name_cap = std::max<size_t>(initial_barcodes, 1u << 22);
+        if (const char *e = getenv("HAST_NAME_CACHE")) name_cap = (size_t)atol(e);
+        for (hast_ctx *c : ctxs) {
+            hast_names *nm = nullptr;
+            if (name_cap) CK(hast_names_create(c, name_cap, &nm), "creating the barcode name cache");
+            name_caches.push_back(nm);
+        }
         pre_fq.assign(std::min<size_t>(read.size(), std::max<size_t>(4, 2 * ctxs.size())), nullptr);
         pre_thread = std::thread([&] {
             for (size_t i = 0; i < pre_fq.size(); i++)
-                if (hast_fq_create(ctxs[i % ctxs.size()], fq_cap, fq_bufs, &pre_fq[i]) != HAST_OK) {
+                if (hast_fq_create(ctxs[i % ctxs.size()], fq_cap, fq_bufs, name_caches[i % ctxs.size()], &pre_fq[i]) != HAST_OK) {
                     pre_error = hast_last_error();
                     return;
                 }
@@ -546,7 +554,7 @@ int main(int argc, char **argv) {
             f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
             const double tc0 = now_s();
             if (next_file < pre_fq.size() && pre_fq[next_file]) f->fq = pre_fq[next_file];     // set up while the table was built
-            else CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, &f->fq), "creating the FASTQ stream");
+            else CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, name_caches[next_file % ctxs.size()], &f->fq), "creating the FASTQ stream");
             t_create += now_s() - tc0;
             next_file++;
             Feed *fp = f.get();
@@ -583,6 +591,7 @@ int main(int argc, char **argv) {
         while (next_file < read.size() && active.size() < max_active) open_next();
         uint64_t seen_gen = 0;
         double t_gpu_wait = 0, t_names = 0, t_commit = 0, t_idle = 0;
+        uint64_t total_named = 0;
         // names the barcodes of the oldest submitted block of a feed and commits it
         auto open_block = [&](Feed &f) {
             hast_fq_block b;
@@ -595,16 +604,20 @@ int main(int argc, char **argv) {
                 exit(3);                                                                   // reference: assert abort (kmer.h:171)
             }
             const size_t n = (size_t)b.n_records;
-            pool.run([&](int t) {
-                const size_t lo = n * (size_t)t / T, hi_ = n * (size_t)(t + 1) / T;
-                for (size_t i = lo; i < hi_; i++) {
+            // records the device-side name cache did not know (all of them without a cache): text -> id in the job's dictionary
+            const size_t nu = b.unknown ? (size_t)b.n_unknown : n;
+            auto name_range = [&](int t, size_t lo, size_t hi_) {
+                for (size_t j = lo; j < hi_; j++) {
+                    const size_t i = b.unknown ? b.unknown[j] : j;
                     const uint8_t *txt = b.bc_text ? b.bc_text + 16 * i : nullptr;      // the framer's compact copy of the barcode text
-                    if (txt && i + 8 < hi_) __builtin_prefetch(&caches[t].e[hast::BarcodeDict::hash(std::string_view(reinterpret_cast<const char *>(txt) + 128 + 1, txt[128] <= 15 ? txt[128] : 0)) & (hast::BarcodeDict::kCacheSlots - 1)]);
                     b.ids[i] = txt && txt[0] != 0xFF
                                    ? dict.get(std::string_view(reinterpret_cast<const char *>(txt) + 1, txt[0]), caches[t])
                                    : dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]);
                 }
-            });
+            };
+            if (nu < 4096) name_range(0, 0, nu);
+            else pool.run([&](int t) { name_range(t, nu * (size_t)t / T, nu * (size_t)(t + 1) / T); });
+            total_named += nu;
             const double t2 = now_s();
             t_names += t2 - t1;
             if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
@@ -681,8 +694,8 @@ int main(int argc, char **argv) {
             }
         }
         if (stats)
-            fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f\n",
-                    t_idle, t_gpu_wait, t_names, t_commit, t_create);
+            fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f records_named_on_host=%llu\n",
+                    t_idle, t_gpu_wait, t_names, t_commit, t_create, (unsigned long long)total_named);
     }
     flush_counts(ctxs, acc, dict.size(), 1);
     const double t_classified = now_s();
@@ -719,6 +732,7 @@ int main(int argc, char **argv) {
     }
     fprintf(stderr, "__END__\n");
     for (hast_fq *f : done_fq) hast_fq_destroy(f);
+    for (hast_names *nm : name_caches) hast_names_destroy(nm);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     return 0;
 }

@@ -30,6 +30,11 @@ struct Slot {
     uint32_t *d_tile = nullptr, *d_nl = nullptr;
     uint64_t *d_off = nullptr;
     uint32_t *d_len = nullptr, *d_bcpos = nullptr, *d_bclen = nullptr, *d_ids = nullptr, *d_votes = nullptr;
+    uint32_t *d_text = nullptr;                        // [h_cap][4]: the barcode text records, for the device-side name cache
+    uint32_t *h_unknown = nullptr;                     // pinned [1 + h_cap]: count, then the records the cache did not know
+    NamePub *h_pubs = nullptr;                         // pinned [h_cap]: what this block teaches the cache
+    hipEvent_t named = nullptr;
+    bool use_cache = false;                            // this block's ids came from the cache (unknown list valid)
     uint32_t *h_bc = nullptr, *h_ids = nullptr;        // pinned: h_bc = [pos x h_cap | len x h_cap], written by the records kernel itself
     size_t h_cap = 0;                                  // records the pinned arrays hold (a block with more: grown, copied)
     size_t k_cap = 0;                                  // ... the capacity the kernel of the submitted block was given
@@ -41,8 +46,17 @@ struct Slot {
 };
 }  // namespace
 
+struct hast_names {            // device-side cache barcode text -> id of one GPU, shared by the FASTQ streams of that GPU
+    hast_ctx *ctx = nullptr;
+    int device = 0;
+    NameEntry *d_tab = nullptr;
+    uint32_t mask = 0;
+    size_t count = 0, limit = 0;                       // entries published / published at most (half the slots)
+};
+
 struct hast_fq {
     hast_ctx *ctx = nullptr;
+    hast_names *names = nullptr;
     int device = 0, k = 0;
     size_t block = 0, pad = 0, max_rec = 0;
     std::vector<Slot> slots;
@@ -59,6 +73,10 @@ static void free_slot(Slot &s) {
     if (s.h_st) (void)hipHostFree(s.h_st);
     if (s.h_bc) (void)hipHostFree(s.h_bc);
     if (s.h_ids) (void)hipHostFree(s.h_ids);
+    if (s.h_unknown) (void)hipHostFree(s.h_unknown);
+    if (s.h_pubs) (void)hipHostFree(s.h_pubs);
+    if (s.d_text) (void)hipFree(s.d_text);
+    if (s.named) (void)hipEventDestroy(s.named);
     for (void *p : {(void *)s.d_buf, (void *)s.d_st, (void *)s.d_tile, (void *)s.d_nl, (void *)s.d_off, (void *)s.d_len, (void *)s.d_bcpos,
                     (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes})
         if (p) (void)hipFree(p);
@@ -70,15 +88,48 @@ static void free_slot(Slot &s) {
 
 extern "C" {
 
-hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, hast_fq **out) {
+hast_status hast_names_create(hast_ctx *ctx, size_t max_barcodes, hast_names **out) {
     if (!ctx || !out) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
+    FQ_TRY(hipSetDevice(hast_ctx_device(ctx)));
+    size_t slots = 1024;
+    while (slots < 2 * std::max<size_t>(max_barcodes, 1) && slots < (1ull << 31)) slots <<= 1;
+    hast_names *nm = new (std::nothrow) hast_names();
+    if (!nm) return set_error(HAST_ERR_OOM, "host allocation failed");
+    nm->ctx = ctx;
+    nm->device = hast_ctx_device(ctx);
+    hipError_t e = hipMalloc((void **)&nm->d_tab, slots * sizeof(NameEntry));
+    if (e == hipSuccess) e = hipMemsetAsync(nm->d_tab, 0, slots * sizeof(NameEntry), ctx_stream_of(ctx));
+    if (e != hipSuccess) {
+        if (nm->d_tab) (void)hipFree(nm->d_tab);
+        delete nm;
+        return set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "name cache: %s", hipGetErrorString(e));
+    }
+    nm->mask = (uint32_t)(slots - 1);
+    nm->limit = slots / 2;
+    *out = nm;
+    return HAST_OK;
+}
+
+void hast_names_destroy(hast_names *nm) {
+    if (!nm) return;
+    (void)hipSetDevice(nm->device);
+    (void)hipStreamSynchronize(ctx_stream_of(nm->ctx));
+    if (nm->d_tab) (void)hipFree(nm->d_tab);
+    delete nm;
+}
+
+hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, hast_names *names, hast_fq **out) {
+    if (!ctx || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (names && names->ctx != ctx) return set_error(HAST_ERR_INVALID, "the name cache belongs to another context");
     if (block_bytes < 4096 || block_bytes > (1ull << 30)) return set_error(HAST_ERR_INVALID, "block_bytes %zu out of [4 KB, 1 GB]", block_bytes);
     if (n_buffers < 2 || n_buffers > 16) return set_error(HAST_ERR_INVALID, "n_buffers %d out of [2,16]", n_buffers);
     FQ_TRY(hipSetDevice(hast_ctx_device(ctx)));
     hast_fq *f = new (std::nothrow) hast_fq();
     if (!f) return set_error(HAST_ERR_OOM, "host allocation failed");
     f->ctx = ctx;
+    f->names = names;
     f->device = hast_ctx_device(ctx);
     f->k = hast_ctx_k(ctx);
     f->block = (block_bytes + 4095) & ~(size_t)4095;
@@ -110,6 +161,10 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
         if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) s.h_cap = (size_t)std::max(1L, atol(e));       // (tests: force the copy path)
         ck(hipHostMalloc((void **)&s.h_bc, (2 + 4) * s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned barcode extents + text");
         ck(hipHostMalloc((void **)&s.h_ids, s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned ids");
+        ck(hipMalloc((void **)&s.d_text, 4 * s.h_cap * sizeof(uint32_t)), "barcode text records");
+        ck(hipHostMalloc((void **)&s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), hipHostMallocDefault), "pinned unknown list");
+        ck(hipHostMalloc((void **)&s.h_pubs, s.h_cap * sizeof(NamePub), hipHostMallocDefault), "pinned publications");
+        ck(hipEventCreateWithFlags(&s.named, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event");
@@ -168,7 +223,7 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     FQ_TRY(hipStreamWaitEvent(hs, s.copied, 0));
     const Slot *prev = f->prev_submitted >= 0 ? &f->slots[(size_t)f->prev_submitted] : nullptr;
     FQ_TRY(launch_fq_block(s.d_buf, s.d_st, prev ? prev->d_buf : nullptr, prev ? prev->d_st : nullptr, f->pad, n_bytes, s.d_tile, s.d_nl, s.d_off,
-                           s.d_len, s.d_bcpos, s.d_bclen, s.h_bc, (uint32_t)s.h_cap, (uint32_t)f->k, last, hs));
+                           s.d_len, s.d_bcpos, s.d_bclen, s.h_bc, s.d_text, (uint32_t)s.h_cap, (uint32_t)f->k, last, hs));
     s.k_cap = s.h_cap;
     FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, hs));
     FQ_TRY(hipEventRecord(s.parsed, hs));
@@ -191,7 +246,8 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     memset(out, 0, sizeof(*out));
     if (f->n_opened >= f->n_submitted) return set_error(HAST_ERR_INVALID, "hast_fq_next: no submitted block");
     Slot &s = f->slots[f->n_opened % f->slots.size()];
-    if (s.state != Slot::SUBMITTED) return set_error(HAST_ERR_INVALID, "hast_fq_next: commit the previous block first");
+    if (s.state != Slot::SUBMITTED || (f->n_opened && f->slots[(f->n_opened - 1) % f->slots.size()].state == Slot::OPEN))
+        return set_error(HAST_ERR_INVALID, "hast_fq_next: commit the previous block first");
     FQ_TRY(hipSetDevice(f->device));
     hipStream_t hs = ctx_stream_of(f->ctx);
     FQ_TRY(hipEventSynchronize(s.parsed));
@@ -213,10 +269,18 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
         FQ_TRY(hipMemcpyAsync(s.h_bc + s.h_cap, s.d_bclen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipEventRecord(s.parsed, hs));
     }
+    // ids from the device-side name cache (after a few blocks nearly every barcode of a block has been seen before)
+    s.use_cache = f->names && n && !by_copy;
+    if (s.use_cache) {
+        s.h_unknown[0] = 0;
+        FQ_TRY(launch_fq_name(s.d_text, (uint32_t)n, f->names->d_tab, f->names->mask, s.h_ids, s.h_unknown, hs));
+        FQ_TRY(hipEventRecord(s.named, hs));
+    }
     // the reads are classified where they lie in the raw block WHILE the host names the barcodes
     if (n && !(st.flags & 1))
         if (hast_status c = classify_framed(f->ctx, s.d_buf, f->pad + s.n_bytes, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
     if (by_copy) FQ_TRY(hipEventSynchronize(s.parsed));        // (the event sits in front of the kernels)
+    if (s.use_cache) FQ_TRY(hipEventSynchronize(s.named));
     // host view of the bytes the barcode extents point into: this block's bytes, preceded by the previous block's tail
     if (st.tail_in != f->carry.size()) return set_error(HAST_ERR_INVALID, "tail bookkeeping out of step (%llu vs %zu)", (unsigned long long)st.tail_in, f->carry.size());
     if (!f->carry.empty()) memcpy(s.h_buf + f->pad - f->carry.size(), f->carry.data(), f->carry.size());
@@ -231,6 +295,8 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     out->bc_len = s.h_bc + s.h_cap;
     out->bc_text = by_copy ? nullptr : reinterpret_cast<const uint8_t *>(s.h_bc + 2 * s.h_cap);
     out->ids = s.h_ids;
+    out->unknown = s.use_cache ? s.h_unknown + 1 : nullptr;
+    out->n_unknown = s.use_cache ? s.h_unknown[0] : n;
     s.state = Slot::OPEN;
     f->n_opened++;
     return HAST_OK;
@@ -246,10 +312,32 @@ hast_status hast_fq_commit(hast_fq *f) {
     const size_t n = s.h_st->n_rec;
     if (n && !(s.h_st->flags & 1)) {
         const size_t nbc = ctx_n_barcodes(f->ctx);
-        for (size_t i = 0; i < n; ++i)
-            if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %zu is outside the %zu counters", s.h_ids[i], i, nbc);
-        FQ_TRY(hipMemcpyAsync(s.d_ids, s.h_ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
-        if (hast_status c = commit_framed(f->ctx, s.d_votes, s.d_ids, n, hs)) return c;
+        if (s.use_cache) {
+            // the caller named the records the cache did not know: check those, teach the cache, and let the bookkeeping kernel
+            // read the ids where they are (pinned host memory: a copy would queue up behind the next block's upload)
+            const uint32_t nu = s.h_unknown[0];
+            hast_names *nm = f->names;
+            uint32_t np = 0;
+            for (uint32_t j = 0; j < nu; ++j) {
+                const uint32_t i = s.h_unknown[1 + j];
+                if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %u is outside the %zu counters", s.h_ids[i], i, nbc);
+                const uint32_t *t = s.h_bc + 2 * s.h_cap + 4 * (size_t)i;
+                if ((t[0] & 0xFFu) == 0xFFu || nm->count + np >= nm->limit) continue;          // long barcodes stay with the host
+                NamePub &p = s.h_pubs[np++];
+                p.key[0] = t[0]; p.key[1] = t[1]; p.key[2] = t[2]; p.key[3] = t[3];
+                p.id = s.h_ids[i];
+            }
+            if (np) {
+                FQ_TRY(launch_names_insert(s.h_pubs, np, nm->d_tab, nm->mask, hs));
+                nm->count += np;                               // (an upper bound: a barcode met twice in one block is counted twice)
+            }
+            if (hast_status c = commit_framed(f->ctx, s.d_votes, s.h_ids, n, hs)) return c;
+        } else {
+            for (size_t i = 0; i < n; ++i)
+                if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %zu is outside the %zu counters", s.h_ids[i], i, nbc);
+            FQ_TRY(hipMemcpyAsync(s.d_ids, s.h_ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
+            if (hast_status c = commit_framed(f->ctx, s.d_votes, s.d_ids, n, hs)) return c;
+        }
     }
     FQ_TRY(hipEventRecord(s.done, hs));
     s.done_pending = true;

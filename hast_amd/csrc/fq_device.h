@@ -15,8 +15,27 @@ struct FqState {               // one per buffer slot, in device memory; copied 
     uint32_t flags;                // 1: a read shorter than K without 'N' (the reference aborts, kmer.h:171); 2: a record larger than the pad
 };
 
+// Device-side cache barcode text -> dense id (the authority stays the host's dictionary, which is one per job): 32-byte
+// entries, open addressing.  key = the 16-byte text record the framer makes (length byte + up to 15 bytes).
+struct NameEntry {
+    uint32_t key[4];
+    uint32_t id;
+    uint32_t state;            // 0 empty, 1 being written, 2 ready
+    uint32_t pad[2];
+};
+struct NamePub {               // what the host publishes after naming a record the cache did not know
+    uint32_t key[4];
+    uint32_t id;
+    uint32_t pad[3];
+};
+constexpr uint32_t kNameUnknown = 0xFFFFFFFFu;
+
+// ids of the first n records from the cache: d_ids / h_ids get the id or kNameUnknown, h_unknown = [count, index, index, ...]
+hipError_t launch_fq_name(const uint32_t *d_text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s);
+hipError_t launch_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, uint32_t mask, hipStream_t s);
+
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
-                           uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last, hipStream_t s);
+                           uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last, hipStream_t s);
 
 }  // namespace hast

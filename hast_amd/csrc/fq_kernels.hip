@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_fq_index(const uint8_t *buf, const FqSt
 // barcode TEXT itself, 16 bytes per record: length byte + up to 15 bytes (0xFF: longer, take it from the block).  The host
 // then names a record from one compact, sequentially read array instead of one cache miss per header line.
 __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
-                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last) {
+                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last) {
     const uint64_t lo = st->parse_lo, hi = st->parse_hi;
     const uint32_t n_nl = st->n_nl;
     uint32_t n_rec = n_nl / 4;
@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState 
             for (uint32_t j = 0; j < bl; ++j) w[(j + 1) >> 2] |= (uint32_t)buf[start + j] << (8 * ((j + 1) & 3));
         } else w[0] = 0xFF;
         reinterpret_cast<uint4 *>(h_bc + 2 * (size_t)h_cap)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        reinterpret_cast<uint4 *>(d_text)[i] = make_uint4(w[0], w[1], w[2], w[3]);          // the same record for k_fq_name
     }
     atomicMax(&st->max_len, len);
     atomicAdd(reinterpret_cast<unsigned long long *>(&st->bases), (unsigned long long)len);
@@ -178,9 +179,69 @@ __global__ void __launch_bounds__(256) k_fq_begin(uint8_t *buf, FqState *st, con
     }
 }
 
+// ---- device-side name cache ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t name_hash(const uint32_t k[4]) {
+    uint32_t h = k[0] * 0x9E3779B1u;
+    h = (h ^ (h >> 15) ^ k[1]) * 0x85EBCA6Bu;
+    h = (h ^ (h >> 13) ^ k[2]) * 0xC2B2AE35u;
+    h = (h ^ (h >> 16) ^ k[3]) * 0x27D4EB2Fu;
+    return h ^ (h >> 15);
+}
+// Runs on the context's stream, after every k_names_insert of earlier blocks: no insert is in flight while it probes.
+__global__ void __launch_bounds__(256) k_fq_name(const uint32_t *text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids,
+                                                 uint32_t *h_unknown) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint4 t = reinterpret_cast<const uint4 *>(text)[i];
+        const uint32_t k[4] = {t.x, t.y, t.z, t.w};
+        uint32_t id = kNameUnknown;
+        if ((t.x & 0xFFu) != 0xFFu && tab) {
+            uint32_t at = name_hash(k) & mask;
+            for (uint32_t probe = 0; probe <= mask; ++probe, at = (at + 1) & mask) {
+                const NameEntry &e = tab[at];
+                if (e.state == 0) break;
+                if (e.state == 2 && e.key[0] == k[0] && e.key[1] == k[1] && e.key[2] == k[2] && e.key[3] == k[3]) { id = e.id; break; }
+            }
+        }
+        h_ids[i] = id;
+        if (id == kNameUnknown) h_unknown[1 + atomicAdd(&h_unknown[0], 1u)] = i;             // (pinned host memory)
+    }
+}
+__global__ void __launch_bounds__(256) k_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, uint32_t mask) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const NamePub p = pubs[i];
+        uint32_t at = name_hash(p.key) & mask;
+        for (uint32_t probe = 0; probe <= mask; ++probe, at = (at + 1) & mask) {
+            NameEntry *e = &tab[at];
+            uint32_t st = __hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (st == 0) {
+                const uint32_t old = atomicCAS(&e->state, 0u, 1u);
+                if (old == 0) {
+                    e->key[0] = p.key[0]; e->key[1] = p.key[1]; e->key[2] = p.key[2]; e->key[3] = p.key[3];
+                    e->id = p.id;
+                    __hip_atomic_store(&e->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                st = old;
+            }
+            while (st == 1) st = __hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // another lane of this launch writes it
+            if (e->key[0] == p.key[0] && e->key[1] == p.key[1] && e->key[2] == p.key[2] && e->key[3] == p.key[3]) break;   // the same barcode twice
+        }
+    }
+}
+hipError_t launch_fq_name(const uint32_t *d_text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fq_name, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, tab, mask, h_ids, h_unknown);
+    return hipGetLastError();
+}
+hipError_t launch_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, uint32_t mask, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_names_insert, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, pubs, n, tab, mask);
+    return hipGetLastError();
+}
+
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
-                           uint32_t *h_bc, uint32_t h_cap, uint32_t k, int last, hipStream_t s) {
+                           uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_st, 0, sizeof(FqState), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_fq_begin, dim3(1), dim3(256), 0, s, d_buf, d_st, d_prev_buf, d_prev_st, pad, n_bytes);
@@ -188,7 +249,7 @@ hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_
     hipLaunchKernelGGL(k_fq_count, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt);
     hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
     hipLaunchKernelGGL(k_fq_index, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt, d_nl);
-    hipLaunchKernelGGL(k_fq_records, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, h_bc, h_cap, k, last);
+    hipLaunchKernelGGL(k_fq_records, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, h_bc, d_text, h_cap, k, last);
     return hipGetLastError();
 }
 

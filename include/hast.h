@@ -230,9 +230,19 @@ typedef struct {
     const uint32_t *bc_len;    /* [n_records] */
     const uint8_t *bc_text;    /* [n_records][16] or NULL: the barcode text itself, byte 0 = its length, bytes 1.. = the text;
                                   length byte 0xFF = longer than 15 bytes, take it from bytes[bc_pos ..) */
-    uint32_t *ids;             /* [n_records], to be filled by the caller before hast_fq_commit */
+    uint32_t *ids;             /* [n_records]: ids the device-side name cache knew are filled in; the caller fills the others */
+    const uint32_t *unknown;   /* [n_unknown] indices of the records whose ids the caller has to fill in, or NULL: all of them */
+    uint64_t n_unknown;
 } hast_fq_block;
-hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_fq **out);
+/* Device-side cache barcode text -> id of one GPU, shared by the FASTQ streams of a context: barcodes repeat (hundreds of
+ * reads each), so after the first blocks the framer names almost every record itself and the host only sees new barcodes
+ * (and the ones longer than 15 bytes).  The ids still come from the caller's dictionary -- one per job, the same on every
+ * GPU -- and hast_fq_commit teaches the cache what the caller named.  max_barcodes sizes it (2 x 32 B per barcode); more
+ * barcodes than that are simply not cached. */
+typedef struct hast_names hast_names;
+hast_status hast_names_create(hast_ctx *, size_t max_barcodes, hast_names **out);
+void        hast_names_destroy(hast_names *);
+hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_names *names_or_null, hast_fq **out);
 void        hast_fq_destroy(hast_fq *);
 size_t      hast_fq_block_bytes(const hast_fq *);
 hast_status hast_fq_acquire(hast_fq *, uint8_t **host_buf);

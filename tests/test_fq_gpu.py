@@ -59,9 +59,12 @@ def make_fastq(rng, n, k, keys, tail):
     return text.encode()
 
 
+@pytest.mark.parametrize("cache", [0, 64, 1 << 16])
 @pytest.mark.parametrize("tail", ["plain", "no_final_newline", "header_only", "unterminated_header", "bases_no_newline"])
 @pytest.mark.parametrize("chunk", [(700, 4096), (4096, 4096), (50_000, 65536)])
-def test_fq_framing_and_counts(oracle_lib, tail, chunk):
+def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
+    """cache: size of the device-side barcode name cache (0: none, the caller names every record; 64: far too small for the
+    ~300 barcodes of the input, so it fills up and stops learning; 65536: ample)"""
     lo, hi = chunk
     rng = random.Random(hash((tail, chunk)) & 0xFFFF)
     k, n_keys = 21, 3000
@@ -75,14 +78,17 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk):
         ctx.table_insert_keys(0, keys[0])
         ctx.table_insert_keys(1, keys[1])
         ctx.counts_resize(4096)
-        fq = C.c_void_p()
-        assert lib.hast_fq_create(ctx._h, hi, 3, C.byref(fq)) == 0, lib.hast_last_error()
+        fq, nm = C.c_void_p(), C.c_void_p()
+        if cache:
+            assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
+        assert lib.hast_fq_create(ctx._h, hi, 3, nm, C.byref(fq)) == 0, lib.hast_last_error()
         names, got, pos, pending = {}, [], 0, 0
+        host_named = 0
         n_bases = 0
         short = []
 
         def drain():
-            nonlocal n_bases
+            nonlocal n_bases, host_named
             b = FqBlock()
             assert lib.hast_fq_next(fq, C.byref(b)) == 0, lib.hast_last_error()
             short.append(b.short_read)
@@ -91,8 +97,20 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk):
                 if b.bc_text:                            # the framer's compact copy of the text: length byte + up to 15 bytes
                     t = bytes(b.bc_text[16 * i:16 * i + 16])
                     assert (t[0] == 0xFF and len(bc) > 15) or (t[0] == len(bc) and t[1:1 + t[0]] == bc), (bc, t)
-                b.ids[i] = names.setdefault(bc, len(names))
                 got.append(bc)
+            if b.unknown:
+                assert cache and b.n_unknown <= b.n_records
+                todo = [b.unknown[j] for j in range(b.n_unknown)]
+                known = set(range(b.n_records)) - set(todo)
+                base = len(got) - b.n_records
+                for i in known:                          # what the cache answered must be what the caller said before
+                    assert b.ids[i] == names[got[base + i]], (got[base + i], b.ids[i])
+            else:
+                assert b.n_unknown == b.n_records
+                todo = range(b.n_records)
+            for i in todo:
+                b.ids[i] = names.setdefault(got[len(got) - b.n_records + i], len(names))
+            host_named += len(todo)
             n_bases += b.n_bases
             assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
 
@@ -112,7 +130,11 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk):
             if last:
                 break
         lib.hast_fq_destroy(fq)
+        if cache:
+            lib.hast_names_destroy(nm)
         counts = ctx.counts_read(len(names))
+    if cache >= 1 << 16 and chunk[0] < 5000:
+        assert host_named < len(got) // 2              # most records were named by the cache (many small blocks: it learns early)
     assert got == [bc for bc, _ in want]
     assert n_bases == sum(len(s) for _, s in want)
     if tail == "header_only":
@@ -146,7 +168,7 @@ def test_fq_short_read_is_reported(oracle_lib):
         ctx.table_insert_keys(0, np.array([12345], dtype=np.uint64))
         ctx.counts_resize(16)
         fq = C.c_void_p()
-        assert lib.hast_fq_create(ctx._h, 4096, 2, C.byref(fq)) == 0
+        assert lib.hast_fq_create(ctx._h, 4096, 2, None, C.byref(fq)) == 0
         data = b"@a#1_1_1/1\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n@b#1_1_1/1\nACGTACGT\n+\nIIIIIIII\n"
         buf = C.POINTER(C.c_uint8)()
         assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0
