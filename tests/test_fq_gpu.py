@@ -134,7 +134,10 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
             lib.hast_names_destroy(nm)
         counts = ctx.counts_read(len(names))
     if cache >= 1 << 16 and chunk[0] < 5000:
-        assert host_named < len(got) // 2              # most records were named by the cache (many small blocks: it learns early)
+        # many small blocks: the cache learns early; what stays with the host are the barcodes longer than 15 bytes (a quarter of
+        # the records here) and first sightings
+        n_long = sum(1 for bc in got if len(bc) > 15)
+        assert n_long <= host_named < n_long + (len(got) - n_long) // 2
     assert got == [bc for bc, _ in want]
     assert n_bases == sum(len(s) for _, s in want)
     if tail == "header_only":
