@@ -532,7 +532,12 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
             if (dst->d_filter) HIP_TRY(hipFree(dst->d_filter));
             dst->d_filter = nullptr;
             dst->filter_bytes = 0;
-            HIP_TRY(hipMalloc(&dst->d_filter, src->filter_bytes));
+            if (hipMalloc(&dst->d_filter, src->filter_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                dst->d_filter = nullptr;
+                dst->use_filter = false;                   // no room: this device probes the table directly
+                return HAST_OK;
+            }
             dst->filter_bytes = src->filter_bytes;
         }
         HIP_TRY(hipMemcpyPeer(dst->d_filter, dst->device, src->d_filter, src->device, src->filter_bytes));
@@ -688,7 +693,14 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
         if (c->d_filter) HIP_TRY(hipFree(c->d_filter));
         c->d_filter = nullptr;
         c->filter_bytes = 0;
-        HIP_TRY(hipMalloc(&c->d_filter, bytes));
+        if (hipMalloc(&c->d_filter, bytes) != hipSuccess) {
+            // no room for the filter next to the table (34 GB at 14-mers): probe the table directly, as round 1 did -- the same
+            // GPU path minus the front end, same results (hast_filter_info tells)
+            (void)hipGetLastError();
+            c->d_filter = nullptr;
+            c->use_filter = false;
+            return HAST_OK;
+        }
         c->filter_bytes = bytes;
     }
     HIP_TRY(hipMemsetAsync(c->d_filter, 0, bytes, hs));
@@ -747,10 +759,11 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     // candidates take the one whose windows fill the waves' 64-window blocks best (a workgroup walks
     // 4 waves x 2 blocks per iteration: 150-bp reads => 31 reads = 4030 windows = 63 of 64 block slots).
     hipStream_t hs = s ? (hipStream_t)s : c->stream;
+    if (c->use_filter)
+        if (hast_status st = ensure_filter(c, hs)) return st;        // (may switch the filter off when HBM is short)
     const bool filt = c->use_filter;
     size_t per_read, pad;
     if (filt) {
-        if (hast_status st = ensure_filter(c, hs)) return st;
         a.filter = c->d_filter;
         a.fg = c->fg;
         a.l1_stride = ((read_len >= (uint32_t)c->fg.t ? read_len - (uint32_t)c->fg.t + 1 : 0) + 1 + 3) & ~3u;

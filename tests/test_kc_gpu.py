@@ -300,7 +300,16 @@ def test_unshared_kmers_slices_overflow_retry_and_table_handoff(built, oracle_di
     assert a.stdout == b.stdout and len(a.stdout) > 0
 
 
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def _n_gpus():
+    import ctypes
+    try:
+        n = ctypes.c_int(0)
+        return n.value if ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", pytest.param("0,1", marks=pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs"))])
 def test_unshared_kmers_key_space_split_over_several_tables(built, golden_workdir, tmp_path, devices):
     """--devices a,b,..: one table per GPU, each owning a share of the minimizer space (here: several tables on the one
     GPU of the test box); with --slices on top and a table that overflows"""
