@@ -141,6 +141,30 @@ def test_cli_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path, gz, threa
     assert len(got.stdout.splitlines()) > 1000
 
 
+def test_cli_empty_crlf_and_many_files(exe, oracle_dir, tmp_path):
+    """Inputs at the edges of the framing (classify.cpp:257-268): an empty file, a file of one record without a final newline,
+    CR LF line ends (the reference does not strip the CR: it is one more base, coded as T), and more input files than
+    streams are kept open at once -- against the oracle's line-by-line reader, framed on the GPU and on the host."""
+    path = _write_case(tmp_path, 3000, seed=5, gz=False)
+    text = path.read_bytes()
+    (tmp_path / "empty.fq").write_bytes(b"")
+    (tmp_path / "one.fq").write_bytes(text.split(b"\n@R")[0].rstrip(b"\n"))
+    crlf = b"\r\n".join(text.split(b"\n")[:4000 - 4000 % 4]) + b"\r\n"
+    (tmp_path / "crlf.fq").write_bytes(crlf)
+    files = ["empty.fq", "one.fq", "crlf.fq", path.name, "empty.fq", path.name, "crlf.fq", "one.fq", path.name, path.name]
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--weight0", "1.04"]
+    for f in files:
+        args += ["--read", f]
+    ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args, cwd=tmp_path, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert ref.returncode == 0, ref.stderr.decode()[-500:]
+    for extra in ([], ["--batch-reads", "40"], ["--host-parse"], ["--devices", "0,0,0"]):
+        got = subprocess.run([exe] + args + ["-t", "5"] + extra, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert got.returncode == 0, got.stderr.decode()[-2000:]
+        assert got.stdout == ref.stdout, extra
+    assert len(ref.stdout.splitlines()) > 500
+
+
 def test_cli_gz_decoders_agree_and_damaged_gz_is_an_error(exe, golden_workdir, tmp_path):
     """the in-tree gzip decoder vs zlib (HAST_INFLATE=zlib) on a golden case with gz reads; a truncated gz file must not
     pass as a shorter input"""
