@@ -22,6 +22,92 @@
 
 namespace hast {
 
+// ---- Huffman decoding tables (shared by the serial decoder below and the parallel one in par_inflate.h) ---------------
+// table entry: bits 0-7 codeword bits to drop, 8-12 extra-bit count (or sub-table index bits), 13 literal, 14 end of block,
+// 15 sub-table pointer, 16-31 value (literal byte / base length / base distance / sub-table start)
+constexpr uint32_t kInflateLit = 1u << 13, kInflateEob = 1u << 14, kInflateSub = 1u << 15;
+constexpr int kInflateLitBits = 11, kInflateDistBits = 8;
+inline uint32_t inflate_rev_bits(uint32_t v, int n) {
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
+    return r;
+}
+// lens[0..n): code lengths (0 = unused).  kind 0: literal/length alphabet, 1: distance alphabet, 2: code-length alphabet.
+// returns nullptr, or what is wrong with the code
+inline const char *inflate_build_table(const uint8_t *lens, int n, int kind, std::vector<uint32_t> &tab, int root) {
+    constexpr uint32_t kLit = kInflateLit, kEob = kInflateEob, kSub = kInflateSub;
+    static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    int count[16] = {0};
+    for (int i = 0; i < n; ++i) count[lens[i]]++;
+    count[0] = 0;
+    int left = 1, used = 0;
+    for (int l = 1; l <= 15; ++l) {
+        left = (left << 1) - count[l];
+        if (left < 0) return "deflate: over-subscribed Huffman code";
+        used += count[l];
+    }
+    tab.assign((size_t)1 << root, 0);                    // 0 = invalid code
+    if (used == 0) return nullptr;                          // e.g. a block without distance codes
+    uint32_t next[16];
+    uint32_t code = 0;
+    for (int l = 1; l <= 15; ++l) {
+        code = (code + (uint32_t)count[l - 1]) << 1;
+        next[l] = code;
+    }
+    // sub-table size per first-level prefix = longest code with that prefix
+    std::vector<uint8_t> sub_bits;
+    std::vector<uint32_t> codes((size_t)n);
+    bool any_long = false;
+    for (int i = 0; i < n; ++i)
+        if (lens[i]) {
+            codes[i] = inflate_rev_bits(next[lens[i]]++, lens[i]);
+            any_long |= lens[i] > root;
+        }
+    if (any_long) {
+        sub_bits.assign((size_t)1 << root, 0);
+        for (int i = 0; i < n; ++i)
+            if (lens[i] > root) {
+                uint8_t &b = sub_bits[codes[i] & ((1u << root) - 1)];
+                b = std::max<uint8_t>(b, (uint8_t)(lens[i] - root));
+            }
+        for (size_t p = 0; p < sub_bits.size(); ++p)
+            if (sub_bits[p]) {
+                const size_t start = tab.size();
+                tab.resize(start + ((size_t)1 << sub_bits[p]), 0);
+                tab[p] = kSub | ((uint32_t)sub_bits[p] << 8) | (uint32_t)root | ((uint32_t)start << 16);
+                if (start >> 16) return "deflate: Huffman table too large";
+            }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int l = lens[i];
+        if (!l) continue;
+        uint32_t e;
+        if (kind == 0) {
+            if (i < 256) e = kLit | ((uint32_t)i << 16);
+            else if (i == 256) e = kEob;
+            else if (i < 286) e = ((uint32_t)len_extra[i - 257] << 8) | ((uint32_t)len_base[i - 257] << 16);
+            else continue;                               // 286, 287 never occur in valid data: leave invalid
+        } else if (kind == 1) {
+            if (i >= 30) continue;
+            e = ((uint32_t)dist_extra[i] << 8) | ((uint32_t)dist_base[i] << 16);
+        } else e = (uint32_t)i << 16;                    // code-length alphabet: the symbol itself
+        if (l <= root) {
+            e |= (uint32_t)l;
+            for (uint32_t k = codes[i]; k < (1u << root); k += 1u << l) tab[k] = e;
+        } else {
+            const uint32_t p = codes[i] & ((1u << root) - 1);
+            const uint32_t ptr = tab[p];
+            const uint32_t sb = (ptr >> 8) & 31, start = ptr >> 16;
+            e |= (uint32_t)(l - root);
+            for (uint32_t k = codes[i] >> root; k < (1u << sb); k += 1u << (l - root)) tab[start + k] = e;
+        }
+    }
+    return nullptr;
+}
+
 class GzInflater {
   public:
     // continuation = true: the stream is the rest of a gzip file whose first members someone else has decoded (the
@@ -70,13 +156,13 @@ class GzInflater {
         return (long)got;
     }
     const std::string &error() const { return err_; }
+    // CRC-32 of the gzip trailer (carry-less-multiply folding where the CPU has it), for the other readers of this directory
+    static uint32_t crc32(uint32_t crc, const uint8_t *p, size_t n) { return crc32_update(crc, p, n); }
 
   private:
     static constexpr size_t kWindow = 32768, kOutChunk = 1u << 20, kSlack = 512, kPad = 64, kBack = 8;
-    static constexpr int kLitBits = 11, kDistBits = 8;
-    // table entry: bits 0-7 codeword bits to drop, 8-12 extra-bit count (or sub-table index bits), 13 literal, 14 end of block,
-    // 15 sub-table pointer, 16-31 value (literal byte / base length / base distance / sub-table start)
-    static constexpr uint32_t kLit = 1u << 13, kEob = 1u << 14, kSub = 1u << 15;
+    static constexpr int kLitBits = kInflateLitBits, kDistBits = kInflateDistBits;
+    static constexpr uint32_t kLit = kInflateLit, kEob = kInflateEob, kSub = kInflateSub;
     enum State { kMemberHeader, kBlockHeader, kStored, kHuffman, kTrailer, kRaw, kDone, kError };
 
     bool fail(const char *what) {
@@ -143,84 +229,9 @@ class GzInflater {
         if (in_left() < 32 && !in_eof_) fill_input();
     }
 
-    // ---- Huffman tables ----------------------------------------------------------------------------------
-    static uint32_t rev_bits(uint32_t v, int n) {
-        uint32_t r = 0;
-        for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
-        return r;
-    }
-    // lens[0..n): code lengths (0 = unused).  kind 0: literal/length alphabet, 1: distance alphabet, 2: code-length alphabet.
     bool build(const uint8_t *lens, int n, int kind, std::vector<uint32_t> &tab, int root) {
-        static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-        static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-        static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-        static const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-        int count[16] = {0};
-        for (int i = 0; i < n; ++i) count[lens[i]]++;
-        count[0] = 0;
-        int left = 1, used = 0;
-        for (int l = 1; l <= 15; ++l) {
-            left = (left << 1) - count[l];
-            if (left < 0) return fail("deflate: over-subscribed Huffman code");
-            used += count[l];
-        }
-        tab.assign((size_t)1 << root, 0);                    // 0 = invalid code
-        if (used == 0) return true;                          // e.g. a block without distance codes
-        uint32_t next[16];
-        uint32_t code = 0;
-        for (int l = 1; l <= 15; ++l) {
-            code = (code + (uint32_t)count[l - 1]) << 1;
-            next[l] = code;
-        }
-        // sub-table size per first-level prefix = longest code with that prefix
-        std::vector<uint8_t> sub_bits;
-        std::vector<uint32_t> codes((size_t)n);
-        bool any_long = false;
-        for (int i = 0; i < n; ++i)
-            if (lens[i]) {
-                codes[i] = rev_bits(next[lens[i]]++, lens[i]);
-                any_long |= lens[i] > root;
-            }
-        if (any_long) {
-            sub_bits.assign((size_t)1 << root, 0);
-            for (int i = 0; i < n; ++i)
-                if (lens[i] > root) {
-                    uint8_t &b = sub_bits[codes[i] & ((1u << root) - 1)];
-                    b = std::max<uint8_t>(b, (uint8_t)(lens[i] - root));
-                }
-            for (size_t p = 0; p < sub_bits.size(); ++p)
-                if (sub_bits[p]) {
-                    const size_t start = tab.size();
-                    tab.resize(start + ((size_t)1 << sub_bits[p]), 0);
-                    tab[p] = kSub | ((uint32_t)sub_bits[p] << 8) | (uint32_t)root | ((uint32_t)start << 16);
-                    if (start >> 16) return fail("deflate: Huffman table too large");
-                }
-        }
-        for (int i = 0; i < n; ++i) {
-            const int l = lens[i];
-            if (!l) continue;
-            uint32_t e;
-            if (kind == 0) {
-                if (i < 256) e = kLit | ((uint32_t)i << 16);
-                else if (i == 256) e = kEob;
-                else if (i < 286) e = ((uint32_t)len_extra[i - 257] << 8) | ((uint32_t)len_base[i - 257] << 16);
-                else continue;                               // 286, 287 never occur in valid data: leave invalid
-            } else if (kind == 1) {
-                if (i >= 30) continue;
-                e = ((uint32_t)dist_extra[i] << 8) | ((uint32_t)dist_base[i] << 16);
-            } else e = (uint32_t)i << 16;                    // code-length alphabet: the symbol itself
-            if (l <= root) {
-                e |= (uint32_t)l;
-                for (uint32_t k = codes[i]; k < (1u << root); k += 1u << l) tab[k] = e;
-            } else {
-                const uint32_t p = codes[i] & ((1u << root) - 1);
-                const uint32_t ptr = tab[p];
-                const uint32_t sb = (ptr >> 8) & 31, start = ptr >> 16;
-                e |= (uint32_t)(l - root);
-                for (uint32_t k = codes[i] >> root; k < (1u << sb); k += 1u << (l - root)) tab[start + k] = e;
-            }
-        }
-        return true;
+        const char *bad = inflate_build_table(lens, n, kind, tab, root);
+        return bad ? fail(bad) : true;
     }
     void build_fixed() {
         uint8_t l[288];

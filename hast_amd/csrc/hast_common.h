@@ -141,8 +141,20 @@ constexpr int kFilterMaxM = 14;                   // 4^14 blocks = 34 GB
 HAST_HD uint32_t filter_w(const FilterGeom &g) { return (uint32_t)(g.kp - g.m + 1); }
 HAST_HD uint32_t filter_nt(const FilterGeom &g) { return (uint32_t)(g.kp - g.t + 1); }
 HAST_HD uint64_t filter_nblocks(const FilterGeom &g) { return 1ull << (2 * g.m); }
-// order of a t-mer: 20 hash bits above 12 position bits; smaller wins, equal t-mers (or equal hashes) -> the leftmost
-HAST_HD uint32_t tmer_order(uint32_t tmer, uint32_t pos) { return ((((tmer + 1u) * 0x9E3779B1u) >> 12) << 12) | pos; }
+// low 32 bits of the product of the operands' low 24 bits.  On the device this is v_mul_u32_u24, a full-rate instruction;
+// v_mul_lo_u32 / v_mul_hi_u32 run at a quarter of the rate, and the probe kernel is bound by VALU issue as much as by
+// HBM requests, so the per-window arithmetic uses 24-bit products wherever the operands allow.
+HAST_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+// order of a t-mer: 20 hash bits above 12 position bits; smaller wins, equal t-mers (or equal hashes) -> the leftmost.
+// (t-mers are at most 12 bases in every geometry filter_geom_for picks, so the 24-bit product sees the whole t-mer; a
+// longer t-mer forced by an override is ordered by its last 12 bases -- still one order shared by build and probe.)
+HAST_HD uint32_t tmer_order(uint32_t tmer, uint32_t pos) { return ((mul24(tmer + 1u, 0x9E3779u) >> 12) << 12) | pos; }
 // position (0 .. W-1) of the m-mer that names the block of the K-mer string `fwd` (2K bits, first base most significant)
 HAST_HD uint32_t filter_sample_pos(uint64_t fwd, const FilterGeom &g) {
     const uint32_t nt = filter_nt(g), tmask = (uint32_t)kmer_mask(g.t);
@@ -154,17 +166,21 @@ HAST_HD uint32_t filter_sample_pos(uint64_t fwd, const FilterGeom &g) {
     const uint32_t x = best & 0xFFFu;
     return x - ((x * g.wdiv) >> 16) * filter_w(g);
 }
-// block of an m-mer: a bijective scramble of its 2m bits (odd multiplier mod 4^m), so no two m-mers share a block
-HAST_HD uint32_t filter_block_of(uint32_t mmer, int m) { return (mmer * 0x9E3779B1u) & (uint32_t)kmer_mask(m); }
+// block of an m-mer: a bijective scramble of its 2m bits, so no two m-mers share a block.  The first half of the m-mer is
+// folded into the second: the busiest blocks are those whose m-mer ENDS in one of the lowest-ordered t-mers, and the low
+// address bits (which pick channel and bank) must not be a function of those last bases alone.
+HAST_HD uint32_t filter_block_of(uint32_t mmer, int m) { return (mmer ^ (mmer >> m)) & (uint32_t)kmer_mask(m); }
 HAST_HD uint32_t filter_block_of_string(uint64_t fwd, const FilterGeom &g) {
     const uint32_t p = filter_sample_pos(fwd, g);
     return filter_block_of((uint32_t)(fwd >> (2 * (g.k - g.m - (int)p))) & (uint32_t)kmer_mask(g.m), g.m);
 }
-// hash of a K-mer string (one strand of a key): sub-bucket = top 3 bits, print = 16 bits from the middle, never 0 (0 = free slot)
+// hash of a K-mer string (one strand of a key): sub-buckets = top bits, print = 16 bits from the middle, never 0 (0 = free
+// slot).  One 32-bit multiply (a quarter-rate instruction on the device) over a fold of the K-mer's two halves; the xor-shift
+// behind it carries the well-mixed top bits down into the print.
 HAST_HD uint32_t filter_keyhash(uint64_t kmer) {
-    uint32_t h = (uint32_t)kmer * 0x85EBCA6Bu ^ (uint32_t)(kmer >> 32) * 0xC2B2AE35u;
-    h ^= h >> 15;
-    return h * 0x9E3779B1u;
+    const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+    uint32_t h = (lo ^ ((hi << 15) | (hi >> 17))) * 0x9E3779B1u;          // rotate: one v_alignbit
+    return h ^ (h >> 15);
 }
 HAST_HD uint32_t filter_sub_of(uint32_t keyhash) { return keyhash >> 29; }
 // Two-choice filing: a print may sit in either of two sub-buckets of its block (the less loaded one at build time; both

@@ -113,6 +113,9 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     const u16x2f r = __builtin_elementwise_min(__builtin_bit_cast(u16x2f, a), __builtin_bit_cast(u16x2f, b));
     return __builtin_bit_cast(uint32_t, r);
 }
+// wave-wide vote as an SGPR pair: the builtin is one s_and of the compare's result with exec (HIP's __ballot goes
+// through a v_cndmask + v_cmp pair)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {          // set bits of mask below my lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -235,7 +238,10 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
                     e[i] = i < nv ? tmer_order((uint32_t)(bits >> (2 * (3 - i))) & tmask, q0 + i) : 0xFFFFFFFFu;
                 const uint32_t s2 = min(e[2], e[3]), s1 = min(e[1], s2), s0 = min(e[0], s1);
                 const uint32_t p1 = min(e[0], e[1]), p2 = min(p1, e[2]);
-                const uint32_t n0 = (uint32_t)__shfl_down((int)e[0], 1), n1 = (uint32_t)__shfl_down((int)p1, 1), n2 = (uint32_t)__shfl_down((int)p2, 1);
+                // the next lane's values: wave_shl:1 in the VALU's own data path (a ds_bpermute would queue behind the LDS traffic)
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)e[0], 0x130, 0xF, 0xF, false);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)p1, 0x130, 0xF, 0xF, false);
+                const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)p2, 0x130, 0xF, 0xF, false);
                 if (lane < 63 && in)
                     *reinterpret_cast<u32x4f *>(s_l1 + (size_t)r * L1S + q0) = u32x4f{s0, min(s1, n0), min(s2, n1), min(e[3], n2)};
             }
@@ -265,8 +271,6 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
 
         // ---- B: probe ---------------------------------------------------------------------------------------------
         const uint32_t P = a.max_pos;                                 // windows per read (stride)
-        const uint32_t Q = tra * P;
-        const uint32_t nblk = (Q + 63) >> 6;
         uint32_t qn = 0;                                              // positives waiting in this wave's queue
         // V: the last `cnt` queue entries, one per lane, against the exact table
         auto drain = [&](uint32_t cnt) {
@@ -311,20 +315,34 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             u32x4f v, v2;                               // the 2 x 8 prints of this lane's window's two sub-buckets
             uint32_t klo, khi, fpw, meta;               // the window's K-mer, print in both halves, read | valid << 31
         };
-        auto start = [&](Blk &B, uint32_t blk) {
-            const uint32_t q = blk * 64 + lane;
-            uint32_t r = FAST ? __umulhi(q, a.div_magic) : (q / P);
-            const bool inq = q < Q;
-            r = inq ? r : 0;
-            const uint32_t p = inq ? q - r * P : 0;
-            bool ok = inq && (p + K <= s_len[r]);
+        // One probe instruction = the next 64 windows of this wave's range, one per lane, starting at `pos`.  Lanes without a
+        // window to probe (read shorter than the stride, read with 'N', range end) ask for the block of a lane that has one:
+        // same 128-B block, no request of their own -- they used to fetch a random block each (26.9 -> 26.0 requests per read
+        // on the bench's reads, where one read in 200 holds an 'N'; ragged reads gain more).
+        // Tried and dropped: cutting the instruction at the first lane of its last run, so that the run which straddles two
+        // instructions asks only once.  TCC_EA0_RDREQ stayed at 26.006 per read: the second request for a block already on
+        // its way never reaches the fabric, and the lanes a cut idles cost 4 % of the time (the kernel is bound by VALU issue
+        // as much as by requests).
+        uint32_t pos = 0, q_end = 0, last_fb = 0;                     // wave-uniform
+        uint32_t cr = 0, cp = 0;                                      // this lane's window in the next instruction: read, position
+        // (re)derive cr, cp from pos: once per range, and per instruction when reads have fewer than 64 windows
+        auto locate = [&]() {
+            const uint32_t q = pos + lane;
+            cr = FAST ? __umulhi(q, a.div_magic) : (q / P);
+            cp = q - cr * P;
+        };
+        auto start = [&](Blk &B) {
+            const bool inq = lane < q_end - pos;                      // pos <= q_end
+            const uint32_t r = min(cr, TR - 1), p = cp;
+            const uint32_t len = s_len[r];
+            bool ok = inq & (p + K <= len);
             if (STRICT) {           // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
-                const uint32_t *iw = s_inv + r * IW + (p >> 5);
+                const uint32_t *iw = s_inv + mul24(r, IW) + (p >> 5);
                 const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
-                ok = ok && (bits >> (64 - K)) == 0;
+                ok = ok & ((bits >> (64 - K)) == 0);
             }
-            const unsigned long long fwd = window_bits(s_pack + (size_t)r * WS, p, kshift);
-            const uint32_t *l1 = s_l1 + r * L1S + p;
+            const unsigned long long fwd = window_bits(s_pack + mul24(r, WS), p, kshift);
+            const uint32_t *l1 = s_l1 + mul24(r, L1S) + p;
             uint32_t x = l1[0];
             if (NTC) {
 #pragma unroll
@@ -333,18 +351,29 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
                 for (uint32_t c = 1; c + 1 < ntc; ++c) x = min(x, l1[c * G]);
             }
             if (ntc > 1) x = min(x, l1[NT - G]);
+            // lanes without a window compute on whatever LDS holds: in range by construction, and never used
             const uint32_t xr = ((x & 0xFFFu) - p) & 63u;             // position of the smallest t-mer inside the window
-            uint32_t pm = xr - ((xr * fg.wdiv) >> 16) * W;            // ... mod W = position of the sampled m-mer
-            pm = ok ? pm : 0;
+            const uint32_t pm = xr - mul24(mul24(xr, fg.wdiv) >> 16, W);      // ... mod W = position of the sampled m-mer
             const uint32_t mm = (uint32_t)(fwd >> (2 * ((uint32_t)(K - M) - pm))) & mmask;
-            const uint32_t fb = filter_block_of(mm, M);
+            uint32_t fb = ok ? filter_block_of(mm, M) : 0xFFFFFFFFu;  // real blocks are < 4^14
             const uint32_t h = filter_keyhash(fwd);                   // of the window as it stands: no canonical form in the probe
-            B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
+            const unsigned long long okm = ballot64(ok);
+            const uint32_t anchor = okm ? (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)__builtin_ctzll(okm)) : last_fb;
+            last_fb = anchor;
+            fb = ok ? fb : anchor;
+            B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];          // (any sub-bucket will do for a lane without a window)
             B.v2 = filt[(size_t)fb * kFilterSubs + filter_sub2_of(h)];
             B.klo = (uint32_t)fwd;
             B.khi = (uint32_t)(fwd >> 32);
-            B.fpw = filter_print_of(h) * 0x00010001u;
+            { const uint32_t fp = filter_print_of(h); B.fpw = fp | (fp << 16); }
             B.meta = r | (ok ? 0x80000000u : 0u);
+            pos = pos + 64 < q_end ? pos + 64 : q_end;
+            if (P >= 64) {                                            // the lane's next window: 64 <= P, one wrap at most
+                cp += 64;
+                const bool wrap = cp >= P;
+                cp -= wrap ? P : 0u;
+                cr += wrap ? 1u : 0u;
+            } else locate();
         };
         auto finish = [&](Blk &B) {
             const uint32_t a1 = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
@@ -353,7 +382,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             const bool match = ((acc - 0x00010001u) & ~acc & 0x80008000u) != 0;      // some halfword of acc is zero
             const bool full = (B.v.w >> 16) != 0 && (B.v2.w >> 16) != 0;             // a key finds no room only when BOTH are full
             const bool pos = (int)B.meta < 0 && (match || full);
-            const unsigned long long pmask = __ballot(pos);
+            const unsigned long long pmask = ballot64(pos);
             if (pmask) {
                 const uint32_t at = qn + lanes_below(pmask);
                 if (pos) {
@@ -366,30 +395,26 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             }
         };
         {
-            // Software pipeline, two blocks deep.  Every start() sits in straight-line code (no branch around it), so the
-            // compiler can count the loads in flight and wait for block i with vmcnt(1) while block i+1's load is still
-            // out; a start() under an `if` makes it fall back to vmcnt(0), i.e. no overlap at all.
-            // a wave takes a CONTIGUOUS quarter of the tile's blocks: the run of windows that straddles two blocks then asks
-            // for its 128-B block twice from the same wave in back-to-back instructions (an L1 hit, not a second request)
-            const uint32_t per = (nblk + 3) >> 2, first = wave * per;
-            const uint32_t n_my = first < nblk ? (nblk - first < per ? nblk - first : per) : 0;
-            if (n_my) {
+            // Software pipeline, two instructions deep.  Every start() sits in straight-line code (no branch around it), so
+            // the compiler can count the loads in flight and wait for instruction i with vmcnt(2) while i+1's loads are
+            // still out; a start() under an `if` makes it fall back to vmcnt(0), i.e. no overlap at all.  Hence the loop
+            // may issue one start() past the end of the range: all its lanes re-ask for the last block (an L1/L2 hit).
+            // A wave takes a contiguous quarter of the tile's READS: range borders are read borders, where runs end anyway.
+            const uint32_t rpw = (tra + 3) >> 2;
+            const uint32_t r_first = wave * rpw < tra ? wave * rpw : tra, r_last = r_first + rpw < tra ? r_first + rpw : tra;
+            pos = r_first * P;
+            q_end = r_last * P;
+            locate();
+            if (pos < q_end) {
                 Blk A, B;
-                uint32_t blk = first;
-                start(A, blk);
-                uint32_t i = 1;
-                for (; i + 1 < n_my; i += 2) {
-                    start(B, blk + 1);
+                start(A);
+                while (pos < q_end) {
+                    start(B);
                     finish(A);
-                    blk += 2;
-                    start(A, blk);
+                    start(A);
                     finish(B);
                 }
-                if (i < n_my) {
-                    start(B, blk + 1);
-                    finish(A);
-                    finish(B);
-                } else finish(A);
+                finish(A);
             }
             while (qn) drain(qn < 64 ? qn : 64);
         }

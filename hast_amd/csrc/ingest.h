@@ -33,67 +33,10 @@
 #include "../../include/hast.h"
 #include "bgzf_reader.h"
 #include "fast_inflate.h"
+#include "par_inflate.h"
+#include "worker_pool.h"
 
 namespace hast {
-
-// ------------------------------------------------------------------------------------------------
-// minimal fork-join pool: run(fn) executes fn(worker_index) on every worker and waits
-// ------------------------------------------------------------------------------------------------
-class WorkerPool {
-  public:
-    explicit WorkerPool(int n) : n_(n < 1 ? 1 : n) {
-        for (int i = 1; i < n_; ++i) threads_.emplace_back([this, i] { loop(i); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-            ++gen_;
-        }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
-    }
-    int size() const { return n_; }
-    void run(const std::function<void(int)> &fn) {
-        if (n_ == 1) { fn(0); return; }
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            fn_ = &fn;
-            pending_ = n_ - 1;
-            ++gen_;
-        }
-        cv_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return pending_ == 0; });
-    }
-
-  private:
-    void loop(int idx) {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(int)> *fn;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-                fn = fn_;
-            }
-            (*fn)(idx);
-            std::lock_guard<std::mutex> g(mu_);
-            if (--pending_ == 0) done_.notify_one();
-        }
-    }
-    int n_;
-    std::vector<std::thread> threads_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)> *fn_ = nullptr;
-    uint64_t gen_ = 0;
-    int pending_ = 0;
-    bool stop_ = false;
-};
 
 // ------------------------------------------------------------------------------------------------
 // barcode dictionary: BarcodeCache keys (classify.cpp:51) -> dense ids, concurrent
@@ -204,9 +147,15 @@ class BarcodeDict {
 
 // ------------------------------------------------------------------------------------------------
 // block source: raw or gz bytes in large blocks, produced by a background reader thread.  gz files go through the
-// in-tree decoder (fast_inflate.h: about twice zlib's speed on FASTQ, members CRC-checked); HAST_INFLATE=zlib in the
-// environment switches back to zlib's gzread.  Blocked gzip (BGZF) is recognised by its first member and inflated by several
-// threads at once (bgzf_reader.h; HAST_BGZF_THREADS).  A damaged gz file ends the stream early and sets error().
+// in-tree decoders; HAST_INFLATE=zlib in the environment switches back to zlib's gzread:
+//   * an ordinary gzip file (one long deflate stream: what `gzip` writes) is inflated by SEVERAL threads at once
+//     (par_inflate.h: block boundaries searched, chunks decoded with an unknown window, windows resolved in order, every
+//     member CRC-checked; HAST_GZ_THREADS, 1 = off);
+//   * blocked gzip (BGZF) is recognised by its first member and inflated member by member, side by side
+//     (bgzf_reader.h; HAST_BGZF_THREADS);
+//   * anything else (a pipe, a ".gz" that is not gzip) goes through the serial decoder (fast_inflate.h: about twice zlib's
+//     speed on FASTQ, members CRC-checked).
+// A damaged gz file ends the stream early and sets error().
 // ------------------------------------------------------------------------------------------------
 class BlockSource {
   public:
@@ -233,6 +182,10 @@ class BlockSource {
                 const unsigned hw = std::thread::hardware_concurrency();
                 const char *e = getenv("HAST_BGZF_THREADS");
                 bgzf_reader_.open(fp_, e ? atoi(e) : (int)std::min(16u, std::max(2u, hw / 8)));
+            } else if (gz_threads() > 1 && ParGzReader::usable(fp_)) {
+                // an ordinary gzip stream in a regular file: several threads at once (par_inflate.h)
+                pargz_ = true;
+                par_reader_.open(fp_, gz_threads());
             } else inflater_.open(fp_, 4u << 20);
         } else if (path == "-") {
             fp_ = stdin;
@@ -254,6 +207,8 @@ class BlockSource {
         }
         cv_.notify_all();
         if (reader_.joinable()) reader_.join();
+        if (pargz_) par_reader_.close();
+        pargz_ = false;
         if (gz_) gzclose(gz_);
         if (fp_ && fp_ != stdin) fclose(fp_);
         gz_ = nullptr;
@@ -314,6 +269,9 @@ class BlockSource {
                     }
                 }
                 if (r == -1) trouble = bgzf_reader_.error();
+            } else if (gz_mode_ && pargz_) {
+                r = par_reader_.read(reinterpret_cast<uint8_t *>(dst + got), want - got);
+                if (r < 0) trouble = par_reader_.error();
             } else if (gz_mode_) {
                 r = inflater_.read(reinterpret_cast<uint8_t *>(dst + got), want - got);
                 if (r < 0) trouble = inflater_.error();
@@ -386,12 +344,21 @@ class BlockSource {
         plain_off_ += (off_t)total;
         return (long)total;
     }
+    // threads that inflate ONE ordinary .gz file (HAST_GZ_THREADS; 1 = the serial decoder).  Default: an eighth of the
+    // machine, at most 8 -- several files are open at once, and on the 1-GPU share of an MI355X host two files x 8 threads
+    // was the fastest setting (one file alone: 9.3 GB/s with 16 threads, 6.7 with 8, 1.4 serial; profiles/r02p_gz_e2e.log)
+    static int gz_threads() {
+        if (const char *e = getenv("HAST_GZ_THREADS")) return std::max(1, atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::min(8u, std::max(2u, hw / 8));
+    }
     static constexpr int kMaxReaders = 32;
     int readers_ = 4;
     std::unique_ptr<WorkerPool> pread_pool_;
     off_t plain_off_ = -1;
-    bool gz_mode_ = false, use_zlib_ = false, bgzf_ = false;
+    bool gz_mode_ = false, use_zlib_ = false, bgzf_ = false, pargz_ = false;
     BgzfReader bgzf_reader_;
+    ParGzReader par_reader_;
     gzFile gz_ = nullptr;
     GzInflater inflater_;
     std::string error_;

@@ -11,9 +11,11 @@
 
 #include "../../hast_amd/csrc/bgzf_reader.h"
 #include "../../hast_amd/csrc/fast_inflate.h"
+#include "../../hast_amd/csrc/par_inflate.h"
 
 int main(int argc, char **argv) {
-    bool use_zlib = false, quiet = false, bgzf = false;
+    bool use_zlib = false, quiet = false, bgzf = false, par = false;
+    size_t chunk = 1u << 20;
     int threads = 4;
     size_t piece = 1 << 20, inbuf = 1 << 20;
     const char *path = nullptr;
@@ -21,6 +23,8 @@ int main(int argc, char **argv) {
         if (!strcmp(argv[i], "-z")) use_zlib = true;
         else if (!strcmp(argv[i], "-q")) quiet = true;
         else if (!strcmp(argv[i], "-b")) bgzf = true;                 // BgzfReader (+ hand-over to the serial decoder), as BlockSource does
+        else if (!strcmp(argv[i], "-P")) par = true;                  // ParGzReader (several threads on one ordinary gzip stream)
+        else if (!strcmp(argv[i], "-c")) chunk = (size_t)atol(argv[++i]);   // ... with this many compressed bytes per chunk
         else if (!strcmp(argv[i], "-t")) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-p")) piece = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-i")) inbuf = (size_t)atol(argv[++i]);
@@ -45,6 +49,22 @@ int main(int argc, char **argv) {
         if (!f) return 2;
         hast::GzInflater z;
         long n;
+        if (par) {
+            if (!hast::ParGzReader::usable(f)) return 4;
+            hast::ParGzReader pz;
+            pz.open(f, threads, chunk);
+            while ((n = pz.read(buf.data(), piece)) > 0) {
+                if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
+                total += (size_t)n;
+            }
+            if (n < 0) {
+                fprintf(stderr, "%s\n", pz.error().c_str());
+                return 3;
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "%zu bytes in %.3f s = %.1f MB/s\n", total, dt, total / dt / 1e6);
+            return 0;
+        }
         if (bgzf) {
             if (!hast::BgzfReader::probe(f)) return 4;
             hast::BgzfReader b;

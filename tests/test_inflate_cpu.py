@@ -210,3 +210,104 @@ def test_damaged_input_is_an_error(driver, tmp_path):
         else:
             flipped += 1
     assert flipped > 30
+
+
+# ---- several threads on ONE ordinary gzip stream (hast_amd/csrc/par_inflate.h) --------------------------------------------
+# chunk sizes far below a deflate block's size force every path: chunks in which no block starts, chunks that starve,
+# boundaries in front of stored / fixed blocks (the search only knows dynamic ones), members that end inside a chunk.
+PAR_SHAPES = ((1 << 20, 4, 1 << 20), (40_000, 3, 100_000), (5_000, 8, 65_536), (700, 2, 1 << 20), (64, 5, 7777), (3_000, 1, 1))
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n not in ("no_input", "not_gzip")))
+def test_parallel_inflate_same_bytes_as_zlib(driver, tmp_path, name):
+    p = tmp_path / (name + ".gz")
+    p.write_bytes(CASES[name])
+    want = subprocess.run([driver, "-z", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0
+    for chunk, threads, piece in PAR_SHAPES:
+        if piece < 100 and len(want.stdout) > 400_000:
+            continue
+        got = subprocess.run([driver, "-P", "-c", str(chunk), "-t", str(threads), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, (name, chunk, threads, piece, got.stderr[-300:])
+        assert got.stdout == want.stdout, (name, chunk, threads, piece)
+
+
+def test_parallel_inflate_leaves_other_inputs_to_the_serial_decoder(driver, tmp_path):
+    for name in ("no_input", "not_gzip"):
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(CASES[name])
+        assert subprocess.run([driver, "-P", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 4
+
+
+def test_parallel_inflate_random_streams_with_flush_points(driver, tmp_path):
+    rng = random.Random(12)
+    for it in range(10):
+        data, blob = b"", b""
+        for _ in range(rng.randint(1, 5)):
+            c = zlib.compressobj(rng.choice([1, 4, 6, 9]), zlib.DEFLATED, 31, 9, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED]))
+            for _ in range(rng.randint(1, 30)):
+                kind = rng.random()
+                d = (bytes(rng.choice(b"ACGTN\n") for _ in range(rng.randint(0, 30000))) if kind < 0.6 else
+                     bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 5000))) if kind < 0.8 else b"A" * rng.randint(0, 700000))
+                data += d
+                blob += c.compress(d)
+                if rng.random() < 0.3:
+                    blob += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            blob += c.flush()
+        p = tmp_path / ("r%d.gz" % it)
+        p.write_bytes(blob)
+        for _ in range(3):
+            chunk, threads, piece = rng.choice([64, 300, 2000, 20000, 1 << 20]), rng.randint(1, 6), rng.choice([1 << 20, 5000, 97])
+            r = subprocess.run([driver, "-P", "-c", str(chunk), "-t", str(threads), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == data, (it, chunk, threads, piece, r.stderr[-300:])
+
+
+def test_parallel_inflate_big_fastq_every_level(driver, tmp_path):
+    rng = random.Random(13)
+    data = fastq(rng, 60_000)
+    for level in (1, 6, 9):
+        p = tmp_path / ("big%d.gz" % level)
+        p.write_bytes(member(data[:7_000_000], level) + member(data[7_000_000:], level))
+        for chunk, threads in ((1 << 20, 4), (100_000, 7), (30_000, 3)):
+            r = subprocess.run([driver, "-P", "-c", str(chunk), "-t", str(threads), "-p", str(1 << 24), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == data, (level, chunk, threads, r.stderr[-300:])
+
+
+def test_parallel_inflate_damaged_input_is_an_error(driver, tmp_path):
+    good = member(FQ[:400_000]) + member(FQ[400_000:700_000], 1)
+    rng = random.Random(4)
+    for cut in (5, 11, 100, len(good) // 3, len(good) // 2, len(good) - 9, len(good) - 1):
+        p = tmp_path / ("cut%d.gz" % cut)
+        p.write_bytes(good[:cut])
+        for chunk in (1 << 20, 9_000):
+            r = subprocess.run([driver, "-q", "-P", "-c", str(chunk), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 3, (cut, chunk, r.stderr)
+    flipped = 0
+    for _ in range(60):
+        b = bytearray(good)
+        i = rng.randrange(12, len(b))
+        b[i] ^= 1 << rng.randrange(8)
+        p = tmp_path / "flip.gz"
+        p.write_bytes(bytes(b))
+        r = subprocess.run([driver, "-P", "-c", str(rng.choice([1 << 20, 20_000, 3_000])), "-t", "3", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode in (0, 3)
+        assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr
+        if r.returncode == 0:                      # a flip can only go unnoticed if it did not change the data (header bytes)
+            assert r.stdout == FQ[:700_000]
+        else:
+            flipped += 1
+    assert flipped > 45
+
+
+def test_parallel_inflate_has_no_data_races(tmp_path):
+    """the same decoder under ThreadSanitizer: the producer thread, its decode pool, the caller's resolve pool"""
+    exe = tmp_path / "test_inflate_tsan"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-o", str(exe), os.path.join(ROOT, "tests", "native", "test_inflate.cpp"),
+                    "-lz", "-pthread"], check=True)
+    p = tmp_path / "m.gz"
+    p.write_bytes(CASES["members"] + CASES["fastq_l1"])
+    want = subprocess.run([str(exe), "-z", str(p)], stdout=subprocess.PIPE).stdout
+    for chunk, threads, piece in ((3000, 6, 65536), (100_000, 3, 1 << 20), (1 << 20, 4, 9999)):
+        r = subprocess.run([str(exe), "-P", "-c", str(chunk), "-t", str(threads), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == want
+        assert b"ThreadSanitizer" not in r.stderr, r.stderr[-2000:]

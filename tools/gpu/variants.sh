@@ -5,7 +5,7 @@ mkdir -p /tmp/variants gpurun_out
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( cd hast_amd/csrc && for f in hast_kernels hast_filter; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $f.hip -o /tmp/variants/${f}_$name.o; done;
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o /tmp/variants/libhast_$name.so /tmp/variants/hast_kernels_$name.o /tmp/variants/hast_filter_$name.o hast_api.o kc_kernels.o kc_api.o -ldl ) 2>&1 | grep -E "error" | head -3
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o /tmp/variants/libhast_$name.so /tmp/variants/hast_kernels_$name.o /tmp/variants/hast_filter_$name.o hast_api.o fq_kernels.o fq_api.o kc_kernels.o kc_api.o -ldl ) 2>&1 | grep -E "error" | head -3
 done
 for spec in "base:" "$@"; do
   name=${spec%%:*}
