@@ -246,7 +246,8 @@ class Context:
         return self._lib.hast_ctx_minimizer(self._h)
 
     def set_filter(self, enable=True, m=0, t=0, kp=0):
-        _ck(self._lib.hast_ctx_set_filter(self._h, 1 if enable else 0, m, t, kp))
+        """enable: False/0 = probe the table directly, True/1 = filter (exact entries where they fit), 2 = filter with prints always"""
+        _ck(self._lib.hast_ctx_set_filter(self._h, int(enable), m, t, kp))
 
     def filter_build(self):
         _ck(self._lib.hast_filter_build(self._h))
@@ -256,6 +257,12 @@ class Context:
         en, m, t, kp, b = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
         _ck(self._lib.hast_filter_info(self._h, C.byref(en), C.byref(m), C.byref(t), C.byref(kp), C.byref(b)))
         return bool(en.value), m.value, t.value, kp.value, b.value
+
+    def filter_mode(self):
+        """0 = off, 1 = 16-bit prints, 2 = exact entries (hast_common.h); known once the filter has been built"""
+        en = C.c_int()
+        _ck(self._lib.hast_filter_info(self._h, C.byref(en), None, None, None, None))
+        return en.value
 
     def close(self):
         if self._h:

@@ -87,6 +87,8 @@ struct hast_ctx {
     bool filter_valid = false;
     bool use_filter = true;                 // HAST_CLASSIFY=exact: probe the exact table directly (the round-1 kernel)
     int filter_m = 0, filter_t = 0, filter_kp = 0;   // overrides (0 = by K and key count)
+    int filter_exact = -1;                           // -1: exact entries where they fit (hast_common.h), 0: prints always
+    bool exact_env_off = false;                      // HAST_FILTER_EXACT=0 in the environment
 };
 
 namespace {
@@ -192,6 +194,8 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     if (const char *e = getenv("HAST_FILTER_M")) c->filter_m = atoi(e);
     if (const char *e = getenv("HAST_FILTER_T")) c->filter_t = atoi(e);
     if (const char *e = getenv("HAST_FILTER_KP")) c->filter_kp = atoi(e);
+    if (const char *e = getenv("HAST_FILTER_EXACT")) c->exact_env_off = atoi(e) == 0;
+    if (c->exact_env_off) c->filter_exact = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     hast_status st = HAST_OK;
@@ -383,6 +387,7 @@ hast_status hast_table_erase(hast_ctx *c, const uint64_t *keys, size_t n, uint8_
     // key listed twice reports its tags once (the second atomicAnd sees them already cleared) --
     // the same as the reference's find-then-erase loop (classify.cpp:318-337).
     HIP_TRY(launch_erase_keys(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, n, d_hit, c->stream));
+    table_changed(c);          // exact filter entries answer hits on their own: an erased key must leave the filter too
     std::vector<uint8_t> hit(n);
     HIP_TRY(hipMemcpyAsync(hit.data(), d_hit, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -543,6 +548,7 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
         HIP_TRY(hipMemcpyPeer(dst->d_filter, dst->device, src->d_filter, src->device, src->filter_bytes));
         dst->fg = src->fg;
         dst->filter_m = src->filter_m;
+        dst->filter_exact = src->filter_exact;
         dst->filter_t = src->filter_t;
         dst->filter_kp = src->filter_kp;
         dst->filter_valid = true;
@@ -687,7 +693,7 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
     HIP_TRY(launch_count_tags(c->d_slots, geom(c), c->d_cnt, hs));
     HIP_TRY(hipMemcpyAsync(h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, hs));
     HIP_TRY(hipStreamSynchronize(hs));
-    const FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t, c->filter_kp);
+    const FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t, c->filter_kp, c->k == 32 ? 0 : c->filter_exact);
     const size_t bytes = (size_t)filter_nblocks(fg) * 128;
     if (bytes != c->filter_bytes) {
         if (c->d_filter) HIP_TRY(hipFree(c->d_filter));
@@ -831,6 +837,7 @@ hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t, int kp) {
     if (t < 0 || (m && t > m)) return fail(HAST_ERR_INVALID, "filter t=%d out of [0,m]", t);
     if (kp < 0 || kp > c->k || (kp && m && (kp < m || kp - m >= 32))) return fail(HAST_ERR_INVALID, "filter kp=%d out of [m,K]", kp);
     c->use_filter = enable != 0;
+    c->filter_exact = (enable == 2 || c->exact_env_off) ? 0 : -1;
     c->filter_m = m;
     c->filter_t = t;
     c->filter_kp = kp;
@@ -848,7 +855,7 @@ hast_status hast_filter_build(hast_ctx *c) {
 
 hast_status hast_filter_info(const hast_ctx *c, int *enabled, int *m, int *t, int *kp, uint64_t *bytes) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
-    if (enabled) *enabled = c->use_filter ? 1 : 0;
+    if (enabled) *enabled = !c->use_filter ? 0 : (c->filter_valid && c->fg.exact) ? 2 : 1;
     if (m) *m = c->filter_valid ? c->fg.m : 0;
     if (t) *t = c->filter_valid ? c->fg.t : 0;
     if (kp) *kp = c->filter_valid ? c->fg.kp : 0;

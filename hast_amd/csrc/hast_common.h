@@ -134,6 +134,7 @@ struct FilterGeom {
     int kp;                 // the sampling only looks at the first kp bases of a window (kp <= k): W = kp-m+1 candidates
     int g;                  // entries per first-level minimum of the kernel's sliding window: min(4, kp-t+1)
     uint32_t wdiv;          // floor(2^16 / W) + 1: x / W for x < 64 by multiply-shift
+    int exact;              // 1: the 16-bit entries are EXACT codes of the filed strings (below), one sub-bucket per string
 };
 constexpr int kFilterSubs = 8;                    // 16-B sub-buckets per 128-B block
 constexpr int kFilterPrints = 8;                  // 16-bit prints per sub-bucket
@@ -192,6 +193,31 @@ HAST_HD uint32_t filter_print_of(uint32_t keyhash) {
     const uint32_t f = (keyhash >> 8) & 0xFFFFu;
     return f ? f : 1u;
 }
+// ---- exact entries (FilterGeom::exact) -----------------------------------------------------------------------------------
+// A block is named by a BIJECTION of the sampled m-mer, so a filed string is known completely by its block, the position
+// pm of the m-mer inside it and the K-m bases outside the m-mer: 2(K-m) + log2(W) bits.  When those fit 17 bits (K = 21 with
+// m = 14, W = 8: 14 + 3) a 16-bit entry can hold them EXACTLY instead of a 16-bit print: the code goes through a bijection of
+// its 17 bits, whose top 3 bits pick THE sub-bucket (one choice: the sub-bucket is part of the code) and whose low 14 bits
+// are stored above the key's 2 tag bits.  An entry that matches a window then IS the window's string with its tags: a hit
+// needs no look-up in the exact table (with prints every hit costs a second HBM request -- 1.3 per read on random keys, 11 per
+// read on keys with real-data structure), and a window whose sub-bucket holds no match and is not full is a proven miss.
+// Only a window that lands in a FULL sub-bucket without a match still asks the table (a key may have found no room).
+HAST_HD int filter_pos_bits(const FilterGeom &g) {
+    int b = 0;
+    while ((1u << b) < filter_w(g)) ++b;
+    return b;
+}
+HAST_HD bool filter_exact_fits(const FilterGeom &g) { return g.k <= 32 && 2 * (g.k - g.m) + filter_pos_bits(g) <= 17; }
+// the 17-bit code of a string whose sampled m-mer sits at pm: (pm, the bases behind the m-mer, the bases in front of it), scrambled
+HAST_HD uint32_t filter_exact_code(uint64_t fwd, uint32_t pm, const FilterGeom &g) {
+    const int rb = 2 * (g.k - g.m);
+    // rotate the m-mer out: only the low rb bits of either term matter (fwd >> 2(K-pm) = the pm bases in front of the m-mer)
+    const uint32_t rest = ((uint32_t)fwd << (2 * pm)) | (uint32_t)(fwd >> (2 * ((uint32_t)g.k - pm)));
+    const uint32_t code = (rest & ((1u << rb) - 1u)) | (pm << rb);
+    return mul24(code, 0x1D2C5u) & 0x1FFFFu;                          // odd multiplier: a bijection of the 17 bits
+}
+HAST_HD uint32_t filter_exact_sub(uint32_t code17) { return code17 >> 14; }
+HAST_HD uint32_t filter_exact_entry(uint32_t code17, uint32_t tags) { return ((code17 & 0x3FFFu) << 2) | tags; }   // tags 1..3: never 0
 // Geometry for K and a key count.  Measured with tools/sim/filter_load_sim.cpp (unscaled: 400M keys, both strands filed):
 // what limits m from below is not the average load of a block but the skew of the sampling -- the sampled m-mers all hold
 // one of the window's lowest-ordered t-mers, so a fraction of the blocks takes most of the keys.  4^m >= 0.67 N keeps the
@@ -200,11 +226,14 @@ HAST_HD uint32_t filter_print_of(uint32_t keyhash) {
 //     N = 100M: m = 13, kp = 21 -> W = 9, t = 4: 23.4 + 0.9
 // kp = min(K, m + 8): longer windows (K = 31) are sampled on their first kp bases only -- more candidates would lower the
 // density further but pile the keys on even fewer blocks.
-HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t_override, int kp_override = 0) {
+// exact_mode: -1 = exact entries where they fit (and, for tables of 16M keys and more, the m that makes them fit: m = K-7,
+// i.e. 14 at K = 21 -- a 34-GB filter next to 288 GB of HBM), 0 = prints always.
+HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t_override, int kp_override = 0, int exact_mode = -1) {
     FilterGeom g;
     g.k = k;
     int m = k < 8 ? k : 8;
     while (m < k && m < kFilterMaxM && (1ull << (2 * m)) * 3 < 2 * n_keys) ++m;
+    if (exact_mode && n_keys >= (16ull << 20) && k - 7 > m && k - 7 <= kFilterMaxM) m = k - 7;
     if (m_override >= 1 && m_override <= k && m_override <= kFilterMaxM) m = m_override;
     g.m = m;
     int kp = k < m + 8 ? k : m + 8;
@@ -217,6 +246,8 @@ HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t
     const int nt = kp - t + 1;
     g.g = nt < 4 ? nt : 4;
     g.wdiv = (65536u / (uint32_t)w) + 1u;
+    g.exact = 0;
+    g.exact = (exact_mode && filter_exact_fits(g)) ? 1 : 0;
     return g;
 }
 

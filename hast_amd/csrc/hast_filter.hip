@@ -39,10 +39,19 @@ __device__ __forceinline__ bool sub_insert(uint32_t *w, uint32_t fp) {
     }
     return false;
 }
-__device__ __forceinline__ void filter_insert(uint32_t *filt, const FilterGeom g, uint64_t key) {
+__device__ __forceinline__ void filter_insert(uint32_t *filt, const FilterGeom g, uint64_t key, uint32_t tags) {
     for (int o = 0; o < 2; ++o) {
         const uint64_t s = o ? kmer_revcomp(key, g.k) : key;
         if (o && s == key) break;                                    // its own reverse complement
+        if (g.exact) {
+            // exact entry (hast_common.h): the string's code picks the one sub-bucket it can sit in and is stored with the tags
+            const uint32_t pm = filter_sample_pos(s, g);
+            const uint32_t blk = filter_block_of((uint32_t)(s >> (2 * (g.k - g.m - (int)pm))) & (uint32_t)kmer_mask(g.m), g.m);
+            const uint32_t c17 = filter_exact_code(s, pm, g);
+            uint32_t *w = filt + (size_t)blk * (kFilterSubs * kFilterPrints / 2) + filter_exact_sub(c17) * (kFilterPrints / 2);
+            (void)sub_insert(w, filter_exact_entry(c17, tags));      // full: not filed; windows that land there ask the table
+            continue;
+        }
         // block, sub-buckets and print all come from the string AS A READ WOULD SHOW IT: the probe never canonicalises
         const uint32_t blk = filter_block_of_string(s, g);
         const uint32_t h = filter_keyhash(s), fp = filter_print_of(h);
@@ -64,8 +73,8 @@ __global__ void __launch_bounds__(256) k_filter_build(const uint64_t *slots, siz
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nslots; i += (size_t)gridDim.x * blockDim.x) {
         const uint64_t s = slots[i];
         if (wide) {
-            if (s < kTombSlot) filter_insert(filt, g, s);
-        } else if (s != kEmptySlot && (s & 3)) filter_insert(filt, g, s >> 2);
+            if (s < kTombSlot) filter_insert(filt, g, s, 0);         // (wide keys carry no tags and are never filed exactly)
+        } else if (s != kEmptySlot && (s & 3)) filter_insert(filt, g, s >> 2, (uint32_t)(s & 3));
     }
 }
 
@@ -116,12 +125,17 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
 // wave-wide vote as an SGPR pair: the builtin is one s_and of the compare's result with exec (HIP's __ballot goes
 // through a v_cndmask + v_cmp pair)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    const u16x2f r = __builtin_elementwise_max(__builtin_bit_cast(u16x2f, a), __builtin_bit_cast(u16x2f, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {          // set bits of mask below my lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 // NTC = first-level minima per window, ceil((K-t+1)/g), when known at compile time (0 = runtime loop)
-template <int NTC, bool FAST, bool STRICT, bool WIDE>
+// EXACT: the filter holds exact entries (hast_common.h): one 16-B load per window, a match IS a hit with its tag bits
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT>
 __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
@@ -356,16 +370,24 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             const uint32_t pm = xr - mul24(mul24(xr, fg.wdiv) >> 16, W);      // ... mod W = position of the sampled m-mer
             const uint32_t mm = (uint32_t)(fwd >> (2 * ((uint32_t)(K - M) - pm))) & mmask;
             uint32_t fb = ok ? filter_block_of(mm, M) : 0xFFFFFFFFu;  // real blocks are < 4^14
-            const uint32_t h = filter_keyhash(fwd);                   // of the window as it stands: no canonical form in the probe
+            // of the window as it stands (no canonical form in the probe): a hash for two sub-buckets and a print, or the
+            // window's exact code, whose top bits are its one sub-bucket
+            const uint32_t h = EXACT ? filter_exact_code(fwd, pm, fg) : filter_keyhash(fwd);
             const unsigned long long okm = ballot64(ok);
             const uint32_t anchor = okm ? (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)__builtin_ctzll(okm)) : last_fb;
             last_fb = anchor;
             fb = ok ? fb : anchor;
-            B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];          // (any sub-bucket will do for a lane without a window)
-            B.v2 = filt[(size_t)fb * kFilterSubs + filter_sub2_of(h)];
+            if (EXACT) {
+                B.v = filt[(size_t)fb * kFilterSubs + filter_exact_sub(h)];   // (any sub-bucket will do for a lane without a window)
+                B.fpw = mul24((h & 0x3FFFu) ^ 0x3FFFu, 0x00040004u);          // the complement of the stored bits, in both halves
+            } else {
+                B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
+                B.v2 = filt[(size_t)fb * kFilterSubs + filter_sub2_of(h)];
+                const uint32_t fp = filter_print_of(h);
+                B.fpw = fp | (fp << 16);
+            }
             B.klo = (uint32_t)fwd;
             B.khi = (uint32_t)(fwd >> 32);
-            { const uint32_t fp = filter_print_of(h); B.fpw = fp | (fp << 16); }
             B.meta = r | (ok ? 0x80000000u : 0u);
             pos = pos + 64 < q_end ? pos + 64 : q_end;
             if (P >= 64) {                                            // the lane's next window: 64 <= P, one wrap at most
@@ -376,12 +398,25 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             } else locate();
         };
         auto finish = [&](Blk &B) {
+            bool pos;
+            if (EXACT) {
+                // entry ^ complement(stored bits): the 14 code bits of a matching entry come out all ones, its tags (1..3) below
+                // them -- the largest halfword of the sub-bucket is >= 0xFFFD iff the window's string is filed here (an empty
+                // slot gives at most 0xFFFC)
+                const uint32_t mx = pk_max_u16(pk_max_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_max_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
+                const uint32_t m16 = max(mx >> 16, mx & 0xFFFFu);
+                const bool valid = (int)B.meta < 0;
+                const bool hit = valid && m16 >= 0xFFFDu;
+                if (hit) atomicAdd(&s_vote[B.meta & 0xFFFFu], (unsigned long long)(m16 & 1u) | ((unsigned long long)((m16 >> 1) & 1u) << 32));
+                pos = valid && !hit && (B.v.w >> 16) != 0;               // no match in a FULL sub-bucket: the key may not have found room
+            } else {
             const uint32_t a1 = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
             const uint32_t a2 = pk_min_u16(pk_min_u16(B.v2.x ^ B.fpw, B.v2.y ^ B.fpw), pk_min_u16(B.v2.z ^ B.fpw, B.v2.w ^ B.fpw));
             const uint32_t acc = pk_min_u16(a1, a2);
             const bool match = ((acc - 0x00010001u) & ~acc & 0x80008000u) != 0;      // some halfword of acc is zero
             const bool full = (B.v.w >> 16) != 0 && (B.v2.w >> 16) != 0;             // a key finds no room only when BOTH are full
-            const bool pos = (int)B.meta < 0 && (match || full);
+            pos = (int)B.meta < 0 && (match || full);
+            }
             const unsigned long long pmask = ballot64(pos);
             if (pmask) {
                 const uint32_t at = qn + lanes_below(pmask);
@@ -438,36 +473,37 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     }
 }
 
-template <int NTC, bool FAST, bool STRICT, bool WIDE = false>
+template <int NTC, bool FAST, bool STRICT, bool WIDE = false, bool EXACT = false>
 static hipError_t launch_f_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE>), dim3(grid), dim3(kThreadsF), smem, s, a);
+    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT>), dim3(grid), dim3(kThreadsF), smem, s, a);
     return hipGetLastError();
 }
 
-template <bool STRICT>
+template <bool STRICT, bool EXACT>
 static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     const bool fast = a.div_magic && a.div_l1g && a.div_hw;
     if (a.wide) return fast ? launch_f_t<0, true, STRICT, true>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true>(a, grid, smem, s);
-    if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT>(a, grid, smem, s) : launch_f_t<0, false, STRICT>(a, grid, smem, s);
+    if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT>(a, grid, smem, s);
     switch ((filter_nt(a.fg) + 3) / 4) {
-    case 1: return launch_f_t<1, true, STRICT>(a, grid, smem, s);
-    case 2: return launch_f_t<2, true, STRICT>(a, grid, smem, s);
-    case 3: return launch_f_t<3, true, STRICT>(a, grid, smem, s);
-    case 4: return launch_f_t<4, true, STRICT>(a, grid, smem, s);
-    case 5: return launch_f_t<5, true, STRICT>(a, grid, smem, s);
-    case 6: return launch_f_t<6, true, STRICT>(a, grid, smem, s);
-    default: return launch_f_t<0, true, STRICT>(a, grid, smem, s);
+    case 1: return launch_f_t<1, true, STRICT, false, EXACT>(a, grid, smem, s);
+    case 2: return launch_f_t<2, true, STRICT, false, EXACT>(a, grid, smem, s);
+    case 3: return launch_f_t<3, true, STRICT, false, EXACT>(a, grid, smem, s);
+    case 4: return launch_f_t<4, true, STRICT, false, EXACT>(a, grid, smem, s);
+    case 5: return launch_f_t<5, true, STRICT, false, EXACT>(a, grid, smem, s);
+    case 6: return launch_f_t<6, true, STRICT, false, EXACT>(a, grid, smem, s);
+    default: return launch_f_t<0, true, STRICT, false, EXACT>(a, grid, smem, s);
     }
 }
 
 hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (a.n_reads == 0) return hipSuccess;
-    return a.strict ? launch_f_s<true>(a, grid, smem, s) : launch_f_s<false>(a, grid, smem, s);
+    if (a.fg.exact && !a.wide) return a.strict ? launch_f_s<true, true>(a, grid, smem, s) : launch_f_s<false, true>(a, grid, smem, s);
+    return a.strict ? launch_f_s<true, false>(a, grid, smem, s) : launch_f_s<false, false>(a, grid, smem, s);
 }
 
 }  // namespace hast

@@ -124,9 +124,13 @@ hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *byt
  * consecutive windows of a read ask for few blocks.  A window the filter cannot rule out is looked up in the table
  * above, which alone decides hits, so results never depend on the filter.  It is (re)built from the table's live keys
  * by the first classification after keys were added, or explicitly by hast_filter_build (e.g. outside a timed region).
+ * Where a filed string fits a 16-bit entry EXACTLY (its block is a bijection of the sampled m-mer, the entry holds the rest:
+ * 2(K-m) + log2(W) <= 17 bits, e.g. K = 21 with m = 14) the entries are exact codes + the key's tag bits instead of prints,
+ * and a match in the filter IS the hit: only windows that land in a full sub-bucket still ask the table.  Same results.
  * hast_ctx_set_filter: enable = 0 probes the table directly (the round-1 kernel; also HAST_CLASSIFY=exact in the
- * environment); m (sampled m-mer, 4^m blocks), t (ordering t-mer), kp (bases of a window the sampling looks at) = 0 picks
- * the geometry from K and the key count. */
+ * environment), 1 = filter, exact entries where they fit, 2 = filter with prints always (also HAST_FILTER_EXACT=0); m (sampled
+ * m-mer, 4^m blocks), t (ordering t-mer), kp (bases of a window the sampling looks at) = 0 picks the geometry from K and
+ * the key count.  hast_filter_info: *enabled = 0 off, 1 prints, 2 exact entries (known once the filter is built). */
 hast_status hast_ctx_set_filter(hast_ctx *, int enable, int m, int t, int kp);
 hast_status hast_filter_build(hast_ctx *);
 hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, int *kp, uint64_t *bytes);

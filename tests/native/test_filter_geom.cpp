@@ -5,7 +5,8 @@
 //      chunks at 0, g, 2g, ... and K-t+1-g) names the same m-mer as filter_sample_pos on the window's own string, for every
 //      window of random reads, over many (K, m, t);
 //   3. the block a read window asks for is one of the (at most two) blocks its canonical key was filed under;
-//   4. the geometry picked for the BASELINE sizes.
+//   4. exact entries (FilterGeom::exact): block + sub-bucket + the 14 stored bits give the filed string back, bit for bit;
+//   5. the geometry picked for the BASELINE sizes.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -23,7 +24,7 @@ int main() {
         for (uint32_t x = 0; x < 64; ++x)
             if (x - ((x * magic) >> 16) * w != x % w) { printf("mod: W=%u x=%u\n", w, x); return 1; }
     }
-    long windows = 0;
+    long windows = 0, exact_windows = 0;
     for (int it = 0; it < 400; ++it) {
         const int k = 1 + (int)(rnd() % 32);
         int m = 1 + (int)(rnd() % (uint64_t)(k < kFilterMaxM ? k : kFilterMaxM));
@@ -65,14 +66,35 @@ int main() {
             if (mine >= filter_nblocks(g)) { printf("range\n"); return 1; }
             const uint32_t h = filter_keyhash(key);
             if (filter_sub_of(h) >= (uint32_t)kFilterSubs || filter_print_of(h) == 0 || filter_print_of(h) > 0xFFFF) { printf("print\n"); return 1; }
+            if (g.exact) {
+                // the string from (block, code): the scramble of the m-mer is an involution, the code's multiplier has an inverse mod 2^17
+                static uint32_t inv = 0;
+                if (!inv) { inv = 1; for (int i = 0; i < 5; ++i) inv *= 2u - 0x1D2C5u * inv; inv &= 0x1FFFFu; }
+                const uint32_t c17 = filter_exact_code(fwd, pm, g);
+                const uint32_t entry = filter_exact_entry(c17, 1 + (uint32_t)(rnd() % 3));
+                if (c17 > 0x1FFFFu || filter_exact_sub(c17) >= (uint32_t)kFilterSubs || entry == 0 || entry > 0xFFFFu) { printf("exact: range\n"); return 1; }
+                const uint32_t back17 = (filter_exact_sub(c17) << 14) | (entry >> 2);
+                const uint32_t code = (back17 * inv) & 0x1FFFFu;
+                const int rb = 2 * (k - g.m);
+                const uint32_t pm2 = code >> rb, rest = code & ((1u << rb) - 1u);
+                const uint64_t mm = (uint64_t)(mine ^ (mine >> g.m)) & kmer_mask(g.m);
+                const uint64_t prefix = rest & ((1ull << (2 * pm2)) - 1), suffix = rest >> (2 * pm2);
+                const uint64_t again = (pm2 ? prefix << (2 * (k - (int)pm2)) : 0) | (mm << (2 * (k - g.m - (int)pm2))) | suffix;
+                if (pm2 != pm || again != fwd) { printf("exact: k=%d m=%d pm=%u: %llx -> %llx\n", k, g.m, pm, (unsigned long long)fwd, (unsigned long long)again); return 1; }
+                ++exact_windows;
+            }
         }
     }
-    struct { int k; uint64_t n; int m, t, kp; } want[] = {{21, 400000000ull, 14, 6, 21}, {21, 100000000ull, 13, 4, 21}, {31, 800000000ull, 14, 5, 22},
-                                                          {21, 40000ull, 8, 8, 16}, {5, 10ull, 5, 4, 5}, {32, 2000000000ull, 14, 5, 22}};
+    // (K = 21 from 16M keys on: m = 14 so that the entries are exact; with prints forced, the smallest m that holds the keys)
+    struct { int k; uint64_t n; int mode, m, t, kp, exact; } want[] = {{21, 400000000ull, -1, 14, 6, 21, 1}, {21, 100000000ull, -1, 14, 6, 21, 1}, {21, 100000000ull, 0, 13, 4, 21, 0},
+                                                                       {21, 400000000ull, 0, 14, 6, 21, 0}, {31, 800000000ull, -1, 14, 5, 22, 0}, {21, 40000ull, -1, 8, 8, 16, 0},
+                                                                       {5, 10ull, -1, 5, 4, 5, 1}, {32, 2000000000ull, -1, 14, 5, 22, 0}, {17, 400000000ull, -1, 14, 6, 17, 1}};
     for (auto &w : want) {
-        const FilterGeom g = filter_geom_for(w.k, w.n, 0, 0);
+        const FilterGeom g = filter_geom_for(w.k, w.n, 0, 0, 0, w.mode);
+        if (g.exact != w.exact) { printf("pick: K=%d n=%llu mode %d -> exact=%d\n", w.k, (unsigned long long)w.n, w.mode, g.exact); return 1; }
         if (g.m != w.m || g.t != w.t || g.kp != w.kp) { printf("pick: K=%d n=%llu -> m=%d t=%d kp=%d (want %d %d %d)\n", w.k, (unsigned long long)w.n, g.m, g.t, g.kp, w.m, w.t, w.kp); return 1; }
     }
-    printf("ok %ld windows\n", windows);
+    if (exact_windows < windows / 20) { printf("too few exact geometries tried: %ld of %ld\n", exact_windows, windows); return 1; }
+    printf("ok %ld windows, %ld with exact entries\n", windows, exact_windows);
     return 0;
 }

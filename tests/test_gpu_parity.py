@@ -501,6 +501,12 @@ def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
     (31, 14, 14, 31, 30000, 0.2),     # plain forward minimizer over the whole window, W=18
     (32, 10, 5, 27, 30000, 0.2),      # wide keys
     (9, 9, 9, 0, 3000, 0.2), (6, 3, 2, 0, 1500, 0.2), (2, 2, 1, 0, 10, 0.2), (1, 1, 1, 0, 2, 0.2),
+    # geometries whose entries are EXACT codes (2(K-m) + log2 W <= 17 bits): a match in the filter is the hit
+    (15, 8, 0, 0, 30000, 0.2),        # W = 8, 14 + 3 bits, like the BASELINE geometry, on a 8-MB filter
+    (11, 4, 0, 0, 60000, 0.2),        # 256 blocks for 240k strings: every sub-bucket FULL -> matches found, misses verified
+    (20, 14, 0, 0, 30000, 0.2),       # W = 7: positions 0..6 in 3 bits
+    (17, 12, 0, 14, 30000, 0.2),      # sampling on a prefix (kp < K): the bases behind it are part of the code all the same
+    (13, 13, 0, 0, 20000, 0.2),       # W = 1, no bases outside the m-mer: the entry is the tag bits alone
 ])
 def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, ft, fkp, n_keys, lf):
     """The fingerprint filter may only cost time: for every geometry (incl. overfull filters, t-mers that do not fit the
@@ -525,7 +531,8 @@ def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, f
     oracle_lib.ho_classify_ids_votes(oc, rag.ctypes.data, off.ctypes.data, ids.ctypes.data, n_reads, e[0].ctypes.data,
                                      e[1].ctypes.data, e[2].ctypes.data, None, exp_votes.ctypes.data, 4)
     oracle_lib.ho_free(oc)
-    for enable in (True, False):
+    modes = []
+    for enable in (1, 2, 0):          # filter (exact entries where they fit) / filter with prints always / the table directly
         with hast_amd.Context(k) as ctx:
             ctx.set_filter(enable, fm if enable else 0, ft if enable else 0, fkp if enable else 0)
             ctx.table_reserve(2 * n_keys, lf)
@@ -537,7 +544,8 @@ def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, f
             got = ctx.counts_read(n_bc)
             votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
             en, m, t, kp, nbytes = ctx.filter_info()
-            assert en == enable
+            assert en == bool(enable)
+            modes.append(ctx.filter_mode())
             if enable:
                 assert nbytes == 128 * 4 ** m and 1 <= t <= m <= min(k, 14) and m <= kp <= k
                 if fkp:
@@ -550,12 +558,19 @@ def test_filter_geometries_vs_oracle_and_exact_table(built, oracle_lib, k, fm, f
         for a, b in zip(got, e):
             assert np.array_equal(a, b), (k, fm, ft, enable)
     assert k < 6 or int(exp_votes.sum()) > 0
+    # which geometries hold exact entries: 2(K-m) + ceil(log2 W) <= 17 with the m and kp the library chose
+    assert modes[1:] == [1, 0] and modes[0] in (1, 2)
+    if fm and k < 32:
+        w = (fkp or min(k, fm + 8)) - fm + 1
+        assert (modes[0] == 2) == (2 * (k - fm) + (w - 1).bit_length() <= 17), (k, fm, fkp, modes)
 
 
-def test_filter_follows_the_table(built, oracle_lib):
+@pytest.mark.parametrize("k,fm,mode", [(21, 0, 1), (15, 8, 2)])
+def test_filter_follows_the_table(built, oracle_lib, k, fm, mode):
     """Keys added after a classification must be seen by the next one (the filter is rebuilt), erased keys must stop
-    counting (the table decides), and a second table in the same context must not see the first one's prints."""
-    k, L, n_keys, n_bc, n_reads = 21, 150, 20000, 50, 8000
+    counting (with prints the table decides; exact entries -- mode 2 -- answer on their own, so an erase must reach the
+    filter), and a second table in the same context must not see the first one's entries."""
+    L, n_keys, n_bc, n_reads = 150, 20000, 50, 8000
     p = make_params(k, L, n_keys, n_bc)
     keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
     bases, ids = hast_amd.synth_reads_host(p, 0, n_reads)
@@ -568,6 +583,7 @@ def test_filter_follows_the_table(built, oracle_lib):
         return r
 
     with hast_amd.Context(k) as ctx:
+        ctx.set_filter(1, fm)
         ctx.table_reserve(2 * n_keys)
         ctx.counts_resize(n_bc)
         d_b, d_i = ctx.to_device(bases), ctx.to_device(ids)
@@ -575,6 +591,7 @@ def test_filter_follows_the_table(built, oracle_lib):
         def run():
             ctx.counts_zero()
             ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i)
+            assert ctx.filter_mode() == mode
             return ctx.counts_read(n_bc)
 
         ctx.table_insert_keys(0, keys[0][:n_keys // 2])
