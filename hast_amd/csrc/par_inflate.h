@@ -64,8 +64,11 @@ class ParGzReader {
         return at >= 0 && pread(fd, h, 2, at) == 2 && h[0] == 0x1f && h[1] == 0x8b;
     }
     // chunk_bytes: compressed bytes per chunk (tests use tiny ones); a batch is 2 chunks per thread
-    void open(FILE *f, int threads, size_t chunk_bytes = 1u << 20) {
+    // max_chunk_out: a chunk stops at the first block boundary behind this many bytes of output (highly compressible data:
+    // 1 MB of deflate can be 1 GB of zeros, and every chunk of a batch holds its output as 16-bit symbols)
+    void open(FILE *f, int threads, size_t chunk_bytes = 1u << 20, size_t max_chunk_out = 48u << 20) {
         close();
+        max_chunk_out_ = std::max<size_t>(max_chunk_out, 1);
         fd_ = fileno(f);
         file_pos_ = (uint64_t)ftello(f);
         threads_ = std::max(1, threads);
@@ -446,6 +449,10 @@ class ParGzReader {
         for (;;) {
             if (c.eos) return true;
             if (c.end_bit >= stop_bit) return true;
+            if (c.n >= max_chunk_out_) {                                // enough output for one chunk: the batch ends here
+                c.starved = true;
+                return true;
+            }
             Bits in{p, len};
             // ---- a gzip member header (RFC 1952) stands here --------------------------------------------------------
             if (c.at_member_header) {
@@ -783,7 +790,7 @@ class ParGzReader {
 
     int fd_ = -1, threads_ = 1;
     uint64_t file_pos_ = 0;
-    size_t chunk_bytes_ = 1u << 20;
+    size_t chunk_bytes_ = 1u << 20, max_chunk_out_ = 48u << 20;
     std::unique_ptr<WorkerPool> pool_, rpool_;
     std::string err_;
     // consumer side

@@ -15,7 +15,7 @@
 
 int main(int argc, char **argv) {
     bool use_zlib = false, quiet = false, bgzf = false, par = false;
-    size_t chunk = 1u << 20;
+    size_t chunk = 1u << 20, max_out = 48u << 20;
     int threads = 4;
     size_t piece = 1 << 20, inbuf = 1 << 20;
     const char *path = nullptr;
@@ -25,6 +25,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-b")) bgzf = true;                 // BgzfReader (+ hand-over to the serial decoder), as BlockSource does
         else if (!strcmp(argv[i], "-P")) par = true;                  // ParGzReader (several threads on one ordinary gzip stream)
         else if (!strcmp(argv[i], "-c")) chunk = (size_t)atol(argv[++i]);   // ... with this many compressed bytes per chunk
+        else if (!strcmp(argv[i], "-m")) max_out = (size_t)atol(argv[++i]); // ... and at most about this much output per chunk
         else if (!strcmp(argv[i], "-t")) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-p")) piece = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-i")) inbuf = (size_t)atol(argv[++i]);
@@ -52,7 +53,7 @@ int main(int argc, char **argv) {
         if (par) {
             if (!hast::ParGzReader::usable(f)) return 4;
             hast::ParGzReader pz;
-            pz.open(f, threads, chunk);
+            pz.open(f, threads, chunk, max_out);
             while ((n = pz.read(buf.data(), piece)) > 0) {
                 if (!quiet) fwrite(buf.data(), 1, (size_t)n, stdout);
                 total += (size_t)n;

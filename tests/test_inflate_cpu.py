@@ -311,3 +311,15 @@ def test_parallel_inflate_has_no_data_races(tmp_path):
         r = subprocess.run([str(exe), "-P", "-c", str(chunk), "-t", str(threads), "-p", str(piece), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0 and r.stdout == want
         assert b"ThreadSanitizer" not in r.stderr, r.stderr[-2000:]
+
+
+def test_parallel_inflate_bounds_a_chunks_output(driver, tmp_path):
+    """highly compressible data (1 MB of deflate can be 1 GB of output): a chunk stops at the first block boundary behind its
+    output budget and the next batch goes on from there"""
+    rng = random.Random(14)
+    data = b"\0" * 6_000_000 + fastq(rng, 3000) + b"ACGT" * 1_000_000 + fastq(rng, 3000) + b"N" * 3_000_000
+    p = tmp_path / "z.gz"
+    p.write_bytes(member(data, 6))
+    for chunk, threads, max_out in ((1 << 20, 4, 100_000), (2_000, 3, 50_000), (1 << 20, 2, 1), (500, 5, 1 << 30)):
+        r = subprocess.run([driver, "-P", "-c", str(chunk), "-t", str(threads), "-m", str(max_out), "-p", str(1 << 22), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == data, (chunk, threads, max_out, r.stderr[-300:])
