@@ -20,6 +20,7 @@
 // FASTQ records on the host as round 1 did; default: raw file bytes go to the GPU and are framed there, hast_fq_*).
 // -t/--thread N is honoured as the number of host parser threads.
 #include <getopt.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <chrono>
@@ -270,27 +271,50 @@ int main(int argc, char **argv) {
         CK(hast_table_load(ctx, load_table.c_str(), 0.0), "loading the k-mer table");
         t_loaded = now_s();
     } else {
-    std::vector<char> txt[2];
-    if (!slurp(hap0, txt[0])) die(2, ("cannot read " + hap0).c_str());
-    if (!slurp(hap1, txt[1])) die(2, ("cannot read " + hap1).c_str());
-    const void *nl0 = memchr(txt[0].data(), '\n', txt[0].size());
-    K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // :35-36
+    // K = length of the first line of hap0 (classify.cpp:35-36); the files themselves are streamed into the table by the
+    // library (hast_table_insert_text_file), a pipe or the like is read into memory first
+    std::vector<char> head;
+    {
+        FILE *f = fopen(hap0.c_str(), "rb");
+        if (!f) die(2, ("cannot read " + hap0).c_str());
+        head.resize(4096);
+        head.resize(fread(head.data(), 1, head.size(), f));
+        fclose(f);
+    }
+    const void *nl0 = memchr(head.data(), '\n', head.size());
+    K = nl0 ? (size_t)((const char *)nl0 - head.data()) : head.size();   // :35-36
     if (K < 1 || K > 32) {
-        fprintf(stderr, "classify: ERROR: K=%zu (length of the first line of %s) is outside [1,32]\n", K, hap0.c_str());
+        fprintf(stderr, "classify: ERROR: K=%zu%s (length of the first line of %s) is outside [1,32]\n", K, (!nl0 && head.size() == 4096) ? " or more" : "", hap0.c_str());
         return 3;
     }
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
     contexts_ready();
-    CK(hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.0), "allocating the k-mer table");
+    const std::string *hap_path[2] = {&hap0, &hap1};
+    std::vector<char> txt[2];
+    bool streamed[2] = {false, false};
+    size_t text_bytes[2] = {0, 0};
+    for (int h = 0; h < 2; h++) {
+        struct stat sb;
+        if (stat(hap_path[h]->c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            streamed[h] = true;
+            text_bytes[h] = (size_t)sb.st_size;
+        } else {
+            if (!slurp(*hap_path[h], txt[h])) die(2, ("cannot read " + *hap_path[h]).c_str());
+            text_bytes[h] = txt[h].size();
+        }
+    }
+    CK(hast_table_reserve(ctx, text_bytes[0] / (K + 1) + text_bytes[1] / (K + 1) + 2, 0.0), "allocating the k-mer table");
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "__load hap%d kmers__\n", h);
         uint64_t lines = 0;
-        hast_status st = hast_table_insert_text(ctx, h, txt[h].data(), txt[h].size(), &lines);
+        hast_status st = streamed[h] ? hast_table_insert_text_file(ctx, h, hap_path[h]->c_str(), &lines)
+                                     : hast_table_insert_text(ctx, h, txt[h].data(), txt[h].size(), &lines);
         if (st == HAST_ERR_FORMAT) die(3, "k-mer file is not one K-mer per line");
+        if (st == HAST_ERR_IO) die(2, ("cannot read " + *hap_path[h]).c_str());
         if (st != HAST_OK) die(4, "building the k-mer table");
-        if (h == 0 && !nl0 && txt[0].size() == K) {
+        if (h == 0 && !nl0 && text_bytes[0] == K) {
             // a single unterminated line: the reference still inserts the FIRST line of hap0 (:35-39)
-            uint64_t key = hast_canon_kmer(txt[0].data(), (int)K);
+            uint64_t key = hast_canon_kmer(head.data(), (int)K);
             CK(hast_table_insert_keys(ctx, 0, &key, 1), "building the k-mer table");
             lines = 1;
         }

@@ -2,9 +2,13 @@
 // Host C++ over the HIP runtime; all device work is in hast_kernels.hip.  No CPU fallback exists:
 // every compute entry point needs a context, and a context needs a GPU.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +19,9 @@
 #include "../../include/hast.h"
 #include "hast_common.h"
 #include "hast_device.h"
+#include "kc_device.h"
 #include "hast_internal.h"
+#include "worker_pool.h"
 
 using namespace hast;
 
@@ -375,6 +381,83 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
     return HAST_OK;
 }
 
+// The same from a FILE, streamed: the reference reads a k-mer file line by line (classify.cpp:30-46; 4.4 GB per haplotype at
+// the BASELINE sizes); here several threads pread the next piece into pinned memory while the previous one is copied to
+// the device and inserted, so the load runs at the page cache's / the storage's rate instead of one thread's.
+hast_status hast_table_insert_text_file(hast_ctx *c, int hap, const char *path, uint64_t *lines_out) {
+    if (hast_status st = need_table(c, hap)) return st;
+    if (lines_out) *lines_out = 0;
+    if (!path) return fail(HAST_ERR_INVALID, "path is null");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(HAST_ERR_IO, "cannot read %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        // not a regular file (a pipe): no pread -- the caller reads it into memory and uses hast_table_insert_text
+        close(fd);
+        return fail(HAST_ERR_IO, "%s is not a regular file", path);
+    }
+    const size_t nbytes = (size_t)sb.st_size, stride = (size_t)c->k + 1;
+    const size_t n_lines = nbytes / stride, rem = nbytes - n_lines * stride;
+    if (rem) {       // classify.cpp:41: a trailing piece without its own newline is dropped -- it must not hold one, though
+        char tail[64];
+        if (pread(fd, tail, rem, (off_t)(n_lines * stride)) != (ssize_t)rem) { close(fd); return fail(HAST_ERR_IO, "cannot read %s", path); }
+        if (memchr(tail, '\n', rem)) { close(fd); return fail(HAST_ERR_FORMAT, "k-mer text: ragged last line"); }
+    }
+    table_changed(c);
+    const size_t per = std::max<size_t>(1, (32u << 20) / stride);             // lines per piece
+    const size_t piece = per * stride;
+    char *h_buf[2] = {nullptr, nullptr};
+    char *d_buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hast_status st = HAST_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void **)&h_buf[i], piece, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_buf[i], piece + 16);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        const int nthreads = 8;
+        WorkerPool pool(nthreads);
+        bool short_read = false;
+        size_t i = 0;
+        for (size_t line = 0; line < n_lines && e == hipSuccess && !short_read; line += per, ++i) {
+            const int b = (int)(i & 1);
+            const size_t m = std::min(per, n_lines - line), bytes = m * stride;
+            if (i >= 2) e = hipEventSynchronize(done[b]);                       // the piece that used this buffer is on the device
+            if (e != hipSuccess) break;
+            const size_t share = ((bytes / nthreads) + 4095) & ~(size_t)4095;
+            std::atomic<bool> bad{false};
+            pool.run([&](int t) {
+                const size_t from = std::min(bytes, share * (size_t)t), to = std::min(bytes, from + share);
+                size_t got = 0;
+                while (from + got < to) {
+                    const ssize_t r = pread(fd, h_buf[b] + from + got, to - from - got, (off_t)(line * stride + from + got));
+                    if (r <= 0) { bad = true; break; }
+                    got += (size_t)r;
+                }
+            });
+            if (bad) { short_read = true; break; }
+            e = hipMemcpyAsync(d_buf[b], h_buf[b], bytes, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_insert_text(c->d_slots, geom(c), d_buf[b], m, (uint32_t)hap, c->d_err, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (short_read) st = fail(HAST_ERR_IO, "%s changed while it was read", path);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (d_buf[i]) (void)hipFree(d_buf[i]);
+        if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+    }
+    close(fd);
+    if (e != hipSuccess) return fail(HAST_ERR_HIP, "k-mer text: %s", hipGetErrorString(e));
+    if (st != HAST_OK) return st;
+    if (hast_status s2 = check_err_word(c, c->stream)) return s2;
+    if (lines_out) *lines_out = n_lines;
+    return HAST_OK;
+}
+
 hast_status hast_table_erase(hast_ctx *c, const uint64_t *keys, size_t n, uint8_t *out_hit) {
     if (hast_status st = need_table(c, 0)) return st;
     if (n == 0) return HAST_OK;
@@ -447,13 +530,24 @@ hast_status hast_table_save(hast_ctx *c, const char *path) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     std::vector<uint64_t> host;
     if (e == hipSuccess && n <= cap) {
+        // sorted: a deterministic file for a given key set.  On the device (a library radix sort, as stage 00 uses for its
+        // output order): one host thread needs ~30 s for the 400M slots of the BASELINE sets.
+        uint64_t *d_sorted = nullptr;
+        void *d_tmp = nullptr;
+        size_t tmp_bytes = 0;
+        if (n) e = kc_sort_keys(nullptr, &tmp_bytes, (unsigned long long *)d_out, nullptr, (size_t)n, 32, c->stream);
+        if (e == hipSuccess && n) e = hipMalloc((void **)&d_sorted, (size_t)n * sizeof(uint64_t));
+        if (e == hipSuccess && n) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
+        if (e == hipSuccess && n) e = kc_sort_keys(d_tmp, &tmp_bytes, (unsigned long long *)d_out, (unsigned long long *)d_sorted, (size_t)n, 32, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         host.resize((size_t)n);
-        if (n) e = hipMemcpy(host.data(), d_out, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n) e = hipMemcpy(host.data(), d_sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost);
+        (void)hipFree(d_sorted);
+        (void)hipFree(d_tmp);
     }
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(HAST_ERR_HIP, "table export: %s", hipGetErrorString(e));
     if (n > cap) return fail(HAST_ERR_INVALID, "table export overflow");
-    std::sort(host.begin(), host.end());                          // deterministic file for a given key set
     FILE *f = fopen(path, "wb");
     if (!f) return fail(HAST_ERR_IO, "cannot write %s", path);
     CacheHeader h;

@@ -87,6 +87,10 @@ hast_status hast_table_reserve(hast_ctx *, uint64_t max_keys, double load_factor
  * HAST_ERR_FORMAT if any line is not exactly K bytes (the reference asserts, kmer.h:154). */
 hast_status hast_table_insert_text(hast_ctx *, int hap, const char *text, size_t nbytes,
                                    uint64_t *lines_out);
+/* The same straight from a regular FILE, streamed (several threads pread the next piece into pinned memory while the
+ * previous one is inserted): 2 x 4.4 GB of 21-mer text load in well under a second instead of at one thread's read rate.
+ * HAST_ERR_IO if the path cannot be opened or is not a regular file (a pipe: read it and use hast_table_insert_text). */
+hast_status hast_table_insert_text_file(hast_ctx *, int hap, const char *path, uint64_t *lines_out);
 /* Same, keys already canonical 2K-bit values (host / device resident). */
 hast_status hast_table_insert_keys(hast_ctx *, int hap, const uint64_t *canon_keys, size_t n);
 hast_status hast_table_insert_keys_device(hast_ctx *, int hap, const uint64_t *d_canon_keys, size_t n,

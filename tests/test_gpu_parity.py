@@ -144,6 +144,44 @@ def test_insert_text_matches_reference_set_sizes(built, oracle_lib, golden_workd
         oracle_lib.ho_free(oc)
 
 
+def test_insert_text_file_streams_the_same_table(built, oracle_lib, golden_workdir, tmp_path):
+    """hast_table_insert_text_file (pread workers + pinned double buffer) == hast_table_insert_text on the file's bytes: the
+    golden k-mer files, and a file of several pieces (3.3M lines) with an unterminated tail that must be dropped"""
+    for case in ("edge_k7", "rand_k21", "rand_k31", "rand_k32"):
+        d = golden_workdir / case
+        t = [open(d / ("hap%d.mer" % h), "rb").read() for h in (0, 1)]
+        k = t[0].index(b"\n")
+        sizes, lines = [], []
+        for from_file in (False, True):
+            with hast_amd.Context(k) as ctx:
+                ctx.table_reserve(len(t[0]) // (k + 1) + len(t[1]) // (k + 1) + 2)
+                lines.append([ctx.table_insert_text_file(h, d / ("hap%d.mer" % h)) if from_file else ctx.table_insert_text(h, t[h]) for h in (0, 1)])
+                sizes.append(ctx.table_sizes())
+        assert sizes[0] == sizes[1] and lines[0] == lines[1], case
+    k, n = 21, 3_300_000
+    p = make_params(k, 150, n, 10)
+    keys = hast_amd.synth_keys_host(p, 0, 0, n)
+    codes = np.frombuffer(b"ACTG", np.uint8)                       # kmer.h:12 int2base
+    shifts = (2 * (k - 1 - np.arange(k))).astype(np.uint64)
+    text = np.full((n, k + 1), ord("\n"), np.uint8)
+    text[:, :k] = codes[((keys[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.int64)]
+    path = tmp_path / "big.mer"
+    path.write_bytes(text.tobytes() + b"ACGTACGTAC")               # the tail has no newline: dropped (classify.cpp:41)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(n + 2)
+        assert ctx.table_insert_text_file(0, path) == n
+        assert ctx.table_sizes() == (np.unique(keys).size, 0)
+        assert np.array_equal(ctx.table_lookup(keys[::1000]), np.ones(keys[::1000].size, np.uint8))
+    (tmp_path / "ragged.mer").write_bytes(b"ACGTA\nACG\nACGTACC\n")
+    with hast_amd.Context(5) as ctx:
+        ctx.table_reserve(100)
+        with pytest.raises(hast_amd.HastError) as ei:
+            ctx.table_insert_text_file(0, tmp_path / "ragged.mer")
+        assert ei.value.status == 6
+        with pytest.raises(hast_amd.HastError):
+            ctx.table_insert_text_file(0, tmp_path / "no_such_file.mer")
+
+
 def test_insert_text_rejects_ragged_lines(built):
     with hast_amd.Context(5) as ctx:
         ctx.table_reserve(100)
