@@ -53,6 +53,7 @@ ABI_SYMBOLS = {
     "hast_table_reserve": (C.c_int, [vp, C.c_uint64, C.c_double]),
     "hast_table_insert_text": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t, u64p]),
     "hast_table_insert_text_file": (C.c_int, [vp, C.c_int, C.c_char_p, u64p]),
+    "hast_ctx_set_text_check": (C.c_int, [vp, C.c_int]),
     "hast_table_insert_keys": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "hast_table_insert_keys_device": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
     "hast_table_erase": (C.c_int, [vp, vp, C.c_size_t, vp]),
@@ -320,6 +321,9 @@ class Context:
         lines = C.c_uint64()
         _ck(self._lib.hast_table_insert_text(self._h, hap, text, len(text), C.byref(lines)))
         return lines.value
+
+    def set_text_check(self, acgt_only=True):
+        _ck(self._lib.hast_ctx_set_text_check(self._h, 1 if acgt_only else 0))
 
     def table_insert_text_file(self, hap, path) -> int:
         lines = C.c_uint64()

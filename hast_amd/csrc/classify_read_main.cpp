@@ -9,6 +9,7 @@
 // Requirement (deviation): k-mer lines must be upper-case A/C/G/T of one length K <= 32 -- what jellyfish/meryl
 // dumps are.  The reference would also store other bytes literally (s03:59-65); we stop with exit 3 instead.
 #include <getopt.h>
+#include <sys/stat.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -82,35 +83,61 @@ int main(int argc, char **argv) {
     }
     fprintf(stderr, "__START__\n");
     // ---- load_kmers (s03:51-70) --------------------------------------------------------------------
-    std::vector<char> txt[2];
-    for (int h = 0; h < 2; h++)
-        if (!slurp(haps[h], txt[h])) die(2, "cannot read " + haps[h]);
-    const void *nl0 = memchr(txt[0].data(), '\n', txt[0].size());
-    const size_t K = nl0 ? (size_t)((const char *)nl0 - txt[0].data()) : txt[0].size();   // s03:57-58
+    // K = length of the first line of the first file (s03:57-58); regular files are streamed into the table by the library,
+    // which also checks on the device that every line is K upper-case A/C/G/T bytes; anything else is read into memory first
+    std::vector<char> head;
+    {
+        FILE *f = fopen(haps[0].c_str(), "rb");
+        if (!f) die(2, "cannot read " + haps[0]);
+        head.resize(4096);
+        head.resize(fread(head.data(), 1, head.size(), f));
+        fclose(f);
+    }
+    const void *nl0 = memchr(head.data(), '\n', head.size());
+    const size_t K = nl0 ? (size_t)((const char *)nl0 - head.data()) : head.size();   // s03:57-58
     if (K < 1 || K > 32) die(3, "K (length of the first k-mer line) must be in [1,32]");
-    for (int h = 0; h < 2; h++)
-        for (char ch : txt[h])
-            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != '\n') die(3, "k-mer files must hold upper-case A/C/G/T lines only");
+    std::vector<char> txt[2];
+    bool streamed[2] = {false, false};
+    size_t text_bytes[2] = {0, 0};
+    for (int h = 0; h < 2; h++) {
+        struct stat sb;
+        if (stat(haps[h].c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            streamed[h] = true;
+            text_bytes[h] = (size_t)sb.st_size;
+        } else {
+            if (!slurp(haps[h], txt[h])) die(2, "cannot read " + haps[h]);
+            text_bytes[h] = txt[h].size();
+        }
+    }
     hast_ctx *ctx = nullptr;
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
-    if (hast_table_reserve(ctx, txt[0].size() / (K + 1) + txt[1].size() / (K + 1) + 2, 0.0) != HAST_OK) die(4, "allocating the k-mer table");
+    if (hast_ctx_set_text_check(ctx, 1) != HAST_OK) die(4, "cannot create GPU context");
+    if (hast_table_reserve(ctx, text_bytes[0] / (K + 1) + text_bytes[1] / (K + 1) + 2, 0.0) != HAST_OK) die(4, "allocating the k-mer table");
     int total_kmers[2] = {0, 0};                                             // s03:50,68 (an `int` in the reference)
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "__load hap%d kmers__\n", h);
         uint64_t lines = 0;
-        // complete lines only: a trailing piece without '\n' is dropped (s03:63) -- except a lone first line
-        size_t usable = txt[h].size();
-        while (usable && txt[h][usable - 1] != '\n') usable--;
-        hast_status st = hast_table_insert_text(ctx, h, txt[h].data(), usable, &lines);
-        if (st == HAST_ERR_FORMAT) die(3, "k-mer file is not one K-mer per line");
+        hast_status st;
+        if (streamed[h]) st = hast_table_insert_text_file(ctx, h, haps[h].c_str(), &lines);
+        else {
+            // complete lines only: a trailing piece without '\n' is dropped (s03:63) -- except a lone first line
+            size_t usable = txt[h].size();
+            while (usable && txt[h][usable - 1] != '\n') usable--;
+            st = hast_table_insert_text(ctx, h, txt[h].data(), usable, &lines);
+        }
+        if (st == HAST_ERR_FORMAT) die(3, std::string(hast_last_error()) + " (k-mer files must hold one K-mer of upper-case A/C/G/T per line)");
+        if (st == HAST_ERR_IO) die(2, "cannot read " + haps[h]);
         if (st != HAST_OK) die(4, "building the k-mer table");
-        if (h == 0 && !nl0 && txt[0].size() == K) {
-            uint64_t key = hast_canon_kmer(txt[0].data(), (int)K);
+        if (h == 0 && !nl0 && text_bytes[0] == K) {
+            for (size_t i = 0; i < K; i++)
+                if (!strchr("ACGT", head[i])) die(3, "k-mer files must hold upper-case A/C/G/T lines only");
+            uint64_t key = hast_canon_kmer(head.data(), (int)K);
             if (hast_table_insert_keys(ctx, 0, &key, 1) != HAST_OK) die(4, "building the k-mer table");
             lines = 1;
         }
         total_kmers[h] = (int)lines;
         fprintf(stderr, "Recorded %d haplotype %d specific %zu-mers\n", total_kmers[h], h, K);
+        std::vector<char>().swap(txt[h]);
     }
     // ---- reads: block ingest with t_num parser threads (ingest.h), one GPU batch per block ------------------------
     // Framing as in the reference: FASTQ = 4 getlines per record, the header must be newline-terminated (s03:255-263);

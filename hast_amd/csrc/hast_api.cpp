@@ -94,6 +94,7 @@ struct hast_ctx {
     bool use_filter = true;                 // HAST_CLASSIFY=exact: probe the exact table directly (the round-1 kernel)
     int filter_m = 0, filter_t = 0, filter_kp = 0;   // overrides (0 = by K and key count)
     int filter_exact = -1;                           // -1: exact entries where they fit (hast_common.h), 0: prints always
+    int text_acgt_only = 0;                          // k-mer text lines must be upper-case A/C/G/T (hast_ctx_set_text_check)
     bool exact_env_off = false;                      // HAST_FILTER_EXACT=0 in the environment
 };
 
@@ -137,6 +138,7 @@ hast_status check_err_word(hast_ctx *c, hipStream_t s) {
     HIP_TRY(hipStreamSynchronize(s));
     if (e) HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), s));
     if (e & 2) return fail(HAST_ERR_FORMAT, "k-mer text: a line is not exactly K=%d bytes", c->k);
+    if (e & 4) return fail(HAST_ERR_FORMAT, "k-mer text: a byte other than upper-case A/C/G/T");
     if (e & 1) return fail(HAST_ERR_TABLE_FULL, "k-mer table full: reserve more keys");
     return HAST_OK;
 }
@@ -332,6 +334,12 @@ static hast_status need_table(hast_ctx *c, int hap) {
     return HAST_OK;
 }
 
+hast_status hast_ctx_set_text_check(hast_ctx *c, int acgt_only) {
+    if (!c) return fail(HAST_ERR_INVALID, "null context");
+    c->text_acgt_only = acgt_only ? 1 : 0;
+    return HAST_OK;
+}
+
 hast_status hast_table_insert_keys_device(hast_ctx *c, int hap, const uint64_t *d_keys, size_t n, hast_stream s) {
     if (hast_status st = need_table(c, hap)) return st;
     hipStream_t hs = s ? (hipStream_t)s : c->stream;
@@ -373,7 +381,7 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
     for (size_t i = 0; i < n_lines; i += per) {
         size_t m = std::min(per, n_lines - i);
         HIP_TRY(hipMemcpyAsync(c->d_scratch, text + i * stride, m * stride, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_insert_text(c->d_slots, geom(c), (const char *)c->d_scratch, m, (uint32_t)hap, c->d_err, c->stream));
+        HIP_TRY(launch_insert_text(c->d_slots, geom(c), (const char *)c->d_scratch, m, (uint32_t)hap, c->text_acgt_only, c->d_err, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (hast_status st = check_err_word(c, c->stream)) return st;
@@ -439,7 +447,7 @@ hast_status hast_table_insert_text_file(hast_ctx *c, int hap, const char *path, 
             });
             if (bad) { short_read = true; break; }
             e = hipMemcpyAsync(d_buf[b], h_buf[b], bytes, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = launch_insert_text(c->d_slots, geom(c), d_buf[b], m, (uint32_t)hap, c->d_err, c->stream);
+            if (e == hipSuccess) e = launch_insert_text(c->d_slots, geom(c), d_buf[b], m, (uint32_t)hap, c->text_acgt_only, c->d_err, c->stream);
             if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -47,7 +47,7 @@ struct ClassifyArgs {
 hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint32_t hap,
                               uint32_t *d_err, hipStream_t s);
 hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, size_t n_lines,
-                              uint32_t hap, uint32_t *d_err, hipStream_t s);
+                              uint32_t hap, int acgt_only, uint32_t *d_err, hipStream_t s);
 hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s);
 hipError_t launch_lookup_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_tags, hipStream_t s);
 hipError_t launch_export_slots(const uint64_t *slots, size_t nslots, uint64_t *d_out, size_t cap, unsigned long long *d_counter, hipStream_t s);

@@ -81,20 +81,24 @@ __global__ void __launch_bounds__(256) k_insert_keys(uint64_t *slots, TableGeom 
 }
 
 // load_kmers (classify.cpp:30-46): line i = text[i*(K+1) .. +K), text[i*(K+1)+K] must be '\n'.
-// err bit0: table full, bit1: a line is not exactly K bytes.
+// err bit0: table full, bit1: a line is not exactly K bytes, bit2 (acgt_only: the stage-03 classifier compares k-mers as
+// case-sensitive strings, S03/src_main/classify.cpp:59-65, so its key files must be what jellyfish / meryl dump): a byte
+// of a line is not one of 'A','C','G','T'.
 __global__ void __launch_bounds__(256) k_insert_text(uint64_t *slots, TableGeom g, const char *text,
-                                                     size_t n_lines, uint32_t hap, uint32_t *err) {
+                                                     size_t n_lines, uint32_t hap, int acgt_only, uint32_t *err) {
     const int k = g.k;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_lines; i += (size_t)gridDim.x * blockDim.x) {
         const char *s = text + i * (size_t)(k + 1);
         uint64_t w = 0;
-        bool bad = s[k] != '\n';
+        bool bad = s[k] != '\n', other = false;
         for (int j = 0; j < k; ++j) {
             uint32_t c = (uint8_t)s[j];
             bad |= (c == '\n');
+            other |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
             w = (w << 2) | base_code(c);
         }
         if (bad) { atomicOr(&err[0], 2u); continue; }
+        if (acgt_only && other) { atomicOr(&err[0], 4u); continue; }
         if (!table_insert(slots, g, kmer_canon(w, k), hap)) atomicOr(&err[0], 1u);
     }
 }
@@ -551,9 +555,9 @@ hipError_t launch_insert_keys(uint64_t *slots, TableGeom g, const uint64_t *d_ke
     return hipGetLastError();
 }
 hipError_t launch_insert_text(uint64_t *slots, TableGeom g, const char *d_text, size_t n_lines,
-                              uint32_t hap, uint32_t *d_err, hipStream_t s) {
+                              uint32_t hap, int acgt_only, uint32_t *d_err, hipStream_t s) {
     if (n_lines == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_text, n_lines, hap, d_err);
+    hipLaunchKernelGGL(k_insert_text, dim3(grid_for(n_lines, 256, 256 * 32)), dim3(256), 0, s, slots, g, d_text, n_lines, hap, acgt_only, d_err);
     return hipGetLastError();
 }
 hipError_t launch_erase_keys(uint64_t *slots, TableGeom g, const uint64_t *d_keys, size_t n, uint8_t *d_hit, hipStream_t s) {

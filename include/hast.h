@@ -91,6 +91,10 @@ hast_status hast_table_insert_text(hast_ctx *, int hap, const char *text, size_t
  * previous one is inserted): 2 x 4.4 GB of 21-mer text load in well under a second instead of at one thread's read rate.
  * HAST_ERR_IO if the path cannot be opened or is not a regular file (a pipe: read it and use hast_table_insert_text). */
 hast_status hast_table_insert_text_file(hast_ctx *, int hap, const char *path, uint64_t *lines_out);
+/* acgt_only != 0: both calls above also fail with HAST_ERR_FORMAT when a line holds a byte other than upper-case A/C/G/T
+ * (checked on the device).  Stage 01 accepts any byte (kmer.h:11 codes them all); the stage-03 classifier compares k-mers
+ * as case-sensitive strings (S03/src_main/classify.cpp:59-65), which integer keys reproduce only for such lines. */
+hast_status hast_ctx_set_text_check(hast_ctx *, int acgt_only);
 /* Same, keys already canonical 2K-bit values (host / device resident). */
 hast_status hast_table_insert_keys(hast_ctx *, int hap, const uint64_t *canon_keys, size_t n);
 hast_status hast_table_insert_keys_device(hast_ctx *, int hap, const uint64_t *d_canon_keys, size_t n,

@@ -182,6 +182,23 @@ def test_insert_text_file_streams_the_same_table(built, oracle_lib, golden_workd
             ctx.table_insert_text_file(0, tmp_path / "no_such_file.mer")
 
 
+def test_insert_text_acgt_check_is_optional(built, tmp_path):
+    """stage 01 codes any byte (kmer.h:11); hast_ctx_set_text_check makes the device refuse lines that are not upper-case
+    A/C/G/T (what the stage-03 string classifier needs), from memory and from a file"""
+    text = b"ACGTA\nACGTn\nacgta\nRYACG\n"
+    (tmp_path / "odd.mer").write_bytes(text)
+    with hast_amd.Context(5) as ctx:
+        ctx.table_reserve(100)
+        assert ctx.table_insert_text(0, text) == 4
+        assert ctx.table_insert_text_file(1, tmp_path / "odd.mer") == 4
+        ctx.set_text_check(True)
+        for call in (lambda: ctx.table_insert_text(0, text), lambda: ctx.table_insert_text_file(0, tmp_path / "odd.mer")):
+            with pytest.raises(hast_amd.HastError) as ei:
+                call()
+            assert ei.value.status == 6
+        assert ctx.table_insert_text(0, b"ACGTA\nTTTTT\n") == 2
+
+
 def test_insert_text_rejects_ragged_lines(built):
     with hast_amd.Context(5) as ctx:
         ctx.table_reserve(100)
@@ -384,8 +401,9 @@ def _kmer_str(key, k):
     return "".join("ACTG"[(int(key) >> (2 * (k - 1 - j))) & 3] for j in range(k))
 
 
-@pytest.mark.parametrize("k,max_len", [(21, 3000), (31, 30000), (32, 2000), (11, 600), (27, 100)])
-def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len):
+@pytest.mark.parametrize("k,max_len,fm", [(21, 3000, 0), (31, 30000, 0), (32, 2000, 0), (11, 600, 0), (27, 100, 0),
+                                          (21, 30000, 14), (15, 3000, 8), (12, 700, 12)])       # fm: exact filter entries
+def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len, fm):
     """Integer hits per read == the stage-03 reference's string lookups: windows containing N / lower-case /
     IUPAC bytes miss (no whole-read skip), reads far longer than an LDS row are segmented on the device."""
     rng = random.Random(k + max_len)
@@ -414,11 +432,14 @@ def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
     with hast_amd.Context(k) as ctx:
+        if fm:
+            ctx.set_filter(1, fm)
         ctx.table_reserve(2 * n_keys)
         ctx.table_insert_text(0, ("\n".join(lines[0]) + "\n").encode())
         ctx.table_insert_text(1, ("\n".join(lines[1]) + "\n").encode())
         votes = ctx.classify_perread(bases, off)
         votes2 = ctx.classify_perread(bases, off)                 # idempotent: the output rows are overwritten
+        assert not fm or ctx.filter_mode() == 2
     exp = np.zeros_like(votes)
     h0, h1 = C.c_uint32(), C.c_uint32()
     for i, sq in enumerate(seqs):
