@@ -1,8 +1,10 @@
-// hast_filter.hip -- gfx950 (MI355X, CDNA4) device code: the fingerprint filter in front of the exact k-mer table and the
-// classify kernel that probes it (k_classify_f).  See hast_common.h ("fingerprint filter") for the structure and why it
-// exists: the probe is bound by the HBM random-request rate, and this front end needs 23 instead of 39 requests per
-// 150-bp read while doing less arithmetic per window.  Results are decided by the exact table alone (every positive of
-// the filter is looked up there), so the reference semantics implemented are exactly those of hast_kernels.hip:
+// hast_filter.hip -- gfx950 (MI355X, CDNA4) device code: the filter in front of the exact k-mer table and the classify
+// kernel that probes it (k_classify_f).  See hast_common.h ("fingerprint filter", "exact entries") for the structure and why
+// it exists: the probe is bound by the HBM random-request rate, and this front end needs 25 instead of 40 requests per
+// 150-bp read while doing less arithmetic per window.  With prints, results are decided by the exact table alone (every
+// positive of the filter is looked up there); with exact entries a match in the filter is the filed string itself with its
+// tag bits, and the table is asked only where a key may have found no room.  Either way the reference semantics implemented
+// are exactly those of hast_kernels.hip:
 //   classify.cpp:182-209 (containN + process_reads), kmer/kmer.h:11,153-166,169-194 (coding, canonical k-mers).
 #include "hast_common.h"
 #include "hast_device.h"
@@ -91,18 +93,20 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 //   A  pack   : as hast_kernels.hip: 16 ASCII bases per lane -> 32 bits of 2-bit codes; 'N' flag / invalid-byte mask.
 //   M  order  : e[q] = tmer_order(t-mer at q, q) for every position, and the first level of the sliding minimum,
 //               L1[q] = min(e[q .. q+3]): a lane takes 4 consecutive positions (one funnel shift, four hashes) and needs
-//               the prefix minima of the next lane's four (three wave shuffles).  A window's smallest t-mer (leftmost on
+//               the prefix minima of the next lane's four (three DPP moves).  A window's smallest t-mer (leftmost on
 //               ties) is then the minimum of ceil((kp-t+1)/4) L1 entries.
-//   B  probe  : each wave walks a contiguous quarter of the tile's 64-window blocks; every LANE owns one window: its
-//               K-mer by funnel shift out of the packed LDS words, smallest t-mer -> position x -> the m-mer at x mod W
-//               names the 128-B block, a hash of the K-mer as it stands names two 16-B sub-buckets and the 16-bit print
-//               (no canonical form anywhere in the probe: every key was filed once per strand).  Two 16-B loads per
-//               window, both in the one block; consecutive windows (adjacent lanes) mostly name the same block, which
-//               the memory system fetches once.  Blocks are software-pipelined: the loads of block i+1 are in flight
-//               while block i is compared (8 xor + 7 v_pk_min_u16 + has-zero-halfword).  Positives (print found, or both
-//               sub-buckets full) -- the real hits, about 1 % of the windows, plus a few in 10^5 false ones -- go to the
-//               wave's own queue in LDS.
-//   V  verify : when a wave's queue holds 64 positives (and at the end of the tile) each lane takes one, canonicalises it
+//   B  probe  : each wave walks a contiguous quarter of the tile's reads, 64 windows per instruction; every LANE owns one
+//               window: its K-mer by funnel shift out of the packed LDS words, smallest t-mer -> position x -> the m-mer at
+//               x mod W names the 128-B block (no canonical form anywhere in the probe: every key was filed once per
+//               strand); consecutive windows (adjacent lanes) mostly name the same block, which the memory system fetches
+//               once.  Instructions are software-pipelined: the loads of instruction i+1 are in flight while i is compared.
+//               prints (K > 21, small tables): a hash of the K-mer as it stands names two 16-B sub-buckets and a 16-bit
+//                 print; two 16-B loads; compare = 8 xor + 7 v_pk_min_u16 + has-zero-halfword.  Positives (print found, or
+//                 both sub-buckets full) -- the real hits plus a few in 10^5 false ones -- go to the wave's queue in LDS.
+//               exact entries (EXACT): the window's 17-bit code names ONE sub-bucket and 14 stored bits; one 16-B load;
+//                 compare = 4 xor + 3 v_pk_max_u16; a match carries the tag bits and is added to the read's votes at once,
+//                 only "no match in a full sub-bucket" is queued.
+//   V  verify : when a wave's queue holds 64 entries (and at the end of the tile) each lane takes one, canonicalises it
 //               (v_bfrev) and finds it in the exact table (home bucket by the table's own minimizer, then the chain)
 //               and adds its tag bits to the read's votes in LDS.
 //   C  votes  : one lane per read stores {vote0, vote1}; k_commit_votes does the per-barcode bookkeeping.
@@ -110,7 +114,7 @@ hipError_t launch_filter_build(const uint64_t *slots, TableGeom tg, void *filter
 constexpr int kThreadsF = 256;
 constexpr int kQCap = 128;                                    // queue entries per wave: < 64 waiting + <= 64 new
 #ifndef HAST_F_MINWAVES
-#define HAST_F_MINWAVES 5      // 96 VGPRs: measured best of 4/5/6/8 (242 vs 226-228 Gbp/s)
+#define HAST_F_MINWAVES 5      // 96 VGPRs: measured best of 4/5/6/8 (242 vs 226-228 Gbp/s with prints; exact entries: 4, 5, 6 within 1.5 %)
 #endif
 typedef unsigned long long u64x2f __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
