@@ -183,9 +183,12 @@ class BlockSource {
                 const char *e = getenv("HAST_BGZF_THREADS");
                 bgzf_reader_.open(fp_, e ? atoi(e) : (int)std::min(16u, std::max(2u, hw / 8)));
             } else if (gz_threads() > 1 && ParGzReader::usable(fp_)) {
-                // an ordinary gzip stream in a regular file: several threads at once (par_inflate.h)
+                // an ordinary gzip stream in a regular file: several threads at once (par_inflate.h).  The files open at
+                // the same time share a budget of inflate threads (a thread inflates ~1 GB/s alone, ~0.6 GB/s as one of 16:
+                // four files with 8 threads each were slower than with 4 each on the 1-GPU share of an MI355X host)
                 pargz_ = true;
-                par_reader_.open(fp_, gz_threads());
+                const int open_now = gz_open_files().fetch_add(1) + 1;
+                par_reader_.open(fp_, std::max(2, std::min(gz_threads(), gz_budget() / open_now)));
             } else inflater_.open(fp_, 4u << 20);
         } else if (path == "-") {
             fp_ = stdin;
@@ -207,7 +210,10 @@ class BlockSource {
         }
         cv_.notify_all();
         if (reader_.joinable()) reader_.join();
-        if (pargz_) par_reader_.close();
+        if (pargz_) {
+            par_reader_.close();
+            gz_open_files().fetch_sub(1);
+        }
         pargz_ = false;
         if (gz_) gzclose(gz_);
         if (fp_ && fp_ != stdin) fclose(fp_);
@@ -351,6 +357,15 @@ class BlockSource {
         if (const char *e = getenv("HAST_GZ_THREADS")) return std::max(1, atoi(e));
         const unsigned hw = std::thread::hardware_concurrency();
         return (int)std::min(8u, std::max(2u, hw / 8));
+    }
+    // inflate threads over all ordinary .gz files open at once (HAST_GZ_BUDGET)
+    static int gz_budget() {
+        if (const char *e = getenv("HAST_GZ_BUDGET")) return std::max(1, atoi(e));
+        return 16;
+    }
+    static std::atomic<int> &gz_open_files() {
+        static std::atomic<int> n{0};
+        return n;
     }
     static constexpr int kMaxReaders = 32;
     int readers_ = 4;

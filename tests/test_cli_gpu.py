@@ -175,9 +175,13 @@ def test_cli_gz_decoders_agree_and_damaged_gz_is_an_error(exe, golden_workdir, t
     a = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_INFLATE="zlib"))
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 100
+    # one gzip stream inflated by several threads (par_inflate.h), and by the serial decoder alone
+    for gz_threads in ("1", "2", "5", "16"):
+        c = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_GZ_THREADS=gz_threads))
+        assert c.returncode == 0 and c.stdout == a.stdout, (gz_threads, c.stderr[-300:])
     whole = (d / "r2.fq.gz").read_bytes()
     (d / "r2.fq.gz").write_bytes(whole[:len(whole) // 2])
-    for env in (None, dict(os.environ, HAST_INFLATE="zlib")):
+    for env in (None, dict(os.environ, HAST_INFLATE="zlib"), dict(os.environ, HAST_GZ_THREADS="1"), dict(os.environ, HAST_GZ_THREADS="6")):
         r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 2 and r.stdout == b"", r.stderr[-300:]
 
