@@ -734,6 +734,70 @@ def test_baseline_size_configs_vs_oracle(built, oracle_lib, name, n_keys, n_bc, 
     assert int(e[0].sum()) + int(e[1].sum()) > n_reads // 2 and int(e[2].sum()) > 0
 
 
+def test_baseline_config5_size_vs_oracle(built, oracle_lib):
+    """BASELINE config 5 at its full table size on one GPU: K=31, 400M + 400M keys, PacBio-style 20-kb reads, barcode-free
+    per-read (hits0, hits1) (S03/src_main/classify.cpp:203-218).  The stage-03 oracle keeps its keys as strings (800M of
+    them do not fit a test); on reads without 'N' its hits are the stage-01 votes -- the number of windows whose canonical
+    k-mer is in set h (classify.cpp:194-206) -- so the integer oracle with its two full-size sets is the checker for those
+    reads, and a read WITH an 'N' must count exactly the windows that do not hold it (checked on the windows' own keys)."""
+    k, L, n_keys, n_reads = 31, 20000, 400_000_000, 1500
+    threads = len(os.sched_getaffinity(0))
+    p = make_params(k, L, n_keys, 1)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys, 0.2)
+        ctx.synth_table_build(p)
+        sizes = ctx.table_sizes()
+        d_b, d_v = ctx.alloc(n_reads * L + 64), ctx.alloc(n_reads * 8)
+        d_o = ctx.to_device(np.arange(n_reads + 1, dtype=np.uint64) * L)
+        ctx.synth_reads_device(p, 77_000_000, n_reads, d_b, 0)
+        ctx.classify_perread_device(d_b, n_reads * L, d_o, n_reads, d_v)
+        ctx.sync()
+        votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+        bases = ctx.to_host(d_b, (n_reads * L,), np.uint8)
+        assert ctx.filter_mode() == 1                                  # K - m = 17 bases do not fit an exact entry: prints
+        oc = oracle_lib.ho_new()
+        d_k = ctx.alloc(n_keys * 8)
+        for h in (0, 1):
+            ctx.synth_keys_device(p, h, 0, n_keys, d_k)
+            ctx.sync()
+            keys = ctx.to_host(d_k, (n_keys,), np.uint64)
+            assert oracle_lib.ho_load_keys_mt(oc, keys.ctypes.data, keys.size, h, k, threads) == 0
+            del keys
+        for f in (d_b, d_v, d_k, d_o):
+            ctx.free(f)
+    assert sizes == (oracle_lib.ho_set_size(oc, 0), oracle_lib.ho_set_size(oc, 1))
+    # reads with an 'N': the oracle sees them with the N replaced (a window over the N then matches nothing it should not:
+    # the replacement bases are part of no planted k-mer), cut at the N into two reads whose windows are exactly the
+    # windows that do not hold it
+    rows = bases.reshape(n_reads, L)
+    has_n = (rows == ord("N")).any(axis=1)
+    pieces, owner = [], []
+    for i in range(n_reads):
+        if not has_n[i]:
+            pieces.append(rows[i])
+            owner.append(i)
+        else:
+            cut = np.flatnonzero(rows[i] == ord("N"))
+            assert cut.size == 1
+            for part in (rows[i][:cut[0]], rows[i][cut[0] + 1:]):
+                if part.size >= k:
+                    pieces.append(part)
+                    owner.append(i)
+    lens = np.array([x.size for x in pieces], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    flat = np.ascontiguousarray(np.concatenate(pieces))
+    ids = np.zeros(len(pieces), np.uint32)
+    pv = np.zeros((len(pieces), 2), np.uint32)
+    e = [np.zeros(1, np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids_votes(oc, flat.ctypes.data, off.ctypes.data, ids.ctypes.data, len(pieces), e[0].ctypes.data,
+                                     e[1].ctypes.data, e[2].ctypes.data, None, pv.ctypes.data, threads)
+    oracle_lib.ho_free(oc)
+    exp = np.zeros((n_reads, 2), np.uint32)
+    np.add.at(exp, np.array(owner), pv)
+    assert np.array_equal(votes, exp)
+    assert int(exp.sum()) > n_reads // 2 and int(has_n.sum()) > 0
+
+
 def _n_gpus():
     import ctypes
     try:
