@@ -131,7 +131,8 @@ if method:
     if "SQ_INSTS_VALU" in kc:
         L, K = bench["config"]["read_len"], bench["config"]["k"]
         summary["valu_lane_instructions_per_window"] = kc["SQ_INSTS_VALU"] * 64 / (bench["config"]["batch_reads"] * (L - K + 1))
-    json.dump({"workload": "c3", "bench_flags": flags, "batch_reads": bench["config"]["batch_reads"],
+    wl = flags.split("--workload")[1].split()[0] if "--workload" in flags else "c3"
+    json.dump({"workload": wl, "bench_flags": flags, "batch_reads": bench["config"]["batch_reads"],
                "kernel_source_id": summary["kernel_source_id"],
                "hbm_bytes_per_launch": fetch + write, "hbm_read_requests_per_launch": req,
                "bytes_per_read_request": summary["bytes_per_read_request"],
