@@ -83,7 +83,6 @@ class ParGzReader {
         done_ = false;
         stop_ = false;
         ready_.reset();
-        bg_failed_ = false;
         // stream state the producer carries from batch to batch
         next_bit_ = 0;
         in_base_ = 0;
@@ -119,7 +118,7 @@ class ParGzReader {
                     break;
                 }
                 std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [this] { return ready_ || bg_failed_ || stop_; });
+                cv_.wait(g, [this] { return ready_ || stop_; });
                 if (!ready_) {
                     if (err_.empty()) err_ = "gz: decoder stopped";
                     return -1;
@@ -803,7 +802,7 @@ class ParGzReader {
     std::mutex mu_;
     std::condition_variable cv_;
     std::unique_ptr<Batch> ready_;
-    bool stop_ = false, bg_failed_ = false;
+    bool stop_ = false;
     std::thread bg_;
     std::mutex spare_mu_;
     std::vector<std::unique_ptr<Chunk>> spare_;
