@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             if (STRICT) {
                 uint16_t *di = reinterpret_cast<uint16_t *>(s_inv + (size_t)r * IW + (j >> 1)) + (1 - (j & 1));
                 *di = (uint16_t)invalid;
+                if (invalid) atomicOr(&s_flag[r], 1u);                          // the row holds a byte outside ACGT somewhere
             } else if (nflag) atomicOr(&s_flag[r], 1u);
         }
         __syncthreads();
@@ -355,9 +356,12 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             const uint32_t len = s_len[r];
             bool ok = inq & (p + K <= len);
             if (STRICT) {           // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
-                const uint32_t *iw = s_inv + mul24(r, IW) + (p >> 5);
-                const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
-                ok = ok & ((bits >> (64 - K)) == 0);
+                // (rows without such a byte -- nearly all of them -- are flagged clean by phase A: the wave skips the masks)
+                if (ballot64(s_flag[r] != 0)) {
+                    const uint32_t *iw = s_inv + mul24(r, IW) + (p >> 5);
+                    const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
+                    ok = ok & ((bits >> (64 - K)) == 0);
+                }
             }
             const unsigned long long fwd = window_bits(s_pack + mul24(r, WS), p, kshift);
             const uint32_t *l1 = s_l1 + mul24(r, L1S) + p;
