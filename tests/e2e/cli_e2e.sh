@@ -7,6 +7,8 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 NP=${1:-1000000}; NK=${2:-1000000}; NB=${3:-10000}; TAG=${4:-c1}
+# each read pair is ~680 bytes of FASTQ, each key 22 bytes of text: refuse sizes that would fill the box's /tmp
+if [ "$NP" -gt 30000000 ] || [ "$NK" -gt 500000000 ]; then echo "cli_e2e.sh: $NP read pairs / $NK keys is more than this script may write" >&2; exit 2; fi
 D=$(mktemp -d /tmp/hast_e2e.XXXXXX)
 OUT=gpurun_out/cli_e2e_$TAG.json
 mkdir -p gpurun_out

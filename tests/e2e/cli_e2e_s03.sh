@@ -5,6 +5,8 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 NR=${1:-5000}; NK=${2:-2000000}; L=${3:-20000}; TAG=${4:-s03}
+# the FASTQ written below is ~2 x NR x L bytes: refuse sizes that would fill the box's /tmp (argument order: reads, KEYS, length)
+if [ $((NR * L)) -gt 8000000000 ] || [ "$NK" -gt 500000000 ]; then echo "cli_e2e_s03.sh: $NR reads x $L bases / $NK keys is more than this script may write" >&2; exit 2; fi
 D=$(mktemp -d /tmp/hast_e2e_s03.XXXXXX)
 OUT=gpurun_out/cli_e2e_$TAG.json
 mkdir -p gpurun_out

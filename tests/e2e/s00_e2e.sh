@@ -7,6 +7,8 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 G=${1:-5000000}; COV=${2:-30}; NF=${3:-2}; TAG=${4:-s00}
+# the four FASTQ sets hold ~4 x G x COV bytes: refuse sizes that would fill the box's /tmp
+if [ $((G * COV)) -gt 4000000000 ]; then echo "s00_e2e.sh: a $G-base genome at ${COV}x is more than this script may write" >&2; exit 2; fi
 D=$(mktemp -d /tmp/hast_e2e_s00.XXXXXX)
 OUT=$PWD/gpurun_out/cli_e2e_$TAG.json
 mkdir -p gpurun_out
