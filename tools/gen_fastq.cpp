@@ -29,6 +29,17 @@ int main(int argc, char **argv) {
     SynthParams p{0x4841535401ull, 0x4841535402ull, 0x4841535403ull, n_keys, (uint32_t)strtoul(argv[4], 0, 10),
                   argc > 6 ? (uint32_t)atoi(argv[6]) : 150u, argc > 5 ? (uint32_t)atoi(argv[5]) : 21u, 0};
     const int threads = argc > 7 ? atoi(argv[7]) : 8;
+    // what this run would write: two key files of K+1 bytes per line, two FASTQ files of ~2L+40 bytes per record.  Refused above
+    // 64 GB (GEN_FASTQ_MAX_GB): a swapped argument once asked for 100 000 reads of 5 Mbp and took the machine down with it.
+    {
+        const double bytes = 2.0 * (double)n_keys * (p.k + 1) + 2.0 * (double)n_pairs * (2.0 * p.read_len + 40);
+        const double cap = (getenv("GEN_FASTQ_MAX_GB") ? atof(getenv("GEN_FASTQ_MAX_GB")) : 64.0) * 1e9;
+        if (bytes > cap || p.k < 1 || p.k > 32 || p.read_len < p.k) {
+            fprintf(stderr, "gen_fastq: %llu pairs of %u bp + %llu %u-mers per haplotype = %.1f GB: refused (limit %.0f GB, GEN_FASTQ_MAX_GB)\n",
+                    (unsigned long long)n_pairs, p.read_len, (unsigned long long)n_keys, p.k, bytes / 1e9, cap / 1e9);
+            return 1;
+        }
+    }
     if (argc > 8 && atoi(argv[8])) p.reserved = 1;            // clustered keys (runs of K windows around variant sites)
     for (int h = 0; h < 2; h++) {
         FILE *f = fopen((dir + "/hap" + std::to_string(h) + ".mer").c_str(), "wb");
