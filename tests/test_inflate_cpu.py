@@ -323,3 +323,44 @@ def test_parallel_inflate_bounds_a_chunks_output(driver, tmp_path):
     for chunk, threads, max_out in ((1 << 20, 4, 100_000), (2_000, 3, 50_000), (1 << 20, 2, 1), (500, 5, 1 << 30)):
         r = subprocess.run([driver, "-P", "-c", str(chunk), "-t", str(threads), "-m", str(max_out), "-p", str(1 << 22), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0 and r.stdout == data, (chunk, threads, max_out, r.stderr[-300:])
+
+
+# ---- the byte source of every CLI (hast_amd/csrc/ingest.h: BlockSource) picks the decoder by what the file is ---------------------
+def test_block_source_routes_every_kind_of_input(tmp_path):
+    """plain file, ordinary gzip (parallel inflate, serial decoder, zlib), blocked gzip with and without an ordinary member
+    behind it, a .gz name on plain bytes, an empty file -- through the background reader and through read_into(), alone and
+    several files open at once (they share the inflate-thread budget); a damaged .gz is an error on every route"""
+    exe = tmp_path / "test_blocksource"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "test_blocksource.cpp"), "-lz"], check=True)
+    rng = random.Random(31)
+    data = fastq(rng, 12000)
+    files = {"plain.fq": data, "ord.fq.gz": member(data, 6), "two.fq.gz": member(data[:1_000_000], 1) + member(data[1_000_000:], 9),
+             "blocked.fq.gz": bgzf(data), "blocked_tail.fq.gz": bgzf(data[:900_000], tail=data[900_000:]), "notgz.fq.gz": data, "empty.fq.gz": b"",
+             "empty.fq": b""}
+    for name, blob in files.items():
+        (tmp_path / name).write_bytes(blob)
+    want = {name: (b"" if name.startswith("empty") else data) for name in files}
+    envs = [{}, {"HAST_GZ_THREADS": "1"}, {"HAST_GZ_THREADS": "5", "HAST_GZ_BUDGET": "5"}, {"HAST_INFLATE": "zlib"}, {"HAST_BGZF_THREADS": "3"}]
+    for env in envs:
+        for name in files:
+            for extra in ([], ["-u"], ["-b", "70000"], ["-u", "-b", "4194304"]):
+                r = subprocess.run([str(exe)] + extra + [str(tmp_path / name)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+                assert r.returncode == 0 and r.stdout == want[name], (env, name, extra, r.stderr[-300:])
+    # all of them open at once
+    names = [n for n in files]
+    for env in envs[:3]:
+        r = subprocess.run([str(exe)] + [str(tmp_path / n) for n in names], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout == b"".join(want[n] for n in names), (env, r.stderr[-300:])
+    # damage
+    whole = files["ord.fq.gz"]
+    (tmp_path / "cut.fq.gz").write_bytes(whole[:len(whole) // 2])
+    flipped = bytearray(whole)
+    flipped[len(flipped) // 2] ^= 0x10
+    (tmp_path / "flip.fq.gz").write_bytes(bytes(flipped))
+    for env in envs[:4]:
+        for name in ("cut.fq.gz", "flip.fq.gz"):
+            for extra in ([], ["-u"]):
+                r = subprocess.run([str(exe)] + extra + [str(tmp_path / name)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+                assert r.returncode == 3, (env, name, extra, r.returncode, r.stderr[-300:])
+                assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr
