@@ -273,24 +273,9 @@ int main(int argc, char **argv) {
     } else {
     // K = length of the first line of hap0 (classify.cpp:35-36); the files themselves are streamed into the table by the
     // library (hast_table_insert_text_file), a pipe or the like is read into memory first
-    std::vector<char> head;
-    {
-        FILE *f = fopen(hap0.c_str(), "rb");
-        if (!f) die(2, ("cannot read " + hap0).c_str());
-        head.resize(4096);
-        head.resize(fread(head.data(), 1, head.size(), f));
-        fclose(f);
-    }
-    const void *nl0 = memchr(head.data(), '\n', head.size());
-    K = nl0 ? (size_t)((const char *)nl0 - head.data()) : head.size();   // :35-36
-    if (K < 1 || K > 32) {
-        fprintf(stderr, "classify: ERROR: K=%zu%s (length of the first line of %s) is outside [1,32]\n", K, (!nl0 && head.size() == 4096) ? " or more" : "", hap0.c_str());
-        return 3;
-    }
-    if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
-    contexts_ready();
+    // (a pipe can be read only once: it is read whole now and its first bytes serve as the head)
     const std::string *hap_path[2] = {&hap0, &hap1};
-    std::vector<char> txt[2];
+    std::vector<char> txt[2], head;
     bool streamed[2] = {false, false};
     size_t text_bytes[2] = {0, 0};
     for (int h = 0; h < 2; h++) {
@@ -303,6 +288,21 @@ int main(int argc, char **argv) {
             text_bytes[h] = txt[h].size();
         }
     }
+    if (streamed[0]) {
+        FILE *f = fopen(hap0.c_str(), "rb");
+        if (!f) die(2, ("cannot read " + hap0).c_str());
+        head.resize(4096);
+        head.resize(fread(head.data(), 1, head.size(), f));
+        fclose(f);
+    } else head.assign(txt[0].begin(), txt[0].begin() + (long)std::min<size_t>(txt[0].size(), 4096));
+    const void *nl0 = memchr(head.data(), '\n', head.size());
+    K = nl0 ? (size_t)((const char *)nl0 - head.data()) : head.size();   // :35-36
+    if (K < 1 || K > 32) {
+        fprintf(stderr, "classify: ERROR: K=%zu%s (length of the first line of %s) is outside [1,32]\n", K, (!nl0 && head.size() == 4096) ? " or more" : "", hap0.c_str());
+        return 3;
+    }
+    if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+    contexts_ready();
     CK(hast_table_reserve(ctx, text_bytes[0] / (K + 1) + text_bytes[1] / (K + 1) + 2, 0.0), "allocating the k-mer table");
     for (int h = 0; h < 2; h++) {
         fprintf(stderr, "__load hap%d kmers__\n", h);

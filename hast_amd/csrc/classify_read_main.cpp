@@ -85,18 +85,8 @@ int main(int argc, char **argv) {
     // ---- load_kmers (s03:51-70) --------------------------------------------------------------------
     // K = length of the first line of the first file (s03:57-58); regular files are streamed into the table by the library,
     // which also checks on the device that every line is K upper-case A/C/G/T bytes; anything else is read into memory first
-    std::vector<char> head;
-    {
-        FILE *f = fopen(haps[0].c_str(), "rb");
-        if (!f) die(2, "cannot read " + haps[0]);
-        head.resize(4096);
-        head.resize(fread(head.data(), 1, head.size(), f));
-        fclose(f);
-    }
-    const void *nl0 = memchr(head.data(), '\n', head.size());
-    const size_t K = nl0 ? (size_t)((const char *)nl0 - head.data()) : head.size();   // s03:57-58
-    if (K < 1 || K > 32) die(3, "K (length of the first k-mer line) must be in [1,32]");
-    std::vector<char> txt[2];
+    // (a pipe can be read only once: it is read whole now and its first bytes serve as the head)
+    std::vector<char> txt[2], head;
     bool streamed[2] = {false, false};
     size_t text_bytes[2] = {0, 0};
     for (int h = 0; h < 2; h++) {
@@ -109,6 +99,16 @@ int main(int argc, char **argv) {
             text_bytes[h] = txt[h].size();
         }
     }
+    if (streamed[0]) {
+        FILE *f = fopen(haps[0].c_str(), "rb");
+        if (!f) die(2, "cannot read " + haps[0]);
+        head.resize(4096);
+        head.resize(fread(head.data(), 1, head.size(), f));
+        fclose(f);
+    } else head.assign(txt[0].begin(), txt[0].begin() + (long)std::min<size_t>(txt[0].size(), 4096));
+    const void *nl0 = memchr(head.data(), '\n', head.size());
+    const size_t K = nl0 ? (size_t)((const char *)nl0 - head.data()) : head.size();   // s03:57-58
+    if (K < 1 || K > 32) die(3, "K (length of the first k-mer line) must be in [1,32]");
     hast_ctx *ctx = nullptr;
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
     if (hast_ctx_set_text_check(ctx, 1) != HAST_OK) die(4, "cannot create GPU context");

@@ -31,6 +31,29 @@ def test_cli_matches_reference_golden(exe, golden_workdir, case, run, extra):
     assert mine == meta["ref_log"]
 
 
+def test_cli_kmer_files_may_be_pipes(exe, golden_workdir):
+    """regular k-mer files are streamed into the table by pread workers; anything else (here: both files through `cat`) can
+    only be read once, front to back -- same stdout, same "Recorded" lines"""
+    case, run = golden_cases("s01")[0]
+    meta = load_case(case)["runs"][run]
+    d = golden_workdir / case
+    argv = list(meta["argv"])
+    files = {}
+    for flag in ("--hap0", "--hap1", "-p", "-m"):
+        if flag in argv:
+            files[flag] = argv[argv.index(flag) + 1]
+    assert len(files) == 2
+    import shlex
+    cmd = []
+    for a in [exe] + argv:
+        cmd.append("<(cat %s)" % shlex.quote(a) if a in files.values() else shlex.quote(a))
+    res = subprocess.run(["bash", "-c", " ".join(cmd)], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert res.stdout == open(d / meta["expected"], "rb").read()
+    mine = [l for l in res.stderr.decode().splitlines() if l.startswith("Recorded") or "erase a adaptor" in l]
+    assert mine == meta["ref_log"]
+
+
 def _n_gpus():
     import ctypes
     try:
