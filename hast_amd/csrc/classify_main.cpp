@@ -82,15 +82,21 @@ void print_usage() {                              // same flags as the reference
 }
 #define CK(call, what) do { if ((call) != HAST_OK) die(4, what); } while (0)
 
+// the whole input, front to back (also from a pipe, which has no size to ask for)
 bool slurp(const std::string &path, std::vector<char> &out) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(sz > 0 ? (size_t)sz : 0);
-    bool ok = sz <= 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+    out.clear();
+    size_t have = 0;
+    for (;;) {
+        if (out.size() - have < (1u << 20)) out.resize(std::max<size_t>(out.size() * 2, 4u << 20));
+        const size_t n = fread(out.data() + have, 1, out.size() - have, f);
+        have += n;
+        if (n == 0) break;
+    }
+    const bool ok = !ferror(f);
     fclose(f);
+    out.resize(have);
     return ok;
 }
 
