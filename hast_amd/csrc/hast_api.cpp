@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -389,6 +390,61 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
     return HAST_OK;
 }
 
+// A region of a regular file through the device, piece by piece: eight threads pread the next piece into pinned memory while
+// the previous one is copied to the device and consumed by `use(d_piece, bytes, first_unit)` (which enqueues on c->stream).
+// Pieces hold whole units of `unit` bytes.  HAST_OK / HAST_ERR_IO (short file) / HAST_ERR_HIP.
+static hast_status stream_file_region(hast_ctx *c, int fd, const char *path, uint64_t file_off, uint64_t n_units, size_t unit,
+                                      const std::function<hipError_t(char *, size_t, uint64_t)> &use) {
+    const uint64_t per = std::max<uint64_t>(1, (32u << 20) / unit);             // units per piece
+    const size_t piece = (size_t)(per * unit);
+    char *h_buf[2] = {nullptr, nullptr};
+    char *d_buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    bool short_read = false;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc((void **)&h_buf[i], piece, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_buf[i], piece + 16);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        const int nthreads = 8;
+        WorkerPool pool(nthreads);
+        size_t i = 0;
+        for (uint64_t first = 0; first < n_units && e == hipSuccess; first += per, ++i) {
+            const int b = (int)(i & 1);
+            const size_t m = (size_t)std::min<uint64_t>(per, n_units - first), bytes = m * unit;
+            if (i >= 2) e = hipEventSynchronize(done[b]);                       // the piece that used this buffer is on the device
+            if (e != hipSuccess) break;
+            const size_t share = ((bytes / nthreads) + 4095) & ~(size_t)4095;
+            std::atomic<bool> bad{false};
+            pool.run([&](int t) {
+                const size_t from = std::min(bytes, share * (size_t)t), to = std::min(bytes, from + share);
+                size_t got = 0;
+                while (from + got < to) {
+                    const ssize_t r = pread(fd, h_buf[b] + from + got, to - from - got, (off_t)(file_off + first * unit + from + got));
+                    if (r <= 0) { bad = true; break; }
+                    got += (size_t)r;
+                }
+            });
+            if (bad) { short_read = true; break; }
+            e = hipMemcpyAsync(d_buf[b], h_buf[b], bytes, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = use(d_buf[b], m, first);
+            if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
+        }
+        const hipError_t e2 = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (d_buf[i]) (void)hipFree(d_buf[i]);
+        if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+    }
+    if (e != hipSuccess) return fail(HAST_ERR_HIP, "%s: %s", path, hipGetErrorString(e));
+    if (short_read) return fail(HAST_ERR_IO, "%s is shorter than its size says (truncated, or changed while it was read)", path);
+    return HAST_OK;
+}
+
 // The same from a FILE, streamed: the reference reads a k-mer file line by line (classify.cpp:30-46; 4.4 GB per haplotype at
 // the BASELINE sizes); here several threads pread the next piece into pinned memory while the previous one is copied to
 // the device and inserted, so the load runs at the page cache's / the storage's rate instead of one thread's.
@@ -412,54 +468,10 @@ hast_status hast_table_insert_text_file(hast_ctx *c, int hap, const char *path, 
         if (memchr(tail, '\n', rem)) { close(fd); return fail(HAST_ERR_FORMAT, "k-mer text: ragged last line"); }
     }
     table_changed(c);
-    const size_t per = std::max<size_t>(1, (32u << 20) / stride);             // lines per piece
-    const size_t piece = per * stride;
-    char *h_buf[2] = {nullptr, nullptr};
-    char *d_buf[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    hast_status st = HAST_OK;
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipHostMalloc((void **)&h_buf[i], piece, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_buf[i], piece + 16);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-    }
-    if (e == hipSuccess) {
-        const int nthreads = 8;
-        WorkerPool pool(nthreads);
-        bool short_read = false;
-        size_t i = 0;
-        for (size_t line = 0; line < n_lines && e == hipSuccess && !short_read; line += per, ++i) {
-            const int b = (int)(i & 1);
-            const size_t m = std::min(per, n_lines - line), bytes = m * stride;
-            if (i >= 2) e = hipEventSynchronize(done[b]);                       // the piece that used this buffer is on the device
-            if (e != hipSuccess) break;
-            const size_t share = ((bytes / nthreads) + 4095) & ~(size_t)4095;
-            std::atomic<bool> bad{false};
-            pool.run([&](int t) {
-                const size_t from = std::min(bytes, share * (size_t)t), to = std::min(bytes, from + share);
-                size_t got = 0;
-                while (from + got < to) {
-                    const ssize_t r = pread(fd, h_buf[b] + from + got, to - from - got, (off_t)(line * stride + from + got));
-                    if (r <= 0) { bad = true; break; }
-                    got += (size_t)r;
-                }
-            });
-            if (bad) { short_read = true; break; }
-            e = hipMemcpyAsync(d_buf[b], h_buf[b], bytes, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = launch_insert_text(c->d_slots, geom(c), d_buf[b], m, (uint32_t)hap, c->text_acgt_only, c->d_err, c->stream);
-            if (e == hipSuccess) e = hipEventRecord(done[b], c->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (short_read) st = fail(HAST_ERR_IO, "%s changed while it was read", path);
-    }
-    for (int i = 0; i < 2; ++i) {
-        if (done[i]) (void)hipEventDestroy(done[i]);
-        if (d_buf[i]) (void)hipFree(d_buf[i]);
-        if (h_buf[i]) (void)hipHostFree(h_buf[i]);
-    }
+    const hast_status st = stream_file_region(c, fd, path, 0, n_lines, stride, [&](char *d_piece, size_t m, uint64_t) {
+        return launch_insert_text(c->d_slots, geom(c), d_piece, m, (uint32_t)hap, c->text_acgt_only, c->d_err, c->stream);
+    });
     close(fd);
-    if (e != hipSuccess) return fail(HAST_ERR_HIP, "k-mer text: %s", hipGetErrorString(e));
     if (st != HAST_OK) return st;
     if (hast_status s2 = check_err_word(c, c->stream)) return s2;
     if (lines_out) *lines_out = n_lines;
@@ -598,16 +610,25 @@ hast_status hast_table_load(hast_ctx *c, const char *path, double load_factor) {
         return fail(HAST_ERR_INVALID, "%s holds %u-mers, the context is K=%d", path, h.k, c->k);
     }
     hast_status st = hast_table_reserve(c, h.n_slots + 1, load_factor);
-    const size_t per = kChunkBytes / sizeof(uint64_t);
-    std::vector<uint64_t> buf(std::min<uint64_t>(per, h.n_slots ? h.n_slots : 1));
-    if (st == HAST_OK) st = ensure_scratch(c, buf.size() * sizeof(uint64_t) + 16);
-    for (uint64_t i = 0; st == HAST_OK && i < h.n_slots; i += per) {
-        const size_t m = (size_t)std::min<uint64_t>(per, h.n_slots - i);
-        if (fread(buf.data(), sizeof(uint64_t), m, f) != m) { st = fail(HAST_ERR_IO, "%s is truncated", path); break; }
-        hipError_t e = hipMemcpyAsync(c->d_scratch, buf.data(), m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = launch_import_slots(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, c->d_err, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) st = fail(HAST_ERR_HIP, "table import: %s", hipGetErrorString(e));
+    struct stat sb;
+    if (st == HAST_OK && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode)) {
+        // a regular file: streamed like the k-mer text (pread workers + pinned double buffer)
+        st = stream_file_region(c, fileno(f), path, sizeof(CacheHeader), h.n_slots, sizeof(uint64_t), [&](char *d_piece, size_t m, uint64_t) {
+            return launch_import_slots(c->d_slots, geom(c), (const uint64_t *)d_piece, m, c->d_err, c->stream);
+        });
+        if (st == HAST_ERR_IO) st = fail(HAST_ERR_IO, "%s is truncated", path);
+    } else {
+        const size_t per = kChunkBytes / sizeof(uint64_t);
+        std::vector<uint64_t> buf(std::min<uint64_t>(per, h.n_slots ? h.n_slots : 1));
+        if (st == HAST_OK) st = ensure_scratch(c, buf.size() * sizeof(uint64_t) + 16);
+        for (uint64_t i = 0; st == HAST_OK && i < h.n_slots; i += per) {
+            const size_t m = (size_t)std::min<uint64_t>(per, h.n_slots - i);
+            if (fread(buf.data(), sizeof(uint64_t), m, f) != m) { st = fail(HAST_ERR_IO, "%s is truncated", path); break; }
+            hipError_t e = hipMemcpyAsync(c->d_scratch, buf.data(), m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_import_slots(c->d_slots, geom(c), (const uint64_t *)c->d_scratch, m, c->d_err, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) st = fail(HAST_ERR_HIP, "table import: %s", hipGetErrorString(e));
+        }
     }
     fclose(f);
     if (st != HAST_OK) return st;
