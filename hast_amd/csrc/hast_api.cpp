@@ -816,13 +816,21 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
     HIP_TRY(launch_count_tags(c->d_slots, geom(c), c->d_cnt, hs));
     HIP_TRY(hipMemcpyAsync(h, c->d_cnt, sizeof(h), hipMemcpyDeviceToHost, hs));
     HIP_TRY(hipStreamSynchronize(hs));
-    const FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t, c->filter_kp, c->k == 32 ? 0 : c->filter_exact);
-    const size_t bytes = (size_t)filter_nblocks(fg) * 128;
+    FilterGeom fg = filter_geom_for(c->k, h[0] + h[1], c->filter_m, c->filter_t, c->filter_kp, c->k == 32 ? 0 : c->filter_exact);
+    size_t bytes = (size_t)filter_nblocks(fg) * 128;
     if (bytes != c->filter_bytes) {
         if (c->d_filter) HIP_TRY(hipFree(c->d_filter));
         c->d_filter = nullptr;
         c->filter_bytes = 0;
-        if (hipMalloc(&c->d_filter, bytes) != hipSuccess) {
+        hipError_t got = hipMalloc(&c->d_filter, bytes);
+        if (got != hipSuccess && !c->filter_m && fg.m == kFilterMaxM) {
+            // no room for 4^15 blocks (137 GB, what 800M keys ask for): 4^14 with two choices per print, as up to round 2
+            (void)hipGetLastError();
+            fg = filter_geom_for(c->k, h[0] + h[1], kFilterMaxM - 1, c->filter_t, c->filter_kp, c->k == 32 ? 0 : c->filter_exact);
+            bytes = (size_t)filter_nblocks(fg) * 128;
+            got = hipMalloc(&c->d_filter, bytes);
+        }
+        if (got != hipSuccess) {
             // no room for the filter next to the table (34 GB at 14-mers): probe the table directly, as round 1 did -- the same
             // GPU path minus the front end, same results (hast_filter_info tells)
             (void)hipGetLastError();

@@ -130,15 +130,16 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
 // found room), is a POSITIVE and is looked up in the exact table, which alone decides hits and tag bits; everything else is a proven
 // miss.  So the filter can only cost time, never change a result.
 struct FilterGeom {
-    int k, m, t;            // k-mer, sampled m-mer (m <= 14, 4^m blocks), ordering t-mer (t <= m)
+    int k, m, t;            // k-mer, sampled m-mer (m <= 15, 4^m blocks), ordering t-mer (t <= m)
     int kp;                 // the sampling only looks at the first kp bases of a window (kp <= k): W = kp-m+1 candidates
     int g;                  // entries per first-level minimum of the kernel's sliding window: min(4, kp-t+1)
     uint32_t wdiv;          // floor(2^16 / W) + 1: x / W for x < 64 by multiply-shift
     int exact;              // 1: the 16-bit entries are EXACT codes of the filed strings (below), one sub-bucket per string
+    int choices;            // prints: sub-buckets a print may sit in (2, or 1 where the blocks are lightly loaded)
 };
 constexpr int kFilterSubs = 8;                    // 16-B sub-buckets per 128-B block
 constexpr int kFilterPrints = 8;                  // 16-bit prints per sub-bucket
-constexpr int kFilterMaxM = 14;                   // 4^14 blocks = 34 GB
+constexpr int kFilterMaxM = 15;                   // 4^15 blocks = 137 GB (4^14 = 34 GB)
 HAST_HD uint32_t filter_w(const FilterGeom &g) { return (uint32_t)(g.kp - g.m + 1); }
 HAST_HD uint32_t filter_nt(const FilterGeom &g) { return (uint32_t)(g.kp - g.t + 1); }
 HAST_HD uint64_t filter_nblocks(const FilterGeom &g) { return 1ull << (2 * g.m); }
@@ -218,6 +219,7 @@ HAST_HD uint32_t filter_exact_code(uint64_t fwd, uint32_t pm, const FilterGeom &
 }
 HAST_HD uint32_t filter_exact_sub(uint32_t code17) { return code17 >> 14; }
 HAST_HD uint32_t filter_exact_entry(uint32_t code17, uint32_t tags) { return ((code17 & 0x3FFFu) << 2) | tags; }   // tags 1..3: never 0
+// Geometry for K and a key count (m = 15, a 137-GB filter, only where the key count asks for it: above 537M keys).
 // Geometry for K and a key count.  Measured with tools/sim/filter_load_sim.cpp (unscaled: 400M keys, both strands filed):
 // what limits m from below is not the average load of a block but the skew of the sampling -- the sampled m-mers all hold
 // one of the window's lowest-ordered t-mers, so a fraction of the blocks takes most of the keys.  4^m >= 0.67 N keeps the
@@ -233,7 +235,7 @@ HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t
     g.k = k;
     int m = k < 8 ? k : 8;
     while (m < k && m < kFilterMaxM && (1ull << (2 * m)) * 3 < 2 * n_keys) ++m;
-    if (exact_mode && n_keys >= (16ull << 20) && k - 7 > m && k - 7 <= kFilterMaxM) m = k - 7;
+    if (exact_mode && n_keys >= (16ull << 20) && k - 7 > m && k - 7 <= 14) m = k - 7;
     if (m_override >= 1 && m_override <= k && m_override <= kFilterMaxM) m = m_override;
     g.m = m;
     int kp = k < m + 8 ? k : m + 8;
@@ -246,8 +248,12 @@ HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t
     const int nt = kp - t + 1;
     g.g = nt < 4 ? nt : 4;
     g.wdiv = (65536u / (uint32_t)w) + 1u;
-    g.exact = 0;
     g.exact = (exact_mode && filter_exact_fits(g)) ? 1 : 0;
+    // One choice where a block holds 2.2 strings or fewer on average (both strands filed): 800M 31-mers in 4^15 blocks (1.5 per
+    // block) leave no window to a full sub-bucket with one choice (tools/sim/filter_load_sim.cpp), and the probe saves its
+    // second load and compare -- config 5 is bound by VALU issue.  At 3 per block (400M keys, m = 14) one choice sends 0.5
+    // windows per read to the table and 6 per block (800M keys, m = 14) 11 % of them: two choices there.
+    g.choices = (2.0 * (double)n_keys <= 2.2 * (double)(1ull << (2 * m))) ? 1 : 2;
     return g;
 }
 

@@ -59,6 +59,10 @@ __device__ __forceinline__ void filter_insert(uint32_t *filt, const FilterGeom g
         const uint32_t h = filter_keyhash(s), fp = filter_print_of(h);
         uint32_t *b = filt + (size_t)blk * (kFilterSubs * kFilterPrints / 2);
         uint32_t *w1 = b + filter_sub_of(h) * (kFilterPrints / 2), *w2 = b + filter_sub2_of(h) * (kFilterPrints / 2);
+        if (g.choices == 1) {                                        // lightly loaded blocks: the one sub-bucket of the print
+            (void)sub_insert(w1, fp);
+            continue;
+        }
         // the less loaded of the two first; a print that is already in either one is not filed again
         bool there = false;
         for (int i = 0; i < kFilterPrints / 2 && !there; ++i) {
@@ -139,7 +143,8 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {      
 
 // NTC = first-level minima per window, ceil((K-t+1)/g), when known at compile time (0 = runtime loop)
 // EXACT: the filter holds exact entries (hast_common.h): one 16-B load per window, a match IS a hit with its tag bits
-template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT>
+// TWO: prints may sit in either of two sub-buckets (FilterGeom::choices == 2): two loads and compares per window
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO>
 __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
@@ -377,7 +382,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             const uint32_t xr = ((x & 0xFFFu) - p) & 63u;             // position of the smallest t-mer inside the window
             const uint32_t pm = xr - mul24(mul24(xr, fg.wdiv) >> 16, W);      // ... mod W = position of the sampled m-mer
             const uint32_t mm = (uint32_t)(fwd >> (2 * ((uint32_t)(K - M) - pm))) & mmask;
-            uint32_t fb = ok ? filter_block_of(mm, M) : 0xFFFFFFFFu;  // real blocks are < 4^14
+            uint32_t fb = ok ? filter_block_of(mm, M) : 0xFFFFFFFFu;  // real blocks are < 4^15
             // of the window as it stands (no canonical form in the probe): a hash for two sub-buckets and a print, or the
             // window's exact code, whose top bits are its one sub-bucket
             const uint32_t h = EXACT ? filter_exact_code(fwd, pm, fg) : filter_keyhash(fwd);
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
                 B.fpw = mul24((h & 0x3FFFu) ^ 0x3FFFu, 0x00040004u);          // the complement of the stored bits, in both halves
             } else {
                 B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
-                B.v2 = filt[(size_t)fb * kFilterSubs + filter_sub2_of(h)];
+                if (TWO) B.v2 = filt[(size_t)fb * kFilterSubs + filter_sub2_of(h)];
                 const uint32_t fp = filter_print_of(h);
                 B.fpw = fp | (fp << 16);
             }
@@ -418,11 +423,13 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
                 if (hit) atomicAdd(&s_vote[B.meta & 0xFFFFu], (unsigned long long)(m16 & 1u) | ((unsigned long long)((m16 >> 1) & 1u) << 32));
                 pos = valid && !hit && (B.v.w >> 16) != 0;               // no match in a FULL sub-bucket: the key may not have found room
             } else {
-            const uint32_t a1 = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
-            const uint32_t a2 = pk_min_u16(pk_min_u16(B.v2.x ^ B.fpw, B.v2.y ^ B.fpw), pk_min_u16(B.v2.z ^ B.fpw, B.v2.w ^ B.fpw));
-            const uint32_t acc = pk_min_u16(a1, a2);
+            uint32_t acc = pk_min_u16(pk_min_u16(B.v.x ^ B.fpw, B.v.y ^ B.fpw), pk_min_u16(B.v.z ^ B.fpw, B.v.w ^ B.fpw));
+            bool full = (B.v.w >> 16) != 0;
+            if (TWO) {
+                acc = pk_min_u16(acc, pk_min_u16(pk_min_u16(B.v2.x ^ B.fpw, B.v2.y ^ B.fpw), pk_min_u16(B.v2.z ^ B.fpw, B.v2.w ^ B.fpw)));
+                full = full && (B.v2.w >> 16) != 0;                                  // a key finds no room only when BOTH are full
+            }
             const bool match = ((acc - 0x00010001u) & ~acc & 0x80008000u) != 0;      // some halfword of acc is zero
-            const bool full = (B.v.w >> 16) != 0 && (B.v2.w >> 16) != 0;             // a key finds no room only when BOTH are full
             pos = (int)B.meta < 0 && (match || full);
             }
             const unsigned long long pmask = ballot64(pos);
@@ -481,37 +488,39 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     }
 }
 
-template <int NTC, bool FAST, bool STRICT, bool WIDE = false, bool EXACT = false>
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO>
 static hipError_t launch_f_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT>), dim3(grid), dim3(kThreadsF), smem, s, a);
+    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO>), dim3(grid), dim3(kThreadsF), smem, s, a);
     return hipGetLastError();
 }
 
-template <bool STRICT, bool EXACT>
+// EXACT implies one sub-bucket per window (TWO = false)
+template <bool STRICT, bool EXACT, bool TWO>
 static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     const bool fast = a.div_magic && a.div_l1g && a.div_hw;
-    if (a.wide) return fast ? launch_f_t<0, true, STRICT, true>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true>(a, grid, smem, s);
-    if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT>(a, grid, smem, s);
+    if (a.wide) return fast ? launch_f_t<0, true, STRICT, true, false, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true, false, TWO>(a, grid, smem, s);
+    if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT, TWO>(a, grid, smem, s);
     switch ((filter_nt(a.fg) + 3) / 4) {
-    case 1: return launch_f_t<1, true, STRICT, false, EXACT>(a, grid, smem, s);
-    case 2: return launch_f_t<2, true, STRICT, false, EXACT>(a, grid, smem, s);
-    case 3: return launch_f_t<3, true, STRICT, false, EXACT>(a, grid, smem, s);
-    case 4: return launch_f_t<4, true, STRICT, false, EXACT>(a, grid, smem, s);
-    case 5: return launch_f_t<5, true, STRICT, false, EXACT>(a, grid, smem, s);
-    case 6: return launch_f_t<6, true, STRICT, false, EXACT>(a, grid, smem, s);
-    default: return launch_f_t<0, true, STRICT, false, EXACT>(a, grid, smem, s);
+    case 1: return launch_f_t<1, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    case 2: return launch_f_t<2, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    case 3: return launch_f_t<3, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    case 4: return launch_f_t<4, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    case 5: return launch_f_t<5, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    case 6: return launch_f_t<6, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    default: return launch_f_t<0, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
     }
 }
 
 hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (a.n_reads == 0) return hipSuccess;
-    if (a.fg.exact && !a.wide) return a.strict ? launch_f_s<true, true>(a, grid, smem, s) : launch_f_s<false, true>(a, grid, smem, s);
-    return a.strict ? launch_f_s<true, false>(a, grid, smem, s) : launch_f_s<false, false>(a, grid, smem, s);
+    if (a.fg.exact && !a.wide) return a.strict ? launch_f_s<true, true, false>(a, grid, smem, s) : launch_f_s<false, true, false>(a, grid, smem, s);
+    if (a.fg.choices == 1) return a.strict ? launch_f_s<true, false, false>(a, grid, smem, s) : launch_f_s<false, false, false>(a, grid, smem, s);
+    return a.strict ? launch_f_s<true, false, true>(a, grid, smem, s) : launch_f_s<false, false, true>(a, grid, smem, s);
 }
 
 }  // namespace hast

@@ -87,10 +87,13 @@ int main() {
     }
     // (K = 21 from 16M keys on: m = 14 so that the entries are exact; with prints forced, the smallest m that holds the keys)
     struct { int k; uint64_t n; int mode, m, t, kp, exact; } want[] = {{21, 400000000ull, -1, 14, 6, 21, 1}, {21, 100000000ull, -1, 14, 6, 21, 1}, {21, 100000000ull, 0, 13, 4, 21, 0},
-                                                                       {21, 400000000ull, 0, 14, 6, 21, 0}, {31, 800000000ull, -1, 14, 5, 22, 0}, {21, 40000ull, -1, 8, 8, 16, 0},
-                                                                       {5, 10ull, -1, 5, 4, 5, 1}, {32, 2000000000ull, -1, 14, 5, 22, 0}, {17, 400000000ull, -1, 14, 6, 17, 1}};
+                                                                       {21, 400000000ull, 0, 14, 6, 21, 0}, {31, 800000000ull, -1, 15, 6, 23, 0}, {21, 40000ull, -1, 8, 8, 16, 0},
+                                                                       {5, 10ull, -1, 5, 4, 5, 1}, {32, 2000000000ull, -1, 15, 6, 23, 0}, {17, 400000000ull, -1, 14, 6, 17, 1}};
     for (auto &w : want) {
         const FilterGeom g = filter_geom_for(w.k, w.n, 0, 0, 0, w.mode);
+        // one choice per print exactly where a block holds <= 2.2 strings on average
+        if (!g.exact && g.choices != ((2.0 * (double)w.n <= 2.2 * (double)(1ull << (2 * g.m))) ? 1 : 2)) { printf("pick: choices\n"); return 1; }
+        if (w.k == 31 && w.n == 800000000ull && g.choices != 1) { printf("pick: config 5 should file prints once\n"); return 1; }
         if (g.exact != w.exact) { printf("pick: K=%d n=%llu mode %d -> exact=%d\n", w.k, (unsigned long long)w.n, w.mode, g.exact); return 1; }
         if (g.m != w.m || g.t != w.t || g.kp != w.kp) { printf("pick: K=%d n=%llu -> m=%d t=%d kp=%d (want %d %d %d)\n", w.k, (unsigned long long)w.n, g.m, g.t, g.kp, w.m, w.t, w.kp); return 1; }
     }
