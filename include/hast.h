@@ -132,6 +132,9 @@ hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *byt
  * consecutive windows of a read ask for few blocks.  A window the filter cannot rule out is looked up in the table
  * above, which alone decides hits, so results never depend on the filter.  It is (re)built from the table's live keys
  * by the first classification after keys were added, or explicitly by hast_filter_build (e.g. outside a timed region).
+ * The geometry follows the key count: 4^m blocks with m up to 15 (137 GB, chosen above 537M keys; 4^14 = 34 GB below that and
+ * when HBM has no room), a print filed in the less loaded of two sub-buckets where blocks are crowded, in one where they hold
+ * <= 2.2 strings on average (the probe then loads and compares one sub-bucket per window).
  * Where a filed string fits a 16-bit entry EXACTLY (its block is a bijection of the sampled m-mer, the entry holds the rest:
  * 2(K-m) + log2(W) <= 17 bits, e.g. K = 21 with m = 14) the entries are exact codes + the key's tag bits instead of prints,
  * and a match in the filter IS the hit: only windows that land in a full sub-bucket still ask the table.  Same results.
