@@ -1,3 +1,4 @@
+# the drop-in CLI on 20M reads (2 x 3.4 GB of plain FASTQ): GPU framing against --host-parse, block sizes, thread counts, gz; stdout md5 in every run
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 D=$(mktemp -d /tmp/hast_e2e.XXXXXX)
