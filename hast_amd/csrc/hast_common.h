@@ -110,12 +110,12 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
     return b + 1 == nbuckets ? 0 : b + 1;
 }
 
-// ---- fingerprint filter (the structure k_classify probes; the exact table above is only consulted for its positives) ----
+// ---- fingerprint filter (the structure k_classify_f probes; the exact table above is only consulted for its positives) ----
 //
 // Why: the probe kernel runs at the HBM random-request rate of the part, so the only way to get faster is
 // fewer requests per read.  A request brings a 128-B block whatever is used of it; the exact table spends 8 B per key,
 // so a block can only answer for ~3 keys and the placement function needs m = 16 (W = K-m+1 = 6 consecutive windows
-// share a block at best).  The filter spends 2 B per key, so a block answers for dozens of keys, m can be 13 and the
+// share a block at best).  The filter spends 2 B per key, so a block answers for dozens of keys, m can be 14 and the
 // sampling function can be any FORWARD-strand scheme, because every key is filed twice -- under the sampled m-mer of
 // its own string and under that of its reverse complement -- and a read window is looked up under the m-mer sampled
 // from the window as it stands (no canonical m-mers anywhere):
@@ -123,12 +123,13 @@ HAST_HD uint32_t next_bucket(uint32_t b, uint32_t step, uint64_t key, uint32_t n
 //     sub-bucket, print  = from a hash of the window's K-mer as it stands                     (8 x 16 B, 8 prints each)
 //   sampling = mod-minimizer (Groot Koerkamp & Pibiri 2024): the window's smallest t-mer (leftmost on ties), position x
 //   among its K-t+1 t-mers, names the m-mer at position x mod W.  With t = r + (m-r) mod W, r = 4, the sampled m-mer stays
-//   put for W consecutive windows and then jumps by W: density ~0.165 at K=21, m=13 (W=9, t=4) against 0.287 for the
-//   exact table's random minimizers (m=16, W=6): 23 instead of 39 blocks per 150-bp read (tools/sim/modmin_filter_sim.py).
+//   put for W consecutive windows and then jumps by W: density ~0.18 at K=21, m=14 (W=8, t=6) against 0.287 for the
+//   exact table's random minimizers (m=16, W=6): 24 instead of 39 blocks per 150-bp read (tools/sim/filter_load_sim.cpp).
 //   When the formula gives t = m the scheme IS the plain forward minimizer (large W).
-// A window whose print is in one of its two sub-buckets, or whose two sub-buckets are both full (then a key may not have
-// found room), is a POSITIVE and is looked up in the exact table, which alone decides hits and tag bits; everything else is a proven
-// miss.  So the filter can only cost time, never change a result.
+// With PRINTS, a window whose print is in one of its sub-buckets, or whose sub-buckets are all full (then a key may not have
+// found room), is a POSITIVE and is looked up in the exact table, which alone decides hits and tag bits; everything else is a
+// proven miss.  So the filter can only cost time, never change a result.  Where a filed string fits a 16-bit entry exactly
+// ("exact entries" below) a match is the hit itself and only full sub-buckets send a window to the table.
 struct FilterGeom {
     int k, m, t;            // k-mer, sampled m-mer (m <= 15, 4^m blocks), ordering t-mer (t <= m)
     int kp;                 // the sampling only looks at the first kp bases of a window (kp <= k): W = kp-m+1 candidates
@@ -187,8 +188,8 @@ HAST_HD uint32_t filter_keyhash(uint64_t kmer) {
 HAST_HD uint32_t filter_sub_of(uint32_t keyhash) { return keyhash >> 29; }
 // Two-choice filing: a print may sit in either of two sub-buckets of its block (the less loaded one at build time; both
 // are in the same 128-B block, so a look-up still costs one request).  Only a window whose TWO sub-buckets are full has to
-// ask the table.  At 400M keys this takes the forced look-ups from 0.54 per read to none, at 800M 31-mers from 11 % of
-// the windows to 1-2 % (tools/sim/filter_load_sim.cpp).
+// ask the table.  At 400M keys in 4^14 blocks this takes the forced look-ups from 0.54 per read to none, at 800M 31-mers from
+// 11 % of the windows to 2.8 % (tools/sim/filter_load_sim.cpp).  Lightly loaded filters file a print once (FilterGeom::choices).
 HAST_HD uint32_t filter_sub2_of(uint32_t keyhash) { return (keyhash >> 26) & 7u; }
 HAST_HD uint32_t filter_print_of(uint32_t keyhash) {
     const uint32_t f = (keyhash >> 8) & 0xFFFFu;
@@ -225,7 +226,8 @@ HAST_HD uint32_t filter_exact_entry(uint32_t code17, uint32_t tags) { return ((c
 // one of the window's lowest-ordered t-mers, so a fraction of the blocks takes most of the keys.  4^m >= 0.67 N keeps the
 // windows that land in a full sub-bucket (and must ask the table) under ~0.5 per 150-bp read:
 //     N = 400M: m = 14, kp = 21 -> W = 8, t = 6: 25.5 blocks + 0.5 forced look-ups per read (m = 13, t = 4: 23 + 77)
-//     N = 100M: m = 13, kp = 21 -> W = 9, t = 4: 23.4 + 0.9
+//     N = 100M: m = 13, kp = 21 -> W = 9, t = 4: 23.4 + 0.9          (prints; with exact entries K = 21 always gets m = 14)
+//     N = 800M: m = 15, kp = 23 -> W = 9, t = 6 (K = 31): 1.5 strings per block, prints filed once, nothing forced
 // kp = min(K, m + 8): longer windows (K = 31) are sampled on their first kp bases only -- more candidates would lower the
 // density further but pile the keys on even fewer blocks.
 // exact_mode: -1 = exact entries where they fit (and, for tables of 16M keys and more, the m that makes them fit: m = K-7,

@@ -3,7 +3,10 @@
 // Written for wave64 / 256 CUs / HBM3E directly: no CUDA-compat macros, no multi-backend paths.
 // The workload is integer + random 64-B HBM reads (no MFMA anywhere by design):
 //   K1  table build   : k_insert_keys / k_insert_text / k_erase_keys / k_count_tags
-//   K3  classify      : k_classify   (the hot kernel; roofline = HBM under random 64-B access)
+//   K3  classify      : k_classify   (round 1's hot kernel: every window probes the exact table; today the fallback when HBM
+//                                       has no room for the filter, and HAST_CLASSIFY=exact -- the hot kernel is
+//                                       k_classify_f in hast_filter.hip), k_commit_votes (per-barcode bookkeeping), the
+//                                       segmentation of long reads
 //   synthetic inputs  : k_synth_keys / k_synth_reads
 //
 // Reference semantics implemented (paths under /root/reference/01.classify_stlfr_reads/):
