@@ -86,6 +86,9 @@ struct hast_ctx {
     // per-read votes of the last barcode-mode launch when the caller gave no buffer for them
     uint32_t *d_votes_scratch = nullptr;
     size_t votes_bytes = 0;
+    // stream_file_region: two pinned pieces, their device twins, "piece is on the device" events
+    char *sf_h[2] = {nullptr, nullptr}, *sf_d[2] = {nullptr, nullptr};
+    hipEvent_t sf_done[2] = {nullptr, nullptr};
     // fingerprint filter in front of the table (hast_common.h): rebuilt from the table's live keys before the first
     // classification after the table gained keys
     void *d_filter = nullptr;
@@ -246,6 +249,11 @@ void hast_ctx_destroy(hast_ctx *c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_seg) (void)hipFree(c->d_seg);
     if (c->d_votes_scratch) (void)hipFree(c->d_votes_scratch);
+    for (int i = 0; i < 2; ++i) {
+        if (c->sf_done[i]) (void)hipEventDestroy(c->sf_done[i]);
+        if (c->sf_d[i]) (void)hipFree(c->sf_d[i]);
+        if (c->sf_h[i]) (void)hipHostFree(c->sf_h[i]);
+    }
     if (c->d_filter) (void)hipFree(c->d_filter);
     for (hipEvent_t e : c->t_ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -395,17 +403,18 @@ hast_status hast_table_insert_text(hast_ctx *c, int hap, const char *text, size_
 // Pieces hold whole units of `unit` bytes.  HAST_OK / HAST_ERR_IO (short file) / HAST_ERR_HIP.
 static hast_status stream_file_region(hast_ctx *c, int fd, const char *path, uint64_t file_off, uint64_t n_units, size_t unit,
                                       const std::function<hipError_t(char *, size_t, uint64_t)> &use) {
-    const uint64_t per = std::max<uint64_t>(1, (32u << 20) / unit);             // units per piece
-    const size_t piece = (size_t)(per * unit);
-    char *h_buf[2] = {nullptr, nullptr};
-    char *d_buf[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
+    // the two pinned pieces (pinning costs ~0.7 ms per MB) and their device twins belong to the context: the second k-mer file
+    // and a later --load-table reuse them
+    constexpr size_t kPieceBytes = 16u << 20;
+    const uint64_t per = std::max<uint64_t>(1, kPieceBytes / unit);             // units per piece
+    char **h_buf = c->sf_h, **d_buf = c->sf_d;
+    hipEvent_t *done = c->sf_done;
     hipError_t e = hipSuccess;
     bool short_read = false;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipHostMalloc((void **)&h_buf[i], piece, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_buf[i], piece + 16);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+        if (!h_buf[i]) e = hipHostMalloc((void **)&h_buf[i], kPieceBytes, hipHostMallocDefault);
+        if (e == hipSuccess && !d_buf[i]) e = hipMalloc((void **)&d_buf[i], kPieceBytes + 16);
+        if (e == hipSuccess && !done[i]) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) {
         const int nthreads = 8;
@@ -434,11 +443,6 @@ static hast_status stream_file_region(hast_ctx *c, int fd, const char *path, uin
         }
         const hipError_t e2 = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = e2;
-    }
-    for (int i = 0; i < 2; ++i) {
-        if (done[i]) (void)hipEventDestroy(done[i]);
-        if (d_buf[i]) (void)hipFree(d_buf[i]);
-        if (h_buf[i]) (void)hipHostFree(h_buf[i]);
     }
     if (e != hipSuccess) return fail(HAST_ERR_HIP, "%s: %s", path, hipGetErrorString(e));
     if (short_read) return fail(HAST_ERR_IO, "%s is shorter than its size says (truncated, or changed while it was read)", path);
