@@ -238,6 +238,9 @@ HAST_HD FilterGeom filter_geom_for(int k, uint64_t n_keys, int m_override, int t
     int m = k < 8 ? k : 8;
     while (m < k && m < kFilterMaxM && (1ull << (2 * m)) * 3 < 2 * n_keys) ++m;
     if (exact_mode && n_keys >= (16ull << 20) && k - 7 > m && k - 7 <= 14) m = k - 7;
+    // long windows (K >= m + 9: the sampling keeps W = 9 either way) get the m that lets prints be filed ONCE (<= 2.2 strings per
+    // block, `choices` below): the probe then loads and compares one sub-bucket per window, and nothing is forced to the table
+    while (m < kFilterMaxM && k >= m + 9 && 2.0 * (double)n_keys > 2.2 * (double)(1ull << (2 * m))) ++m;
     if (m_override >= 1 && m_override <= k && m_override <= kFilterMaxM) m = m_override;
     g.m = m;
     int kp = k < m + 8 ? k : m + 8;

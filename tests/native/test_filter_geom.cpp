@@ -88,7 +88,9 @@ int main() {
     // (K = 21 from 16M keys on: m = 14 so that the entries are exact; with prints forced, the smallest m that holds the keys)
     struct { int k; uint64_t n; int mode, m, t, kp, exact; } want[] = {{21, 400000000ull, -1, 14, 6, 21, 1}, {21, 100000000ull, -1, 14, 6, 21, 1}, {21, 100000000ull, 0, 13, 4, 21, 0},
                                                                        {21, 400000000ull, 0, 14, 6, 21, 0}, {31, 800000000ull, -1, 15, 6, 23, 0}, {21, 40000ull, -1, 8, 8, 16, 0},
-                                                                       {5, 10ull, -1, 5, 4, 5, 1}, {32, 2000000000ull, -1, 15, 6, 23, 0}, {17, 400000000ull, -1, 14, 6, 17, 1}};
+                                                                       {5, 10ull, -1, 5, 4, 5, 1}, {32, 2000000000ull, -1, 15, 6, 23, 0}, {17, 400000000ull, -1, 14, 6, 17, 1},
+                                                                       // long windows get the m that files prints once (W = 9 either way)
+                                                                       {31, 400000000ull, -1, 15, 6, 23, 0}, {31, 100000000ull, -1, 14, 5, 22, 0}, {23, 400000000ull, -1, 15, 6, 23, 0}};
     for (auto &w : want) {
         const FilterGeom g = filter_geom_for(w.k, w.n, 0, 0, 0, w.mode);
         // one choice per print exactly where a block holds <= 2.2 strings on average
