@@ -138,3 +138,29 @@ def test_find_bounds_matches_oracle_and_the_awk_program(lib, oracle_lib, tmp_pat
             r = subprocess.run(["awk", "-f", awk, str(tmp_path / "h.histo")], stdout=subprocess.PIPE, check=True).stdout.decode()
             ref = tuple(int(l.split("=")[1]) for l in r.splitlines())
             assert got == ref, (shape, got, ref)
+
+
+def test_committed_pmc_profiles_belong_to_these_device_sources(monkeypatch):
+    """bench.py prices the HBM traffic of k_classify_f from profiles/pmc_traffic*.json and refuses a profile taken on other
+    device code (roofline.frac would then be null in the driver's bench line): the committed profiles must carry the hash of
+    the device sources in this tree, for every workload bench.py can be asked for.  Runs under measurement switches have no
+    profile of their own and get no fraction."""
+    import json
+    import types
+    import bench
+    for v in ("HAST_CLASSIFY", "HAST_FILTER_EXACT", "HAST_FILTER_M", "HAST_FILTER_T", "HAST_FILTER_KP", "HAST_TILE_LDS", "HAST_LIB"):
+        monkeypatch.delenv(v, raising=False)
+    sid = bench.kernel_source_id()
+    for name, wl, clustered in (("pmc_traffic.json", "c3", False), ("pmc_traffic_clustered.json", "c3", True),
+                                ("pmc_traffic_workloadc2.json", "c2", False), ("pmc_traffic_workloadc5.json", "c5", False)):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d["kernel_source_id"] == sid, "%s was taken on other device code: run tools/gpu/collect_all.sh + profiles/summarize.py" % name
+        assert d["workload"] == wl
+        args = types.SimpleNamespace(workload=wl, clustered=clustered, no_plants=False)
+        R = d["batch_reads"]
+        ms = d["hbm_read_requests_per_launch"] / 47e9 * 1e3           # a launch at 47 G requests/s, about what the part serves
+        rf = bench.roofline(args, R, 1.0, [ms, ms * 1.02], [2.0, 2.0], [ms + 2, ms + 3])
+        assert rf["frac"] is not None and 0.3 < rf["frac"] < 1.0 and rf["request_rate"]["frac"] <= 1.0, (name, rf)
+    monkeypatch.setenv("HAST_FILTER_EXACT", "0")
+    rf = bench.roofline(types.SimpleNamespace(workload="c3", clustered=False, no_plants=False), 48_000_000, 1.0, [25.0], [2.0], [27.0])
+    assert rf["frac"] is None and "HAST_FILTER_EXACT" in rf["traffic_source"]
