@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <string_view>
 #include <vector>
 
@@ -156,26 +158,60 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> bases;
     std::vector<uint64_t> offsets;
     std::vector<std::string> names;
-    std::vector<uint32_t> votes;
     std::vector<uint64_t> part(T + 1);
     std::vector<int> bad(T);
     std::string out_rows;
     const bool fastq = format == "fastq";
-    // classify the parsed batch (names/offsets/bases) and append its rows
-    auto classify_batch = [&]() {
-        if (names.empty()) return;
-        votes.assign(names.size() * 2, 0);
-        if (hast_classify_perread(ctx, bases.data(), offsets.data(), names.size(), votes.data()) != HAST_OK) die(4, "classifying a batch");
+    // Classify the parsed batch (names/offsets/bases) and append its rows.  The batch is handed to ONE background thread (rows
+    // stay in order) so that the upload, the kernel and the formatting of block i run while block i+1 is indexed and copied.
+    struct Batch {
+        std::vector<uint8_t> bases;
+        std::vector<uint64_t> offsets;
+        std::vector<std::string> names;
+    };
+    std::thread bg;
+    struct Joiner {                                         // every way out of main() waits for the batch in flight
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{bg};
+    Batch bt[2];                                            // the batch in flight and the one before it (its buffers are reused)
+    int cur = 0;
+    std::string bg_error;
+    auto wait_bg = [&]() {
+        if (bg.joinable()) bg.join();
+        if (!bg_error.empty()) die(4, bg_error);
+    };
+    auto run_batch = [&](Batch &b) {
+        if (b.names.empty()) return;
+        std::vector<uint32_t> v(b.names.size() * 2, 0);
+        if (hast_classify_perread(ctx, b.bases.data(), b.offsets.data(), b.names.size(), v.data()) != HAST_OK) {
+            bg_error = std::string("classifying a batch (") + hast_last_error() + ")";
+            return;
+        }
         char row[96];
-        for (size_t i = 0; i < names.size(); i++) {
-            const double d0 = (double)votes[2 * i] / total_kmers[0], d1 = (double)votes[2 * i + 1] / total_kmers[1];   // s03:215-216
+        for (size_t i = 0; i < b.names.size(); i++) {
+            const double d0 = (double)v[2 * i] / total_kmers[0], d1 = (double)v[2 * i + 1] / total_kmers[1];   // s03:215-216
             // s03:110-133 for two haplotypes: both zero -> ambiguous 0.0; else the larger density, ties to haplotype0
             if (!(d0 > 0) && !(d1 > 0)) snprintf(row, sizeof(row), "\tambiguous\t0.0\n");
             else if (d1 > d0) snprintf(row, sizeof(row), "\thaplotype1\t%0.6f\n", d1);
             else snprintf(row, sizeof(row), "\thaplotype0\t%0.6f\n", d0);
-            out_rows += names[i];
+            out_rows += b.names[i];
             out_rows += row;
         }
+    };
+    auto classify_batch = [&]() {
+        wait_bg();                                          // one batch in flight; its rows are in out_rows now
+        if (names.empty()) return;
+        Batch &b = bt[cur];
+        b.bases.swap(bases);
+        b.offsets.swap(offsets);
+        b.names.swap(names);
+        bg = std::thread([&run_batch, &b] { run_batch(b); });
+        cur ^= 1;
+        Batch &o = bt[cur];                                 // idle since the wait above: its vectors (and their capacity) are the next work area
+        bases.swap(o.bases);
+        offsets.swap(o.offsets);
+        names.swap(o.names);
     };
     // records = [first, last) pairs of line indices: header line, then sequence lines; fills names/offsets/bases in parallel
     struct RecSpan { uint32_t head, seq_first, seq_end; };             // line indices; sequence lines [seq_first, seq_end)
@@ -223,6 +259,7 @@ int main(int argc, char **argv) {
         hast::BlockSource src;
         if (!src.open(r, block_bytes)) die(2, "cannot open " + r);
         std::vector<char> carry;
+        wait_bg();
         out_rows.clear();
         bool seen_header = false;                       // FASTA: lines before the first '>' belong to no record (s03:286-292)
         for (;;) {
@@ -314,6 +351,7 @@ int main(int argc, char **argv) {
             carry.swap(keep);
             src.recycle(std::move(blk));
         }
+        wait_bg();
         fwrite(out_rows.data(), 1, out_rows.size(), stdout);
         fprintf(stderr, "__process read done__\n");
     }
