@@ -361,7 +361,17 @@ class BlockSource {
     // inflate threads over all ordinary .gz files open at once (HAST_GZ_BUDGET)
     static int gz_budget() {
         if (const char *e = getenv("HAST_GZ_BUDGET")) return std::max(1, atoi(e));
-        return 16;
+        // what the container may really use (cgroup v2 cpu.max: a 1-GPU share of an MI355X host shows 256 hardware threads and
+        // grants 16 cores), else 16
+        static const int quota = [] {
+            long q = 0, per = 0;
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                if (fscanf(f, "%ld %ld", &q, &per) != 2) q = per = 0;
+                fclose(f);
+            }
+            return (q > 0 && per > 0) ? (int)std::max(2L, std::min(64L, q / per)) : 16;
+        }();
+        return quota;
     }
     static std::atomic<int> &gz_open_files() {
         static std::atomic<int> n{0};
