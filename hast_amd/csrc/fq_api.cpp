@@ -68,6 +68,27 @@ struct hast_fq {
     std::vector<uint8_t> carry;                                // host copy of the previous block's tail (barcodes may lie in it)
 };
 
+// Every per-record array of a slot has ONE capacity, h_cap, and is only ever resized here: h_bc = [pos | len | 4 words of
+// text] x cap, h_ids, d_text, h_unknown (1 + cap), h_pubs.  The records kernel is handed h_cap and writes text records at
+// h_bc + 2*h_cap and d_text[4*i]; k_fq_name writes up to n + 1 words of h_unknown; hast_fq_commit fills up to n h_pubs.
+static hast_status grow_records(Slot &s, size_t cap) {
+    if (s.h_bc) (void)hipHostFree(s.h_bc);
+    if (s.h_ids) (void)hipHostFree(s.h_ids);
+    if (s.h_unknown) (void)hipHostFree(s.h_unknown);
+    if (s.h_pubs) (void)hipHostFree(s.h_pubs);
+    if (s.d_text) (void)hipFree(s.d_text);
+    s.h_bc = s.h_ids = s.h_unknown = s.d_text = nullptr;
+    s.h_pubs = nullptr;
+    s.h_cap = 0;
+    FQ_TRY(hipHostMalloc((void **)&s.h_bc, (2 + 4) * cap * sizeof(uint32_t), hipHostMallocDefault));
+    FQ_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
+    FQ_TRY(hipMalloc((void **)&s.d_text, 4 * cap * sizeof(uint32_t)));
+    FQ_TRY(hipHostMalloc((void **)&s.h_unknown, (1 + cap) * sizeof(uint32_t), hipHostMallocDefault));
+    FQ_TRY(hipHostMalloc((void **)&s.h_pubs, cap * sizeof(NamePub), hipHostMallocDefault));
+    s.h_cap = cap;
+    return HAST_OK;
+}
+
 static void free_slot(Slot &s) {
     if (s.h_buf) (void)hipHostFree(s.h_buf);
     if (s.h_st) (void)hipHostFree(s.h_st);
@@ -157,13 +178,9 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
         ck(hipMalloc((void **)&s.d_off, f->max_rec * sizeof(uint64_t)), "record offsets");
         for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) ck(hipMalloc((void **)p, f->max_rec * sizeof(uint32_t)), "record arrays");
         ck(hipMalloc((void **)&s.d_votes, f->max_rec * 2 * sizeof(uint32_t)), "votes");
-        s.h_cap = f->block / 96 + 4096;                    // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
-        if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) s.h_cap = (size_t)std::max(1L, atol(e));       // (tests: force the copy path)
-        ck(hipHostMalloc((void **)&s.h_bc, (2 + 4) * s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned barcode extents + text");
-        ck(hipHostMalloc((void **)&s.h_ids, s.h_cap * sizeof(uint32_t), hipHostMallocDefault), "pinned ids");
-        ck(hipMalloc((void **)&s.d_text, 4 * s.h_cap * sizeof(uint32_t)), "barcode text records");
-        ck(hipHostMalloc((void **)&s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), hipHostMallocDefault), "pinned unknown list");
-        ck(hipHostMalloc((void **)&s.h_pubs, s.h_cap * sizeof(NamePub), hipHostMallocDefault), "pinned publications");
+        size_t cap = f->block / 96 + 4096;                 // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
+        if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) cap = (size_t)std::max(1L, atol(e));           // (tests: force the copy path)
+        if (st == HAST_OK) st = grow_records(s, cap);
         ck(hipEventCreateWithFlags(&s.named, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming), "event");
         ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
@@ -218,6 +235,9 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     hipStream_t hs = f->parse_stream;
     s.n_bytes = n_bytes;
     s.last = last;
+    // this slot's device buffer held block i - n_buffers, whose unfinished tail the NEXT block's k_fq_begin reads on the parse
+    // stream: the upload that overwrites it waits for that kernel (the successor slot's `parsed` event, recorded behind it)
+    if (f->n_submitted >= f->slots.size()) FQ_TRY(hipStreamWaitEvent(f->copy_stream, f->slots[(size_t)(si + 1) % f->slots.size()].parsed, 0));
     if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, f->copy_stream));
     FQ_TRY(hipEventRecord(s.copied, f->copy_stream));
     FQ_TRY(hipStreamWaitEvent(hs, s.copied, 0));
@@ -257,14 +277,8 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     const size_t n = st.n_rec;
     const bool by_copy = n > s.k_cap;          // more (short) records than the kernel could write to the host itself
     if (by_copy) {
-        FQ_TRY(hipHostFree(s.h_bc));
-        FQ_TRY(hipHostFree(s.h_ids));
-        s.h_bc = s.h_ids = nullptr;
-        s.h_cap = 0;
-        const size_t cap = n + n / 4 + 1024;
-        FQ_TRY(hipHostMalloc((void **)&s.h_bc, 2 * cap * sizeof(uint32_t), hipHostMallocDefault));
-        FQ_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
-        s.h_cap = cap;
+        // every per-record array grows together (the slot's next block hands the new h_cap to the records kernel)
+        if (hast_status g = grow_records(s, n + n / 4 + 1024)) return g;
         FQ_TRY(hipMemcpyAsync(s.h_bc, s.d_bcpos, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipMemcpyAsync(s.h_bc + s.h_cap, s.d_bclen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipEventRecord(s.parsed, hs));

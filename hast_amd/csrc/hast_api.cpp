@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -793,8 +795,18 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
             return fail(HAST_ERR_INVALID, "hast_counts_allreduce: two contexts on one device (a communicator has one rank per GPU)");
     }
-    std::vector<comm_t> comms(n);
-    if (int rc = init_all(comms.data(), n, devs.data())) return fail(HAST_ERR_RCCL, "ncclCommInitAll failed (%d)", rc);
+    // one communicator clique per device list, kept for the life of the process: ncclCommInitAll costs hundreds of ms on 8
+    // GPUs, and the CLI merges at every counter regrowth (classify_main.cpp) as well as at the end
+    static std::mutex comm_mu;
+    static std::map<std::vector<int>, std::vector<comm_t>> comm_cache;
+    std::lock_guard<std::mutex> lock(comm_mu);
+    auto it = comm_cache.find(devs);
+    if (it == comm_cache.end()) {
+        std::vector<comm_t> fresh(n);
+        if (int rc = init_all(fresh.data(), n, devs.data())) return fail(HAST_ERR_RCCL, "ncclCommInitAll failed (%d)", rc);
+        it = comm_cache.emplace(devs, std::move(fresh)).first;
+    }
+    const std::vector<comm_t> &comms = it->second;
     const int kUint32 = 3, kSum = 0;   // ncclUint32, ncclSum
     int rc = gstart();
     for (int i = 0; i < n && !rc; i++) {
@@ -806,7 +818,10 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
         (void)hipSetDevice(ctxs[i]->device);
         (void)hipStreamSynchronize(ctxs[i]->stream);
     }
-    for (auto cm : comms) destroy(cm);
+    if (rc || rc2) {                   // a failed collective leaves the clique in an unknown state: drop it
+        for (auto cm : comms) destroy(cm);
+        comm_cache.erase(it);
+    }
     if (rc || rc2) return fail(HAST_ERR_RCCL, "ncclAllReduce failed (%d/%d)", rc, rc2);
     return HAST_OK;
 }
@@ -851,6 +866,9 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
     return HAST_OK;
 }
 
+static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
+static constexpr uint32_t kLongRead = 4096;      // longer reads go through the segmented path: a row's positions must fit the 12 bits tmer_order gives them
+
 static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  const uint32_t *d_lens, const uint32_t *d_seg_read, int strict, uint32_t read_len,
                                  const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads, hast_stream s) {
@@ -859,6 +877,8 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     if (!d_bases) return fail(HAST_ERR_INVALID, "d_bases is null");
     if (d_barcode_ids && !c->d_counts) return fail(HAST_ERR_INVALID, "barcode ids given but no counters bound");
     if (read_len == 0 || read_len > (1u << 24)) return fail(HAST_ERR_INVALID, "read_len %u out of range", read_len);
+    // (tmer_order keeps a row position in 12 bits: longer rows are cut into segments by the callers)
+    if (read_len > kLongRead && c->use_filter) return fail(HAST_ERR_INVALID, "internal: a row of %u bases reached the filter kernel", read_len);
     if (!d_offsets && (uint64_t)n_reads * read_len > bases_bytes)
         return fail(HAST_ERR_INVALID, "bases_bytes too small for %zu reads of %u", n_reads, read_len);
     ClassifyArgs a;
@@ -961,10 +981,8 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
 }
 
 static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets, const uint32_t *d_lens,
-                                      size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
+                                      uint32_t fixed_len, size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
                                       hipStream_t hs);
-static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
-static constexpr uint32_t kLongRead = 4096;      // longer reads (with offsets) go through the segmented path
 
 hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t, int kp) {
     if (!c) return fail(HAST_ERR_INVALID, "null context");
@@ -1028,11 +1046,15 @@ hast_status hast_classify_times(hast_ctx *c, float *classify_ms, float *commit_m
 hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  uint32_t read_len, const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads,
                                  hast_stream s) {
-    if (read_len > kLongRead && d_offsets && c && c->d_slots && n_reads) {
-        // stage-01 semantics on long reads: whole-read N skip by a pre-pass, windows through segments
+    if (read_len > kLongRead && c && c->d_slots && n_reads) {
+        // stage-01 semantics on long reads (with offsets or of one fixed length): whole-read N skip by a pre-pass, windows
+        // through segments
         if (d_barcode_ids && !c->d_counts) return fail(HAST_ERR_INVALID, "barcode ids given but no counters bound");
+        if (!d_bases) return fail(HAST_ERR_INVALID, "d_bases is null");
+        if (!d_offsets && (uint64_t)n_reads * read_len > bases_bytes)
+            return fail(HAST_ERR_INVALID, "bases_bytes too small for %zu reads of %u", n_reads, read_len);
         if (hast_status st = use(c)) return st;
-        return classify_segmented(c, d_bases, bases_bytes, d_offsets, nullptr, n_reads, 0, d_barcode_ids, d_votes, s ? (hipStream_t)s : c->stream);
+        return classify_segmented(c, d_bases, bases_bytes, d_offsets, nullptr, read_len, n_reads, 0, d_barcode_ids, d_votes, s ? (hipStream_t)s : c->stream);
     }
     return classify_rows(c, d_bases, bases_bytes, d_offsets, nullptr, nullptr, 0, read_len, d_barcode_ids, d_votes, n_reads, s);
 }
@@ -1042,7 +1064,7 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
 //   strict = 0: stage-01 semantics (a read holding 'N' is skipped as a whole: found by a pre-pass, such reads get no
 //               windows), then per-read bookkeeping into the barcode counters and/or d_votes_out.
 static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets, const uint32_t *d_lens,
-                                      size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
+                                      uint32_t fixed_len, size_t n_reads, int strict, const uint32_t *d_barcode_ids, uint32_t *d_votes_out,
                                       hipStream_t hs) {
     const size_t max_seg = n_reads + bases_bytes / kSegWindows + 1;
     const size_t votes_b = ((n_reads * 2 * sizeof(uint32_t) + 255) & ~(size_t)255), flags_b = ((n_reads + 255) & ~(size_t)255);
@@ -1065,8 +1087,8 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
     uint32_t *target = strict ? d_votes_out : acc;
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), hs));
     HIP_TRY(hipMemsetAsync(target, 0, n_reads * 2 * sizeof(uint32_t), hs));
-    if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, d_lens, n_reads, has_n, hs));
-    HIP_TRY(launch_build_segments(d_offsets, d_lens, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt,
+    if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, d_lens, fixed_len, n_reads, has_n, hs));
+    HIP_TRY(launch_build_segments(d_offsets, d_lens, fixed_len, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt,
                                   strict ? nullptr : has_n, hs));
     unsigned long long n_seg = 0;
     HIP_TRY(hipMemcpyAsync(&n_seg, c->d_cnt, sizeof(n_seg), hipMemcpyDeviceToHost, hs));
@@ -1084,7 +1106,7 @@ hast_status hast_classify_perread_device(hast_ctx *c, const uint8_t *d_bases, si
     if (hast_status st = need_table(c, 0)) return st;
     if (n_reads == 0) return HAST_OK;
     if (!d_bases || !d_offsets || !d_votes) return fail(HAST_ERR_INVALID, "null argument");
-    return classify_segmented(c, d_bases, bases_bytes, d_offsets, nullptr, n_reads, 1, nullptr, d_votes, s ? (hipStream_t)s : c->stream);
+    return classify_segmented(c, d_bases, bases_bytes, d_offsets, nullptr, 0, n_reads, 1, nullptr, d_votes, s ? (hipStream_t)s : c->stream);
 }
 
 hast_status hast_classify_perread(hast_ctx *c, const uint8_t *bases, const uint64_t *offsets, size_t n_reads,
@@ -1199,7 +1221,7 @@ hast_status classify_framed(hast_ctx *c, const uint8_t *d_buf, size_t buf_bytes,
                             uint32_t *d_votes, size_t n_reads, hipStream_t hs) {
     if (hast_status st = need_table(c, 0)) return st;
     if (n_reads == 0) return HAST_OK;
-    if (max_len > kLongRead) return classify_segmented(c, d_buf, buf_bytes, d_off, d_len, n_reads, 0, nullptr, d_votes, hs);
+    if (max_len > kLongRead) return classify_segmented(c, d_buf, buf_bytes, d_off, d_len, 0, n_reads, 0, nullptr, d_votes, hs);
     return classify_rows(c, d_buf, buf_bytes, d_off, d_len, nullptr, 0, max_len ? max_len : 1, nullptr, d_votes, n_reads, hs);
 }
 hast_status commit_framed(hast_ctx *c, const uint32_t *d_votes, const uint32_t *d_ids, size_t n_reads, hipStream_t hs) {

@@ -58,10 +58,11 @@ hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStre
 hipError_t launch_filter_build(const uint64_t *slots, TableGeom g, void *filter, FilterGeom fg, hipStream_t s);
 hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
 size_t classify_f_queue_bytes();      // LDS the kernel needs besides the per-read arrays
-hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
+// d_offsets == nullptr: reads of fixed_len bytes back to back
+hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
                                  uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
                                  hipStream_t s);
-hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, size_t n_reads, uint8_t *d_has_n, hipStream_t s);
+hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, uint8_t *d_has_n, hipStream_t s);
 hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
                                size_t n_reads, hipStream_t s);
 hipError_t launch_add_u32(uint32_t *d_dst, const uint32_t *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]

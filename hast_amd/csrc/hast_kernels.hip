@@ -626,11 +626,13 @@ hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStre
 // Long reads -> segments of at most seg_windows windows (consecutive segments overlap by K-1 bases), so that a
 // row of the classify kernel always fits LDS.  One thread per read; segment rows are handed out with one atomic.
 __global__ void k_build_segments(const uint64_t *offsets, const uint32_t *lens, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
-                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter, const uint8_t *skip) {
+                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter, const uint8_t *skip, uint64_t fixed_len) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n_reads) return;
-    // lens == nullptr: offsets holds n_reads+1 boundaries; else n_reads starts + their lengths (reads framed out of a raw FASTQ block)
-    const uint64_t off = offsets[i], len = (skip && skip[i]) ? 0 : (lens ? (uint64_t)lens[i] : offsets[i + 1] - off);   // skipped read: no windows
+    // offsets == nullptr: reads of fixed_len back to back; lens == nullptr: offsets holds n_reads+1 boundaries; else n_reads
+    // starts + their lengths (reads framed out of a raw FASTQ block)
+    const uint64_t off = offsets ? offsets[i] : i * fixed_len;
+    const uint64_t len = (skip && skip[i]) ? 0 : !offsets ? fixed_len : (lens ? (uint64_t)lens[i] : offsets[i + 1] - off);   // skipped read: no windows
     const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
     const uint64_t nseg = nwin ? (nwin + seg_windows - 1) / seg_windows : 1;
     const unsigned long long base = atomicAdd(counter, (unsigned long long)nseg);
@@ -645,11 +647,11 @@ __global__ void k_build_segments(const uint64_t *offsets, const uint32_t *lens, 
 }
 
 // containN (classify.cpp:182-185) for reads too long for one kernel row: one wave per read scans its bytes.
-__global__ void __launch_bounds__(256) k_scan_n(const uint8_t *bases, const uint64_t *offsets, const uint32_t *lens, size_t n_reads, uint8_t *has_n) {
+__global__ void __launch_bounds__(256) k_scan_n(const uint8_t *bases, const uint64_t *offsets, const uint32_t *lens, size_t n_reads, uint8_t *has_n, uint64_t fixed_len) {
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (wave >= n_reads) return;
-    const uint64_t off = offsets[wave], len = lens ? (uint64_t)lens[wave] : offsets[wave + 1] - off;
+    const uint64_t off = offsets ? offsets[wave] : wave * fixed_len, len = !offsets ? fixed_len : lens ? (uint64_t)lens[wave] : offsets[wave + 1] - off;
     bool found = false;
     for (uint64_t i = lane; i < len && !found; i += 64) found = bases[off + i] == 'N';
     const bool any = __any(found);
@@ -719,9 +721,9 @@ __global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, con
         }
     }
 }
-hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, size_t n_reads, uint8_t *d_has_n, hipStream_t s) {
+hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, uint8_t *d_has_n, hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_n, dim3((unsigned)((n_reads * 64 + 255) / 256)), dim3(256), 0, s, d_bases, d_offsets, d_lens, n_reads, d_has_n);
+    hipLaunchKernelGGL(k_scan_n, dim3((unsigned)((n_reads * 64 + 255) / 256)), dim3(256), 0, s, d_bases, d_offsets, d_lens, n_reads, d_has_n, fixed_len);
     return hipGetLastError();
 }
 hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
@@ -732,12 +734,12 @@ hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcod
     return hipGetLastError();
 }
 
-hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
+hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
                                  uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
                                  hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_segments, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_offsets, d_lens, n_reads, k,
-                       seg_windows, seg_off, seg_len, seg_read, d_counter, d_skip);
+                       seg_windows, seg_off, seg_len, seg_read, d_counter, d_skip, fixed_len);
     return hipGetLastError();
 }
 

@@ -160,7 +160,8 @@ hast_status hast_counts_read(hast_ctx *, uint32_t *c0, uint32_t *c1, uint32_t *n
 /* Thread-merge of the reference (collectBarcodes/BarcodeCache::Add, classify.cpp:57-63,226-229)
  * across the GPUs of ONE process: a single in-place RCCL all-reduce(sum,u32) over the counters of
  * n_ctx contexts (one per device, same n_barcodes).  Contexts that all share ONE device (a logical split) are summed
- * by a kernel on that device instead; a mix of shared and distinct devices is refused. */
+ * by a kernel on that device instead; a mix of shared and distinct devices is refused.  The communicators of a device list
+ * are created by the first call that names it and kept until the process ends (later calls only enqueue the all-reduce). */
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
 
 /* ---- classification: MultiThread::process_reads (classify.cpp:186-209) ---------------------

@@ -15,25 +15,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(cmd, env_extra):
-    env = dict(os.environ, **env_extra)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = r.stdout.decode().strip().splitlines()
     assert len(lines) == 1, lines
     return json.loads(lines[0])
-
-
-def test_two_ranks_equal_one_process():
-    common = ["--workload", "c1", "--batch-reads", "300000", "--cpu-seconds", "0"]
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + common,
-               {"HAST_BENCH_SHARE_GPU": "1", "HAST_BENCH_BACKEND": "gloo"})
-    # ranks 0,1 at timed steps j=1..3 own batches (2j + r) = 2..7; one process with warmup 2 owns j = 2..7
-    one = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"] + common, {})
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
-    assert two["config"]["reads_total"] == one["config"]["reads_total"] == 6 * 300000
-    assert two["hits"] == one["hits"] and two["hits"]["c0"] > 0
-    assert two["scaling"] == "weak" and "all_reduce" in two["config"]["collective"]
 
 
 def _n_gpus():
@@ -45,11 +33,57 @@ def _n_gpus():
         return 0
 
 
-@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: one rank per GPU, all-reduce over RCCL/xGMI")
-def test_two_ranks_over_rccl_equal_one_process():
-    """the driver's N=2 launch, as is: one rank per GPU, nccl(=RCCL) backend, ONE all_reduce(sum,u32) of the counters"""
-    common = ["--workload", "c1", "--batch-reads", "300000", "--cpu-seconds", "0"]
+
+COMMON = ["--workload", "c1", "--batch-reads", "300000", "--cpu-seconds", "0"]
+
+
+@pytest.fixture(scope="module")
+def one_process():
+    """one plain process over read batches j = 2..7"""
+    return _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"] + COMMON, {})
+
+
+def test_one_rank_over_rccl_self_launched(one_process):
+    """The N>1 code path of bench.py on the nccl (= RCCL) backend with ONE rank, started the way a user would start N ranks:
+    `python bench.py --gpus 1` with HAST_BENCH_FORCE_DIST=1 and no WORLD_SIZE launches torch.distributed.run as a child itself;
+    the rank runs RCCL init, barrier(device_ids), the all_reduce of the int32 view of the counters and the MAX of the elapsed
+    times.  The totals must equal the plain run's and the line must say where the time went."""
+    env = {"HAST_BENCH_FORCE_DIST": "1"}
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2"] + COMMON, env)
+    assert r["n_gpus"] == 1 and r["hits"] == one_process["hits"] and r["hits"]["c0"] > 0
+    assert "all_reduce" in r["config"]["collective"] and "nccl" in r["ranks"]["backend"]
+    assert r["allreduce_ms"] > 0 and r["ranks"]["allreduce_ms"]["per_rank"] == [pytest.approx(r["allreduce_ms"], abs=1e-3)]
+    assert r["ranks"]["kernel_ms_avg"]["min"] > 0 and len(r["ranks"]["kernel_ms_avg"]["per_rank"]) == 1
+    assert one_process["allreduce_ms"] == 0.0 and one_process["ranks"]["backend"] is None
+
+
+@pytest.mark.skipif(_n_gpus() >= 2, reason="a box with two GPUs runs this launch for real (test_two_ranks_over_rccl_equal_one_process)")
+def test_more_ranks_than_gpus_fails_in_the_child_with_a_clear_message():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"] + COMMON, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert b"has no GPU of its own" in r.stderr and b"launching 2 ranks" in r.stderr
+
+
+def test_two_ranks_equal_one_process(one_process):
+    common, one = COMMON, one_process
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + common, {})
-    one = _run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"] + common, {})
-    assert two["n_gpus"] == 2 and two["hits"] == one["hits"] and two["hits"]["c0"] > 0
+                "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + common,
+               {"HAST_BENCH_SHARE_GPU": "1", "HAST_BENCH_BACKEND": "gloo"})
+    # ranks 0,1 at timed steps j=1..3 own batches (2j + r) = 2..7; one process with warmup 2 owns j = 2..7
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert len(two["ranks"]["kernel_ms_avg"]["per_rank"]) == 2 and two["allreduce_ms"] >= 0
+    assert two["config"]["reads_total"] == one["config"]["reads_total"] == 6 * 300000
+    assert two["hits"] == one["hits"] and two["hits"]["c0"] > 0
+    assert two["scaling"] == "weak" and "all_reduce" in two["config"]["collective"]
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: one rank per GPU, all-reduce over RCCL/xGMI")
+def test_two_ranks_over_rccl_equal_one_process(one_process):
+    """the driver's N=2 launch, as is: one rank per GPU, nccl(=RCCL) backend, ONE all_reduce(sum,u32) of the counters -- and the
+    same through bench.py's own launcher (`python bench.py --gpus 2`)"""
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + COMMON, {})
+    assert two["n_gpus"] == 2 and two["hits"] == one_process["hits"] and two["hits"]["c0"] > 0
+    own = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + COMMON, {})
+    assert own["n_gpus"] == 2 and own["hits"] == one_process["hits"]
