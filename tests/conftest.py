@@ -16,6 +16,13 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "heavy: BASELINE-size case (full-size oracle sets, GB of input): run after everything else")
+
+
+def pytest_collection_modifyitems(config, items):
+    """cheap tests first, the BASELINE-size ones last: a run that is cut short (-x, a time limit on a slow box) then loses only
+    the heavy tail"""
+    items.sort(key=lambda it: 1 if it.get_closest_marker("heavy") else 0)       # (stable: the order within each group stays)
 
 
 def _make(target_dir, *targets):

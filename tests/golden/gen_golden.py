@@ -192,6 +192,7 @@ def random_case(name, k, n_keys, n_pairs, n_barcodes, seed, read_len=100, extra_
     runs = {"pair_w104": base + ["--read", "r1.fq.gz", "--read", "r2.fq.gz", "--thread", "8", "--weight0", "1.04"]}
     if extra_runs:
         runs["single_w1"] = base + ["--read", "r2.fq.gz", "-t", "3"]
+        runs["wrapper_argv"] = WRAPPER_ARGV
     try:
         finish_case(name, {k_: v for k_, v in files.items() if k_.startswith("r")}, runs)
     finally:
@@ -199,6 +200,35 @@ def random_case(name, k, n_keys, n_pairs, n_barcodes, seed, read_len=100, extra_
             p = os.path.join(d, fn)
             write(p + ".gz", open(p).read(), gz=True)
             os.remove(p)
+
+
+# The literal command line of the stage-01 wrapper (classify_stlfr_reads.sh:44-45,142-149): --hap0/--hap1, --thread, --weight0 1.04,
+# one --read per filial file, and the LONG --adaptor_f/--adaptor_r spellings with the wrapper's default sequences.
+WRAPPER_ARGV = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--thread", "8", "--weight0", "1.04", "--read", "r1.fq.gz", "--read", "r2.fq.gz",
+                "--adaptor_f", ADAPTOR_F, "--adaptor_r", ADAPTOR_R]
+
+
+def case_wrapper_argv():
+    """adds the run `wrapper_argv` to the rand_k21 case as it is committed (inputs untouched)"""
+    import shutil
+    import tempfile
+    d = os.path.join(HERE, "rand_k21")
+    tmp = tempfile.mkdtemp()
+    try:
+        for fn in os.listdir(d):
+            shutil.copy(os.path.join(d, fn), tmp)
+        for fn in ("hap0.mer", "hap1.mer"):
+            open(os.path.join(tmp, fn), "wb").write(gzip.open(os.path.join(tmp, fn + ".gz")).read())
+        stdout, stderr = run_ref(tmp, WRAPPER_ARGV)
+    finally:
+        shutil.rmtree(tmp)
+    write(os.path.join(d, "expected.wrapper_argv.tsv"), stdout)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    meta["runs"]["wrapper_argv"] = {"argv": WRAPPER_ARGV, "expected": "expected.wrapper_argv.tsv",
+                                    "ref_log": [l for l in stderr.splitlines() if l.startswith("Recorded") or "erase a adaptor" in l]}
+    with open(os.path.join(d, "case.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote rand_k21/wrapper_argv:", len(stdout.splitlines()), "rows")
 
 
 def case_s03(name, k, n_keys, seed, max_len):

@@ -298,3 +298,32 @@ def test_classify_read_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path,
     assert got.returncode == 0, got.stderr.decode()[-2000:]
     assert got.stdout == ref.stdout
     assert len(ref.stdout.splitlines()) == 2 * (len(recs) + 1)
+
+
+@pytest.mark.heavy
+def test_cli_baseline_config1_full_size_vs_oracle(exe, oracle_dir, tmp_path):
+    """BASELINE config 1 at its full size through the boundary: 1M synthetic 150-bp stLFR read pairs in two FASTQ files, 1M +
+    1M 21-mers as k-mer text files, 10k barcodes (tools/gen_fastq writes SURVEY 8(d)'s generator to files), the wrapper's
+    argument list.  stdout of the drop-in == stdout of the oracle's line-by-line restatement of classify.cpp, byte for byte."""
+    import shutil
+    from tests.conftest import ROOT
+    gen = os.path.join(ROOT, "tools", "gen_fastq")
+    if not os.path.exists(gen):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tools"), "gen_fastq"], check=True)
+    d = tmp_path / "c1"
+    d.mkdir()
+    try:
+        subprocess.run([gen, str(d), "1000000", "1000000", "10000", "21", "150", "8"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=900)
+        args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--thread", "8", "--weight0", "1.04", "--read", "r1.fq", "--read", "r2.fq",
+                "--adaptor_f", "CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA", "--adaptor_r", "TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"]
+        ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert ref.returncode == 0, ref.stderr.decode()[-500:]
+        rows = ref.stdout.splitlines()
+        assert len(rows) == 10000 and sum(1 for r in rows if r.split(b"\t")[1] in (b"0", b"1")) > 9000
+        for extra in ([], ["--devices", "0,0"]):
+            got = subprocess.run([exe] + args + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            assert got.returncode == 0, got.stderr.decode()[-2000:]
+            assert got.stdout == ref.stdout, extra
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -59,6 +59,68 @@ def make_fastq(rng, n, k, keys, tail):
     return text.encode()
 
 
+def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3):
+    """feed `data` to hast_fq_* in pieces of lo..hi bytes, name the records the way the CLI does; returns the barcodes in record
+    order, the dictionary, the base count, the per-block short-read flags and how many records the host had to name"""
+    lib = hast_amd.lib()
+    fq, nm = C.c_void_p(), C.c_void_p()
+    if cache:
+        assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
+    assert lib.hast_fq_create(ctx._h, hi, n_buffers, nm, C.byref(fq)) == 0, lib.hast_last_error()
+    names, got, pos, pending = {}, [], 0, 0
+    st = {"host_named": 0, "n_bases": 0}
+    short = []
+
+    def drain():
+        b = FqBlock()
+        assert lib.hast_fq_next(fq, C.byref(b)) == 0, lib.hast_last_error()
+        short.append(b.short_read)
+        for i in range(b.n_records):
+            bc = bytes(b.bytes[b.bc_pos[i]:b.bc_pos[i] + b.bc_len[i]])
+            if b.bc_text:                            # the framer's compact copy of the text: length byte + up to 15 bytes
+                t = bytes(b.bc_text[16 * i:16 * i + 16])
+                assert (t[0] == 0xFF and len(bc) > 15) or (t[0] == len(bc) and t[1:1 + t[0]] == bc), (bc, t)
+            got.append(bc)
+        if b.unknown:
+            assert cache and b.n_unknown <= b.n_records
+            todo = [b.unknown[j] for j in range(b.n_unknown)]
+            known = set(range(b.n_records)) - set(todo)
+            base = len(got) - b.n_records
+            for i in known:                          # what the cache answered must be what the caller said before
+                assert b.ids[i] == names[got[base + i]], (got[base + i], b.ids[i])
+        else:
+            assert b.n_unknown == b.n_records
+            todo = range(b.n_records)
+        for i in todo:
+            b.ids[i] = names.setdefault(got[len(got) - b.n_records + i], len(names))
+        st["host_named"] += len(todo)
+        st["n_bases"] += b.n_bases
+        assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
+
+    while True:
+        n = min(len(data) - pos, rng.randint(lo, hi))
+        buf = C.POINTER(C.c_uint8)()
+        assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
+        C.memmove(buf, data[pos:pos + n], n)
+        pos += n
+        last = pos >= len(data)
+        assert lib.hast_fq_submit(fq, n, 1 if last else 0) == 0, lib.hast_last_error()
+        pending += 1
+        if pending == n_buffers - 1 or last:     # keep block(s) in flight behind the one being named
+            while pending > (0 if last else n_buffers - 2):
+                drain()
+                pending -= 1
+        if last:
+            break
+    lib.hast_fq_destroy(fq)
+    if cache:
+        lib.hast_names_destroy(nm)
+    return got, names, st["n_bases"], short, st["host_named"]
+
+
+SEEDS = {"plain": 11, "no_final_newline": 23, "header_only": 37, "unterminated_header": 41, "bases_no_newline": 59}
+
+
 @pytest.mark.parametrize("cache", [0, 64, 1 << 16])
 @pytest.mark.parametrize("tail", ["plain", "no_final_newline", "header_only", "unterminated_header", "bases_no_newline"])
 @pytest.mark.parametrize("chunk", [(700, 4096), (4096, 4096), (50_000, 65536)])
@@ -66,72 +128,18 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
     """cache: size of the device-side barcode name cache (0: none, the caller names every record; 64: far too small for the
     ~300 barcodes of the input, so it fills up and stops learning; 65536: ample)"""
     lo, hi = chunk
-    rng = random.Random(hash((tail, chunk)) & 0xFFFF)
+    rng = random.Random(SEEDS[tail] * 1000 + chunk[0] % 997)       # literal seeds: a failure can be replayed
     k, n_keys = 21, 3000
     p = make_params(k, 100, n_keys, 1)
     keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
     data = make_fastq(rng, 1500, k, np.concatenate(keys), tail)
     want = reference_framing(data, oracle_lib)
-    lib = hast_amd.lib()
     with hast_amd.Context(k) as ctx:
         ctx.table_reserve(2 * n_keys)
         ctx.table_insert_keys(0, keys[0])
         ctx.table_insert_keys(1, keys[1])
         ctx.counts_resize(4096)
-        fq, nm = C.c_void_p(), C.c_void_p()
-        if cache:
-            assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
-        assert lib.hast_fq_create(ctx._h, hi, 3, nm, C.byref(fq)) == 0, lib.hast_last_error()
-        names, got, pos, pending = {}, [], 0, 0
-        host_named = 0
-        n_bases = 0
-        short = []
-
-        def drain():
-            nonlocal n_bases, host_named
-            b = FqBlock()
-            assert lib.hast_fq_next(fq, C.byref(b)) == 0, lib.hast_last_error()
-            short.append(b.short_read)
-            for i in range(b.n_records):
-                bc = bytes(b.bytes[b.bc_pos[i]:b.bc_pos[i] + b.bc_len[i]])
-                if b.bc_text:                            # the framer's compact copy of the text: length byte + up to 15 bytes
-                    t = bytes(b.bc_text[16 * i:16 * i + 16])
-                    assert (t[0] == 0xFF and len(bc) > 15) or (t[0] == len(bc) and t[1:1 + t[0]] == bc), (bc, t)
-                got.append(bc)
-            if b.unknown:
-                assert cache and b.n_unknown <= b.n_records
-                todo = [b.unknown[j] for j in range(b.n_unknown)]
-                known = set(range(b.n_records)) - set(todo)
-                base = len(got) - b.n_records
-                for i in known:                          # what the cache answered must be what the caller said before
-                    assert b.ids[i] == names[got[base + i]], (got[base + i], b.ids[i])
-            else:
-                assert b.n_unknown == b.n_records
-                todo = range(b.n_records)
-            for i in todo:
-                b.ids[i] = names.setdefault(got[len(got) - b.n_records + i], len(names))
-            host_named += len(todo)
-            n_bases += b.n_bases
-            assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
-
-        while True:
-            n = min(len(data) - pos, rng.randint(lo, hi))
-            buf = C.POINTER(C.c_uint8)()
-            assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
-            C.memmove(buf, data[pos:pos + n], n)
-            pos += n
-            last = pos >= len(data)
-            assert lib.hast_fq_submit(fq, n, 1 if last else 0) == 0, lib.hast_last_error()
-            pending += 1
-            if pending == 2 or last:                 # keep one block in flight behind the one being named
-                while pending > (0 if last else 1):
-                    drain()
-                    pending -= 1
-            if last:
-                break
-        lib.hast_fq_destroy(fq)
-        if cache:
-            lib.hast_names_destroy(nm)
+        got, names, n_bases, short, host_named = stream_through_framer(ctx, data, lo, hi, cache, rng)
         counts = ctx.counts_read(len(names))
     if cache >= 1 << 16 and chunk[0] < 5000:
         # many small blocks: the cache learns early; what stays with the host are the barcodes longer than 15 bytes (a quarter of
@@ -181,3 +189,48 @@ def test_fq_short_read_is_reported(oracle_lib):
         assert lib.hast_fq_next(fq, C.byref(b)) == 0
         assert b.n_records == 2 and b.short_read == 1
         lib.hast_fq_destroy(fq)
+
+
+@pytest.mark.parametrize("n_buffers", [2, 3])
+def test_fq_slot_grown_on_the_copy_path_is_reused(oracle_lib, monkeypatch, n_buffers):
+    """A block with more records than the slot's pinned per-record arrays hold takes the copy path and GROWS the slot; the
+    slot's next block is then framed with the larger capacity, so every per-record array (extents + text, ids, device text,
+    unknown list, publications) must have grown with it.  Tiny records (25 bytes) in 64-KB blocks: ~2600 records per block
+    against an initial capacity of 7, every slot reused several times, device name cache on."""
+    monkeypatch.setenv("HAST_FQ_HOST_RECORDS", "7")
+    k = 5
+    rng = random.Random(20260)
+    kmers = ["".join(rng.choice("ACGT") for _ in range(k)).encode() for _ in range(200)]
+    keys = [np.array(sorted({hast_amd.canon_kmer(x) for x in kmers[h::2]}), dtype=np.uint64) for h in (0, 1)]
+    recs = []
+    for i in range(40000):
+        L = rng.randint(k, k + 3)
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        recs.append("@%d#%d_%d/1\n%s\n+\n%s\n" % (i % 10, rng.randint(1, 40), rng.randint(1, 9), s, "I" * L))
+    data = "".join(recs).encode()
+    want = reference_framing(data, oracle_lib)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(1000)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        ctx.counts_resize(4096)
+        got, names, n_bases, short, host_named = stream_through_framer(ctx, data, 60_000, 65536, 1 << 12, rng, n_buffers=n_buffers)
+        counts = ctx.counts_read(len(names))
+    assert got == [bc for bc, _ in want] and not any(short)
+    assert n_bases == sum(len(s) for _, s in want)
+    assert len(data) > 12 * 65536                      # every slot came round at least four times
+    assert host_named < len(got) // 2                   # ... and after the first round the cache answered (the normal path ran)
+    oc = oracle_lib.ho_new()
+    for h in (0, 1):
+        assert oracle_lib.ho_load_keys(oc, keys[h].ctypes.data, keys[h].size, h, k) == 0
+    bases = np.frombuffer(b"".join(s for _, s in want), dtype=np.uint8)
+    off = np.zeros(len(want) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for _, s in want])
+    ids = np.array([names[bc] for bc, _ in want], dtype=np.uint32)
+    e = [np.zeros(len(names), np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, ids.size, e[0].ctypes.data, e[1].ctypes.data,
+                               e[2].ctypes.data, None, 2)
+    oracle_lib.ho_free(oc)
+    for a, b in zip(counts, e):
+        assert np.array_equal(a, b)
+    assert int(e[0].sum()) > 1000

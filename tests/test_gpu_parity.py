@@ -252,6 +252,52 @@ def test_classify_fixed_length_vs_oracle(built, oracle_lib, k, L):
     oracle_lib.ho_free(oc)
 
 
+@pytest.mark.parametrize("k,L,fm", [(21, 6000, 0), (31, 9000, 0), (21, 4097, 8), (21, 4096, 8)])
+def test_classify_fixed_long_reads_without_offsets_vs_oracle(built, oracle_lib, k, L, fm):
+    """Fixed-length reads longer than a kernel row's 4096 positions, handed over WITHOUT offsets (hast.h: d_offsets == NULL):
+    they must take the segmented path like reads with offsets do -- the filter's t-mer order keeps a row position in 12 bits, so
+    a longer row would sample another m-mer than the one a key was filed under and miss it.  Keys are the reads' own windows
+    at positions >= 4000, so that almost all hits lie where positions would wrap; with and without 'N'; votes and counters ==
+    oracle, for the filter (exact entries / prints) and for the table probed directly."""
+    rng = np.random.default_rng(k * 1000 + L)
+    n_reads, n_bc = 400, 37
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n_reads * L)].copy()
+    rows = bases.reshape(n_reads, L)
+    rows[5, 17] = ord("N")                       # whole-read skip (classify.cpp:190-193)
+    rows[6, L - 1] = ord("N")
+    rows[7, 4500 % L] = ord("n")                 # lower case is a base (kmer.h:11)
+    keys = [[], []]
+    for i in range(60):
+        km = hast_amd.chop_read(rows[i, 4000:].tobytes(), k)
+        keys[i & 1] += km[::2]
+        keys[1 - (i & 1)] += km[5::11]           # some keys in both sets
+    keys = [np.unique(np.array(x, dtype=np.uint64)) for x in keys]
+    rows[100:160] = rows[0:60]                   # the key-bearing reads once more, further down the batch
+    ids = rng.integers(0, n_bc, n_reads).astype(np.uint32)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    exp_votes = np.zeros((n_reads, 2), np.uint32)
+    e = [np.zeros(n_bc, np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids_votes(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, n_reads, e[0].ctypes.data,
+                                     e[1].ctypes.data, e[2].ctypes.data, None, exp_votes.ctypes.data, 4)
+    oracle_lib.ho_free(oc)
+    assert int(exp_votes.sum()) > 30 * (L - 4000 - k) and int(e[2].sum()) >= 2
+    for enable in (1, 2, 0):
+        with hast_amd.Context(k) as ctx:
+            ctx.set_filter(enable, fm if enable else 0)
+            ctx.table_reserve(keys[0].size + keys[1].size)
+            ctx.table_insert_keys(0, keys[0])
+            ctx.table_insert_keys(1, keys[1])
+            ctx.counts_resize(n_bc)
+            d_b, d_i, d_v = ctx.to_device(bases), ctx.to_device(ids), ctx.alloc(n_reads * 8)
+            ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i, d_votes=d_v)
+            got = ctx.counts_read(n_bc)
+            votes = ctx.to_host(d_v, (n_reads, 2), np.uint32)
+        assert np.array_equal(votes, exp_votes), (k, L, enable)
+        for a, b in zip(got, e):
+            assert np.array_equal(a, b), (k, L, enable)
+
+
 def ragged_reads(rng, k, keys, n, max_len):
     seqs = []
     for i in range(n):
@@ -510,12 +556,13 @@ def test_counts_allreduce_rccl_path_single_rank(built, monkeypatch):
     assert int(before[0].sum()) > 0
 
 
-@pytest.mark.parametrize("k,n_keys,L,n_reads", [(21, 200_000_000, 150, 2_000_000), (31, 400_000_000, 5000, 40_000)])
-def test_full_scale_tables_placement_invariance(built, k, n_keys, L, n_reads):
-    """BASELINE-size tables (C3: 200M+200M 21-mers, 16 GB; C5: 400M+400M 31-mers, 32 GB -- slot indices beyond 2^32
-    bytes and 2^31 slots): results must not depend on where keys live.  The same reads are classified against a table
-    placed by the default minimizer and against one placed by plain hashing of the key (m = K), in one batch and
-    split in two; set sizes, per-read votes and per-barcode counts must be identical, and hits must exist."""
+@pytest.mark.parametrize("k,n_keys,L,n_reads", [(21, 20_000_000, 150, 500_000), (31, 20_000_000, 5000, 10_000)])
+def test_tables_placement_invariance(built, k, n_keys, L, n_reads):
+    """Results must not depend on where keys live.  The same reads are classified against a table placed by the default
+    minimizer and against one placed by plain hashing of the key (m = K), in one batch and split in two; set sizes,
+    per-read votes and per-barcode counts must be identical, and hits must exist.  (A self-comparison; the BASELINE-size
+    tables -- slot indices beyond 2^32 bytes and 2^31 slots -- are compared with the oracle's full-size sets in
+    test_baseline_size_configs_vs_oracle / test_baseline_config5_size_vs_oracle.)"""
     n_bc = 100_000
     p = make_params(k, L, n_keys, n_bc)
     results = []
@@ -676,6 +723,7 @@ ADAPTOR_F = b"CTGTCTCTTATACACATCTTAGGAAGACAAGCACTGACGACATGA"   # classify.cpp:31
 ADAPTOR_R = b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"   # classify.cpp:313
 
 
+@pytest.mark.heavy
 @pytest.mark.parametrize("name,n_keys,n_bc,n_reads,clustered", [
     ("C2", 50_000_000, 1_000_000, 2_000_000, False),
     ("C3", 200_000_000, 10_000_000, 2_000_000, False),
@@ -734,6 +782,7 @@ def test_baseline_size_configs_vs_oracle(built, oracle_lib, name, n_keys, n_bc, 
     assert int(e[0].sum()) + int(e[1].sum()) > n_reads // 2 and int(e[2].sum()) > 0
 
 
+@pytest.mark.heavy
 def test_baseline_config5_size_vs_oracle(built, oracle_lib):
     """BASELINE config 5 at its full table size on one GPU: K=31, 400M + 400M keys, PacBio-style 20-kb reads, barcode-free
     per-read (hits0, hits1) (S03/src_main/classify.cpp:203-218).  The stage-03 oracle keeps its keys as strings (800M of
