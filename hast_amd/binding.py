@@ -83,6 +83,9 @@ ABI_SYMBOLS = {
     "hast_names_create": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "hast_names_destroy": (None, [vp]),
     "hast_fq_create": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(vp)]),
+    "hast_fq_create_striped": (C.c_int, [C.POINTER(vp), C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
+    "hast_fq_lanes": (C.c_int, [vp]),
+    "hast_fq_lane_records": (C.c_uint64, [vp, C.c_int]),
     "hast_fq_destroy": (None, [vp]),
     "hast_fq_block_bytes": (C.c_size_t, [vp]),
     "hast_fq_acquire": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8))]),

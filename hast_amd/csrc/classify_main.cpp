@@ -13,7 +13,9 @@
 //     kmer.h:154,171);
 //   * K must be in [1,32] like the reference's correct range (it is silently wrong above 32).
 // Additive flags: --device N (GPU ordinal, default 0), --devices A,B,... (several GPUs of this node: the table is built
-// on the first one and copied to the others over xGMI, parsed batches are dealt round-robin, the per-barcode counters are
+// on the first one and copied to the others over xGMI; the BLOCKS of every input file are dealt to the GPUs in turn and framed
+// there -- the reference spreads the reads of one file over all its workers, classify.cpp:211-219 -- (HAST_DEAL=files: whole
+// files in turn, as round 2 did; --host-parse: host-framed batches in turn); the per-barcode counters are
 // summed with ONE RCCL all-reduce at the end -- the thread merge of classify.cpp:226-229,276-277 across GPUs; integer sums,
 // so stdout is byte-identical to a single-GPU run), --block-mb N (ingest block size), --batch-reads N
 // (approximate records per GPU batch, for tests), --initial-barcodes N, --stats (timings on stderr), --host-parse (frame the
@@ -228,7 +230,8 @@ int main(int argc, char **argv) {
     if (batch_reads) block_bytes = std::max<size_t>(4096, std::min(block_bytes, batch_reads * 320));
     const bool block_given = block_mb != 256 || batch_reads;
     // GPU framing: bytes per block of a file, blocks a file may have between its reader and the commit
-    const size_t fq_cap = std::max<size_t>(4096, block_given ? std::min<size_t>(block_bytes, 256u << 20) : (16u << 20));
+    // (a multiple of 4 KB, as the library's blocks are: the blocks of a striped stream must be full)
+    const size_t fq_cap = (std::max<size_t>(4096, block_given ? std::min<size_t>(block_bytes, 256u << 20) : (16u << 20)) + 4095) & ~(size_t)4095;
     const int fq_bufs = 6;
 
     // ---- load_kmers (classify.cpp:30-46): both files to memory, table built on the GPU --------
@@ -241,6 +244,13 @@ int main(int argc, char **argv) {
     std::vector<hast_names *> name_caches;                 // per GPU: device-side cache barcode text -> id
     std::thread pre_thread;
     std::string pre_error;
+    // several GPUs: the blocks of every file go to all of them in turn (a striped stream); HAST_DEAL=files deals whole files
+    bool stripe = false;
+    auto make_fq = [&](size_t file_index, hast_fq **out) -> hast_status {
+        if (stripe)
+            return hast_fq_create_striped(ctxs.data(), (int)ctxs.size(), fq_cap, std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()), name_caches.data(), out);
+        return hast_fq_create(ctxs[file_index % ctxs.size()], fq_cap, fq_bufs, name_caches[file_index % ctxs.size()], out);
+    };
     auto contexts_ready = [&]() {
         ctxs.push_back(ctx);
         for (size_t i = 1; i < devices.size(); i++) {
@@ -249,6 +259,8 @@ int main(int argc, char **argv) {
             ctxs.push_back(c2);
         }
         if (host_parse) return;
+        const char *deal = getenv("HAST_DEAL");
+        stripe = ctxs.size() > 1 && !(deal && !strcmp(deal, "files"));
         size_t name_cap = std::max<size_t>(initial_barcodes, 1u << 22);
         if (const char *e = getenv("HAST_NAME_CACHE")) name_cap = (size_t)atol(e);
         for (hast_ctx *c : ctxs) {
@@ -256,10 +268,10 @@ int main(int argc, char **argv) {
             if (name_cap) CK(hast_names_create(c, name_cap, &nm), "creating the barcode name cache");
             name_caches.push_back(nm);
         }
-        pre_fq.assign(std::min<size_t>(read.size(), std::max<size_t>(4, 2 * ctxs.size())), nullptr);
+        pre_fq.assign(std::min<size_t>(read.size(), stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size())), nullptr);
         pre_thread = std::thread([&] {
             for (size_t i = 0; i < pre_fq.size(); i++)
-                if (hast_fq_create(ctxs[i % ctxs.size()], fq_cap, fq_bufs, name_caches[i % ctxs.size()], &pre_fq[i]) != HAST_OK) {
+                if (make_fq(i, &pre_fq[i]) != HAST_OK) {
                     pre_error = hast_last_error();
                     return;
                 }
@@ -567,7 +579,7 @@ int main(int argc, char **argv) {
             size_t held = 0;                                       // acquired and not yet committed
             size_t submitted = 0, opened = 0;
         };
-        const int n_buf = fq_bufs;
+        const int n_buf = stripe ? std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()) : fq_bufs;     // per context
         double t_create = 0;
         std::mutex wake_mu;
         std::condition_variable wake_cv;
@@ -584,7 +596,7 @@ int main(int argc, char **argv) {
             f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
             const double tc0 = now_s();
             if (next_file < pre_fq.size() && pre_fq[next_file]) f->fq = pre_fq[next_file];     // set up while the table was built
-            else CK(hast_fq_create(ctxs[next_file % ctxs.size()], cap, n_buf, name_caches[next_file % ctxs.size()], &f->fq), "creating the FASTQ stream");
+            else CK(make_fq(next_file, &f->fq), "creating the FASTQ stream");
             t_create += now_s() - tc0;
             next_file++;
             Feed *fp = f.get();
@@ -617,7 +629,7 @@ int main(int argc, char **argv) {
             });
             active.push_back(std::move(f));
         };
-        const size_t max_active = std::max<size_t>(4, 2 * ctxs.size());
+        const size_t max_active = stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size());
         while (next_file < read.size() && active.size() < max_active) open_next();
         uint64_t seen_gen = 0;
         double t_gpu_wait = 0, t_names = 0, t_commit = 0, t_idle = 0;
@@ -664,7 +676,7 @@ int main(int argc, char **argv) {
             for (size_t fi = 0; fi < active.size(); ++fi) {
                 Feed &f = *active[fi];
                 // 1. hand empty buffers to the reader
-                while (!f.eof_acquired && f.held < (size_t)n_buf) {
+                while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq)) {
                     uint8_t *buf;
                     CK(hast_fq_acquire(f.fq, &buf), "staging a block");
                     f.held++;
@@ -722,6 +734,15 @@ int main(int argc, char **argv) {
                 seen_gen = wake_gen;
                 t_idle += now_s() - t0;
             }
+        }
+        if (stats && stripe) {
+            std::string per;
+            for (size_t g = 0; g < ctxs.size(); g++) {
+                uint64_t n = 0;
+                for (hast_fq *q : done_fq) n += hast_fq_lane_records(q, (int)g);
+                per += (g ? "," : "") + std::to_string(n);
+            }
+            fprintf(stderr, "__stats_devices__ blocks_of_every_file_dealt_to=%zu records_per_context=%s\n", ctxs.size(), per.c_str());
         }
         if (stats)
             fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f records_named_on_host=%llu\n",

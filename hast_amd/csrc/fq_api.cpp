@@ -43,6 +43,13 @@ struct Slot {
     hipEvent_t copied = nullptr, parsed = nullptr, done = nullptr;
     enum { FREE, ACQUIRED, SUBMITTED, OPEN } state = FREE;
     bool done_pending = false;
+    // striped streams
+    int lane = 0;                                      // which context / GPU this slot's buffers live on
+    FqState *h_cnt = nullptr;                          // pinned: the newline count of the block's own bytes lands here
+    hipEvent_t counted = nullptr, over_copied = nullptr;
+    size_t n_over = 0;                                 // bytes of the next block behind this block's own bytes
+    bool over_ready = false, eof_view = false, first_of_file = false;
+    uint8_t last_byte = 0;
 };
 }  // namespace
 
@@ -54,10 +61,24 @@ struct hast_names {            // device-side cache barcode text -> id of one GP
     size_t count = 0, limit = 0;                       // entries published / published at most (half the slots)
 };
 
+struct FqLane {                // what a striped stream keeps per context: its GPU's streams and name cache
+    hast_ctx *ctx = nullptr;
+    hast_names *names = nullptr;
+    int device = 0;
+    hipStream_t copy_stream = nullptr, parse_stream = nullptr;
+};
+
 struct hast_fq {
     hast_ctx *ctx = nullptr;
     hast_names *names = nullptr;
     int device = 0, k = 0;
+    // striped: block i of the stream lives on lane i % lanes.size(); framed from the newline count of the blocks in front of it
+    bool striped = false;
+    std::vector<FqLane> lanes;
+    size_t over_cap = 0;                                       // bytes of the next block a block's view may reach into
+    size_t n_framed = 0;                                       // blocks whose framing has been launched
+    uint64_t nl_before = 0;                                    // newlines of the current file in front of block n_framed
+    std::vector<uint64_t> records_per_lane;
     size_t block = 0, pad = 0, max_rec = 0;
     std::vector<Slot> slots;
     size_t n_acquired = 0, n_submitted = 0, n_opened = 0;      // blocks handed out / submitted / returned by hast_fq_next
@@ -90,6 +111,9 @@ static hast_status grow_records(Slot &s, size_t cap) {
 }
 
 static void free_slot(Slot &s) {
+    if (s.h_cnt) (void)hipHostFree(s.h_cnt);
+    if (s.counted) (void)hipEventDestroy(s.counted);
+    if (s.over_copied) (void)hipEventDestroy(s.over_copied);
     if (s.h_buf) (void)hipHostFree(s.h_buf);
     if (s.h_st) (void)hipHostFree(s.h_st);
     if (s.h_bc) (void)hipHostFree(s.h_bc);
@@ -105,6 +129,94 @@ static void free_slot(Slot &s) {
     if (s.parsed) (void)hipEventDestroy(s.parsed);
     if (s.done) (void)hipEventDestroy(s.done);
     s = Slot();
+}
+
+static int dev_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].device : f->device; }
+static hast_ctx *ctx_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].ctx : f->ctx; }
+static hast_names *names_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].names : f->names; }
+
+// Striped streams: launch the framing of every block that can be framed now, in order.  Block j needs (a) the bytes of block
+// j + 1 that its records may reach into (there once j + 1 has been submitted, or j ends its file) and (b) the number of
+// newlines in front of it: the count of block j - 1's own bytes (a kernel of its own, queued right behind that block's
+// upload) added to the running sum of the file.  wait: block on (b) instead of giving up (hast_fq_next needs its block).
+static hast_status advance_striped(hast_fq *f, bool wait, size_t upto) {
+    while (f->n_framed < f->n_submitted && f->n_framed < upto) {
+        const size_t j = f->n_framed;
+        Slot &s = f->slots[j % f->slots.size()];
+        if (!s.over_ready) break;
+        uint32_t phase = 0;
+        int bol = 1;
+        if (s.first_of_file) f->nl_before = 0;
+        else {
+            Slot &pv = f->slots[(j - 1) % f->slots.size()];
+            FQ_TRY(hipSetDevice(dev_of(f, pv)));
+            if (wait) FQ_TRY(hipEventSynchronize(pv.counted));
+            else {
+                const hipError_t q = hipEventQuery(pv.counted);
+                if (q == hipErrorNotReady) break;
+                if (q != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+            }
+            f->nl_before += pv.h_cnt->n_nl;
+            bol = pv.last_byte == '\n';
+        }
+        phase = (uint32_t)(f->nl_before & 3);
+        FqLane &ln = f->lanes[(size_t)s.lane];
+        FQ_TRY(hipSetDevice(ln.device));
+        if (s.n_over) FQ_TRY(hipStreamWaitEvent(ln.parse_stream, s.over_copied, 0));
+        FQ_TRY(launch_fq_block_striped(s.d_buf, s.d_st, f->pad, s.n_bytes, s.n_over, phase, bol, s.eof_view ? 1 : 0, s.d_tile, s.d_nl, s.d_off, s.d_len,
+                                       s.d_bcpos, s.d_bclen, s.h_bc, s.d_text, (uint32_t)s.h_cap, (uint32_t)f->k, ln.parse_stream));
+        s.k_cap = s.h_cap;
+        FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, ln.parse_stream));
+        FQ_TRY(hipEventRecord(s.parsed, ln.parse_stream));
+        f->n_framed++;
+    }
+    return HAST_OK;
+}
+
+static hast_status submit_striped(hast_fq *f, size_t n_bytes, int last) {
+    const size_t i = f->n_submitted, S = f->slots.size();
+    if (!last && n_bytes != f->block)
+        return set_error(HAST_ERR_INVALID, "a striped stream takes full blocks (%zu bytes) except for the last one of a file, got %zu", f->block, n_bytes);
+    // this slot held block i - S; the framing of block i - S + 1 read that block's newline count and last byte: it must have been
+    // launched before they are overwritten
+    if (i >= S)
+        if (hast_status st = advance_striped(f, true, i - S + 2)) return st;
+    Slot &s = f->slots[i % S];
+    FqLane &ln = f->lanes[(size_t)s.lane];
+    FQ_TRY(hipSetDevice(ln.device));
+    s.n_bytes = n_bytes;
+    s.last = last;
+    s.n_over = 0;
+    s.over_ready = last != 0;                      // the last block of a file has nothing behind it
+    s.eof_view = last != 0;
+    s.first_of_file = i == 0 || f->slots[(i - 1) % S].last != 0;
+    s.last_byte = n_bytes ? s.h_buf[f->pad + n_bytes - 1] : (uint8_t)'\n';
+    if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, ln.copy_stream));
+    FQ_TRY(hipEventRecord(s.copied, ln.copy_stream));
+    FQ_TRY(hipStreamWaitEvent(ln.parse_stream, s.copied, 0));
+    // newlines of the block's own bytes, for the blocks behind it
+    FQ_TRY(launch_fq_count_own(s.d_buf, s.d_st, f->pad, n_bytes, s.d_tile, ln.parse_stream));
+    FQ_TRY(hipMemcpyAsync(s.h_cnt, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, ln.parse_stream));
+    FQ_TRY(hipEventRecord(s.counted, ln.parse_stream));
+    if (!s.first_of_file) {
+        // the block in front gets the first bytes of this one behind its own: host copy (the barcode extents of its records may
+        // point there) + upload on ITS GPU
+        Slot &pv = f->slots[(i - 1) % S];
+        FqLane &pl = f->lanes[(size_t)pv.lane];
+        const size_t ov = std::min(f->over_cap, n_bytes);
+        pv.n_over = ov;
+        pv.eof_view = last != 0 && ov == n_bytes;  // the whole rest of the file is in its view
+        if (ov) {
+            memcpy(pv.h_buf + f->pad + pv.n_bytes, s.h_buf + f->pad, ov);
+            FQ_TRY(hipSetDevice(pl.device));
+            FQ_TRY(hipMemcpyAsync(pv.d_buf + f->pad + pv.n_bytes, pv.h_buf + f->pad + pv.n_bytes, ov, hipMemcpyHostToDevice, pl.copy_stream));
+            FQ_TRY(hipEventRecord(pv.over_copied, pl.copy_stream));
+        }
+        pv.over_ready = true;
+    }
+    s.state = Slot::SUBMITTED;
+    f->n_submitted++;
+    return advance_striped(f, false, f->n_submitted);
 }
 
 extern "C" {
@@ -140,6 +252,29 @@ void hast_names_destroy(hast_names *nm) {
     delete nm;
 }
 
+// buffers + events of one slot, on the current device
+static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, size_t block, bool striped) {
+    FQ_TRY(hipHostMalloc((void **)&s.h_buf, buf, hipHostMallocDefault));
+    FQ_TRY(hipHostMalloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault));
+    FQ_TRY(hipMalloc((void **)&s.d_buf, buf));
+    FQ_TRY(hipMalloc((void **)&s.d_st, sizeof(FqState)));
+    FQ_TRY(hipMalloc((void **)&s.d_tile, (buf / 4096 + 2) * sizeof(uint32_t)));
+    FQ_TRY(hipMalloc((void **)&s.d_nl, (buf + 16) * sizeof(uint32_t)));
+    FQ_TRY(hipMalloc((void **)&s.d_off, max_rec * sizeof(uint64_t)));
+    for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) FQ_TRY(hipMalloc((void **)p, max_rec * sizeof(uint32_t)));
+    FQ_TRY(hipMalloc((void **)&s.d_votes, max_rec * 2 * sizeof(uint32_t)));
+    size_t cap = block / 96 + 4096;                    // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
+    if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) cap = (size_t)std::max(1L, atol(e));           // (tests: force the copy path)
+    if (hast_status st = grow_records(s, cap)) return st;
+    for (hipEvent_t *e : {&s.named, &s.copied, &s.parsed, &s.done}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (striped) {
+        FQ_TRY(hipHostMalloc((void **)&s.h_cnt, sizeof(FqState), hipHostMallocDefault));
+        for (hipEvent_t *e : {&s.counted, &s.over_copied}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    (void)pad;
+    return HAST_OK;
+}
+
 hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, hast_names *names, hast_fq **out) {
     if (!ctx || !out) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -158,34 +293,62 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
     const size_t buf = f->pad + f->block + 4096;
     f->max_rec = (f->pad + f->block) / 4 + 2;                                           // a record holds at least four newlines
     f->slots.resize((size_t)n_buffers);
-    hast_status st = HAST_OK;
     if (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&f->parse_stream, hipStreamNonBlocking) != hipSuccess) {
         if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
         delete f;
         return set_error(HAST_ERR_HIP, "hipStreamCreate failed");
     }
-    auto ck = [&](hipError_t e, const char *what) {
-        if (e != hipSuccess && st == HAST_OK) st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
-    };
-    for (Slot &s : f->slots) {
-        ck(hipHostMalloc((void **)&s.h_buf, buf, hipHostMallocDefault), "pinned block");
-        ck(hipHostMalloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault), "pinned state");
-        ck(hipMalloc((void **)&s.d_buf, buf), "device block");
-        ck(hipMalloc((void **)&s.d_st, sizeof(FqState)), "device state");
-        ck(hipMalloc((void **)&s.d_tile, (buf / 4096 + 2) * sizeof(uint32_t)), "tile counts");
-        ck(hipMalloc((void **)&s.d_nl, (f->pad + f->block + 16) * sizeof(uint32_t)), "newline index");
-        ck(hipMalloc((void **)&s.d_off, f->max_rec * sizeof(uint64_t)), "record offsets");
-        for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) ck(hipMalloc((void **)p, f->max_rec * sizeof(uint32_t)), "record arrays");
-        ck(hipMalloc((void **)&s.d_votes, f->max_rec * 2 * sizeof(uint32_t)), "votes");
-        size_t cap = f->block / 96 + 4096;                 // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
-        if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) cap = (size_t)std::max(1L, atol(e));           // (tests: force the copy path)
-        if (st == HAST_OK) st = grow_records(s, cap);
-        ck(hipEventCreateWithFlags(&s.named, hipEventDisableTiming), "event");
-        ck(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming), "event");
-        ck(hipEventCreateWithFlags(&s.parsed, hipEventDisableTiming), "event");
-        ck(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "event");
-        if (st != HAST_OK) break;
+    for (Slot &s : f->slots)
+        if (hast_status st = alloc_slot(s, buf, f->max_rec, f->pad, f->block, false)) {
+            hast_fq_destroy(f);
+            return st;
+        }
+    *out = f;
+    return HAST_OK;
+}
+
+// A stream whose blocks go to n_ctx contexts in turn (block i -> context i % n_ctx): the blocks of ONE file on several GPUs, like
+// the reference spreads the reads of one file over all its workers (classify.cpp:211-219).  A block is framed on its own GPU
+// from the number of newlines in front of it in the file (fq_kernels.hip, "striped streams").
+hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx, hast_names *const *names, hast_fq **out) {
+    if (!ctxs || !out || n_ctx < 1) return set_error(HAST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (block_bytes < 4096 || block_bytes > (1ull << 30)) return set_error(HAST_ERR_INVALID, "block_bytes %zu out of [4 KB, 1 GB]", block_bytes);
+    if (n_buffers_per_ctx < 2 || n_buffers_per_ctx * n_ctx > 64) return set_error(HAST_ERR_INVALID, "n_buffers_per_ctx %d out of range for %d contexts", n_buffers_per_ctx, n_ctx);
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctxs[i] || hast_ctx_k(ctxs[i]) != hast_ctx_k(ctxs[0])) return set_error(HAST_ERR_INVALID, "contexts need one K");
+        if (names && names[i] && names[i]->ctx != ctxs[i]) return set_error(HAST_ERR_INVALID, "name cache %d belongs to another context", i);
+    }
+    hast_fq *f = new (std::nothrow) hast_fq();
+    if (!f) return set_error(HAST_ERR_OOM, "host allocation failed");
+    f->striped = true;
+    f->ctx = ctxs[0];
+    f->device = hast_ctx_device(ctxs[0]);
+    f->k = hast_ctx_k(ctxs[0]);
+    f->block = (block_bytes + 4095) & ~(size_t)4095;
+    f->pad = 1u << 20;
+    f->over_cap = std::min(f->pad, f->block);              // a record reaches into the next block only: at most this many bytes
+    const size_t buf = f->pad + f->block + f->over_cap + 4096;
+    f->max_rec = (f->block + f->over_cap) / 4 + 4;
+    f->lanes.resize((size_t)n_ctx);
+    f->records_per_lane.assign((size_t)n_ctx, 0);
+    f->slots.resize((size_t)n_buffers_per_ctx * (size_t)n_ctx);
+    hast_status st = HAST_OK;
+    for (int i = 0; i < n_ctx && st == HAST_OK; i++) {
+        FqLane &ln = f->lanes[(size_t)i];
+        ln.ctx = ctxs[i];
+        ln.names = names ? names[i] : nullptr;
+        ln.device = hast_ctx_device(ctxs[i]);
+        if (hipSetDevice(ln.device) != hipSuccess || hipStreamCreateWithFlags(&ln.copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&ln.parse_stream, hipStreamNonBlocking) != hipSuccess)
+            st = set_error(HAST_ERR_HIP, "hipStreamCreate failed on device %d", ln.device);
+    }
+    for (size_t si = 0; si < f->slots.size() && st == HAST_OK; si++) {
+        Slot &s = f->slots[si];
+        s.lane = (int)(si % (size_t)n_ctx);
+        if (hipSetDevice(f->lanes[(size_t)s.lane].device) != hipSuccess) st = set_error(HAST_ERR_HIP, "hipSetDevice failed");
+        else st = alloc_slot(s, buf, f->max_rec, f->pad, f->block, true);
     }
     if (st != HAST_OK) {
         hast_fq_destroy(f);
@@ -197,6 +360,23 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
 
 void hast_fq_destroy(hast_fq *f) {
     if (!f) return;
+    if (f->striped) {
+        for (FqLane &ln : f->lanes) {
+            (void)hipSetDevice(ln.device);
+            if (ln.ctx) (void)hipStreamSynchronize(ctx_stream_of(ln.ctx));
+            for (hipStream_t st : {ln.copy_stream, ln.parse_stream})
+                if (st) {
+                    (void)hipStreamSynchronize(st);
+                    (void)hipStreamDestroy(st);
+                }
+        }
+        for (Slot &s : f->slots) {
+            (void)hipSetDevice(f->lanes[(size_t)s.lane].device);
+            free_slot(s);
+        }
+        delete f;
+        return;
+    }
     (void)hipSetDevice(f->device);
     (void)hipStreamSynchronize(ctx_stream_of(f->ctx));
     for (hipStream_t st : {f->copy_stream, f->parse_stream})
@@ -208,13 +388,20 @@ void hast_fq_destroy(hast_fq *f) {
     delete f;
 }
 
+int hast_fq_lanes(const hast_fq *f) { return !f ? 0 : f->striped ? (int)f->lanes.size() : 1; }
+uint64_t hast_fq_lane_records(const hast_fq *f, int lane) {
+    if (!f || lane < 0) return 0;
+    if (!f->striped) return 0;
+    return (size_t)lane < f->records_per_lane.size() ? f->records_per_lane[(size_t)lane] : 0;
+}
+
 size_t hast_fq_block_bytes(const hast_fq *f) { return f ? f->block : 0; }
 
 hast_status hast_fq_acquire(hast_fq *f, uint8_t **host_buf) {
     if (!f || !host_buf) return set_error(HAST_ERR_INVALID, "null argument");
     Slot &s = f->slots[f->n_acquired % f->slots.size()];
     if (s.state != Slot::FREE) return set_error(HAST_ERR_INVALID, "hast_fq_acquire: all %zu buffers are in use (commit the oldest block first)", f->slots.size());
-    FQ_TRY(hipSetDevice(f->device));
+    FQ_TRY(hipSetDevice(dev_of(f, s)));
     if (s.done_pending) {
         FQ_TRY(hipEventSynchronize(s.done));
         s.done_pending = false;
@@ -229,6 +416,7 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     if (!f) return set_error(HAST_ERR_INVALID, "null argument");
     if (f->n_submitted >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_submit without hast_fq_acquire");
     if (n_bytes > f->block) return set_error(HAST_ERR_INVALID, "block of %zu bytes exceeds the capacity %zu", n_bytes, f->block);
+    if (f->striped) return submit_striped(f, n_bytes, last);
     const int si = (int)(f->n_submitted % f->slots.size());
     Slot &s = f->slots[(size_t)si];
     FQ_TRY(hipSetDevice(f->device));
@@ -257,7 +445,10 @@ int hast_fq_poll(hast_fq *f) {
     if (!f || f->n_opened >= f->n_submitted) return 0;
     Slot &s = f->slots[f->n_opened % f->slots.size()];
     if (s.state != Slot::SUBMITTED) return 0;
-    (void)hipSetDevice(f->device);
+    if (f->striped) {
+        if (advance_striped(f, false, f->n_submitted) != HAST_OK || f->n_framed <= f->n_opened) return 0;
+    }
+    (void)hipSetDevice(dev_of(f, s));
     return hipEventQuery(s.parsed) == hipSuccess ? 1 : 0;
 }
 
@@ -268,11 +459,18 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     Slot &s = f->slots[f->n_opened % f->slots.size()];
     if (s.state != Slot::SUBMITTED || (f->n_opened && f->slots[(f->n_opened - 1) % f->slots.size()].state == Slot::OPEN))
         return set_error(HAST_ERR_INVALID, "hast_fq_next: commit the previous block first");
-    FQ_TRY(hipSetDevice(f->device));
-    hipStream_t hs = ctx_stream_of(f->ctx);
+    if (f->striped) {
+        if (hast_status a = advance_striped(f, true, f->n_opened + 1)) return a;
+        if (f->n_framed <= f->n_opened)
+            return set_error(HAST_ERR_INVALID, "hast_fq_next: a block of a striped stream is framed once the block behind it has been submitted (or it ends the file)");
+    }
+    hast_ctx *const sctx = ctx_of(f, s);
+    hast_names *const snames = names_of(f, s);
+    FQ_TRY(hipSetDevice(dev_of(f, s)));
+    hipStream_t hs = ctx_stream_of(sctx);
     FQ_TRY(hipEventSynchronize(s.parsed));
     const FqState st = *s.h_st;
-    if (st.flags & 2) return set_error(HAST_ERR_FORMAT, "a FASTQ record is larger than %zu bytes", f->pad);
+    if (st.flags & 2) return set_error(HAST_ERR_FORMAT, "a FASTQ record is larger than %zu bytes", f->striped ? f->over_cap : f->pad);
     if (st.n_rec > f->max_rec) return set_error(HAST_ERR_INVALID, "record table overflow");
     const size_t n = st.n_rec;
     const bool by_copy = n > s.k_cap;          // more (short) records than the kernel could write to the host itself
@@ -284,22 +482,27 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
         FQ_TRY(hipEventRecord(s.parsed, hs));
     }
     // ids from the device-side name cache (after a few blocks nearly every barcode of a block has been seen before)
-    s.use_cache = f->names && n && !by_copy;
+    s.use_cache = snames && n && !by_copy;
     if (s.use_cache) {
         s.h_unknown[0] = 0;
-        FQ_TRY(launch_fq_name(s.d_text, (uint32_t)n, f->names->d_tab, f->names->mask, s.h_ids, s.h_unknown, hs));
+        FQ_TRY(launch_fq_name(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, s.h_ids, s.h_unknown, hs));
         FQ_TRY(hipEventRecord(s.named, hs));
     }
     // the reads are classified where they lie in the raw block WHILE the host names the barcodes
     if (n && !(st.flags & 1))
-        if (hast_status c = classify_framed(f->ctx, s.d_buf, f->pad + s.n_bytes, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
+        if (hast_status c = classify_framed(sctx, s.d_buf, f->pad + s.n_bytes + s.n_over, s.d_off, s.d_len, st.max_len, s.d_votes, n, hs)) return c;
     if (by_copy) FQ_TRY(hipEventSynchronize(s.parsed));        // (the event sits in front of the kernels)
     if (s.use_cache) FQ_TRY(hipEventSynchronize(s.named));
+    if (f->striped) {
+        // (the host view already holds the first bytes of the next block behind this block's own: submit_striped put them there)
+        f->records_per_lane[(size_t)s.lane] += n;
+    } else {
     // host view of the bytes the barcode extents point into: this block's bytes, preceded by the previous block's tail
     if (st.tail_in != f->carry.size()) return set_error(HAST_ERR_INVALID, "tail bookkeeping out of step (%llu vs %zu)", (unsigned long long)st.tail_in, f->carry.size());
     if (!f->carry.empty()) memcpy(s.h_buf + f->pad - f->carry.size(), f->carry.data(), f->carry.size());
     const size_t tail = s.last ? 0 : (size_t)(st.parse_hi - st.tail_lo);
     f->carry.assign(s.h_buf + st.parse_hi - tail, s.h_buf + st.parse_hi);
+    }
     out->n_records = n;
     out->n_bases = st.bases;
     out->max_read_len = st.max_len;
@@ -321,16 +524,17 @@ hast_status hast_fq_commit(hast_fq *f) {
     if (f->n_opened == 0) return set_error(HAST_ERR_INVALID, "hast_fq_commit without hast_fq_next");
     Slot &s = f->slots[(f->n_opened - 1) % f->slots.size()];
     if (s.state != Slot::OPEN) return set_error(HAST_ERR_INVALID, "hast_fq_commit: no open block");
-    FQ_TRY(hipSetDevice(f->device));
-    hipStream_t hs = ctx_stream_of(f->ctx);
+    hast_ctx *const sctx = ctx_of(f, s);
+    FQ_TRY(hipSetDevice(dev_of(f, s)));
+    hipStream_t hs = ctx_stream_of(sctx);
     const size_t n = s.h_st->n_rec;
     if (n && !(s.h_st->flags & 1)) {
-        const size_t nbc = ctx_n_barcodes(f->ctx);
+        const size_t nbc = ctx_n_barcodes(sctx);
         if (s.use_cache) {
             // the caller named the records the cache did not know: check those, teach the cache, and let the bookkeeping kernel
             // read the ids where they are (pinned host memory: a copy would queue up behind the next block's upload)
             const uint32_t nu = s.h_unknown[0];
-            hast_names *nm = f->names;
+            hast_names *nm = names_of(f, s);
             uint32_t np = 0;
             for (uint32_t j = 0; j < nu; ++j) {
                 const uint32_t i = s.h_unknown[1 + j];
@@ -345,12 +549,12 @@ hast_status hast_fq_commit(hast_fq *f) {
                 FQ_TRY(launch_names_insert(s.h_pubs, np, nm->d_tab, nm->mask, hs));
                 nm->count += np;                               // (an upper bound: a barcode met twice in one block is counted twice)
             }
-            if (hast_status c = commit_framed(f->ctx, s.d_votes, s.h_ids, n, hs)) return c;
+            if (hast_status c = commit_framed(sctx, s.d_votes, s.h_ids, n, hs)) return c;
         } else {
             for (size_t i = 0; i < n; ++i)
                 if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %zu is outside the %zu counters", s.h_ids[i], i, nbc);
             FQ_TRY(hipMemcpyAsync(s.d_ids, s.h_ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, hs));
-            if (hast_status c = commit_framed(f->ctx, s.d_votes, s.d_ids, n, hs)) return c;
+            if (hast_status c = commit_framed(sctx, s.d_votes, s.d_ids, n, hs)) return c;
         }
     }
     FQ_TRY(hipEventRecord(s.done, hs));

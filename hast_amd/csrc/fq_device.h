@@ -13,6 +13,13 @@ struct FqState {               // one per buffer slot, in device memory; copied 
     uint32_t n_nl, n_rec;          // newlines in the parse range, records framed
     uint32_t max_len;              // longest base line
     uint32_t flags;                // 1: a read shorter than K without 'N' (the reference aborts, kmer.h:171); 2: a record larger than the pad
+    // striped streams (the blocks of one file go to several GPUs): the view [parse_lo, parse_hi) = this block's own bytes
+    // followed by the first bytes of the next block; records that START before own_hi are this block's
+    uint64_t own_hi;
+    uint32_t phase;                // newlines of the file in front of parse_lo, mod 4 (the line of a record parse_lo lies in)
+    uint32_t bol;                  // a line starts at parse_lo (the byte in front of it is a newline, or the file starts here)
+    uint32_t eof;                  // the file ends at parse_hi
+    uint32_t reserved;
 };
 
 // Device-side cache barcode text -> dense id (the authority stays the host's dictionary, which is one per job): 32-byte
@@ -37,5 +44,13 @@ hipError_t launch_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, 
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
                            uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last, hipStream_t s);
+
+// ---- striped streams: a block is framed on its own, from the number of newlines in front of it ----------------------------
+// newlines of the block's own bytes [pad, pad + n_bytes) -> d_st->n_nl (the host adds them up over the blocks of the file)
+hipError_t launch_fq_count_own(const uint8_t *d_buf, FqState *d_st, uint64_t pad, uint64_t n_bytes, uint32_t *d_tile_cnt, hipStream_t s);
+// frames the records that start in [pad, pad + n_bytes); their header and base lines may reach into the n_over bytes behind
+hipError_t launch_fq_block_striped(const uint8_t *d_buf, FqState *d_st, uint64_t pad, uint64_t n_bytes, uint64_t n_over, uint32_t phase, int bol, int eof,
+                                   uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
+                                   uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, hipStream_t s);
 
 }  // namespace hast

@@ -100,30 +100,10 @@ __global__ void __launch_bounds__(256) k_fq_index(const uint8_t *buf, const FqSt
     }
 }
 
-// One lane per complete record i (lines 4i .. 4i+3 of the parse range, which always starts at a record boundary).
-// `last`: the input ends with this block, so a final record whose header line is terminated counts even when its bases /
-// '+' / quality lines lack their newlines (classify.cpp:257-268: a getline that hits EOF still yields the line read).
-// h_bc: pinned HOST memory the kernel writes the first h_cap barcode extents to ([pos x h_cap | len x h_cap]), so that the host
-// needs no device-to-host copy for them (such a copy would queue up behind the next block's 16-MB upload), followed by the
-// barcode TEXT itself, 16 bytes per record: length byte + up to 15 bytes (0xFF: longer, take it from the block).  The host
-// then names a record from one compact, sequentially read array instead of one cache miss per header line.
-__global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
-                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last) {
-    const uint64_t lo = st->parse_lo, hi = st->parse_hi;
-    const uint32_t n_nl = st->n_nl;
-    uint32_t n_rec = n_nl / 4;
-    // the EOF record without all four newlines: it counts iff its header line is terminated (even with an empty bases line)
-    const bool partial = last && n_nl - 4 * n_rec >= 1;
-    const uint32_t total = n_rec + (partial ? 1 : 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->n_rec = total;
-        const uint64_t consumed = last ? hi : (n_rec ? (uint64_t)nl[4 * n_rec - 1] + 1 : lo);
-        st->tail_lo = consumed;                               // bytes [consumed, hi) belong to the next block's first record
-    }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const uint64_t h0 = i ? (uint64_t)nl[4 * i - 1] + 1 : lo;
-    const uint64_t h1 = nl[4 * i];                            // end of the header line (exists for every counted record)
-    const uint64_t s1 = (4 * i + 1 < n_nl) ? nl[4 * i + 1] : hi;   // end of the bases line, or EOF
+// record i of a block: header line [h0, h1), bases [h1 + 1, s1)
+__device__ __forceinline__ void fq_emit_record(const uint8_t *buf, FqState *st, uint32_t i, uint64_t h0, uint64_t h1, uint64_t s1, uint64_t *r_off,
+                                               uint32_t *r_len, uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap,
+                                               uint32_t k) {
     const uint32_t len = (uint32_t)(s1 - h1 - 1 > 0xFFFFFFFFull ? 0xFFFFFFFFull : s1 - h1 - 1);
     r_off[i] = h1 + 1;
     r_len[i] = len;
@@ -157,7 +137,78 @@ __global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState 
         for (uint64_t p = h1 + 1; p < s1 && !has_n; ++p) has_n = buf[p] == 'N';
         if (!has_n) atomicOr(&st->flags, 1u);
     }
+}
+
+// One lane per complete record i (lines 4i .. 4i+3 of the parse range, which always starts at a record boundary).
+// `last`: the input ends with this block, so a final record whose header line is terminated counts even when its bases /
+// '+' / quality lines lack their newlines (classify.cpp:257-268: a getline that hits EOF still yields the line read).
+// h_bc: pinned HOST memory the kernel writes the first h_cap barcode extents to ([pos x h_cap | len x h_cap]), so that the host
+// needs no device-to-host copy for them (such a copy would queue up behind the next block's 16-MB upload), followed by the
+// barcode TEXT itself, 16 bytes per record: length byte + up to 15 bytes (0xFF: longer, take it from the block).  The host
+// then names a record from one compact, sequentially read array instead of one cache miss per header line.
+__global__ void __launch_bounds__(256) k_fq_records(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
+                                                    uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last) {
+    const uint64_t lo = st->parse_lo, hi = st->parse_hi;
+    const uint32_t n_nl = st->n_nl;
+    uint32_t n_rec = n_nl / 4;
+    // the EOF record without all four newlines: it counts iff its header line is terminated (even with an empty bases line)
+    const bool partial = last && n_nl - 4 * n_rec >= 1;
+    const uint32_t total = n_rec + (partial ? 1 : 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->n_rec = total;
+        const uint64_t consumed = last ? hi : (n_rec ? (uint64_t)nl[4 * n_rec - 1] + 1 : lo);
+        st->tail_lo = consumed;                               // bytes [consumed, hi) belong to the next block's first record
     }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint64_t h0 = i ? (uint64_t)nl[4 * i - 1] + 1 : lo;
+        const uint64_t h1 = nl[4 * i];                            // end of the header line (exists for every counted record)
+        const uint64_t s1 = (4 * i + 1 < n_nl) ? nl[4 * i + 1] : hi;   // end of the bases line, or EOF
+        fq_emit_record(buf, st, i, h0, h1, s1, r_off, r_len, bc_pos, bc_len, h_bc, d_text, h_cap, k);
+    }
+}
+
+// Striped streams: the blocks of ONE file are framed on several GPUs (classify.cpp:211-219 spreads the reads of one file over
+// all its workers).  A block cannot wait for the block in front of it, so it is framed from what the host can know early: the
+// number of newlines in the bytes in front of it (k_fq_count of the earlier blocks, summed on the host), i.e. the line `phase`
+// its first byte lies in.  Records are four lines counted from the start of the file (no '@'/'+' validation), so a record
+// starts behind every newline whose index in the file is 3 mod 4 -- and at the block's first byte when phase == 0 and a line
+// starts there.  A block owns the records that START in its own bytes; their header and base lines may reach into the view's
+// overlap (the first bytes of the next block); '+' and quality lines are only ever counted.
+__global__ void __launch_bounds__(256) k_fq_records_striped(const uint8_t *buf, FqState *st, const uint32_t *nl, uint64_t *r_off, uint32_t *r_len,
+                                                            uint32_t *bc_pos, uint32_t *bc_len, uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap,
+                                                            uint32_t k) {
+    const uint64_t lo = st->parse_lo, hi = st->parse_hi, own_hi = st->own_hi;
+    const uint32_t n_nl = st->n_nl, s0 = (3u - st->phase) & 3u;       // nl[s0], nl[s0 + 4], ... end a record
+    const uint32_t has0 = (st->phase == 0 && st->bol) ? 1u : 0u;      // a record starts at lo
+    const bool eof = st->eof != 0;
+    const uint32_t cand = has0 + (n_nl > s0 ? (n_nl - s0 + 3) / 4 : 0);
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < cand; c += gridDim.x * blockDim.x) {
+        const uint32_t j = s0 + 4 * (c - has0);                       // (c >= has0) the newline in front of the record
+        const uint64_t h0 = c < has0 ? lo : (uint64_t)nl[j] + 1;
+        if (h0 >= own_hi) continue;                                   // starts in the next block (or at EOF): not this block's
+        const uint32_t hidx = c < has0 ? 0u : j + 1;                  // the newline that ends its header line
+        if (hidx >= n_nl) {
+            // the header line is not terminated inside the view: at EOF the reference drops such a record (classify.cpp:257-259);
+            // anywhere else the record is larger than the overlap
+            if (!eof) atomicOr(&st->flags, 2u);
+            continue;
+        }
+        const uint64_t h1 = nl[hidx];
+        uint64_t s1 = hi;                                             // at EOF the bases are whatever follows (classify.cpp:260-268)
+        if (hidx + 1 < n_nl) s1 = nl[hidx + 1];
+        else if (!eof) { atomicOr(&st->flags, 2u); continue; }
+        atomicMax(&st->n_rec, c + 1);                                 // the records of a block are a prefix of its candidates
+        fq_emit_record(buf, st, c, h0, h1, s1, r_off, r_len, bc_pos, bc_len, h_bc, d_text, h_cap, k);
+    }
+}
+
+__global__ void k_fq_view(FqState *st, uint64_t lo, uint64_t hi, uint64_t own_hi, uint32_t phase, uint32_t bol, uint32_t eof) {
+    st->parse_lo = lo;
+    st->parse_hi = hi;
+    st->own_hi = own_hi;
+    st->phase = phase;
+    st->bol = bol;
+    st->eof = eof;
 }
 
 // copies the previous block's tail in front of this block's bytes and sets the parse range; one workgroup is plenty
@@ -250,6 +301,30 @@ hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_
     hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
     hipLaunchKernelGGL(k_fq_index, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt, d_nl);
     hipLaunchKernelGGL(k_fq_records, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, h_bc, d_text, h_cap, k, last);
+    return hipGetLastError();
+}
+
+hipError_t launch_fq_count_own(const uint8_t *d_buf, FqState *d_st, uint64_t pad, uint64_t n_bytes, uint32_t *d_tile_cnt, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_st, 0, sizeof(FqState), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fq_view, dim3(1), dim3(1), 0, s, d_st, pad, pad + n_bytes, pad + n_bytes, 0u, 0u, 0u);
+    const uint32_t n_tiles = (uint32_t)((pad + n_bytes + kFqTile - 1) / kFqTile);
+    hipLaunchKernelGGL(k_fq_count, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
+    return hipGetLastError();
+}
+
+hipError_t launch_fq_block_striped(const uint8_t *d_buf, FqState *d_st, uint64_t pad, uint64_t n_bytes, uint64_t n_over, uint32_t phase, int bol, int eof,
+                                   uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
+                                   uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_st, 0, sizeof(FqState), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fq_view, dim3(1), dim3(1), 0, s, d_st, pad, pad + n_bytes + n_over, pad + n_bytes, phase, bol ? 1u : 0u, eof ? 1u : 0u);
+    const uint32_t n_tiles = (uint32_t)((pad + n_bytes + n_over + kFqTile - 1) / kFqTile);
+    hipLaunchKernelGGL(k_fq_count, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, s, d_tile_cnt, n_tiles, d_st);
+    hipLaunchKernelGGL(k_fq_index, dim3(n_tiles), dim3(256), 0, s, d_buf, d_st, d_tile_cnt, d_nl);
+    hipLaunchKernelGGL(k_fq_records_striped, dim3(2048), dim3(256), 0, s, d_buf, d_st, d_nl, d_off, d_len, d_bc_pos, d_bc_len, h_bc, d_text, h_cap, k);
     return hipGetLastError();
 }
 

@@ -259,6 +259,19 @@ typedef struct hast_names hast_names;
 hast_status hast_names_create(hast_ctx *, size_t max_barcodes, hast_names **out);
 void        hast_names_destroy(hast_names *);
 hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_names *names_or_null, hast_fq **out);
+/* The blocks of ONE input stream on several contexts in turn (block i -> ctxs[i % n_ctx], one context per GPU; several
+ * contexts on one GPU also work): the reference spreads the reads of one file over all its workers (classify.cpp:211-219),
+ * one process per file would leave all GPUs but two idle on HAST's two input files (HAST.sh:162-166).  A block is framed
+ * on its own GPU from the number of newlines in front of it in the file -- each block's own count is a kernel queued behind
+ * its upload, the host adds them up -- so no GPU waits for another one's framing.  A block owns the records that START in
+ * it; their header and base lines may reach into the first bytes of the next block (at most min(1 MB, block_bytes): a
+ * larger record is HAST_ERR_FORMAT), which are uploaded to both GPUs.  Differences to hast_fq_create streams: every block
+ * but the last of a file must be full (n_bytes == hast_fq_block_bytes), and a block can be opened (hast_fq_poll /
+ * hast_fq_next) once the block behind it has been submitted.  names: one cache per context, or NULL. */
+hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx,
+                                   hast_names *const *names_or_null, hast_fq **out);
+int         hast_fq_lanes(const hast_fq *);                      /* contexts the stream's blocks rotate over (1 for hast_fq_create) */
+uint64_t    hast_fq_lane_records(const hast_fq *, int lane);     /* records opened so far on that context (striped streams) */
 void        hast_fq_destroy(hast_fq *);
 size_t      hast_fq_block_bytes(const hast_fq *);
 hast_status hast_fq_acquire(hast_fq *, uint8_t **host_buf);

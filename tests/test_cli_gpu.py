@@ -63,19 +63,32 @@ def _n_gpus():
         return 0
 
 
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0", pytest.param("0,1", marks=pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs"))])
+@pytest.mark.parametrize("devices,deal", [("0,0", "blocks"), ("0,0,0", "blocks"), ("0,0,0", "files"),
+                                          pytest.param("0,1", "blocks", marks=pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs"))])
 @pytest.mark.parametrize("case,run", golden_cases("s01"))
-def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, devices):
-    """--devices: the table is built once and copied to the other contexts, batches are dealt round-robin, the counters
-    are summed once at the end (classify.cpp:226-229,276-277 across GPUs).  Integer sums: stdout must be byte-identical
-    to the real reference's.  "0,0" = several contexts on the one GPU of the test box (same code path up to the sum:
-    a kernel instead of RCCL); "0,1" = two GPUs over RCCL."""
+def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, devices, deal):
+    """--devices: the table is built once and copied to the other contexts, the BLOCKS of every input file are dealt to the
+    contexts in turn and framed there (classify.cpp:211-219 spreads the reads of one file over all workers; deal == "files":
+    whole files in turn, HAST_DEAL=files), the counters are summed once at the end (classify.cpp:226-229,276-277 across GPUs).
+    Integer sums: stdout must be byte-identical to the real reference's.  "0,0" = several contexts on the one GPU of the test
+    box (same code path up to the sum: a kernel instead of RCCL); "0,1" = two GPUs over RCCL.  With blocks dealt, every context
+    must have framed records of the (one or two) input files."""
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case
-    res = subprocess.run([exe] + meta["argv"] + ["--devices", devices, "--batch-reads", "700", "--initial-barcodes", "50"], cwd=d,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    env = dict(os.environ, HAST_DEAL="files") if deal == "files" else None
+    res = subprocess.run([exe] + meta["argv"] + ["--devices", devices, "--batch-reads", "50", "--initial-barcodes", "50", "--stats"], cwd=d,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()
+    line = [l for l in res.stderr.decode().splitlines() if l.startswith("__stats_devices__")]
+    if deal == "files":
+        assert not line
+        return
+    assert len(line) == 1, res.stderr.decode()[-2000:]
+    per = [int(x) for x in line[0].split("records_per_context=")[1].split(",")]
+    assert len(per) == len(devices.split(","))
+    if case.startswith("rand_"):                      # (the hand-made edge case is a single 2-KB block)
+        assert all(x > 0 for x in per), line
 
 
 @pytest.mark.parametrize("extra", [["--batch-reads", "257"], ["--batch-reads", "13"], ["--batch-reads", "257", "--host-parse"]])

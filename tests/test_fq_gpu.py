@@ -59,14 +59,30 @@ def make_fastq(rng, n, k, keys, tail):
     return text.encode()
 
 
-def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3):
+def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=(), eager=False):
     """feed `data` to hast_fq_* in pieces of lo..hi bytes, name the records the way the CLI does; returns the barcodes in record
-    order, the dictionary, the base count, the per-block short-read flags and how many records the host had to name"""
+    order, the dictionary, the base count, the per-block short-read flags and how many records the host had to name.
+    more_ctxs: further contexts -> a striped stream (block i on context i % n; n_buffers per context; lo == hi: full blocks);
+    eager: open a block as soon as the one behind it has been submitted (else: as late as the buffers allow)"""
     lib = hast_amd.lib()
     fq, nm = C.c_void_p(), C.c_void_p()
-    if cache:
-        assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
-    assert lib.hast_fq_create(ctx._h, hi, n_buffers, nm, C.byref(fq)) == 0, lib.hast_last_error()
+    ctxs = [ctx] + list(more_ctxs)
+    nms = []
+    if len(ctxs) > 1:
+        assert lo == hi
+        for c in ctxs:
+            h = C.c_void_p()
+            if cache:
+                assert lib.hast_names_create(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
+            nms.append(h)
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        narr = (C.c_void_p * len(ctxs))(*[h.value for h in nms])
+        assert lib.hast_fq_create_striped(arr, len(ctxs), hi, n_buffers, narr, C.byref(fq)) == 0, lib.hast_last_error()
+        assert lib.hast_fq_lanes(fq) == len(ctxs) and lib.hast_fq_block_bytes(fq) == hi
+    else:
+        if cache:
+            assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
+        assert lib.hast_fq_create(ctx._h, hi, n_buffers, nm, C.byref(fq)) == 0, lib.hast_last_error()
     names, got, pos, pending = {}, [], 0, 0
     st = {"host_named": 0, "n_bases": 0}
     short = []
@@ -106,15 +122,27 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3):
         last = pos >= len(data)
         assert lib.hast_fq_submit(fq, n, 1 if last else 0) == 0, lib.hast_last_error()
         pending += 1
-        if pending == n_buffers - 1 or last:     # keep block(s) in flight behind the one being named
+        if len(ctxs) > 1:
+            # a block of a striped stream can be opened once the block behind it has been submitted
+            keep = 0 if last else 1 if eager else n_buffers * len(ctxs) - 1
+            while pending > keep:
+                drain()
+                pending -= 1
+        elif pending == n_buffers - 1 or last:     # keep block(s) in flight behind the one being named
             while pending > (0 if last else n_buffers - 2):
                 drain()
                 pending -= 1
         if last:
             break
+    if len(ctxs) > 1:
+        st["lane_records"] = [lib.hast_fq_lane_records(fq, g) for g in range(len(ctxs))]
+        assert sum(st["lane_records"]) == len(got)
     lib.hast_fq_destroy(fq)
-    if cache:
-        lib.hast_names_destroy(nm)
+    for h in nms + [nm]:
+        if h:
+            lib.hast_names_destroy(h)
+    if len(ctxs) > 1:
+        return got, names, st["n_bases"], short, st["host_named"], st["lane_records"]
     return got, names, st["n_bases"], short, st["host_named"]
 
 
@@ -234,3 +262,87 @@ def test_fq_slot_grown_on_the_copy_path_is_reused(oracle_lib, monkeypatch, n_buf
     for a, b in zip(counts, e):
         assert np.array_equal(a, b)
     assert int(e[0].sum()) > 1000
+
+
+def _oracle_counts_of(oracle_lib, keys, k, want, names):
+    oc = oracle_lib.ho_new()
+    for h in (0, 1):
+        assert oracle_lib.ho_load_keys(oc, keys[h].ctypes.data, keys[h].size, h, k) == 0
+    bases = np.frombuffer(b"".join(s for _, s in want), dtype=np.uint8)
+    off = np.zeros(len(want) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for _, s in want])
+    ids = np.array([names[bc] for bc, _ in want], dtype=np.uint32)
+    e = [np.zeros(len(names), np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, ids.size, e[0].ctypes.data, e[1].ctypes.data,
+                               e[2].ctypes.data, None, 2)
+    oracle_lib.ho_free(oc)
+    return e
+
+
+@pytest.mark.parametrize("n_ctx,cache,eager", [(2, 1 << 16, False), (3, 0, True), (4, 64, False)])
+@pytest.mark.parametrize("tail", ["plain", "no_final_newline", "header_only", "unterminated_header", "bases_no_newline"])
+@pytest.mark.parametrize("block", [4096, 65536])
+def test_fq_striped_stream_framing_and_counts(oracle_lib, tail, block, n_ctx, cache, eager):
+    """ONE byte stream whose blocks rotate over several contexts (hast_fq_create_striped; here all on the one GPU of the test
+    box: the same code up to the device ordinal): every block is framed on its own from the number of newlines in front of it,
+    with a context switch at every block border -- records, headers and barcodes straddle them all the time (4-KB blocks hold
+    a dozen records).  Records, barcode text and base counts == the reference's reader, the summed per-barcode counters ==
+    oracle, every context got records."""
+    rng = random.Random(SEEDS[tail] * 7919 + block + n_ctx)
+    k, n_keys = 21, 3000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    data = make_fastq(rng, 1500, k, np.concatenate(keys), tail)
+    if tail == "plain" and block == 4096:
+        # one more record that makes the file end exactly at a block border: the last block is then empty
+        need = (-len(data)) % block
+        need += block if need < 64 else 0
+        head = b"@pad#5_5_5/1" + (b"x" if (need - 17) % 2 else b"")
+        L = (need - len(head) - 5) // 2
+        data += head + b"\n" + b"ACGT" * (L // 4) + b"A" * (L % 4) + b"\n+\n" + b"I" * L + b"\n"
+        assert len(data) % block == 0
+    want = reference_framing(data, oracle_lib)
+    lib = hast_amd.lib()
+    ctxs = [hast_amd.Context(k) for _ in range(n_ctx)]
+    try:
+        ctxs[0].table_reserve(2 * n_keys)
+        ctxs[0].table_insert_keys(0, keys[0])
+        ctxs[0].table_insert_keys(1, keys[1])
+        for c in ctxs[1:]:
+            assert lib.hast_table_clone(c._h, ctxs[0]._h) == 0, lib.hast_last_error()
+        for c in ctxs:
+            c.counts_resize(4096)
+        got, names, n_bases, short, host_named, lanes = stream_through_framer(ctxs[0], data, block, block, cache, rng, n_buffers=2,
+                                                                              more_ctxs=ctxs[1:], eager=eager)
+        arr = (C.c_void_p * n_ctx)(*[c._h for c in ctxs])
+        assert lib.hast_counts_allreduce(arr, n_ctx) == 0, lib.hast_last_error()
+        counts = ctxs[0].counts_read(len(names))
+    finally:
+        for c in ctxs:
+            c.close()
+    assert got == [bc for bc, _ in want]
+    assert n_bases == sum(len(s) for _, s in want)
+    assert all(x > 0 for x in lanes), lanes
+    if tail == "header_only":
+        assert short[-1] == 1 or any(short)
+        return
+    assert not any(short)
+    for a, b in zip(counts, _oracle_counts_of(oracle_lib, keys, k, want, names)):
+        assert np.array_equal(a, b)
+
+
+def test_fq_striped_stream_rejects_partial_blocks_and_early_opens():
+    lib = hast_amd.lib()
+    with hast_amd.Context(21) as a, hast_amd.Context(21) as b:
+        arr = (C.c_void_p * 2)(a._h, b._h)
+        fq = C.c_void_p()
+        assert lib.hast_fq_create_striped(arr, 2, 4096, 2, None, C.byref(fq)) == 0, lib.hast_last_error()
+        buf = C.POINTER(C.c_uint8)()
+        assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0
+        assert lib.hast_fq_submit(fq, 100, 0) != 0 and b"full blocks" in lib.hast_last_error()
+        C.memmove(buf, b"@r#1_1_1/1\n" + b"A" * 4084 + b"\n", 4096)
+        assert lib.hast_fq_submit(fq, 4096, 0) == 0, lib.hast_last_error()
+        blk = FqBlock()
+        assert lib.hast_fq_poll(fq) == 0
+        assert lib.hast_fq_next(fq, C.byref(blk)) != 0 and b"block behind it" in lib.hast_last_error()
+        lib.hast_fq_destroy(fq)
