@@ -67,6 +67,7 @@ ABI_SYMBOLS = {
     "hast_ctx_set_filter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hast_filter_build": (C.c_int, [vp]),
     "hast_filter_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), u64p]),
+    "hast_filter_request_ceiling": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "hast_counts_resize": (C.c_int, [vp, C.c_size_t]),
     "hast_counts_bind": (C.c_int, [vp, vp, C.c_size_t]),
     "hast_counts_zero": (C.c_int, [vp, vp]),
@@ -256,6 +257,12 @@ class Context:
 
     def filter_build(self):
         _ck(self._lib.hast_filter_build(self._h))
+
+    def filter_request_ceiling(self):
+        """requests/s at which this GPU serves random 128-B blocks of this context's filter (measurement entry)"""
+        r = C.c_double()
+        _ck(self._lib.hast_filter_request_ceiling(self._h, C.byref(r)))
+        return r.value
 
     def filter_info(self):
         """(enabled, m, t, kp, bytes); m = t = kp = bytes = 0 until the filter has been built for the current table"""

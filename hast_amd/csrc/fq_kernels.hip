@@ -257,25 +257,40 @@ __global__ void __launch_bounds__(256) k_fq_name(const uint32_t *text, uint32_t 
         if (id == kNameUnknown) h_unknown[1 + atomicAdd(&h_unknown[0], 1u)] = i;             // (pinned host memory)
     }
 }
+// Two lanes of ONE wave may claim the same slot (the same new barcode twice in a block): the loser must not spin on the
+// winner's "ready" flag inside a divergent branch -- which side of a branch a wave runs first is the compiler's choice.  So
+// every lane is a small state machine stepped by a wave-uniform loop: a lane that finds a slot "being written" simply looks
+// again in the next round, by when the winner (same wave or not) has had its turn to publish.
 __global__ void __launch_bounds__(256) k_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, uint32_t mask) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const NamePub p = pubs[i];
-        uint32_t at = name_hash(p.key) & mask;
-        for (uint32_t probe = 0; probe <= mask; ++probe, at = (at + 1) & mask) {
-            NameEntry *e = &tab[at];
-            uint32_t st = __hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (st == 0) {
-                const uint32_t old = atomicCAS(&e->state, 0u, 1u);
-                if (old == 0) {
-                    e->key[0] = p.key[0]; e->key[1] = p.key[1]; e->key[2] = p.key[2]; e->key[3] = p.key[3];
-                    e->id = p.id;
-                    __hip_atomic_store(&e->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+    const uint32_t n_round = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t r = 0; r < n_round; ++r) {
+        const uint32_t i = r * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
+        bool busy = i < n;
+        NamePub p = {};
+        if (busy) p = pubs[i];
+        uint32_t at = busy ? name_hash(p.key) & mask : 0, probes = 0;
+        while (__any(busy)) {
+            if (busy) {
+                NameEntry *e = &tab[at];
+                uint32_t st = __hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (st == 0) {
+                    st = atomicCAS(&e->state, 0u, 1u);
+                    if (st == 0) {                                    // claimed: write and publish
+                        e->key[0] = p.key[0]; e->key[1] = p.key[1]; e->key[2] = p.key[2]; e->key[3] = p.key[3];
+                        e->id = p.id;
+                        __hip_atomic_store(&e->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        busy = false;
+                    }
                 }
-                st = old;
+                if (busy && st == 2) {                                // a ready entry: the same barcode, or someone else's -> next slot
+                    if (e->key[0] == p.key[0] && e->key[1] == p.key[1] && e->key[2] == p.key[2] && e->key[3] == p.key[3]) busy = false;
+                    else {
+                        at = (at + 1) & mask;
+                        if (++probes > mask) busy = false;            // (a full table: the cache simply does not learn this one)
+                    }
+                }
+                // st == 1: being written by another lane -- look again in the next round
             }
-            while (st == 1) st = __hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // another lane of this launch writes it
-            if (e->key[0] == p.key[0] && e->key[1] == p.key[1] && e->key[2] == p.key[2] && e->key[3] == p.key[3]) break;   // the same barcode twice
         }
     }
 }

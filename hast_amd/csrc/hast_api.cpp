@@ -1016,6 +1016,39 @@ hast_status hast_filter_info(const hast_ctx *c, int *enabled, int *m, int *t, in
     return HAST_OK;
 }
 
+// Measurement: the rate at which this GPU serves uniformly random 128-B blocks of the context's own filter (the allocation
+// k_classify_f probes), in requests per second -- the ceiling the probe kernel's request rate is priced against, measured in
+// the same run on the same box over the same footprint (it differs by a few per cent from box to box and with the footprint:
+// 47.5 G/s over 6 GB, 45.6 over 137 GB, profiles/round3_hbm_randread_footprint.jsonl).
+hast_status hast_filter_request_ceiling(hast_ctx *c, double *requests_per_s) {
+    if (hast_status st = need_table(c, 0)) return st;
+    if (!requests_per_s) return fail(HAST_ERR_INVALID, "null argument");
+    if (!c->use_filter) return fail(HAST_ERR_INVALID, "the filter is off");
+    if (hast_status st = ensure_filter(c, c->stream)) return st;
+    if (!c->use_filter || !c->d_filter) return fail(HAST_ERR_INVALID, "no filter (HBM too small for it)");
+    const uint64_t nblocks = filter_nblocks(c->fg);
+    const int grid = c->n_cu * 8;
+    const uint32_t iters = 256;                                    // 2048 x 32 groups x 1024 blocks = 67M requests = 8.6 GB
+    uint32_t *d_sink = reinterpret_cast<uint32_t *>(c->d_cnt + 2);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 0;
+    for (int rep = 0; rep < 3; ++rep) {                            // the first launch warms the TLBs
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(launch_request_ceiling(c->d_filter, nblocks, iters, grid, d_sink, c->stream));
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && (best == 0 || ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *requests_per_s = (double)grid * 32.0 * 4.0 * (double)iters / ((double)best * 1e-3);
+    return HAST_OK;
+}
+
 hast_status hast_classify_timing(hast_ctx *c, int n_slots) {
     if (hast_status st = use(c)) return st;
     for (hipEvent_t e : c->t_ev) (void)hipEventDestroy(e);

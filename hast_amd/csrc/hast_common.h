@@ -154,6 +154,17 @@ HAST_HD uint32_t mul24(uint32_t a, uint32_t b) {
     return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
 #endif
 }
+// as mul24, for call sites where the compiler proves both operands below 2^24, rewrites the product as a plain 32-bit multiply
+// and then fails to select the 24-bit instruction for it (v_mul_lo_u32, a quarter of the rate): the instruction by name
+HAST_HD uint32_t mul24_forced(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
 // order of a t-mer: 20 hash bits above 12 position bits; smaller wins, equal t-mers (or equal hashes) -> the leftmost.
 // (t-mers are at most 12 bases in every geometry filter_geom_for picks, so the 24-bit product sees the whole t-mer; a
 // longer t-mer forced by an override is ordered by its last 12 bases -- still one order shared by build and probe.)
@@ -209,14 +220,15 @@ HAST_HD int filter_pos_bits(const FilterGeom &g) {
     while ((1u << b) < filter_w(g)) ++b;
     return b;
 }
-HAST_HD bool filter_exact_fits(const FilterGeom &g) { return g.k <= 32 && 2 * (g.k - g.m) + filter_pos_bits(g) <= 17; }
+// (m <= 14: block * 8 + sub-bucket then fits 32 bits, which the probe's address arithmetic relies on)
+HAST_HD bool filter_exact_fits(const FilterGeom &g) { return g.k <= 32 && g.m <= 14 && 2 * (g.k - g.m) + filter_pos_bits(g) <= 17; }
 // the 17-bit code of a string whose sampled m-mer sits at pm: (pm, the bases behind the m-mer, the bases in front of it), scrambled
 HAST_HD uint32_t filter_exact_code(uint64_t fwd, uint32_t pm, const FilterGeom &g) {
     const int rb = 2 * (g.k - g.m);
     // rotate the m-mer out: only the low rb bits of either term matter (fwd >> 2(K-pm) = the pm bases in front of the m-mer)
     const uint32_t rest = ((uint32_t)fwd << (2 * pm)) | (uint32_t)(fwd >> (2 * ((uint32_t)g.k - pm)));
     const uint32_t code = (rest & ((1u << rb) - 1u)) | (pm << rb);
-    return mul24(code, 0x1D2C5u) & 0x1FFFFu;                          // odd multiplier: a bijection of the 17 bits
+    return mul24_forced(code, 0x1D2C5u) & 0x1FFFFu;                   // odd multiplier: a bijection of the 17 bits
 }
 HAST_HD uint32_t filter_exact_sub(uint32_t code17) { return code17 >> 14; }
 HAST_HD uint32_t filter_exact_entry(uint32_t code17, uint32_t tags) { return ((code17 & 0x3FFFu) << 2) | tags; }   // tags 1..3: never 0

@@ -57,6 +57,8 @@ hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStre
 // filter front end: builds the filter from the live slots of the exact table; classify through it
 hipError_t launch_filter_build(const uint64_t *slots, TableGeom g, void *filter, FilterGeom fg, hipStream_t s);
 hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
+// measurement: grid x 256 lanes, each group of 8 lanes reads 4 x iters random 128-B blocks of the filter
+hipError_t launch_request_ceiling(const void *filter, uint64_t nblocks, uint32_t iters, int grid, uint32_t *d_sink, hipStream_t s);
 size_t classify_f_queue_bytes();      // LDS the kernel needs besides the per-read arrays
 // d_offsets == nullptr: reads of fixed_len bytes back to back
 hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,

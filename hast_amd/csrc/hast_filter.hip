@@ -359,13 +359,19 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             const bool inq = lane < q_end - pos;                      // pos <= q_end
             const uint32_t r = min(cr, TR - 1), p = cp;
             const uint32_t len = s_len[r];
-            bool ok = inq & (p + K <= len);
+            const bool fits = p + K <= len;
+            bool ok = inq & fits;
+            // the wave-wide mask of `ok`: a ballot per compare (each is the compare itself, written to an SGPR pair) and one
+            // scalar AND -- a ballot of the combined condition goes through v_cndmask + v_cmp
+            unsigned long long okm = ballot64(inq) & ballot64(fits);
             if (STRICT) {           // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
                 // (rows without such a byte -- nearly all of them -- are flagged clean by phase A: the wave skips the masks)
                 if (ballot64(s_flag[r] != 0)) {
                     const uint32_t *iw = s_inv + mul24(r, IW) + (p >> 5);
                     const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
-                    ok = ok & ((bits >> (64 - K)) == 0);
+                    const bool clean = (bits >> (64 - K)) == 0;
+                    ok = ok & clean;
+                    okm &= ballot64(clean);
                 }
             }
             const unsigned long long fwd = window_bits(s_pack + mul24(r, WS), p, kshift);
@@ -386,12 +392,13 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             // of the window as it stands (no canonical form in the probe): a hash for two sub-buckets and a print, or the
             // window's exact code, whose top bits are its one sub-bucket
             const uint32_t h = EXACT ? filter_exact_code(fwd, pm, fg) : filter_keyhash(fwd);
-            const unsigned long long okm = ballot64(ok);
             const uint32_t anchor = okm ? (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)__builtin_ctzll(okm)) : last_fb;
             last_fb = anchor;
             fb = ok ? fb : anchor;
             if (EXACT) {
-                B.v = filt[(size_t)fb * kFilterSubs + filter_exact_sub(h)];   // (any sub-bucket will do for a lane without a window)
+                // exact entries mean m <= 14 (filter_exact_fits: 2(K-m) <= 17): block * 8 + sub-bucket fits 32 bits, one shift-or
+                // and one 64-bit shift-add make the address
+                B.v = filt[(fb << 3) | filter_exact_sub(h)];                  // (any sub-bucket will do for a lane without a window)
                 B.fpw = mul24((h & 0x3FFFu) ^ 0x3FFFu, 0x00040004u);          // the complement of the stored bits, in both halves
             } else {
                 B.v = filt[(size_t)fb * kFilterSubs + filter_sub_of(h)];
@@ -486,6 +493,34 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         // no barrier needed here: the next tile's header only touches this lane's own s_* entries
         // and is followed by a barrier before anyone else reads them.
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Measurement entry (hast_filter_request_ceiling): uniformly random 128-B blocks of the filter itself, read in the probe's
+// access shape (a group of 8 lanes takes one block, 16 B per lane, four blocks in flight per lane) with next to no
+// arithmetic -- what the memory system serves over THIS allocation on THIS box, the ceiling k_classify_f's request rate is
+// priced against in the same run.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_request_ceiling(const u32x4f *filt, uint64_t nblocks, uint32_t iters, uint32_t *sink) {
+    const uint64_t gid = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 3;
+    const uint32_t sub = threadIdx.x & 7;
+    u32x4f acc = {0, 0, 0, 0};
+    for (uint32_t it = 0; it < iters; ++it) {
+        u32x4f v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t h = splitmix64(gid * 0x10001ull + (uint64_t)it * 4 + (uint64_t)u);
+            const uint64_t blk = (uint64_t)(((unsigned __int128)h * nblocks) >> 64);
+            v[u] = filt[blk * kFilterSubs + sub];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = 1;       // keeps the loads alive
+}
+hipError_t launch_request_ceiling(const void *filter, uint64_t nblocks, uint32_t iters, int grid, uint32_t *d_sink, hipStream_t s) {
+    hipLaunchKernelGGL(k_request_ceiling, dim3(grid), dim3(256), 0, s, reinterpret_cast<const u32x4f *>(filter), nblocks, iters, d_sink);
+    return hipGetLastError();
 }
 
 template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO>

@@ -18,6 +18,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <cerrno>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -283,10 +284,17 @@ class BlockSource {
                 if (r < 0) trouble = inflater_.error();
             } else if (fp_ != stdin && want >= (4u << 20) && plain_off_ != -2) {
                 r = parallel_pread(dst + got, want - got);     // regular file: several readers per block (never mixed with fread)
-            } else r = (long)fread(dst + got, 1, want - got, fp_);
+                if (r < 0) trouble = io_error_;
+            } else {
+                r = (long)fread(dst + got, 1, want - got, fp_);
+                if (r == 0 && ferror(fp_)) trouble = "read failed";
+            }
             if (r <= 0) break;
             got += (size_t)r;
         }
+        // the decoders read through stdio: a failed read looks like the end of the input to them (and a gzip stream that ends
+        // at a member border is a complete stream) -- the stream's error flag tells the two apart
+        if (trouble.empty() && fp_ && ferror(fp_)) trouble = std::string("read failed: ") + strerror(errno ? errno : EIO);
         return got;
     }
     void pump() {
@@ -324,15 +332,25 @@ class BlockSource {
             plain_off_ = ftello(fp_);
             if (plain_off_ < 0 || pread(fd, dst, 0, 0) != 0) plain_off_ = -2;
         }
-        if (plain_off_ == -2) return (long)fread(dst, 1, want, fp_);      // nothing has been pread yet: fread from here on
+        if (plain_off_ == -2) {                                           // nothing has been pread yet: fread from here on
+            const size_t r = fread(dst, 1, want, fp_);
+            if (r == 0 && ferror(fp_)) {
+                io_error_ = std::string("read failed: ") + strerror(errno ? errno : EIO);
+                return -1;
+            }
+            return (long)r;
+        }
         const int kReaders = (int)std::max<size_t>(1, std::min<size_t>((size_t)readers_, want >> 20));     // at least 1 MB per reader
         const size_t share = (want / kReaders + 4095) & ~(size_t)4095;
         size_t got[kMaxReaders] = {0};
+        int io_errno[kMaxReaders] = {0};             // a failed read is an error, not the end of the file
         auto work = [&](int t) {
             const size_t from = std::min(want, share * (size_t)t), to = std::min(want, from + share);
             size_t done = 0;
             while (from + done < to) {
                 const ssize_t r = pread(fd, dst + from + done, to - from - done, plain_off_ + (off_t)(from + done));
+                if (r < 0 && errno == EINTR) continue;
+                if (r < 0) io_errno[t] = errno ? errno : EIO;
                 if (r <= 0) break;
                 done += (size_t)r;
             }
@@ -348,6 +366,11 @@ class BlockSource {
             if (got[t] < to - from) break;
         }
         plain_off_ += (off_t)total;
+        for (int t = 0; t < kReaders; ++t)
+            if (io_errno[t]) {
+                io_error_ = std::string("read failed: ") + strerror(io_errno[t]);
+                return -1;
+            }
         return (long)total;
     }
     // threads that inflate ONE ordinary .gz file (HAST_GZ_THREADS; 1 = the serial decoder).  Default: an eighth of the
@@ -387,6 +410,7 @@ class BlockSource {
     gzFile gz_ = nullptr;
     GzInflater inflater_;
     std::string error_;
+    std::string io_error_;       // a failed pread of a plain file
     FILE *fp_ = nullptr;
     size_t block_bytes_ = 0;
     std::thread reader_;

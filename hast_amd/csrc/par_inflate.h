@@ -33,6 +33,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -605,16 +606,21 @@ class ParGzReader {
             const size_t need = want_bytes - in_len_, nthr = (size_t)pool_->size();
             const size_t share = ((need + nthr - 1) / nthr + 4095) & ~(size_t)4095;
             std::vector<size_t> got(nthr, 0);
+            std::vector<int> io_errno(nthr, 0);                         // a failed read is an error, not the end of the file
             pool_->run([&](int t) {
                 const size_t from = std::min(need, share * (size_t)t), to = std::min(need, from + share);
                 size_t done = 0;
                 while (from + done < to) {
                     const ssize_t r = pread(fd_, in_.data() + in_len_ + from + done, to - from - done, (off_t)(file_pos_ + in_base_ + in_len_ + from + done));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r < 0) io_errno[(size_t)t] = errno ? errno : EIO;
                     if (r <= 0) break;
                     done += (size_t)r;
                 }
                 got[(size_t)t] = done;
             });
+            for (size_t t = 0; t < nthr; ++t)
+                if (io_errno[t] && io_error_.empty()) io_error_ = std::string("gz: read failed: ") + strerror(io_errno[t]);
             size_t total = 0;                                           // contiguous bytes from the start: a short share is the file's end
             for (size_t t = 0; t < nthr; ++t) {
                 const size_t from = std::min(need, share * t), to = std::min(need, from + share);
@@ -655,6 +661,12 @@ class ParGzReader {
         // in_base_ counts from the first byte of the stream (file_pos_)
         const uint64_t first_byte = next_bit_ >> 3;
         fill_input((nchunks + 1) * chunk_bytes_);
+        if (!io_error_.empty()) {                    // an I/O error is not the end of the stream
+            b.error = io_error_;
+            b.last = true;
+            stream_done_ = true;
+            return;
+        }
         std::vector<std::unique_ptr<Chunk>> ch(nchunks);
         for (size_t i = 0; i < nchunks; ++i) {
             ch[i] = take_chunk();
@@ -811,6 +823,7 @@ class ParGzReader {
     size_t chunk_bytes_ = 1u << 20, max_chunk_out_ = 48u << 20;
     std::unique_ptr<WorkerPool> pool_, rpool_;
     std::string err_;
+    std::string io_error_;       // set by fill_input when a pread fails (EIO ...)
     // consumer side
     std::unique_ptr<Batch> cur_;
     size_t cur_chunk_ = 0;

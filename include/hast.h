@@ -145,6 +145,10 @@ hast_status hast_table_info(const hast_ctx *, uint64_t *n_buckets, uint64_t *byt
 hast_status hast_ctx_set_filter(hast_ctx *, int enable, int m, int t, int kp);
 hast_status hast_filter_build(hast_ctx *);
 hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, int *kp, uint64_t *bytes);
+/* Measurement entry (bench.py's roofline): requests per second at which this GPU serves uniformly random 128-B blocks of the
+ * context's own filter, read in the probe kernel's access shape with no arithmetic -- the request-rate ceiling of this box
+ * over this footprint, against which k_classify_f's own request rate is priced in the same run. */
+hast_status hast_filter_request_ceiling(hast_ctx *, double *requests_per_s);
 
 /* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
  * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:

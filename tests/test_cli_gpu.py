@@ -313,6 +313,17 @@ def test_classify_read_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path,
     assert len(ref.stdout.splitlines()) == 2 * (len(recs) + 1)
 
 
+def test_cli_read_error_is_not_end_of_file(exe, golden_workdir, tmp_path):
+    """a read() that FAILS (here: the input is a directory, EISDIR) must end the run with exit code 2, not pass as an empty or
+    shorter input with exit code 0 -- with the GPU framer and with --host-parse"""
+    d = golden_workdir / "rand_k21"
+    (tmp_path / "adir.fq").mkdir()
+    for extra in ([], ["--host-parse"]):
+        r = subprocess.run([exe, "--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", str(tmp_path / "adir.fq")] + extra, cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 2 and r.stdout == b"", (extra, r.returncode, r.stderr[-300:])
+
+
 @pytest.mark.heavy
 def test_cli_baseline_config1_full_size_vs_oracle(exe, oracle_dir, tmp_path):
     """BASELINE config 1 at its full size through the boundary: 1M synthetic 150-bp stLFR read pairs in two FASTQ files, 1M +

@@ -364,3 +364,12 @@ def test_block_source_routes_every_kind_of_input(tmp_path):
                 r = subprocess.run([str(exe)] + extra + [str(tmp_path / name)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
                 assert r.returncode == 3, (env, name, extra, r.returncode, r.stderr[-300:])
                 assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr
+    # a read that FAILS is not the end of the input (here: the "file" is a directory, every read gives EISDIR): an error on
+    # every route -- it used to pass as an empty input with exit code 0
+    for d in ("adir.fq", "adir.fq.gz"):
+        (tmp_path / d).mkdir()
+        for env in envs[:4]:
+            for extra in ([], ["-u"], ["-u", "-b", "16777216"], ["-b", "16777216"]):
+                r = subprocess.run([str(exe)] + extra + [str(tmp_path / d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+                assert r.returncode == 3 and r.stdout == b"", (d, env, extra, r.returncode, r.stderr[-300:])
+                assert b"AddressSanitizer" not in r.stderr and b"runtime error" not in r.stderr
