@@ -6,11 +6,16 @@
 // reference does on the host around them: flag parsing, FASTA/FASTQ framing (s03:248-302), the density and
 // the call (s03:110-133, 215-216).
 //
+// Additive flags: --device N, --devices A,B,... (several GPUs of this node: the table is built on the first one and copied to
+// the others over xGMI; every batch of reads is cut into one contiguous share per GPU, balanced by bases, classified at the same
+// time and printed in read order -- per-read rows need no reduction, BASELINE config 5's "barcode-free per-read assignment").
+//
 // Requirement (deviation): k-mer lines must be upper-case A/C/G/T of one length K <= 32 -- what jellyfish/meryl
 // dumps are.  The reference would also store other bytes literally (s03:59-65); we stop with exit 3 instead.
 #include <getopt.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,7 +41,8 @@ namespace {
 void print_usage() {   // same flags as the reference (s03:316-324); stderr is free-form
     fputs("classify_read (MI355X) -- per-read haplotype assignment\n"
           "  classify_read --hap HAP0.mer --hap HAP1.mer --read READS [--read ...] [--format fasta|fastq] [--thread N]\n"
-          "  reads may be gzip files when the name ends in .gz; --format defaults to fasta\n",
+          "  reads may be gzip files when the name ends in .gz; --format defaults to fasta\n"
+          "  --device N / --devices A,B,..   GPU(s); with several, every batch of reads is shared out between them\n",
           stderr);
 }
 
@@ -64,10 +70,11 @@ int main(int argc, char **argv) {
     static struct option long_options[] = {{"hap", required_argument, NULL, 'p'},    {"read", required_argument, NULL, 'r'},
                                            {"format", required_argument, NULL, 'f'}, {"thread", required_argument, NULL, 't'},
                                            {"help", no_argument, NULL, 'h'},         {"device", required_argument, NULL, 1001},
-                                           {0, 0, 0, 0}};
+                                           {"devices", required_argument, NULL, 1002}, {0, 0, 0, 0}};
     std::vector<std::string> haps, read;
     std::string format = "fasta";
     int t_num = 8, device = 0;
+    std::vector<int> devices;
     for (;;) {
         int c = getopt_long(argc, argv, "p:r:t:f:h", long_options, NULL);   // s03:324
         if (c < 0) break;
@@ -77,6 +84,15 @@ int main(int argc, char **argv) {
         case 'f': format = optarg; break;
         case 't': t_num = atoi(optarg); break;
         case 1001: device = atoi(optarg); break;
+        case 1002:
+            for (const char *q = optarg; *q;) {
+                char *end;
+                const long v = strtol(q, &end, 10);
+                if (end == q || v < 0 || (*end && *end != ',')) { print_usage(); return -1; }
+                devices.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+            }
+            break;
         case 'h':
         default: print_usage(); return -1;
         }
@@ -85,6 +101,8 @@ int main(int argc, char **argv) {
         print_usage();
         return -1;
     }
+    if (devices.empty()) devices.push_back(device);
+    device = devices[0];
     if (format != "fasta" && format != "fastq") {
         fprintf(stderr, " ERROR : invalid format : [%s] . exit ...\n", format.c_str());
         return -1;
@@ -147,6 +165,14 @@ int main(int argc, char **argv) {
         fprintf(stderr, "Recorded %d haplotype %d specific %zu-mers\n", total_kmers[h], h, K);
         std::vector<char>().swap(txt[h]);
     }
+    // the other GPUs get a copy of the finished table, peer to peer
+    std::vector<hast_ctx *> ctxs{ctx};
+    for (size_t i = 1; i < devices.size(); i++) {
+        hast_ctx *c2 = nullptr;
+        if (hast_ctx_create(devices[i], (int)K, &c2) != HAST_OK) die(4, "cannot create GPU context");
+        if (hast_table_clone(c2, ctx) != HAST_OK) die(4, "copying the k-mer table to another GPU");
+        ctxs.push_back(c2);
+    }
     // ---- reads: block ingest with t_num parser threads (ingest.h), one GPU batch per block ------------------------
     // Framing as in the reference: FASTQ = 4 getlines per record, the header must be newline-terminated (s03:255-263);
     // FASTA = '>' lines start a record, other non-empty lines are appended, a last line without '\n' is dropped
@@ -183,10 +209,38 @@ int main(int argc, char **argv) {
     };
     auto run_batch = [&](Batch &b) {
         if (b.names.empty()) return;
-        std::vector<uint32_t> v(b.names.size() * 2, 0);
-        if (hast_classify_perread(ctx, b.bases.data(), b.offsets.data(), b.names.size(), v.data()) != HAST_OK) {
-            bg_error = std::string("classifying a batch (") + hast_last_error() + ")";
-            return;
+        const size_t n = b.names.size(), G = ctxs.size();
+        std::vector<uint32_t> v(n * 2, 0);
+        if (G == 1) {
+            if (hast_classify_perread(ctx, b.bases.data(), b.offsets.data(), n, v.data()) != HAST_OK) {
+                bg_error = std::string("classifying a batch (") + hast_last_error() + ")";
+                return;
+            }
+        } else {
+            // one contiguous share of the reads per GPU, cut where the bases divide evenly (reads differ in length by orders of
+            // magnitude); the shares run at the same time, every one on a thread of its own (a context is driven by one thread)
+            std::vector<size_t> cut(G + 1, n);
+            cut[0] = 0;
+            const uint64_t total = b.offsets[n] - b.offsets[0];
+            for (size_t g = 1; g < G; g++) {
+                const uint64_t want = b.offsets[0] + total * g / G;
+                cut[g] = (size_t)(std::lower_bound(b.offsets.begin(), b.offsets.begin() + (long)n, want) - b.offsets.begin());
+                if (cut[g] < cut[g - 1]) cut[g] = cut[g - 1];
+            }
+            std::vector<std::string> errs(G);
+            std::vector<std::thread> th;
+            for (size_t g = 0; g < G; g++)
+                th.emplace_back([&, g] {
+                    const size_t lo = cut[g], hi = cut[g + 1];
+                    if (hi > lo && hast_classify_perread(ctxs[g], b.bases.data(), b.offsets.data() + lo, hi - lo, v.data() + 2 * lo) != HAST_OK)
+                        errs[g] = hast_last_error();
+                });
+            for (std::thread &t : th) t.join();
+            for (const std::string &e : errs)
+                if (!e.empty()) {
+                    bg_error = "classifying a batch (" + e + ")";
+                    return;
+                }
         }
         char row[96];
         for (size_t i = 0; i < b.names.size(); i++) {
@@ -357,6 +411,6 @@ int main(int argc, char **argv) {
     }
     fflush(stdout);
     fprintf(stderr, "__END__\n");
-    hast_ctx_destroy(ctx);
+    for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     return 0;
 }

@@ -235,14 +235,17 @@ def test_cli_long_reads_stage01_semantics(exe, oracle_dir, tmp_path):
         assert got.stdout == ref.stdout
 
 
+@pytest.mark.parametrize("devices", [None, "0,0,0", pytest.param("0,1", marks=pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs"))])
 @pytest.mark.parametrize("case,run", golden_cases("s03"))
-def test_classify_read_cli_matches_s03_reference_golden(exe, golden_workdir, case, run):
+def test_classify_read_cli_matches_s03_reference_golden(exe, golden_workdir, case, run, devices):
     """Drop-in for the per-read classifier of stage 03 (config 5 analogue): stdout identical to the real reference
-    binary's on FASTA (multi-line) and gz FASTQ inputs with reads up to 20 kb."""
+    binary's on FASTA (multi-line) and gz FASTQ inputs with reads up to 20 kb.  --devices: every batch of reads is shared out
+    between the contexts (a copy of the table each), rows stay in read order -- BASELINE config 5's read sharding."""
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case
     # our loader drops the unterminated tail exactly like the reference; the fixture's hap1.mer has one
-    res = subprocess.run([hast_amd.classify_read_exe()] + meta["argv"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    res = subprocess.run([hast_amd.classify_read_exe()] + meta["argv"] + (["--devices", devices] if devices else []), cwd=d,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert res.stdout == open(d / meta["expected"], "rb").read()
@@ -306,10 +309,13 @@ def test_classify_read_parallel_ingest_matches_oracle(exe, oracle_dir, tmp_path,
     env = dict(os.environ)
     if block:
         env["HAST_READ_BLOCK_BYTES"] = str(block)
-    got = subprocess.run([hast_amd.classify_read_exe()] + args + ["--thread", str(threads)], cwd=tmp_path, env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert got.returncode == 0, got.stderr.decode()[-2000:]
-    assert got.stdout == ref.stdout
+    for extra in ([], ["--devices", "0,0,0,0"] if threads in (3, 5) else None):
+        if extra is None:
+            continue
+        got = subprocess.run([hast_amd.classify_read_exe()] + args + ["--thread", str(threads)] + extra, cwd=tmp_path, env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert got.returncode == 0, got.stderr.decode()[-2000:]
+        assert got.stdout == ref.stdout, extra
     assert len(ref.stdout.splitlines()) == 2 * (len(recs) + 1)
 
 
