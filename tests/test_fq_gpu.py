@@ -346,3 +346,44 @@ def test_fq_striped_stream_rejects_partial_blocks_and_early_opens():
         assert lib.hast_fq_poll(fq) == 0
         assert lib.hast_fq_next(fq, C.byref(blk)) != 0 and b"block behind it" in lib.hast_last_error()
         lib.hast_fq_destroy(fq)
+
+
+def test_fq_striped_stream_reports_a_record_larger_than_the_overlap():
+    """a block of a striped stream sees min(1 MB, block size) bytes of the next block: a record that needs more is an error
+    (HAST_ERR_FORMAT), never a silently cut read"""
+    lib = hast_amd.lib()
+    data = b"@a#1_1_1/1\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 40
+    data += b"@long#2_2_2/1\n" + b"ACGT" * 3000 + b"\n+\n" + b"I" * 12000 + b"\n" + b"@b#3_3_3/1\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 100
+    with hast_amd.Context(21) as a, hast_amd.Context(21) as b:
+        a.table_reserve(100)
+        a.table_insert_keys(0, np.array([12345], dtype=np.uint64))
+        assert lib.hast_table_clone(b._h, a._h) == 0
+        a.counts_resize(16)
+        b.counts_resize(16)
+        arr = (C.c_void_p * 2)(a._h, b._h)
+        fq = C.c_void_p()
+        assert lib.hast_fq_create_striped(arr, 2, 4096, 4, None, C.byref(fq)) == 0, lib.hast_last_error()
+        pos, statuses = 0, []
+        pending = 0
+        while pos < len(data):
+            n = min(4096, len(data) - pos)
+            buf = C.POINTER(C.c_uint8)()
+            assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
+            C.memmove(buf, data[pos:pos + n], n)
+            pos += n
+            assert lib.hast_fq_submit(fq, n, 1 if pos >= len(data) else 0) == 0, lib.hast_last_error()
+            pending += 1
+            while pending > (0 if pos >= len(data) else 1):
+                blk = FqBlock()
+                st = lib.hast_fq_next(fq, C.byref(blk))
+                statuses.append(st)
+                if st != 0:
+                    break
+                for i in range(blk.n_records):
+                    blk.ids[i] = 0
+                assert lib.hast_fq_commit(fq) == 0
+                pending -= 1
+            if statuses and statuses[-1] != 0:
+                break
+        assert statuses and statuses[-1] == 6 and b"larger than" in lib.hast_last_error(), (statuses, lib.hast_last_error())
+        lib.hast_fq_destroy(fq)
