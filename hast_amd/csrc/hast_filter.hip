@@ -144,7 +144,17 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {      
 // NTC = first-level minima per window, ceil((K-t+1)/g), when known at compile time (0 = runtime loop)
 // EXACT: the filter holds exact entries (hast_common.h): one 16-B load per window, a match IS a hit with its tag bits
 // TWO: prints may sit in either of two sub-buckets (FilterGeom::choices == 2): two loads and compares per window
-template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO>
+// GEO: 0 = the filter's geometry is read from the arguments; 1 / 2 = the two BASELINE geometries as compile-time constants
+// (1: K = 21, m = 14, t = 6, kp = 21 -- config 1-4 with exact entries; 2: K = 31, m = 15, t = 6, kp = 23 -- config 5).  The kernel
+// keeps more wave-uniform values alive than a wave has SGPRs; with the geometry folded into immediates the shifts, masks and the
+// x mod W of the probe loop need no registers at all and the spill reloads (v_readlane) leave the loop: 1612 -> 1453 static VALU
+// instructions (GEO 1), 1716 -> 1596 (GEO 2); measured on one box, both ways twice (profiles/round3_ab_geo.log): 1-2 % less
+// kernel time on C3, config 5 and clustered keys.
+template <int GEO> struct GeoConst { static constexpr int k = 0, m = 0, t = 0, kp = 0; };
+template <> struct GeoConst<1> { static constexpr int k = 21, m = 14, t = 6, kp = 21; };
+template <> struct GeoConst<2> { static constexpr int k = 31, m = 15, t = 6, kp = 23; };
+
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0>
 __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TR = a.tile_reads;
@@ -165,8 +175,14 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     const uint32_t lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));      // wave-uniform: loop control stays scalar
     uint32_t *q_lo = s_q + wave * 3 * kQCap, *q_hi = q_lo + kQCap, *q_rd = q_hi + kQCap;
-    const FilterGeom fg = a.fg;
-    const int K = a.k, M = fg.m, T = fg.t;
+    typedef GeoConst<GEO> GC;
+    FilterGeom fg = a.fg;
+    if (GEO) {                       // (the launcher has checked that the arguments say the same)
+        fg.k = GC::k; fg.m = GC::m; fg.t = GC::t; fg.kp = GC::kp;
+        fg.g = 4;
+        fg.wdiv = 65536u / (uint32_t)(GC::kp - GC::m + 1) + 1u;
+    }
+    const int K = GEO ? GC::k : a.k, M = fg.m, T = fg.t;
     const uint32_t G = (uint32_t)fg.g, W = filter_w(fg), NT = filter_nt(fg);
     const uint32_t ntc = NTC ? (uint32_t)NTC : (NT + G - 1) / G;
     const uint32_t kshift = 64 - 2 * K, tshift = 64 - 2 * T;
@@ -386,7 +402,8 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             if (ntc > 1) x = min(x, l1[NT - G]);
             // lanes without a window compute on whatever LDS holds: in range by construction, and never used
             const uint32_t xr = ((x & 0xFFFu) - p) & 63u;             // position of the smallest t-mer inside the window
-            const uint32_t pm = xr - mul24(mul24(xr, fg.wdiv) >> 16, W);      // ... mod W = position of the sampled m-mer
+            // ... mod W = position of the sampled m-mer (a mask when W is a known power of two)
+            const uint32_t pm = (GEO && (W & (W - 1)) == 0) ? (xr & (W - 1)) : xr - mul24(mul24(xr, fg.wdiv) >> 16, W);
             const uint32_t mm = (uint32_t)(fwd >> (2 * ((uint32_t)(K - M) - pm))) & mmask;
             uint32_t fb = ok ? filter_block_of(mm, M) : 0xFFFFFFFFu;  // real blocks are < 4^15
             // of the window as it stands (no canonical form in the probe): a hash for two sub-buckets and a print, or the
@@ -523,15 +540,18 @@ hipError_t launch_request_ceiling(const void *filter, uint64_t nblocks, uint32_t
     return hipGetLastError();
 }
 
-template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO>
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0>
 static hipError_t launch_f_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO, GEO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO>), dim3(grid), dim3(kThreadsF), smem, s, a);
+    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO, GEO>), dim3(grid), dim3(kThreadsF), smem, s, a);
     return hipGetLastError();
+}
+static bool geo_is(const ClassifyArgs &a, int k, int m, int t, int kp) {
+    return a.k == k && a.fg.k == k && a.fg.m == m && a.fg.t == t && a.fg.kp == kp && a.fg.g == 4;
 }
 
 // EXACT implies one sub-bucket per window (TWO = false)
@@ -540,6 +560,10 @@ static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipSt
     const bool fast = a.div_magic && a.div_l1g && a.div_hw;
     if (a.wide) return fast ? launch_f_t<0, true, STRICT, true, false, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true, false, TWO>(a, grid, smem, s);
     if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT, TWO>(a, grid, smem, s);
+    // the BASELINE geometries with their constants folded in (HAST_F_GEO=0 in the environment: the generic instantiations)
+    static const bool geo_on = [] { const char *e = getenv("HAST_F_GEO"); return !(e && e[0] == '0'); }();
+    if (geo_on && !STRICT && EXACT && !TWO && geo_is(a, 21, 14, 6, 21)) return launch_f_t<4, true, false, false, true, false, 1>(a, grid, smem, s);
+    if (geo_on && STRICT && !EXACT && !TWO && geo_is(a, 31, 15, 6, 23)) return launch_f_t<5, true, true, false, false, false, 2>(a, grid, smem, s);
     switch ((filter_nt(a.fg) + 3) / 4) {
     case 1: return launch_f_t<1, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
     case 2: return launch_f_t<2, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);

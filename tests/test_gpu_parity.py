@@ -448,7 +448,8 @@ def _kmer_str(key, k):
 
 
 @pytest.mark.parametrize("k,max_len,fm", [(21, 3000, 0), (31, 30000, 0), (32, 2000, 0), (11, 600, 0), (27, 100, 0),
-                                          (21, 30000, 14), (15, 3000, 8), (12, 700, 12)])       # fm: exact filter entries
+                                          (21, 30000, 14), (15, 3000, 8), (12, 700, 12),        # fm: exact filter entries
+                                          (31, 30000, 15)])     # config 5's geometry (m = 15, t = 6, kp = 23, prints filed once): the kernel with that geometry compiled in
 def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len, fm):
     """Integer hits per read == the stage-03 reference's string lookups: windows containing N / lower-case /
     IUPAC bytes miss (no whole-read skip), reads far longer than an LDS row are segmented on the device."""
@@ -485,7 +486,9 @@ def test_perread_strict_mode_vs_s03_oracle(built, oracle_lib, k, max_len, fm):
         ctx.table_insert_text(1, ("\n".join(lines[1]) + "\n").encode())
         votes = ctx.classify_perread(bases, off)
         votes2 = ctx.classify_perread(bases, off)                 # idempotent: the output rows are overwritten
-        assert not fm or ctx.filter_mode() == 2
+        assert not fm or ctx.filter_mode() == (1 if (k, fm) == (31, 15) else 2)
+        if (k, fm) == (31, 15):
+            assert ctx.filter_info()[1:4] == (15, 6, 23)
     exp = np.zeros_like(votes)
     h0, h1 = C.c_uint32(), C.c_uint32()
     for i, sq in enumerate(seqs):
