@@ -315,7 +315,10 @@ hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t bloc
     if (!ctxs || !out || n_ctx < 1) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
     if (block_bytes < 4096 || block_bytes > (1ull << 30)) return set_error(HAST_ERR_INVALID, "block_bytes %zu out of [4 KB, 1 GB]", block_bytes);
-    if (n_buffers_per_ctx < 2 || n_buffers_per_ctx * n_ctx > 64) return set_error(HAST_ERR_INVALID, "n_buffers_per_ctx %d out of range for %d contexts", n_buffers_per_ctx, n_ctx);
+    // at least three buffers in all: a buffer is reused once the block BEHIND its old block has been framed (that framing reads
+    // the old block's newline count and last byte), and a block is framed once the block behind IT has been submitted
+    if (n_buffers_per_ctx < 2 || n_buffers_per_ctx * n_ctx < 3 || n_buffers_per_ctx * n_ctx > 64)
+        return set_error(HAST_ERR_INVALID, "n_buffers_per_ctx %d out of range for %d contexts (3 to 64 buffers in all)", n_buffers_per_ctx, n_ctx);
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i] || hast_ctx_k(ctxs[i]) != hast_ctx_k(ctxs[0])) return set_error(HAST_ERR_INVALID, "contexts need one K");
         if (names && names[i] && names[i]->ctx != ctxs[i]) return set_error(HAST_ERR_INVALID, "name cache %d belongs to another context", i);

@@ -271,7 +271,8 @@ hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_n
  * it; their header and base lines may reach into the first bytes of the next block (at most min(1 MB, block_bytes): a
  * larger record is HAST_ERR_FORMAT), which are uploaded to both GPUs.  Differences to hast_fq_create streams: every block
  * but the last of a file must be full (n_bytes == hast_fq_block_bytes), and a block can be opened (hast_fq_poll /
- * hast_fq_next) once the block behind it has been submitted.  names: one cache per context, or NULL. */
+ * hast_fq_next) once the block behind it has been submitted.  n_buffers_per_ctx >= 2 and at least 3 buffers in all.  names: one
+ * cache per context, or NULL. */
 hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx,
                                    hast_names *const *names_or_null, hast_fq **out);
 int         hast_fq_lanes(const hast_fq *);                      /* contexts the stream's blocks rotate over (1 for hast_fq_create) */

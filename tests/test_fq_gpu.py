@@ -336,6 +336,7 @@ def test_fq_striped_stream_rejects_partial_blocks_and_early_opens():
     with hast_amd.Context(21) as a, hast_amd.Context(21) as b:
         arr = (C.c_void_p * 2)(a._h, b._h)
         fq = C.c_void_p()
+        assert lib.hast_fq_create_striped(arr, 1, 4096, 2, None, C.byref(fq)) != 0 and b"buffers in all" in lib.hast_last_error()
         assert lib.hast_fq_create_striped(arr, 2, 4096, 2, None, C.byref(fq)) == 0, lib.hast_last_error()
         buf = C.POINTER(C.c_uint8)()
         assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0
