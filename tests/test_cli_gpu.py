@@ -73,6 +73,8 @@ def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, 
     Integer sums: stdout must be byte-identical to the real reference's.  "0,0" = several contexts on the one GPU of the test
     box (same code path up to the sum: a kernel instead of RCCL); "0,1" = two GPUs over RCCL.  With blocks dealt, every context
     must have framed records of the (one or two) input files."""
+    if (devices, deal) != ("0,0,0", "blocks") and case != "rand_k21":
+        pytest.skip("the other dealings run on the rand_k21 case only (suite time)")
     meta = load_case(case)["runs"][run]
     d = golden_workdir / case
     env = dict(os.environ, HAST_DEAL="files") if deal == "files" else None

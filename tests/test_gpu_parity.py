@@ -559,7 +559,7 @@ def test_counts_allreduce_rccl_path_single_rank(built, monkeypatch):
     assert int(before[0].sum()) > 0
 
 
-@pytest.mark.parametrize("k,n_keys,L,n_reads", [(21, 20_000_000, 150, 500_000), (31, 20_000_000, 5000, 10_000)])
+@pytest.mark.parametrize("k,n_keys,L,n_reads", [(21, 5_000_000, 150, 300_000), (31, 5_000_000, 5000, 6_000)])
 def test_tables_placement_invariance(built, k, n_keys, L, n_reads):
     """Results must not depend on where keys live.  The same reads are classified against a table placed by the default
     minimizer and against one placed by plain hashing of the key (m = K), in one batch and split in two; set sizes,
@@ -728,9 +728,9 @@ ADAPTOR_R = b"TCTGCTGAGTCGAGAACGTCTCTGTGAGCCAAGGAGTTGCTCTGG"   # classify.cpp:31
 
 @pytest.mark.heavy
 @pytest.mark.parametrize("name,n_keys,n_bc,n_reads,clustered", [
-    ("C2", 50_000_000, 1_000_000, 2_000_000, False),
+    ("C2", 50_000_000, 1_000_000, 1_000_000, False),
     ("C3", 200_000_000, 10_000_000, 2_000_000, False),
-    ("C3-clustered-keys", 200_000_000, 10_000_000, 1_000_000, True),
+    ("C3-clustered-keys", 200_000_000, 10_000_000, 500_000, True),
 ])
 def test_baseline_size_configs_vs_oracle(built, oracle_lib, name, n_keys, n_bc, n_reads, clustered):
     """BASELINE configs 2 and 3 at their full table and barcode sizes (50M+50M keys / 1M barcodes; 200M+200M keys / 10M
