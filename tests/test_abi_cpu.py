@@ -148,7 +148,7 @@ def test_committed_pmc_profiles_belong_to_these_device_sources(monkeypatch):
     import json
     import types
     import bench
-    for v in ("HAST_CLASSIFY", "HAST_FILTER_EXACT", "HAST_FILTER_M", "HAST_FILTER_T", "HAST_FILTER_KP", "HAST_TILE_LDS", "HAST_LIB"):
+    for v in ("HAST_CLASSIFY", "HAST_FILTER_EXACT", "HAST_FILTER_M", "HAST_FILTER_T", "HAST_FILTER_KP", "HAST_TILE_LDS", "HAST_LIB", "HAST_F_GEO"):
         monkeypatch.delenv(v, raising=False)
     sid = bench.kernel_source_id()
     for name, wl, clustered in (("pmc_traffic.json", "c3", False), ("pmc_traffic_clustered.json", "c3", True),
