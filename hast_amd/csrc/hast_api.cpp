@@ -88,6 +88,9 @@ struct hast_ctx {
     // per-read votes of the last barcode-mode launch when the caller gave no buffer for them
     uint32_t *d_votes_scratch = nullptr;
     size_t votes_bytes = 0;
+    // scratch of the partitioned commit (bins of compressed records + overflow list)
+    void *d_part = nullptr;
+    size_t part_bytes = 0;
     // stream_file_region: two pinned pieces, their device twins, "piece is on the device" events
     char *sf_h[2] = {nullptr, nullptr}, *sf_d[2] = {nullptr, nullptr};
     hipEvent_t sf_done[2] = {nullptr, nullptr};
@@ -251,6 +254,7 @@ void hast_ctx_destroy(hast_ctx *c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_seg) (void)hipFree(c->d_seg);
     if (c->d_votes_scratch) (void)hipFree(c->d_votes_scratch);
+    if (c->d_part) (void)hipFree(c->d_part);
     for (int i = 0; i < 2; ++i) {
         if (c->sf_done[i]) (void)hipEventDestroy(c->sf_done[i]);
         if (c->sf_d[i]) (void)hipFree(c->sf_d[i]);
@@ -971,7 +975,24 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     if (ev) HIP_TRY(hipEventRecord(ev[0], hs));
     HIP_TRY(filt ? launch_classify_f(a, grid, smem, hs) : launch_classify(a, grid, smem, hs));
     if (ev) HIP_TRY(hipEventRecord(ev[1], hs));
-    if (d_barcode_ids) HIP_TRY(launch_commit_votes(votes_buf, d_barcode_ids, c->d_counts, nullptr, n_reads, hs));
+    if (d_barcode_ids) {
+        // per-barcode bookkeeping: one atomic per read, or -- large batches over many barcodes -- the pairs partitioned by barcode
+        // range and summed in LDS (hast_kernels.hip, "partitioned commit"; HAST_COMMIT=atomic / partition forces either)
+        const char *ce = getenv("HAST_COMMIT");                      // (read per call: the tests switch it)
+        const int mode = !ce ? 0 : !strcmp(ce, "atomic") ? 1 : !strcmp(ce, "partition") ? 2 : 0;
+        if (mode != 1 && !d_seg_read && commit_partition_usable(n_reads, c->n_barcodes, a.max_pos, mode == 2)) {
+            const size_t need = commit_partition_scratch_bytes(n_reads, c->n_barcodes, nullptr, nullptr);
+            if (c->part_bytes < need) {
+                HIP_TRY(hipStreamSynchronize(hs));
+                if (c->d_part) HIP_TRY(hipFree(c->d_part));
+                c->d_part = nullptr;
+                c->part_bytes = 0;
+                HIP_TRY(hipMalloc(&c->d_part, need + need / 8));
+                c->part_bytes = need + need / 8;
+            }
+            HIP_TRY(launch_commit_partitioned(votes_buf, d_barcode_ids, c->d_counts, c->n_barcodes, n_reads, c->d_part, hs));
+        } else HIP_TRY(launch_commit_votes(votes_buf, d_barcode_ids, c->d_counts, nullptr, n_reads, hs));
+    }
     if (ev) {
         HIP_TRY(hipEventRecord(ev[2], hs));
         c->t_next++;

@@ -67,6 +67,12 @@ hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_le
 hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, uint8_t *d_has_n, hipStream_t s);
 hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
                                size_t n_reads, hipStream_t s);
+// the same bookkeeping without one atomic per read (large batches over many barcodes): pairs partitioned by barcode range in
+// LDS, bins summed in LDS, plain read-modify-writes of the counters; max_votes = the most votes a read can have (<= 255)
+bool commit_partition_usable(size_t n_reads, size_t n_barcodes, uint32_t max_votes, bool forced);
+size_t commit_partition_scratch_bytes(size_t n_reads, size_t n_barcodes, uint32_t *n_bins_out, uint32_t *cap_out);
+hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, size_t n_barcodes, size_t n_reads,
+                                     void *d_scratch, hipStream_t s);
 hipError_t launch_add_u32(uint32_t *d_dst, const uint32_t *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
 hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);

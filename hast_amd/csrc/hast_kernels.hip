@@ -666,8 +666,11 @@ __global__ void __launch_bounds__(256) k_scan_n(const uint8_t *bases, const uint
 // everyone else does its one global atomic.
 constexpr int kCommitSlots = 128;              // power of two
 constexpr uint32_t kCommitSpan = 8192, kCommitFlush = 2048, kNoBarcode = 0xFFFFFFFFu;
+// n_ptr != nullptr: the list's length is only known on the device (the overflow list of the partitioned commit below)
 __global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, const uint32_t *barcode_ids, uint32_t *counts,
-                                                      uint32_t *votes_out, size_t n_reads) {
+                                                      uint32_t *votes_out, size_t n_reads_arg, const unsigned long long *n_ptr) {
+    const size_t n_reads = n_ptr ? (size_t)*n_ptr : n_reads_arg;
+    if ((size_t)blockIdx.x * kCommitSpan >= n_reads) return;                     // (wave-uniform)
     __shared__ unsigned long long s_vote[kCommitSlots];
     __shared__ uint32_t s_neg[kCommitSlots], s_id[kCommitSlots];
     const uint32_t tid = threadIdx.x;
@@ -721,6 +724,216 @@ __global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, con
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// Partitioned commit (large batches over many barcodes).  k_commit_votes does one memory-side atomic per read, and this part
+// executes 27 G of them per second whatever their scope or footprint (tools/l2_atomics_probe): 48M reads = 2.0 ms, 7 % of a
+// bench step.  Here the (barcode, votes) pairs are first PARTITIONED by barcode range -- in LDS, so that every bin receives
+// whole runs of records, and compressed to 4 bytes (13 bits of barcode inside the bin, 8 + 8 bits of votes: a read of up to
+// 255 windows) -- and then every bin is summed in LDS and added to its counters with plain coalesced read-modify-writes: the
+// workgroup of a bin is the only one that touches those counters.  No atomic leaves the chip except one reservation per
+// (workgroup, bin).  Bins have a fixed capacity; what does not fit (a barcode that owns a large share of the reads) goes to an
+// overflow list that k_commit_pairs adds with atomics afterwards.  Same integer sums, any order.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kPartMaxSpanBits = 13;                                        // at most 8192 barcodes per bin (13 + 8 + 8 bits per record)
+constexpr uint32_t kPartRecs = 16384;                                            // records a workgroup partitions at a time
+constexpr int kPartThreads = 1024;
+constexpr uint32_t kPartMaxBins = 4096;
+__global__ void __launch_bounds__(kPartThreads) k_commit_partition(const unsigned long long *votes, const uint32_t *ids, size_t n, uint32_t n_bins,
+                                                                  uint32_t span_bits, uint32_t cap, uint32_t *bin_fill, uint32_t *bin_valid, uint32_t *bin_recs,
+                                                                  unsigned long long *over_n, uint32_t *over_ids, unsigned long long *over_votes) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);                       // [n_bins] records of this span per bin
+    uint32_t *s_off = s_cnt + n_bins;                                            // [n_bins] where the bin starts in s_rec
+    uint32_t *s_dst = s_off + n_bins;                                            // [n_bins] where the bin's run goes (bit 31: overflow list)
+    uint32_t *s_rec = s_dst + n_bins;                                            // [kPartRecs] compressed records, grouped by bin
+    __shared__ uint32_t s_scan[kPartThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t kPartSpanBits = span_bits, kPartSpan = 1u << span_bits;
+    const size_t r0 = (size_t)blockIdx.x * kPartRecs;
+    const uint32_t nr = (uint32_t)(n - r0 < kPartRecs ? n - r0 : kPartRecs);
+    for (uint32_t b = tid; b < n_bins; b += kPartThreads) s_cnt[b] = 0;
+    __syncthreads();
+    constexpr int PER = kPartRecs / kPartThreads;                                // 16 records per thread
+    uint32_t rec[PER], rank[PER];                                                // rec: bin << 29-bit payload is not stored: bin is id >> 13
+    uint32_t bin_of[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t i = (uint32_t)q * kPartThreads + tid;                     // coalesced
+        bin_of[q] = 0xFFFFFFFFu;
+        if (i < nr) {
+            const uint32_t id = ids[r0 + i];
+            const unsigned long long v = votes[r0 + i];
+            bin_of[q] = id >> kPartSpanBits;
+            if (bin_of[q] >= n_bins) { bin_of[q] = 0xFFFFFFFFu; continue; }       // an id outside the counters (the caller's contract): dropped
+            rec[q] = (id & (kPartSpan - 1)) | ((uint32_t)v & 0xFFu) << 13 | ((uint32_t)(v >> 32) & 0xFFu) << 21;
+            rank[q] = atomicAdd(&s_cnt[bin_of[q]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of s_cnt over the bins (n_bins <= 4096 = 4 per thread)
+    {
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t b = tid * 4 + q;
+            c[q] = b < n_bins ? s_cnt[b] : 0;
+            sum += c[q];
+        }
+        uint32_t incl = sum;
+        const uint32_t lane = tid & 63;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        if (lane == 63) s_scan[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - sum;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) base += s_scan[w];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t b = tid * 4 + q;
+            if (b < n_bins) {
+                s_off[b] = base;
+                base += c[q];
+                // one reservation per (workgroup, bin): a run of c[q] records in the bin, or -- when the bin is full -- in the overflow list
+                uint32_t dst = 0;
+                if (c[q]) {
+                    const uint32_t g = atomicAdd(&bin_fill[b], c[q]);
+                    if (g + c[q] <= cap) dst = g;
+                    else {
+                        atomicMin(&bin_valid[b], g);                             // records [0, first failed reservation) of a bin are real
+                        dst = 0x80000000u | (uint32_t)atomicAdd(over_n, (unsigned long long)c[q]);
+                    }
+                }
+                s_dst[b] = dst;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (bin_of[q] != 0xFFFFFFFFu) s_rec[s_off[bin_of[q]] + rank[q]] = rec[q] | 0u;
+    __syncthreads();
+    // runs out: a quarter of a wave per bin (a run holds ~13 records: 16384 records over ~1200 bins), 16 lanes over the run
+    const uint32_t grp = tid >> 4, gl = tid & 15;
+    for (uint32_t b = grp; b < n_bins; b += kPartThreads / 16) {
+        const uint32_t cnt = s_cnt[b];
+        if (!cnt) continue;
+        const uint32_t dst = s_dst[b], off = s_off[b];
+        if (!(dst & 0x80000000u)) {
+            uint32_t *out = bin_recs + (size_t)b * cap + dst;
+            for (uint32_t j = gl; j < cnt; j += 16) out[j] = s_rec[off + j];
+        } else {
+            const uint32_t o = dst & 0x7FFFFFFFu;
+            for (uint32_t j = gl; j < cnt; j += 16) {
+                const uint32_t r = s_rec[off + j];
+                over_ids[o + j] = (b << kPartSpanBits) | (r & (kPartSpan - 1));
+                over_votes[o + j] = (unsigned long long)((r >> 13) & 0xFFu) | ((unsigned long long)((r >> 21) & 0xFFu) << 32);
+            }
+        }
+    }
+}
+
+// one workgroup per bin: sum its records in LDS, then add the sums to the bin's counters (nobody else touches them in this kernel)
+constexpr int kBinThreads = 1024;
+__global__ void __launch_bounds__(kBinThreads) k_commit_bins(const uint32_t *bin_recs, const uint32_t *bin_fill, const uint32_t *bin_valid, uint32_t cap,
+                                                     uint32_t span_bits, uint32_t *counts, size_t n_barcodes) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t kPartSpanBits = span_bits, kPartSpan = 1u << span_bits;
+    unsigned long long *s_vote = reinterpret_cast<unsigned long long *>(smem);   // [kPartSpan] {c0, c1}
+    uint32_t *s_neg = reinterpret_cast<uint32_t *>(s_vote + kPartSpan);          // [kPartSpan]
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t fill = bin_fill[b], valid = bin_valid[b];
+    const uint32_t n = fill < valid ? (fill < cap ? fill : cap) : valid;
+    if (n == 0) return;
+    for (uint32_t j = tid; j < kPartSpan; j += kBinThreads) {
+        s_vote[j] = 0;
+        s_neg[j] = 0;
+    }
+    __syncthreads();
+    const uint32_t *recs = bin_recs + (size_t)b * cap;
+    for (uint32_t i = tid; i < n; i += kBinThreads) {
+        const uint32_t r = recs[i];
+        const uint32_t id = r & (kPartSpan - 1), v0 = (r >> 13) & 0xFFu, v1 = (r >> 21) & 0xFFu;
+        if (v0 | v1) atomicAdd(&s_vote[id], (unsigned long long)v0 | ((unsigned long long)v1 << 32));
+        else atomicAdd(&s_neg[id], 1u);
+    }
+    __syncthreads();
+    const size_t first = (size_t)b << kPartSpanBits;
+    for (uint32_t j = tid; j < kPartSpan && first + j < n_barcodes; j += kBinThreads) {
+        const unsigned long long v = s_vote[j];
+        const uint32_t g = s_neg[j];
+        if (v | g) {
+            uint4 *rec = reinterpret_cast<uint4 *>(counts + 4 * (first + j));
+            uint4 c = *rec;
+            c.x += (uint32_t)v;
+            c.y += (uint32_t)(v >> 32);
+            c.z += g;
+            *rec = c;
+        }
+    }
+}
+
+static uint32_t part_span_bits(size_t n_barcodes) {               // ~1000 bins where the barcodes allow it, 256 .. 8192 barcodes per bin
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < n_barcodes) ++lg;
+    const uint32_t want = lg > 10 ? lg - 10 : 0;
+    return want < 8 ? 8u : (want > kPartMaxSpanBits ? kPartMaxSpanBits : want);
+}
+size_t commit_partition_scratch_bytes(size_t n_reads, size_t n_barcodes, uint32_t *n_bins_out, uint32_t *cap_out) {
+    const uint32_t sb = part_span_bits(n_barcodes);
+    const uint32_t n_bins = (uint32_t)((n_barcodes + ((size_t)1 << sb) - 1) >> sb);
+    const uint64_t mean = n_bins ? (n_reads + n_bins - 1) / n_bins : 0;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, mean + mean / 2 + 2048);
+    if (n_bins_out) *n_bins_out = n_bins;
+    if (cap_out) *cap_out = cap;
+    // [over_n u64 | pad][bin_fill][bin_valid][bin_recs n_bins x cap][over_ids n][over_votes n]
+    return 256 + (size_t)n_bins * 8 + 256 + (size_t)n_bins * cap * 4 + 256 + n_reads * 4 + 256 + n_reads * 8;
+}
+// worth it (and possible) for large batches over many barcodes: enough bins to fill the GPU, votes that fit a byte
+bool commit_partition_usable(size_t n_reads, size_t n_barcodes, uint32_t max_votes, bool forced) {
+    uint32_t n_bins, cap;
+    (void)commit_partition_scratch_bytes(n_reads, n_barcodes, &n_bins, &cap);
+    if (max_votes > 255 || n_bins < 1 || n_bins > kPartMaxBins || n_reads < 1 || n_reads >= (1ull << 31)) return false;
+    return forced || (n_bins >= 128 && n_reads >= (1u << 21));
+}
+hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, size_t n_barcodes, size_t n_reads,
+                                     void *d_scratch, hipStream_t s) {
+    uint32_t n_bins, cap;
+    (void)commit_partition_scratch_bytes(n_reads, n_barcodes, &n_bins, &cap);
+    const uint32_t sb = part_span_bits(n_barcodes);
+    unsigned char *p = reinterpret_cast<unsigned char *>(d_scratch);
+    unsigned long long *over_n = reinterpret_cast<unsigned long long *>(p);
+    uint32_t *bin_fill = reinterpret_cast<uint32_t *>(p + 256);
+    uint32_t *bin_valid = bin_fill + n_bins;
+    size_t at = 256 + (size_t)n_bins * 8;
+    at = (at + 255) & ~(size_t)255;
+    uint32_t *bin_recs = reinterpret_cast<uint32_t *>(p + at);
+    at += (size_t)n_bins * cap * 4;
+    at = (at + 255) & ~(size_t)255;
+    uint32_t *over_ids = reinterpret_cast<uint32_t *>(p + at);
+    at += n_reads * 4;
+    at = (at + 255) & ~(size_t)255;
+    unsigned long long *over_votes = reinterpret_cast<unsigned long long *>(p + at);
+    hipError_t e = hipMemsetAsync(p, 0, 256 + (size_t)n_bins * 4, s);                        // over_n, bin_fill
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(bin_valid, 0xFF, (size_t)n_bins * 4, s);
+    if (e != hipSuccess) return e;
+    const size_t lds1 = (size_t)n_bins * 12 + (size_t)kPartRecs * 4, lds2 = ((size_t)12 << sb);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_partition), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_bins), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_commit_partition, dim3((unsigned)((n_reads + kPartRecs - 1) / kPartRecs)), dim3(kPartThreads), lds1, s,
+                       reinterpret_cast<const unsigned long long *>(d_votes), d_barcode_ids, n_reads, n_bins, sb, cap, bin_fill, bin_valid, bin_recs,
+                       over_n, over_ids, over_votes);
+    hipLaunchKernelGGL(k_commit_bins, dim3(n_bins), dim3(kBinThreads), lds2, s, bin_recs, bin_fill, bin_valid, cap, sb, d_counts, n_barcodes);
+    // what found no room in its bin (a barcode that owns a large share of the reads): the atomic kernel with its LDS cache for such barcodes
+    hipLaunchKernelGGL(k_commit_votes, dim3((unsigned)((n_reads + kCommitSpan - 1) / kCommitSpan)), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t *>(over_votes), over_ids, d_counts, (uint32_t *)nullptr, (size_t)0, over_n);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, uint8_t *d_has_n, hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scan_n, dim3((unsigned)((n_reads * 64 + 255) / 256)), dim3(256), 0, s, d_bases, d_offsets, d_lens, n_reads, d_has_n, fixed_len);
@@ -730,7 +943,7 @@ hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcod
                                size_t n_reads, hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_commit_votes, dim3((unsigned)((n_reads + kCommitSpan - 1) / kCommitSpan)), dim3(256), 0, s, d_votes, d_barcode_ids,
-                       d_counts, d_votes_out, n_reads);
+                       d_counts, d_votes_out, n_reads, (const unsigned long long *)nullptr);
     return hipGetLastError();
 }
 

@@ -154,7 +154,9 @@ hast_status hast_filter_request_ceiling(hast_ctx *, double *requests_per_s);
  * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:
  *   c0/c1 = sum of per-read votes for key 0/1 (classify.cpp:203-206), neg = key -1 (:191,:207-208).
  * A barcode was "seen" (gets an output row, classify.cpp:94) iff c0|c1|neg != 0.
- * A read's two votes are added with one 64-bit atomic, so a c0 that passes 2^32 between two read-backs would carry into c1.
+ * A read's two votes are added with one 64-bit atomic, so a c0 that passes 2^32 between two read-backs would carry into c1
+ * (large device-resident batches over many barcodes take a partitioned path instead -- pairs grouped by barcode range and summed
+ * in LDS, plain 32-bit adds, no carry; HAST_COMMIT=atomic|partition forces either; same sums).
  * The reference counts in `int` (classify.cpp:51): parity is undefined past INT_MAX there; the classify program warns when a
  * counter it reads back is above INT_MAX. */
 hast_status hast_counts_resize(hast_ctx *, size_t n_barcodes);                 /* library-owned, zeroed */

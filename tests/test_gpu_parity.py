@@ -1101,3 +1101,39 @@ def test_kernel_timing_ring(built):
         ctx.classify_device(d_b, n * L, n, L, d_barcode_ids=d_i)
         assert ctx.classify_times() == ([], [])
         ctx.sync()
+
+
+@pytest.mark.parametrize("n_bc,hot", [(300, 0.0), (100_000, 0.0), (3_000_000, 0.0), (100_000, 0.4), (2_000_000, 0.9)])
+def test_partitioned_commit_equals_atomic_commit_and_oracle(built, oracle_lib, monkeypatch, n_bc, hot):
+    """The per-barcode bookkeeping (classify.cpp:203-208) two ways: one memory-side atomic per read (k_commit_votes) and the
+    partitioned commit of large batches (pairs grouped by barcode range in LDS, bins summed in LDS, plain adds; HAST_COMMIT
+    forces either).  hot: share of the reads that belong to ONE barcode (real stLFR data: "0_0_0" owns 10-20 %) -- its bin
+    overflows and the rest goes through the overflow list.  All three counters of every barcode == oracle, both ways."""
+    k, L, n_keys, n_reads = 21, 150, 20000, 300_000
+    p = make_params(k, L, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    bases, ids = hast_amd.synth_reads_host(p, 11, n_reads)
+    rng = np.random.default_rng(n_bc + int(hot * 10))
+    if hot:
+        ids = ids.copy()
+        ids[rng.random(n_reads) < hot] = min(7, n_bc - 1)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    exp = oracle_counts(oracle_lib, oc, bases, off, ids, n_bc)
+    oracle_lib.ho_free(oc)
+    assert int(exp[2].sum()) > 0 and int(exp[0].sum()) > 0
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        ctx.counts_resize(n_bc)
+        d_b, d_i = ctx.to_device(bases), ctx.to_device(ids)
+        for mode in ("partition", "atomic", "partition"):
+            monkeypatch.setenv("HAST_COMMIT", mode)
+            ctx.counts_zero()
+            ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i)
+            # twice into the same counters: the sums add up (plain adds of the partitioned path must not lose the first round)
+            ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i)
+            got = ctx.counts_read(n_bc)
+            for a, b in zip(got, exp):
+                assert np.array_equal(a, 2 * b), (mode, n_bc, hot)
