@@ -74,7 +74,7 @@ struct hast_ctx {
     bool counts_owned = false;
     // small scratch
     uint32_t *d_err = nullptr;              // [4]
-    unsigned long long *d_cnt = nullptr;    // [4]: [0..1] set sizes / segment counter, [3] tile queue of k_classify
+    unsigned long long *d_cnt = nullptr;    // [8]: [0..1] set sizes, [2] sink of measurement kernels, [3] tile queue of k_classify, [4] segment counter
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
     Staging stage[2];
@@ -221,7 +221,7 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     };
     bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
     bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
-    bail(hipMalloc(&c->d_cnt, 4 * sizeof(unsigned long long)), "hipMalloc(cnt)");
+    bail(hipMalloc(&c->d_cnt, 8 * sizeof(unsigned long long)), "hipMalloc(cnt)");
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
     if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     for (auto &s : c->stage)
@@ -875,7 +875,8 @@ static constexpr uint32_t kLongRead = 4096;      // longer reads go through the 
 
 static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  const uint32_t *d_lens, const uint32_t *d_seg_read, int strict, uint32_t read_len,
-                                 const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads, hast_stream s) {
+                                 const uint32_t *d_barcode_ids, uint32_t *d_votes, size_t n_reads, hast_stream s,
+                                 const unsigned long long *d_n_rows = nullptr) {
     if (hast_status st = need_table(c, 0)) return st;
     if (n_reads == 0) return HAST_OK;
     if (!d_bases) return fail(HAST_ERR_INVALID, "d_bases is null");
@@ -912,6 +913,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     a.votes = votes_buf;
     a.slots = c->d_slots;
     a.n_reads = n_reads;
+    a.n_rows_ptr = d_n_rows;                   // (n_reads is then the most rows there can be)
     a.nbuckets = c->nbuckets;
     a.read_len = read_len;
     a.k = c->k;
@@ -1139,17 +1141,18 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
     uint32_t *seg_read = seg_len + cap;
     // strict callers own an output row per read; otherwise accumulate privately and commit afterwards
     uint32_t *target = strict ? d_votes_out : acc;
-    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), hs));
+    unsigned long long *d_nseg = c->d_cnt + 4;                           // (its own word: ensure_filter counts tags in [0..1])
+    HIP_TRY(hipMemsetAsync(d_nseg, 0, sizeof(unsigned long long), hs));
     HIP_TRY(hipMemsetAsync(target, 0, n_reads * 2 * sizeof(uint32_t), hs));
     if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, d_lens, fixed_len, n_reads, has_n, hs));
-    HIP_TRY(launch_build_segments(d_offsets, d_lens, fixed_len, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, c->d_cnt,
+    HIP_TRY(launch_build_segments(d_offsets, d_lens, fixed_len, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, d_nseg,
                                   strict ? nullptr : has_n, hs));
-    unsigned long long n_seg = 0;
-    HIP_TRY(hipMemcpyAsync(&n_seg, c->d_cnt, sizeof(n_seg), hipMemcpyDeviceToHost, hs));
-    HIP_TRY(hipStreamSynchronize(hs));
-    if (n_seg > cap) return fail(HAST_ERR_INVALID, "segment table overflow (%llu > %zu)", n_seg, cap);
+    // the number of segments stays on the device (no host round trip between the two kernels): the classify kernel reads it
+    // from d_nseg and is launched for the most segments there can be -- every read has at least one, every further one
+    // covers kSegWindows more bases -- which the table was sized for above
+    if (max_seg > cap) return fail(HAST_ERR_INVALID, "segment table too small (%zu > %zu)", max_seg, cap);
     if (hast_status st = classify_rows(c, d_bases, bases_bytes, seg_off, seg_len, seg_read, strict, kSegWindows + (uint32_t)c->k - 1,
-                                       nullptr, target, (size_t)n_seg, hs))
+                                       nullptr, target, max_seg, hs, d_nseg))
         return st;
     if (!strict) HIP_TRY(launch_commit_votes(acc, d_barcode_ids, c->d_counts, d_votes_out, n_reads, hs));
     return HAST_OK;

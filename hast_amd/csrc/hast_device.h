@@ -24,6 +24,8 @@ struct ClassifyArgs {
     unsigned long long *tile_queue; // zeroed before the launch: next tile index (dynamic load balance)
     const uint64_t *slots;       // table
     uint64_t n_reads;
+    const unsigned long long *n_rows_ptr;   // not nullptr: the number of rows is read from here (segment tables built on the device:
+                                            // no host round trip for their size); n_reads is then an upper bound for the launch
     uint32_t nbuckets;
     uint32_t read_len;           // fixed length, or upper bound when offsets != nullptr
     uint32_t max_pos;            // read_len-K+1 (0 when read_len<K): position stride per read

@@ -188,7 +188,8 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     const uint32_t kshift = 64 - 2 * K, tshift = 64 - 2 * T;
     const uint32_t mmask = (uint32_t)kmer_mask(M);
     const uint32_t nb = a.nbuckets;
-    const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
+    const uint64_t n_rows = a.n_rows_ptr ? (uint64_t)*a.n_rows_ptr : a.n_reads;
+    const uint64_t n_tiles = (n_rows + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
     const u32x4f *filt = reinterpret_cast<const u32x4f *>(a.filter);
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         const uint64_t tile = *s_tile;
         if (tile >= n_tiles) break;
         const uint64_t r0 = tile * TR;
-        const uint32_t tra = (uint32_t)((a.n_reads - r0 < TR) ? (a.n_reads - r0) : TR);
+        const uint32_t tra = (uint32_t)((n_rows - r0 < TR) ? (n_rows - r0) : TR);
 
         // ---- per-read header --------------------------------------------------------------
         if (tid < tra) {

@@ -265,7 +265,8 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint32_t W = WT ? (uint32_t)WT : (uint32_t)(K - M + 1);
     const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
     const uint32_t nb = a.nbuckets;
-    const uint64_t n_tiles = (a.n_reads + TR - 1) / TR;
+    const uint64_t n_rows = a.n_rows_ptr ? (uint64_t)*a.n_rows_ptr : a.n_reads;
+    const uint64_t n_tiles = (n_rows + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
     const u64x2 *tab0 = reinterpret_cast<const u64x2 *>(a.slots) + sub;    // this lane's first 16-B piece of bucket 0
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
         const uint64_t tile = *s_tile;
         if (tile >= n_tiles) break;
         const uint64_t r0 = tile * TR;
-        const uint32_t tra = (uint32_t)((a.n_reads - r0 < TR) ? (a.n_reads - r0) : TR);
+        const uint32_t tra = (uint32_t)((n_rows - r0 < TR) ? (n_rows - r0) : TR);
 
         // ---- per-read header --------------------------------------------------------------
         if (tid < tra) {
@@ -624,25 +625,57 @@ hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStre
 }
 
 // Long reads -> segments of at most seg_windows windows (consecutive segments overlap by K-1 bases), so that a
-// row of the classify kernel always fits LDS.  One thread per read; segment rows are handed out with one atomic.
-__global__ void k_build_segments(const uint64_t *offsets, const uint32_t *lens, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
-                                 uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter, const uint8_t *skip, uint64_t fixed_len) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
+// row of the classify kernel always fits LDS.  Segment rows are handed out with one atomic per read.
+// A workgroup takes 256 reads: every thread sizes one read, the workgroup reserves all their rows with ONE atomic (one atomic per
+// read on the one counter word serialises at the memory side: 360k of them = 0.65-1.1 ms, 2-4 % of a config-5 step), then 16
+// lanes write a read's rows side by side (a 20-kb read has 42).
+__global__ void __launch_bounds__(256) k_build_segments(const uint64_t *offsets, const uint32_t *lens, size_t n_reads, int k, uint32_t seg_windows,
+                                                        uint64_t *seg_off, uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter,
+                                                        const uint8_t *skip, uint64_t fixed_len) {
+    __shared__ unsigned long long s_off[256], s_len[256], s_first[256];
+    __shared__ uint32_t s_nseg[256], s_wave[4];
+    __shared__ unsigned long long s_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const size_t i = blockIdx.x * (size_t)256 + tid;
     // offsets == nullptr: reads of fixed_len back to back; lens == nullptr: offsets holds n_reads+1 boundaries; else n_reads
     // starts + their lengths (reads framed out of a raw FASTQ block)
-    const uint64_t off = offsets ? offsets[i] : i * fixed_len;
-    const uint64_t len = (skip && skip[i]) ? 0 : !offsets ? fixed_len : (lens ? (uint64_t)lens[i] : offsets[i + 1] - off);   // skipped read: no windows
-    const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
-    const uint64_t nseg = nwin ? (nwin + seg_windows - 1) / seg_windows : 1;
-    const unsigned long long base = atomicAdd(counter, (unsigned long long)nseg);
-    for (uint64_t j = 0; j < nseg; ++j) {
-        const uint64_t start = j * seg_windows;
-        const uint64_t rest = len - start;
-        const uint64_t sl = rest < (uint64_t)seg_windows + k - 1 ? rest : (uint64_t)seg_windows + k - 1;
-        seg_off[base + j] = off + start;
-        seg_len[base + j] = (uint32_t)sl;
-        seg_read[base + j] = (uint32_t)i;
+    uint64_t off = 0, len = 0;
+    uint32_t nseg = 0;
+    if (i < n_reads) {
+        off = offsets ? offsets[i] : i * fixed_len;
+        len = (skip && skip[i]) ? 0 : !offsets ? fixed_len : (lens ? (uint64_t)lens[i] : offsets[i + 1] - off);   // skipped read: no windows
+        const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
+        nseg = (uint32_t)(nwin ? (nwin + seg_windows - 1) / seg_windows : 1);
+    }
+    uint32_t incl = nseg;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    if (lane == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - nseg;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) before += s_wave[w];
+    if (tid == 255) s_base = atomicAdd(counter, (unsigned long long)(before + nseg));
+    __syncthreads();
+    s_off[tid] = off;
+    s_len[tid] = len;
+    s_nseg[tid] = nseg;
+    s_first[tid] = s_base + before;
+    __syncthreads();
+    const uint32_t grp = tid >> 4, gl = tid & 15;
+    for (uint32_t r = grp; r < 256; r += 16) {
+        const uint32_t ns = s_nseg[r];
+        const uint64_t o = s_off[r], l = s_len[r], first = s_first[r];
+        const uint32_t read = (uint32_t)(blockIdx.x * (size_t)256 + r);
+        for (uint32_t j = gl; j < ns; j += 16) {
+            const uint64_t start = (uint64_t)j * seg_windows;
+            const uint64_t rest = l - start;
+            const uint64_t sl = rest < (uint64_t)seg_windows + k - 1 ? rest : (uint64_t)seg_windows + k - 1;
+            seg_off[first + j] = o + start;
+            seg_len[first + j] = (uint32_t)sl;
+            seg_read[first + j] = read;
+        }
     }
 }
 
