@@ -154,12 +154,17 @@ template <int GEO> struct GeoConst { static constexpr int k = 0, m = 0, t = 0, k
 template <> struct GeoConst<1> { static constexpr int k = 21, m = 14, t = 6, kp = 21; };
 template <> struct GeoConst<2> { static constexpr int k = 31, m = 15, t = 6, kp = 23; };
 
-template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0>
+// RL (only with GEO): the rows' length as a compile-time constant too (150-bp reads; the 512-base segment rows of long reads):
+// words per row, the L1 stride and the windows per row become immediates and the row/position divisions constant divisions.
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0, int RL = 0>
 __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(ClassifyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
+    typedef GeoConst<GEO> GC0;
+    constexpr bool RLC = RL != 0 && GEO != 0;                        // row shape known at compile time
     const uint32_t TR = a.tile_reads;
-    const uint32_t WS = a.w64 + 1;                                   // LDS words per read incl. pad
-    const uint32_t L1S = a.l1_stride;
+    const uint32_t W64 = RLC ? (uint32_t)((RL + 31) / 32) : a.w64;
+    const uint32_t WS = W64 + 1;                                     // LDS words per read incl. pad
+    const uint32_t L1S = RLC ? (uint32_t)((RL - GC0::t + 1 + 1 + 3) & ~3) : a.l1_stride;
     unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);            // next tile of this workgroup
     uint32_t *s_l1 = reinterpret_cast<uint32_t *>(s_tile + 2);                             // [TR][L1S] (+ 64 pad), 16-B aligned rows
     unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(s_l1 + (size_t)TR * L1S + 64);   // [TR][WS]
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_off + TR);                            // [TR]
     uint32_t *s_flag = s_len + TR;                                                         // [TR]
     uint32_t *s_q = s_flag + TR;                                                           // [4][3][kQCap]
-    const uint32_t IW = 2 * a.w64 + 1;                                                     // invalid-byte mask words per read
+    const uint32_t IW = 2 * W64 + 1;                                                       // invalid-byte mask words per read
     uint32_t *s_inv = s_q + 4 * 3 * kQCap;                                                 // [TR][IW], STRICT only
 
     const uint32_t tid = threadIdx.x;
@@ -206,9 +211,10 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         // ---- per-read header --------------------------------------------------------------
         if (tid < tra) {
             uint64_t off, len;
+            const uint32_t rlen = RLC ? (uint32_t)RL : a.read_len;
             if (a.offsets) { off = a.offsets[r0 + tid]; len = a.lens ? a.lens[r0 + tid] : a.offsets[r0 + tid + 1] - off; }
-            else           { off = (r0 + tid) * (uint64_t)a.read_len; len = a.read_len; }
-            if (len > a.read_len) len = a.read_len;          // contract: read_len bounds every read
+            else           { off = (r0 + tid) * (uint64_t)rlen; len = rlen; }
+            if (len > rlen) len = rlen;                      // contract: read_len bounds every read
             s_off[tid] = off;
             s_len[tid] = (uint32_t)len;
             s_flag[tid] = 0;
@@ -219,9 +225,9 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
 
         // ---- A: pack ----------------------------------------------------------------------
-        const uint32_t HW = a.w64 * 2;                                // 16-base half-words per read
+        const uint32_t HW = W64 * 2;                                  // 16-base half-words per read
         for (uint32_t t = tid; t < tra * HW; t += kThreadsF) {
-            const uint32_t r = FAST ? __umulhi(t, a.div_hw) : (t / HW);
+            const uint32_t r = RLC ? (t / HW) : FAST ? __umulhi(t, a.div_hw) : (t / HW);
             const uint32_t j = t - r * HW;
             const uint32_t len = s_len[r];
             if (16 * j >= len) continue;
@@ -268,7 +274,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             for (uint32_t b0 = wave * 63; b0 < total; b0 += 4 * 63) {
                 const uint32_t gi = b0 + lane;
                 const bool in = gi < total;
-                uint32_t r = FAST ? __umulhi(gi, a.div_l1g) : (gi / gpr);
+                uint32_t r = RLC ? (gi / gpr) : FAST ? __umulhi(gi, a.div_l1g) : (gi / gpr);
                 r = in ? r : 0;
                 const uint32_t q0 = in ? 4 * (gi - r * gpr) : 0;
                 const int nv = in ? (int)s_len[r] - T + 1 - (int)q0 : 0;                  // e[q0 + i] exists iff i < nv
@@ -311,7 +317,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         }
 
         // ---- B: probe ---------------------------------------------------------------------------------------------
-        const uint32_t P = a.max_pos;                                 // windows per read (stride)
+        const uint32_t P = RLC ? (uint32_t)(RL - GC0::k + 1) : a.max_pos;   // windows per read (stride)
         uint32_t qn = 0;                                              // positives waiting in this wave's queue
         // V: the last `cnt` queue entries, one per lane, against the exact table
         auto drain = [&](uint32_t cnt) {
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         // (re)derive cr, cp from pos: once per range, and per instruction when reads have fewer than 64 windows
         auto locate = [&]() {
             const uint32_t q = pos + lane;
-            cr = FAST ? __umulhi(q, a.div_magic) : (q / P);
+            cr = RLC ? (q / P) : FAST ? __umulhi(q, a.div_magic) : (q / P);
             cp = q - cr * P;
         };
         auto start = [&](Blk &B) {
@@ -541,15 +547,19 @@ hipError_t launch_request_ceiling(const void *filter, uint64_t nblocks, uint32_t
     return hipGetLastError();
 }
 
-template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0>
+template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0, int RL = 0>
 static hipError_t launch_f_t(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
     if (smem > (48u << 10)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO, GEO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO, GEO, RL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO, GEO>), dim3(grid), dim3(kThreadsF), smem, s, a);
+    hipLaunchKernelGGL((k_classify_f<NTC, FAST, STRICT, WIDE, EXACT, TWO, GEO, RL>), dim3(grid), dim3(kThreadsF), smem, s, a);
     return hipGetLastError();
+}
+// the row shape the host computed is the one a kernel with RL compiled in assumes
+static bool rows_are(const ClassifyArgs &a, uint32_t rl, int k, int t) {
+    return a.read_len == rl && a.w64 == (rl + 31) / 32 && a.max_pos == rl - (uint32_t)k + 1 && a.l1_stride == ((rl - (uint32_t)t + 1 + 1 + 3) & ~3u);
 }
 static bool geo_is(const ClassifyArgs &a, int k, int m, int t, int kp) {
     return a.k == k && a.fg.k == k && a.fg.m == m && a.fg.t == t && a.fg.kp == kp && a.fg.g == 4;
@@ -563,8 +573,15 @@ static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipSt
     if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT, TWO>(a, grid, smem, s);
     // the BASELINE geometries with their constants folded in (HAST_F_GEO=0 in the environment: the generic instantiations)
     static const bool geo_on = [] { const char *e = getenv("HAST_F_GEO"); return !(e && e[0] == '0'); }();
-    if (geo_on && !STRICT && EXACT && !TWO && geo_is(a, 21, 14, 6, 21)) return launch_f_t<4, true, false, false, true, false, 1>(a, grid, smem, s);
-    if (geo_on && STRICT && !EXACT && !TWO && geo_is(a, 31, 15, 6, 23)) return launch_f_t<5, true, true, false, false, false, 2>(a, grid, smem, s);
+    static const bool rl_on = [] { const char *e = getenv("HAST_F_RL"); return !(e && e[0] == '0'); }();
+    if (geo_on && !STRICT && EXACT && !TWO && geo_is(a, 21, 14, 6, 21)) {
+        if (rl_on && rows_are(a, 150, 21, 6)) return launch_f_t<4, true, false, false, true, false, 1, 150>(a, grid, smem, s);
+        return launch_f_t<4, true, false, false, true, false, 1>(a, grid, smem, s);
+    }
+    if (geo_on && STRICT && !EXACT && !TWO && geo_is(a, 31, 15, 6, 23)) {
+        if (rl_on && rows_are(a, 512, 31, 6)) return launch_f_t<5, true, true, false, false, false, 2, 512>(a, grid, smem, s);
+        return launch_f_t<5, true, true, false, false, false, 2>(a, grid, smem, s);
+    }
     switch ((filter_nt(a.fg) + 3) / 4) {
     case 1: return launch_f_t<1, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
     case 2: return launch_f_t<2, true, STRICT, false, EXACT, TWO>(a, grid, smem, s);
