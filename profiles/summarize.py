@@ -39,7 +39,8 @@ def kernel_source_id():
 
 def counters(d, want):
     """last dispatch's value of every counter of the first kernel whose name contains `want`"""
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    # (gpurun MERGES a call's files into gpurun_out/: a tag collected twice leaves the older run's files next to the newer ones)
+    f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     out = {}
     if not f:
         return out
