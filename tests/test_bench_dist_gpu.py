@@ -65,17 +65,21 @@ def test_more_ranks_than_gpus_fails_in_the_child_with_a_clear_message():
     assert b"has no GPU of its own" in r.stderr and b"launching 2 ranks" in r.stderr
 
 
-def test_two_ranks_equal_one_process(one_process):
-    common, one = COMMON, one_process
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"] + common,
-               {"HAST_BENCH_SHARE_GPU": "1", "HAST_BENCH_BACKEND": "gloo"})
-    # ranks 0,1 at timed steps j=1..3 own batches (2j + r) = 2..7; one process with warmup 2 owns j = 2..7
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
-    assert len(two["ranks"]["kernel_ms_avg"]["per_rank"]) == 2 and two["allreduce_ms"] >= 0
-    assert two["config"]["reads_total"] == one["config"]["reads_total"] == 6 * 300000
-    assert two["hits"] == one["hits"] and two["hits"]["c0"] > 0
-    assert two["scaling"] == "weak" and "all_reduce" in two["config"]["collective"]
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_sharing_the_gpu_equal_one_process(one_process, ranks):
+    """N ranks on the one GPU of the box (HAST_BENCH_SHARE_GPU) reducing over gloo: the read ranges of the ranks, the merge and
+    the rank-0 output for N = 2 and N = 4 (the box allows six processes on its GPU)."""
+    common = COMMON
+    n = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+              "--master-port", str(29533 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "3", "--warmup", "1"] + common,
+             {"HAST_BENCH_SHARE_GPU": "1", "HAST_BENCH_BACKEND": "gloo"})
+    # ranks r = 0..N-1 at timed steps j = 1..3 own batches (N j + r) = N .. 4N-1; one process with warmup N owns the same range
+    one = one_process if ranks == 2 else _run([sys.executable, "bench.py", "--steps", str(3 * ranks), "--warmup", str(ranks)] + common, {})
+    assert n["n_gpus"] == ranks and one["n_gpus"] == 1
+    assert len(n["ranks"]["kernel_ms_avg"]["per_rank"]) == ranks and n["allreduce_ms"] >= 0
+    assert n["config"]["reads_total"] == one["config"]["reads_total"] == 3 * ranks * 300000
+    assert n["hits"] == one["hits"] and n["hits"]["c0"] > 0
+    assert n["scaling"] == "weak" and "all_reduce" in n["config"]["collective"]
 
 
 @pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: one rank per GPU, all-reduce over RCCL/xGMI")
