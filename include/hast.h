@@ -185,11 +185,13 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
  *                  ignored; they must be mapped device memory, which holds for any pointer into an allocation made by
  *                  hipMalloc or a sub-allocator with >= 4-byte granules (torch's: 512 B).
  * A read shorter than K has no windows (the reference aborts, kmer.h:171): it votes 0/0.
- * Reads of any length: with d_offsets and read_len > 4096 the reads are cut into segments on the device
- * (same result; the call then waits for one small device->host counter before the main launch).
- * Otherwise asynchronous on `stream`.  Two kernels run per call: the probes (k_classify) write per-read votes -- to d_votes, or
- * to library scratch that grows on demand (a larger batch than ever before synchronises once) -- and k_commit_votes turns
- * them into the per-barcode counters (updates interleaved with the probes' reads cost four times as much). */
+ * Reads of any length: with read_len > 4096 (with or without d_offsets) the reads are cut into segments on the device (same
+ * result; the segment count stays on the device, nothing waits for the host).
+ * Asynchronous on `stream`.  Per call: the probes (k_classify_f) write per-read votes -- to d_votes, or to library scratch that
+ * grows on demand (a larger batch than ever before synchronises once) -- and a second step turns them into the per-barcode
+ * counters: one atomic per read (k_commit_votes), or, for batches of >= 2M reads over many barcodes, the pairs grouped by barcode
+ * range and summed in LDS (k_commit_partition + k_commit_bins) -- DESIGN.md section 3: updates interleaved with the probes' reads
+ * cost four times as much, hence kernels of their own. */
 hast_status hast_classify_device(hast_ctx *, const uint8_t *d_bases, size_t bases_bytes,
                                  const uint64_t *d_offsets, uint32_t read_len,
                                  const uint32_t *d_barcode_ids, uint32_t *d_votes,
