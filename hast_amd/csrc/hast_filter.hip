@@ -154,7 +154,7 @@ template <int GEO> struct GeoConst { static constexpr int k = 0, m = 0, t = 0, k
 template <> struct GeoConst<1> { static constexpr int k = 21, m = 14, t = 6, kp = 21; };
 template <> struct GeoConst<2> { static constexpr int k = 31, m = 15, t = 6, kp = 23; };
 
-// RL (only with GEO): the rows' length as a compile-time constant too (150-bp reads; the 512-base segment rows of long reads):
+// RL (only with GEO): the rows' length as a compile-time constant too (150- and 100-bp reads; the 512-base segment rows of long reads):
 // words per row, the L1 stride and the windows per row become immediates and the row/position divisions constant divisions.
 template <int NTC, bool FAST, bool STRICT, bool WIDE, bool EXACT, bool TWO, int GEO = 0, int RL = 0>
 __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(ClassifyArgs a) {
@@ -572,10 +572,12 @@ static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipSt
     if (a.wide) return fast ? launch_f_t<0, true, STRICT, true, false, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true, false, TWO>(a, grid, smem, s);
     if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT, TWO>(a, grid, smem, s);
     // the BASELINE geometries with their constants folded in (HAST_F_GEO=0 in the environment: the generic instantiations)
-    static const bool geo_on = [] { const char *e = getenv("HAST_F_GEO"); return !(e && e[0] == '0'); }();
-    static const bool rl_on = [] { const char *e = getenv("HAST_F_RL"); return !(e && e[0] == '0'); }();
+    const char *ge = getenv("HAST_F_GEO"), *re = getenv("HAST_F_RL");             // (read per launch: the tests switch them)
+    const bool geo_on = !(ge && ge[0] == '0');
+    const bool rl_on = !(re && re[0] == '0');
     if (geo_on && !STRICT && EXACT && !TWO && geo_is(a, 21, 14, 6, 21)) {
         if (rl_on && rows_are(a, 150, 21, 6)) return launch_f_t<4, true, false, false, true, false, 1, 150>(a, grid, smem, s);
+        if (rl_on && rows_are(a, 100, 21, 6)) return launch_f_t<4, true, false, false, true, false, 1, 100>(a, grid, smem, s);   // stLFR PE100
         return launch_f_t<4, true, false, false, true, false, 1>(a, grid, smem, s);
     }
     if (geo_on && STRICT && !EXACT && !TWO && geo_is(a, 31, 15, 6, 23)) {

@@ -1137,3 +1137,44 @@ def test_partitioned_commit_equals_atomic_commit_and_oracle(built, oracle_lib, m
             got = ctx.counts_read(n_bc)
             for a, b in zip(got, exp):
                 assert np.array_equal(a, 2 * b), (mode, n_bc, hot)
+
+
+@pytest.mark.parametrize("L", [100, 150, 151])
+def test_kernels_with_geometry_and_row_length_compiled_in_vs_oracle(built, oracle_lib, monkeypatch, L):
+    """k_classify_f exists with the BASELINE geometry (K = 21, m = 14, t = 6, kp = 21) and the row length (100, 150) compiled in;
+    L = 151 takes the instantiation with the geometry alone, HAST_F_GEO=0 the generic one.  Fixed-length rows and ragged rows of
+    at most L bases: votes and counters == oracle, and all three kernels agree."""
+    k, n_keys, n_bc, n_reads = 21, 30000, 97, 20000
+    p = make_params(k, L, n_keys, n_bc)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    bases, ids = hast_amd.synth_reads_host(p, 3, n_reads)
+    rng = np.random.default_rng(L)
+    lens = rng.integers(k - 2, L + 1, n_reads).astype(np.uint64)
+    lens[::5] = L
+    off = np.zeros(n_reads + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    rag = np.concatenate([bases[i * L:i * L + int(lens[i])] for i in range(n_reads)])
+    oc = oracle_from_keys(oracle_lib, k, keys[0], keys[1])
+    fixed_off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    exp_fixed = oracle_counts(oracle_lib, oc, bases, fixed_off, ids, n_bc)
+    exp_rag = oracle_counts(oracle_lib, oc, rag, off, ids, n_bc)
+    oracle_lib.ho_free(oc)
+    assert int(exp_fixed[0].sum()) > 0 and int(exp_rag[0].sum()) > 0
+    for geo in ("1", "0"):
+        monkeypatch.setenv("HAST_F_GEO", geo)
+        with hast_amd.Context(k) as ctx:
+            ctx.set_filter(1, 14, 6, 21)
+            ctx.table_reserve(2 * n_keys)
+            ctx.table_insert_keys(0, keys[0])
+            ctx.table_insert_keys(1, keys[1])
+            ctx.counts_resize(n_bc)
+            d_b, d_i = ctx.to_device(bases), ctx.to_device(ids)
+            ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i)
+            assert ctx.filter_mode() == 2 and ctx.filter_info()[1:4] == (14, 6, 21)
+            for a, b in zip(ctx.counts_read(n_bc), exp_fixed):
+                assert np.array_equal(a, b), (L, geo, "fixed")
+            ctx.counts_zero()
+            d_r, d_o = ctx.to_device(rag), ctx.to_device(off)
+            ctx.classify_device(d_r, rag.size, n_reads, L, d_offsets=d_o, d_barcode_ids=d_i)
+            for a, b in zip(ctx.counts_read(n_bc), exp_rag):
+                assert np.array_equal(a, b), (L, geo, "ragged")
