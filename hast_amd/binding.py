@@ -43,6 +43,8 @@ ABI_SYMBOLS = {
     "hast_ctx_minimizer": (C.c_int, [vp]),
     "hast_ctx_set_minimizer": (C.c_int, [vp, C.c_int]),
     "hast_ctx_device": (C.c_int, [vp]),
+    "hast_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
+    "hast_ctx_options": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "hast_ctx_stream": (vp, [vp]),
     "hast_stream_sync": (C.c_int, [vp, vp]),
     "hast_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
@@ -72,6 +74,7 @@ ABI_SYMBOLS = {
     "hast_counts_bind": (C.c_int, [vp, vp, C.c_size_t]),
     "hast_counts_zero": (C.c_int, [vp, vp]),
     "hast_counts_read": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+    "hast_counts_add_votes": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint32, vp]),
     "hast_counts_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
     "hast_classify_timing": (C.c_int, [vp, C.c_int]),
     "hast_classify_times": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
@@ -95,7 +98,7 @@ ABI_SYMBOLS = {
     "hast_fq_next": (C.c_int, [vp, C.POINTER(FqBlock)]),
     "hast_fq_commit": (C.c_int, [vp]),
     "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
-    "hast_get_hap": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
+    "hast_get_hap": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
     "hast_canon_kmer": (C.c_uint64, [C.c_char_p, C.c_int]),
     "hast_chop_read": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_int, u64p]),
     "hast_kmer_to_str": (None, [C.c_uint64, C.c_int, C.c_char_p]),
@@ -389,11 +392,23 @@ class Context:
         _ck(self._lib.hast_counts_zero(self._h, stream))
 
     def counts_read(self, n):
-        c0 = np.zeros(n, dtype=np.uint32)
-        c1 = np.zeros(n, dtype=np.uint32)
-        neg = np.zeros(n, dtype=np.uint32)
+        """(c0, c1, neg) as uint64 arrays: the device counts in 64-bit words (include/hast.h)."""
+        c0 = np.zeros(n, dtype=np.uint64)
+        c1 = np.zeros(n, dtype=np.uint64)
+        neg = np.zeros(n, dtype=np.uint64)
         _ck(self._lib.hast_counts_read(self._h, _ptr(c0), _ptr(c1), _ptr(neg), n))
         return c0, c1, neg
+
+    def counts_add_votes(self, d_votes, d_barcode_ids, n_reads, max_votes, stream=None):
+        _ck(self._lib.hast_counts_add_votes(self._h, C.c_void_p(d_votes), C.c_void_p(d_barcode_ids), n_reads, max_votes, stream))
+
+    def set_option(self, name, value):
+        _ck(self._lib.hast_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def options(self):
+        buf = C.create_string_buffer(512)
+        _ck(self._lib.hast_ctx_options(self._h, buf, len(buf)))
+        return buf.value.decode()
 
     # classify
     def classify_device(self, d_bases, bases_bytes, n_reads, read_len, d_offsets=None, d_barcode_ids=None,

@@ -125,26 +125,22 @@ struct Counts {                                    // host accumulators behind t
 
 void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, size_t n_known, size_t new_cap) {
     // fold what the devices have counted so far into the host sums, then (re)size the device arrays.  Several GPUs: ONE
-    // all-reduce(sum,u32) over RCCL/xGMI leaves the totals on every device (collectBarcodes + data.Add, classify.cpp:226-229,277)
+    // all-reduce(sum,u64) over RCCL/xGMI leaves the totals on every device (collectBarcodes + data.Add, classify.cpp:226-229,277)
     hast_ctx *ctx = ctxs[0];
     if (acc.device_cap) {
         if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
-        std::vector<uint32_t> a(acc.device_cap), b(acc.device_cap), c(acc.device_cap);
+        std::vector<uint64_t> a(acc.device_cap), b(acc.device_cap), c(acc.device_cap);
         CK(hast_counts_read(ctx, a.data(), b.data(), c.data(), acc.device_cap), "reading counters");
         if (acc.c0.size() < acc.device_cap) {
             acc.c0.resize(acc.device_cap);
             acc.c1.resize(acc.device_cap);
             acc.neg.resize(acc.device_cap);
         }
-        bool past_int = false;
-        for (size_t i = 0; i < acc.device_cap; i++) {
-            past_int = past_int || a[i] > 0x7FFFFFFFu || b[i] > 0x7FFFFFFFu;
+        for (size_t i = 0; i < acc.device_cap; i++) {       // (64-bit on the device and here: nothing wraps)
             acc.c0[i] += a[i];
             acc.c1[i] += b[i];
             acc.neg[i] += c[i];
         }
-        if (past_int)        // the reference's `int` counters (classify.cpp:51) overflow here: its output is undefined from this point on
-            fprintf(stderr, " WARN : a barcode has more than INT_MAX hits; the reference's counters overflow on this input\n");
     }
     (void)n_known;
     for (hast_ctx *c : ctxs) CK(hast_counts_resize(c, new_cap), "allocating counters");
@@ -277,13 +273,14 @@ int main(int argc, char **argv) {
                 }
         });
     };
-    double t_loaded = 0;
+    double t_loaded = 0, t_ctx = 0;
     if (!load_table.empty()) {
         // binary key-set cache written by --save-table (both sets, after the adaptor scrub of that run)
         int kk = 0;
         if (hast_table_file_info(load_table.c_str(), &kk, nullptr) != HAST_OK) die(2, "cannot use --load-table file");
         K = (size_t)kk;
         if (hast_ctx_create(device, kk, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+        t_ctx = now_s();
         contexts_ready();
         fprintf(stderr, "__load kmer table %s__\n", load_table.c_str());
         CK(hast_table_load(ctx, load_table.c_str(), 0.0), "loading the k-mer table");
@@ -320,6 +317,7 @@ int main(int argc, char **argv) {
         return 3;
     }
     if (hast_ctx_create(device, (int)K, &ctx) != HAST_OK) die(4, "cannot create GPU context");
+    t_ctx = now_s();
     contexts_ready();
     CK(hast_table_reserve(ctx, text_bytes[0] / (K + 1) + text_bytes[1] / (K + 1) + 2, 0.0), "allocating the k-mer table");
     for (int h = 0; h < 2; h++) {
@@ -381,6 +379,7 @@ int main(int argc, char **argv) {
         }
     }
     logtime();
+    const double t_scrubbed = now_s();
 
     // ---- processFastq (classify.cpp:238-278) for each --read, in order ------------------------
     // reader thread -> blocks of raw bytes -> t_num workers index newlines and parse records in parallel
@@ -748,6 +747,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f records_named_on_host=%llu\n",
                     t_idle, t_gpu_wait, t_names, t_commit, t_create, (unsigned long long)total_named);
     }
+    const double t_read_done = now_s();
     flush_counts(ctxs, acc, dict.size(), 1);
     const double t_classified = now_s();
     const std::vector<std::string_view> names = dict.names();
@@ -759,13 +759,17 @@ int main(int argc, char **argv) {
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
     std::string out;
     out.reserve(1 << 20);
-    char num[64];
+    char num[96];
+    bool past_int = false;
     for (uint32_t i : order) {
         const std::string_view bc = names[i];
         const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
-        int hap = hast_get_hap(bc.data(), bc.size(), (uint32_t)c0, (uint32_t)c1, n_set[0], n_set[1], w0, w1);
+        int hap = hast_get_hap(bc.data(), bc.size(), c0, c1, n_set[0], n_set[1], w0, w1);
         out.append(bc.data(), bc.size());
-        snprintf(num, sizeof(num), "\t%d\t%d\t%d\n", hap, (int)c0, (int)c1);      // `int` counters, classify.cpp:51
+        // the reference prints `int` counters (classify.cpp:51,98-100): the same digits up to INT_MAX; past it the reference's
+        // counter has overflowed (undefined behaviour there) -- the exact count is printed and the run says so once
+        past_int = past_int || c0 > 0x7FFFFFFFull || c1 > 0x7FFFFFFFull;
+        snprintf(num, sizeof(num), "\t%d\t%llu\t%llu\n", hap, (unsigned long long)c0, (unsigned long long)c1);
         out += num;
         if (out.size() > (1 << 20) - 256) {
             fwrite(out.data(), 1, out.size(), stdout);
@@ -774,6 +778,8 @@ int main(int argc, char **argv) {
     }
     fwrite(out.data(), 1, out.size(), stdout);
     fflush(stdout);
+    if (past_int)
+        fprintf(stderr, " WARN : a barcode has more than INT_MAX hits: the reference's `int` counters overflow on this input; the exact counts were printed\n");
     logtime();
     if (stats) {
         double dt = t_classified - t_loaded;
@@ -781,9 +787,19 @@ int main(int argc, char **argv) {
                 K, (unsigned long long)n_set[0], (unsigned long long)n_set[1], (unsigned long long)total_reads,
                 (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
+    if (stats) {
+        char sw[512] = "";
+        (void)hast_ctx_options(ctx, sw, sizeof(sw));          // measurement switches this context was created with (none by default)
+        fprintf(stderr, "__stats_switches__ %s\n", sw[0] ? sw : "none");
+    }
     fprintf(stderr, "__END__\n");
+    const double t_printed = now_s();
     for (hast_fq *f : done_fq) hast_fq_destroy(f);
     for (hast_names *nm : name_caches) hast_names_destroy(nm);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
+    if (stats)                 // where a run's wall time goes, phase by phase (sums to the process's own lifetime from main() on)
+        fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=%.3f total_s=%.3f\n",
+                t_ctx - t_start, t_loaded - t_ctx, t_scrubbed - t_loaded, t_read_done - t_scrubbed, t_classified - t_read_done,
+                t_printed - t_classified, now_s() - t_printed, now_s() - t_start);
     return 0;
 }

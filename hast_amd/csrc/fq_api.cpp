@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/hast.h"
@@ -78,6 +79,8 @@ struct hast_fq {
     size_t over_cap = 0;                                       // bytes of the next block a block's view may reach into
     size_t n_framed = 0;                                       // blocks whose framing has been launched
     uint64_t nl_before = 0;                                    // newlines of the current file in front of block n_framed
+    hast_status failed = HAST_OK;                              // sticky failure of the striped framing path (advance_striped)
+    std::string fail_msg;
     std::vector<uint64_t> records_per_lane;
     size_t block = 0, pad = 0, max_rec = 0;
     std::vector<Slot> slots;
@@ -139,15 +142,27 @@ static hast_names *names_of(const hast_fq *f, const Slot &s) { return f->striped
 // j + 1 that its records may reach into (there once j + 1 has been submitted, or j ends its file) and (b) the number of
 // newlines in front of it: the count of block j - 1's own bytes (a kernel of its own, queued right behind that block's
 // upload) added to the running sum of the file.  wait: block on (b) instead of giving up (hast_fq_next needs its block).
+static hast_status advance_striped_once(hast_fq *f, bool wait, size_t upto);
+// A failure on this path (an event query, a launch, a device switch) is STICKY: the stream stays failed, hast_fq_poll then says
+// "go on" so that the caller's next hast_fq_next returns the error instead of waiting for a block that will never be framed.
 static hast_status advance_striped(hast_fq *f, bool wait, size_t upto) {
+    if (f->failed != HAST_OK) return set_error(f->failed, "%s", f->fail_msg.c_str());
+    const hast_status st = advance_striped_once(f, wait, upto);
+    if (st != HAST_OK) {
+        f->failed = st;
+        f->fail_msg = hast_last_error();
+    }
+    return st;
+}
+static hast_status advance_striped_once(hast_fq *f, bool wait, size_t upto) {
     while (f->n_framed < f->n_submitted && f->n_framed < upto) {
         const size_t j = f->n_framed;
         Slot &s = f->slots[j % f->slots.size()];
         if (!s.over_ready) break;
         uint32_t phase = 0;
         int bol = 1;
-        if (s.first_of_file) f->nl_before = 0;
-        else {
+        uint64_t nl_before = 0;                       // (f->nl_before moves on only once the framing launch has succeeded)
+        if (!s.first_of_file) {
             Slot &pv = f->slots[(j - 1) % f->slots.size()];
             FQ_TRY(hipSetDevice(dev_of(f, pv)));
             if (wait) FQ_TRY(hipEventSynchronize(pv.counted));
@@ -156,10 +171,10 @@ static hast_status advance_striped(hast_fq *f, bool wait, size_t upto) {
                 if (q == hipErrorNotReady) break;
                 if (q != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
             }
-            f->nl_before += pv.h_cnt->n_nl;
+            nl_before = f->nl_before + pv.h_cnt->n_nl;
             bol = pv.last_byte == '\n';
         }
-        phase = (uint32_t)(f->nl_before & 3);
+        phase = (uint32_t)(nl_before & 3);
         FqLane &ln = f->lanes[(size_t)s.lane];
         FQ_TRY(hipSetDevice(ln.device));
         if (s.n_over) FQ_TRY(hipStreamWaitEvent(ln.parse_stream, s.over_copied, 0));
@@ -168,6 +183,7 @@ static hast_status advance_striped(hast_fq *f, bool wait, size_t upto) {
         s.k_cap = s.h_cap;
         FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, ln.parse_stream));
         FQ_TRY(hipEventRecord(s.parsed, ln.parse_stream));
+        f->nl_before = nl_before;
         f->n_framed++;
     }
     return HAST_OK;
@@ -449,7 +465,8 @@ int hast_fq_poll(hast_fq *f) {
     Slot &s = f->slots[f->n_opened % f->slots.size()];
     if (s.state != Slot::SUBMITTED) return 0;
     if (f->striped) {
-        if (advance_striped(f, false, f->n_submitted) != HAST_OK || f->n_framed <= f->n_opened) return 0;
+        if (advance_striped(f, false, f->n_submitted) != HAST_OK) return 1;      // failed for good: hast_fq_next reports it
+        if (f->n_framed <= f->n_opened) return 0;
     }
     (void)hipSetDevice(dev_of(f, s));
     return hipEventQuery(s.parsed) == hipSuccess ? 1 : 0;

@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/hast.h"
@@ -69,7 +70,7 @@ struct hast_ctx {
     uint64_t *d_slots = nullptr;
     uint32_t nbuckets = 0;
     // counters
-    uint32_t *d_counts = nullptr;
+    unsigned long long *d_counts = nullptr;  // [n_barcodes][4] = {c0, c1, neg, reserved}, 64-bit words
     size_t n_barcodes = 0;
     bool counts_owned = false;
     // small scratch
@@ -105,6 +106,12 @@ struct hast_ctx {
     int filter_exact = -1;                           // -1: exact entries where they fit (hast_common.h), 0: prints always
     int text_acgt_only = 0;                          // k-mer text lines must be upper-case A/C/G/T (hast_ctx_set_text_check)
     bool exact_env_off = false;                      // HAST_FILTER_EXACT=0 in the environment
+    // measurement switches: read from the environment ONCE, when the context is created (hast_ctx_set_option changes them on a
+    // live context); a variable that appears in a user's shell later cannot re-route a running job
+    int commit_mode = 0;                             // HAST_COMMIT: 0 by batch size, 1 = one atomic per read, 2 = partitioned
+    int kernel_geo = 1, kernel_rl = 1;               // HAST_F_GEO / HAST_F_RL = 0: the generic k_classify_f instantiations
+    size_t tile_lds = 0;                             // HAST_TILE_LDS: LDS budget of a tile (0 = default)
+    bool part_oom = false;                           // the partitioned commit's scratch did not fit once: atomics from then on
 };
 
 namespace {
@@ -115,12 +122,13 @@ size_t table_slots(const hast_ctx *c) { return (size_t)c->nbuckets * kSlotsPerBu
 // default minimizer length: w = K-m+1 consecutive windows can share a bucket line; m stays >= 16 so that
 // the minimizer space (4^m/2 = 2.1 G) is well above human-scale key counts (4e8) and buckets stay evenly
 // loaded; measured sweep in DESIGN.md
+int default_minimizer_plain(int k) { return k <= 16 ? k : std::max(16, k - 8); }
 int default_minimizer(int k) {
     if (const char *e = getenv("HAST_MINIMIZER")) {
         int v = atoi(e);
         if (v >= 1 && v <= k) return v;
     }
-    return k <= 16 ? k : std::max(16, k - 8);
+    return default_minimizer_plain(k);
 }
 
 hast_status use(hast_ctx *c) {
@@ -150,6 +158,15 @@ hast_status check_err_word(hast_ctx *c, hipStream_t s) {
     if (e & 4) return fail(HAST_ERR_FORMAT, "k-mer text: a byte other than upper-case A/C/G/T");
     if (e & 1) return fail(HAST_ERR_TABLE_FULL, "k-mer table full: reserve more keys");
     return HAST_OK;
+}
+
+// d_err[1]: raised by kernels of the (asynchronous) classification path; looked at wherever the caller waits for results
+hast_status check_classify_err(hast_ctx *c) {
+    uint32_t e = 0;
+    HIP_TRY(hipMemcpy(&e, c->d_err + 1, sizeof(e), hipMemcpyDeviceToHost));
+    if (!e) return HAST_OK;
+    HIP_TRY(hipMemset(c->d_err + 1, 0, sizeof(uint32_t)));
+    return fail(HAST_ERR_INVALID, "read offsets overlap or are not monotonic (their lengths add up to more than bases_bytes): rows were dropped");
 }
 
 SynthParams resolve(const hast_synth_params *p) {
@@ -213,6 +230,13 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     if (const char *e = getenv("HAST_FILTER_KP")) c->filter_kp = atoi(e);
     if (const char *e = getenv("HAST_FILTER_EXACT")) c->exact_env_off = atoi(e) == 0;
     if (c->exact_env_off) c->filter_exact = 0;
+    if (const char *e = getenv("HAST_COMMIT")) c->commit_mode = !strcmp(e, "atomic") ? 1 : !strcmp(e, "partition") ? 2 : 0;
+    if (const char *e = getenv("HAST_F_GEO")) c->kernel_geo = e[0] != '0';
+    if (const char *e = getenv("HAST_F_RL")) c->kernel_rl = e[0] != '0';
+    if (const char *e = getenv("HAST_TILE_LDS")) {
+        const long v = atol(e);
+        if (v >= 4096 && v <= 160 * 1024) c->tile_lds = (size_t)v;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     hast_status st = HAST_OK;
@@ -282,7 +306,7 @@ hast_stream hast_ctx_stream(const hast_ctx *c) { return c ? (hast_stream)c->stre
 hast_status hast_stream_sync(hast_ctx *c, hast_stream s) {
     if (hast_status st = use(c)) return st;
     HIP_TRY(hipStreamSynchronize(s ? (hipStream_t)s : c->stream));
-    return HAST_OK;
+    return check_classify_err(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,8 +728,8 @@ hast_status hast_counts_resize(hast_ctx *c, size_t n) {
     c->d_counts = nullptr;
     c->n_barcodes = 0;
     c->counts_owned = false;
-    size_t bytes = (n ? n : 1) * 4 * sizeof(uint32_t);
-    HIP_TRY(hipMalloc(&c->d_counts, bytes));
+    size_t bytes = (n ? n : 1) * 4 * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_counts), bytes));
     c->counts_owned = true;
     c->n_barcodes = n;
     HIP_TRY(hipMemsetAsync(c->d_counts, 0, bytes, c->stream));
@@ -713,13 +737,13 @@ hast_status hast_counts_resize(hast_ctx *c, size_t n) {
     return HAST_OK;
 }
 
-hast_status hast_counts_bind(hast_ctx *c, uint32_t *d_counts, size_t n) {
+hast_status hast_counts_bind(hast_ctx *c, uint64_t *d_counts, size_t n) {
     if (hast_status st = use(c)) return st;
     if (!d_counts) return fail(HAST_ERR_INVALID, "d_counts is null");
-    if ((uintptr_t)d_counts & 15) return fail(HAST_ERR_INVALID, "d_counts must be 16-byte aligned");
+    if ((uintptr_t)d_counts & 31) return fail(HAST_ERR_INVALID, "d_counts must be 32-byte aligned (one record = 4 x u64)");
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->counts_owned && c->d_counts) HIP_TRY(hipFree(c->d_counts));
-    c->d_counts = d_counts;
+    c->d_counts = reinterpret_cast<unsigned long long *>(d_counts);
     c->counts_owned = false;
     c->n_barcodes = n;
     return HAST_OK;
@@ -728,17 +752,18 @@ hast_status hast_counts_bind(hast_ctx *c, uint32_t *d_counts, size_t n) {
 hast_status hast_counts_zero(hast_ctx *c, hast_stream s) {
     if (hast_status st = use(c)) return st;
     if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters: call hast_counts_resize/bind");
-    HIP_TRY(hipMemsetAsync(c->d_counts, 0, c->n_barcodes * 4 * sizeof(uint32_t), s ? (hipStream_t)s : c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counts, 0, c->n_barcodes * 4 * sizeof(unsigned long long), s ? (hipStream_t)s : c->stream));
     return HAST_OK;
 }
 
-hast_status hast_counts_read(hast_ctx *c, uint32_t *c0, uint32_t *c1, uint32_t *neg, size_t n) {
+hast_status hast_counts_read(hast_ctx *c, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n) {
     if (hast_status st = use(c)) return st;
     if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters");
     if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
-    std::vector<uint32_t> h(n * 4);
+    std::vector<uint64_t> h(n * 4);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n) HIP_TRY(hipMemcpy(h.data(), c->d_counts, n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (hast_status st = check_classify_err(c)) return st;
+    if (n) HIP_TRY(hipMemcpy(h.data(), c->d_counts, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++) {
         if (c0) c0[i] = h[4 * i];
         if (c1) c1[i] = h[4 * i + 1];
@@ -762,9 +787,9 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
                 HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
             }
             const size_t nw = ctxs[0]->n_barcodes * 4;
-            for (int i = 1; i < n; i++) HIP_TRY(launch_add_u32(ctxs[0]->d_counts, ctxs[i]->d_counts, nw, ctxs[0]->stream));
+            for (int i = 1; i < n; i++) HIP_TRY(launch_add_u64(ctxs[0]->d_counts, ctxs[i]->d_counts, nw, ctxs[0]->stream));
             for (int i = 1; i < n; i++)
-                HIP_TRY(hipMemcpyAsync(ctxs[i]->d_counts, ctxs[0]->d_counts, nw * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctxs[0]->stream));
+                HIP_TRY(hipMemcpyAsync(ctxs[i]->d_counts, ctxs[0]->d_counts, nw * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctxs[0]->stream));
             HIP_TRY(hipStreamSynchronize(ctxs[0]->stream));
             return HAST_OK;
         }
@@ -811,11 +836,11 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
         it = comm_cache.emplace(devs, std::move(fresh)).first;
     }
     const std::vector<comm_t> &comms = it->second;
-    const int kUint32 = 3, kSum = 0;   // ncclUint32, ncclSum
+    const int kUint64 = 5, kSum = 0;   // ncclUint64, ncclSum (nccl.h: ncclInt64 = 4, ncclUint64 = 5)
     int rc = gstart();
     for (int i = 0; i < n && !rc; i++) {
         (void)hipSetDevice(ctxs[i]->device);
-        rc = allreduce(ctxs[i]->d_counts, ctxs[i]->d_counts, ctxs[i]->n_barcodes * 4, kUint32, kSum, comms[i], ctxs[i]->stream);
+        rc = allreduce(ctxs[i]->d_counts, ctxs[i]->d_counts, ctxs[i]->n_barcodes * 4, kUint64, kSum, comms[i], ctxs[i]->stream);
     }
     int rc2 = gend();
     for (int i = 0; i < n; i++) {
@@ -872,6 +897,36 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
 
 static constexpr uint32_t kSegWindows = 482;     // + K-1 <= 513 bases per segment row for K <= 32
 static constexpr uint32_t kLongRead = 4096;      // longer reads go through the segmented path: a row's positions must fit the 12 bits tmer_order gives them
+
+// Per-barcode bookkeeping of n_reads (vote0, vote1) pairs: one atomic per read, or -- large batches over many barcodes -- the pairs
+// partitioned by barcode range and summed in LDS (hast_kernels.hip, "partitioned commit"; hast_ctx_set_option "commit" / HAST_COMMIT
+// force either).  The partitioned path needs ~19 B of scratch per read: when HBM has no room for that the atomic path does the same
+// sums (an optional speed-up must not turn a run that fits into an error), and the context does not ask again.
+static hast_status commit_votes(hast_ctx *c, const uint32_t *d_votes, const uint32_t *d_ids, size_t n_reads, uint32_t max_votes,
+                                bool atomic_only, hipStream_t hs) {
+    const int mode = c->commit_mode;
+    if (mode != 1 && !atomic_only && !c->part_oom && commit_partition_usable(n_reads, c->n_barcodes, max_votes, mode == 2)) {
+        const size_t need = commit_partition_scratch_bytes(n_reads, c->n_barcodes, nullptr, nullptr);
+        if (c->part_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(hs));
+            if (c->d_part) HIP_TRY(hipFree(c->d_part));
+            c->d_part = nullptr;
+            c->part_bytes = 0;
+            if (hipMalloc(&c->d_part, need + need / 8) == hipSuccess) c->part_bytes = need + need / 8;
+            else {
+                (void)hipGetLastError();
+                c->d_part = nullptr;
+                c->part_oom = true;
+            }
+        }
+        if (c->d_part) {
+            HIP_TRY(launch_commit_partitioned(d_votes, d_ids, c->d_counts, c->n_barcodes, n_reads, c->d_part, hs));
+            return HAST_OK;
+        }
+    }
+    HIP_TRY(launch_commit_votes(d_votes, d_ids, c->d_counts, nullptr, n_reads, hs));
+    return HAST_OK;
+}
 
 static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bases_bytes, const uint64_t *d_offsets,
                                  const uint32_t *d_lens, const uint32_t *d_seg_read, int strict, uint32_t read_len,
@@ -945,8 +1000,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
         per_read = (size_t)(a.w64 + 1) * 8 + 8 + 8 + 4 + 4 + (size_t)a.mh_stride * 4 + (strict ? (size_t)(2 * a.w64 + 1) * 4 : 0);
         pad = (size_t)wlen * 4 + 64 + 64 + 16;
     }
-    static const size_t lds_env = [] { const char *e = getenv("HAST_TILE_LDS"); size_t v = e ? (size_t)atol(e) : 0; return v >= 4096 && v <= 160 * 1024 ? v : (size_t)0; }();
-    const size_t lds_budget = lds_env ? lds_env : (filt ? (size_t)32000 : (size_t)19968);      // 5 / 8 workgroups per CU
+    const size_t lds_budget = c->tile_lds ? c->tile_lds : (filt ? (size_t)32000 : (size_t)19968);      // 5 / 8 workgroups per CU
     const uint32_t tr_max = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, lds_budget > pad + per_read ? (lds_budget - pad) / per_read : 1));
     uint32_t tr = tr_max;
     if (a.max_pos > 0) {
@@ -975,25 +1029,12 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
     HIP_TRY(hipMemsetAsync(a.tile_queue, 0, sizeof(unsigned long long), hs));
     hipEvent_t *ev = c->t_slots ? &c->t_ev[3 * (c->t_next % c->t_slots)] : nullptr;
     if (ev) HIP_TRY(hipEventRecord(ev[0], hs));
-    HIP_TRY(filt ? launch_classify_f(a, grid, smem, hs) : launch_classify(a, grid, smem, hs));
+    HIP_TRY(filt ? launch_classify_f(a, grid, smem, (c->kernel_geo ? 1 : 0) | (c->kernel_rl ? 2 : 0), hs) : launch_classify(a, grid, smem, hs));
     if (ev) HIP_TRY(hipEventRecord(ev[1], hs));
     if (d_barcode_ids) {
         // per-barcode bookkeeping: one atomic per read, or -- large batches over many barcodes -- the pairs partitioned by barcode
         // range and summed in LDS (hast_kernels.hip, "partitioned commit"; HAST_COMMIT=atomic / partition forces either)
-        const char *ce = getenv("HAST_COMMIT");                      // (read per call: the tests switch it)
-        const int mode = !ce ? 0 : !strcmp(ce, "atomic") ? 1 : !strcmp(ce, "partition") ? 2 : 0;
-        if (mode != 1 && !d_seg_read && commit_partition_usable(n_reads, c->n_barcodes, a.max_pos, mode == 2)) {
-            const size_t need = commit_partition_scratch_bytes(n_reads, c->n_barcodes, nullptr, nullptr);
-            if (c->part_bytes < need) {
-                HIP_TRY(hipStreamSynchronize(hs));
-                if (c->d_part) HIP_TRY(hipFree(c->d_part));
-                c->d_part = nullptr;
-                c->part_bytes = 0;
-                HIP_TRY(hipMalloc(&c->d_part, need + need / 8));
-                c->part_bytes = need + need / 8;
-            }
-            HIP_TRY(launch_commit_partitioned(votes_buf, d_barcode_ids, c->d_counts, c->n_barcodes, n_reads, c->d_part, hs));
-        } else HIP_TRY(launch_commit_votes(votes_buf, d_barcode_ids, c->d_counts, nullptr, n_reads, hs));
+        if (hast_status st = commit_votes(c, votes_buf, d_barcode_ids, n_reads, a.max_pos, d_seg_read != nullptr, hs)) return st;
     }
     if (ev) {
         HIP_TRY(hipEventRecord(ev[2], hs));
@@ -1018,6 +1059,39 @@ hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t, int kp) {
     c->filter_t = t;
     c->filter_kp = kp;
     c->filter_valid = false;
+    return HAST_OK;
+}
+
+// Measurement switches of a live context (the environment is read once, in hast_ctx_create).
+hast_status hast_ctx_set_option(hast_ctx *c, const char *name, long value) {
+    if (!c || !name) return fail(HAST_ERR_INVALID, "null argument");
+    if (!strcmp(name, "commit")) {
+        if (value < 0 || value > 2) return fail(HAST_ERR_INVALID, "commit: 0 = by batch size, 1 = atomic, 2 = partitioned");
+        c->commit_mode = (int)value;
+    } else if (!strcmp(name, "kernel_geo")) c->kernel_geo = value != 0;
+    else if (!strcmp(name, "kernel_rl")) c->kernel_rl = value != 0;
+    else if (!strcmp(name, "tile_lds")) {
+        if (value && (value < 4096 || value > 160 * 1024)) return fail(HAST_ERR_INVALID, "tile_lds %ld out of [4096, 163840]", value);
+        c->tile_lds = (size_t)value;
+    } else return fail(HAST_ERR_INVALID, "unknown option %s", name);
+    return HAST_OK;
+}
+// the switches that differ from their defaults, as "name=value name=value" ("" when there are none): what --stats prints
+hast_status hast_ctx_options(const hast_ctx *c, char *out, size_t cap) {
+    if (!c || !out || !cap) return fail(HAST_ERR_INVALID, "null argument");
+    std::string s;
+    auto add = [&](const char *n, long v) { s += (s.empty() ? "" : " "); s += n; s += "=" + std::to_string(v); };
+    if (!c->use_filter) add("filter", 0);
+    if (c->filter_exact == 0) add("filter_exact", 0);
+    if (c->filter_m) add("filter_m", c->filter_m);
+    if (c->filter_t) add("filter_t", c->filter_t);
+    if (c->filter_kp) add("filter_kp", c->filter_kp);
+    if (c->commit_mode) add("commit", c->commit_mode);
+    if (!c->kernel_geo) add("kernel_geo", 0);
+    if (!c->kernel_rl) add("kernel_rl", 0);
+    if (c->tile_lds) add("tile_lds", (long)c->tile_lds);
+    if (c->m != default_minimizer_plain(c->k)) add("minimizer", c->m);
+    snprintf(out, cap, "%s", s.c_str());
     return HAST_OK;
 }
 
@@ -1053,21 +1127,22 @@ hast_status hast_filter_request_ceiling(hast_ctx *c, double *requests_per_s) {
     const int grid = c->n_cu * 8;
     const uint32_t iters = 256;                                    // 2048 x 32 groups x 1024 blocks = 67M requests = 8.6 GB
     uint32_t *d_sink = reinterpret_cast<uint32_t *>(c->d_cnt + 2);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
     float best = 0;
-    for (int rep = 0; rep < 3; ++rep) {                            // the first launch warms the TLBs
-        HIP_TRY(hipEventRecord(e0, c->stream));
-        HIP_TRY(launch_request_ceiling(c->d_filter, nblocks, iters, grid, d_sink, c->stream));
-        HIP_TRY(hipEventRecord(e1, c->stream));
-        HIP_TRY(hipEventSynchronize(e1));
+    for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {         // the first launch warms the TLBs
+        e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) e = launch_request_ceiling(c->d_filter, nblocks, iters, grid, d_sink, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (rep && (best == 0 || ms < best)) best = ms;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && rep && (best == 0 || ms < best)) best = ms;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);                             // (also on the error paths)
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(HAST_ERR_HIP, "request ceiling: %s", hipGetErrorString(e));
     *requests_per_s = (double)grid * 32.0 * 4.0 * (double)iters / ((double)best * 1e-3);
     return HAST_OK;
 }
@@ -1115,6 +1190,18 @@ hast_status hast_classify_device(hast_ctx *c, const uint8_t *d_bases, size_t bas
     return classify_rows(c, d_bases, bases_bytes, d_offsets, nullptr, nullptr, 0, read_len, d_barcode_ids, d_votes, n_reads, s);
 }
 
+// process_reads' bookkeeping alone (classify.cpp:203-208) for votes the caller holds (e.g. per-read votes kept from an earlier
+// classification, or a test's synthetic votes): barcode[0] += vote0, barcode[1] += vote1, or barcode[-1] += 1 when both are zero.
+hast_status hast_counts_add_votes(hast_ctx *c, const uint32_t *d_votes, const uint32_t *d_barcode_ids, size_t n_reads, uint32_t max_votes,
+                                  hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters: call hast_counts_resize/bind");
+    if (n_reads == 0) return HAST_OK;
+    if (!d_votes || !d_barcode_ids) return fail(HAST_ERR_INVALID, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_votes) & 7) return fail(HAST_ERR_INVALID, "d_votes must be 8-byte aligned");
+    return commit_votes(c, d_votes, d_barcode_ids, n_reads, max_votes, false, s ? (hipStream_t)s : c->stream);
+}
+
 // Reads of any length: cut into segments on the device, classify the segments, add their votes per read.
 //   strict = 1: stage-03 semantics (per-window validity), votes written to d_votes_out.
 //   strict = 0: stage-01 semantics (a read holding 'N' is skipped as a whole: found by a pre-pass, such reads get no
@@ -1146,10 +1233,12 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
     HIP_TRY(hipMemsetAsync(target, 0, n_reads * 2 * sizeof(uint32_t), hs));
     if (!strict) HIP_TRY(launch_scan_n(d_bases, d_offsets, d_lens, fixed_len, n_reads, has_n, hs));
     HIP_TRY(launch_build_segments(d_offsets, d_lens, fixed_len, n_reads, c->k, kSegWindows, seg_off, seg_len, seg_read, d_nseg,
-                                  strict ? nullptr : has_n, hs));
+                                  strict ? nullptr : has_n, (uint64_t)max_seg, (uint64_t)bases_bytes, c->d_err + 1, hs));
     // the number of segments stays on the device (no host round trip between the two kernels): the classify kernel reads it
     // from d_nseg and is launched for the most segments there can be -- every read has at least one, every further one
     // covers kSegWindows more bases -- which the table was sized for above
+    // (offsets that overlap or run backwards make the lengths add up to more: k_build_segments drops such rows and raises
+    // c->d_err[1], which hast_stream_sync / hast_counts_read / the synchronous calls report)
     if (max_seg > cap) return fail(HAST_ERR_INVALID, "segment table too small (%zu > %zu)", max_seg, cap);
     if (hast_status st = classify_rows(c, d_bases, bases_bytes, seg_off, seg_len, seg_read, strict, kSegWindows + (uint32_t)c->k - 1,
                                        nullptr, target, max_seg, hs, d_nseg))
@@ -1186,7 +1275,7 @@ hast_status hast_classify_perread(hast_ctx *c, const uint8_t *bases, const uint6
     if (hast_status st = hast_classify_perread_device(c, d_b, nbytes ? nbytes : 1, d_o, n_reads, d_v, c->stream)) return st;
     HIP_TRY(hipMemcpyAsync(votes_out, d_v, vb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return HAST_OK;
+    return check_classify_err(c);
 }
 
 static hast_status stage_reserve(hast_ctx *c, Staging &s, size_t nbytes, size_t nreads) {
@@ -1309,14 +1398,15 @@ void hast_parse_barcode(const char *head, size_t len, size_t *start, size_t *n) 
     *n = (cnt < 0 || (size_t)cnt > avail) ? avail : (size_t)cnt;
 }
 
-int hast_get_hap(const char *bc, size_t blen, uint32_t c0, uint32_t c1, uint64_t n0, uint64_t n1, double w0, double w1) {
+int hast_get_hap(const char *bc, size_t blen, uint64_t c0, uint64_t c1, uint64_t n0, uint64_t n1, double w0, double w1) {
     // classify.cpp:66-86
     if ((blen == 5 && !memcmp(bc, "0_0_0", 5)) || (blen == 3 && !memcmp(bc, "0_0", 3)) || (blen == 1 && bc[0] == '0'))
         return -1;
     if (c0 > 0 && c1 > 0) {
-        // the reference holds counts in `int` (classify.cpp:51) and converts int -> double
-        double df0 = double((int)c0) / double(n0);
-        double df1 = double((int)c1) / double(n1);
+        // the reference holds counts in `int` (classify.cpp:51) and converts int -> double: the same value up to INT_MAX; past it
+        // the reference's counter has overflowed (undefined there), here the call goes by the true count
+        double df0 = double(c0) / double(n0);
+        double df1 = double(c1) / double(n1);
         df0 *= w0;
         df1 *= w1;
         if (df0 > df1) return 0;

@@ -58,24 +58,24 @@ hipError_t launch_count_tags(const uint64_t *slots, TableGeom g, unsigned long l
 hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
 // filter front end: builds the filter from the live slots of the exact table; classify through it
 hipError_t launch_filter_build(const uint64_t *slots, TableGeom g, void *filter, FilterGeom fg, hipStream_t s);
-hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s);
+hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, int variants, hipStream_t s);
 // measurement: grid x 256 lanes, each group of 8 lanes reads 4 x iters random 128-B blocks of the filter
 hipError_t launch_request_ceiling(const void *filter, uint64_t nblocks, uint32_t iters, int grid, uint32_t *d_sink, hipStream_t s);
 size_t classify_f_queue_bytes();      // LDS the kernel needs besides the per-read arrays
 // d_offsets == nullptr: reads of fixed_len bytes back to back
 hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
                                  uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
-                                 hipStream_t s);
+                                 uint64_t cap, uint64_t bases_bytes, uint32_t *d_err, hipStream_t s);
 hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, uint8_t *d_has_n, hipStream_t s);
-hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
+hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, unsigned long long *d_counts, uint32_t *d_votes_out,
                                size_t n_reads, hipStream_t s);
 // the same bookkeeping without one atomic per read (large batches over many barcodes): pairs partitioned by barcode range in
 // LDS, bins summed in LDS, plain read-modify-writes of the counters; max_votes = the most votes a read can have (<= 255)
 bool commit_partition_usable(size_t n_reads, size_t n_barcodes, uint32_t max_votes, bool forced);
 size_t commit_partition_scratch_bytes(size_t n_reads, size_t n_barcodes, uint32_t *n_bins_out, uint32_t *cap_out);
-hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, size_t n_barcodes, size_t n_reads,
+hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, unsigned long long *d_counts, size_t n_barcodes, size_t n_reads,
                                      void *d_scratch, hipStream_t s);
-hipError_t launch_add_u32(uint32_t *d_dst, const uint32_t *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]
+hipError_t launch_add_u64(unsigned long long *d_dst, const unsigned long long *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
 hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);
 

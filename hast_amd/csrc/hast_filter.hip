@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     const uint32_t kshift = 64 - 2 * K, tshift = 64 - 2 * T;
     const uint32_t mmask = (uint32_t)kmer_mask(M);
     const uint32_t nb = a.nbuckets;
-    const uint64_t n_rows = a.n_rows_ptr ? (uint64_t)*a.n_rows_ptr : a.n_reads;
+    const uint64_t n_rows = a.n_rows_ptr ? min((uint64_t)*a.n_rows_ptr, (uint64_t)a.n_reads) : a.n_reads;   // (never past the table the host sized)
     const uint64_t n_tiles = (n_rows + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             if (a.offsets) { off = a.offsets[r0 + tid]; len = a.lens ? a.lens[r0 + tid] : a.offsets[r0 + tid + 1] - off; }
             else           { off = (r0 + tid) * (uint64_t)rlen; len = rlen; }
             if (len > rlen) len = rlen;                      // contract: read_len bounds every read
+            if (a.offsets && off > a.bases_bytes) len = 0;   // an offset outside the buffer (a caller's bug): no windows, no loads out of bounds
             s_off[tid] = off;
             s_len[tid] = (uint32_t)len;
             s_flag[tid] = 0;
@@ -566,15 +567,15 @@ static bool geo_is(const ClassifyArgs &a, int k, int m, int t, int kp) {
 }
 
 // EXACT implies one sub-bucket per window (TWO = false)
+// variants: bit 0 = instantiations with the geometry compiled in allowed, bit 1 = with the row length too (the context's switches,
+// read from the environment once when it was created)
 template <bool STRICT, bool EXACT, bool TWO>
-static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, int variants, hipStream_t s) {
     const bool fast = a.div_magic && a.div_l1g && a.div_hw;
     if (a.wide) return fast ? launch_f_t<0, true, STRICT, true, false, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, true, false, TWO>(a, grid, smem, s);
     if (!fast || a.fg.g != 4) return fast ? launch_f_t<0, true, STRICT, false, EXACT, TWO>(a, grid, smem, s) : launch_f_t<0, false, STRICT, false, EXACT, TWO>(a, grid, smem, s);
-    // the BASELINE geometries with their constants folded in (HAST_F_GEO=0 in the environment: the generic instantiations)
-    const char *ge = getenv("HAST_F_GEO"), *re = getenv("HAST_F_RL");             // (read per launch: the tests switch them)
-    const bool geo_on = !(ge && ge[0] == '0');
-    const bool rl_on = !(re && re[0] == '0');
+    // the BASELINE geometries with their constants folded in (kernel_geo = 0: the generic instantiations)
+    const bool geo_on = (variants & 1) != 0, rl_on = (variants & 2) != 0;
     if (geo_on && !STRICT && EXACT && !TWO && geo_is(a, 21, 14, 6, 21)) {
         if (rl_on && rows_are(a, 150, 21, 6)) return launch_f_t<4, true, false, false, true, false, 1, 150>(a, grid, smem, s);
         if (rl_on && rows_are(a, 100, 21, 6)) return launch_f_t<4, true, false, false, true, false, 1, 100>(a, grid, smem, s);   // stLFR PE100
@@ -595,11 +596,11 @@ static hipError_t launch_f_s(const ClassifyArgs &a, int grid, size_t smem, hipSt
     }
 }
 
-hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, hipStream_t s) {
+hipError_t launch_classify_f(const ClassifyArgs &a, int grid, size_t smem, int variants, hipStream_t s) {
     if (a.n_reads == 0) return hipSuccess;
-    if (a.fg.exact && !a.wide) return a.strict ? launch_f_s<true, true, false>(a, grid, smem, s) : launch_f_s<false, true, false>(a, grid, smem, s);
-    if (a.fg.choices == 1) return a.strict ? launch_f_s<true, false, false>(a, grid, smem, s) : launch_f_s<false, false, false>(a, grid, smem, s);
-    return a.strict ? launch_f_s<true, false, true>(a, grid, smem, s) : launch_f_s<false, false, true>(a, grid, smem, s);
+    if (a.fg.exact && !a.wide) return a.strict ? launch_f_s<true, true, false>(a, grid, smem, variants, s) : launch_f_s<false, true, false>(a, grid, smem, variants, s);
+    if (a.fg.choices == 1) return a.strict ? launch_f_s<true, false, false>(a, grid, smem, variants, s) : launch_f_s<false, false, false>(a, grid, smem, variants, s);
+    return a.strict ? launch_f_s<true, false, true>(a, grid, smem, variants, s) : launch_f_s<false, false, true>(a, grid, smem, variants, s);
 }
 
 }  // namespace hast

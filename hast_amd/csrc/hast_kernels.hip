@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
     const uint32_t W = WT ? (uint32_t)WT : (uint32_t)(K - M + 1);
     const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
     const uint32_t nb = a.nbuckets;
-    const uint64_t n_rows = a.n_rows_ptr ? (uint64_t)*a.n_rows_ptr : a.n_reads;
+    const uint64_t n_rows = a.n_rows_ptr ? min((uint64_t)*a.n_rows_ptr, (uint64_t)a.n_reads) : a.n_reads;   // (never past the table the host sized)
     const uint64_t n_tiles = (n_rows + TR - 1) / TR;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t end_addr = (base_addr + a.bases_bytes + 3) & ~(uintptr_t)3;
@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(kThreads, HAST_MINWAVES) k_classify(ClassifyAr
             if (a.offsets) { off = a.offsets[r0 + tid]; len = a.lens ? a.lens[r0 + tid] : a.offsets[r0 + tid + 1] - off; }
             else           { off = (r0 + tid) * (uint64_t)a.read_len; len = a.read_len; }
             if (len > a.read_len) len = a.read_len;          // contract: read_len bounds every read
+            if (a.offsets && off > a.bases_bytes) len = 0;   // an offset outside the buffer (a caller's bug): no windows, no loads out of bounds
             s_off[tid] = off;
             s_len[tid] = (uint32_t)len;
             s_flag[tid] = 0;
@@ -631,7 +632,7 @@ hipError_t launch_classify(const ClassifyArgs &a, int grid, size_t smem, hipStre
 // lanes write a read's rows side by side (a 20-kb read has 42).
 __global__ void __launch_bounds__(256) k_build_segments(const uint64_t *offsets, const uint32_t *lens, size_t n_reads, int k, uint32_t seg_windows,
                                                         uint64_t *seg_off, uint32_t *seg_len, uint32_t *seg_read, unsigned long long *counter,
-                                                        const uint8_t *skip, uint64_t fixed_len) {
+                                                        const uint8_t *skip, uint64_t fixed_len, uint64_t cap, uint64_t bases_bytes, uint32_t *err) {
     __shared__ unsigned long long s_off[256], s_len[256], s_first[256];
     __shared__ uint32_t s_nseg[256], s_wave[4];
     __shared__ unsigned long long s_base;
@@ -644,6 +645,9 @@ __global__ void __launch_bounds__(256) k_build_segments(const uint64_t *offsets,
     if (i < n_reads) {
         off = offsets ? offsets[i] : i * fixed_len;
         len = (skip && skip[i]) ? 0 : !offsets ? fixed_len : (lens ? (uint64_t)lens[i] : offsets[i + 1] - off);   // skipped read: no windows
+        // offsets that run backwards or past the buffer (a caller's bug) must not become rows: the read gets none and the context's
+        // error word says so (hast_stream_sync / hast_counts_read / the synchronous calls report it)
+        if (off > bases_bytes || len > bases_bytes - off) { atomicOr(err, 1u); len = 0; }
         const uint64_t nwin = len >= (uint64_t)k ? len - k + 1 : 0;
         nseg = (uint32_t)(nwin ? (nwin + seg_windows - 1) / seg_windows : 1);
     }
@@ -672,6 +676,9 @@ __global__ void __launch_bounds__(256) k_build_segments(const uint64_t *offsets,
             const uint64_t start = (uint64_t)j * seg_windows;
             const uint64_t rest = l - start;
             const uint64_t sl = rest < (uint64_t)seg_windows + k - 1 ? rest : (uint64_t)seg_windows + k - 1;
+            // reads that overlap make the lengths add up to more than the table was sized for: such rows are dropped, with the
+            // same report
+            if (first + j >= cap) { atomicOr(err, 1u); break; }
             seg_off[first + j] = o + start;
             seg_len[first + j] = (uint32_t)sl;
             seg_read[first + j] = read;
@@ -690,38 +697,42 @@ __global__ void __launch_bounds__(256) k_scan_n(const uint8_t *bases, const uint
     const bool any = __any(found);
     if (lane == 0) has_n[wave] = any ? 1 : 0;
 }
-// process_reads' bookkeeping (classify.cpp:203-208) from per-read votes: barcode[0] += vote0, barcode[1] += vote1 (one u64
-// add) or barcode[-1] += 1 when both are zero.  A workgroup takes a span of kCommitSpan consecutive reads.  Real stLFR
-// data has barcodes that own a large share of the reads ("0_0_0" = no barcode: 10-20 %), and agent-scope atomics execute
-// at the memory side on this part, so a million adds to ONE record serialise (measured inside k_classify before the
-// split: 16 barcodes -> 3x, 1 barcode -> 12x the kernel time).  Hence a small LDS cache keyed by barcode id: a barcode
-// that holds one of its two candidate slots is summed in LDS and written out at the end of every kCommitFlush reads;
-// everyone else does its one global atomic.
+// process_reads' bookkeeping (classify.cpp:203-208) from per-read votes: barcode[0] += vote0, barcode[1] += vote1, or
+// barcode[-1] += 1 when both are zero.  Counters are 64-bit words (u64 counts[n][4] = {c0, c1, neg, reserved}): the reference
+// counts in `int` (classify.cpp:51), which "0_0_0" -- 10-20 % of real stLFR reads -- can overflow; here nothing wraps and
+// nothing carries from one counter into the next, the narrowing is the caller's ("Hot barcode").
+// A workgroup takes a span of kCommitSpan consecutive reads.  Agent-scope atomics execute at the memory side on this part,
+// so a million adds to ONE record serialise (measured inside k_classify before the split: 16 barcodes -> 3x, 1 barcode ->
+// 12x the kernel time).  Hence a small LDS cache keyed by barcode id: a barcode that holds one of its two candidate slots
+// is summed in LDS and written out at the end of every kCommitFlush reads; everyone else does its own global atomics.
 constexpr int kCommitSlots = 128;              // power of two
 constexpr uint32_t kCommitSpan = 8192, kCommitFlush = 2048, kNoBarcode = 0xFFFFFFFFu;
 // n_ptr != nullptr: the list's length is only known on the device (the overflow list of the partitioned commit below)
-__global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, const uint32_t *barcode_ids, uint32_t *counts,
+__global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, const uint32_t *barcode_ids, unsigned long long *counts,
                                                       uint32_t *votes_out, size_t n_reads_arg, const unsigned long long *n_ptr) {
     const size_t n_reads = n_ptr ? (size_t)*n_ptr : n_reads_arg;
     if ((size_t)blockIdx.x * kCommitSpan >= n_reads) return;                     // (wave-uniform)
-    __shared__ unsigned long long s_vote[kCommitSlots];
+    __shared__ unsigned long long s_v0[kCommitSlots], s_v1[kCommitSlots];
     __shared__ uint32_t s_neg[kCommitSlots], s_id[kCommitSlots];
     const uint32_t tid = threadIdx.x;
     auto flush = [&]() {
         if (tid < kCommitSlots) {
             if (s_id[tid] != kNoBarcode) {
-                uint32_t *rec = counts + 4 * (size_t)s_id[tid];
-                if (s_vote[tid]) atomicAdd(reinterpret_cast<unsigned long long *>(rec), s_vote[tid]);
-                if (s_neg[tid]) atomicAdd(rec + 2, s_neg[tid]);
+                unsigned long long *rec = counts + 4 * (size_t)s_id[tid];
+                if (s_v0[tid]) atomicAdd(rec, s_v0[tid]);
+                if (s_v1[tid]) atomicAdd(rec + 1, s_v1[tid]);
+                if (s_neg[tid]) atomicAdd(rec + 2, (unsigned long long)s_neg[tid]);
             }
             s_id[tid] = kNoBarcode;
-            s_vote[tid] = 0;
+            s_v0[tid] = 0;
+            s_v1[tid] = 0;
             s_neg[tid] = 0;
         }
     };
     if (tid < kCommitSlots) {                  // (LDS starts out undefined: never flush before this)
         s_id[tid] = kNoBarcode;
-        s_vote[tid] = 0;
+        s_v0[tid] = 0;
+        s_v1[tid] = 0;
         s_neg[tid] = 0;
     }
     __syncthreads();
@@ -733,6 +744,7 @@ __global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, con
             if (votes_out) reinterpret_cast<unsigned long long *>(votes_out)[i] = v;
             if (barcode_ids) {
                 const uint32_t id = barcode_ids[i];
+                const unsigned long long v0 = (uint32_t)v, v1 = v >> 32;
                 const uint32_t h = id * 0x9E3779B1u;
                 uint32_t slot = h >> (32 - 7);                                   // log2(kCommitSlots) = 7
                 uint32_t owner = atomicCAS(&s_id[slot], kNoBarcode, id);
@@ -741,12 +753,14 @@ __global__ void __launch_bounds__(256) k_commit_votes(const uint32_t *votes, con
                     owner = atomicCAS(&s_id[slot], kNoBarcode, id);
                 }
                 if (owner == kNoBarcode || owner == id) {
-                    if (v) atomicAdd(&s_vote[slot], v);
-                    else atomicAdd(&s_neg[slot], 1u);
+                    if (v0) atomicAdd(&s_v0[slot], v0);
+                    if (v1) atomicAdd(&s_v1[slot], v1);
+                    if (!v) atomicAdd(&s_neg[slot], 1u);
                 } else {
-                    uint32_t *rec = counts + 4 * (size_t)id;
-                    if (v) atomicAdd(reinterpret_cast<unsigned long long *>(rec), v);
-                    else atomicAdd(rec + 2, 1u);
+                    unsigned long long *rec = counts + 4 * (size_t)id;
+                    if (v0) atomicAdd(rec, v0);
+                    if (v1) atomicAdd(rec + 1, v1);
+                    if (!v) atomicAdd(rec + 2, 1ull);
                 }
             }
         }
@@ -870,10 +884,10 @@ __global__ void __launch_bounds__(kPartThreads) k_commit_partition(const unsigne
 // one workgroup per bin: sum its records in LDS, then add the sums to the bin's counters (nobody else touches them in this kernel)
 constexpr int kBinThreads = 1024;
 __global__ void __launch_bounds__(kBinThreads) k_commit_bins(const uint32_t *bin_recs, const uint32_t *bin_fill, const uint32_t *bin_valid, uint32_t cap,
-                                                     uint32_t span_bits, uint32_t *counts, size_t n_barcodes) {
+                                                     uint32_t span_bits, unsigned long long *counts, size_t n_barcodes) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t kPartSpanBits = span_bits, kPartSpan = 1u << span_bits;
-    unsigned long long *s_vote = reinterpret_cast<unsigned long long *>(smem);   // [kPartSpan] {c0, c1}
+    unsigned long long *s_vote = reinterpret_cast<unsigned long long *>(smem);   // [kPartSpan] {c0, c1}: a bin holds <= cap records of <= 255 votes, cap * 255 < 2^32 (commit_partition_usable)
     uint32_t *s_neg = reinterpret_cast<uint32_t *>(s_vote + kPartSpan);          // [kPartSpan]
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t fill = bin_fill[b], valid = bin_valid[b];
@@ -896,13 +910,15 @@ __global__ void __launch_bounds__(kBinThreads) k_commit_bins(const uint32_t *bin
     for (uint32_t j = tid; j < kPartSpan && first + j < n_barcodes; j += kBinThreads) {
         const unsigned long long v = s_vote[j];
         const uint32_t g = s_neg[j];
-        if (v | g) {
-            uint4 *rec = reinterpret_cast<uint4 *>(counts + 4 * (first + j));
-            uint4 c = *rec;
-            c.x += (uint32_t)v;
-            c.y += (uint32_t)(v >> 32);
-            c.z += g;
-            *rec = c;
+        if (v | g) {                                                             // 64-bit counters: no wrap, no carry between them
+            unsigned long long *rec = counts + 4 * (first + j);
+            if (v) {
+                ulonglong2 c = *reinterpret_cast<ulonglong2 *>(rec);
+                c.x += (uint32_t)v;
+                c.y += v >> 32;
+                *reinterpret_cast<ulonglong2 *>(rec) = c;
+            }
+            if (g) rec[2] += g;
         }
     }
 }
@@ -928,9 +944,10 @@ bool commit_partition_usable(size_t n_reads, size_t n_barcodes, uint32_t max_vot
     uint32_t n_bins, cap;
     (void)commit_partition_scratch_bytes(n_reads, n_barcodes, &n_bins, &cap);
     if (max_votes > 255 || n_bins < 1 || n_bins > kPartMaxBins || n_reads < 1 || n_reads >= (1ull << 31)) return false;
+    if ((uint64_t)cap * 255u >= (1ull << 32)) return false;                  // a bin's sums are 32 + 32 bits in LDS
     return forced || (n_bins >= 128 && n_reads >= (1u << 21));
 }
-hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, size_t n_barcodes, size_t n_reads,
+hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, unsigned long long *d_counts, size_t n_barcodes, size_t n_reads,
                                      void *d_scratch, hipStream_t s) {
     uint32_t n_bins, cap;
     (void)commit_partition_scratch_bytes(n_reads, n_barcodes, &n_bins, &cap);
@@ -972,7 +989,7 @@ hipError_t launch_scan_n(const uint8_t *d_bases, const uint64_t *d_offsets, cons
     hipLaunchKernelGGL(k_scan_n, dim3((unsigned)((n_reads * 64 + 255) / 256)), dim3(256), 0, s, d_bases, d_offsets, d_lens, n_reads, d_has_n, fixed_len);
     return hipGetLastError();
 }
-hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, uint32_t *d_counts, uint32_t *d_votes_out,
+hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcode_ids, unsigned long long *d_counts, uint32_t *d_votes_out,
                                size_t n_reads, hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_commit_votes, dim3((unsigned)((n_reads + kCommitSpan - 1) / kCommitSpan)), dim3(256), 0, s, d_votes, d_barcode_ids,
@@ -982,19 +999,19 @@ hipError_t launch_commit_votes(const uint32_t *d_votes, const uint32_t *d_barcod
 
 hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_lens, uint64_t fixed_len, size_t n_reads, int k, uint32_t seg_windows, uint64_t *seg_off,
                                  uint32_t *seg_len, uint32_t *seg_read, unsigned long long *d_counter, const uint8_t *d_skip,
-                                 hipStream_t s) {
+                                 uint64_t cap, uint64_t bases_bytes, uint32_t *d_err, hipStream_t s) {
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_segments, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_offsets, d_lens, n_reads, k,
-                       seg_windows, seg_off, seg_len, seg_read, d_counter, d_skip, fixed_len);
+                       seg_windows, seg_off, seg_len, seg_read, d_counter, d_skip, fixed_len, cap, bases_bytes, d_err);
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) k_add_u32(uint32_t *dst, const uint32_t *src, size_t n) {
+__global__ void __launch_bounds__(256) k_add_u64(unsigned long long *dst, const unsigned long long *src, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
-hipError_t launch_add_u32(uint32_t *d_dst, const uint32_t *d_src, size_t n, hipStream_t s) {
+hipError_t launch_add_u64(unsigned long long *d_dst, const unsigned long long *d_src, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_add_u32, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_dst, d_src, n);
+    hipLaunchKernelGGL(k_add_u64, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_dst, d_src, n);
     return hipGetLastError();
 }
 

@@ -58,8 +58,9 @@ int main(int argc, char **argv) {
         }
     }
     for (const auto &kv : sum) {
-        int hap = hast_get_hap(kv.first.data(), kv.first.size(), (uint32_t)kv.second.first, (uint32_t)kv.second.second, n0, n1, w0, w1);
-        printf("%s\t%d\t%d\t%d\n", kv.first.c_str(), hap, (int)kv.second.first, (int)kv.second.second);
+        // 64-bit sums: shards whose totals pass INT_MAX (classify.cpp:51 counts in `int`) print the exact count, as classify does
+        int hap = hast_get_hap(kv.first.data(), kv.first.size(), (uint64_t)kv.second.first, (uint64_t)kv.second.second, n0, n1, w0, w1);
+        printf("%s\t%d\t%lld\t%lld\n", kv.first.c_str(), hap, kv.second.first, kv.second.second);
     }
     return 0;
 }

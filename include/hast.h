@@ -60,6 +60,13 @@ int         hast_ctx_k(const hast_ctx *);
 int         hast_ctx_minimizer(const hast_ctx *);
 hast_status hast_ctx_set_minimizer(hast_ctx *, int m);
 int         hast_ctx_device(const hast_ctx *);
+/* Measurement switches.  The environment is read ONCE, when a context is created (HAST_CLASSIFY, HAST_FILTER_*, HAST_COMMIT,
+ * HAST_F_GEO, HAST_F_RL, HAST_TILE_LDS, HAST_MINIMIZER); results never depend on them.  hast_ctx_set_option changes one on a live
+ * context: "commit" 0 = by batch size / 1 = one atomic per read / 2 = partitioned; "kernel_geo", "kernel_rl" 0 = the generic
+ * k_classify_f instantiations instead of the ones with the BASELINE geometry / row length compiled in; "tile_lds" bytes (0 =
+ * default).  hast_ctx_options writes the switches that differ from their defaults as "name=value ..." ("" = none). */
+hast_status hast_ctx_set_option(hast_ctx *, const char *name, long value);
+hast_status hast_ctx_options(const hast_ctx *, char *out, size_t cap);
 hast_stream hast_ctx_stream(const hast_ctx *);
 hast_status hast_stream_sync(hast_ctx *, hast_stream);
 
@@ -151,20 +158,30 @@ hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, int
 hast_status hast_filter_request_ceiling(hast_ctx *, double *requests_per_s);
 
 /* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
- * Device layout: uint32 counts[n_barcodes][4] = { c0, c1, neg, reserved }:
+ * Device layout: uint64 counts[n_barcodes][4] = { c0, c1, neg, reserved } (32-byte records):
  *   c0/c1 = sum of per-read votes for key 0/1 (classify.cpp:203-206), neg = key -1 (:191,:207-208).
  * A barcode was "seen" (gets an output row, classify.cpp:94) iff c0|c1|neg != 0.
- * A read's two votes are added with one 64-bit atomic, so a c0 that passes 2^32 between two read-backs would carry into c1
- * (large device-resident batches over many barcodes take a partitioned path instead -- pairs grouped by barcode range and summed
- * in LDS, plain 32-bit adds, no carry; HAST_COMMIT=atomic|partition forces either; same sums).
- * The reference counts in `int` (classify.cpp:51): parity is undefined past INT_MAX there; the classify program warns when a
- * counter it reads back is above INT_MAX. */
+ * 64-bit accumulation on the device, narrowed by whoever prints ("Hot barcode"): the reference counts in `int`
+ * (classify.cpp:51), which the no-barcode bucket "0_0_0" -- 10-20 % of real stLFR reads -- overflows on large runs (undefined
+ * there).  Here no counter wraps and none carries into its neighbour, whichever commit path a batch takes: one atomic per
+ * counter and read (k_commit_votes), or, for large device-resident batches over many barcodes, pairs grouped by barcode range and
+ * summed in LDS, then plain adds by the one workgroup that owns the range (hast_ctx_set_option "commit" / HAST_COMMIT=
+ * atomic|partition at context creation force either; same sums).  The classify program prints the exact count and warns when it
+ * is above INT_MAX.
+ * Exclusivity: while a classification of a context is in flight nothing else may update the counters it is bound to -- the
+ * partitioned path adds with plain read-modify-writes.  Two contexts (or two streams) may share a caller-owned buffer only if
+ * their classify calls do not overlap in time. */
 hast_status hast_counts_resize(hast_ctx *, size_t n_barcodes);                 /* library-owned, zeroed */
-hast_status hast_counts_bind(hast_ctx *, uint32_t *d_counts, size_t n_barcodes); /* caller-owned buffer */
+hast_status hast_counts_bind(hast_ctx *, uint64_t *d_counts, size_t n_barcodes); /* caller-owned buffer, 32-byte aligned */
 hast_status hast_counts_zero(hast_ctx *, hast_stream);
-hast_status hast_counts_read(hast_ctx *, uint32_t *c0, uint32_t *c1, uint32_t *neg, size_t n_barcodes);
+hast_status hast_counts_read(hast_ctx *, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n_barcodes);
+/* The bookkeeping alone (classify.cpp:203-208) for per-read votes the caller holds: d_votes[n_reads][2] = (vote0, vote1), 8-byte
+ * aligned; d_barcode_ids[n_reads] < n_barcodes; max_votes = an upper bound on any single vote (reads of up to 255 windows may take
+ * the partitioned path).  Asynchronous on `stream`. */
+hast_status hast_counts_add_votes(hast_ctx *, const uint32_t *d_votes, const uint32_t *d_barcode_ids, size_t n_reads,
+                                  uint32_t max_votes, hast_stream);
 /* Thread-merge of the reference (collectBarcodes/BarcodeCache::Add, classify.cpp:57-63,226-229)
- * across the GPUs of ONE process: a single in-place RCCL all-reduce(sum,u32) over the counters of
+ * across the GPUs of ONE process: a single in-place RCCL all-reduce(sum,u64) over the counters of
  * n_ctx contexts (one per device, same n_barcodes).  Contexts that all share ONE device (a logical split) are summed
  * by a kernel on that device instead; a mix of shared and distinct devices is refused.  The communicators of a device list
  * are created by the first call that names it and kept until the process ends (later calls only enqueue the all-reduce). */
@@ -293,7 +310,7 @@ hast_status hast_fq_commit(hast_fq *);
 /* parseName (classify.cpp:112-119): barcode = head[last '#' + 1 .. last '/'). */
 void     hast_parse_barcode(const char *head, size_t len, size_t *start, size_t *n);
 /* getHap (classify.cpp:66-86). */
-int      hast_get_hap(const char *barcode, size_t blen, uint32_t c0, uint32_t c1,
+int      hast_get_hap(const char *barcode, size_t blen, uint64_t c0, uint64_t c1,
                       uint64_t n_hap0, uint64_t n_hap1, double w0, double w1);
 /* Kmer::str2Kmer (kmer.h:153-166) / chopRead2Kmer (kmer.h:169-194) on the host, used for the
  * <=2x(45-K+1) adaptor keys of InitAdaptor. */

@@ -148,7 +148,7 @@ def test_committed_pmc_profiles_belong_to_these_device_sources(monkeypatch):
     import json
     import types
     import bench
-    for v in ("HAST_CLASSIFY", "HAST_FILTER_EXACT", "HAST_FILTER_M", "HAST_FILTER_T", "HAST_FILTER_KP", "HAST_TILE_LDS", "HAST_LIB", "HAST_F_GEO"):
+    for v in bench.MEASUREMENT_SWITCHES:
         monkeypatch.delenv(v, raising=False)
     sid = bench.kernel_source_id()
     for name, wl, clustered in (("pmc_traffic.json", "c3", False), ("pmc_traffic_clustered.json", "c3", True),
@@ -156,11 +156,18 @@ def test_committed_pmc_profiles_belong_to_these_device_sources(monkeypatch):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert d["kernel_source_id"] == sid, "%s was taken on other device code: run tools/gpu/collect_all.sh + profiles/summarize.py" % name
         assert d["workload"] == wl
-        args = types.SimpleNamespace(workload=wl, clustered=clustered, no_plants=False)
+        k, L = (31, 20000) if wl == "c5" else (21, 150)
+        args = types.SimpleNamespace(workload=wl, clustered=clustered, no_plants=False, k=k, read_len=L)
         R = d["batch_reads"]
         ms = d["hbm_read_requests_per_launch"] / 47e9 * 1e3           # a launch at 47 G requests/s, about what the part serves
-        rf = bench.roofline(args, R, 1.0, [ms, ms * 1.02], [2.0, 2.0], [ms + 2, ms + 3])
+        rf = bench.roofline(args, R, 1.0, [ms, ms * 1.02], [2.0, 2.0], [ms + 2, ms + 3], None, (15, 23) if wl == "c5" else (14, 21))
         assert rf["frac"] is not None and 0.3 < rf["frac"] < 1.0 and rf["request_rate"]["frac"] <= 1.0, (name, rf)
+        # the efficiency figures next to the utilisation: bytes and requests per read against the useful-bytes floor and the
+        # sampling scheme's lower bound (K = 21: 1190 B and 17.7 requests per 150-bp read)
+        us = rf["useful"]
+        assert us["floor_bytes_per_read"] == L + (L - k + 1) * 8 and 0 < us["frac_of_floor"] < 1 and 0 < us["frac_of_scheme_bound"] < 1, us
+        if wl != "c5":
+            assert us["scheme_bound_requests_per_read"] == pytest.approx(130 * 3 / 22)
     monkeypatch.setenv("HAST_FILTER_EXACT", "0")
-    rf = bench.roofline(types.SimpleNamespace(workload="c3", clustered=False, no_plants=False), 48_000_000, 1.0, [25.0], [2.0], [27.0])
+    rf = bench.roofline(types.SimpleNamespace(workload="c3", clustered=False, no_plants=False, k=21, read_len=150), 48_000_000, 1.0, [25.0], [2.0], [27.0])
     assert rf["frac"] is None and "HAST_FILTER_EXACT" in rf["traffic_source"]

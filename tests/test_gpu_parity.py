@@ -1106,8 +1106,8 @@ def test_kernel_timing_ring(built):
 @pytest.mark.parametrize("n_bc,hot", [(300, 0.0), (100_000, 0.0), (3_000_000, 0.0), (100_000, 0.4), (2_000_000, 0.9)])
 def test_partitioned_commit_equals_atomic_commit_and_oracle(built, oracle_lib, monkeypatch, n_bc, hot):
     """The per-barcode bookkeeping (classify.cpp:203-208) two ways: one memory-side atomic per read (k_commit_votes) and the
-    partitioned commit of large batches (pairs grouped by barcode range in LDS, bins summed in LDS, plain adds; HAST_COMMIT
-    forces either).  hot: share of the reads that belong to ONE barcode (real stLFR data: "0_0_0" owns 10-20 %) -- its bin
+    partitioned commit of large batches (pairs grouped by barcode range in LDS, bins summed in LDS, plain adds; the context
+    option "commit" -- HAST_COMMIT in the environment when the context is created -- forces either).  hot: share of the reads that belong to ONE barcode (real stLFR data: "0_0_0" owns 10-20 %) -- its bin
     overflows and the rest goes through the overflow list.  All three counters of every barcode == oracle, both ways."""
     k, L, n_keys, n_reads = 21, 150, 20000, 300_000
     p = make_params(k, L, n_keys, n_bc)
@@ -1128,8 +1128,10 @@ def test_partitioned_commit_equals_atomic_commit_and_oracle(built, oracle_lib, m
         ctx.table_insert_keys(1, keys[1])
         ctx.counts_resize(n_bc)
         d_b, d_i = ctx.to_device(bases), ctx.to_device(ids)
+        assert ctx.options() == ""
         for mode in ("partition", "atomic", "partition"):
-            monkeypatch.setenv("HAST_COMMIT", mode)
+            ctx.set_option("commit", {"atomic": 1, "partition": 2}[mode])
+            assert ctx.options() == "commit=%d" % {"atomic": 1, "partition": 2}[mode]
             ctx.counts_zero()
             ctx.classify_device(d_b, bases.size, n_reads, L, d_barcode_ids=d_i)
             # twice into the same counters: the sums add up (plain adds of the partitioned path must not lose the first round)
@@ -1137,6 +1139,72 @@ def test_partitioned_commit_equals_atomic_commit_and_oracle(built, oracle_lib, m
             got = ctx.counts_read(n_bc)
             for a, b in zip(got, exp):
                 assert np.array_equal(a, 2 * b), (mode, n_bc, hot)
+
+
+@pytest.mark.parametrize("first", ["partition", "atomic"])
+def test_counters_past_2_to_32_both_commit_paths(built, first):
+    """SURVEY section 7 "Hot barcode": the no-barcode bucket "0_0_0" owns 10-20 % of real stLFR reads and the reference's `int`
+    counters (classify.cpp:51) overflow on it.  The device counts in 64-bit words: synthetic per-read votes (hast_counts_add_votes:
+    the bookkeeping of classify.cpp:203-208 alone) drive ONE barcode past 2^32 in c0 AND c1 through both commit paths -- one atomic
+    per counter and read, and the partitioned path whose bin for that barcode overflows into the overflow list -- and both must
+    give the exact sums: no wrap, no carry of c0 into c1, neighbours untouched."""
+    n_bc, n, hot, rounds = 300_000, 4_000_000, 123_457, 7
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, n_bc, n, dtype=np.uint32)
+    ids[rng.random(n) < 0.8] = hot                                   # 80 % of the reads belong to one barcode
+    votes = rng.integers(0, 256, (n, 2), dtype=np.uint32)            # <= 255 per read: the partitioned path is usable
+    votes[rng.random(n) < 0.25] = 0                                  # reads without a hit: neg += 1
+    votes[::7, 1] = 0
+    e0 = np.zeros(n_bc, np.uint64); e1 = np.zeros(n_bc, np.uint64); eneg = np.zeros(n_bc, np.uint64)
+    np.add.at(e0, ids, votes[:, 0].astype(np.uint64))
+    np.add.at(e1, ids, votes[:, 1].astype(np.uint64))
+    np.add.at(eneg, ids, ((votes[:, 0] | votes[:, 1]) == 0).astype(np.uint64))
+    assert rounds * int(e0[hot]) > 2**32 and rounds * int(e1[hot]) > 2**32 and int(e0[hot]) < 2**32
+    with hast_amd.Context(21) as ctx:
+        ctx.counts_resize(n_bc)
+        d_v, d_i = ctx.to_device(votes), ctx.to_device(ids)
+        modes = [first, "atomic" if first == "partition" else "partition"]
+        for r in range(rounds):
+            ctx.set_option("commit", {"atomic": 1, "partition": 2}[modes[r % 2]])
+            ctx.counts_add_votes(d_v, d_i, n, 255)
+        ctx.sync()
+        c0, c1, neg = ctx.counts_read(n_bc)
+    assert c0.dtype == np.uint64
+    assert int(c0[hot]) == rounds * int(e0[hot]) > 2**32 and int(c1[hot]) == rounds * int(e1[hot]) > 2**32
+    assert np.array_equal(c0, rounds * e0) and np.array_equal(c1, rounds * e1) and np.array_equal(neg, rounds * eneg)
+
+
+def test_offsets_that_run_backwards_are_an_error_not_garbage(built):
+    """Caller-supplied read offsets whose lengths add up to more than the buffer (overlapping or non-monotonic: a caller's bug)
+    used to overflow the device-side segment table silently; now such reads get no rows and the next call that waits for results
+    says so."""
+    k = 21
+    p = make_params(k, 150, 5000, 1)
+    rng = np.random.default_rng(1)
+    bases = rng.choice(np.frombuffer(b"ACGT", np.uint8), 60000)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(10000)
+        ctx.synth_table_build(p)
+        good = np.array([0, 20000, 40000, 60000], np.uint64)
+        v = ctx.classify_perread(bases, good)                                   # fine
+        assert v.shape == (3, 2)
+        for bad in (np.array([0, 30000, 10, 60000], np.uint64),                 # runs backwards: a "length" of 2^64 - 29990
+                    np.array([0, 20000, 40000, 70000], np.uint64)):             # ends past the buffer
+            d_b, d_o, d_v = ctx.to_device(bases), ctx.to_device(bad), ctx.alloc(3 * 8)
+            ctx.classify_perread_device(d_b, bases.size, d_o, 3, d_v)
+            with pytest.raises(hast_amd.HastError) as ei:
+                ctx.sync()
+            assert "offsets" in str(ei.value)
+            ctx.sync()                                                          # reported once
+        assert np.array_equal(ctx.classify_perread(bases, good), v)             # the context still works
+
+
+def test_get_hap_and_cli_rows_past_int_max(built):
+    """getHap (classify.cpp:66-86) on counts the reference's `int` cannot hold: the call goes by the true 64-bit counts."""
+    n = 1000
+    assert hast_amd.get_hap(b"1_2_3", 2**32 + 5, 7, n, n) == 0 and hast_amd.get_hap(b"1_2_3", 7, 2**33, n, n) == 1
+    assert hast_amd.get_hap(b"1_2_3", 2**32, 2**32, n, n) == -1 and hast_amd.get_hap(b"0_0_0", 2**40, 1, n, n) == -1
+    assert hast_amd.get_hap(b"1_2_3", 2**32, 0, n, n) == 0          # (a wrapped 32-bit c0 would read 0 here: "no hit at all")
 
 
 @pytest.mark.parametrize("L", [100, 150, 151])
@@ -1160,9 +1228,17 @@ def test_kernels_with_geometry_and_row_length_compiled_in_vs_oracle(built, oracl
     exp_rag = oracle_counts(oracle_lib, oc, rag, off, ids, n_bc)
     oracle_lib.ho_free(oc)
     assert int(exp_fixed[0].sum()) > 0 and int(exp_rag[0].sum()) > 0
-    for geo in ("1", "0"):
-        monkeypatch.setenv("HAST_F_GEO", geo)
+    for geo in ("1", "0", "rl0"):
+        # the switches are read from the environment ONCE, when the context is created (a variable that appears later cannot
+        # re-route a live context), or set on the context itself
+        monkeypatch.delenv("HAST_F_GEO", raising=False)
+        if geo != "rl0":
+            monkeypatch.setenv("HAST_F_GEO", geo)
         with hast_amd.Context(k) as ctx:
+            monkeypatch.setenv("HAST_F_GEO", "1")                       # too late for this context
+            if geo == "rl0":
+                ctx.set_option("kernel_rl", 0)
+            assert ctx.options() == {"1": "", "0": "kernel_geo=0", "rl0": "kernel_rl=0"}[geo]
             ctx.set_filter(1, 14, 6, 21)
             ctx.table_reserve(2 * n_keys)
             ctx.table_insert_keys(0, keys[0])
