@@ -1148,7 +1148,7 @@ def test_counters_past_2_to_32_both_commit_paths(built, first):
     the bookkeeping of classify.cpp:203-208 alone) drive ONE barcode past 2^32 in c0 AND c1 through both commit paths -- one atomic
     per counter and read, and the partitioned path whose bin for that barcode overflows into the overflow list -- and both must
     give the exact sums: no wrap, no carry of c0 into c1, neighbours untouched."""
-    n_bc, n, hot, rounds = 300_000, 4_000_000, 123_457, 7
+    n_bc, n, hot, rounds = 300_000, 4_000_000, 123_457, 20
     rng = np.random.default_rng(5)
     ids = rng.integers(0, n_bc, n, dtype=np.uint32)
     ids[rng.random(n) < 0.8] = hot                                   # 80 % of the reads belong to one barcode

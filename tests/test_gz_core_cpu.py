@@ -1,0 +1,120 @@
+"""Host-only test of the DEVICE inflate's per-lane code and host logic (hast_amd/csrc/gz_core.h, gz_chain.h), driven by
+tests/native/test_gz_core.cpp with plain loops standing in for the kernels: the same corpus as the host decoders' test
+(every block type, member layout, header field, flush point, level and window size), chunks from 64 bytes to 1 MB (chunks
+in which no block starts, blocks larger than a chunk, stored / fixed blocks at chunk borders, members that end inside a
+chunk), symbol buffers too small for a block, candidates arriving segment by segment -- same bytes as zlib, CRC-32 and ISIZE
+of every member checked by slices + GF(2) operators as the CRC kernel does it; truncated and damaged input are errors.
+Built with ASAN + UBSAN.  (tests/test_gz_gpu.py runs the same corpus through the kernels themselves.)"""
+import gzip
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+from tests.conftest import ROOT
+from tests.test_inflate_cpu import CASES, FQ, fastq, member
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("gzcore") / "test_gz_core"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "test_gz_core.cpp")], check=True)
+    return str(exe)
+
+
+def inflate_all(blob):
+    """zlib's view of a gzip file: members one after the other, trailing garbage ignored (as gzread does)"""
+    out, rest = b"", blob
+    while rest[:2] == b"\x1f\x8b":
+        d = zlib.decompressobj(31)
+        out += d.decompress(rest)
+        rest = d.unused_data
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n not in ("not_gzip",)))
+def test_same_bytes_as_zlib(driver, tmp_path, name):
+    p = tmp_path / (name + ".gz")
+    p.write_bytes(CASES[name])
+    want = inflate_all(CASES[name])
+    for chunk, seg, room in ((32768, 64, 12), (1 << 20, 2, 12), (4096, 3, 12), (700, 50, 40), (64, 1000, 100), (32768, 1, 0.5), (5000, 7, 1.0)):
+        if chunk < 1000 and len(CASES[name]) > 200_000:
+            continue
+        got = subprocess.run([driver, "-c", str(chunk), "-s", str(seg), "-r", str(room), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, (name, chunk, seg, room, got.stderr[-300:])
+        assert got.stdout == want, (name, chunk, seg, room)
+
+
+def test_not_gzip_is_refused(driver, tmp_path):
+    p = tmp_path / "plain.gz"
+    p.write_bytes(CASES["not_gzip"])
+    got = subprocess.run([driver, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 3 and b"not a gzip file" in got.stderr
+
+
+def test_big_stream_long_runs_and_many_members(driver, tmp_path):
+    rng = random.Random(9)
+    data = fastq(rng, 40_000) + b"\x00" * 3_000_000 + fastq(rng, 20_000)
+    p = tmp_path / "big.gz"
+    with gzip.open(p, "wb", compresslevel=4) as f:
+        f.write(data)
+    for chunk, room in ((32768, 12), (8192, 3)):
+        got = subprocess.run([driver, "-c", str(chunk), "-r", str(room), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0 and got.stdout == data, got.stderr[-300:]
+    data, blob = b"", b""
+    for _ in range(2000):
+        d = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 400)))
+        data += d
+        blob += member(d, rng.choice([0, 1, 6, 9]))
+    p = tmp_path / "many.gz"
+    p.write_bytes(blob)
+    for chunk in (32768, 300):
+        got = subprocess.run([driver, "-c", str(chunk), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0 and got.stdout == data, got.stderr[-300:]
+
+
+def test_random_streams_with_flush_points(driver, tmp_path):
+    """sync / full flushes at random places (the empty stored blocks pigz and bgzip write between their pieces), random levels
+    and strategies: a chunk's decode runs on through stored / fixed / final blocks behind its stop, which no search can find"""
+    rng = random.Random(11)
+    for it in range(12):
+        data, blob = b"", b""
+        for _ in range(rng.randint(1, 6)):
+            c = zlib.compressobj(rng.choice([1, 4, 6, 9]), zlib.DEFLATED, 31, 9, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED]))
+            for _ in range(rng.randint(1, 30)):
+                kind = rng.random()
+                d = (bytes(rng.choice(b"ACGTN\n") for _ in range(rng.randint(0, 3000))) if kind < 0.6 else
+                     bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 500))) if kind < 0.8 else b"A" * rng.randint(0, 70000))
+                data += d
+                blob += c.compress(d)
+                if rng.random() < 0.5:
+                    blob += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            blob += c.flush()
+        p = tmp_path / ("r%d.gz" % it)
+        p.write_bytes(blob)
+        for chunk, seg in ((32768, 64), (2048, 5), (300, 11)):
+            r = subprocess.run([driver, "-c", str(chunk), "-s", str(seg), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0 and r.stdout == data, (it, chunk, seg, r.stderr[-300:])
+
+
+def test_truncated_and_damaged_input_is_an_error_never_other_data(driver, tmp_path):
+    blob = member(FQ[:400_000])
+    rng = random.Random(3)
+    want = FQ[:400_000]
+    for cut in (len(blob) - 1, len(blob) - 5, len(blob) - 9, len(blob) // 2, 11, 3):
+        p = tmp_path / "cut.gz"
+        p.write_bytes(blob[:cut])
+        r = subprocess.run([driver, "-c", "8192", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 3, cut
+        assert want.startswith(r.stdout)                     # what was delivered before the error is a prefix of the real data
+    for _ in range(25):
+        b = bytearray(blob)
+        at = rng.randrange(10, len(b) - 8)
+        b[at] ^= 1 << rng.randrange(8)
+        p = tmp_path / "flip.gz"
+        p.write_bytes(bytes(b))
+        r = subprocess.run([driver, "-c", "8192", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 3 or r.stdout == want, at    # (a flip in a stored block's padding bits changes nothing)
