@@ -8,4 +8,4 @@ every call needs the shared library, and every compute call needs a GPU.
 from .binding import (HastError, Context, SynthParams, lib, lib_path, classify_exe, classify_read_exe, build,  # noqa: F401
                       parse_barcode, get_hap, canon_kmer, chop_read, synth_keys_host, synth_reads_host,
                       ABI_SYMBOLS, B_ALG_PER_READ, KmerCounter, KcSynth, KC_HISTO_HIGH, kc_find_bounds, kc_synth_host,
-                      unshared_kmers_exe)
+                      unshared_kmers_exe, GzReader, GzStats)

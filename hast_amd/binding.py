@@ -10,7 +10,7 @@ _LIB = None
 
 u8p, u32p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
 
-STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "TABLE_FULL", 6: "FORMAT", 7: "RCCL", 8: "IO"}
+STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "TABLE_FULL", 6: "FORMAT", 7: "RCCL", 8: "IO", 9: "UNSUPPORTED"}
 
 
 class SynthParams(C.Structure):
@@ -29,6 +29,11 @@ class FqBlock(C.Structure):
                 ("bytes", C.POINTER(C.c_uint8)), ("bc_pos", C.POINTER(C.c_uint32)), ("bc_len", C.POINTER(C.c_uint32)),
                 ("bc_text", C.POINTER(C.c_uint8)), ("ids", C.POINTER(C.c_uint32)), ("unknown", C.POINTER(C.c_uint32)),
                 ("n_unknown", C.c_uint64)]
+
+
+class GzStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("compressed_bytes", "out_bytes", "chunks", "accepted", "followup_jobs", "followup_rounds", "followup_accepted", "members")] + \
+               [(n, C.c_double) for n in ("decode_s", "windows_crc_s", "wait_upload_s", "wait_consumer_s", "wait_decode_s")]
 
 
 KC_HISTO_HIGH = 10000
@@ -94,9 +99,17 @@ ABI_SYMBOLS = {
     "hast_fq_block_bytes": (C.c_size_t, [vp]),
     "hast_fq_acquire": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8))]),
     "hast_fq_submit": (C.c_int, [vp, C.c_size_t, C.c_int]),
+    "hast_fq_device_block": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+    "hast_fq_submit_device": (C.c_int, [vp, C.c_size_t, C.c_int]),
+    "hast_fq_block_host_bytes": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8))]),
     "hast_fq_poll": (C.c_int, [vp]),
     "hast_fq_next": (C.c_int, [vp, C.POINTER(FqBlock)]),
     "hast_fq_commit": (C.c_int, [vp]),
+    "hast_gz_open": (C.c_int, [vp, C.c_char_p, C.POINTER(vp)]),
+    "hast_gz_open_ex": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(vp)]),
+    "hast_gz_read_device": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
+    "hast_gz_get_stats": (C.c_int, [vp, C.POINTER(GzStats)]),
+    "hast_gz_close": (None, [vp]),
     "hast_parse_barcode": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hast_get_hap": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
     "hast_canon_kmer": (C.c_uint64, [C.c_char_p, C.c_int]),
@@ -470,6 +483,63 @@ def kc_synth_host(p: KcSynth, parent, first, n_reads):
     out = np.empty(n_reads * (p.read_len + 1), dtype=np.uint8)
     _ck(lib().hast_kc_synth_host(C.byref(p), parent, first, n_reads, _ptr(out)))
     return out
+
+
+class GzReader:
+    """hast_gz: one .gz file inflated on the GPU (include/hast.h); read() returns the next bytes as a numpy array (test view:
+    the product hands the bytes to the FASTQ framer on the device)."""
+
+    def __init__(self, ctx, path, chunk_bytes=0, chunks_per_pass=0, room=0.0):
+        self._lib = lib()
+        self._ctx = ctx
+        h = C.c_void_p()
+        _ck(self._lib.hast_gz_open_ex(ctx._h, os.fsencode(path), chunk_bytes, chunks_per_pass, room, C.byref(h)))
+        self._h = h
+        self._d = None
+        self._cap = 0
+
+    def read_device(self, d_dst, cap, stream=None):
+        n = C.c_size_t()
+        _ck(self._lib.hast_gz_read_device(self._h, C.c_void_p(d_dst), cap, C.byref(n), stream))
+        return n.value
+
+    def read(self, cap):
+        if self._cap < cap:
+            if self._d:
+                self._ctx.free(self._d)
+            self._d = self._ctx.alloc(cap + 16)
+            self._cap = cap
+        n = self.read_device(self._d, cap)
+        self._ctx.sync()
+        return self._ctx.to_host(self._d, (n,), np.uint8) if n else np.zeros(0, np.uint8)
+
+    def read_all(self, piece=1 << 22):
+        parts = []
+        while True:
+            a = self.read(piece)
+            if a.size == 0:
+                break
+            parts.append(a)
+        return np.concatenate(parts).tobytes() if parts else b""
+
+    def stats(self):
+        st = GzStats()
+        _ck(self._lib.hast_gz_get_stats(self._h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in GzStats._fields_}
+
+    def close(self):
+        if self._h:
+            self._lib.hast_gz_close(self._h)
+            self._h = None
+        if self._d:
+            self._ctx.free(self._d)
+            self._d = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class KmerCounter:

@@ -237,13 +237,34 @@ int main(int argc, char **argv) {
     // The FASTQ streams of the first files (pinned staging + device buffers: ~0.1 s of page pinning) are set up by a thread
     // of their own while this one reads the k-mer files and builds the table.
     std::vector<hast_fq *> pre_fq, done_fq;
+    std::vector<hast_gz *> done_gz;
     std::vector<hast_names *> name_caches;                 // per GPU: device-side cache barcode text -> id
     std::thread pre_thread;
     std::string pre_error;
     // several GPUs: the blocks of every file go to all of them in turn (a striped stream); HAST_DEAL=files deals whole files
     bool stripe = false;
+    // .gz inputs are inflated ON THE GPU (hast_gz_*: the compressed bytes cross PCIe, the framer reads the inflated bytes where they
+    // lie) when they are ordinary gzip files; blocked gzip (BGZF: thousands of one-block members, which the host inflates side by
+    // side), pipes and ".gz" files that are not gzip stay with the host decoders, as does everything under HAST_INFLATE=host|zlib
+    std::vector<char> dev_gz(read.size(), 0);
+    {
+        const char *which = getenv("HAST_INFLATE");
+        const bool allow = !host_parse && (!which || !strcmp(which, "device"));
+        for (size_t i = 0; allow && i < read.size(); i++) {
+            const std::string &r = read[i];
+            struct stat sb;
+            if (r.size() <= 3 || r.compare(r.size() - 3, 3, ".gz") != 0 || stat(r.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
+            FILE *fp = fopen(r.c_str(), "rb");
+            if (!fp) continue;                                      // (reported where the file is opened for good)
+            unsigned char magic[2] = {0, 0};
+            const bool gzip_magic = fread(magic, 1, 2, fp) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+            rewind(fp);
+            dev_gz[i] = (gzip_magic || sb.st_size == 0) && !hast::BgzfReader::probe(fp);
+            fclose(fp);
+        }
+    }
     auto make_fq = [&](size_t file_index, hast_fq **out) -> hast_status {
-        if (stripe)
+        if (stripe && !dev_gz[file_index])
             return hast_fq_create_striped(ctxs.data(), (int)ctxs.size(), fq_cap, std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()), name_caches.data(), out);
         return hast_fq_create(ctxs[file_index % ctxs.size()], fq_cap, fq_bufs, name_caches[file_index % ctxs.size()], out);
     };
@@ -568,6 +589,8 @@ int main(int argc, char **argv) {
             std::string name;
             hast::BlockSource src;
             hast_fq *fq = nullptr;
+            hast_gz *gz = nullptr;                                 // the file is inflated on the GPU: blocks are filled there
+            hast_stream fill_stream = nullptr;
             std::thread th;
             std::mutex mu;
             std::condition_variable cv;
@@ -591,8 +614,21 @@ int main(int argc, char **argv) {
             fprintf(stderr, "__process read: %s\n", r.c_str());
             std::unique_ptr<Feed> f(new Feed());
             f->name = r;
-            if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
-            f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
+            if (dev_gz[next_file]) {
+                const hast_status gs = hast_gz_open(ctxs[next_file % ctxs.size()], r.c_str(), &f->gz);
+                if (gs == HAST_ERR_UNSUPPORTED) {                  // e.g. no room on the device: the host inflates
+                    f->gz = nullptr;
+                    dev_gz[next_file] = 0;
+                    if (stripe && next_file < pre_fq.size() && pre_fq[next_file]) {   // (a plain stream was set up for it)
+                        hast_fq_destroy(pre_fq[next_file]);
+                        pre_fq[next_file] = nullptr;
+                    }
+                } else if (gs != HAST_OK) die(2, ("cannot open " + r).c_str());
+            }
+            if (!f->gz) {
+                if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
+                f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
+            }
             const double tc0 = now_s();
             if (next_file < pre_fq.size() && pre_fq[next_file]) f->fq = pre_fq[next_file];     // set up while the table was built
             else CK(make_fq(next_file, &f->fq), "creating the FASTQ stream");
@@ -611,6 +647,11 @@ int main(int argc, char **argv) {
                     }
                     Feed::Filled fl{0, false, std::string()};
                     const double tr0 = now_s();
+                    if (fp->gz) {                                   // (buf is a DEVICE address: the translate kernel writes the block there)
+                        size_t n = 0;
+                        if (hast_gz_read_device(fp->gz, buf, cap, &n, fp->fill_stream) != HAST_OK) fl.err = hast_last_error();
+                        fl.n = n;
+                    } else
                     fl.n = fp->src.read_into(reinterpret_cast<char *>(buf), cap, fl.err);
                     if (getenv("HAST_TRACE_BLOCKS")) fprintf(stderr, "trace %s fill %.3f ms at %.4f\n", fp->name.c_str() + (fp->name.size() > 5 ? fp->name.size() - 5 : 0), (now_s() - tr0) * 1e3, now_s());
                     fl.last = fl.n < cap || !fl.err.empty();
@@ -647,6 +688,13 @@ int main(int argc, char **argv) {
             const size_t n = (size_t)b.n_records;
             // records the device-side name cache did not know (all of them without a cache): text -> id in the job's dictionary
             const size_t nu = b.unknown ? (size_t)b.n_unknown : n;
+            if (!b.bytes) {
+                // a block that was filled on the device: the host copy is fetched only when a record's barcode text did not fit the
+                // framer's 16-byte copy (longer than 15 bytes), or when there are no such copies (more records than they hold)
+                bool need = !b.bc_text;
+                for (size_t j = 0; !need && j < nu; j++) need = b.bc_text[16 * (b.unknown ? b.unknown[j] : j)] == 0xFF;
+                if (need) CK(hast_fq_block_host_bytes(f.fq, &b.bytes), "fetching a block");
+            }
             auto name_range = [&](int t, size_t lo, size_t hi_) {
                 for (size_t j = lo; j < hi_; j++) {
                     const size_t i = b.unknown ? b.unknown[j] : j;
@@ -678,6 +726,7 @@ int main(int argc, char **argv) {
                 while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq)) {
                     uint8_t *buf;
                     CK(hast_fq_acquire(f.fq, &buf), "staging a block");
+                    if (f.gz) CK(hast_fq_device_block(f.fq, &buf, &f.fill_stream), "staging a block");
                     f.held++;
                     std::lock_guard<std::mutex> g(f.mu);
                     f.empty.push_back(buf);
@@ -694,7 +743,7 @@ int main(int argc, char **argv) {
                         f.filled.pop_front();
                     }
                     if (!fl.err.empty()) die(2, (f.name + ": " + fl.err).c_str());
-                    CK(hast_fq_submit(f.fq, fl.n, fl.last ? 1 : 0), "framing a block");
+                    CK(f.gz ? hast_fq_submit_device(f.fq, fl.n, fl.last ? 1 : 0) : hast_fq_submit(f.fq, fl.n, fl.last ? 1 : 0), "framing a block");
                     if (getenv("HAST_TRACE_BLOCKS")) fprintf(stderr, "trace %s submit at %.4f\n", f.name.c_str() + (f.name.size() > 5 ? f.name.size() - 5 : 0), now_s());
                     f.submitted++;
                     if (fl.last) f.eof_acquired = true;
@@ -716,6 +765,16 @@ int main(int argc, char **argv) {
                     }
                     f.cv.notify_all();
                     f.th.join();
+                    if (f.gz) {
+                        hast_gz_stats gs;
+                        if (stats && hast_gz_get_stats(f.gz, &gs) == HAST_OK)
+                            fprintf(stderr, "__stats_gz__ file=%s compressed_bytes=%llu inflated_bytes=%llu chunks=%llu accepted=%llu followup_jobs=%llu followup_rounds=%llu members=%llu "
+                                            "decode_s=%.3f windows_crc_s=%.3f producer_waited_for_upload_s=%.3f producer_waited_for_reader_s=%.3f reader_waited_for_decode_s=%.3f\n",
+                                    f.name.c_str(), (unsigned long long)gs.compressed_bytes, (unsigned long long)gs.out_bytes, (unsigned long long)gs.chunks,
+                                    (unsigned long long)gs.accepted, (unsigned long long)gs.followup_jobs, (unsigned long long)gs.followup_rounds, (unsigned long long)gs.members,
+                                    gs.decode_s, gs.windows_crc_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s);
+                        done_gz.push_back(f.gz);
+                    }
                     done_fq.push_back(f.fq);                       // (freed after the output: unpinning costs as much as pinning)
                     logtime();
                     fprintf(stderr, "__process read done__\n");
@@ -794,6 +853,7 @@ int main(int argc, char **argv) {
     }
     fprintf(stderr, "__END__\n");
     const double t_printed = now_s();
+    for (hast_gz *z : done_gz) hast_gz_close(z);
     for (hast_fq *f : done_fq) hast_fq_destroy(f);
     for (hast_names *nm : name_caches) hast_names_destroy(nm);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);

@@ -51,6 +51,8 @@ struct Slot {
     size_t n_over = 0;                                 // bytes of the next block behind this block's own bytes
     bool over_ready = false, eof_view = false, first_of_file = false;
     uint8_t last_byte = 0;
+    bool dev_src = false;                              // the block's bytes were written on the device (hast_fq_submit_device): h_buf holds nothing
+    bool host_view = false;                            // ... until hast_fq_block_host_bytes has fetched them
 };
 }  // namespace
 
@@ -78,7 +80,9 @@ struct hast_fq {
     std::vector<FqLane> lanes;
     size_t over_cap = 0;                                       // bytes of the next block a block's view may reach into
     size_t n_framed = 0;                                       // blocks whose framing has been launched
+    size_t n_device_blocks = 0;                                // hast_fq_device_block calls (device-side blocks)
     uint64_t nl_before = 0;                                    // newlines of the current file in front of block n_framed
+    int source = 0;                                            // 0 = not decided, 1 = host blocks (hast_fq_submit), 2 = device blocks (hast_fq_submit_device)
     hast_status failed = HAST_OK;                              // sticky failure of the striped framing path (advance_striped)
     std::string fail_msg;
     std::vector<uint64_t> records_per_lane;
@@ -431,10 +435,34 @@ hast_status hast_fq_acquire(hast_fq *f, uint8_t **host_buf) {
     return HAST_OK;
 }
 
-hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
+// The bytes of the next block are written ON THE DEVICE (e.g. by hast_gz_read_device): after hast_fq_acquire, *d_block is where
+// they belong (room for hast_fq_block_bytes) and *fill_stream the stream the writes must be enqueued on -- the wait for the
+// kernels that still read this buffer's previous block is already on it.  Then hast_fq_submit_device instead of hast_fq_submit.
+hast_status hast_fq_device_block(hast_fq *f, uint8_t **d_block, hast_stream *fill_stream) {
+    if (!f || !d_block || !fill_stream) return set_error(HAST_ERR_INVALID, "null argument");
+    if (f->striped) return set_error(HAST_ERR_INVALID, "device-side blocks are not available on striped streams");
+    if (f->n_device_blocks >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_device_block without hast_fq_acquire");
+    if (f->source == 1) return set_error(HAST_ERR_INVALID, "a stream takes host blocks or device blocks, not both");
+    f->source = 2;
+    const size_t i = f->n_device_blocks;
+    const int si = (int)(i % f->slots.size());
+    Slot &s = f->slots[(size_t)si];
+    FQ_TRY(hipSetDevice(f->device));
+    // (as in hast_fq_submit: the successor slot's framing reads this buffer's old tail)
+    if (i >= f->slots.size()) FQ_TRY(hipStreamWaitEvent(f->copy_stream, f->slots[(size_t)(si + 1) % f->slots.size()].parsed, 0));
+    f->n_device_blocks++;
+    *d_block = s.d_buf + f->pad;
+    *fill_stream = (hast_stream)f->copy_stream;
+    return HAST_OK;
+}
+
+static hast_status submit_block(hast_fq *f, size_t n_bytes, int last, bool dev_src) {
     if (!f) return set_error(HAST_ERR_INVALID, "null argument");
     if (f->n_submitted >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_submit without hast_fq_acquire");
     if (n_bytes > f->block) return set_error(HAST_ERR_INVALID, "block of %zu bytes exceeds the capacity %zu", n_bytes, f->block);
+    if (dev_src ? (f->striped || f->source != 2 || f->n_device_blocks <= f->n_submitted) : f->source == 2)
+        return set_error(HAST_ERR_INVALID, dev_src ? "hast_fq_submit_device without hast_fq_device_block" : "a stream takes host blocks or device blocks, not both");
+    if (!dev_src) f->source = 1;
     if (f->striped) return submit_striped(f, n_bytes, last);
     const int si = (int)(f->n_submitted % f->slots.size());
     Slot &s = f->slots[(size_t)si];
@@ -442,10 +470,14 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     hipStream_t hs = f->parse_stream;
     s.n_bytes = n_bytes;
     s.last = last;
+    s.dev_src = dev_src;
+    s.host_view = !dev_src;
     // this slot's device buffer held block i - n_buffers, whose unfinished tail the NEXT block's k_fq_begin reads on the parse
     // stream: the upload that overwrites it waits for that kernel (the successor slot's `parsed` event, recorded behind it)
-    if (f->n_submitted >= f->slots.size()) FQ_TRY(hipStreamWaitEvent(f->copy_stream, f->slots[(size_t)(si + 1) % f->slots.size()].parsed, 0));
-    if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, f->copy_stream));
+    if (!dev_src) {
+        if (f->n_submitted >= f->slots.size()) FQ_TRY(hipStreamWaitEvent(f->copy_stream, f->slots[(size_t)(si + 1) % f->slots.size()].parsed, 0));
+        if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, f->copy_stream));
+    }
     FQ_TRY(hipEventRecord(s.copied, f->copy_stream));
     FQ_TRY(hipStreamWaitEvent(hs, s.copied, 0));
     const Slot *prev = f->prev_submitted >= 0 ? &f->slots[(size_t)f->prev_submitted] : nullptr;
@@ -457,6 +489,28 @@ hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) {
     s.state = Slot::SUBMITTED;
     f->n_submitted++;
     f->prev_submitted = last ? -1 : si;                       // the next block starts a new file after `last`
+    return HAST_OK;
+}
+hast_status hast_fq_submit(hast_fq *f, size_t n_bytes, int last) { return submit_block(f, n_bytes, last, false); }
+hast_status hast_fq_submit_device(hast_fq *f, size_t n_bytes, int last) { return submit_block(f, n_bytes, last, true); }
+
+// Host copy of the open block's bytes (the view bc_pos / bc_len point into): always there for host blocks; a device block is
+// fetched on the first call (16 MB over PCIe: for the rare record whose barcode text the framer could not hand over in its 16-byte
+// copy -- longer than 15 bytes -- or for a block with more records than the pinned arrays hold).
+hast_status hast_fq_block_host_bytes(hast_fq *f, const uint8_t **bytes) {
+    if (!f || !bytes) return set_error(HAST_ERR_INVALID, "null argument");
+    *bytes = nullptr;
+    if (f->n_opened == 0) return set_error(HAST_ERR_INVALID, "no open block");
+    Slot &s = f->slots[(f->n_opened - 1) % f->slots.size()];
+    if (s.state != Slot::OPEN) return set_error(HAST_ERR_INVALID, "no open block");
+    if (!s.host_view) {
+        FQ_TRY(hipSetDevice(dev_of(f, s)));
+        hipStream_t hs = ctx_stream_of(ctx_of(f, s));
+        FQ_TRY(hipMemcpyAsync(s.h_buf, s.d_buf, f->pad + s.n_bytes, hipMemcpyDeviceToHost, hs));
+        FQ_TRY(hipStreamSynchronize(hs));
+        s.host_view = true;
+    }
+    *bytes = s.h_buf;
     return HAST_OK;
 }
 
@@ -516,7 +570,7 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     if (f->striped) {
         // (the host view already holds the first bytes of the next block behind this block's own: submit_striped put them there)
         f->records_per_lane[(size_t)s.lane] += n;
-    } else {
+    } else if (!s.dev_src) {
     // host view of the bytes the barcode extents point into: this block's bytes, preceded by the previous block's tail
     if (st.tail_in != f->carry.size()) return set_error(HAST_ERR_INVALID, "tail bookkeeping out of step (%llu vs %zu)", (unsigned long long)st.tail_in, f->carry.size());
     if (!f->carry.empty()) memcpy(s.h_buf + f->pad - f->carry.size(), f->carry.data(), f->carry.size());
@@ -527,7 +581,7 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     out->n_bases = st.bases;
     out->max_read_len = st.max_len;
     out->short_read = (st.flags & 1) ? 1 : 0;
-    out->bytes = s.h_buf;
+    out->bytes = s.dev_src ? nullptr : s.h_buf;              // (device blocks: hast_fq_block_host_bytes fetches them when asked)
     out->bc_pos = s.h_bc;
     out->bc_len = s.h_bc + s.h_cap;
     out->bc_text = by_copy ? nullptr : reinterpret_cast<const uint8_t *>(s.h_bc + 2 * s.h_cap);

@@ -1,0 +1,574 @@
+// gz_api.cpp -- hast_gz_*: one ordinary .gz file inflated ON THE GPU (include/hast.h, "gzip input decoded on the device").
+// Host side of gz_kernels.hip: an uploader thread moves the COMPRESSED bytes to HBM (pread by several threads into pinned
+// pieces), a producer thread runs the passes segment by segment -- search + decode of every 32-KB chunk, the chain of accepted
+// chunks with its follow-up jobs (gz_chain.h), windows, CRC-32 -- and checks every member's CRC-32 / ISIZE; the caller's thread
+// (hast_gz_read_device) only launches the translate kernel that writes the bytes it asks for where it wants them.
+// Replaces, for this path, gzstream.h:47 + classify.cpp:245-254 (one zlib stream per file on one host thread).
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hast.h"
+#include "gz_chain.h"
+#include "gz_core.h"
+#include "gz_device.h"
+#include "hast_internal.h"
+#include "worker_pool.h"
+
+using namespace hast;
+using namespace hast::gz;
+
+namespace {
+
+constexpr size_t kPiece = 16u << 20;         // upload granule
+constexpr size_t kInPad = 256;               // zero bytes behind the file's last byte on the device
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct DevBuf {                               // a device allocation that only ever grows
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct Batch {                                // accepted chunks the consumer may translate
+    int arena = -1;
+    std::vector<Accepted> acc;
+    uint64_t out_lo = 0, out_hi = 0;
+    size_t next = 0;                          // consumer: first chunk not fully delivered
+    bool eof = false;
+    std::string error;
+};
+
+struct Arena {
+    DevBuf syms, windows, acc, need, crc, carry;
+    std::vector<DevBuf> gap;                  // follow-up jobs' symbols (reused from batch to batch)
+    size_t gap_used = 0;
+    bool busy = false;                        // a published batch lives in it
+    hipEvent_t done = nullptr;                // recorded behind the consumer's last translate of that batch
+    bool done_recorded = false;
+};
+
+}  // namespace
+
+struct hast_gz {
+    hast_ctx *ctx = nullptr;
+    int device = 0;
+    int fd = -1;
+    std::string path;
+    uint64_t file_size = 0;
+    size_t chunk_bytes = 32768, seg_chunks = 8192;
+    double room = 12.0;
+    uint32_t slot_syms = 0;
+    // device
+    uint32_t *d_in = nullptr;
+    DevBuf jobs, tabs, carry_next;
+    ChunkJob *h_jobs = nullptr;               // pinned
+    size_t h_jobs_cap = 0;
+    uint32_t *h_crc = nullptr;                // pinned
+    size_t h_crc_cap = 0;
+    Arena arena[2];
+    hipStream_t up_stream = nullptr, dec_stream = nullptr;
+    // threads
+    std::thread uploader, producer;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t uploaded = 0;                    // bytes of the file on the device
+    std::string up_error;
+    bool stop = false;
+    std::deque<std::unique_ptr<Batch>> ready; // producer -> consumer
+    // consumer
+    std::unique_ptr<Batch> cur;
+    uint64_t cursor = 0;                      // bytes delivered
+    bool done = false;
+    std::string err;
+    // chain + member check (producer)
+    Chain chain;
+    uint32_t crc_acc = 0;
+    uint64_t isize_acc = 0;
+    bool crc_started = false;
+    // stats
+    hast_gz_stats st{};
+};
+
+namespace {
+
+#define GZ_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return std::string(#expr ": ") + hipGetErrorString(e_);          \
+    } while (0)
+
+bool read_at(int fd, uint64_t off, size_t n, uint8_t *dst, size_t *got) {
+    size_t have = 0;
+    while (have < n) {
+        const ssize_t r = pread(fd, dst + have, n - have, (off_t)(off + have));
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return false;
+        if (r == 0) break;
+        have += (size_t)r;
+    }
+    *got = have;
+    return true;
+}
+
+// compressed bytes -> HBM, piece by piece; `uploaded` moves on when a piece IS there
+void upload_loop(hast_gz *g) {
+    (void)hipSetDevice(g->device);
+    uint8_t *h[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::string bad;
+    for (int i = 0; i < 2 && bad.empty(); ++i) {
+        if (hipHostMalloc((void **)&h[i], kPiece, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) bad = "gz: pinned staging allocation failed";
+    }
+    const int nthr = 8;
+    WorkerPool pool(nthr);
+    uint64_t end_of[2] = {0, 0};
+    bool in_flight[2] = {false, false};
+    auto land = [&](int b) {                                       // piece in buffer b is on the device
+        if (!in_flight[b]) return;
+        if (hipEventSynchronize(ev[b]) != hipSuccess && bad.empty()) bad = "gz: upload failed";
+        in_flight[b] = false;
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->uploaded = std::max(g->uploaded, end_of[b]);
+        g->cv.notify_all();
+    };
+    size_t i = 0;
+    for (uint64_t off = 0; off < g->file_size && bad.empty(); off += kPiece, ++i) {
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (g->stop) break;
+        }
+        const int b = (int)(i & 1);
+        land(b);
+        const size_t n = (size_t)std::min<uint64_t>(kPiece, g->file_size - off);
+        const size_t share = ((n / nthr) + 4095) & ~(size_t)4095;
+        std::atomic<bool> short_read{false};
+        pool.run([&](int t) {
+            const size_t from = std::min(n, share * (size_t)t), to = std::min(n, from + share);
+            size_t got = 0;
+            if (to > from && (!read_at(g->fd, off + from, to - from, h[b] + from, &got) || got != to - from)) short_read = true;
+        });
+        if (short_read) { bad = "gz: read failed (the file is shorter than its size says, or an I/O error)"; break; }
+        if (hipMemcpyAsync(reinterpret_cast<uint8_t *>(g->d_in) + off, h[b], n, hipMemcpyHostToDevice, g->up_stream) != hipSuccess ||
+            hipEventRecord(ev[b], g->up_stream) != hipSuccess) { bad = "gz: upload failed"; break; }
+        end_of[b] = off + n;
+        in_flight[b] = true;
+        land(b ^ 1);                                               // (the piece before this one: usually there by now)
+    }
+    land(0);
+    land(1);
+    for (int k = 0; k < 2; ++k) {
+        if (h[k]) (void)hipHostFree(h[k]);
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
+    }
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!bad.empty()) g->up_error = bad;
+    g->cv.notify_all();
+}
+
+void publish(hast_gz *g, std::unique_ptr<Batch> b) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->ready.push_back(std::move(b));
+    g->cv.notify_all();
+}
+void publish_error(hast_gz *g, const std::string &msg) {
+    std::unique_ptr<Batch> b(new Batch);
+    b->error = msg;
+    publish(g, std::move(b));
+}
+
+// one segment's passes; returns "" or what failed
+std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t first_bit, bool &finished) {
+    const size_t C = g->chunk_bytes, S = g->seg_chunks;
+    const size_t c0 = k * S, c1 = std::min(n_chunks, c0 + S);
+    const bool all_in = c1 >= n_chunks;
+    // the compressed bytes this segment's chunks may read: their own and a margin behind them (a chunk runs on to the first
+    // block boundary behind its stop)
+    const uint64_t need_up = all_in ? g->file_size : std::min<uint64_t>(g->file_size, (uint64_t)c1 * C + std::min<uint64_t>((uint64_t)S * C, 16u << 20));
+    Arena &A = g->arena[k & 1];
+    uint64_t have_up = 0;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        const double t0 = now_s();
+        g->cv.wait(lk, [&] { return g->stop || !g->up_error.empty() || g->uploaded >= need_up; });
+        g->st.wait_upload_s += now_s() - t0;
+        if (g->stop) { finished = true; return ""; }
+        if (!g->up_error.empty()) return g->up_error;
+        have_up = g->uploaded;
+        const double t1 = now_s();
+        g->cv.wait(lk, [&] { return g->stop || !A.busy; });
+        g->st.wait_consumer_s += now_s() - t1;
+        if (g->stop) { finished = true; return ""; }
+    }
+    if (A.done_recorded) {                                          // the batch that lived here: its last translate must be through
+        GZ_HIP(hipEventSynchronize(A.done));
+        A.done_recorded = false;
+    }
+    A.gap_used = 0;
+    const uint64_t input_bits = (all_in ? g->file_size : have_up) * 8;
+    const double t_seg0 = now_s();
+    // ---- nominal pass: search + decode of every chunk of the segment ---------------------------------------------------------
+    size_t n_jobs = 0;
+    GZ_HIP(A.syms.ensure((size_t)(c1 - c0) * g->slot_syms * sizeof(uint16_t) + 64));
+    const uint64_t sym_base = reinterpret_cast<uintptr_t>(A.syms.p) / 2;      // job.sym_off counts u16 from address 0
+    for (size_t c = c0; c < c1; ++c) {
+        ChunkJob &j = g->h_jobs[n_jobs];
+        memset(&j, 0, sizeof(j));
+        const uint64_t nominal = (uint64_t)c * C * 8;
+        if (nominal + C * 8 <= first_bit) continue;                           // nothing but the first member's header
+        if (nominal <= first_bit) {
+            j.from_bit = first_bit;
+            j.flags = kJobKnown | kJobNoHistory;
+        } else j.from_bit = nominal;
+        j.stop_bit = (uint64_t)(c + 1) * C * 8;
+        j.search_to_lo = (uint32_t)(j.stop_bit - j.from_bit);
+        j.sym_cap = g->slot_syms;
+        j.sym_off = sym_base + (uint64_t)(c - c0) * g->slot_syms;
+        ++n_jobs;
+    }
+    if (n_jobs) {
+        GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
+        GZ_HIP(launch_search((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint32_t *)g->tabs.p, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint32_t *)g->tabs.p, nullptr, g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
+        GZ_HIP(hipStreamSynchronize(g->dec_stream));
+    }
+    g->st.chunks += n_jobs;
+    g->chain.add_candidates(g->h_jobs, n_jobs, all_in);
+    // ---- the chain, with its follow-up jobs ------------------------------------------------------------------------------------
+    std::vector<Chain::Gap> gaps;
+    while (g->chain.plan(gaps, input_bits)) {
+        if (gaps.size() > g->h_jobs_cap) return "gz: internal: more follow-up jobs than chunks";
+        size_t total = 0;
+        std::vector<size_t> at(gaps.size());
+        for (size_t i = 0; i < gaps.size(); ++i) {
+            at[i] = total;
+            total += ((size_t)std::min<uint64_t>(gaps[i].want_syms, 1ull << 26) + 520 + 7) & ~(size_t)7;
+        }
+        if (A.gap_used == A.gap.size()) A.gap.emplace_back();
+        DevBuf &gb = A.gap[A.gap_used++];
+        GZ_HIP(gb.ensure(total * sizeof(uint16_t) + 64));
+        const uint64_t gbase = reinterpret_cast<uintptr_t>(gb.p) / 2;
+        for (size_t i = 0; i < gaps.size(); ++i) {
+            ChunkJob &j = g->h_jobs[i];
+            j = gaps[i].job;
+            j.sym_cap = (uint32_t)std::min<uint64_t>(gaps[i].want_syms, 1ull << 26);
+            j.sym_off = gbase + at[i];
+            j.start_bit = j.from_bit;
+            j.status = kStFound;
+        }
+        GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, (uint32_t *)g->tabs.p, nullptr, g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
+        GZ_HIP(hipStreamSynchronize(g->dec_stream));
+        g->chain.gap_done(g->h_jobs, gaps.size(), input_bits);
+        g->st.followup_jobs += gaps.size();
+        g->st.followup_rounds++;
+    }
+    g->st.decode_s += now_s() - t_seg0;
+    // ---- what became final: windows, CRC-32, member checks, hand-over --------------------------------------------------------------
+    std::unique_ptr<Batch> b(new Batch);
+    b->arena = (int)(k & 1);
+    g->chain.take_confirmed(b->acc);
+    const size_t n = b->acc.size();
+    std::string bad;
+    if (n) {
+        const double t_w0 = now_s();
+        std::vector<AccDev> host(n);
+        for (size_t i = 0; i < n; ++i) {
+            const Accepted &a = b->acc[i];
+            host[i].sym = reinterpret_cast<const uint16_t *>((uintptr_t)(a.tag * 2));
+            host[i].out_off = a.out_off;
+            host[i].n_out = a.job.n_out;
+            host[i].no_history = a.no_history ? 1u : 0u;
+        }
+        b->out_lo = b->acc.front().out_off;
+        b->out_hi = b->acc.back().out_off + b->acc.back().job.n_out;
+        GZ_HIP(A.acc.ensure(n * sizeof(AccDev)));
+        GZ_HIP(A.windows.ensure(n * (size_t)kWindow));
+        GZ_HIP(A.need.ensure(n * sizeof(uint32_t)));
+        GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
+        GZ_HIP(A.carry.ensure(kWindow));
+        if (g->h_crc_cap < n) {
+            if (g->h_crc) (void)hipHostFree(g->h_crc);
+            g->h_crc = nullptr;
+            g->h_crc_cap = 0;
+            GZ_HIP(hipHostMalloc((void **)&g->h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            g->h_crc_cap = n + n / 2 + 64;
+        }
+        // (pageable source: the copy is done with `host` when the call returns)
+        GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, g->dec_stream));
+        GZ_HIP(hipStreamSynchronize(g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(A.carry.p, g->carry_next.p, kWindow, hipMemcpyDeviceToDevice, g->dec_stream));
+        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.need.p, g->dec_stream));
+        GZ_HIP(launch_crc((const AccDev *)A.acc.p, (uint32_t)n, (const uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.crc.p, g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(g->carry_next.p, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToDevice, g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(g->h_crc, A.crc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, g->dec_stream));
+        GZ_HIP(hipStreamSynchronize(g->dec_stream));
+        for (size_t i = 0; i < n && bad.empty(); ++i) {
+            const Accepted &a = b->acc[i];
+            const uint32_t len = a.job.n_out;
+            if (len) {
+                g->crc_acc = g->crc_started ? crc_combine_op(g->crc_acc, g->h_crc[i], crc_x2nmodp(len, 3)) : g->h_crc[i];
+                g->crc_started = true;
+                g->isize_acc += len;
+            }
+            if (a.member_end) {
+                if (g->crc_acc != a.want_crc) bad = "gz: CRC-32 mismatch";
+                else if ((uint32_t)g->isize_acc != a.want_isize) bad = "gz: length check (ISIZE) failed";
+                g->crc_acc = 0;
+                g->isize_acc = 0;
+                g->crc_started = false;
+                g->st.members++;
+            }
+            if (a.is_gap) g->st.followup_accepted++;
+        }
+        g->st.accepted += n;
+        g->st.out_bytes = b->out_hi;
+        g->st.windows_crc_s += now_s() - t_w0;
+        if (bad.empty()) {
+            std::lock_guard<std::mutex> lk(g->mu);
+            A.busy = true;
+            g->ready.push_back(std::move(b));
+            g->cv.notify_all();
+        }
+    }
+    if (!bad.empty()) return bad;
+    if (g->chain.failed()) return g->chain.error();
+    if (all_in) {
+        if (!g->chain.finished()) return "gz: internal: the chain of chunks stalled";
+        finished = true;
+    }
+    return "";
+}
+
+void produce_loop(hast_gz *g) {
+    (void)hipSetDevice(g->device);
+    const uint64_t first_bit = g->chain.first_deflate_bit();
+    const size_t n_chunks = first_bit == ~0ull ? 0 : (size_t)((g->file_size + g->chunk_bytes - 1) / g->chunk_bytes);
+    bool finished = n_chunks == 0;
+    std::string bad;
+    for (size_t k = 0; !finished && bad.empty(); ++k) bad = produce_segment(g, k, n_chunks, first_bit, finished);
+    if (!bad.empty()) publish_error(g, bad);
+    else {
+        std::unique_ptr<Batch> b(new Batch);
+        b->eof = true;
+        publish(g, std::move(b));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes, size_t seg_chunks, double room, hast_gz **out) {
+    if (!ctx || !path || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return set_error(HAST_ERR_IO, "cannot read %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fd);
+        return set_error(HAST_ERR_UNSUPPORTED, "%s is not a regular file: the device inflate reads by position", path);
+    }
+    std::unique_ptr<hast_gz> g(new (std::nothrow) hast_gz());
+    if (!g) {
+        close(fd);
+        return set_error(HAST_ERR_OOM, "host allocation failed");
+    }
+    g->ctx = ctx;
+    g->device = hast_ctx_device(ctx);
+    g->fd = fd;
+    g->path = path;
+    g->file_size = (uint64_t)sb.st_size;
+    g->chunk_bytes = chunk_bytes ? std::max<size_t>(chunk_bytes, 64) : 32768;
+    g->chunk_bytes = (g->chunk_bytes + 3) & ~(size_t)3;
+    g->seg_chunks = seg_chunks ? seg_chunks : 8192;
+    g->room = room > 0 ? room : 12.0;
+    if (g->chunk_bytes > (1u << 26)) { close(fd); return set_error(HAST_ERR_INVALID, "chunk_bytes too large"); }
+    g->slot_syms = (uint32_t)std::min<double>((double)(1u << 27), (double)g->chunk_bytes * g->room + 600);
+    g->slot_syms = (g->slot_syms + 7) & ~7u;
+    const int cfd = fd;
+    g->chain.begin(g->file_size, [cfd](uint64_t off, size_t n, uint8_t *dst, size_t *got) { return read_at(cfd, off, n, dst, got); });
+    if (g->chain.failed()) {
+        // no gzip magic (zlib's gzread passes such a file through as it is), or a header this decoder does not take
+        const std::string why = g->chain.error();
+        close(fd);
+        return set_error(HAST_ERR_UNSUPPORTED, "%s: %s", path, why.c_str());
+    }
+    if (hipSetDevice(g->device) != hipSuccess) { close(fd); return set_error(HAST_ERR_HIP, "hipSetDevice failed"); }
+    const size_t n_chunks = (size_t)((g->file_size + g->chunk_bytes - 1) / g->chunk_bytes);
+    const size_t seg = std::max<size_t>(1, std::min(g->seg_chunks, n_chunks));
+    g->seg_chunks = seg;
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
+    const uint64_t alloc = ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
+    step(hipMalloc((void **)&g->d_in, alloc));
+    if (e == hipSuccess) step(hipMemset(reinterpret_cast<uint8_t *>(g->d_in) + tail_from, 0, alloc - tail_from));
+    step(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
+    step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
+    g->h_jobs_cap = seg + 8;
+    step(hipHostMalloc((void **)&g->h_jobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+    step(g->jobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
+    step(g->tabs.ensure(g->h_jobs_cap * (size_t)kTabWords * sizeof(uint32_t)));
+    step(g->carry_next.ensure(kWindow));
+    if (e == hipSuccess) step(hipMemset(g->carry_next.p, 0, kWindow));
+    for (Arena &a : g->arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    // both symbol arenas up front: an allocation that fails later would fail in mid-file
+    for (int i = 0; i < 2 && e == hipSuccess; ++i)
+        if (i == 0 || n_chunks > seg) step(g->arena[i].syms.ensure(seg * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
+    if (e != hipSuccess) {
+        const hast_status st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_UNSUPPORTED : HAST_ERR_HIP, "device inflate of %s: %s", path, hipGetErrorString(e));
+        (void)hipGetLastError();
+        hast_gz_close(g.release());
+        return st;
+    }
+    hast_gz *raw = g.release();
+    raw->uploader = std::thread(upload_loop, raw);
+    raw->producer = std::thread(produce_loop, raw);
+    *out = raw;
+    return HAST_OK;
+}
+
+hast_status hast_gz_open(hast_ctx *ctx, const char *path, hast_gz **out) { return hast_gz_open_ex(ctx, path, 0, 0, 0, out); }
+
+void hast_gz_close(hast_gz *g) {
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->stop = true;
+        for (Arena &a : g->arena) a.busy = false;
+        g->cv.notify_all();
+    }
+    if (g->uploader.joinable()) g->uploader.join();
+    if (g->producer.joinable()) g->producer.join();
+    (void)hipSetDevice(g->device);
+    if (g->dec_stream) (void)hipStreamSynchronize(g->dec_stream);
+    if (g->up_stream) (void)hipStreamSynchronize(g->up_stream);
+    for (Arena &a : g->arena) {
+        if (a.done_recorded) (void)hipEventSynchronize(a.done);
+        if (a.done) (void)hipEventDestroy(a.done);
+        for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry}) b->release();
+        for (DevBuf &b : a.gap) b.release();
+    }
+    g->jobs.release();
+    g->tabs.release();
+    g->carry_next.release();
+    if (g->d_in) (void)hipFree(g->d_in);
+    if (g->h_jobs) (void)hipHostFree(g->h_jobs);
+    if (g->h_crc) (void)hipHostFree(g->h_crc);
+    if (g->up_stream) (void)hipStreamDestroy(g->up_stream);
+    if (g->dec_stream) (void)hipStreamDestroy(g->dec_stream);
+    if (g->fd >= 0) close(g->fd);
+    delete g;
+}
+
+hast_status hast_gz_read_device(hast_gz *g, uint8_t *d_dst, size_t cap, size_t *n_out, hast_stream s) {
+    if (!g || !n_out || (cap && !d_dst)) return set_error(HAST_ERR_INVALID, "null argument");
+    *n_out = 0;
+    if (!g->err.empty()) return set_error(HAST_ERR_IO, "%s: %s", g->path.c_str(), g->err.c_str());
+    if (hipSetDevice(g->device) != hipSuccess) return set_error(HAST_ERR_HIP, "hipSetDevice failed");
+    hipStream_t hs = s ? (hipStream_t)s : ctx_stream_of(g->ctx);
+    size_t got = 0;
+    while (got < cap && !g->done) {
+        if (!g->cur) {
+            std::unique_lock<std::mutex> lk(g->mu);
+            const double t0 = now_s();
+            g->cv.wait(lk, [&] { return !g->ready.empty(); });
+            g->st.wait_decode_s += now_s() - t0;
+            g->cur = std::move(g->ready.front());
+            g->ready.pop_front();
+        }
+        Batch &b = *g->cur;
+        if (!b.error.empty()) {
+            g->err = b.error;
+            g->cur.reset();
+            // what was decoded in front of the damage has been delivered (as zlib's gzread does); the error comes with the next call
+            if (got) break;
+            return set_error(HAST_ERR_IO, "%s: %s", g->path.c_str(), g->err.c_str());
+        }
+        if (b.eof) {
+            g->done = true;
+            g->cur.reset();
+            break;
+        }
+        Arena &A = g->arena[b.arena];
+        // the bytes [cursor, cursor + want) out of this batch's chunks
+        const uint64_t o_lo = g->cursor, o_hi = std::min<uint64_t>(b.out_hi, g->cursor + (cap - got));
+        if (o_hi > o_lo) {
+            size_t c = b.next;
+            while (c < b.acc.size()) {
+                // launches of at most 65535 chunks (grid.y)
+                size_t c_end = c;
+                uint32_t max_syms = 0;
+                while (c_end < b.acc.size() && c_end - c < 65535 && b.acc[c_end].out_off < o_hi) {
+                    max_syms = std::max(max_syms, b.acc[c_end].job.n_out);
+                    ++c_end;
+                }
+                if (c_end == c) break;
+                const hipError_t e = launch_translate((const AccDev *)A.acc.p, (uint32_t)c, (uint32_t)(c_end - c), max_syms, (const uint8_t *)A.windows.p,
+                                                      (const uint8_t *)A.carry.p, o_lo, o_hi, d_dst + got, hs);
+                if (e != hipSuccess) return set_error(HAST_ERR_HIP, "translate: %s", hipGetErrorString(e));
+                c = c_end;
+            }
+            got += (size_t)(o_hi - o_lo);
+            g->cursor = o_hi;
+            while (b.next < b.acc.size() && b.acc[b.next].out_off + b.acc[b.next].job.n_out <= g->cursor) b.next++;
+        }
+        if (g->cursor >= b.out_hi) {
+            // the batch is through: its arena is free once this stream has run the launches above
+            if (hipEventRecord(A.done, hs) != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventRecord failed");
+            {
+                std::lock_guard<std::mutex> lk(g->mu);
+                A.done_recorded = true;
+                A.busy = false;
+                g->cv.notify_all();
+            }
+            g->cur.reset();
+        }
+    }
+    *n_out = got;
+    return HAST_OK;
+}
+
+hast_status hast_gz_get_stats(hast_gz *g, hast_gz_stats *out) {
+    if (!g || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    *out = g->st;
+    out->compressed_bytes = g->file_size;
+    return HAST_OK;
+}
+
+}  // extern "C"

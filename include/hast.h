@@ -38,7 +38,8 @@ typedef enum {
     HAST_ERR_TABLE_FULL = 5, /* more distinct keys than hast_table_reserve planned for      */
     HAST_ERR_FORMAT = 6,     /* k-mer text is not fixed-width K-byte lines (kmer.h:154)     */
     HAST_ERR_RCCL = 7,       /* the RCCL all-reduce failed                                  */
-    HAST_ERR_IO = 8          /* file could not be opened / read                             */
+    HAST_ERR_IO = 8,         /* file could not be opened / read / is damaged                */
+    HAST_ERR_UNSUPPORTED = 9 /* this entry cannot take this input; another one can (e.g. hast_gz_open: inflate on the host) */
 } hast_status;
 
 typedef struct hast_ctx hast_ctx;
@@ -266,7 +267,8 @@ typedef struct {
     uint32_t max_read_len;
     uint32_t short_read;       /* != 0: some read is shorter than K and holds no 'N' (the reference aborts, kmer.h:171);
                                   nothing of this block has been classified */
-    const uint8_t *bytes;      /* host view of the block (with the previous block's tail in front of it) */
+    const uint8_t *bytes;      /* host view of the block (with the previous block's tail in front of it); NULL for a block submitted
+                                  with hast_fq_submit_device (hast_fq_block_host_bytes fetches it) */
     const uint32_t *bc_pos;    /* [n_records] */
     const uint32_t *bc_len;    /* [n_records] */
     const uint8_t *bc_text;    /* [n_records][16] or NULL: the barcode text itself, byte 0 = its length, bytes 1.. = the text;
@@ -302,9 +304,52 @@ void        hast_fq_destroy(hast_fq *);
 size_t      hast_fq_block_bytes(const hast_fq *);
 hast_status hast_fq_acquire(hast_fq *, uint8_t **host_buf);
 hast_status hast_fq_submit(hast_fq *, size_t n_bytes, int last);
+/* Blocks whose bytes are written ON THE DEVICE (e.g. by hast_gz_read_device: a .gz input inflated on the GPU): after
+ * hast_fq_acquire (its host buffer stays unused), hast_fq_device_block gives the device address the block's bytes belong at and
+ * the stream the writes must be enqueued on; hast_fq_submit_device then frames them where they lie -- no upload.  A stream takes
+ * host blocks or device blocks, not both; striped streams take host blocks only.  hast_fq_block.bytes is NULL for such a block:
+ * hast_fq_block_host_bytes (valid between hast_fq_next and hast_fq_commit, for any block) fetches the host copy when the caller
+ * needs the text behind bc_pos / bc_len -- a barcode longer than the 15 bytes bc_text holds. */
+hast_status hast_fq_device_block(hast_fq *, uint8_t **d_block, hast_stream *fill_stream);
+hast_status hast_fq_submit_device(hast_fq *, size_t n_bytes, int last);
+hast_status hast_fq_block_host_bytes(hast_fq *, const uint8_t **bytes);
 int         hast_fq_poll(hast_fq *);      /* 1: hast_fq_next would not have to wait for the framing of the oldest submitted block */
 hast_status hast_fq_next(hast_fq *, hast_fq_block *out);
 hast_status hast_fq_commit(hast_fq *);
+
+/* ---- gzip input decoded on the device (gzstream.h:47, classify.cpp:245-254: one zlib stream per .gz file) -----------------
+ * HAST's real inputs are ordinary .fq.gz files: ONE deflate stream per file, which the reference inflates on the thread that
+ * also frames the records.  hast_gz inflates such a file on the GPU: the COMPRESSED bytes cross PCIe (5-6 x fewer than the
+ * FASTQ text) and the inflated bytes are written where the caller wants them in HBM -- e.g. straight into a block of the FASTQ
+ * framer (hast_fq_submit_device), which reads them where they lie.  Method (hast_amd/csrc/gz_core.h, gz_chain.h, gz_kernels.hip):
+ * every 32-KB chunk of the compressed bytes searches its first dynamic-block header and is decoded by ONE LANE into 16-bit
+ * symbols with the 32 KB in front of it unknown ("marker" symbols); a chunk counts iff the chunk in front of it ended exactly
+ * at its start (holes are decoded by follow-up jobs); windows are resolved in stream order, markers translated, and every
+ * member's CRC-32 and ISIZE are checked (CRC by slices on the device, combined with GF(2) operators), so a decoding bug or a
+ * damaged file cannot pass as data.  Any gzip file is taken: all block types, several members, header fields, trailing garbage
+ * (ignored, as gzread does).
+ * hast_gz_open: HAST_ERR_UNSUPPORTED when the path is not a regular file, does not start with a gzip member (zlib passes such a
+ * file through as it is) or the device has no room -- the caller then inflates on the host; HAST_ERR_IO when it cannot be read.
+ * hast_gz_read_device: the next up to `cap` bytes of the inflated stream, written to d_dst by a kernel on `stream` (NULL: the
+ * context's); *n_out < cap only at the end of the stream (0 = nothing left).  Blocks until those bytes are decoded.  A damaged or
+ * truncated file is HAST_ERR_IO -- after what could be decoded in front of the damage has been delivered, as gzread does.
+ * One reader per object; several of them -- one per input file -- run side by side. */
+typedef struct hast_gz hast_gz;
+typedef struct {
+    uint64_t compressed_bytes, out_bytes;
+    uint64_t chunks, accepted, followup_jobs, followup_rounds, followup_accepted, members;
+    double decode_s;           /* search + decode passes (host wall time of the producer thread) */
+    double windows_crc_s;      /* windows + CRC passes */
+    double wait_upload_s;      /* the producer waited for compressed bytes to reach the device */
+    double wait_consumer_s;    /* ... for the reader to be through with a symbol arena */
+    double wait_decode_s;      /* the reader waited for decoded bytes */
+} hast_gz_stats;
+hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
+/* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 8192), symbols of room per compressed byte (0 = 12) */
+hast_status hast_gz_open_ex(hast_ctx *, const char *path, size_t chunk_bytes, size_t chunks_per_pass, double room, hast_gz **out);
+hast_status hast_gz_read_device(hast_gz *, uint8_t *d_dst, size_t cap, size_t *n_out, hast_stream);
+hast_status hast_gz_get_stats(hast_gz *, hast_gz_stats *out);
+void        hast_gz_close(hast_gz *);
 
 /* ---- host-side pieces of the path (no device work) ---------------------------------------- */
 /* parseName (classify.cpp:112-119): barcode = head[last '#' + 1 .. last '/'). */

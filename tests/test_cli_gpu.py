@@ -6,8 +6,10 @@ import subprocess
 
 import pytest
 
+import numpy as np
+
 import hast_amd
-from tests.conftest import golden_cases, load_case
+from tests.conftest import ROOT, golden_cases, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -204,24 +206,72 @@ def test_cli_empty_crlf_and_many_files(exe, oracle_dir, tmp_path):
 
 
 def test_cli_gz_decoders_agree_and_damaged_gz_is_an_error(exe, golden_workdir, tmp_path):
-    """the in-tree gzip decoder vs zlib (HAST_INFLATE=zlib) on a golden case with gz reads; a truncated gz file must not
-    pass as a shorter input"""
+    """.gz reads through every inflate route on a golden case: ON THE GPU (the default for ordinary gzip files: hast_gz_* +
+    device-side blocks of the framer; --stats says so), zlib (HAST_INFLATE=zlib), the host's parallel and serial decoders
+    (HAST_INFLATE=host); also with two contexts (a .gz file stays on one GPU).  A truncated or bit-flipped gz file must not pass as
+    a shorter / other input on any route."""
     import shutil
     d = tmp_path / "gz"
     shutil.copytree(golden_workdir / "rand_k21", d)
     args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "r1.fq.gz", "--read", "r2.fq.gz"]
-    a = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    b = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_INFLATE="zlib"))
+    a = subprocess.run([exe] + args + ["--stats"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([exe] + args + ["--stats"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_INFLATE="zlib"))
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 100
-    # one gzip stream inflated by several threads (par_inflate.h), and by the serial decoder alone
+    assert a.stderr.count(b"__stats_gz__") == 2 and b"__stats_gz__" not in b.stderr          # both files inflated on the device / none
+    for extra in (["--devices", "0,0"], ["--devices", "0,0,0"], ["--batch-reads", "13"]):
+        c = subprocess.run([exe] + args + extra + ["--stats"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert c.returncode == 0 and c.stdout == a.stdout and c.stderr.count(b"__stats_gz__") == 2, (extra, c.stderr[-300:])
+    # one gzip stream inflated by several host threads (par_inflate.h), and by the serial decoder alone
     for gz_threads in ("1", "2", "5", "16"):
-        c = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_GZ_THREADS=gz_threads))
-        assert c.returncode == 0 and c.stdout == a.stdout, (gz_threads, c.stderr[-300:])
+        c = subprocess.run([exe] + args + ["--stats"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_INFLATE="host", HAST_GZ_THREADS=gz_threads))
+        assert c.returncode == 0 and c.stdout == a.stdout and b"__stats_gz__" not in c.stderr, (gz_threads, c.stderr[-300:])
     whole = (d / "r2.fq.gz").read_bytes()
-    (d / "r2.fq.gz").write_bytes(whole[:len(whole) // 2])
-    for env in (None, dict(os.environ, HAST_INFLATE="zlib"), dict(os.environ, HAST_GZ_THREADS="1"), dict(os.environ, HAST_GZ_THREADS="6")):
-        r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-        assert r.returncode == 2 and r.stdout == b"", r.stderr[-300:]
+    flipped = bytearray(whole)
+    flipped[len(whole) // 3] ^= 0x10
+    for damaged in (whole[:len(whole) // 2], whole[:-4], bytes(flipped)):
+        (d / "r2.fq.gz").write_bytes(damaged)
+        for env in (None, dict(os.environ, HAST_INFLATE="zlib"), dict(os.environ, HAST_INFLATE="host", HAST_GZ_THREADS="1"), dict(os.environ, HAST_INFLATE="host", HAST_GZ_THREADS="6")):
+            r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert r.returncode == 2 and r.stdout == b"", (len(damaged), r.stderr[-300:])
+
+
+def test_cli_device_inflate_long_barcodes_and_odd_files(exe, oracle_dir, tmp_path):
+    """Device-side blocks hand the host no copy of their bytes: a barcode longer than the 15 bytes of the framer's compact copy makes
+    the program fetch the block; a ".gz" that is not gzip, an empty .gz and a blocked-gzip (BGZF) file take the host route; == oracle."""
+    import gzip
+    rng = np.random.default_rng(12)
+    k = 21
+    keys = ["".join(rng.choice(list("ACGT"), k)) for _ in range(400)]
+    (tmp_path / "hap0.mer").write_text("\n".join(keys[:200]) + "\n")
+    (tmp_path / "hap1.mer").write_text("\n".join(keys[200:]) + "\n")
+    recs = []
+    for i in range(4000):
+        seq = "".join(rng.choice(list("ACGT"), 150))
+        if i % 3 == 0:
+            kk = keys[int(rng.integers(0, 400))]
+            seq = seq[:40] + kk + seq[40 + k:]
+        bc = "%d_%d_%d" % (i % 50 + 1, i % 7 + 1, i % 3 + 1) if i % 11 else "a_barcode_that_is_much_longer_than_fifteen_bytes_%d" % (i % 5)
+        recs.append("@r%d#%s/1\n%s\n+\n%s\n" % (i, bc, seq, "F" * 150))
+    text = "".join(recs).encode()
+    with gzip.open(tmp_path / "reads.fq.gz", "wb", compresslevel=6) as f:
+        f.write(text)
+    (tmp_path / "plain.fq.gz").write_bytes(text)                                   # not gzip: passed through, as zlib does
+    (tmp_path / "empty.fq.gz").write_bytes(b"")
+    (tmp_path / "reads.fq").write_bytes(text)
+    if not os.path.exists(os.path.join(ROOT, "tools", "to_bgzf")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tools"), "to_bgzf"], check=True)
+    subprocess.run([os.path.join(ROOT, "tools", "to_bgzf"), str(tmp_path / "reads.fq"), str(tmp_path / "blocked.fq.gz"), "2", "6"], check=True)
+    base = ["--hap0", "hap0.mer", "--hap1", "hap1.mer"]
+    ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + base + ["--read", "reads.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert ref.returncode == 0 and len(ref.stdout.splitlines()) > 300
+    for name, n_dev in (("reads.fq.gz", 1), ("plain.fq.gz", 0), ("blocked.fq.gz", 0)):
+        if not (tmp_path / name).exists():
+            continue
+        for extra in ([], ["--batch-reads", "40"]):
+            got = subprocess.run([exe] + base + ["--read", name, "--read", "empty.fq.gz", "--stats"] + extra, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert got.returncode == 0, got.stderr.decode()[-2000:]
+            assert got.stdout == ref.stdout, (name, extra)
+            assert got.stderr.count(b"__stats_gz__") == n_dev + 1, (name, got.stderr[-500:])     # (+1: the empty file is taken by the device route)
 
 
 def test_cli_long_reads_stage01_semantics(exe, oracle_dir, tmp_path):
