@@ -92,6 +92,7 @@ ABI_SYMBOLS = {
     "hast_names_create": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "hast_names_destroy": (None, [vp]),
     "hast_fq_create": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(vp)]),
+    "hast_fq_create_ex": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_int, C.POINTER(vp)]),
     "hast_fq_create_striped": (C.c_int, [C.POINTER(vp), C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
     "hast_fq_lanes": (C.c_int, [vp]),
     "hast_fq_lane_records": (C.c_uint64, [vp, C.c_int]),

@@ -23,6 +23,7 @@
 // -t/--thread N is honoured as the number of host parser threads.
 #include <getopt.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -80,7 +81,10 @@ void print_usage() {                              // same flags as the reference
     const char *e = hast_last_error();
     if (e && *e) fprintf(stderr, " (%s)", e);
     fputc('\n', stderr);
-    exit(code);
+    // (no destructors: reader / inflate threads of the library may be at work, and nothing is left to save)
+    fflush(stdout);
+    fflush(stderr);
+    _exit(code);
 }
 #define CK(call, what) do { if ((call) != HAST_OK) die(4, what); } while (0)
 
@@ -129,20 +133,21 @@ void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, size_t n_known, si
     hast_ctx *ctx = ctxs[0];
     if (acc.device_cap) {
         if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
-        std::vector<uint64_t> a(acc.device_cap), b(acc.device_cap), c(acc.device_cap);
-        CK(hast_counts_read(ctx, a.data(), b.data(), c.data(), acc.device_cap), "reading counters");
-        if (acc.c0.size() < acc.device_cap) {
-            acc.c0.resize(acc.device_cap);
-            acc.c1.resize(acc.device_cap);
-            acc.neg.resize(acc.device_cap);
+        // (only the barcodes that exist: the counters are sized ahead of the dictionary, 1M records = 32 MB at the start)
+        const size_t n_read = std::min(acc.device_cap, n_known);
+        std::vector<uint64_t> a(n_read), b(n_read), c(n_read);
+        CK(hast_counts_read(ctx, a.data(), b.data(), c.data(), n_read), "reading counters");
+        if (acc.c0.size() < n_read) {
+            acc.c0.resize(n_read);
+            acc.c1.resize(n_read);
+            acc.neg.resize(n_read);
         }
-        for (size_t i = 0; i < acc.device_cap; i++) {       // (64-bit on the device and here: nothing wraps)
+        for (size_t i = 0; i < n_read; i++) {                // (64-bit on the device and here: nothing wraps)
             acc.c0[i] += a[i];
             acc.c1[i] += b[i];
             acc.neg[i] += c[i];
         }
     }
-    (void)n_known;
     for (hast_ctx *c : ctxs) CK(hast_counts_resize(c, new_cap), "allocating counters");
     acc.device_cap = new_cap;
 }
@@ -238,7 +243,7 @@ int main(int argc, char **argv) {
     // of their own while this one reads the k-mer files and builds the table.
     std::vector<hast_fq *> pre_fq, done_fq;
     std::vector<hast_gz *> done_gz;
-    std::vector<hast_names *> name_caches;                 // per GPU: device-side cache barcode text -> id
+    std::vector<hast_names *> name_caches, own_caches;     // per context / per GPU: device-side cache barcode text -> id
     std::thread pre_thread;
     std::string pre_error;
     // several GPUs: the blocks of every file go to all of them in turn (a striped stream); HAST_DEAL=files deals whole files
@@ -266,7 +271,7 @@ int main(int argc, char **argv) {
     auto make_fq = [&](size_t file_index, hast_fq **out) -> hast_status {
         if (stripe && !dev_gz[file_index])
             return hast_fq_create_striped(ctxs.data(), (int)ctxs.size(), fq_cap, std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()), name_caches.data(), out);
-        return hast_fq_create(ctxs[file_index % ctxs.size()], fq_cap, fq_bufs, name_caches[file_index % ctxs.size()], out);
+        return hast_fq_create_ex(ctxs[file_index % ctxs.size()], fq_cap, fq_bufs, name_caches[file_index % ctxs.size()], dev_gz[file_index] ? 1 : 0, out);
     };
     auto contexts_ready = [&]() {
         ctxs.push_back(ctx);
@@ -280,9 +285,15 @@ int main(int argc, char **argv) {
         stripe = ctxs.size() > 1 && !(deal && !strcmp(deal, "files"));
         size_t name_cap = std::max<size_t>(initial_barcodes, 1u << 22);
         if (const char *e = getenv("HAST_NAME_CACHE")) name_cap = (size_t)atol(e);
-        for (hast_ctx *c : ctxs) {
+        for (size_t i = 0; i < ctxs.size(); i++) {
+            // one cache per GPU: contexts that share a device (--devices 0,0) share what it has learnt
             hast_names *nm = nullptr;
-            if (name_cap) CK(hast_names_create(c, name_cap, &nm), "creating the barcode name cache");
+            for (size_t j = 0; j < i && !nm; j++)
+                if (devices[j] == devices[i]) nm = name_caches[j];
+            if (!nm && name_cap) {
+                CK(hast_names_create(ctxs[i], name_cap, &nm), "creating the barcode name cache");
+                own_caches.push_back(nm);
+            }
             name_caches.push_back(nm);
         }
         pre_fq.assign(std::min<size_t>(read.size(), stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size())), nullptr);
@@ -619,7 +630,7 @@ int main(int argc, char **argv) {
                 if (gs == HAST_ERR_UNSUPPORTED) {                  // e.g. no room on the device: the host inflates
                     f->gz = nullptr;
                     dev_gz[next_file] = 0;
-                    if (stripe && next_file < pre_fq.size() && pre_fq[next_file]) {   // (a plain stream was set up for it)
+                    if (next_file < pre_fq.size() && pre_fq[next_file]) {   // (a stream of device-side blocks was set up for it)
                         hast_fq_destroy(pre_fq[next_file]);
                         pre_fq[next_file] = nullptr;
                     }
@@ -853,9 +864,19 @@ int main(int argc, char **argv) {
     }
     fprintf(stderr, "__END__\n");
     const double t_printed = now_s();
+    // The output is complete.  Unpinning and freeing hundreds of MB of staging memory, the table and the streams takes ~0.1 s that the
+    // operating system does anyway when the process ends: leave at once (HAST_TEARDOWN=1 runs the destructors, for leak checks).
+    if (!getenv("HAST_TEARDOWN")) {
+        if (stats)
+            fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=skipped total_s=%.3f\n",
+                    t_ctx - t_start, t_loaded - t_ctx, t_scrubbed - t_loaded, t_read_done - t_scrubbed, t_classified - t_read_done, t_printed - t_classified, now_s() - t_start);
+        fflush(stdout);
+        fflush(stderr);
+        _exit(0);
+    }
     for (hast_gz *z : done_gz) hast_gz_close(z);
     for (hast_fq *f : done_fq) hast_fq_destroy(f);
-    for (hast_names *nm : name_caches) hast_names_destroy(nm);
+    for (hast_names *nm : own_caches) hast_names_destroy(nm);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     if (stats)                 // where a run's wall time goes, phase by phase (sums to the process's own lifetime from main() on)
         fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=%.3f total_s=%.3f\n",

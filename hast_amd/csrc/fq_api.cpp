@@ -27,6 +27,7 @@ namespace {
 
 struct Slot {
     uint8_t *h_buf = nullptr, *d_buf = nullptr;        // pad + block bytes (+ slack)
+    size_t h_buf_bytes = 0;
     FqState *d_st = nullptr, *h_st = nullptr;          // h_st pinned
     uint32_t *d_tile = nullptr, *d_nl = nullptr;
     uint64_t *d_off = nullptr;
@@ -223,7 +224,18 @@ static hast_status submit_striped(hast_fq *f, size_t n_bytes, int last) {
         // point there) + upload on ITS GPU
         Slot &pv = f->slots[(i - 1) % S];
         FqLane &pl = f->lanes[(size_t)pv.lane];
-        const size_t ov = std::min(f->over_cap, n_bytes);
+        // ... as far as its last record can reach: that record started in the block in front, so its header and base lines end at
+        // the latest with the 4th newline of this block (a FASTQ record is four lines).  Copying the whole 1 MB a long read may
+        // need cost ~0.15 ms of host memcpy per 16-MB block -- what made a file striped over several contexts slower than on one.
+        // (Fewer than 4 newlines in the first over_cap bytes: long lines; then all of it, as before.  Too short a view would be a
+        // loud HAST_ERR_FORMAT from the framer, never a cut read.)
+        size_t ov = std::min(f->over_cap, n_bytes);
+        {
+            const uint8_t *p0 = s.h_buf + f->pad, *p = p0, *const pe = p0 + ov;
+            int nl = 0;
+            while (nl < 4 && p < pe && (p = static_cast<const uint8_t *>(memchr(p, '\n', (size_t)(pe - p))))) { ++nl; ++p; }
+            if (nl == 4) ov = (size_t)(p - p0);
+        }
         pv.n_over = ov;
         pv.eof_view = last != 0 && ov == n_bytes;  // the whole rest of the file is in its view
         if (ov) {
@@ -273,8 +285,11 @@ void hast_names_destroy(hast_names *nm) {
 }
 
 // buffers + events of one slot, on the current device
-static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, size_t block, bool striped) {
-    FQ_TRY(hipHostMalloc((void **)&s.h_buf, buf, hipHostMallocDefault));
+static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, size_t block, bool striped, bool device_blocks = false) {
+    // (a stream of device-side blocks pins no host copy of its blocks: ~0.7 ms per MB, 6 x 17 MB per stream -- the copy is made
+    // if and when hast_fq_block_host_bytes asks for one)
+    s.h_buf_bytes = buf;
+    if (!device_blocks) FQ_TRY(hipHostMalloc((void **)&s.h_buf, buf, hipHostMallocDefault));
     FQ_TRY(hipHostMalloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault));
     FQ_TRY(hipMalloc((void **)&s.d_buf, buf));
     FQ_TRY(hipMalloc((void **)&s.d_st, sizeof(FqState)));
@@ -296,9 +311,14 @@ static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, s
 }
 
 hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, hast_names *names, hast_fq **out) {
+    return hast_fq_create_ex(ctx, block_bytes, n_buffers, names, 0, out);
+}
+hast_status hast_fq_create_ex(hast_ctx *ctx, size_t block_bytes, int n_buffers, hast_names *names, int device_blocks, hast_fq **out) {
     if (!ctx || !out) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (names && names->ctx != ctx) return set_error(HAST_ERR_INVALID, "the name cache belongs to another context");
+    // (contexts of ONE device may share a cache: an insert of one context's stream that is in flight while another's stream
+    // probes can at worst hide a barcode from that probe -- the host then names the record, as for any new barcode)
+    if (names && names->device != hast_ctx_device(ctx)) return set_error(HAST_ERR_INVALID, "the name cache belongs to another device");
     if (block_bytes < 4096 || block_bytes > (1ull << 30)) return set_error(HAST_ERR_INVALID, "block_bytes %zu out of [4 KB, 1 GB]", block_bytes);
     if (n_buffers < 2 || n_buffers > 16) return set_error(HAST_ERR_INVALID, "n_buffers %d out of [2,16]", n_buffers);
     FQ_TRY(hipSetDevice(hast_ctx_device(ctx)));
@@ -319,8 +339,9 @@ hast_status hast_fq_create(hast_ctx *ctx, size_t block_bytes, int n_buffers, has
         delete f;
         return set_error(HAST_ERR_HIP, "hipStreamCreate failed");
     }
+    if (device_blocks) f->source = 2;
     for (Slot &s : f->slots)
-        if (hast_status st = alloc_slot(s, buf, f->max_rec, f->pad, f->block, false)) {
+        if (hast_status st = alloc_slot(s, buf, f->max_rec, f->pad, f->block, false, device_blocks != 0)) {
             hast_fq_destroy(f);
             return st;
         }
@@ -341,7 +362,7 @@ hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t bloc
         return set_error(HAST_ERR_INVALID, "n_buffers_per_ctx %d out of range for %d contexts (3 to 64 buffers in all)", n_buffers_per_ctx, n_ctx);
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i] || hast_ctx_k(ctxs[i]) != hast_ctx_k(ctxs[0])) return set_error(HAST_ERR_INVALID, "contexts need one K");
-        if (names && names[i] && names[i]->ctx != ctxs[i]) return set_error(HAST_ERR_INVALID, "name cache %d belongs to another context", i);
+        if (names && names[i] && names[i]->device != hast_ctx_device(ctxs[i])) return set_error(HAST_ERR_INVALID, "name cache %d belongs to another device", i);
     }
     hast_fq *f = new (std::nothrow) hast_fq();
     if (!f) return set_error(HAST_ERR_OOM, "host allocation failed");
@@ -431,7 +452,7 @@ hast_status hast_fq_acquire(hast_fq *f, uint8_t **host_buf) {
     }
     s.state = Slot::ACQUIRED;
     f->n_acquired++;
-    *host_buf = s.h_buf + f->pad;
+    *host_buf = s.h_buf ? s.h_buf + f->pad : nullptr;          // (NULL on a stream created for device-side blocks)
     return HAST_OK;
 }
 
@@ -460,7 +481,7 @@ static hast_status submit_block(hast_fq *f, size_t n_bytes, int last, bool dev_s
     if (!f) return set_error(HAST_ERR_INVALID, "null argument");
     if (f->n_submitted >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_submit without hast_fq_acquire");
     if (n_bytes > f->block) return set_error(HAST_ERR_INVALID, "block of %zu bytes exceeds the capacity %zu", n_bytes, f->block);
-    if (dev_src ? (f->striped || f->source != 2 || f->n_device_blocks <= f->n_submitted) : f->source == 2)
+    if (dev_src ? (f->striped || f->source != 2 || f->n_device_blocks <= f->n_submitted) : (f->source == 2 || !f->slots[f->n_submitted % f->slots.size()].h_buf))
         return set_error(HAST_ERR_INVALID, dev_src ? "hast_fq_submit_device without hast_fq_device_block" : "a stream takes host blocks or device blocks, not both");
     if (!dev_src) f->source = 1;
     if (f->striped) return submit_striped(f, n_bytes, last);
@@ -505,6 +526,7 @@ hast_status hast_fq_block_host_bytes(hast_fq *f, const uint8_t **bytes) {
     if (s.state != Slot::OPEN) return set_error(HAST_ERR_INVALID, "no open block");
     if (!s.host_view) {
         FQ_TRY(hipSetDevice(dev_of(f, s)));
+        if (!s.h_buf) FQ_TRY(hipHostMalloc((void **)&s.h_buf, s.h_buf_bytes, hipHostMallocDefault));
         hipStream_t hs = ctx_stream_of(ctx_of(f, s));
         FQ_TRY(hipMemcpyAsync(s.h_buf, s.d_buf, f->pad + s.n_bytes, hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipStreamSynchronize(hs));

@@ -71,7 +71,7 @@ struct Batch {                                // accepted chunks the consumer ma
 };
 
 struct Arena {
-    DevBuf syms, windows, acc, need, crc, carry;
+    DevBuf syms, windows, acc, need, crc, carry;   // (need: scratch of the windows pass)
     std::vector<DevBuf> gap;                  // follow-up jobs' symbols (reused from batch to batch)
     size_t gap_used = 0;
     bool busy = false;                        // a published batch lives in it
@@ -260,7 +260,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
     if (n_jobs) {
         GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
         GZ_HIP(launch_search((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint32_t *)g->tabs.p, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint32_t *)g->tabs.p, nullptr, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
         GZ_HIP(hipStreamSynchronize(g->dec_stream));
     }
@@ -289,7 +289,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
             j.status = kStFound;
         }
         GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, (uint32_t *)g->tabs.p, nullptr, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
         GZ_HIP(hipStreamSynchronize(g->dec_stream));
         g->chain.gap_done(g->h_jobs, gaps.size(), input_bits);
@@ -317,7 +317,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
         b->out_hi = b->acc.back().out_off + b->acc.back().job.n_out;
         GZ_HIP(A.acc.ensure(n * sizeof(AccDev)));
         GZ_HIP(A.windows.ensure(n * (size_t)kWindow));
-        GZ_HIP(A.need.ensure(n * sizeof(uint32_t)));
+        GZ_HIP(A.need.ensure(windows_scratch_bytes((uint32_t)n)));
         GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
         GZ_HIP(A.carry.ensure(kWindow));
         if (g->h_crc_cap < n) {
@@ -331,7 +331,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
         GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, g->dec_stream));
         GZ_HIP(hipStreamSynchronize(g->dec_stream));
         GZ_HIP(hipMemcpyAsync(A.carry.p, g->carry_next.p, kWindow, hipMemcpyDeviceToDevice, g->dec_stream));
-        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.need.p, g->dec_stream));
+        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, A.need.p, g->dec_stream));
         GZ_HIP(launch_crc((const AccDev *)A.acc.p, (uint32_t)n, (const uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.crc.p, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->carry_next.p, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToDevice, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->h_crc, A.crc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, g->dec_stream));

@@ -1,6 +1,8 @@
-// gz_core.h -- deflate (RFC 1951) decoding of ONE chunk of a gzip stream by ONE lane, written once for the device
-// (gz_kernels.hip: a lane per chunk) and for the host (tests/native/test_gz_core.cpp runs the same functions chunk by
-// chunk against zlib, so the arithmetic is checked on the CPU before it costs GPU time).
+// gz_core.h -- deflate (RFC 1951) decoding of ONE chunk of a gzip stream, written once for the device and for the host
+// (tests/native/test_gz_core.cpp runs these functions chunk by chunk against zlib, so the arithmetic and the rules for where
+// a chunk ends are checked on the CPU before they cost GPU time).  On the device (gz_kernels.hip) the search's strict header
+// parse, every block's header parse and table construction are these functions run by one lane; the symbol loop of
+// k_gz_decode is decode_huffman re-shaped for a whole wave (uniform bit buffer, tables in LDS, matches copied by all lanes).
 //
 // What it is for (reference: gzstream.h:47, classify.cpp:245-254 -- one zlib stream per input file read
 // through a 303-byte buffer): the drop-in CLI's .fq.gz inputs are inflated ON THE GPU, so that the compressed bytes cross
@@ -31,7 +33,8 @@ namespace gz {
 
 constexpr uint32_t kLit = 1u << 13, kEob = 1u << 14, kSub = 1u << 15;
 constexpr int kLitRoot = 10, kDistRoot = 7;
-constexpr uint32_t kLitTabCap = 2560, kDistTabCap = 1024, kPreTabCap = 128;     // entries (u32); see gz_build_table
+constexpr uint32_t kLitTabCap = 2048, kDistTabCap = 640, kPreTabCap = 128;      // entries (u32): first level + sub-tables (zlib's own bounds for complete codes
+                                                                                 // are 1332 and < 600 at these roots); a code that needs more is refused (kErrTableSize)
 constexpr uint32_t kTabWords = kLitTabCap + kDistTabCap + kPreTabCap;           // a lane's tables, back to back
 constexpr uint32_t kWindow = 32768;
 constexpr uint16_t kMarker = 0x8000;
@@ -366,8 +369,14 @@ GZ_HD void decode_chunk(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32
     uint32_t n = 0, status = kStFound, err = kErrNone;
     bool any = false;
     for (;;) {
-        if (at >= job.stop_bit && any) { status |= kStStop; break; }
-        if (at >= job.stop_bit && !any && !(job.flags & kJobKnown)) { status |= kStStop; break; }
+        if (at >= job.stop_bit && (any || !(job.flags & kJobKnown))) {
+            // a boundary at or behind the stop: the chunk ends here -- unless what follows is a block no search can find (stored,
+            // fixed, or final: the chunk behind this one starts at the first NON-FINAL DYNAMIC header), which this chunk takes too
+            // (pigz and bgzip put an empty stored block between their pieces: without this, every such place costs a follow-up job)
+            bool hidden = false;
+            if (any && at + 3 <= nbits) hidden = (bits_at(w, at) & 7) != 4;
+            if (!hidden) { status |= kStStop; break; }
+        }
         if (at + 3 > nbits) { status |= kStStarved; break; }
         Bits in{w, nbits, 0, 0, 0};
         seek(in, at);

@@ -17,10 +17,11 @@ struct AccDev {                  // an accepted chunk, in stream order
 };
 
 hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint32_t *d_tabs, hipStream_t s);
-// a lane per job; job.sym_off counts from d_syms
-hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint32_t *d_tabs, uint16_t *d_syms, hipStream_t s);
-// d_windows[c] = the 32 KB behind chunk c; d_carry = the 32 KB in front of chunk 0; d_need: scratch, n words
-hipError_t launch_windows(const AccDev *d_acc, uint32_t n, uint8_t *d_windows, const uint8_t *d_carry, uint32_t *d_need, hipStream_t s);
+// a wave per job; job.sym_off = the device address of the job's symbol buffer / 2
+hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s);
+// d_windows[c] = the 32 KB behind chunk c; d_carry = the 32 KB in front of chunk 0; d_scratch: windows_scratch_bytes(n)
+size_t windows_scratch_bytes(uint32_t n);
+hipError_t launch_windows(const AccDev *d_acc, uint32_t n, uint8_t *d_windows, const uint8_t *d_carry, void *d_scratch, hipStream_t s);
 hipError_t launch_crc(const AccDev *d_acc, uint32_t n, const uint8_t *d_windows, const uint8_t *d_carry, uint32_t *d_crc, hipStream_t s);
 // bytes [o_lo, o_hi) of the stream out of chunks c_first .. c_first + n_chunks - 1 (max_syms = the largest n_out among them) -> d_dst[0 ..)
 hipError_t launch_translate(const AccDev *d_acc, uint32_t c_first, uint32_t n_chunks, uint32_t max_syms, const uint8_t *d_windows, const uint8_t *d_carry,

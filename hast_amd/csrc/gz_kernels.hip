@@ -3,16 +3,16 @@
 // chunk of the compressed bytes; here are the launches around it:
 //   k_gz_search     a wave per chunk: 64 bit positions per step through the cheap header test (gz_core.h candidate), survivors
 //                   parsed in full by their own lane, lowest position first
-//   k_gz_decode     a LANE per chunk: blocks -> 16-bit symbols (literal, or marker "byte i of the 32 KB in front of this chunk").
-//                   Serial by nature -- Huffman codes have no boundaries anyone wrote down -- so the parallelism is chunks:
-//                   a 614-MB .fq.gz is 19 000 chunks of 32 KB, all in flight at once
-//   k_gz_window_a   per accepted chunk: the 32 KB behind it when they hold no marker (FASTQ: nearly always) -- else flagged
-//   k_gz_window_b   ONE workgroup walks the flagged chunks in stream order (each needs the window in front of it)
+//   k_gz_decode     a WAVE per chunk: blocks -> 16-bit symbols (literal, or marker "byte i of the 32 KB in front of this chunk").
+//                   Serial by nature -- Huffman codes have no boundaries anyone wrote down -- so the parallelism is chunks (a
+//                   614-MB .fq.gz is 19 000 chunks of 32 KB) plus, inside a chunk, the lanes that copy a match together
+//   k_gz_maps / k_gz_carry / k_gz_window   the 32 KB behind every accepted chunk (each depends on the one in front of it: maps
+//                   composed per group of 64 chunks in LDS, the groups chained by one workgroup, then everything at once)
 //   k_gz_crc        per chunk: CRC-32 of its bytes by 256 slices, combined with GF(2) operators (gz_core.h crc_*)
 //   k_gz_translate  symbols -> bytes (markers through the window in front of the chunk) straight into the caller's buffer,
 //                   e.g. a block buffer of the FASTQ framer
-// Bound: k_gz_decode by memory LATENCY per lane (table look-ups and copies are dependent loads), hence by lanes in flight; the
-// other kernels stream (2 B read + 1 B written per byte of output).
+// Bound: k_gz_decode by LATENCY per symbol (an LDS table look-up depends on the bits the look-up in front of it consumed), hence by
+// waves in flight (14 per CU: 11 KB of tables each); the other kernels stream (2 B read + 1 B written per byte of output).
 #include <hip/hip_runtime.h>
 
 #include "gz_core.h"
@@ -22,7 +22,11 @@ namespace hast {
 namespace gz {
 
 // ---- search: the first position in [from_bit, from_bit + search_to_lo) that parses as a non-final dynamic block header -----
+// A wave per chunk, 64 bit positions per step, three sieves: (1) the 17 header bits every lane tests for itself (type bits 100b,
+// HLIT, HDIST in range: one position in 9 passes); (2) the survivors are queued (LDS, in position order) and, 64 at a time, tested
+// for a COMPLETE code-length code (one in ~100 passes); (3) what is left is parsed in full by one lane, lowest position first.
 __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits, uint32_t *tabs) {
+    __shared__ uint32_t s_q[128];                                             // positions (relative to from_bit) that passed sieve 1
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob &job = jobs[j];
@@ -39,23 +43,52 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
     if (to > lim) to = lim;
     uint32_t *my_tabs = tabs + (size_t)j * kTabWords;
     uint64_t found = ~0ull;
-    for (uint64_t base = from; base < to && found == ~0ull; base += 64) {
-        const uint64_t bit = base + lane;
+    uint32_t qn = 0;
+    // sieves 2 + 3 over the first `cnt` queue entries (position order)
+    auto drain = [&](uint32_t cnt) {
         bool c = false;
-        if (bit < to) c = candidate(bits_at(w, bit), bits_at(w, bit + 56));
+        uint64_t bit = 0;
+        if (lane < cnt) {
+            bit = from + s_q[lane];
+            c = candidate(bits_at(w, bit), bits_at(w, bit + 56));
+        }
         unsigned long long mask = __ballot(c);
-        while (mask) {                                                          // survivors, lowest position first (about 1 in 1500)
+        while (mask && found == ~0ull) {
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1;
             int ok = 0;
             if ((int)lane == l) ok = header_parses(w, nbits, bit, my_tabs) ? 1 : 0;
             ok = __shfl(ok, l);
-            if (ok) {
-                found = base + (uint64_t)l;
-                break;
-            }
+            if (ok) found = from + s_q[l];
+        }
+        // the rest of the queue moves to the front
+        const uint32_t rest = qn - cnt;
+        uint32_t v = 0;
+        if (lane < rest) v = s_q[cnt + lane];
+        __syncthreads();
+        if (lane < rest) s_q[lane] = v;
+        qn = rest;
+        __syncthreads();
+    };
+    for (uint64_t base = from; base < to && found == ~0ull; base += 64) {
+        const uint64_t bit = base + lane;
+        bool pre = false;
+        if (bit < to) {
+            const uint64_t wi = bit >> 5;
+            const uint32_t sh = (uint32_t)(bit & 31);
+            const uint32_t v = (uint32_t)((((uint64_t)w[wi + 1] << 32) | w[wi]) >> sh);
+            pre = (v & 7) == 4 && ((v >> 3) & 31) <= 29 && ((v >> 8) & 31) <= 29;
+        }
+        const unsigned long long pm = __ballot(pre);
+        if (pm) {
+            const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            if (pre) s_q[at] = (uint32_t)(bit - from);
+            qn += (uint32_t)__popcll(pm);
+            __syncthreads();
+            if (qn >= 64) drain(64);
         }
     }
+    while (qn && found == ~0ull) drain(qn < 64 ? qn : 64);
     if (lane == 0) {
         job.start_bit = found == ~0ull ? from : found;
         job.end_bit = job.start_bit;
@@ -65,67 +98,276 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
     }
 }
 
-// ---- decode: a lane per chunk ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits, uint32_t *tabs, uint16_t *syms) {
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+// ---- decode: a WAVE per chunk -----------------------------------------------------------------------------------------------------
+// Huffman decoding is serial (no code boundary is known before the code in front of it is decoded), so one symbol at a time --
+// but by the whole wave in lockstep: every lane carries the same bit buffer and reads the same table entry (a broadcast read of
+// the tables in LDS, built per block by lane 0 with the code of gz_core.h), which keeps the control flow uniform, and the part
+// that IS parallel runs on all lanes: a match of length L is copied by L lanes at once.  The copy's load is issued when the match
+// is decoded and its store one symbol later, so its latency hides behind the next table look-ups.  Output symbols: literal byte, or
+// kMarker + i = "byte i of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
+// Lanes of ONE wave write and read the symbol buffer: wavefront-scope accesses, which the hardware keeps in program order.
+struct WBits {                     // wave-uniform bit input with one word of look-ahead (its load is issued a refill early)
+    const uint32_t *w;
+    uint64_t nwords;               // words that may be read (real words + padding)
+    uint64_t bb;
+    uint64_t wp;                   // index of `ahead`
+    uint32_t bc, ahead;
+};
+__device__ __forceinline__ uint32_t wload(const WBits &b, uint64_t i) { return i < b.nwords ? b.w[i] : 0u; }
+__device__ __forceinline__ void wseek(WBits &b, uint64_t bit) {
+    const uint64_t wi = bit >> 5;
+    const uint32_t sh = (uint32_t)(bit & 31);
+    b.bb = (uint64_t)wload(b, wi) >> sh;
+    b.bc = 32 - sh;
+    b.wp = wi + 1;
+    b.ahead = wload(b, b.wp);
+}
+__device__ __forceinline__ void wrefill(WBits &b) {
+    if (b.bc <= 32) {
+        b.bb |= (uint64_t)b.ahead << b.bc;
+        b.bc += 32;
+        b.wp++;
+        b.ahead = wload(b, b.wp);
+    }
+}
+__device__ __forceinline__ uint64_t wpos(const WBits &b) { return b.wp * 32 - b.bc; }
+__device__ __forceinline__ void sym_store(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ uint16_t sym_load(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+
+__global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
+    __shared__ uint32_t s_tab[kTabWords];
+    __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob job = jobs[j];
     if (!(job.status & kStFound)) {
-        job.n_out = 0;
-        job.end_bit = job.start_bit;
-        jobs[j] = job;
+        if (lane == 0) {
+            jobs[j].n_out = 0;
+            jobs[j].end_bit = job.start_bit;
+        }
         return;
     }
-    decode_chunk(job, w, nbits, tabs + (size_t)j * kTabWords, syms + job.sym_off);
-    jobs[j] = job;
+    uint16_t *const sym = reinterpret_cast<uint16_t *>((uintptr_t)(job.sym_off * 2));
+    const uint32_t cap = job.sym_cap;
+    const bool no_history = (job.flags & kJobNoHistory) != 0;
+    const uint32_t *const lit = s_tab, *const dst = s_tab + kLitTabCap;
+    constexpr uint32_t LM = (1u << kLitRoot) - 1, DM = (1u << kDistRoot) - 1;
+    WBits in{w, ((nbits + 31) >> 5) + 2, 0, 0, 0, 0};
+    uint64_t at = job.start_bit;
+    uint32_t n = 0, status = kStFound, err = kErrNone;
+    bool any = false;
+    for (;;) {
+        if (at >= job.stop_bit && (any || !(job.flags & kJobKnown))) {
+            // a boundary at or behind the stop: the chunk ends here -- unless what follows is a block no search can find (stored,
+            // fixed, or final: the chunk behind this one starts at the first NON-FINAL DYNAMIC header), which this chunk takes too
+            bool hidden = false;
+            if (any && at + 3 <= nbits) {
+                const uint32_t h = (uint32_t)(bits_at(w, at) & 7);
+                hidden = h != 4;
+            }
+            if (!hidden) { status |= kStStop; break; }
+        }
+        if (at + 3 > nbits) { status |= kStStarved; break; }
+        wseek(in, at);
+        wrefill(in);
+        const uint32_t final = (uint32_t)(in.bb & 1), type = (uint32_t)((in.bb >> 1) & 3);
+        in.bb >>= 3;
+        in.bc -= 3;
+        uint32_t n2 = n, rc = 0;
+        if (type == 0) {
+            const uint64_t byte = (wpos(in) + 7) >> 3;
+            if ((byte + 4) * 8 > nbits) { status |= kStStarved; break; }
+            const uint8_t *bytes = reinterpret_cast<const uint8_t *>(w) + byte;
+            const uint32_t len = bytes[0] | ((uint32_t)bytes[1] << 8), nlen = bytes[2] | ((uint32_t)bytes[3] << 8);
+            if ((len ^ 0xFFFFu) != nlen) { status |= kStError; err = kErrStoredLen; break; }
+            if ((byte + 4 + len) * 8 > nbits) { status |= kStStarved; break; }
+            if (n + len + 4 > cap) { status |= kStNoRoom; break; }
+            for (uint32_t k = lane; k < len; k += 64) sym_store(sym + n + k, bytes[4 + k]);
+            n2 = n + len;
+            at = (byte + 4 + len) * 8;
+        } else if (type == 3) {
+            status |= kStError;
+            err = kErrBlockType;
+            break;
+        } else {
+            // tables for this block: lane 0 parses the header / builds them in LDS (gz_core.h), the wave waits
+            __syncthreads();                                                  // (everyone is done with the previous block's tables)
+            if (lane == 0) {
+                Tables t = tables_at(s_tab);
+                uint32_t bad = 0;
+                uint64_t behind = wpos(in);
+                if (type == 1) fixed_tables(t);
+                else {
+                    Bits hb{w, nbits, 0, 0, 0};
+                    seek(hb, behind);
+                    bad = read_dynamic(hb, t, false);
+                    if (bad && overran(hb)) bad = 0x80000000u;                // an "error" read out of the padding: the block is not all here
+                    if (!bad && overran(hb)) bad = 0x80000000u;
+                    behind = pos(hb);
+                }
+                s_hdr[0] = bad;
+                s_hdr[1] = (uint32_t)behind;
+                s_hdr[2] = (uint32_t)(behind >> 32);
+            }
+            __syncthreads();
+            const uint32_t bad = s_hdr[0];
+            if (bad) {
+                if (bad == 0x80000000u) status |= kStStarved;
+                else { status |= kStError; err = bad; }
+                break;
+            }
+            wseek(in, (uint64_t)s_hdr[1] | ((uint64_t)s_hdr[2] << 32));
+            // ---- the block's symbols ----
+            uint16_t pend_v = 0;                                              // a copy whose load is under way: value, target, "this lane has one"
+            uint32_t pend_at = 0;
+            bool pend = false;
+            for (;;) {
+                if (n2 + 260 > cap) { rc = kStNoRoom; break; }
+                if (wpos(in) > nbits) { rc = kStStarved; break; }
+                wrefill(in);
+                uint32_t e = lit[in.bb & LM];
+                if (e & kSub) {
+                    in.bb >>= kLitRoot;
+                    in.bc -= kLitRoot;
+                    e = lit[(e >> 16) + (uint32_t)(in.bb & ((1u << ((e >> 8) & 31)) - 1))];
+                }
+                in.bb >>= (e & 0xFF);
+                in.bc -= (e & 0xFF);
+                if (e & kLit) {
+                    if (pend) sym_store(sym + pend_at, pend_v);
+                    pend = false;
+                    if (lane == 0) sym_store(sym + n2, (uint16_t)(e >> 16));
+                    ++n2;
+                    continue;
+                }
+                if ((e & 0xFF) == 0) { err = kErrLitCode; rc = kStError; break; }
+                if (e & kEob) break;
+                const uint32_t leb = (e >> 8) & 31;
+                const uint32_t len = (e >> 16) + (uint32_t)(in.bb & ((1u << leb) - 1));
+                in.bb >>= leb;
+                in.bc -= leb;
+                wrefill(in);
+                uint32_t d = dst[in.bb & DM];
+                if (d & kSub) {
+                    in.bb >>= kDistRoot;
+                    in.bc -= kDistRoot;
+                    d = dst[(d >> 16) + (uint32_t)(in.bb & ((1u << ((d >> 8) & 31)) - 1))];
+                }
+                if ((d & 0xFF) == 0) { err = kErrDistCode; rc = kStError; break; }
+                in.bb >>= (d & 0xFF);
+                in.bc -= (d & 0xFF);
+                const uint32_t deb = (d >> 8) & 31;
+                const uint32_t distance = (d >> 16) + (uint32_t)(in.bb & ((1u << deb) - 1));
+                in.bb >>= deb;
+                in.bc -= deb;
+                if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; rc = kStError; break; }
+                // the copy in front of this one lands before this one reads
+                if (pend) sym_store(sym + pend_at, pend_v);
+                pend = false;
+                // symbol n2 + k comes from n2 + k - distance, or -- periodic -- from the first `distance` of them; what lies in
+                // front of the chunk is a marker
+                for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    if (pend) sym_store(sym + pend_at, pend_v);               // (matches longer than 64: one round of lanes at a time)
+                    pend = k < len;
+                    if (pend) {
+                        const uint32_t kk = k < distance ? k : k % distance;
+                        const int64_t src = (int64_t)n2 - (int64_t)distance + (int64_t)kk;
+                        pend_at = n2 + k;
+                        pend_v = src < 0 ? (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src)) : sym_load(sym + src);
+                    }
+                }
+                n2 += len;
+            }
+            if (pend) sym_store(sym + pend_at, pend_v);
+            if (rc) {
+                status |= rc;
+                break;
+            }
+            if (wpos(in) > nbits) { status |= kStStarved; break; }
+            at = wpos(in);
+        }
+        n = n2;
+        any = true;
+        if (final) { status |= kStFinal; break; }
+    }
+    if (!any) status |= kStNoBlock;
+    if (lane == 0) {
+        jobs[j].end_bit = at;
+        jobs[j].n_out = n;
+        jobs[j].status = status;
+        jobs[j].err_code = (status & kStError) ? err : kErrNone;
+    }
 }
 
-// ---- windows -------------------------------------------------------------------------------------------------------------------
-// windows[c] = the kWindow bytes of the stream behind accepted chunk c (window -1 = `carry`, what the batch in front left)
-__global__ void __launch_bounds__(256) k_gz_window_a(const AccDev *acc, uint32_t n_acc, uint8_t *windows, uint32_t *need) {
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    if (c >= n_acc) return;
-    const AccDev a = acc[c];
-    uint8_t *wdw = windows + (size_t)c * kWindow;
-    const uint16_t *s = a.sym;
-    if (a.n_out < kWindow && !a.no_history) {                                   // part of the window is the window in front
-        if (tid == 0) need[c] = 1;
-        return;
-    }
-    const uint32_t zeros = a.n_out < kWindow ? kWindow - a.n_out : 0u;          // (a member shorter than the window: nothing valid copies from there)
-    const uint32_t first = a.n_out - (kWindow - zeros);
-    int marker = 0;
-    for (uint32_t k = tid; k < kWindow; k += 256) {
-        uint32_t v = 0;
-        if (k >= zeros) {
-            v = s[first + (k - zeros)];
-            marker |= v >= kMarker;
-        }
-        wdw[k] = (uint8_t)v;
-    }
-    marker = __syncthreads_or(marker);
-    if (tid == 0) need[c] = marker ? 1u : 0u;
-}
-__global__ void __launch_bounds__(1024) k_gz_window_b(const AccDev *acc, uint32_t n_acc, uint8_t *windows, const uint8_t *carry, const uint32_t *need) {
+// ---- windows: W[c] = the kWindow bytes of the stream behind accepted chunk c (W[-1] = `carry`, what the batch in front left) ----
+// W[c] depends on W[c-1] wherever chunk c's last 32 KB hold markers (or are fewer than 32 KB): a chain through the whole batch.
+// A "map" of 32768 16-bit entries says for every byte of a window what it is: a literal, or kMarker + i = byte i of an EARLIER
+// window; maps compose, so the chain is cut into groups of kGroup chunks:
+//   k_gz_maps    a workgroup per group walks its chunks in order, composing in LDS: maps[c] = W[c] in terms of the window in front
+//                of the GROUP
+//   k_gz_carry   one workgroup walks the groups: the window in front of each group (gwin[g]) from the last map of the group before
+//   k_gz_window  every chunk at once: W[c] = maps[c] resolved through gwin[group of c]
+constexpr uint32_t kGroup = 64;
+__global__ void __launch_bounds__(1024) k_gz_maps(const AccDev *acc, uint32_t n_acc, uint16_t *maps) {
+    extern __shared__ uint16_t s_map[];                                       // 2 x kWindow
     const uint32_t tid = threadIdx.x;
-    for (uint32_t c = 0; c < n_acc; ++c) {
-        if (!need[c]) continue;                                                 // (uniform)
+    const uint32_t c0 = blockIdx.x * kGroup, c1 = c0 + kGroup < n_acc ? c0 + kGroup : n_acc;
+    uint16_t *cur = s_map, *nxt = s_map + kWindow;
+    for (uint32_t k = tid; k < kWindow; k += 1024) cur[k] = (uint16_t)(kMarker + k);      // the identity: byte k of the window in front of the group
+    __syncthreads();
+    for (uint32_t c = c0; c < c1; ++c) {
         const AccDev a = acc[c];
-        const uint8_t *prev = c ? windows + (size_t)(c - 1) * kWindow : carry;
-        uint8_t *wdw = windows + (size_t)c * kWindow;
         const uint16_t *s = a.sym;
-        const uint32_t own = a.n_out < kWindow ? a.n_out : kWindow;             // symbols of this chunk in its window
+        const uint32_t own = a.n_out < kWindow ? a.n_out : kWindow;           // symbols of this chunk in its window
+        uint16_t *out = maps + (size_t)c * kWindow;
         for (uint32_t k = tid; k < kWindow; k += 1024) {
-            uint8_t b;
-            if (k < kWindow - own) b = prev[k + own];                           // the window in front, shifted
+            uint16_t v;
+            if (k < kWindow - own) v = a.no_history ? (uint16_t)0 : cur[k + own];      // the window in front, shifted (nothing in front of a member)
             else {
-                const uint32_t v = s[a.n_out - own + (k - (kWindow - own))];
-                b = v < kMarker ? (uint8_t)v : prev[v - kMarker];
+                v = s[a.n_out - own + (k - (kWindow - own))];
+                if (v >= kMarker) v = cur[v - kMarker];
             }
-            wdw[k] = b;
+            nxt[k] = v;
+            out[k] = v;
         }
-        __threadfence();                                                        // the next flagged chunk reads this window
         __syncthreads();
+        uint16_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+}
+__global__ void __launch_bounds__(1024) k_gz_carry(const uint16_t *maps, uint32_t n_acc, const uint8_t *carry, uint8_t *gwin) {
+    extern __shared__ uint8_t s_win[];                                        // 2 x kWindow
+    const uint32_t tid = threadIdx.x;
+    uint8_t *cur = s_win, *nxt = s_win + kWindow;
+    for (uint32_t k = tid; k < kWindow; k += 1024) cur[k] = carry[k];
+    __syncthreads();
+    const uint32_t n_groups = (n_acc + kGroup - 1) / kGroup;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        uint8_t *out = gwin + (size_t)g * kWindow;
+        for (uint32_t k = tid; k < kWindow; k += 1024) out[k] = cur[k];
+        const uint32_t last = (g + 1) * kGroup < n_acc ? (g + 1) * kGroup - 1 : n_acc - 1;
+        const uint16_t *m = maps + (size_t)last * kWindow;
+        for (uint32_t k = tid; k < kWindow; k += 1024) {
+            const uint16_t v = m[k];
+            nxt[k] = v < kMarker ? (uint8_t)v : cur[v - kMarker];
+        }
+        __syncthreads();
+        uint8_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+}
+__global__ void __launch_bounds__(256) k_gz_window(const uint16_t *maps, uint32_t n_acc, const uint8_t *gwin, uint8_t *windows) {
+    const uint32_t c = blockIdx.x;
+    if (c >= n_acc) return;
+    const uint16_t *m = maps + (size_t)c * kWindow;
+    const uint8_t *gw = gwin + (size_t)(c / kGroup) * kWindow;
+    uint8_t *out = windows + (size_t)c * kWindow;
+    for (uint32_t k = threadIdx.x; k < kWindow; k += 256) {
+        const uint16_t v = m[k];
+        out[k] = v < kMarker ? (uint8_t)v : gw[v - kMarker];
     }
 }
 
@@ -148,11 +390,21 @@ __global__ void __launch_bounds__(256) k_gz_crc(const AccDev *acc, uint32_t n_ac
     const uint32_t slice = (n + 255) / 256;
     const long long hi = (long long)n - (long long)(255 - tid) * slice, lo = hi - slice;
     uint32_t v = 0xFFFFFFFFu;
-    for (long long i = lo < 0 ? 0 : lo; i < hi; ++i) {
-        const uint32_t x = s[i];
+    auto step = [&](uint32_t x) {
         const uint32_t b = x < kMarker ? x : prev[x - kMarker];
         v = s_tab[(v ^ b) & 0xFF] ^ (v >> 8);
+    };
+    // a lane's slice is contiguous: 8 symbols per 16-byte load (the buffer is 16-byte aligned), so that a fetched line is used up
+    // by the next few loads of the same lane -- symbol by symbol, the 64 lanes of a load touch 64 lines for 2 bytes each and evict
+    // one another's lines before they come back for the rest
+    long long i = lo < 0 ? 0 : lo;
+    for (; i < hi && (i & 7); ++i) step(s[i]);
+    for (; i + 8 <= hi; i += 8) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(s + i);
+        step(q.x & 0xFFFFu); step(q.x >> 16); step(q.y & 0xFFFFu); step(q.y >> 16);
+        step(q.z & 0xFFFFu); step(q.z >> 16); step(q.w & 0xFFFFu); step(q.w >> 16);
     }
+    for (; i < hi; ++i) step(s[i]);
     s_part[tid] = hi <= 0 ? 0u : v ^ 0xFFFFFFFFu;
     uint32_t xk = crc_x2nmodp(slice, 3);
     __syncthreads();
@@ -165,7 +417,7 @@ __global__ void __launch_bounds__(256) k_gz_crc(const AccDev *acc, uint32_t n_ac
 }
 
 // ---- translate: the bytes [o_lo, o_hi) of the inflated stream, taken from the chunks acc[c_first ..], to dst[0 ..) ---------------
-constexpr uint32_t kTile = 4096;                                                // symbols per workgroup
+constexpr uint32_t kTile = 8192;                                                // symbols per workgroup
 __global__ void __launch_bounds__(256) k_gz_translate(const AccDev *acc, uint32_t c_first, const uint8_t *windows, const uint8_t *carry,
                                                       uint64_t o_lo, uint64_t o_hi, uint8_t *dst) {
     const uint32_t c = c_first + blockIdx.y;
@@ -175,11 +427,29 @@ __global__ void __launch_bounds__(256) k_gz_translate(const AccDev *acc, uint32_
     const uint8_t *prev = c ? windows + (size_t)(c - 1) * kWindow : carry;
     const uint16_t *s = a.sym;
     const uint32_t t1 = t0 + kTile < a.n_out ? t0 + kTile : a.n_out;
-    for (uint32_t i = t0 + threadIdx.x; i < t1; i += 256) {
+    auto byte_of = [&](uint32_t x) -> uint32_t { return x < kMarker ? x : prev[x - kMarker]; };
+    // 8 symbols per lane and step: one 16-byte load (the symbol buffer is 16-byte aligned, tiles start at multiples of 8)
+    for (uint32_t i = t0 + 8 * threadIdx.x; i < t1; i += 8 * 256) {
         const uint64_t o = a.out_off + i;
-        if (o < o_lo || o >= o_hi) continue;
-        const uint32_t x = s[i];
-        dst[o - o_lo] = x < kMarker ? (uint8_t)x : prev[x - kMarker];
+        if (o >= o_hi || o + 8 <= o_lo) continue;
+        if (i + 8 <= t1 && o >= o_lo && o + 8 <= o_hi) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(s + i);
+            const uint32_t lo4 = byte_of(q.x & 0xFFFFu) | byte_of(q.x >> 16) << 8 | byte_of(q.y & 0xFFFFu) << 16 | byte_of(q.y >> 16) << 24;
+            const uint32_t hi4 = byte_of(q.z & 0xFFFFu) | byte_of(q.z >> 16) << 8 | byte_of(q.w & 0xFFFFu) << 16 | byte_of(q.w >> 16) << 24;
+            uint8_t *d = dst + (o - o_lo);
+            if ((reinterpret_cast<uintptr_t>(d) & 3) == 0) {
+                reinterpret_cast<uint32_t *>(d)[0] = lo4;
+                reinterpret_cast<uint32_t *>(d)[1] = hi4;
+            } else {
+                for (int k = 0; k < 4; ++k) d[k] = (uint8_t)(lo4 >> (8 * k));
+                for (int k = 0; k < 4; ++k) d[4 + k] = (uint8_t)(hi4 >> (8 * k));
+            }
+        } else {
+            for (uint32_t k = i; k < i + 8 && k < t1; ++k) {
+                const uint64_t ok = a.out_off + k;
+                if (ok >= o_lo && ok < o_hi) dst[ok - o_lo] = (uint8_t)byte_of(s[k]);
+            }
+        }
     }
 }
 
@@ -189,15 +459,27 @@ hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint
     hipLaunchKernelGGL(k_gz_search, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits, d_tabs);
     return hipGetLastError();
 }
-hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint32_t *d_tabs, uint16_t *d_syms, hipStream_t s) {
+hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_decode, dim3((n + 63) / 64), dim3(64), 0, s, d_jobs, n, d_w, nbits, d_tabs, d_syms);
+    hipLaunchKernelGGL(k_gz_decode, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits);
     return hipGetLastError();
 }
-hipError_t launch_windows(const AccDev *d_acc, uint32_t n, uint8_t *d_windows, const uint8_t *d_carry, uint32_t *d_need, hipStream_t s) {
+size_t windows_scratch_bytes(uint32_t n) { return (size_t)n * kWindow * sizeof(uint16_t) + (size_t)((n + kGroup - 1) / kGroup) * kWindow; }
+hipError_t launch_windows(const AccDev *d_acc, uint32_t n, uint8_t *d_windows, const uint8_t *d_carry, void *d_scratch, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_window_a, dim3(n), dim3(256), 0, s, d_acc, n, d_windows, d_need);
-    hipLaunchKernelGGL(k_gz_window_b, dim3(1), dim3(1024), 0, s, d_acc, n, d_windows, d_carry, d_need);
+    uint16_t *maps = reinterpret_cast<uint16_t *>(d_scratch);
+    uint8_t *gwin = reinterpret_cast<uint8_t *>(maps + (size_t)n * kWindow);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gz_maps), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWindow * (int)sizeof(uint16_t));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gz_carry), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kWindow);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const uint32_t n_groups = (n + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(k_gz_maps, dim3(n_groups), dim3(1024), 2 * kWindow * sizeof(uint16_t), s, d_acc, n, maps);
+    hipLaunchKernelGGL(k_gz_carry, dim3(1), dim3(1024), 2 * kWindow, s, maps, n, d_carry, gwin);
+    hipLaunchKernelGGL(k_gz_window, dim3(n), dim3(256), 0, s, maps, n, gwin, d_windows);
     return hipGetLastError();
 }
 hipError_t launch_crc(const AccDev *d_acc, uint32_t n, const uint8_t *d_windows, const uint8_t *d_carry, uint32_t *d_crc, hipStream_t s) {

@@ -277,7 +277,7 @@ typedef struct {
     const uint32_t *unknown;   /* [n_unknown] indices of the records whose ids the caller has to fill in, or NULL: all of them */
     uint64_t n_unknown;
 } hast_fq_block;
-/* Device-side cache barcode text -> id of one GPU, shared by the FASTQ streams of a context: barcodes repeat (hundreds of
+/* Device-side cache barcode text -> id of one GPU, shared by the FASTQ streams of all contexts on that GPU: barcodes repeat (hundreds of
  * reads each), so after the first blocks the framer names almost every record itself and the host only sees new barcodes
  * (and the ones longer than 15 bytes).  The ids still come from the caller's dictionary -- one per job, the same on every
  * GPU -- and hast_fq_commit teaches the cache what the caller named.  max_barcodes sizes it (2 x 32 B per barcode); more
@@ -286,6 +286,9 @@ typedef struct hast_names hast_names;
 hast_status hast_names_create(hast_ctx *, size_t max_barcodes, hast_names **out);
 void        hast_names_destroy(hast_names *);
 hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_names *names_or_null, hast_fq **out);
+/* device_blocks != 0: a stream of device-side blocks only (hast_fq_device_block / hast_fq_submit_device, below): no pinned host
+ * copy of the block buffers is set up (hast_fq_acquire hands out NULL), which saves ~0.1 s of page pinning per stream. */
+hast_status hast_fq_create_ex(hast_ctx *, size_t block_bytes, int n_buffers, hast_names *names_or_null, int device_blocks, hast_fq **out);
 /* The blocks of ONE input stream on several contexts in turn (block i -> ctxs[i % n_ctx], one context per GPU; several
  * contexts on one GPU also work): the reference spreads the reads of one file over all its workers (classify.cpp:211-219),
  * one process per file would leave all GPUs but two idle on HAST's two input files (HAST.sh:162-166).  A block is framed

@@ -4,7 +4,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_cli_gpu.py -x -q -k "gz or device_inflate or parallel_ingest" > $O/r4c_pytest_cli.log 2>&1; echo "pytest cli rc=$? $(tail -1 $O/r4c_pytest_cli.log)"
+timeout -k 10 600 python -m pytest tests/test_gz_gpu.py -x -q > $O/r4c_pytest_gz.log 2>&1; echo "pytest gz rc=$? $(tail -1 $O/r4c_pytest_gz.log)"
+timeout -k 10 600 python -m pytest tests/test_cli_gpu.py tests/test_fq_gpu.py -x -q -k "gz or device_inflate or parallel_ingest or striped" > $O/r4c_pytest_cli.log 2>&1; echo "pytest cli rc=$? $(tail -1 $O/r4c_pytest_cli.log)"
 D=$(mktemp -d /tmp/hast_e2e.XXXXXX)
 tools/gen_fastq $D 10000000 5000000 100000 21 150 64 0 || exit 1
 ARGS="--hap0 $D/hap0.mer --hap1 $D/hap1.mer --weight0 1.04"
