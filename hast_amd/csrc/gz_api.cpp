@@ -395,6 +395,7 @@ extern "C" {
 hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes, size_t seg_chunks, double room, hast_gz **out) {
     if (!ctx || !path || !out) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
+    const double t_open0 = now_s();
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return set_error(HAST_ERR_IO, "cannot read %s", path);
     struct stat sb;
@@ -456,6 +457,7 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
         return st;
     }
     hast_gz *raw = g.release();
+    raw->st.open_s = now_s() - t_open0;
     raw->uploader = std::thread(upload_loop, raw);
     raw->producer = std::thread(produce_loop, raw);
     *out = raw;

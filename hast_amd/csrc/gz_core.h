@@ -229,7 +229,9 @@ GZ_HD Tables tables_at(uint32_t *words) { return Tables{words, words + kLitTabCa
 
 // the header of a dynamic block behind its 3 type bits: code lengths -> tables.  strict: zlib's completeness rules (what the
 // search demands of a candidate).  Returns kErrNone or the reason; the caller looks at overran() for "input ended".
-GZ_HD uint32_t read_dynamic(Bits &in, Tables &t, bool strict) {
+// build = false: only the checks (the search's strict parse of a candidate needs no literal / distance tables: building them is
+// most of the work -- ~300 candidates per chunk reach this point when no block starts in it)
+GZ_HD uint32_t read_dynamic(Bits &in, Tables &t, bool strict, bool build = true) {
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     refill(in);
     const int hlit = (int)take(in, 5) + 257, hdist = (int)take(in, 5) + 1, hclen = (int)take(in, 4) + 4;
@@ -269,6 +271,7 @@ GZ_HD uint32_t read_dynamic(Bits &in, Tables &t, bool strict) {
     }
     if (lens[256] == 0) return kErrNoEob;
     if (strict && (!complete(lens, hlit, true) || !complete(lens + hlit, hdist, true))) return kErrIncomplete;
+    if (!build) return kErrNone;
     if (uint32_t bad = build_table(lens, hlit, 0, t.lit, kLitTabCap, kLitRoot)) return bad;
     if (uint32_t bad = build_table(lens + hlit, hdist, 1, t.dist, kDistTabCap, kDistRoot)) return bad;
     return kErrNone;
@@ -435,7 +438,7 @@ GZ_HD bool header_parses(const uint32_t *w, uint64_t nbits, uint64_t bit, uint32
     Tables t = tables_at(tabs);
     Bits in{w, nbits, 0, 0, 0};
     seek(in, bit + 3);
-    return read_dynamic(in, t, true) == kErrNone && !overran(in);
+    return read_dynamic(in, t, true, false) == kErrNone && !overran(in);
 }
 
 // ---- CRC-32 (IEEE, reflected) as polynomial arithmetic over GF(2), after zlib's crc32.c (x2nmodp / multmodp) -----------------

@@ -102,10 +102,10 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
 // Huffman decoding is serial (no code boundary is known before the code in front of it is decoded), so one symbol at a time --
 // but by the whole wave in lockstep: every lane carries the same bit buffer and reads the same table entry (a broadcast read of
 // the tables in LDS, built per block by lane 0 with the code of gz_core.h), which keeps the control flow uniform, and the part
-// that IS parallel runs on all lanes: a match of length L is copied by L lanes at once.  The copy's load is issued when the match
-// is decoded and its store one symbol later, so its latency hides behind the next table look-ups.  Output symbols: literal byte, or
-// kMarker + i = "byte i of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
-// Lanes of ONE wave write and read the symbol buffer: wavefront-scope accesses, which the hardware keeps in program order.
+// that IS parallel runs on all lanes: a match of length L is copied by L lanes at once -- out of a ring of the chunk's last 4096
+// symbols in LDS when it reaches back less than that (a global load per match would put ~1 us on the path of every symbol behind
+// it), out of the symbol buffer otherwise (behind a fence, past the L1).  Output symbols: literal byte, or kMarker + i = "byte i
+// of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
 struct WBits {                     // wave-uniform bit input with one word of look-ahead (its load is issued a refill early)
     const uint32_t *w;
     uint64_t nwords;               // words that may be read (real words + padding)
@@ -132,11 +132,15 @@ __device__ __forceinline__ void wrefill(WBits &b) {
 }
 __device__ __forceinline__ uint64_t wpos(const WBits &b) { return b.wp * 32 - b.bc; }
 __device__ __forceinline__ void sym_store(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-__device__ __forceinline__ uint16_t sym_load(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ uint16_t sym_load_far(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (past the L1)
 
 __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
     __shared__ uint32_t s_tab[kTabWords];
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
+    // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ nearly all: the records in front) is
+    // copied out of LDS -- a global load per match would put ~1 us of latency on the path of every symbol behind it
+    constexpr uint32_t kRing = 4096, kRingReach = kRing - 320;
+    __shared__ uint16_t s_ring[kRing];
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob job = jobs[j];
@@ -182,7 +186,15 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
             if ((len ^ 0xFFFFu) != nlen) { status |= kStError; err = kErrStoredLen; break; }
             if ((byte + 4 + len) * 8 > nbits) { status |= kStStarved; break; }
             if (n + len + 4 > cap) { status |= kStNoRoom; break; }
-            for (uint32_t k = lane; k < len; k += 64) sym_store(sym + n + k, bytes[4 + k]);
+            for (uint32_t k0 = 0; k0 < len; k0 += 64) {                     // (64 consecutive symbols per step: ring slots of a step are distinct)
+                const uint32_t k = k0 + lane;
+                if (k < len) {
+                    const uint16_t v = bytes[4 + k];
+                    s_ring[(n + k) & (kRing - 1)] = v;
+                    sym_store(sym + n + k, v);
+                }
+            }
+            __syncthreads();
             n2 = n + len;
             at = (byte + 4 + len) * 8;
         } else if (type == 3) {
@@ -218,9 +230,6 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
             }
             wseek(in, (uint64_t)s_hdr[1] | ((uint64_t)s_hdr[2] << 32));
             // ---- the block's symbols ----
-            uint16_t pend_v = 0;                                              // a copy whose load is under way: value, target, "this lane has one"
-            uint32_t pend_at = 0;
-            bool pend = false;
             for (;;) {
                 if (n2 + 260 > cap) { rc = kStNoRoom; break; }
                 if (wpos(in) > nbits) { rc = kStStarved; break; }
@@ -234,9 +243,10 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
                 in.bb >>= (e & 0xFF);
                 in.bc -= (e & 0xFF);
                 if (e & kLit) {
-                    if (pend) sym_store(sym + pend_at, pend_v);
-                    pend = false;
-                    if (lane == 0) sym_store(sym + n2, (uint16_t)(e >> 16));
+                    if (lane == 0) {
+                        s_ring[n2 & (kRing - 1)] = (uint16_t)(e >> 16);
+                        sym_store(sym + n2, (uint16_t)(e >> 16));
+                    }
                     ++n2;
                     continue;
                 }
@@ -261,25 +271,27 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
                 in.bb >>= deb;
                 in.bc -= deb;
                 if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; rc = kStError; break; }
-                // the copy in front of this one lands before this one reads
-                if (pend) sym_store(sym + pend_at, pend_v);
-                pend = false;
                 // symbol n2 + k comes from n2 + k - distance, or -- periodic -- from the first `distance` of them; what lies in
-                // front of the chunk is a marker
+                // front of the chunk is a marker.  64 symbols per step: the lanes of a step read before any of them writes (LDS
+                // operations of a wave execute in order), and a later step reads what the earlier ones wrote.
+                const bool near = distance <= kRingReach;
+                // a copy out of the symbol buffer itself reads what this wave stored a moment ago: the stores must have reached
+                // the L2 (the CU's L1 is not kept coherent with stores that cross a line fill in flight) and the loads must go
+                // there -- an intermittent wrong symbol otherwise (seen: a FASTQ record cut short, one run in three)
+                if (!near) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                 for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                     const uint32_t k = k0 + lane;
-                    if (pend) sym_store(sym + pend_at, pend_v);               // (matches longer than 64: one round of lanes at a time)
-                    pend = k < len;
-                    if (pend) {
+                    if (k < len) {
                         const uint32_t kk = k < distance ? k : k % distance;
                         const int64_t src = (int64_t)n2 - (int64_t)distance + (int64_t)kk;
-                        pend_at = n2 + k;
-                        pend_v = src < 0 ? (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src)) : sym_load(sym + src);
+                        const uint16_t v = src < 0 ? (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src))
+                                                   : near ? s_ring[(uint32_t)src & (kRing - 1)] : sym_load_far(sym + src);
+                        s_ring[(n2 + k) & (kRing - 1)] = v;
+                        sym_store(sym + n2 + k, v);
                     }
                 }
                 n2 += len;
             }
-            if (pend) sym_store(sym + pend_at, pend_v);
             if (rc) {
                 status |= rc;
                 break;

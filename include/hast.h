@@ -346,6 +346,7 @@ typedef struct {
     double wait_upload_s;      /* the producer waited for compressed bytes to reach the device */
     double wait_consumer_s;    /* ... for the reader to be through with a symbol arena */
     double wait_decode_s;      /* the reader waited for decoded bytes */
+    double open_s;             /* hast_gz_open itself: device buffers (two symbol arenas of 8192 chunks each), streams, threads */
 } hast_gz_stats;
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
 /* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 8192), symbols of room per compressed byte (0 = 12) */

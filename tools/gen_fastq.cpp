@@ -4,6 +4,7 @@
 // Header shape: @V300R%09d#<barcode>/<mate>\t<id>\t1 ; barcode id 0 -> 0_0_0, else a_b_c with a,b,c in [1,1536].
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -66,7 +67,11 @@ int main(int argc, char **argv) {
                 th.emplace_back([&, t] {
                     std::string &o = out[t];
                     std::vector<uint8_t> seq(p.read_len);
-                    const std::string qual(p.read_len, 'F');
+                    std::string qual(p.read_len, 'F');
+                    // GEN_FASTQ_QUAL=noisy: quality strings like a sequencer's (MGI / Illumina binned scores: mostly 'F', some ':' ',' '#'
+                    // at random places) instead of the constant one -- the classification does not look at them, a gzip stream does:
+                    // constant lines become 150-byte matches and 300-KB deflate blocks, noisy ones literals and ~40-KB blocks
+                    static const bool noisy = getenv("GEN_FASTQ_QUAL") && !strcmp(getenv("GEN_FASTQ_QUAL"), "noisy");
                     char head[128];
                     for (uint64_t i = c0 + chunk * t; i < std::min(n_pairs, c0 + chunk * (t + 1)); i++) {
                         const uint32_t bc = synth_barcode(p, i);
@@ -76,6 +81,14 @@ int main(int argc, char **argv) {
                         o.append(head, n);
                         o.append((const char *)seq.data(), seq.size());
                         o.append("\n+\n");
+                        if (noisy) {
+                            uint64_t h = splitmix64((2 * i + mate) * 0x9E3779B97F4A7C15ull + 77);
+                            for (uint32_t q = 0; q < p.read_len; q++) {
+                                if ((q & 7) == 0) h = splitmix64(h + q);
+                                const uint32_t r = (uint32_t)(h >> (8 * (q & 7))) & 0xFF;
+                                qual[q] = r < 218 ? 'F' : r < 238 ? ':' : r < 251 ? ',' : '#';
+                            }
+                        }
                         o.append(qual);
                         o.push_back('\n');
                     }
