@@ -129,6 +129,7 @@ ABI_SYMBOLS = {
     "hast_kc_count_device": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "hast_kc_count": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "hast_kc_sync": (C.c_int, [vp]),
+    "hast_kc_partition_info": (C.c_int, [vp, u64p]),
     "hast_kc_stats": (C.c_int, [vp, u64p]),
     "hast_kc_histo": (C.c_int, [vp, C.c_int, vp]),
     "hast_kc_find_bounds": (None, [vp, C.POINTER(C.c_long)]),
@@ -576,6 +577,11 @@ class KmerCounter:
 
     def sync(self):
         _ck(self._lib.hast_kc_sync(self._h))
+
+    def partition_info(self):
+        out = np.zeros(5, dtype=np.uint64)
+        _ck(self._lib.hast_kc_partition_info(self._h, out.ctypes.data_as(u64p)))
+        return dict(partitioned=bool(out[0]), flushes=int(out[1]), records=int(out[2]), spilled_windows=int(out[3]), record_capacity=int(out[4]))
 
     def stats(self):
         out = np.zeros(6, dtype=np.uint64)

@@ -610,7 +610,7 @@ int main(int argc, char **argv) {
             std::deque<Filled> filled;                             // filled, in order, waiting for hast_fq_submit
             bool stop = false, eof_acquired = false;
             size_t held = 0;                                       // acquired and not yet committed
-            size_t submitted = 0, opened = 0;
+            size_t submitted = 0, opened = 0, acquired = 0;
         };
         const int n_buf = stripe ? std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()) : fq_bufs;     // per context
         double t_create = 0;
@@ -734,11 +734,13 @@ int main(int argc, char **argv) {
             for (size_t fi = 0; fi < active.size(); ++fi) {
                 Feed &f = *active[fi];
                 // 1. hand empty buffers to the reader
-                while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq)) {
+                // (device-side blocks: one buffer fewer may be in hand unsubmitted, include/hast.h)
+                while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq) && (!f.gz || f.acquired - f.submitted + 1 < (size_t)n_buf)) {
                     uint8_t *buf;
                     CK(hast_fq_acquire(f.fq, &buf), "staging a block");
                     if (f.gz) CK(hast_fq_device_block(f.fq, &buf, &f.fill_stream), "staging a block");
                     f.held++;
+                    f.acquired++;
                     std::lock_guard<std::mutex> g(f.mu);
                     f.empty.push_back(buf);
                     f.cv.notify_one();

@@ -466,6 +466,13 @@ hast_status hast_fq_device_block(hast_fq *f, uint8_t **d_block, hast_stream *fil
     if (f->source == 1) return set_error(HAST_ERR_INVALID, "a stream takes host blocks or device blocks, not both");
     f->source = 2;
     const size_t i = f->n_device_blocks;
+    // This buffer held block i - n_buffers, whose unfinished tail the framing of block i - n_buffers + 1 reads: that framing must
+    // have been LAUNCHED before anyone may be told to write here (the wait below is on its event).  A host block is uploaded by
+    // hast_fq_submit, by when every earlier block has been submitted; a device block is filled by the caller, who could get here
+    // with blocks in hand that it has not submitted yet -- seen: a record that straddles two blocks cut short, one run in two.
+    if (i >= f->slots.size() && f->n_submitted + f->slots.size() <= i + 1)
+        return set_error(HAST_ERR_INVALID, "hast_fq_device_block: %zu blocks are in hand and not submitted; a stream of %zu buffers allows %zu",
+                         i - f->n_submitted, f->slots.size(), f->slots.size() - 1);
     const int si = (int)(i % f->slots.size());
     Slot &s = f->slots[(size_t)si];
     FQ_TRY(hipSetDevice(f->device));

@@ -275,10 +275,11 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
                 // front of the chunk is a marker.  64 symbols per step: the lanes of a step read before any of them writes (LDS
                 // operations of a wave execute in order), and a later step reads what the earlier ones wrote.
                 const bool near = distance <= kRingReach;
-                // a copy out of the symbol buffer itself reads what this wave stored a moment ago: the stores must have reached
-                // the L2 (the CU's L1 is not kept coherent with stores that cross a line fill in flight) and the loads must go
-                // there -- an intermittent wrong symbol otherwise (seen: a FASTQ record cut short, one run in three)
-                if (!near) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                // a copy out of the symbol buffer itself reads what this wave stored a moment ago: the stores must have reached the
+                // L2 (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache
+                // maintenance: an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the
+                // GPU 10 x slower while this one runs
+                if (!near) __builtin_amdgcn_s_waitcnt(0);
                 for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                     const uint32_t k = k0 + lane;
                     if (k < len) {

@@ -31,7 +31,7 @@ struct KcStage {
     bool busy = false;
 };
 // d_small layout (unsigned long long words)
-enum { kQueue = 0, kTotal = 1 /* ,2 */, kCursor = 3, kStats = 4 /* ,5,6 */, kSmallWords = 8 };
+enum { kQueue = 0, kTotal = 1 /* ,2 */, kCursor = 3, kStats = 4 /* ,5,6 */, kRecCursor = 7, kSpillN = 8, kSmallWords = 10 };
 }  // namespace
 
 struct hast_kc {
@@ -50,6 +50,15 @@ struct hast_kc {
     uint32_t *h_err = nullptr;
     hipEvent_t err_ev = nullptr;
     bool err_pending = false;
+    // partitioned counting (kc_kernels.hip, "partitioned counting"): windows are written out as records and applied to the table in
+    // flushes -- at hast_kc_sync, before the table is read, and when the record buffer is nearly full
+    bool part_on = false;
+    uint32_t fine_shift = 9, n_fine = 0, n_l1 = 0, f2 = 0;
+    unsigned long long *d_rec = nullptr, *d_l1 = nullptr, *d_spill = nullptr;
+    uint32_t *d_fills = nullptr;               // [n_l1 fill | n_l1 valid | n_fine fill | n_fine valid]
+    uint64_t rec_cap = 0, a_cap = 0, b_cap = 0, spill_cap = 0;
+    uint64_t est_records = 0;                  // upper bound of the records written since the last flush
+    uint64_t n_flushes = 0, n_flushed_records = 0, n_spilled = 0;
     std::vector<uint64_t> sel[2];              // print keys selected so far (host side, unsorted)
     unsigned long long *d_sorted[2] = {nullptr, nullptr};
     size_t n_sorted[2] = {0, 0};
@@ -85,6 +94,88 @@ hast_status check_synth(const hast_kc_synth *p) {
     return HAST_OK;
 }
 }  // namespace
+
+// Partitioned counting is worth its buffers when the table is far larger than the caches (>= 2^20 buckets = 128 MB) and K leaves
+// room for a run of windows in a record (K <= 29); HAST_KC_COUNT=atomic|partition in the environment (read here, once) forces either.
+// The buffers take what is left of the device memory next to the table: ~22.5 B per record of capacity.
+static void part_setup(hast_kc *c) {
+    const char *e = getenv("HAST_KC_COUNT");
+    const bool forced = e && !strcmp(e, "partition"), off = e && !strcmp(e, "atomic");
+    if (off || c->k > 29 || (!forced && c->nbuckets < (1u << 20))) return;
+    c->fine_shift = ((uint64_t)c->nbuckets >> 9) > (1u << 20) ? 10 : 9;
+    const uint64_t n_fine = ((uint64_t)c->nbuckets + (1u << c->fine_shift) - 1) >> c->fine_shift;
+    if (n_fine > (1u << 20)) return;                                   // a table of more than 2^30 buckets (128 GB): two levels of 1024 do not reach
+    c->n_fine = (uint32_t)n_fine;
+    c->n_l1 = (uint32_t)std::min<uint64_t>(1024, n_fine);
+    c->f2 = (uint32_t)((n_fine + c->n_l1 - 1) / c->n_l1);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const uint64_t fixed = 8ull * (64ull * c->n_fine + 4096ull * c->n_l1 + (1u << 20)) + 8ull * (c->n_l1 + c->n_fine) + (64u << 20);
+    const uint64_t budget = (uint64_t)((double)free_b * 0.8);
+    if (budget <= fixed + (16u << 20)) return;
+    uint64_t R = (uint64_t)((double)(budget - fixed) / 22.6);
+    R = std::min<uint64_t>(R, 6ull << 30);
+    if (const char *m = getenv("HAST_KC_RECORD_MB")) R = std::min<uint64_t>(R, ((uint64_t)atol(m) << 20) / 8);     // (the record buffer itself)
+    if (R < (forced ? 4096u : (16u << 20))) return;
+    c->rec_cap = R;
+    c->a_cap = R + R / 2 + 64ull * c->n_fine + 1024;
+    c->b_cap = R + R / 4 + 4096ull * c->n_l1 + 1024;
+    c->spill_cap = R / 16 + (1u << 20);
+    hipError_t h = hipMalloc(reinterpret_cast<void **>(&c->d_rec), c->a_cap * 8);
+    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_l1), c->b_cap * 8);
+    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_spill), c->spill_cap * 8);
+    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_fills), 8ull * (c->n_l1 + c->n_fine));
+    if (h != hipSuccess) {                                             // no room: count with atomics, as before
+        (void)hipGetLastError();
+        for (void *p : {(void *)c->d_rec, (void *)c->d_l1, (void *)c->d_spill, (void *)c->d_fills})
+            if (p) (void)hipFree(p);
+        c->d_rec = c->d_l1 = c->d_spill = nullptr;
+        c->d_fills = nullptr;
+        return;
+    }
+    c->part_on = true;
+}
+
+// apply what has been written out since the last flush (no-op when there is nothing)
+static hast_status part_flush(hast_kc *c) {
+    if (!c->part_on || c->est_records == 0) return HAST_OK;
+    unsigned long long cur = 0;
+    KC_TRY(hipMemcpyAsync(&cur, c->d_small + kRecCursor, sizeof(cur), hipMemcpyDeviceToHost, c->stream));
+    KC_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t n = std::min<uint64_t>(cur, c->rec_cap);
+    KcFlushArgs a;
+    a.table = c->d_table;
+    a.nbuckets = c->nbuckets;
+    a.k = c->k;
+    a.m = c->m;
+    a.fine_shift = c->fine_shift;
+    a.n_fine = c->n_fine;
+    a.n_l1 = c->n_l1;
+    a.f2 = c->f2;
+    a.records = c->d_rec;
+    a.n_records = n;
+    a.l1_recs = c->d_l1;
+    a.l1_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->b_cap / c->n_l1, n / c->n_l1 + n / c->n_l1 / 4 + 4096));
+    a.fine_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->a_cap / c->n_fine, n / c->n_fine + n / c->n_fine / 2 + 64));
+    a.l1_fill = c->d_fills;
+    a.l1_valid = c->d_fills + c->n_l1;
+    a.fine_fill = c->d_fills + 2 * (size_t)c->n_l1;
+    a.fine_valid = a.fine_fill + c->n_fine;
+    a.spill = c->d_spill;
+    a.spill_cap = c->spill_cap;
+    a.spill_n = c->d_small + kSpillN;
+    a.err = c->d_err;
+    KC_TRY(launch_kc_flush(a, c->stream));
+    unsigned long long sp = 0;
+    KC_TRY(hipMemcpyAsync(&sp, c->d_small + kSpillN, sizeof(sp), hipMemcpyDeviceToHost, c->stream));
+    KC_TRY(hipMemsetAsync(c->d_small + kRecCursor, 0, 2 * sizeof(unsigned long long), c->stream));      // cursor and spill count
+    KC_TRY(hipStreamSynchronize(c->stream));
+    c->est_records = 0;
+    c->n_flushes++;
+    c->n_flushed_records += n;
+    c->n_spilled += sp;
+    return HAST_OK;
+}
 
 hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out) {
     if (!out) return set_error(HAST_ERR_INVALID, "out is null");
@@ -130,6 +221,7 @@ hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out)
         c->nbuckets = (uint32_t)nb;
         bail(hipMalloc(&c->d_table, nb * kKcBucketWords * sizeof(unsigned long long)), "hipMalloc(count table)");
     }
+    if (st == HAST_OK) part_setup(c);
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream), "hipMemset");
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
     if (st == HAST_OK) bail(launch_kc_clear(c->d_table, c->nbuckets, c->stream), "clear table");
@@ -156,6 +248,8 @@ void hast_kc_destroy(hast_kc *c) {
     for (auto *p : c->d_sorted)
         if (p) (void)hipFree(p);
     if (c->d_table) (void)hipFree(c->d_table);
+    for (void *p : {(void *)c->d_rec, (void *)c->d_l1, (void *)c->d_spill, (void *)c->d_fills})
+        if (p) (void)hipFree(p);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_histo) (void)hipFree(c->d_histo);
@@ -178,6 +272,7 @@ hast_status hast_kc_set_slice(hast_kc *c, uint32_t slice, uint32_t n_slices) {
         c->err_pending = false;
     }
     *c->h_err = 0;
+    c->est_records = 0;                            // (records of the old slice are void with its table; the cursor words were zeroed above)
     return HAST_OK;
 }
 
@@ -198,6 +293,19 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
     a.tile_queue = c->d_small + kQueue;
     a.total = c->d_small + kTotal;
     a.err = c->d_err;
+    a.rec_out = nullptr;
+    a.rec_cap = 0;
+    a.rec_cursor = nullptr;
+    if (c->part_on) {
+        // (an upper bound of one record per two windows; a minimizer run holds ~3.5.  What does not fit the buffer after all is
+        // counted on the spot, by the kernel itself)
+        if (c->est_records + n_starts / 2 + 1 > c->rec_cap)
+            if (hast_status st = part_flush(c)) return st;
+        a.rec_out = c->d_rec;
+        a.rec_cap = c->rec_cap;
+        a.rec_cursor = c->d_small + kRecCursor;
+        c->est_records += n_starts / 2 + 1;
+    }
     const size_t n_tiles = (n_starts + a.tile_bases - 1) / a.tile_bases;
     const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)c->n_cu * 8);
     KC_TRY(hipMemsetAsync(c->d_small + kQueue, 0, sizeof(unsigned long long), c->stream));
@@ -251,6 +359,8 @@ hast_status hast_kc_count(hast_kc *c, int parent, const uint8_t *bytes, size_t n
 
 hast_status hast_kc_sync(hast_kc *c) {
     if (hast_status st = use(c)) return st;
+    if (c->d_table)
+        if (hast_status st = part_flush(c)) return st;
     uint32_t e = 0;
     KC_TRY(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     KC_TRY(hipStreamSynchronize(c->stream));
@@ -264,6 +374,7 @@ hast_status hast_kc_sync(hast_kc *c) {
 hast_status hast_kc_stats(hast_kc *c, uint64_t out[6]) {
     if (hast_status st = need_table(c)) return st;
     if (!out) return set_error(HAST_ERR_INVALID, "out is null");
+    if (hast_status st = part_flush(c)) return st;
     unsigned long long h[kSmallWords];
     KC_TRY(hipMemsetAsync(c->d_small + kStats, 0, 3 * sizeof(unsigned long long), c->stream));
     KC_TRY(launch_kc_stats(c->d_table, c->nbuckets, c->d_small + kStats, c->stream));
@@ -282,6 +393,7 @@ hast_status hast_kc_histo(hast_kc *c, int parent, uint64_t *histo) {
     if (hast_status st = need_table(c)) return st;
     if (hast_status st = check_parent(parent)) return st;
     if (!histo) return set_error(HAST_ERR_INVALID, "histo is null");
+    if (hast_status st = part_flush(c)) return st;
     const size_t n = HAST_KC_HISTO_HIGH + 2;
     std::vector<unsigned long long> h(n);
     KC_TRY(hipMemsetAsync(c->d_histo, 0, n * sizeof(unsigned long long), c->stream));
@@ -322,6 +434,7 @@ hast_status hast_kc_select(hast_kc *c, int parent, uint32_t lower, uint32_t uppe
     if (hast_status st = need_table(c)) return st;
     if (hast_status st = check_parent(parent)) return st;
     if (n_added) *n_added = 0;
+    if (hast_status st = part_flush(c)) return st;
     unsigned long long n = 0;
     unsigned long long *cur = c->d_small + kCursor;
     KC_TRY(hipMemsetAsync(cur, 0, sizeof(unsigned long long), c->stream));
@@ -374,11 +487,28 @@ hast_status hast_kc_selection_adopt(hast_kc *dst, hast_kc *src) {
     return HAST_OK;
 }
 
+// out[0] = 1 when windows go through the partitioned path, out[1] flushes so far, out[2] records applied, out[3] windows that took
+// the atomic path after all (full buckets beyond a slice), out[4] capacity of the record buffer
+hast_status hast_kc_partition_info(hast_kc *c, uint64_t out[5]) {
+    if (!c || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    out[0] = c->part_on ? 1 : 0;
+    out[1] = c->n_flushes;
+    out[2] = c->n_flushed_records;
+    out[3] = c->n_spilled;
+    out[4] = c->rec_cap;
+    return HAST_OK;
+}
+
 hast_status hast_kc_release_table(hast_kc *c) {
     if (hast_status st = use(c)) return st;
     KC_TRY(hipStreamSynchronize(c->stream));
     if (c->d_table) KC_TRY(hipFree(c->d_table));
     c->d_table = nullptr;
+    for (void *p : {(void *)c->d_rec, (void *)c->d_l1, (void *)c->d_spill, (void *)c->d_fills})
+        if (p) KC_TRY(hipFree(p));
+    c->d_rec = c->d_l1 = c->d_spill = nullptr;
+    c->d_fills = nullptr;
+    c->part_on = false;
     for (auto &s : c->stage) {
         if (s.d) KC_TRY(hipFree(s.d));
         s.d = nullptr;

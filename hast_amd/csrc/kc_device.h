@@ -21,8 +21,29 @@ struct KcCountArgs {
     unsigned long long *tile_queue;  // zeroed before the launch
     unsigned long long *total;       // [2] windows counted per parent
     uint32_t *err;                   // bit 0: table full
+    // partitioned path (rec_out != nullptr): the windows are written out as records instead (kc_kernels.hip, "records")
+    unsigned long long *rec_out;
+    unsigned long long rec_cap;
+    unsigned long long *rec_cursor;  // records written so far (may run past rec_cap: those were counted on the spot)
 };
 
+// one flush of the partitioned path: records -> level-1 regions -> fine regions (in the flat buffer's place) -> slices in LDS -> spill
+struct KcFlushArgs {
+    unsigned long long *table;
+    uint32_t nbuckets;
+    int k, m;
+    uint32_t fine_shift, n_fine, n_l1, f2;
+    unsigned long long *records;     // flat buffer: n_records records in; then n_fine regions of fine_cap records
+    unsigned long long n_records;
+    unsigned long long *l1_recs;     // n_l1 regions of l1_cap records
+    uint32_t l1_cap, fine_cap;
+    uint32_t *l1_fill, *l1_valid, *fine_fill, *fine_valid;
+    unsigned long long *spill;       // spill_cap records
+    unsigned long long spill_cap;
+    unsigned long long *spill_n;     // zeroed by the caller before the first record of a flush period is emitted
+    uint32_t *err;
+};
+hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s);
 size_t kc_count_smem(uint32_t tile_bases, int k, int m);
 hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s);
 hipError_t launch_kc_clear(unsigned long long *table, size_t nbuckets, hipStream_t s);

@@ -28,8 +28,21 @@ constexpr int kKcThreads = 256;
 // wave are consecutive windows, mostly of the same bucket, and their adds to one 32-B counter sector leave the CU as a
 // single request only when they come from the same instruction (tools/atomic_merge_probe.hip; an instrumented build
 // counted 48 distinct counter sectors per 150-bp read with the add inside the probe loop, against ~37 minimizer runs).
-__device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t nb, uint32_t b, uint64_t key, uint32_t parent) {
+// Probe sequence of a key (kc_slot, and k_kc_apply inside its slice): the minimizer's bucket, then -- only when that one is full --
+// the next three (the same DRAM page; a minimizer's ~3.5 genomic k-mers plus the error k-mers that keep it are ~8.5 keys on average
+// at 30x, so half the occupied buckets overflow, while 7 buckets in 8 are empty), then a bucket chosen by the KEY's own hash and
+// on from there (minimizers that thousands of keys share -- poly-A -- must not pile up in one run of full buckets).
+__device__ __forceinline__ uint32_t kc_probe(uint32_t home, uint32_t p, uint64_t key, uint32_t nb) {
+    if (p < 4) {
+        const uint32_t b = home + p;
+        return b >= nb ? b - nb : b;
+    }
+    const uint64_t b = (uint64_t)overflow_bucket(key, nb) + (p - 4);
+    return (uint32_t)(b % nb);
+}
+__device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t nb, uint32_t home, uint64_t key, uint32_t parent) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    uint32_t b = home;
     for (uint32_t probe = 0; probe < nb; ++probe) {
         unsigned long long *bk = table + (size_t)b * kKcBucketWords;
         uint32_t *cnt = reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots;   // this parent's 8 counters: one 32-B sector
@@ -52,13 +65,41 @@ __device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t
             if (old == kEmptySlot || old == key) idx = i;
         }
         if (idx >= 0) return cnt + idx;
-        b = next_bucket(b, probe + 1, key, nb);              // bucket full: jump to the key's own overflow bucket, then walk on
+        b = kc_probe(home, probe + 1, key, nb);              // bucket full: the next three, then the key's own overflow bucket, then on from there
     }
     return nullptr;
 }
 
 // One workgroup walks tiles of `tile_bases` window starts (+ K-1 bytes of overlap) of the byte stream.
-template <int WT>
+// ---- records of the partitioned path ("super-k-mers": what KMC-style counters partition by) -------------------------------------
+// A record = the bases of a run of consecutive windows that share their minimizer hash, packed: (bases << 6) | (run - 1) << 1 |
+// parent, bases = 2 (K + run - 1) bits, first base most significant, run <= 29 - K + 1 windows (K <= 29).  One 8-byte record
+// stands for ~3.5 windows, and its bucket follows from its own bases.
+__device__ __forceinline__ uint32_t kc_run_max(int k) { return (uint32_t)(29 - k + 1); }
+__device__ __forceinline__ uint32_t kc_rec_minhash(unsigned long long first_window, int k, int m) {
+    const unsigned long long mm_mask = kmer_mask(m);
+    uint32_t best = 0xFFFFFFFFu;
+    for (int j = 0; j + m <= k; ++j) {
+        const uint32_t h = mmer_hash32(kmer_canon((first_window >> (2 * (k - m - j))) & mm_mask, m));
+        best = h < best ? h : best;
+    }
+    return best;
+}
+// every window of a record through the atomic path (records that found no room in a buffer, spilled windows)
+__device__ __forceinline__ void kc_count_record(unsigned long long *table, uint32_t nb, int k, int m, unsigned long long rec, uint32_t *err) {
+    const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
+    const unsigned long long bases = rec >> 6, kmask = kmer_mask(k);
+    const uint32_t home = bucket_of_minhash(kc_rec_minhash((bases >> (2 * (run - 1))) & kmask, k, m), nb);
+    for (uint32_t j = 0; j < run; ++j) {
+        const unsigned long long key = kmer_canon((bases >> (2 * (run - 1 - j))) & kmask, k);
+        uint32_t *counter = kc_slot(table, nb, home, key, parent);
+        if (counter) atomicAdd(counter, 1u);
+        else atomicOr(err, 1u);
+    }
+}
+
+// EMIT: instead of updating the table, write the windows out as records (a.rec_out; what finds no room there is counted on the spot)
+template <int WT, bool EMIT>
 __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t TB = a.tile_bases;
@@ -147,6 +188,35 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                 for (uint32_t j = 1; j < W; ++j) mn = min(mn, s_mh[p + j]);
             }
             if (a.n_slices > 1 && kc_slice_of(mn, a.n_slices) != a.slice) valid = false;
+            if (EMIT) {
+                // runs of consecutive valid windows with one minimizer hash, cut every kc_run_max windows (and by the 64 lanes of a step)
+                const uint32_t prev_mn = (uint32_t)__shfl_up((int)mn, 1, 64);
+                const bool prev_ok = __shfl_up((int)valid, 1, 64) != 0;
+                const bool start0 = valid && (lane == 0 || !prev_ok || prev_mn != mn);
+                const unsigned long long s0 = __ballot(start0), vm = __ballot(valid);
+                if (valid) ++counted;
+                const unsigned long long below = s0 & (~0ull >> (63 - lane));
+                const uint32_t first = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
+                const uint32_t rmax = kc_run_max(K);
+                const bool start = valid && ((lane - first) % rmax) == 0;
+                const unsigned long long sm = __ballot(start);
+                const unsigned long long after = lane == 63 ? 0ull : ((sm | ~vm) >> (lane + 1));
+                const uint32_t run = after ? 1u + (uint32_t)__builtin_ctzll(after) : 64u - lane;
+                if (sm) {
+                    const uint32_t cnt = (uint32_t)__popcll(sm);
+                    unsigned long long at0 = 0;
+                    if (lane == 0) at0 = atomicAdd(a.rec_cursor, (unsigned long long)cnt);
+                    at0 = __shfl(at0, 0, 64);
+                    if (start) {
+                        const uint32_t nbases = (uint32_t)K + run - 1;
+                        const unsigned long long rec = (window_bits(s_pack, p, 64 - 2 * nbases) << 6) | ((unsigned long long)(run - 1) << 1) | a.parent;
+                        const unsigned long long at = at0 + (unsigned long long)__popcll(sm & ((1ull << lane) - 1));
+                        if (at < a.rec_cap) a.rec_out[at] = rec;
+                        else kc_count_record(a.table, a.nbuckets, K, M, rec, a.err);
+                    }
+                }
+                continue;
+            }
             const uint64_t prev_key = __shfl_up(key, 1, 64);
             const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
             const bool follower = valid && lane > 0 && prev_valid && prev_key == key;
@@ -170,14 +240,18 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
     if ((tid & 63) == 0 && counted) atomicAdd(a.total + a.parent, counted);
 }
 
-template <int WT>
-static hipError_t launch_kc_count_t(const KcCountArgs &a, unsigned grid, size_t smem, hipStream_t s) {
+template <int WT, bool EMIT>
+static hipError_t launch_kc_count_e(const KcCountArgs &a, unsigned grid, size_t smem, hipStream_t s) {
     if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_count<WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_count<WT, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_kc_count<WT>), dim3(grid), dim3(kKcThreads), smem, s, a);
+    hipLaunchKernelGGL((k_kc_count<WT, EMIT>), dim3(grid), dim3(kKcThreads), smem, s, a);
     return hipGetLastError();
+}
+template <int WT>
+static hipError_t launch_kc_count_t(const KcCountArgs &a, unsigned grid, size_t smem, hipStream_t s) {
+    return a.rec_out ? launch_kc_count_e<WT, true>(a, grid, smem, s) : launch_kc_count_e<WT, false>(a, grid, smem, s);
 }
 size_t kc_count_smem(uint32_t tile_bases, int k, int m) {
     const uint32_t span = tile_bases + (uint32_t)k - 1, nw = (span + 31) / 32 + 2, w = (uint32_t)(k - m + 1);
@@ -193,6 +267,229 @@ hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s) {
     case 9: return launch_kc_count_t<9>(a, grid, smem, s);
     default: return launch_kc_count_t<0>(a, grid, smem, s);
     }
+}
+
+// ---- partitioned counting ---------------------------------------------------------------------------------------------------------
+// k_kc_count (above) does one memory-side atomic per minimizer run and wave step, and this part executes 27 G of them per second
+// whatever their scope or footprint (tools/l2_atomics_probe): 81 per 150-bp read = the kernel's wall.  The
+// way past it is the partitioned commit of stage 01 applied to the table itself: the windows are written out as records (EMIT),
+// the records are PARTITIONED by bucket range in two levels -- in LDS, so that every bin receives whole runs -- down to bins of
+// 512 or 1024 buckets, and then one workgroup per bin holds its slice of the table in LDS, counts its records there with LDS
+// atomics and writes the slice back: the table is read and written once per flush, sequentially, and no atomic leaves the chip
+// except one reservation per (workgroup, bin) and the few windows whose buckets are full beyond the slice (k_kc_spill).
+//   HBM traffic per window: 8 B x 6 / ~3.5 windows per record + the sweep of the table (11 B at 30x) ~ 25 B, against one 128-B
+//   line read + one atomic per minimizer run before.
+struct KcPartGeom {
+    unsigned long long *table;
+    uint32_t nbuckets;
+    int k, m;
+    uint32_t fine_shift;         // log2(buckets per fine bin): 9 or 10
+    uint32_t n_fine, n_l1, f2;   // fine bins, level-1 bins, fine bins per level-1 bin (n_l1 * f2 >= n_fine)
+    uint32_t *err;
+};
+constexpr uint32_t kKcPartRecs = 8192, kKcPartThreads = 1024, kKcMaxFan = 1024;
+__device__ __forceinline__ uint32_t kc_rec_fine(const KcPartGeom &g, unsigned long long rec) {
+    const uint32_t run = (uint32_t)((rec >> 1) & 31) + 1;
+    const unsigned long long first = ((rec >> 6) >> (2 * (run - 1))) & kmer_mask(g.k);
+    return bucket_of_minhash(kc_rec_minhash(first, g.k, g.m), g.nbuckets) >> g.fine_shift;
+}
+// records that found no room in a bin: to the spill list, or -- that one full too -- through the atomic path at once (no slice
+// of the table is held in LDS while a partition kernel runs)
+__device__ __forceinline__ void kc_spill(const KcPartGeom &g, unsigned long long rec, unsigned long long *spill, unsigned long long spill_cap,
+                                         unsigned long long *spill_n) {
+    const unsigned long long at = atomicAdd(spill_n, 1ull);
+    if (at < spill_cap) spill[at] = rec;
+    else kc_count_record(g.table, g.nbuckets, g.k, g.m, rec, g.err);
+}
+// LEVEL 1: in = the flat record buffer [0, n_flat); bin = fine / f2, region = bin.  LEVEL 2: blockIdx.y = a level-1 bin, in = its
+// region (in_cap records apart, in_fill / in_valid say how many are real); bin = fine - l1 * f2, region = fine.
+template <int LEVEL>
+__global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const unsigned long long *in, unsigned long long n_flat, const uint32_t *in_fill,
+                                                            const uint32_t *in_valid, uint32_t in_cap, unsigned long long *out, uint32_t out_cap,
+                                                            uint32_t *out_fill, uint32_t *out_valid, unsigned long long *spill, unsigned long long spill_cap,
+                                                            unsigned long long *spill_n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);                       // [kKcMaxFan] records of this tile per bin
+    uint32_t *s_off = s_cnt + kKcMaxFan;                                        // where the bin starts in s_rec
+    uint32_t *s_dst = s_off + kKcMaxFan;                                        // where the bin's run goes (bit 31: spill)
+    unsigned long long *s_rec = reinterpret_cast<unsigned long long *>(s_dst + kKcMaxFan);   // [kKcPartRecs], grouped by bin
+    __shared__ uint32_t s_scan[kKcPartThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t l1 = LEVEL == 2 ? blockIdx.y : 0;
+    const uint32_t n_bins = LEVEL == 1 ? g.n_l1 : g.f2;
+    unsigned long long n_in = n_flat;
+    const unsigned long long *src = in;
+    if (LEVEL == 2) {
+        const uint32_t f = in_fill[l1], v = in_valid[l1];
+        n_in = f < v ? (f < in_cap ? f : in_cap) : v;
+        src = in + (size_t)l1 * in_cap;
+    }
+    const unsigned long long r0 = (unsigned long long)blockIdx.x * kKcPartRecs;
+    if (r0 >= n_in) return;
+    const uint32_t nr = (uint32_t)(n_in - r0 < kKcPartRecs ? n_in - r0 : kKcPartRecs);
+    for (uint32_t b = tid; b < n_bins; b += kKcPartThreads) s_cnt[b] = 0;
+    __syncthreads();
+    constexpr int PER = kKcPartRecs / kKcPartThreads;                           // 8 records per thread
+    unsigned long long rec[PER];
+    uint32_t bin_of[PER], rank[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t i = (uint32_t)q * kKcPartThreads + tid;                  // coalesced
+        bin_of[q] = 0xFFFFFFFFu;
+        if (i < nr) {
+            rec[q] = src[r0 + i];
+            const uint32_t fine = kc_rec_fine(g, rec[q]);
+            uint32_t b = LEVEL == 1 ? fine / g.f2 : fine - l1 * g.f2;
+            if (b >= n_bins) b = n_bins - 1;                                    // (cannot happen: a record lies where its bucket says)
+            bin_of[q] = b;
+            rank[q] = atomicAdd(&s_cnt[b], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of s_cnt (one bin per thread), and one reservation per (workgroup, bin)
+        const uint32_t c = tid < n_bins ? s_cnt[tid] : 0;
+        uint32_t incl = c;
+        const uint32_t lane = tid & 63;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        if (lane == 63) s_scan[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - c;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) base += s_scan[w];
+        if (tid < n_bins) {
+            s_off[tid] = base;
+            uint32_t dst = 0;
+            if (c) {
+                const uint32_t region = LEVEL == 1 ? tid : l1 * g.f2 + tid;
+                const uint32_t at = atomicAdd(&out_fill[region], c);
+                if (at + c <= out_cap) dst = at;
+                else {
+                    atomicMin(&out_valid[region], at);                          // records [0, first failed reservation) of a region are real
+                    dst = 0x80000000u;
+                }
+            }
+            s_dst[tid] = dst;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (bin_of[q] != 0xFFFFFFFFu) s_rec[s_off[bin_of[q]] + rank[q]] = rec[q];
+    __syncthreads();
+    // runs out: 16 lanes per bin
+    const uint32_t grp = tid >> 4, gl = tid & 15;
+    for (uint32_t b = grp; b < n_bins; b += kKcPartThreads / 16) {
+        const uint32_t cnt = s_cnt[b];
+        if (!cnt) continue;
+        const uint32_t dst = s_dst[b], off = s_off[b];
+        if (!(dst & 0x80000000u)) {
+            const uint32_t region = LEVEL == 1 ? b : l1 * g.f2 + b;
+            unsigned long long *o = out + (size_t)region * out_cap + dst;
+            for (uint32_t j = gl; j < cnt; j += 16) o[j] = s_rec[off + j];
+        } else {
+            for (uint32_t j = gl; j < cnt; j += 16) kc_spill(g, s_rec[off + j], spill, spill_cap, spill_n);
+        }
+    }
+}
+
+// One workgroup per fine bin: its slice of the table in LDS, its records counted there, the slice written back.  A window whose
+// bucket and the next three are full (or lie behind the slice's end) goes to the spill list as a record of one window; a full
+// spill list is a full table as far as the caller is concerned (err bit 0).
+constexpr int kKcApplyThreads = 256;
+__global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, const unsigned long long *recs, uint32_t cap, const uint32_t *fill, const uint32_t *valid,
+                                                              unsigned long long *spill, unsigned long long spill_cap, unsigned long long *spill_n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(smem);   // [buckets of the slice][kKcBucketWords]
+    const uint32_t fine = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = fill[fine], v = valid[fine];
+    const uint32_t n = f < v ? (f < cap ? f : cap) : v;
+    if (n == 0) return;
+    const uint32_t b0 = fine << g.fine_shift;
+    const uint32_t nb_here = g.nbuckets - b0 < (1u << g.fine_shift) ? g.nbuckets - b0 : (1u << g.fine_shift);
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    {
+        const u64x2 *gsrc = reinterpret_cast<const u64x2 *>(g.table + (size_t)b0 * kKcBucketWords);
+        u64x2 *ldst = reinterpret_cast<u64x2 *>(s_tab);
+        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) ldst[i] = gsrc[i];
+    }
+    __syncthreads();
+    const unsigned long long *mine = recs + (size_t)fine * cap;
+    const unsigned long long kmask = kmer_mask(g.k);
+    for (uint32_t i = tid; i < n; i += kKcApplyThreads) {
+        const unsigned long long rec = mine[i];
+        const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
+        const unsigned long long bases = rec >> 6;
+        const uint32_t home = bucket_of_minhash(kc_rec_minhash((bases >> (2 * (run - 1))) & kmask, g.k, g.m), g.nbuckets);
+        for (uint32_t j = 0; j < run; ++j) {
+            const unsigned long long raw = (bases >> (2 * (run - 1 - j))) & kmask;
+            const unsigned long long key = kmer_canon(raw, g.k);
+            bool done = false;
+            for (uint32_t p = 0; p < 4 && !done; ++p) {
+                const uint32_t b = home + p;                                    // (kc_probe: the bucket, then the next three)
+                if (b < b0 || b >= b0 + nb_here) break;                          // behind the slice (or wrapped): the atomic path's business
+                unsigned long long *bk = s_tab + (size_t)(b - b0) * kKcBucketWords;
+                uint32_t *cnt = reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots;
+                for (int sl = 0; sl < kKcSlots;) {
+                    unsigned long long cur = __hip_atomic_load(&bk[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == kEmptySlot) {
+                        const unsigned long long old = atomicCAS(&bk[sl], (unsigned long long)kEmptySlot, key);
+                        cur = old == kEmptySlot ? key : old;
+                    }
+                    if (cur == key) {
+                        atomicAdd(&cnt[sl], 1u);
+                        done = true;
+                        break;
+                    }
+                    ++sl;                                                        // taken by another key: slots never change once written
+                }
+            }
+            if (!done) {
+                const unsigned long long at = atomicAdd(spill_n, 1ull);
+                if (at < spill_cap) spill[at] = (raw << 6) | parent;            // a record of one window
+                else atomicOr(g.err, 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        u64x2 *gdst = reinterpret_cast<u64x2 *>(g.table + (size_t)b0 * kKcBucketWords);
+        const u64x2 *lsrc = reinterpret_cast<const u64x2 *>(s_tab);
+        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) gdst[i] = lsrc[i];
+    }
+}
+// the spill list through the atomic path (after k_kc_apply: nobody holds a slice any more)
+__global__ void __launch_bounds__(256) k_kc_spill(KcPartGeom g, const unsigned long long *spill, unsigned long long spill_cap, const unsigned long long *spill_n) {
+    const unsigned long long n = *spill_n < spill_cap ? *spill_n : spill_cap;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        kc_count_record(g.table, g.nbuckets, g.k, g.m, spill[i], g.err);
+}
+
+hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
+    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err};
+    const size_t lds_part = (size_t)3 * kKcMaxFan * 4 + (size_t)kKcPartRecs * 8;
+    const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcBucketWords * 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply);
+    if (e != hipSuccess) return e;
+    // fills to zero, "valid" marks to all ones: [l1 fill | l1 valid | fine fill | fine valid]
+    e = hipMemsetAsync(a.l1_fill, 0, (size_t)a.n_l1 * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(a.l1_valid, 0xFF, (size_t)a.n_l1 * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(a.fine_fill, 0, (size_t)a.n_fine * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(a.fine_valid, 0xFF, (size_t)a.n_fine * 4, s);
+    if (e != hipSuccess) return e;
+    if (a.n_records) {
+        hipLaunchKernelGGL(k_kc_part<1>, dim3((unsigned)((a.n_records + kKcPartRecs - 1) / kKcPartRecs)), dim3(kKcPartThreads), lds_part, s, g, a.records, a.n_records,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, a.l1_recs, a.l1_cap, a.l1_fill, a.l1_valid, a.spill, a.spill_cap, a.spill_n);
+        // level 2 overwrites the flat buffer (its records are all in the level-1 regions by then)
+        hipLaunchKernelGGL(k_kc_part<2>, dim3((a.l1_cap + kKcPartRecs - 1) / kKcPartRecs, a.n_l1), dim3(kKcPartThreads), lds_part, s, g, a.l1_recs, 0ull, a.l1_fill,
+                           a.l1_valid, a.l1_cap, a.records, a.fine_cap, a.fine_fill, a.fine_valid, a.spill, a.spill_cap, a.spill_n);
+        hipLaunchKernelGGL(k_kc_apply, dim3(a.n_fine), dim3(kKcApplyThreads), lds_apply, s, g, a.records, a.fine_cap, a.fine_fill, a.fine_valid, a.spill, a.spill_cap, a.spill_n);
+    }
+    hipLaunchKernelGGL(k_kc_spill, dim3(256 * 8), dim3(256), 0, s, g, a.spill, a.spill_cap, a.spill_n);
+    return hipGetLastError();
 }
 
 // empty table: keys all ones, counters zero

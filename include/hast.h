@@ -309,7 +309,8 @@ hast_status hast_fq_acquire(hast_fq *, uint8_t **host_buf);
 hast_status hast_fq_submit(hast_fq *, size_t n_bytes, int last);
 /* Blocks whose bytes are written ON THE DEVICE (e.g. by hast_gz_read_device: a .gz input inflated on the GPU): after
  * hast_fq_acquire (its host buffer stays unused), hast_fq_device_block gives the device address the block's bytes belong at and
- * the stream the writes must be enqueued on; hast_fq_submit_device then frames them where they lie -- no upload.  A stream takes
+ * the stream the writes must be enqueued on; hast_fq_submit_device then frames them where they lie -- no upload.  At most
+ * n_buffers - 1 blocks may be in hand (hast_fq_device_block called, not yet submitted) at a time.  A stream takes
  * host blocks or device blocks, not both; striped streams take host blocks only.  hast_fq_block.bytes is NULL for such a block:
  * hast_fq_block_host_bytes (valid between hast_fq_next and hast_fq_commit, for any block) fetches the host copy when the caller
  * needs the text behind bc_pos / bc_len -- a barcode longer than the 15 bytes bc_text holds. */
@@ -419,6 +420,15 @@ hast_status hast_kc_count_device(hast_kc *, int parent, const uint8_t *d_bytes, 
 hast_status hast_kc_count(hast_kc *, int parent, const uint8_t *bytes, size_t n_bytes);
 /* wait for all counting submitted so far; HAST_ERR_TABLE_FULL when some k-mer found no slot */
 hast_status hast_kc_sync(hast_kc *);
+/* How the windows reach the table.  Tables of >= 2^20 buckets (128 MB) and K <= 29 count by PARTITIONING (hast_amd/csrc/kc_kernels.hip):
+ * the windows are written out as 8-byte records of a minimizer run each, the records are partitioned by bucket range in two levels
+ * down to slices of 512 or 1024 buckets, and one workgroup per slice counts its records in LDS -- the table is read and written
+ * once per flush, sequentially, instead of one memory-side atomic per minimizer run (which is what bounds the direct kernel).
+ * Flushes happen at hast_kc_sync, before the table is read, and when the record buffer (what is left of the device memory next to
+ * the table; HAST_KC_RECORD_MB caps the record buffer itself) is nearly full.  HAST_KC_COUNT=atomic|partition in the environment at hast_kc_create forces
+ * either path; the results are the same.  out[0] = 1: partitioned; out[1] flushes; out[2] records applied; out[3] windows that took
+ * the atomic path after all (their bucket and the next three full beyond the slice); out[4] record capacity. */
+hast_status hast_kc_partition_info(hast_kc *, uint64_t out[5]);
 /* out[0..1] distinct k-mers per parent, out[2] keys in the table, out[3] table capacity (slots),
  * out[4..5] k-mer occurrences counted per parent */
 hast_status hast_kc_stats(hast_kc *, uint64_t out[6]);

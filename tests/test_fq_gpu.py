@@ -199,6 +199,145 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
     assert int(e[0].sum()) + int(e[1].sum()) > 100
 
 
+def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=4096, gz_pass=7):
+    """the same walk with DEVICE-side blocks: a .gz file inflated on the GPU (hast_gz_read_device) straight into the framer's block
+    buffers (hast_fq_device_block / hast_fq_submit_device); `lag` blocks are kept in hand, filled but not yet submitted"""
+    lib = hast_amd.lib()
+    fq, nm = C.c_void_p(), C.c_void_p()
+    if cache:
+        assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
+    assert lib.hast_fq_create_ex(ctx._h, block, n_buffers, nm, 1, C.byref(fq)) == 0, lib.hast_last_error()
+    names, got, st = {}, [], {"n_bases": 0, "fetched": 0}
+    short = []
+
+    def drain():
+        b = FqBlock()
+        assert lib.hast_fq_next(fq, C.byref(b)) == 0, lib.hast_last_error()
+        assert not b.bytes                                       # a device block has no host view ...
+        short.append(b.short_read)
+        host = None
+        for i in range(b.n_records):
+            t = bytes(b.bc_text[16 * i:16 * i + 16])
+            if t[0] == 0xFF:                                     # ... until it is asked for (a barcode longer than 15 bytes)
+                if host is None:
+                    hp = C.POINTER(C.c_uint8)()
+                    assert lib.hast_fq_block_host_bytes(fq, C.byref(hp)) == 0, lib.hast_last_error()
+                    host = hp
+                    st["fetched"] += 1
+                got.append(bytes(host[b.bc_pos[i]:b.bc_pos[i] + b.bc_len[i]]))
+            else:
+                got.append(t[1:1 + t[0]])
+        todo = [b.unknown[j] for j in range(b.n_unknown)] if b.unknown else range(b.n_records)
+        for i in todo:
+            b.ids[i] = names.setdefault(got[len(got) - b.n_records + i], len(names))
+        st["n_bases"] += b.n_bases
+        assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
+
+    with hast_amd.GzReader(ctx, gz_path, gz_chunk, gz_pass) as z:
+        in_hand, submitted, opened, eof = [], 0, 0, False
+        while not (eof and not in_hand and opened == submitted):
+            in_use = (submitted - opened) + len(in_hand)
+            if not eof and len(in_hand) < lag and in_use < n_buffers:
+                buf = C.POINTER(C.c_uint8)()
+                assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
+                assert not buf                                       # no pinned host copy on such a stream
+                d, fs = C.c_void_p(), C.c_void_p()
+                assert lib.hast_fq_device_block(fq, C.byref(d), C.byref(fs)) == 0, lib.hast_last_error()
+                n = z.read_device(d.value, block, fs)
+                in_hand.append(n)
+                eof = n < block
+            elif in_hand and (len(in_hand) >= lag or eof or in_use >= n_buffers):
+                n = in_hand.pop(0)
+                assert lib.hast_fq_submit_device(fq, n, 1 if (eof and not in_hand) else 0) == 0, lib.hast_last_error()
+                submitted += 1
+            else:
+                assert opened < submitted
+                drain()
+                opened += 1
+    lib.hast_fq_destroy(fq)
+    if nm:
+        lib.hast_names_destroy(nm)
+    return got, names, st["n_bases"], short, st["fetched"]
+
+
+@pytest.mark.parametrize("block,n_buffers,lag", [(4096, 3, 2), (4096, 6, 5), (65536, 2, 1), (20480, 4, 3), (8192, 6, 1)])
+@pytest.mark.parametrize("tail", ["plain", "bases_no_newline"])
+def test_fq_device_blocks_filled_by_the_gpu_inflate(oracle_lib, tmp_path, tail, block, n_buffers, lag):
+    """Blocks whose bytes never see the host: inflated on the GPU into the framer's buffers.  Small blocks, so that every buffer is
+    reused dozens of times and records, headers and barcodes straddle block borders; `lag` = n_buffers - 1 is the most the API allows
+    in hand unsubmitted (a buffer's old tail is still read by the framing of the block behind it: one more is refused).  Records,
+    barcode text (fetched from the device for barcodes longer than 15 bytes), base counts and counters == the reference's framing."""
+    import gzip
+    rng = random.Random(SEEDS[tail] * 77 + block + lag)
+    k, n_keys = 21, 3000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    data = make_fastq(rng, 1500, k, np.concatenate(keys), tail)
+    want = reference_framing(data, oracle_lib)
+    gz = tmp_path / "reads.fq.gz"
+    with gzip.open(gz, "wb", compresslevel=6) as f:
+        f.write(data)
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        ctx.counts_resize(4096)
+        got, names, n_bases, short, fetched = stream_device_blocks(ctx, str(gz), block, 1 << 16, n_buffers, lag)
+        counts = ctx.counts_read(len(names))
+    assert got == [bc for bc, _ in want] and fetched > 0
+    assert n_bases == sum(len(s) for _, s in want) and not any(short)
+    oc = oracle_lib.ho_new()
+    for h in (0, 1):
+        assert oracle_lib.ho_load_keys(oc, keys[h].ctypes.data, keys[h].size, h, k) == 0
+    bases = np.frombuffer(b"".join(s for _, s in want), dtype=np.uint8)
+    off = np.zeros(len(want) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for _, s in want])
+    ids = np.array([names[bc] for bc, _ in want], dtype=np.uint32)
+    e = [np.zeros(len(names), np.uint32) for _ in range(3)]
+    oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, ids.size, e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, None, 2)
+    oracle_lib.ho_free(oc)
+    for a, b in zip(counts, e):
+        assert np.array_equal(a, b)
+
+
+def test_fq_device_blocks_too_many_in_hand_is_refused(tmp_path):
+    import gzip
+    gz = tmp_path / "x.fq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(b"@a#1_1_1/1\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 2000)
+    lib = hast_amd.lib()
+    with hast_amd.Context(21) as ctx:
+        ctx.table_reserve(100)
+        ctx.table_insert_keys(0, np.array([12345], dtype=np.uint64))
+        ctx.counts_resize(16)
+        fq = C.c_void_p()
+        assert lib.hast_fq_create_ex(ctx._h, 4096, 3, None, 1, C.byref(fq)) == 0
+        with hast_amd.GzReader(ctx, str(gz)) as z:
+            def fill():
+                buf, d, fs = C.POINTER(C.c_uint8)(), C.c_void_p(), C.c_void_p()
+                assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0
+                st = lib.hast_fq_device_block(fq, C.byref(d), C.byref(fs))
+                if st == 0:
+                    assert z.read_device(d.value, 4096, fs) == 4096
+                return st
+            blk = FqBlock()
+            for _ in range(3):                                # the first round of buffers: nothing to wait for
+                assert fill() == 0
+                assert lib.hast_fq_submit_device(fq, 4096, 0) == 0
+                assert lib.hast_fq_next(fq, C.byref(blk)) == 0 and lib.hast_fq_commit(fq) == 0
+            assert fill() == 0 and fill() == 0                # two in hand of three buffers: the most there may be
+            assert lib.hast_fq_submit_device(fq, 4096, 0) == 0
+            assert lib.hast_fq_next(fq, C.byref(blk)) == 0 and lib.hast_fq_commit(fq) == 0
+            assert fill() == 0                                # again two in hand
+            assert lib.hast_fq_submit_device(fq, 4096, 0) == 0 and lib.hast_fq_submit_device(fq, 4096, 0) == 0
+            for _ in range(2):
+                assert lib.hast_fq_next(fq, C.byref(blk)) == 0 and lib.hast_fq_commit(fq) == 0
+            # three acquired, none submitted: the third would overwrite a tail that the framing of the first has yet to read
+            assert fill() == 0 and fill() == 0
+            assert fill() == 1 and b"in hand" in lib.hast_last_error()
+        lib.hast_fq_destroy(fq)
+
+
 def test_fq_short_read_is_reported(oracle_lib):
     k = 21
     lib = hast_amd.lib()

@@ -119,6 +119,67 @@ def test_counts_histograms_selections_vs_oracle(built, oracle_lib, k):
     o.ho_s00_free(c)
 
 
+@pytest.mark.parametrize("k,table_mb,record_mb", [(21, 64, 0), (21, 256, 2), (11, 64, 1), (29, 64, 0), (5, 64, 0), (27, 1024, 0), (31, 64, 0)])
+def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, table_mb, record_mb):
+    """The counting path of large tables (kc_kernels.hip "partitioned counting": windows written out as records of a minimizer run,
+    partitioned by bucket range in two levels, counted per slice in LDS), forced on small ones: counts, histograms and selections ==
+    oracle -- with an ample record buffer (one flush at sync), with a tiny one (HAST_KC_RECORD_MB: many flushes, records that find
+    no room are counted on the spot, bins that overflow go through the spill list), for K up to 29 (one window per record); K = 31
+    has no room for a run in a record and stays with the atomic kernel.  Streams with every byte class, homopolymers (thousands of
+    windows of one bucket: the spill path), both parents, a second round of counting after a read of the table."""
+    o = oracle_lib
+    rng = random.Random(900 + k + table_mb)
+    pat, mat = random_stream(rng, 400_000, k), random_stream(rng, 300_000, k)
+    shared = random_stream(rng, 150_000, k)
+    more = random_stream(rng, 100_000, k)
+    monkeypatch.setenv("HAST_KC_COUNT", "partition")
+    if record_mb:
+        monkeypatch.setenv("HAST_KC_RECORD_MB", str(record_mb))
+    with KmerCounter(k, table_bytes=table_mb << 20) as kc:
+        info = kc.partition_info()
+        assert info["partitioned"] == (k <= 29), info
+        kc.count(0, pat)
+        kc.count(1, mat)
+        for p in (0, 1):
+            kc.count(p, shared)
+        kc.sync()
+        c = oracle_table(o, k, [(0, pat), (0, shared), (1, mat), (1, shared)])
+        check_against_oracle(o, kc, c, k, None)
+        for lo, hi in [(1, 1 << 30), (2, 5), (1, 1)]:
+            assert [kc.select(p, lo, hi) for p in (0, 1)] == [oracle_select(o, c, p, lo, hi).size for p in (0, 1)], (lo, hi)
+        # counting goes on after the table has been read (a flush happens before every read)
+        kc.count(1, more)
+        o.ho_s00_add_stream(c, 1, more.ctypes.data, more.size)
+        check_against_oracle(o, kc, c, k, None)
+        info = kc.partition_info()
+        if k <= 29:
+            assert info["flushes"] >= 2 and info["records"] > 0, info
+            if record_mb:
+                assert info["flushes"] >= 3, info
+    o.ho_s00_free(c)
+
+
+def test_partitioned_and_atomic_counting_agree_on_a_trio(built, monkeypatch):
+    """the synthetic trio of the bench (reads with errors over two parental genomes) through both paths: same histograms, same
+    selections, same distinct / total counts"""
+    g = hast_amd.KcSynth(0, 3_000_000, 150, 2, 20, 20)
+    res = {}
+    for mode in ("atomic", "partition"):
+        monkeypatch.setenv("HAST_KC_COUNT", mode)
+        with KmerCounter(21, table_bytes=1 << 30) as kc:
+            assert kc.partition_info()["partitioned"] == (mode == "partition")
+            for parent in (0, 1):
+                for first in (0, 150_000):
+                    kc.count(parent, hast_amd.kc_synth_host(g, parent, first, 150_000))
+            kc.sync()
+            st = kc.stats()
+            res[mode] = (st["distinct"], st["total"], st["keys"], [kc.histo(p) for p in (0, 1)], [kc.select(p, 5, 60) for p in (0, 1)])
+    a, b = res["atomic"], res["partition"]
+    assert a[:3] == b[:3] and a[4] == b[4] and a[4][0] > 1000
+    for p in (0, 1):
+        assert np.array_equal(a[3][p], b[3][p])
+
+
 def test_slices_partition_the_key_space(built, oracle_lib):
     o, k = oracle_lib, 21
     rng = random.Random(7)
