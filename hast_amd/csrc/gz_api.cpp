@@ -92,7 +92,7 @@ struct hast_gz {
     uint32_t slot_syms = 0;
     // device
     uint32_t *d_in = nullptr;
-    DevBuf jobs, tabs, carry_next;
+    DevBuf jobs, carry_next;
     ChunkJob *h_jobs = nullptr;               // pinned
     size_t h_jobs_cap = 0;
     uint32_t *h_crc = nullptr;                // pinned
@@ -211,7 +211,9 @@ void publish_error(hast_gz *g, const std::string &msg) {
 // one segment's passes; returns "" or what failed
 std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t first_bit, bool &finished) {
     const size_t C = g->chunk_bytes, S = g->seg_chunks;
-    const size_t c0 = k * S, c1 = std::min(n_chunks, c0 + S);
+    // the first pass is a short one: the reader (the FASTQ framer, the classification behind it) has nothing to do until it is through
+    const size_t S0 = std::min<size_t>(S, 1024);
+    const size_t c0 = k == 0 ? 0 : S0 + (k - 1) * S, c1 = std::min(n_chunks, k == 0 ? S0 : c0 + S);
     const bool all_in = c1 >= n_chunks;
     // the compressed bytes this segment's chunks may read: their own and a margin behind them (a chunk runs on to the first
     // block boundary behind its stop)
@@ -259,7 +261,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
     }
     if (n_jobs) {
         GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(launch_search((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint32_t *)g->tabs.p, g->dec_stream));
+        GZ_HIP(launch_search((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, g->dec_stream));
         GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
         GZ_HIP(hipStreamSynchronize(g->dec_stream));
@@ -443,7 +445,6 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
     g->h_jobs_cap = seg + 8;
     step(hipHostMalloc((void **)&g->h_jobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
     step(g->jobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
-    step(g->tabs.ensure(g->h_jobs_cap * (size_t)kTabWords * sizeof(uint32_t)));
     step(g->carry_next.ensure(kWindow));
     if (e == hipSuccess) step(hipMemset(g->carry_next.p, 0, kWindow));
     for (Arena &a : g->arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
@@ -486,7 +487,6 @@ void hast_gz_close(hast_gz *g) {
         for (DevBuf &b : a.gap) b.release();
     }
     g->jobs.release();
-    g->tabs.release();
     g->carry_next.release();
     if (g->d_in) (void)hipFree(g->d_in);
     if (g->h_jobs) (void)hipHostFree(g->h_jobs);

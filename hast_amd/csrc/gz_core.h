@@ -32,9 +32,11 @@ namespace hast {
 namespace gz {
 
 constexpr uint32_t kLit = 1u << 13, kEob = 1u << 14, kSub = 1u << 15;
-constexpr int kLitRoot = 10, kDistRoot = 7;
-constexpr uint32_t kLitTabCap = 2048, kDistTabCap = 640, kPreTabCap = 128;      // entries (u32): first level + sub-tables (zlib's own bounds for complete codes
-                                                                                 // are 1332 and < 600 at these roots); a code that needs more is refused (kErrTableSize)
+// first-level table sizes as zlib's (9 / 6 bits): the tables of a block live in LDS on the device, 7 KB per wave, and the number of
+// waves a CU holds is what the decode kernel's throughput scales with
+constexpr int kLitRoot = 9, kDistRoot = 6;
+constexpr uint32_t kLitTabCap = 1024, kDistTabCap = 640, kPreTabCap = 128;      // entries (u32): first level + sub-tables (zlib's own bounds for complete codes
+                                                                                 // are 852 and 592 at these roots); a code that needs more is refused (kErrTableSize)
 constexpr uint32_t kTabWords = kLitTabCap + kDistTabCap + kPreTabCap;           // a lane's tables, back to back
 constexpr uint32_t kWindow = 32768;
 constexpr uint16_t kMarker = 0x8000;
@@ -434,8 +436,9 @@ GZ_HD void decode_chunk(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32
 }
 
 // Strict parse of a candidate position (what the search accepts as a block start): true iff a whole dynamic header stands there.
-GZ_HD bool header_parses(const uint32_t *w, uint64_t nbits, uint64_t bit, uint32_t *tabs) {
-    Tables t = tables_at(tabs);
+// pre: kPreTabCap words of scratch for the code-length code's table (LDS on the device: ~300 look-ups per parse)
+GZ_HD bool header_parses(const uint32_t *w, uint64_t nbits, uint64_t bit, uint32_t *pre) {
+    Tables t{nullptr, nullptr, pre};
     Bits in{w, nbits, 0, 0, 0};
     seek(in, bit + 3);
     return read_dynamic(in, t, true, false) == kErrNone && !overran(in);

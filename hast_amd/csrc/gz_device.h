@@ -16,7 +16,7 @@ struct AccDev {                  // an accepted chunk, in stream order
     uint32_t no_history;         // a member starts with it: no markers, the window in front of it is not part of its own
 };
 
-hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint32_t *d_tabs, hipStream_t s);
+hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s);
 // a wave per job; job.sym_off = the device address of the job's symbol buffer / 2
 hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s);
 // d_windows[c] = the 32 KB behind chunk c; d_carry = the 32 KB in front of chunk 0; d_scratch: windows_scratch_bytes(n)

@@ -25,8 +25,9 @@ namespace gz {
 // A wave per chunk, 64 bit positions per step, three sieves: (1) the 17 header bits every lane tests for itself (type bits 100b,
 // HLIT, HDIST in range: one position in 9 passes); (2) the survivors are queued (LDS, in position order) and, 64 at a time, tested
 // for a COMPLETE code-length code (one in ~100 passes); (3) what is left is parsed in full by one lane, lowest position first.
-__global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits, uint32_t *tabs) {
+__global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
     __shared__ uint32_t s_q[128];                                             // positions (relative to from_bit) that passed sieve 1
+    __shared__ uint32_t s_pre[kPreTabCap];                                    // the strict parse's code-length table (one lane at a time)
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob &job = jobs[j];
@@ -41,7 +42,6 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
     const uint64_t lim = nbits > 192 ? nbits - 192 : 0;                       // (bits_at reads 12 bytes, the strict parse more: the buffer is padded)
     uint64_t to = from + job.search_to_lo;
     if (to > lim) to = lim;
-    uint32_t *my_tabs = tabs + (size_t)j * kTabWords;
     uint64_t found = ~0ull;
     uint32_t qn = 0;
     // sieves 2 + 3 over the first `cnt` queue entries (position order)
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1;
             int ok = 0;
-            if ((int)lane == l) ok = header_parses(w, nbits, bit, my_tabs) ? 1 : 0;
+            if ((int)lane == l) ok = header_parses(w, nbits, bit, s_pre) ? 1 : 0;
             ok = __shfl(ok, l);
             if (ok) found = from + s_q[l];
         }
@@ -137,9 +137,9 @@ __device__ __forceinline__ uint16_t sym_load_far(const uint16_t *p) { return __h
 __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
     __shared__ uint32_t s_tab[kTabWords];
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
-    // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ nearly all: the records in front) is
+    // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the few records in front) is
     // copied out of LDS -- a global load per match would put ~1 us of latency on the path of every symbol behind it
-    constexpr uint32_t kRing = 4096, kRingReach = kRing - 320;
+    constexpr uint32_t kRing = 2048, kRingReach = kRing - 320;
     __shared__ uint16_t s_ring[kRing];
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
@@ -467,9 +467,9 @@ __global__ void __launch_bounds__(256) k_gz_translate(const AccDev *acc, uint32_
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------------------
-hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint32_t *d_tabs, hipStream_t s) {
+hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_search, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits, d_tabs);
+    hipLaunchKernelGGL(k_gz_search, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits);
     return hipGetLastError();
 }
 hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s) {

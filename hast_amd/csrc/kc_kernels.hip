@@ -110,7 +110,12 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
     unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);
     unsigned long long *s_pack = s_tile + 2;                         // [NW]
     uint32_t *s_inv = reinterpret_cast<uint32_t *>(s_pack + NW);     // [NW] invalid-byte masks (bit 31 = first base)
-    uint32_t *s_mh = s_inv + NW;                                     // [TB + W]
+    uint32_t *s_mh = s_inv + NW;                                     // [TB + W] (+ 64: kc_count_smem)
+    // EMIT: the tile's records are gathered here and go out with ONE reservation per tile -- a reservation per wave step is 160 M
+    // atomic adds on one word per 10 G windows, and adds to ONE address serialise at the memory side (measured: 10 x the kernel's time)
+    unsigned long long *s_rec = reinterpret_cast<unsigned long long *>(smem + ((16 + (size_t)NW * 8 + (size_t)NW * 4 + (size_t)(TB + W + 64) * 4 + 15) & ~(size_t)15));   // [TB]
+    __shared__ uint32_t s_nrec;
+    __shared__ unsigned long long s_rec_base;
     const uint32_t tid = threadIdx.x;
     const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
     const uint64_t n_tiles = (a.n_starts + TB - 1) / TB;
@@ -125,7 +130,10 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
         if (tile >= n_tiles) break;
         const uint64_t t0 = tile * TB;
         __syncthreads();
-        if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
+        if (tid == 0) {
+            *s_tile = atomicAdd(a.tile_queue, 1ull);
+            s_nrec = 0;
+        }
 
         // ---- A: 16 bytes per lane -> 32 bits of codes + 16 validity bits -----------------------------------
         const uint32_t HW = NW * 2;
@@ -204,15 +212,13 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                 const uint32_t run = after ? 1u + (uint32_t)__builtin_ctzll(after) : 64u - lane;
                 if (sm) {
                     const uint32_t cnt = (uint32_t)__popcll(sm);
-                    unsigned long long at0 = 0;
-                    if (lane == 0) at0 = atomicAdd(a.rec_cursor, (unsigned long long)cnt);
-                    at0 = __shfl(at0, 0, 64);
+                    uint32_t at0 = 0;
+                    if (lane == 0) at0 = atomicAdd(&s_nrec, cnt);
+                    at0 = (uint32_t)__shfl((int)at0, 0, 64);
                     if (start) {
                         const uint32_t nbases = (uint32_t)K + run - 1;
-                        const unsigned long long rec = (window_bits(s_pack, p, 64 - 2 * nbases) << 6) | ((unsigned long long)(run - 1) << 1) | a.parent;
-                        const unsigned long long at = at0 + (unsigned long long)__popcll(sm & ((1ull << lane) - 1));
-                        if (at < a.rec_cap) a.rec_out[at] = rec;
-                        else kc_count_record(a.table, a.nbuckets, K, M, rec, a.err);
+                        s_rec[at0 + (uint32_t)__popcll(sm & ((1ull << lane) - 1))] =
+                            (window_bits(s_pack, p, 64 - 2 * nbases) << 6) | ((unsigned long long)(run - 1) << 1) | a.parent;
                     }
                 }
                 continue;
@@ -235,13 +241,24 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             }
         }
         __syncthreads();
+        if (EMIT) {
+            const uint32_t n = s_nrec;
+            if (tid == 0 && n) s_rec_base = atomicAdd(a.rec_cursor, (unsigned long long)n);
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kKcThreads) {
+                const unsigned long long at = s_rec_base + i;
+                if (at < a.rec_cap) a.rec_out[at] = s_rec[i];
+                else kc_count_record(a.table, a.nbuckets, K, M, s_rec[i], a.err);          // (no room: counted on the spot)
+            }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) counted += __shfl_down(counted, off, 64);
     if ((tid & 63) == 0 && counted) atomicAdd(a.total + a.parent, counted);
 }
 
 template <int WT, bool EMIT>
-static hipError_t launch_kc_count_e(const KcCountArgs &a, unsigned grid, size_t smem, hipStream_t s) {
+static hipError_t launch_kc_count_e(const KcCountArgs &a, unsigned grid, size_t smem0, hipStream_t s) {
+    const size_t smem = EMIT ? ((smem0 + 15) & ~(size_t)15) + (size_t)a.tile_bases * 8 + 16 : smem0;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_count<WT, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
@@ -445,10 +462,18 @@ __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, cons
                     ++sl;                                                        // taken by another key: slots never change once written
                 }
             }
-            if (!done) {
-                const unsigned long long at = atomicAdd(spill_n, 1ull);
-                if (at < spill_cap) spill[at] = (raw << 6) | parent;            // a record of one window
-                else atomicOr(g.err, 1u);
+            // (one reservation per wave and step, not per window: adds to one address serialise at the memory side)
+            const unsigned long long lost = __ballot(!done);
+            if (lost) {
+                const uint32_t lane = tid & 63, first = (uint32_t)__builtin_ctzll(lost);
+                unsigned long long at0 = 0;
+                if (lane == first) at0 = atomicAdd(spill_n, (unsigned long long)__popcll(lost));
+                at0 = __shfl(at0, first, 64);
+                if (!done) {
+                    const unsigned long long at = at0 + (unsigned long long)__popcll(lost & ((1ull << lane) - 1));
+                    if (at < spill_cap) spill[at] = (raw << 6) | parent;        // a record of one window
+                    else atomicOr(g.err, 1u);
+                }
             }
         }
     }

@@ -32,7 +32,7 @@ PASS[l2]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
 PASS[sq]="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
 PASS[sq2]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT"
 for name in rdsize rddram fetch write l2 sq sq2; do
-  rocprofv3 --pmc ${PASS[$name]} --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 $FLAGS > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc ${PASS[$name]} --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --batches-per-step 1 --no-secondary --cpu-seconds 0 $FLAGS > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
 done
 if [ -z "$FLAGS" ]; then
   for name in rdsize rddram fetch; do

@@ -29,7 +29,7 @@ static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std
         const uint64_t lim = nbits > 192 ? nbits - 192 : 0;
         for (uint64_t bit = j.from_bit; bit < j.from_bit + j.search_to_lo && bit < lim; ++bit) {
             if (!candidate(bits_at(g_words.data(), bit), bits_at(g_words.data(), bit + 56))) continue;
-            if (!header_parses(g_words.data(), nbits, bit, tabs.data())) continue;
+            if (!header_parses(g_words.data(), nbits, bit, tabs.data() + kLitTabCap + kDistTabCap)) continue;
             j.start_bit = bit;
             found = true;
             break;

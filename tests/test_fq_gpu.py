@@ -240,7 +240,7 @@ def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=40
             if not eof and len(in_hand) < lag and in_use < n_buffers:
                 buf = C.POINTER(C.c_uint8)()
                 assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
-                assert not buf                                       # no pinned host copy on such a stream
+                assert submitted or not buf                          # no pinned host copy on such a stream (until a block was fetched)
                 d, fs = C.c_void_p(), C.c_void_p()
                 assert lib.hast_fq_device_block(fq, C.byref(d), C.byref(fs)) == 0, lib.hast_last_error()
                 n = z.read_device(d.value, block, fs)
