@@ -262,7 +262,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
     if (n_jobs) {
         GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
         GZ_HIP(launch_search((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint16_t *)A.syms.p, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
         GZ_HIP(hipStreamSynchronize(g->dec_stream));
     }
@@ -291,7 +291,7 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
             j.status = kStFound;
         }
         GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, (uint16_t *)gb.p, g->dec_stream));
         GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
         GZ_HIP(hipStreamSynchronize(g->dec_stream));
         g->chain.gap_done(g->h_jobs, gaps.size(), input_bits);

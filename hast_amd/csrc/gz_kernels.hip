@@ -106,35 +106,52 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
 // symbols in LDS when it reaches back less than that (a global load per match would put ~1 us on the path of every symbol behind
 // it), out of the symbol buffer otherwise (behind a fence, past the L1).  Output symbols: literal byte, or kMarker + i = "byte i
 // of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
-struct WBits {                     // wave-uniform bit input with one word of look-ahead (its load is issued a refill early)
-    const uint32_t *w;
-    uint64_t nwords;               // words that may be read (real words + padding)
-    uint64_t bb;
-    uint64_t wp;                   // index of `ahead`
-    uint32_t bc, ahead;
+struct WBits {                     // wave-uniform bit input.  The next 64 words of the stream sit in a VGPR, one per lane (`win`,
+    const uint32_t *w;             // word wbase + lane), the 64 behind them in `nxt` (loaded when `win` is taken into use, a few hundred
+    uint64_t nwords;               // symbols before anyone needs them): a refill is a v_readlane, no memory access is on the
+    uint64_t bb;                   // path from one symbol to the next
+    uint64_t wp;                   // index of the next word to take
+    uint64_t wbase;                // index of win's lane 0
+    uint32_t bc, win, nxt;
 };
 __device__ __forceinline__ uint32_t wload(const WBits &b, uint64_t i) { return i < b.nwords ? b.w[i] : 0u; }
+__device__ __forceinline__ uint32_t wword(WBits &b) {            // the word at wp
+    uint64_t idx = b.wp - b.wbase;
+    if (idx >= 64) {                                              // (uniform)
+        b.win = b.nxt;
+        b.wbase += 64;
+        b.nxt = wload(b, b.wbase + 64 + threadIdx.x);
+        idx -= 64;
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)b.win, (int)idx);
+}
 __device__ __forceinline__ void wseek(WBits &b, uint64_t bit) {
     const uint64_t wi = bit >> 5;
     const uint32_t sh = (uint32_t)(bit & 31);
-    b.bb = (uint64_t)wload(b, wi) >> sh;
+    b.wbase = wi;
+    b.win = wload(b, wi + threadIdx.x);
+    b.nxt = wload(b, wi + 64 + threadIdx.x);
+    b.wp = wi;
+    b.bb = (uint64_t)wword(b) >> sh;
     b.bc = 32 - sh;
     b.wp = wi + 1;
-    b.ahead = wload(b, b.wp);
 }
 __device__ __forceinline__ void wrefill(WBits &b) {
     if (b.bc <= 32) {
-        b.bb |= (uint64_t)b.ahead << b.bc;
+        b.bb |= (uint64_t)wword(b) << b.bc;
         b.bc += 32;
         b.wp++;
-        b.ahead = wload(b, b.wp);
     }
 }
 __device__ __forceinline__ uint64_t wpos(const WBits &b) { return b.wp * 32 - b.bc; }
 __device__ __forceinline__ void sym_store(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ uint16_t sym_load_far(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (past the L1)
 
-__global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
+// syms: the base of the symbol memory the jobs' buffers lie in (job.sym_off is an absolute address / 2: the buffer is reached as
+// syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
+// which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
+// symbol instead of ~300)
+__global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
     __shared__ uint32_t s_tab[kTabWords];
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
     // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the few records in front) is
@@ -151,12 +168,12 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
         }
         return;
     }
-    uint16_t *const sym = reinterpret_cast<uint16_t *>((uintptr_t)(job.sym_off * 2));
+    uint16_t *const sym = syms + (ptrdiff_t)((long long)job.sym_off - (long long)(reinterpret_cast<uintptr_t>(syms) >> 1));
     const uint32_t cap = job.sym_cap;
     const bool no_history = (job.flags & kJobNoHistory) != 0;
     const uint32_t *const lit = s_tab, *const dst = s_tab + kLitTabCap;
     constexpr uint32_t LM = (1u << kLitRoot) - 1, DM = (1u << kDistRoot) - 1;
-    WBits in{w, ((nbits + 31) >> 5) + 2, 0, 0, 0, 0};
+    WBits in{w, ((nbits + 31) >> 5) + 2, 0, 0, 0, 0, 0, 0};
     uint64_t at = job.start_bit;
     uint32_t n = 0, status = kStFound, err = kErrNone;
     bool any = false;
@@ -472,9 +489,9 @@ hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint
     hipLaunchKernelGGL(k_gz_search, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits);
     return hipGetLastError();
 }
-hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s) {
+hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint16_t *d_syms, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_decode, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits);
+    hipLaunchKernelGGL(k_gz_decode, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits, d_syms);
     return hipGetLastError();
 }
 size_t windows_scratch_bytes(uint32_t n) { return (size_t)n * kWindow * sizeof(uint16_t) + (size_t)((n + kGroup - 1) / kGroup) * kWindow; }

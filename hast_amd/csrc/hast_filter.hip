@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
     const uint32_t WS = W64 + 1;                                     // LDS words per read incl. pad
     const uint32_t L1S = RLC ? (uint32_t)((RL - GC0::t + 1 + 1 + 3) & ~3) : a.l1_stride;
     unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);            // next tile of this workgroup
+    uint32_t *s_dirty = reinterpret_cast<uint32_t *>(s_tile + 1);                          // STRICT: some row of the tile holds a byte outside ACGT
     uint32_t *s_l1 = reinterpret_cast<uint32_t *>(s_tile + 2);                             // [TR][L1S] (+ 64 pad), 16-B aligned rows
     unsigned long long *s_pack = reinterpret_cast<unsigned long long *>(s_l1 + (size_t)TR * L1S + 64);   // [TR][WS]
     unsigned long long *s_vote = s_pack + (size_t)TR * WS;                                 // [TR]
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
         const uint32_t tra = (uint32_t)((n_rows - r0 < TR) ? (n_rows - r0) : TR);
 
         // ---- per-read header --------------------------------------------------------------
+        if (STRICT && tid == 0) *s_dirty = 0;           // (phase A, behind the barrier below, raises it; everyone is past the previous tile's probes)
         if (tid < tra) {
             uint64_t off, len;
             const uint32_t rlen = RLC ? (uint32_t)RL : a.read_len;
@@ -261,7 +263,10 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             if (STRICT) {
                 uint16_t *di = reinterpret_cast<uint16_t *>(s_inv + (size_t)r * IW + (j >> 1)) + (1 - (j & 1));
                 *di = (uint16_t)invalid;
-                if (invalid) atomicOr(&s_flag[r], 1u);                          // the row holds a byte outside ACGT somewhere
+                if (invalid) {
+                    atomicOr(&s_flag[r], 1u);                                   // the row holds a byte outside ACGT somewhere
+                    *s_dirty = 1;                                                // ... and so does the tile
+                }
             } else if (nflag) atomicOr(&s_flag[r], 1u);
         }
         __syncthreads();
@@ -319,6 +324,9 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
 
         // ---- B: probe ---------------------------------------------------------------------------------------------
         const uint32_t P = RLC ? (uint32_t)(RL - GC0::k + 1) : a.max_pos;   // windows per read (stride)
+        // STRICT: nearly every tile is clean (long reads hold an 'N' or a lower-case run every few hundred kb): one scalar test per
+        // probe instruction instead of a row-flag read + compare + ballot per window
+        const bool tile_dirty = STRICT && __builtin_amdgcn_readfirstlane((int)*s_dirty) != 0;
         uint32_t qn = 0;                                              // positives waiting in this wave's queue
         // V: the last `cnt` queue entries, one per lane, against the exact table
         auto drain = [&](uint32_t cnt) {
@@ -390,7 +398,7 @@ __global__ void __launch_bounds__(kThreadsF, HAST_F_MINWAVES) k_classify_f(Class
             unsigned long long okm = ballot64(inq) & ballot64(fits);
             if (STRICT) {           // any byte of [p, p+K) outside ACGT => the window cannot match a stored string
                 // (rows without such a byte -- nearly all of them -- are flagged clean by phase A: the wave skips the masks)
-                if (ballot64(s_flag[r] != 0)) {
+                if (tile_dirty && ballot64(s_flag[r] != 0)) {
                     const uint32_t *iw = s_inv + mul24(r, IW) + (p >> 5);
                     const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
                     const bool clean = (bits >> (64 - K)) == 0;

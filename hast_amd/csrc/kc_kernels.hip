@@ -414,7 +414,9 @@ __global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const 
 // One workgroup per fine bin: its slice of the table in LDS, its records counted there, the slice written back.  A window whose
 // bucket and the next three are full (or lie behind the slice's end) goes to the spill list as a record of one window; a full
 // spill list is a full table as far as the caller is concerned (err bit 0).
-constexpr int kKcApplyThreads = 256;
+// 1024 threads: a slice takes 64 or 128 KB of LDS, so a CU holds one or two of these workgroups -- with 256 threads that was 8 waves
+// per CU, every one of them waiting on its own chain of loads (measured: 0.52 s per flush of the bench's 60-GB table, 270 GB/s)
+constexpr int kKcApplyThreads = 1024;
 __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, const unsigned long long *recs, uint32_t cap, const uint32_t *fill, const uint32_t *valid,
                                                               unsigned long long *spill, unsigned long long spill_cap, unsigned long long *spill_n) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -434,8 +436,15 @@ __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, cons
     __syncthreads();
     const unsigned long long *mine = recs + (size_t)fine * cap;
     const unsigned long long kmask = kmer_mask(g.k);
-    for (uint32_t i = tid; i < n; i += kKcApplyThreads) {
-        const unsigned long long rec = mine[i];
+    // (the records of a thread are fetched four at a time: their loads overlap instead of queueing one behind the other's use)
+    for (uint32_t i0 = tid; i0 < n; i0 += 4 * kKcApplyThreads) {
+      unsigned long long batch[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) batch[q] = i0 + (uint32_t)q * kKcApplyThreads < n ? mine[i0 + (uint32_t)q * kKcApplyThreads] : ~0ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i0 + (uint32_t)q * kKcApplyThreads >= n) break;
+        const unsigned long long rec = batch[q];
         const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
         const unsigned long long bases = rec >> 6;
         const uint32_t home = bucket_of_minhash(kc_rec_minhash((bases >> (2 * (run - 1))) & kmask, g.k, g.m), g.nbuckets);
@@ -476,6 +485,7 @@ __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, cons
                 }
             }
         }
+      }
     }
     __syncthreads();
     {
