@@ -417,10 +417,14 @@ __global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const 
 // 1024 threads: a slice takes 64 or 128 KB of LDS, so a CU holds one or two of these workgroups -- with 256 threads that was 8 waves
 // per CU, every one of them waiting on its own chain of loads (measured: 0.52 s per flush of the bench's 60-GB table, 270 GB/s)
 constexpr int kKcApplyThreads = 1024;
+constexpr uint32_t kKcLdsStride = kKcBucketWords + 1;                            // words per bucket in LDS (k_kc_apply)
 __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, const unsigned long long *recs, uint32_t cap, const uint32_t *fill, const uint32_t *valid,
                                                               unsigned long long *spill, unsigned long long spill_cap, unsigned long long *spill_n) {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(smem);   // [buckets of the slice][kKcBucketWords]
+    // [buckets of the slice][kKcLdsStride]: a bucket is 16 words = 128 B = exactly the 32 LDS banks, so slot i of EVERY bucket would sit
+    // in the same bank and the 64 lanes of a probe (64 different buckets, the same slot) would take 64 turns at it; one word of
+    // padding per bucket spreads them (measured: the kernel 0.43 s per flush without it)
+    unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(smem);
     const uint32_t fine = blockIdx.x, tid = threadIdx.x;
     const uint32_t f = fill[fine], v = valid[fine];
     const uint32_t n = f < v ? (f < cap ? f : cap) : v;
@@ -430,8 +434,12 @@ __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, cons
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     {
         const u64x2 *gsrc = reinterpret_cast<const u64x2 *>(g.table + (size_t)b0 * kKcBucketWords);
-        u64x2 *ldst = reinterpret_cast<u64x2 *>(s_tab);
-        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) ldst[i] = gsrc[i];
+        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) {
+            const u64x2 v = gsrc[i];
+            unsigned long long *d = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
+            d[0] = v.x;
+            d[1] = v.y;
+        }
     }
     __syncthreads();
     const unsigned long long *mine = recs + (size_t)fine * cap;
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, cons
             for (uint32_t p = 0; p < 4 && !done; ++p) {
                 const uint32_t b = home + p;                                    // (kc_probe: the bucket, then the next three)
                 if (b < b0 || b >= b0 + nb_here) break;                          // behind the slice (or wrapped): the atomic path's business
-                unsigned long long *bk = s_tab + (size_t)(b - b0) * kKcBucketWords;
+                unsigned long long *bk = s_tab + (size_t)(b - b0) * kKcLdsStride;
                 uint32_t *cnt = reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots;
                 for (int sl = 0; sl < kKcSlots;) {
                     unsigned long long cur = __hip_atomic_load(&bk[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -490,8 +498,10 @@ __global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, cons
     __syncthreads();
     {
         u64x2 *gdst = reinterpret_cast<u64x2 *>(g.table + (size_t)b0 * kKcBucketWords);
-        const u64x2 *lsrc = reinterpret_cast<const u64x2 *>(s_tab);
-        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) gdst[i] = lsrc[i];
+        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) {
+            const unsigned long long *sp = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
+            gdst[i] = u64x2{sp[0], sp[1]};
+        }
     }
 }
 // the spill list through the atomic path (after k_kc_apply: nobody holds a slice any more)
@@ -504,7 +514,7 @@ __global__ void __launch_bounds__(256) k_kc_spill(KcPartGeom g, const unsigned l
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
     KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err};
     const size_t lds_part = (size_t)3 * kKcMaxFan * 4 + (size_t)kKcPartRecs * 8;
-    const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcBucketWords * 8;
+    const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcLdsStride * 8;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply);
