@@ -95,13 +95,14 @@ hast_status check_synth(const hast_kc_synth *p) {
 }
 }  // namespace
 
-// Partitioned counting is worth its buffers when the table is far larger than the caches (>= 2^20 buckets = 128 MB) and K leaves
-// room for a run of windows in a record (K <= 29); HAST_KC_COUNT=atomic|partition in the environment (read here, once) forces either.
-// The buffers take what is left of the device memory next to the table: ~22.5 B per record of capacity.
+// Partitioned counting (kc_kernels.hip): opt-in with HAST_KC_COUNT=partition in the environment (read here, once) as long as its
+// last pass is slower than the direct kernel (measured in round 4: 0.58 s against 0.27 s on the bench's trio; the passes in front
+// of the LDS probes take 0.20 s).  K must leave room for a run of windows in a record (K <= 29).  The buffers take what is left
+// of the device memory next to the table: ~22.5 B per record of capacity.
 static void part_setup(hast_kc *c) {
     const char *e = getenv("HAST_KC_COUNT");
-    const bool forced = e && !strcmp(e, "partition"), off = e && !strcmp(e, "atomic");
-    if (off || c->k > 29 || (!forced && c->nbuckets < (1u << 20))) return;
+    const bool forced = e && !strcmp(e, "partition");
+    if (!forced || c->k > 29) return;
     c->fine_shift = ((uint64_t)c->nbuckets >> 9) > (1u << 20) ? 10 : 9;
     const uint64_t n_fine = ((uint64_t)c->nbuckets + (1u << c->fine_shift) - 1) >> c->fine_shift;
     if (n_fine > (1u << 20)) return;                                   // a table of more than 2^30 buckets (128 GB): two levels of 1024 do not reach

@@ -8,6 +8,7 @@
 //                  the window's minimizer bucket (128-B line: 8 keys + 8 paternal + 8 maternal counters) -> one atomic add
 //   k_kc_stats / k_kc_histo / k_kc_select : streaming passes over the table
 //   k_kc_format  : selected keys -> text lines
+#include <cstdlib>
 #include <cstring>
 
 #include "hast_common.h"
@@ -294,8 +295,13 @@ hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s) {
 // 512 or 1024 buckets, and then one workgroup per bin holds its slice of the table in LDS, counts its records there with LDS
 // atomics and writes the slice back: the table is read and written once per flush, sequentially, and no atomic leaves the chip
 // except one reservation per (workgroup, bin) and the few windows whose buckets are full beyond the slice (k_kc_spill).
-//   HBM traffic per window: 8 B x 6 / ~3.5 windows per record + the sweep of the table (11 B at 30x) ~ 25 B, against one 128-B
+//   HBM traffic per window: 8 B x 6 / ~3.3 windows per record + the sweep of the table (11 B at 30x) ~ 25 B, against one 128-B
 //   line read + one atomic per minimizer run before.
+// Measured (round 4, bench.py --workload s00, 10.4 G windows, 60-GB table): emit 76 ms + two partition passes
+// 61 ms + the sweep of the table 30 ms + record loads / minimizers / canonical keys 33 ms = 0.20 s = 59 Gbp/s -- and the LDS probes
+// of k_kc_apply on top of that 0.38 s (a lane per RECORD: runs of 1..9 windows and 1..32 slot probes diverge, 4-way bank
+// conflicts), 0.58 s in all against 0.27 s of the direct kernel.  Hence OPT-IN (HAST_KC_COUNT=partition) until the probes are
+// re-shaped (a lane per window, slot-major slices).
 struct KcPartGeom {
     unsigned long long *table;
     uint32_t nbuckets;

@@ -420,14 +420,16 @@ hast_status hast_kc_count_device(hast_kc *, int parent, const uint8_t *d_bytes, 
 hast_status hast_kc_count(hast_kc *, int parent, const uint8_t *bytes, size_t n_bytes);
 /* wait for all counting submitted so far; HAST_ERR_TABLE_FULL when some k-mer found no slot */
 hast_status hast_kc_sync(hast_kc *);
-/* How the windows reach the table.  Tables of >= 2^20 buckets (128 MB) and K <= 29 count by PARTITIONING (hast_amd/csrc/kc_kernels.hip):
- * the windows are written out as 8-byte records of a minimizer run each, the records are partitioned by bucket range in two levels
- * down to slices of 512 or 1024 buckets, and one workgroup per slice counts its records in LDS -- the table is read and written
- * once per flush, sequentially, instead of one memory-side atomic per minimizer run (which is what bounds the direct kernel).
- * Flushes happen at hast_kc_sync, before the table is read, and when the record buffer (what is left of the device memory next to
- * the table; HAST_KC_RECORD_MB caps the record buffer itself) is nearly full.  HAST_KC_COUNT=atomic|partition in the environment at hast_kc_create forces
- * either path; the results are the same.  out[0] = 1: partitioned; out[1] flushes; out[2] records applied; out[3] windows that took
- * the atomic path after all (their bucket and the next three full beyond the slice); out[4] record capacity. */
+/* How the windows reach the table.  By default: find-or-insert in the window's minimizer bucket + one atomic add per minimizer run
+ * (k_kc_count), which stands at the rate at which this part executes memory-side atomics.  HAST_KC_COUNT=partition in the
+ * environment at hast_kc_create (K <= 29) counts by PARTITIONING instead (hast_amd/csrc/kc_kernels.hip): the windows are written out
+ * as 8-byte records of a minimizer run each, the records are partitioned by bucket range in two levels down to slices of 512 or
+ * 1024 buckets, and one workgroup per slice counts its records in LDS -- the table is read and written once per flush,
+ * sequentially.  Same results (tests); opt-in because its last pass is still slower than the direct kernel (DESIGN.md section 9
+ * has the measured breakdown).  Flushes happen at hast_kc_sync, before the table is read, and when the record buffer (what is left
+ * of the device memory next to the table; HAST_KC_RECORD_MB caps the record buffer itself) is nearly full.  out[0] = 1: partitioned;
+ * out[1] flushes; out[2] records applied; out[3] windows that took the atomic path after all (their bucket and the next three full
+ * beyond the slice); out[4] record capacity. */
 hast_status hast_kc_partition_info(hast_kc *, uint64_t out[5]);
 /* out[0..1] distinct k-mers per parent, out[2] keys in the table, out[3] table capacity (slots),
  * out[4..5] k-mer occurrences counted per parent */
