@@ -55,7 +55,7 @@ struct hast_kc {
     bool part_on = false;
     uint32_t fine_shift = 9, n_fine = 0, n_l1 = 0, f2 = 0;
     unsigned long long *d_rec = nullptr, *d_l1 = nullptr, *d_spill = nullptr;
-    uint32_t *d_fills = nullptr;               // [n_l1 fill | n_l1 valid | n_fine fill | n_fine valid]
+    uint32_t *d_fills = nullptr;               // [n_l1 fill | n_l1 valid] (kKcL1FillWords apart) [n_fine fill | n_fine valid]
     uint64_t rec_cap = 0, a_cap = 0, b_cap = 0, spill_cap = 0;
     uint64_t est_records = 0;                  // upper bound of the records written since the last flush
     uint64_t n_flushes = 0, n_flushed_records = 0, n_spilled = 0;
@@ -102,7 +102,7 @@ hast_status check_synth(const hast_kc_synth *p) {
 static void part_setup(hast_kc *c) {
     const char *e = getenv("HAST_KC_COUNT");
     const bool forced = e && !strcmp(e, "partition");
-    if (!forced || c->k > 29) return;
+    if (!forced || kc_run_max(c->k, c->m) == 0) return;                 // (K <= 27 with the default minimizer length: a record is 64 bits)
     c->fine_shift = ((uint64_t)c->nbuckets >> 9) > (1u << 20) ? 10 : 9;
     const uint64_t n_fine = ((uint64_t)c->nbuckets + (1u << c->fine_shift) - 1) >> c->fine_shift;
     if (n_fine > (1u << 20)) return;                                   // a table of more than 2^30 buckets (128 GB): two levels of 1024 do not reach
@@ -111,7 +111,7 @@ static void part_setup(hast_kc *c) {
     c->f2 = (uint32_t)((n_fine + c->n_l1 - 1) / c->n_l1);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-    const uint64_t fixed = 8ull * (64ull * c->n_fine + 4096ull * c->n_l1 + (1u << 20)) + 8ull * (c->n_l1 + c->n_fine) + (64u << 20);
+    const uint64_t fixed = 8ull * (64ull * c->n_fine + 4096ull * c->n_l1 + (1u << 20)) + 8ull * ((uint64_t)c->n_l1 * kKcL1FillWords + c->n_fine) + (64u << 20);
     const uint64_t budget = (uint64_t)((double)free_b * 0.8);
     if (budget <= fixed + (16u << 20)) return;
     uint64_t R = (uint64_t)((double)(budget - fixed) / 22.6);
@@ -125,7 +125,7 @@ static void part_setup(hast_kc *c) {
     hipError_t h = hipMalloc(reinterpret_cast<void **>(&c->d_rec), c->a_cap * 8);
     if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_l1), c->b_cap * 8);
     if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_spill), c->spill_cap * 8);
-    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_fills), 8ull * (c->n_l1 + c->n_fine));
+    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_fills), 8ull * ((uint64_t)c->n_l1 * kKcL1FillWords + c->n_fine));
     if (h != hipSuccess) {                                             // no room: count with atomics, as before
         (void)hipGetLastError();
         for (void *p : {(void *)c->d_rec, (void *)c->d_l1, (void *)c->d_spill, (void *)c->d_fills})
@@ -159,8 +159,8 @@ static hast_status part_flush(hast_kc *c) {
     a.l1_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->b_cap / c->n_l1, n / c->n_l1 + n / c->n_l1 / 4 + 4096));
     a.fine_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->a_cap / c->n_fine, n / c->n_fine + n / c->n_fine / 2 + 64));
     a.l1_fill = c->d_fills;
-    a.l1_valid = c->d_fills + c->n_l1;
-    a.fine_fill = c->d_fills + 2 * (size_t)c->n_l1;
+    a.l1_valid = c->d_fills + (size_t)c->n_l1 * kKcL1FillWords;
+    a.fine_fill = c->d_fills + 2 * (size_t)c->n_l1 * kKcL1FillWords;
     a.fine_valid = a.fine_fill + c->n_fine;
     a.spill = c->d_spill;
     a.spill_cap = c->spill_cap;
@@ -297,18 +297,25 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
     a.rec_out = nullptr;
     a.rec_cap = 0;
     a.rec_cursor = nullptr;
+    a.rec_chunk = 0;
+    a.rec_run_max = a.rec_off_bits = 0;
     if (c->part_on) {
         // (an upper bound of one record per two windows; a minimizer run holds ~3.5.  What does not fit the buffer after all is
         // counted on the spot, by the kernel itself)
-        if (c->est_records + n_starts / 2 + 1 > c->rec_cap)
+        // ... plus the chunk a workgroup has in hand when it ends (filled with null records)
+        a.rec_chunk = 2 * a.tile_bases;
+        a.rec_run_max = kc_run_max(c->k, c->m);
+        a.rec_off_bits = kc_rec_off_bits(c->k, c->m);
+        const uint64_t worst = n_starts / 2 + 1 + (uint64_t)c->n_cu * 4 * a.rec_chunk;
+        if (c->est_records + worst > c->rec_cap)
             if (hast_status st = part_flush(c)) return st;
         a.rec_out = c->d_rec;
         a.rec_cap = c->rec_cap;
         a.rec_cursor = c->d_small + kRecCursor;
-        c->est_records += n_starts / 2 + 1;
+        c->est_records += worst;
     }
     const size_t n_tiles = (n_starts + a.tile_bases - 1) / a.tile_bases;
-    const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)c->n_cu * 8);
+    const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)c->n_cu * (c->part_on ? 4 : 8));
     KC_TRY(hipMemsetAsync(c->d_small + kQueue, 0, sizeof(unsigned long long), c->stream));
     KC_TRY(launch_kc_count(a, grid, c->stream));
     return HAST_OK;

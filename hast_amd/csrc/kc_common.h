@@ -24,6 +24,30 @@ HAST_HD uint64_t kc_to_print_key(uint64_t key, int k) {
 // and back: printed key -> table key
 HAST_HD uint64_t kc_from_print_key(uint64_t pk, int k) { return kmer_canon(kc_recode(pk), k); }   // the recoding is an involution
 
+// ---- records of the partitioned counting path (kc_kernels.hip) -----------------------------------------------------------------
+// A record = the bases of a run of consecutive windows that share their minimizer (the SAME m-mer occurrence, so that a run is at
+// most W = K - m + 1 windows), packed into 64 bits:
+//   [offset of that m-mer in the run's first window : ob bits at the top][bases: 2 (K + run - 1) bits, first base most
+//   significant, ending at bit 6][run - 1 : 5 bits][parent : 1 bit]
+// The offset is what makes a record cheap to place: its bucket follows from ONE canonical m-mer hash instead of the minimum over W
+// of them (the partition passes and the LDS pass each place every record once; recomputing the minimum took most of their time).
+HAST_HD uint32_t kc_rec_off_bits(int k, int m) {
+    uint32_t b = 0;
+    while ((1u << b) < (uint32_t)(k - m + 1)) ++b;
+    return b;
+}
+// longest run a record has room for (0: none -- K too large for this path)
+HAST_HD uint32_t kc_run_max(int k, int m) {
+    const int r = (58 - (int)kc_rec_off_bits(k, m)) / 2 - k + 1, w = k - m + 1;
+    const int c = r < w ? r : w;
+    return c < 1 ? 0u : (c > 16 ? 16u : (uint32_t)c);
+}
+HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
+    const uint32_t run = (uint32_t)((rec >> 1) & 31) + 1, off = ob ? (uint32_t)(rec >> (64 - ob)) : 0u;
+    const uint64_t first = ((rec >> 6) >> (2 * (run - 1))) & kmer_mask(k);
+    return mmer_hash32(kmer_canon((first >> (2 * ((uint32_t)(k - m) - off))) & kmer_mask(m), m));
+}
+
 // slice of the key space a window belongs to (decided by its minimizer, so a bucket never mixes slices)
 HAST_HD uint32_t kc_slice_of(uint32_t minh, uint32_t n_slices) {
     uint32_t h = minh * 0x85EBCA6Bu;

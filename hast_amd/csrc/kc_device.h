@@ -25,6 +25,8 @@ struct KcCountArgs {
     unsigned long long *rec_out;
     unsigned long long rec_cap;
     unsigned long long *rec_cursor;  // records written so far (may run past rec_cap: those were counted on the spot)
+    uint32_t rec_run_max, rec_off_bits;   // kc_run_max / kc_rec_off_bits of (k, m)
+    uint32_t rec_chunk;              // records a workgroup reserves at a time (>= tile_bases / 2); unused ends are filled with null records
 };
 
 // one flush of the partitioned path: records -> level-1 regions -> fine regions (in the flat buffer's place) -> slices in LDS -> spill
@@ -43,6 +45,8 @@ struct KcFlushArgs {
     unsigned long long *spill_n;     // zeroed by the caller before the first record of a flush period is emitted
     uint32_t *err;
 };
+constexpr uint32_t kKcL1FillWords = 1;    // words between two level-1 fill / valid counters (a line apart, 32, was slower: the adds of a wave
+                                          // to neighbouring counters leave the CU merged per 32-B sector)
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s);
 size_t kc_count_smem(uint32_t tile_bases, int k, int m);
 hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s);

@@ -72,25 +72,12 @@ __device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t
 }
 
 // One workgroup walks tiles of `tile_bases` window starts (+ K-1 bytes of overlap) of the byte stream.
-// ---- records of the partitioned path ("super-k-mers": what KMC-style counters partition by) -------------------------------------
-// A record = the bases of a run of consecutive windows that share their minimizer hash, packed: (bases << 6) | (run - 1) << 1 |
-// parent, bases = 2 (K + run - 1) bits, first base most significant, run <= 29 - K + 1 windows (K <= 29).  One 8-byte record
-// stands for ~3.5 windows, and its bucket follows from its own bases.
-__device__ __forceinline__ uint32_t kc_run_max(int k) { return (uint32_t)(29 - k + 1); }
-__device__ __forceinline__ uint32_t kc_rec_minhash(unsigned long long first_window, int k, int m) {
-    const unsigned long long mm_mask = kmer_mask(m);
-    uint32_t best = 0xFFFFFFFFu;
-    for (int j = 0; j + m <= k; ++j) {
-        const uint32_t h = mmer_hash32(kmer_canon((first_window >> (2 * (k - m - j))) & mm_mask, m));
-        best = h < best ? h : best;
-    }
-    return best;
-}
+// ---- records of the partitioned path ("super-k-mers": what KMC-style counters partition by): layout in kc_common.h --------------
 // every window of a record through the atomic path (records that found no room in a buffer, spilled windows)
 __device__ __forceinline__ void kc_count_record(unsigned long long *table, uint32_t nb, int k, int m, unsigned long long rec, uint32_t *err) {
     const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
-    const unsigned long long bases = rec >> 6, kmask = kmer_mask(k);
-    const uint32_t home = bucket_of_minhash(kc_rec_minhash((bases >> (2 * (run - 1))) & kmask, k, m), nb);
+    const unsigned long long bases = rec >> 6, kmask = kmer_mask(k);           // (the offset bits lie above every window's bits)
+    const uint32_t home = bucket_of_minhash(kc_rec_minhash(rec, k, m, kc_rec_off_bits(k, m)), nb);
     for (uint32_t j = 0; j < run; ++j) {
         const unsigned long long key = kmer_canon((bases >> (2 * (run - 1 - j))) & kmask, k);
         uint32_t *counter = kc_slot(table, nb, home, key, parent);
@@ -114,9 +101,14 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
     uint32_t *s_mh = s_inv + NW;                                     // [TB + W] (+ 64: kc_count_smem)
     // EMIT: the tile's records are gathered here and go out with ONE reservation per tile -- a reservation per wave step is 160 M
     // atomic adds on one word per 10 G windows, and adds to ONE address serialise at the memory side (measured: 10 x the kernel's time)
-    unsigned long long *s_rec = reinterpret_cast<unsigned long long *>(smem + ((16 + (size_t)NW * 8 + (size_t)NW * 4 + (size_t)(TB + W + 64) * 4 + 15) & ~(size_t)15));   // [TB]
+    unsigned long long *s_rec = reinterpret_cast<unsigned long long *>(smem + ((16 + (size_t)NW * 8 + (size_t)NW * 4 + (size_t)(TB + W + 64) * 4 + 15) & ~(size_t)15));   // [RC]
+    const uint32_t RC = TB / 2;
     __shared__ uint32_t s_nrec;
-    __shared__ unsigned long long s_rec_base;
+    // EMIT: a workgroup reserves room for its records a.rec_chunk at a time and fills the end of a chunk it cannot use (and of its
+    // last chunk) with NULL records (all ones: no record has run - 1 == 31), which the partition pass skips.  One reservation per
+    // tile was 2.5 M adds on ONE word per 10 G windows -- adds to one address serialise at the memory side -- and the tile queue
+    // was another 2.5 M on a second word: with tiles of half the size the kernel took 0.064 s longer (round 4).
+    __shared__ unsigned long long s_rec_base, s_chunk_at, s_chunk_end, s_fill_lo, s_fill_hi;
     const uint32_t tid = threadIdx.x;
     const uint32_t kshift = 64 - 2 * K, mshift = 64 - 2 * M;
     const uint64_t n_tiles = (a.n_starts + TB - 1) / TB;
@@ -124,7 +116,10 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
     const uintptr_t end_addr = base_addr + a.n_bytes;                // bytes at and beyond it read as separators
     unsigned long long counted = 0;
 
-    if (tid == 0) *s_tile = atomicAdd(a.tile_queue, 1ull);
+    if (tid == 0) {
+        *s_tile = EMIT ? (unsigned long long)blockIdx.x : atomicAdd(a.tile_queue, 1ull);     // EMIT: tiles cost the same, dealt in turn
+        s_chunk_at = s_chunk_end = 0;
+    }
     __syncthreads();
     for (;;) {
         const uint64_t tile = *s_tile;
@@ -132,7 +127,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
         const uint64_t t0 = tile * TB;
         __syncthreads();
         if (tid == 0) {
-            *s_tile = atomicAdd(a.tile_queue, 1ull);
+            *s_tile = EMIT ? tile + gridDim.x : atomicAdd(a.tile_queue, 1ull);
             s_nrec = 0;
         }
 
@@ -189,24 +184,33 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             const unsigned long long bits = (((unsigned long long)iw[0] << 32) | iw[1]) << (p & 31);
             bool valid = p < nwin && (bits >> (64 - K)) == 0;       // every byte of the window is a base
             const uint64_t key = kmer_canon(window_bits(s_pack, p, kshift), K);
-            uint32_t mn = s_mh[p];
+            uint32_t mn = s_mh[p], off = 0;                              // the window's minimizer: smallest hash, leftmost on ties
             if (WT) {
 #pragma unroll
-                for (int j = 1; j < (WT ? WT : 1); ++j) mn = min(mn, s_mh[p + j]);
+                for (int j = 1; j < (WT ? WT : 1); ++j) {
+                    const uint32_t h = s_mh[p + j];
+                    if (EMIT) off = h < mn ? (uint32_t)j : off;
+                    mn = min(mn, h);
+                }
             } else {
-                for (uint32_t j = 1; j < W; ++j) mn = min(mn, s_mh[p + j]);
+                for (uint32_t j = 1; j < W; ++j) {
+                    const uint32_t h = s_mh[p + j];
+                    if (EMIT) off = h < mn ? j : off;
+                    mn = min(mn, h);
+                }
             }
             if (a.n_slices > 1 && kc_slice_of(mn, a.n_slices) != a.slice) valid = false;
             if (EMIT) {
-                // runs of consecutive valid windows with one minimizer hash, cut every kc_run_max windows (and by the 64 lanes of a step)
-                const uint32_t prev_mn = (uint32_t)__shfl_up((int)mn, 1, 64);
+                // runs of consecutive valid windows whose minimizer is the same m-mer OCCURRENCE (position p + off), cut every kc_run_max
+                // windows (and by the 64 lanes of a step): every window of a run then holds the m-mer its first window names
+                const uint32_t at_pos = p + off, prev_pos = (uint32_t)__shfl_up((int)at_pos, 1, 64);
                 const bool prev_ok = __shfl_up((int)valid, 1, 64) != 0;
-                const bool start0 = valid && (lane == 0 || !prev_ok || prev_mn != mn);
+                const bool start0 = valid && (lane == 0 || !prev_ok || prev_pos != at_pos);
                 const unsigned long long s0 = __ballot(start0), vm = __ballot(valid);
                 if (valid) ++counted;
                 const unsigned long long below = s0 & (~0ull >> (63 - lane));
                 const uint32_t first = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
-                const uint32_t rmax = kc_run_max(K);
+                const uint32_t rmax = a.rec_run_max;
                 const bool start = valid && ((lane - first) % rmax) == 0;
                 const unsigned long long sm = __ballot(start);
                 const unsigned long long after = lane == 63 ? 0ull : ((sm | ~vm) >> (lane + 1));
@@ -216,10 +220,23 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                     uint32_t at0 = 0;
                     if (lane == 0) at0 = atomicAdd(&s_nrec, cnt);
                     at0 = (uint32_t)__shfl((int)at0, 0, 64);
-                    if (start) {
-                        const uint32_t nbases = (uint32_t)K + run - 1;
-                        s_rec[at0 + (uint32_t)__popcll(sm & ((1ull << lane) - 1))] =
-                            (window_bits(s_pack, p, 64 - 2 * nbases) << 6) | ((unsigned long long)(run - 1) << 1) | a.parent;
+                    unsigned long long rec = 0;
+                    if (start) rec = (a.rec_off_bits ? (unsigned long long)off << (64 - a.rec_off_bits) : 0ull) | (window_bits(s_pack, p, 64 - 2 * ((uint32_t)K + run - 1)) << 6) |
+                                     ((unsigned long long)(run - 1) << 1) | a.parent;
+                    const uint32_t idx = at0 + (uint32_t)__popcll(sm & ((1ull << lane) - 1));
+                    if (start && idx < RC) s_rec[idx] = rec;
+                    // the staging area holds one record per two windows (a minimizer run holds ~3.3): the rare rest goes out at once
+                    const unsigned long long om = __ballot(start && idx >= RC);
+                    if (om) {
+                        const uint32_t first = (uint32_t)__builtin_ctzll(om);
+                        unsigned long long g0 = 0;
+                        if (lane == first) g0 = atomicAdd(a.rec_cursor, (unsigned long long)__popcll(om));
+                        g0 = __shfl(g0, (int)first, 64);
+                        if (start && idx >= RC) {
+                            const unsigned long long at = g0 + (unsigned long long)__popcll(om & ((1ull << lane) - 1));
+                            if (at < a.rec_cap) a.rec_out[at] = rec;
+                            else kc_count_record(a.table, a.nbuckets, K, M, rec, a.err);
+                        }
                     }
                 }
                 continue;
@@ -243,9 +260,20 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
         }
         __syncthreads();
         if (EMIT) {
-            const uint32_t n = s_nrec;
-            if (tid == 0 && n) s_rec_base = atomicAdd(a.rec_cursor, (unsigned long long)n);
+            const uint32_t n = s_nrec < RC ? s_nrec : RC;
+            if (tid == 0) {
+                s_fill_lo = s_fill_hi = 0;
+                if (s_chunk_at + n > s_chunk_end) {                                        // (n <= RC <= a.rec_chunk)
+                    s_fill_lo = s_chunk_at;
+                    s_fill_hi = s_chunk_end;
+                    s_chunk_at = atomicAdd(a.rec_cursor, (unsigned long long)a.rec_chunk);
+                    s_chunk_end = s_chunk_at + a.rec_chunk;
+                }
+                s_rec_base = s_chunk_at;
+                s_chunk_at += n;
+            }
             __syncthreads();
+            for (unsigned long long at = s_fill_lo + tid; at < s_fill_hi && at < a.rec_cap; at += kKcThreads) a.rec_out[at] = ~0ull;
             for (uint32_t i = tid; i < n; i += kKcThreads) {
                 const unsigned long long at = s_rec_base + i;
                 if (at < a.rec_cap) a.rec_out[at] = s_rec[i];
@@ -253,13 +281,17 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             }
         }
     }
+    if (EMIT) {
+        __syncthreads();
+        for (unsigned long long at = s_chunk_at + tid; at < s_chunk_end && at < a.rec_cap; at += kKcThreads) a.rec_out[at] = ~0ull;
+    }
     for (int off = 32; off > 0; off >>= 1) counted += __shfl_down(counted, off, 64);
     if ((tid & 63) == 0 && counted) atomicAdd(a.total + a.parent, counted);
 }
 
 template <int WT, bool EMIT>
 static hipError_t launch_kc_count_e(const KcCountArgs &a, unsigned grid, size_t smem0, hipStream_t s) {
-    const size_t smem = EMIT ? ((smem0 + 15) & ~(size_t)15) + (size_t)a.tile_bases * 8 + 16 : smem0;
+    const size_t smem = EMIT ? ((smem0 + 15) & ~(size_t)15) + (size_t)(a.tile_bases / 2) * 8 + 16 : smem0;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_count<WT, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
@@ -309,12 +341,12 @@ struct KcPartGeom {
     uint32_t fine_shift;         // log2(buckets per fine bin): 9 or 10
     uint32_t n_fine, n_l1, f2;   // fine bins, level-1 bins, fine bins per level-1 bin (n_l1 * f2 >= n_fine)
     uint32_t *err;
+    uint32_t ob, rmax;           // kc_rec_off_bits, kc_run_max
 };
 constexpr uint32_t kKcPartRecs = 8192, kKcPartThreads = 1024, kKcMaxFan = 1024;
+constexpr uint32_t kKcFillPad = kKcL1FillWords;                                // words between two level-1 fill counters
 __device__ __forceinline__ uint32_t kc_rec_fine(const KcPartGeom &g, unsigned long long rec) {
-    const uint32_t run = (uint32_t)((rec >> 1) & 31) + 1;
-    const unsigned long long first = ((rec >> 6) >> (2 * (run - 1))) & kmer_mask(g.k);
-    return bucket_of_minhash(kc_rec_minhash(first, g.k, g.m), g.nbuckets) >> g.fine_shift;
+    return bucket_of_minhash(kc_rec_minhash(rec, g.k, g.m, g.ob), g.nbuckets) >> g.fine_shift;
 }
 // records that found no room in a bin: to the spill list, or -- that one full too -- through the atomic path at once (no slice
 // of the table is held in LDS while a partition kernel runs)
@@ -327,7 +359,7 @@ __device__ __forceinline__ void kc_spill(const KcPartGeom &g, unsigned long long
 // LEVEL 1: in = the flat record buffer [0, n_flat); bin = fine / f2, region = bin.  LEVEL 2: blockIdx.y = a level-1 bin, in = its
 // region (in_cap records apart, in_fill / in_valid say how many are real); bin = fine - l1 * f2, region = fine.
 template <int LEVEL>
-__global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const unsigned long long *in, unsigned long long n_flat, const uint32_t *in_fill,
+__global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) k_kc_part(KcPartGeom g, const unsigned long long *in, unsigned long long n_flat, const uint32_t *in_fill,
                                                             const uint32_t *in_valid, uint32_t in_cap, unsigned long long *out, uint32_t out_cap,
                                                             uint32_t *out_fill, uint32_t *out_valid, unsigned long long *spill, unsigned long long spill_cap,
                                                             unsigned long long *spill_n) {
@@ -343,7 +375,7 @@ __global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const 
     unsigned long long n_in = n_flat;
     const unsigned long long *src = in;
     if (LEVEL == 2) {
-        const uint32_t f = in_fill[l1], v = in_valid[l1];
+        const uint32_t f = in_fill[l1 * kKcFillPad], v = in_valid[l1 * kKcFillPad];
         n_in = f < v ? (f < in_cap ? f : in_cap) : v;
         src = in + (size_t)l1 * in_cap;
     }
@@ -359,8 +391,8 @@ __global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const 
     for (int q = 0; q < PER; ++q) {
         const uint32_t i = (uint32_t)q * kKcPartThreads + tid;                  // coalesced
         bin_of[q] = 0xFFFFFFFFu;
-        if (i < nr) {
-            rec[q] = src[r0 + i];
+        if (i < nr) rec[q] = src[r0 + i];
+        if (i < nr && rec[q] != ~0ull) {                                        // (all ones: a chunk's unused end, k_kc_count<EMIT>)
             const uint32_t fine = kc_rec_fine(g, rec[q]);
             uint32_t b = LEVEL == 1 ? fine / g.f2 : fine - l1 * g.f2;
             if (b >= n_bins) b = n_bins - 1;                                    // (cannot happen: a record lies where its bucket says)
@@ -386,10 +418,11 @@ __global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const 
             uint32_t dst = 0;
             if (c) {
                 const uint32_t region = LEVEL == 1 ? tid : l1 * g.f2 + tid;
-                const uint32_t at = atomicAdd(&out_fill[region], c);
+                // (level 1: every workgroup adds to every one of <= 1024 counters -- a line apart, or they share 32 lines)
+                const uint32_t at = atomicAdd(&out_fill[LEVEL == 1 ? region * kKcFillPad : region], c);
                 if (at + c <= out_cap) dst = at;
                 else {
-                    atomicMin(&out_valid[region], at);                          // records [0, first failed reservation) of a region are real
+                    atomicMin(&out_valid[LEVEL == 1 ? region * kKcFillPad : region], at);                          // records [0, first failed reservation) of a region are real
                     dst = 0x80000000u;
                 }
             }
@@ -421,85 +454,140 @@ __global__ void __launch_bounds__(kKcPartThreads) k_kc_part(KcPartGeom g, const 
 // bucket and the next three are full (or lie behind the slice's end) goes to the spill list as a record of one window; a full
 // spill list is a full table as far as the caller is concerned (err bit 0).
 // 1024 threads: a slice takes 64 or 128 KB of LDS, so a CU holds one or two of these workgroups -- with 256 threads that was 8 waves
-// per CU, every one of them waiting on its own chain of loads (measured: 0.52 s per flush of the bench's 60-GB table, 270 GB/s)
+// per CU, every one of them waiting on its own chain of loads (measured: 0.52 s per flush of the bench's 60-GB table, 270 GB/s).
+// A LANE PER WINDOW, a whole bucket per probe: a wave takes 64 records, scans their run lengths, and spreads the windows of those
+// records over its lanes (a byte map window -> record in LDS, the record's words fetched from the owning lane by ds_bpermute);
+// a window reads the 8 key slots of its bucket at once, compares them all, and only a key that is not there yet goes through
+// compare-and-swap on the first slot that looked empty.  The first version gave a lane a RECORD and walked the slots one LDS
+// round trip at a time: runs of 1..9 windows x 1..32 slots, every wave as slow as its slowest lane -- 0.38 s of LDS probes per
+// flush against 0.20 s for everything else.
 constexpr int kKcApplyThreads = 1024;
 constexpr uint32_t kKcLdsStride = kKcBucketWords + 1;                            // words per bucket in LDS (k_kc_apply)
-__global__ void __launch_bounds__(kKcApplyThreads) k_kc_apply(KcPartGeom g, const unsigned long long *recs, uint32_t cap, const uint32_t *fill, const uint32_t *valid,
+constexpr uint32_t kKcMapMax = 1024;                                             // bytes of window -> record map per wave, at most
+__host__ __device__ inline uint32_t kc_apply_map_bytes(uint32_t rmax) { return 64u * rmax < kKcMapMax ? 64u * rmax : kKcMapMax; }
+__global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) k_kc_apply(KcPartGeom g, const unsigned long long *recs, uint32_t cap, const uint32_t *fill, const uint32_t *valid,
                                                               unsigned long long *spill, unsigned long long spill_cap, unsigned long long *spill_n) {
     extern __shared__ __align__(16) unsigned char smem[];
     // [buckets of the slice][kKcLdsStride]: a bucket is 16 words = 128 B = exactly the 32 LDS banks, so slot i of EVERY bucket would sit
     // in the same bank and the 64 lanes of a probe (64 different buckets, the same slot) would take 64 turns at it; one word of
-    // padding per bucket spreads them (measured: the kernel 0.43 s per flush without it)
+    // padding per bucket spreads them
     unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(smem);
-    const uint32_t fine = blockIdx.x, tid = threadIdx.x;
+    const uint32_t fine = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t f = fill[fine], v = valid[fine];
     const uint32_t n = f < v ? (f < cap ? f : cap) : v;
     if (n == 0) return;
     const uint32_t b0 = fine << g.fine_shift;
     const uint32_t nb_here = g.nbuckets - b0 < (1u << g.fine_shift) ? g.nbuckets - b0 : (1u << g.fine_shift);
+    const uint32_t map_bytes = kc_apply_map_bytes(g.rmax);
+    uint8_t *s_map = smem + ((size_t)1 << g.fine_shift) * kKcLdsStride * 8 + (size_t)wave * map_bytes;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     {
         const u64x2 *gsrc = reinterpret_cast<const u64x2 *>(g.table + (size_t)b0 * kKcBucketWords);
-        for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) {
-            const u64x2 v = gsrc[i];
-            unsigned long long *d = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
-            d[0] = v.x;
-            d[1] = v.y;
-        }
-    }
-    __syncthreads();
-    const unsigned long long *mine = recs + (size_t)fine * cap;
-    const unsigned long long kmask = kmer_mask(g.k);
-    // (the records of a thread are fetched four at a time: their loads overlap instead of queueing one behind the other's use)
-    for (uint32_t i0 = tid; i0 < n; i0 += 4 * kKcApplyThreads) {
-      unsigned long long batch[4];
+        const uint32_t nvec = nb_here * (kKcBucketWords / 2);
+        for (uint32_t i0 = tid; i0 < nvec; i0 += 4 * kKcApplyThreads) {            // four loads in flight per lane
+            u64x2 t[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) batch[q] = i0 + (uint32_t)q * kKcApplyThreads < n ? mine[i0 + (uint32_t)q * kKcApplyThreads] : ~0ull;
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = i0 + (uint32_t)q * kKcApplyThreads;
+                if (i < nvec) t[q] = gsrc[i];
+            }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (i0 + (uint32_t)q * kKcApplyThreads >= n) break;
-        const unsigned long long rec = batch[q];
-        const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
-        const unsigned long long bases = rec >> 6;
-        const uint32_t home = bucket_of_minhash(kc_rec_minhash((bases >> (2 * (run - 1))) & kmask, g.k, g.m), g.nbuckets);
-        for (uint32_t j = 0; j < run; ++j) {
-            const unsigned long long raw = (bases >> (2 * (run - 1 - j))) & kmask;
-            const unsigned long long key = kmer_canon(raw, g.k);
-            bool done = false;
-            for (uint32_t p = 0; p < 4 && !done; ++p) {
-                const uint32_t b = home + p;                                    // (kc_probe: the bucket, then the next three)
-                if (b < b0 || b >= b0 + nb_here) break;                          // behind the slice (or wrapped): the atomic path's business
-                unsigned long long *bk = s_tab + (size_t)(b - b0) * kKcLdsStride;
-                uint32_t *cnt = reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots;
-                for (int sl = 0; sl < kKcSlots;) {
-                    unsigned long long cur = __hip_atomic_load(&bk[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (cur == kEmptySlot) {
-                        const unsigned long long old = atomicCAS(&bk[sl], (unsigned long long)kEmptySlot, key);
-                        cur = old == kEmptySlot ? key : old;
-                    }
-                    if (cur == key) {
-                        atomicAdd(&cnt[sl], 1u);
-                        done = true;
-                        break;
-                    }
-                    ++sl;                                                        // taken by another key: slots never change once written
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = i0 + (uint32_t)q * kKcApplyThreads;
+                if (i < nvec) {
+                    unsigned long long *d = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
+                    d[0] = t[q].x;
+                    d[1] = t[q].y;
                 }
             }
-            // (one reservation per wave and step, not per window: adds to one address serialise at the memory side)
-            const unsigned long long lost = __ballot(!done);
-            if (lost) {
-                const uint32_t lane = tid & 63, first = (uint32_t)__builtin_ctzll(lost);
-                unsigned long long at0 = 0;
-                if (lane == first) at0 = atomicAdd(spill_n, (unsigned long long)__popcll(lost));
-                at0 = __shfl(at0, first, 64);
+        }
+    }
+    const unsigned long long *mine = recs + (size_t)fine * cap;
+    const unsigned long long kmask = kmer_mask(g.k);
+    const uint32_t rmax = g.rmax;
+    const uint32_t RS = map_bytes / rmax < 64u ? map_bytes / rmax : 64u;       // records of a wave step (64 unless K is tiny)
+    // (the records of a step are fetched one step ahead, the first ones beside the slice itself)
+    unsigned long long rec_next = lane < RS && wave * RS + lane < n ? mine[wave * RS + lane] : 0ull;
+    __syncthreads();
+    for (uint32_t base = wave * RS; base < n; base += (kKcApplyThreads / 64) * RS) {               // wave-uniform
+        const bool has = lane < RS && base + lane < n;
+        const unsigned long long rec = rec_next;
+        {
+            const uint32_t nx = base + (kKcApplyThreads / 64) * RS + lane;
+            rec_next = lane < RS && nx < n ? mine[nx] : 0ull;
+        }
+        const uint32_t run = has ? (uint32_t)((rec >> 1) & 31) + 1 : 0u;
+        uint32_t incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        const uint32_t P = incl - run, T = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t home = 0;
+        if (has) home = bucket_of_minhash(kc_rec_minhash(rec, g.k, g.m, g.ob), g.nbuckets) - b0;
+        for (uint32_t j = 0; j < run; ++j) s_map[P + j] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t w0 = 0; w0 < T; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const bool act = w < T;
+            const uint32_t src = act ? s_map[w] : lane;
+            const unsigned long long rw = __shfl(rec, (int)src, 64);
+            const uint32_t hw = (uint32_t)__shfl((int)home, (int)src, 64), pw = (uint32_t)__shfl((int)P, (int)src, 64);
+            const uint32_t parent = (uint32_t)(rw & 1), run_w = (uint32_t)((rw >> 1) & 31) + 1;
+            const uint32_t jw = act ? w - pw : 0u;                                 // window jw of its record
+            const unsigned long long raw = ((rw >> 6) >> (2 * (run_w - 1 - jw))) & kmask;
+            const unsigned long long key = kmer_canon(raw, g.k);
+            bool done = !act, lost = false;
+#pragma unroll 1
+            for (uint32_t p = 0; p < 4; ++p) {                                     // (kc_probe: the bucket, then the next three)
+                if (!__ballot(!done)) break;
+                const uint32_t b = hw + p;
+                if (!done && b >= nb_here) {                                        // behind the slice (or wrapped): the atomic path's business
+                    lost = true;
+                    done = true;
+                }
                 if (!done) {
-                    const unsigned long long at = at0 + (unsigned long long)__popcll(lost & ((1ull << lane) - 1));
-                    if (at < spill_cap) spill[at] = (raw << 6) | parent;        // a record of one window
+                    unsigned long long *bk = s_tab + (size_t)b * kKcLdsStride;
+                    unsigned long long sl[kKcSlots];
+#pragma unroll
+                    for (int i = 0; i < kKcSlots; ++i) sl[i] = bk[i];
+                    int idx = -1, fe = kKcSlots;
+#pragma unroll
+                    for (int i = kKcSlots - 1; i >= 0; --i) {
+                        if (sl[i] == key) idx = i;
+                        if (sl[i] == kEmptySlot) fe = i;
+                    }
+                    // slots fill in order and never change: a key not seen is settled by compare-and-swap from the first slot that looked empty
+                    for (int i = fe; idx < 0 && i < kKcSlots; ++i) {
+                        const unsigned long long old = atomicCAS(&bk[i], (unsigned long long)kEmptySlot, key);
+                        if (old == kEmptySlot || old == key) idx = i;
+                    }
+                    if (idx >= 0) {
+                        atomicAdd(reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots + idx, 1u);
+                        done = true;
+                    }
+                }
+            }
+            lost = lost || !done;
+            // (one reservation per wave and step, not per window: adds to one address serialise at the memory side)
+            const unsigned long long lm = __ballot(lost);
+            if (lm) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(lm);
+                unsigned long long at0 = 0;
+                if (lane == first) at0 = atomicAdd(spill_n, (unsigned long long)__popcll(lm));
+                at0 = __shfl(at0, (int)first, 64);
+                if (lost) {
+                    const unsigned long long at = at0 + (unsigned long long)__popcll(lm & ((1ull << lane) - 1));
+                    // a record of one window: the minimizer lies jw bases nearer to its start
+                    if (at < spill_cap) spill[at] = (g.ob ? (unsigned long long)((uint32_t)(rw >> (64 - g.ob)) - jw) << (64 - g.ob) : 0ull) | (raw << 6) | parent;
                     else atomicOr(g.err, 1u);
                 }
             }
         }
-      }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                     // (the map is rewritten by the next step)
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     {
@@ -518,16 +606,16 @@ __global__ void __launch_bounds__(256) k_kc_spill(KcPartGeom g, const unsigned l
 }
 
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
-    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err};
+    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m)};
     const size_t lds_part = (size_t)3 * kKcMaxFan * 4 + (size_t)kKcPartRecs * 8;
-    const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcLdsStride * 8;
+    const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcLdsStride * 8 + (size_t)(kKcApplyThreads / 64) * kc_apply_map_bytes(kc_run_max(a.k, a.m));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply);
     if (e != hipSuccess) return e;
     // fills to zero, "valid" marks to all ones: [l1 fill | l1 valid | fine fill | fine valid]
-    e = hipMemsetAsync(a.l1_fill, 0, (size_t)a.n_l1 * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(a.l1_valid, 0xFF, (size_t)a.n_l1 * 4, s);
+    e = hipMemsetAsync(a.l1_fill, 0, (size_t)a.n_l1 * kKcFillPad * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(a.l1_valid, 0xFF, (size_t)a.n_l1 * kKcFillPad * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_fill, 0, (size_t)a.n_fine * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_valid, 0xFF, (size_t)a.n_fine * 4, s);
     if (e != hipSuccess) return e;

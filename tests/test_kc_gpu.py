@@ -124,8 +124,8 @@ def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, t
     """The counting path of large tables (kc_kernels.hip "partitioned counting": windows written out as records of a minimizer run,
     partitioned by bucket range in two levels, counted per slice in LDS), forced on small ones: counts, histograms and selections ==
     oracle -- with an ample record buffer (one flush at sync), with a tiny one (HAST_KC_RECORD_MB: many flushes, records that find
-    no room are counted on the spot, bins that overflow go through the spill list), for K up to 29 (one window per record); K = 31
-    has no room for a run in a record and stays with the atomic kernel.  Streams with every byte class, homopolymers (thousands of
+    no room are counted on the spot, bins that overflow go through the spill list), for K up to 27 (one window per record: 2 K bits of bases + 4 bits for the place of its minimizer +
+    6 bits of run length and parent); K = 29 and 31 have no room in a 64-bit record and stay with the atomic kernel.  Streams with every byte class, homopolymers (thousands of
     windows of one bucket: the spill path), both parents, a second round of counting after a read of the table."""
     o = oracle_lib
     rng = random.Random(900 + k + table_mb)
@@ -137,7 +137,7 @@ def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, t
         monkeypatch.setenv("HAST_KC_RECORD_MB", str(record_mb))
     with KmerCounter(k, table_bytes=table_mb << 20) as kc:
         info = kc.partition_info()
-        assert info["partitioned"] == (k <= 29), info
+        assert info["partitioned"] == (k <= 27), info
         kc.count(0, pat)
         kc.count(1, mat)
         for p in (0, 1):
@@ -152,7 +152,7 @@ def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, t
         o.ho_s00_add_stream(c, 1, more.ctypes.data, more.size)
         check_against_oracle(o, kc, c, k, None)
         info = kc.partition_info()
-        if k <= 29:
+        if k <= 27:
             assert info["flushes"] >= 2 and info["records"] > 0, info
             if record_mb:
                 assert info["flushes"] >= 3, info
