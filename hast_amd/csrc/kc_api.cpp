@@ -54,10 +54,17 @@ struct hast_kc {
     // flushes -- at hast_kc_sync, before the table is read, and when the record buffer is nearly full
     bool part_on = false;
     uint32_t fine_shift = 9, n_fine = 0, n_l1 = 0, f2 = 0;
+    int small_flush = 0;                       // HAST_KC_FLUSH=sweep|atomic pins how a flush is applied (1 | 2); default: by size
     unsigned long long *d_rec = nullptr, *d_l1 = nullptr, *d_spill = nullptr;
     uint32_t *d_fills = nullptr;               // [n_l1 fill | n_l1 valid] (kKcL1FillWords apart) [n_fine fill | n_fine valid]
     uint64_t rec_cap = 0, a_cap = 0, b_cap = 0, spill_cap = 0;
     uint64_t est_records = 0;                  // upper bound of the records written since the last flush
+    // ... kept tight by the device's own cursor: a copy of it travels back behind a count launch and replaces the bound of everything
+    // launched up to there (a bound of one record per two windows is twice what real reads write: the bench flushed twice a step)
+    unsigned long long *h_cursor = nullptr;    // pinned
+    hipEvent_t cur_ev = nullptr;
+    bool cur_pending = false;
+    uint64_t est_after = 0;                    // bound of the launches behind the copy in flight
     uint64_t n_flushes = 0, n_flushed_records = 0, n_spilled = 0;
     std::vector<uint64_t> sel[2];              // print keys selected so far (host side, unsorted)
     unsigned long long *d_sorted[2] = {nullptr, nullptr};
@@ -95,20 +102,23 @@ hast_status check_synth(const hast_kc_synth *p) {
 }
 }  // namespace
 
-// Partitioned counting (kc_kernels.hip): opt-in with HAST_KC_COUNT=partition in the environment (read here, once) as long as its
-// last pass is slower than the direct kernel (measured in round 4: 0.58 s against 0.27 s on the bench's trio; the passes in front
-// of the LDS probes take 0.20 s).  K must leave room for a run of windows in a record (K <= 29).  The buffers take what is left
-// of the device memory next to the table: ~22.5 B per record of capacity.
+// Partitioned counting (kc_kernels.hip) is worth its buffers when the table is far larger than the caches (>= 2^20 buckets = 128 MB)
+// and a record has room for a window (K <= 27 with the default minimizer length); HAST_KC_COUNT=atomic|partition in the environment
+// (read here, once) forces either.  Round 4, bench.py --workload s00 (10.4 G windows, 60-GB table): 0.151 s a step against 0.271 s
+// of the direct kernel.  The buffers take what is left of the device memory next to the table: ~22.5 B per record of capacity.
+// HAST_KC_FLUSH=sweep|atomic pins how a flush is applied (default: by the number of records, launch_kc_flush).
 static void part_setup(hast_kc *c) {
     const char *e = getenv("HAST_KC_COUNT");
-    const bool forced = e && !strcmp(e, "partition");
-    if (!forced || kc_run_max(c->k, c->m) == 0) return;                 // (K <= 27 with the default minimizer length: a record is 64 bits)
+    const bool forced = e && !strcmp(e, "partition"), off = e && !strcmp(e, "atomic");
+    if (const char *fl = getenv("HAST_KC_FLUSH")) c->small_flush = !strcmp(fl, "sweep") ? 1 : !strcmp(fl, "atomic") ? 2 : 0;
+    if (off || kc_run_max(c->k, c->m) == 0 || (!forced && c->nbuckets < (1u << 20))) return;
     c->fine_shift = ((uint64_t)c->nbuckets >> 9) > (1u << 20) ? 10 : 9;
     const uint64_t n_fine = ((uint64_t)c->nbuckets + (1u << c->fine_shift) - 1) >> c->fine_shift;
     if (n_fine > (1u << 20)) return;                                   // a table of more than 2^30 buckets (128 GB): two levels of 1024 do not reach
     c->n_fine = (uint32_t)n_fine;
-    c->n_l1 = (uint32_t)std::min<uint64_t>(1024, n_fine);
-    c->f2 = (uint32_t)((n_fine + c->n_l1 - 1) / c->n_l1);
+    c->f2 = 1;                                                         // fine bins per level-1 bin: a power of two (a shift in the kernels)
+    while ((n_fine + c->f2 - 1) / c->f2 > 1024) c->f2 <<= 1;
+    c->n_l1 = (uint32_t)((n_fine + c->f2 - 1) / c->f2);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     const uint64_t fixed = 8ull * (64ull * c->n_fine + 4096ull * c->n_l1 + (1u << 20)) + 8ull * ((uint64_t)c->n_l1 * kKcL1FillWords + c->n_fine) + (64u << 20);
@@ -116,6 +126,9 @@ static void part_setup(hast_kc *c) {
     if (budget <= fixed + (16u << 20)) return;
     uint64_t R = (uint64_t)((double)(budget - fixed) / 22.6);
     R = std::min<uint64_t>(R, 6ull << 30);
+    // ... and no more records than the table has slots: a caller sizes the table for its input, and device memory that another
+    // process has just given back is slow to get (seconds per 100 GB: the stage-00 program run back to back)
+    R = std::min<uint64_t>(R, std::max<uint64_t>((uint64_t)c->nbuckets * kKcSlots, 64ull << 20));
     if (const char *m = getenv("HAST_KC_RECORD_MB")) R = std::min<uint64_t>(R, ((uint64_t)atol(m) << 20) / 8);     // (the record buffer itself)
     if (R < (forced ? 4096u : (16u << 20))) return;
     c->rec_cap = R;
@@ -155,6 +168,8 @@ static hast_status part_flush(hast_kc *c) {
     a.f2 = c->f2;
     a.records = c->d_rec;
     a.n_records = n;
+    a.rec_cursor = c->d_small + kRecCursor;
+    a.small_flush = c->small_flush;
     a.l1_recs = c->d_l1;
     a.l1_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->b_cap / c->n_l1, n / c->n_l1 + n / c->n_l1 / 4 + 4096));
     a.fine_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->a_cap / c->n_fine, n / c->n_fine + n / c->n_fine / 2 + 64));
@@ -171,7 +186,8 @@ static hast_status part_flush(hast_kc *c) {
     KC_TRY(hipMemcpyAsync(&sp, c->d_small + kSpillN, sizeof(sp), hipMemcpyDeviceToHost, c->stream));
     KC_TRY(hipMemsetAsync(c->d_small + kRecCursor, 0, 2 * sizeof(unsigned long long), c->stream));      // cursor and spill count
     KC_TRY(hipStreamSynchronize(c->stream));
-    c->est_records = 0;
+    c->est_records = c->est_after = 0;
+    c->cur_pending = false;                        // (the stream has been waited for: a copy of the old cursor is history)
     c->n_flushes++;
     c->n_flushed_records += n;
     c->n_spilled += sp;
@@ -211,6 +227,8 @@ hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out)
     for (auto &s : c->stage) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
     bail(hipEventCreateWithFlags(&c->err_ev, hipEventDisableTiming), "hipEventCreate");
     bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc(err)");
+    bail(hipEventCreateWithFlags(&c->cur_ev, hipEventDisableTiming), "hipEventCreate");
+    bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_cursor), sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(cursor)");
     if (c->h_err) *c->h_err = 0;
     if (st == HAST_OK) {
         size_t free_b = 0, total_b = 0;
@@ -245,6 +263,8 @@ void hast_kc_destroy(hast_kc *c) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (c->err_ev) (void)hipEventDestroy(c->err_ev);
+    if (c->cur_ev) (void)hipEventDestroy(c->cur_ev);
+    if (c->h_cursor) (void)hipHostFree(c->h_cursor);
     if (c->h_err) (void)hipHostFree(c->h_err);
     for (auto *p : c->d_sorted)
         if (p) (void)hipFree(p);
@@ -273,7 +293,11 @@ hast_status hast_kc_set_slice(hast_kc *c, uint32_t slice, uint32_t n_slices) {
         c->err_pending = false;
     }
     *c->h_err = 0;
-    c->est_records = 0;                            // (records of the old slice are void with its table; the cursor words were zeroed above)
+    c->est_records = c->est_after = 0;             // (records of the old slice are void with its table; the cursor words were zeroed above)
+    if (c->cur_pending) {
+        KC_TRY(hipEventSynchronize(c->cur_ev));
+        c->cur_pending = false;
+    }
     return HAST_OK;
 }
 
@@ -298,7 +322,7 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
     a.rec_cap = 0;
     a.rec_cursor = nullptr;
     a.rec_chunk = 0;
-    a.rec_run_max = a.rec_off_bits = 0;
+    a.rec_run_max = a.rec_off_bits = a.fine_shift = 0;
     if (c->part_on) {
         // (an upper bound of one record per two windows; a minimizer run holds ~3.5.  What does not fit the buffer after all is
         // counted on the spot, by the kernel itself)
@@ -306,7 +330,17 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
         a.rec_chunk = 2 * a.tile_bases;
         a.rec_run_max = kc_run_max(c->k, c->m);
         a.rec_off_bits = kc_rec_off_bits(c->k, c->m);
+        a.fine_shift = c->fine_shift;
         const uint64_t worst = n_starts / 2 + 1 + (uint64_t)c->n_cu * 4 * a.rec_chunk;
+        if (c->cur_pending && hipEventQuery(c->cur_ev) == hipSuccess) {
+            c->est_records = std::min<uint64_t>(c->est_records, (uint64_t)*c->h_cursor + c->est_after);
+            c->cur_pending = false;
+        }
+        if (c->est_records + worst > c->rec_cap && c->cur_pending) {       // before the table is swept: what does the device say?
+            KC_TRY(hipEventSynchronize(c->cur_ev));
+            c->est_records = std::min<uint64_t>(c->est_records, (uint64_t)*c->h_cursor + c->est_after);
+            c->cur_pending = false;
+        }
         if (c->est_records + worst > c->rec_cap)
             if (hast_status st = part_flush(c)) return st;
         a.rec_out = c->d_rec;
@@ -318,6 +352,14 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
     const unsigned grid = (unsigned)std::min<size_t>(n_tiles, (size_t)c->n_cu * (c->part_on ? 4 : 8));
     KC_TRY(hipMemsetAsync(c->d_small + kQueue, 0, sizeof(unsigned long long), c->stream));
     KC_TRY(launch_kc_count(a, grid, c->stream));
+    if (c->part_on) {
+        if (!c->cur_pending) {
+            KC_TRY(hipMemcpyAsync(c->h_cursor, c->d_small + kRecCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            KC_TRY(hipEventRecord(c->cur_ev, c->stream));
+            c->cur_pending = true;
+            c->est_after = 0;
+        } else c->est_after += n_starts / 2 + 1 + (uint64_t)c->n_cu * 4 * a.rec_chunk;
+    }
     return HAST_OK;
 }
 

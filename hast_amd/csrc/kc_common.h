@@ -48,6 +48,18 @@ HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
     return mmer_hash32(kmer_canon((first >> (2 * ((uint32_t)(k - m) - off))) & kmer_mask(m), m));
 }
 
+// PLACEMENT.  Direct counting (one atomic per minimizer run) files a key in its minimizer's bucket, then the next three, then from a
+// bucket of the key's own hash on (kc_kernels.hip kc_probe): the windows of a read that share a minimizer touch one 128-B line.
+// Partitioned counting only needs the minimizer to pick the SLICE of 2^fine_shift buckets a record goes to -- the slice is in LDS
+// while it is counted -- so inside the slice a key is filed by its OWN hash: bucket kc_key_bucket, then the next three (wrapping
+// inside the slice), then the same overflow walk.  A minimizer's keys (~8.5 per occupied minimizer at 30x, error k-mers included)
+// then no longer pile up in one bucket while seven in eight stay empty, and a wave's 64 windows rarely need a second bucket.
+// A table is filled by one of the two ways only (hast_kc_create decides), and its readers are scans.
+HAST_HD uint32_t kc_key_bucket(uint64_t key, uint32_t n_here) {
+    const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) * 0x85EBCA6Bu;
+    return (uint32_t)(((uint64_t)(h ^ (h >> 15)) * n_here) >> 32);
+}
+
 // slice of the key space a window belongs to (decided by its minimizer, so a bucket never mixes slices)
 HAST_HD uint32_t kc_slice_of(uint32_t minh, uint32_t n_slices) {
     uint32_t h = minh * 0x85EBCA6Bu;

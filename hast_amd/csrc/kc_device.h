@@ -25,6 +25,7 @@ struct KcCountArgs {
     unsigned long long *rec_out;
     unsigned long long rec_cap;
     unsigned long long *rec_cursor;  // records written so far (may run past rec_cap: those were counted on the spot)
+    uint32_t fine_shift;             // log2(buckets of a slice): where a record that finds no room in the buffer is counted (kc_common.h PLACEMENT)
     uint32_t rec_run_max, rec_off_bits;   // kc_run_max / kc_rec_off_bits of (k, m)
     uint32_t rec_chunk;              // records a workgroup reserves at a time (>= tile_bases / 2); unused ends are filled with null records
 };
@@ -37,6 +38,8 @@ struct KcFlushArgs {
     uint32_t fine_shift, n_fine, n_l1, f2;
     unsigned long long *records;     // flat buffer: n_records records in; then n_fine regions of fine_cap records
     unsigned long long n_records;
+    const unsigned long long *rec_cursor;   // device word behind n_records (>= n_records)
+    int small_flush;                 // 0: few records for the table's size go through the atomic path where they lie; 1: never; 2: always
     unsigned long long *l1_recs;     // n_l1 regions of l1_cap records
     uint32_t l1_cap, fine_cap;
     uint32_t *l1_fill, *l1_valid, *fine_fill, *fine_valid;

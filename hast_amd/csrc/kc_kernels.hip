@@ -33,15 +33,21 @@ constexpr int kKcThreads = 256;
 // the next three (the same DRAM page; a minimizer's ~3.5 genomic k-mers plus the error k-mers that keep it are ~8.5 keys on average
 // at 30x, so half the occupied buckets overflow, while 7 buckets in 8 are empty), then a bucket chosen by the KEY's own hash and
 // on from there (minimizers that thousands of keys share -- poly-A -- must not pile up in one run of full buckets).
-__device__ __forceinline__ uint32_t kc_probe(uint32_t home, uint32_t p, uint64_t key, uint32_t nb) {
+// slice_n != 0: partitioned placement (kc_common.h): `home` lies in the slice [slice_lo, slice_lo + slice_n), and so do the next three
+__device__ __forceinline__ uint32_t kc_probe(uint32_t home, uint32_t p, uint64_t key, uint32_t nb, uint32_t slice_lo, uint32_t slice_n) {
     if (p < 4) {
+        if (slice_n) {
+            const uint32_t x = home - slice_lo + p;
+            return slice_lo + (x >= slice_n ? x - slice_n : x);
+        }
         const uint32_t b = home + p;
         return b >= nb ? b - nb : b;
     }
     const uint64_t b = (uint64_t)overflow_bucket(key, nb) + (p - 4);
     return (uint32_t)(b % nb);
 }
-__device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t nb, uint32_t home, uint64_t key, uint32_t parent) {
+__device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t nb, uint32_t home, uint64_t key, uint32_t parent, uint32_t slice_lo = 0,
+                                              uint32_t slice_n = 0) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     uint32_t b = home;
     for (uint32_t probe = 0; probe < nb; ++probe) {
@@ -66,7 +72,7 @@ __device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t
             if (old == kEmptySlot || old == key) idx = i;
         }
         if (idx >= 0) return cnt + idx;
-        b = kc_probe(home, probe + 1, key, nb);              // bucket full: the next three, then the key's own overflow bucket, then on from there
+        b = kc_probe(home, probe + 1, key, nb, slice_lo, slice_n);              // bucket full: the next three, then the key's own overflow bucket, then on from there
     }
     return nullptr;
 }
@@ -74,13 +80,14 @@ __device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t
 // One workgroup walks tiles of `tile_bases` window starts (+ K-1 bytes of overlap) of the byte stream.
 // ---- records of the partitioned path ("super-k-mers": what KMC-style counters partition by): layout in kc_common.h --------------
 // every window of a record through the atomic path (records that found no room in a buffer, spilled windows)
-__device__ __forceinline__ void kc_count_record(unsigned long long *table, uint32_t nb, int k, int m, unsigned long long rec, uint32_t *err) {
+__device__ __forceinline__ void kc_count_record(unsigned long long *table, uint32_t nb, int k, int m, uint32_t fine_shift, unsigned long long rec, uint32_t *err) {
     const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
     const unsigned long long bases = rec >> 6, kmask = kmer_mask(k);           // (the offset bits lie above every window's bits)
-    const uint32_t home = bucket_of_minhash(kc_rec_minhash(rec, k, m, kc_rec_off_bits(k, m)), nb);
+    const uint32_t lo = (bucket_of_minhash(kc_rec_minhash(rec, k, m, kc_rec_off_bits(k, m)), nb) >> fine_shift) << fine_shift;
+    const uint32_t n_here = nb - lo < (1u << fine_shift) ? nb - lo : (1u << fine_shift);
     for (uint32_t j = 0; j < run; ++j) {
         const unsigned long long key = kmer_canon((bases >> (2 * (run - 1 - j))) & kmask, k);
-        uint32_t *counter = kc_slot(table, nb, home, key, parent);
+        uint32_t *counter = kc_slot(table, nb, lo + kc_key_bucket(key, n_here), key, parent, lo, n_here);
         if (counter) atomicAdd(counter, 1u);
         else atomicOr(err, 1u);
     }
@@ -167,8 +174,17 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
         __syncthreads();
 
         // ---- M: hash of the canonical m-mer at every position --------------------------------------------
-        for (uint32_t q = tid; q < TB + W - 1; q += kKcThreads)
-            s_mh[q] = mmer_hash32(kmer_canon(window_bits(s_pack, q, mshift), M));
+        if (M <= 16) {                                                // an m-mer of <= 16 bases is one dword: half the instructions
+            for (uint32_t q = tid; q < TB + W - 1; q += kKcThreads) {
+                const uint32_t f = (uint32_t)window_bits(s_pack, q, mshift);
+                uint32_t r = __brev(f ^ 0xAAAAAAAAu);
+                r = (((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u)) >> (32 - 2 * M);
+                s_mh[q] = mmer_hash32((unsigned long long)(f < r ? f : r));
+            }
+        } else {
+            for (uint32_t q = tid; q < TB + W - 1; q += kKcThreads)
+                s_mh[q] = mmer_hash32(kmer_canon(window_bits(s_pack, q, mshift), M));
+        }
         __syncthreads();
 
         // ---- B: one lane per window --------------------------------------------------------------------
@@ -208,11 +224,15 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                 const bool start0 = valid && (lane == 0 || !prev_ok || prev_pos != at_pos);
                 const unsigned long long s0 = __ballot(start0), vm = __ballot(valid);
                 if (valid) ++counted;
-                const unsigned long long below = s0 & (~0ull >> (63 - lane));
-                const uint32_t first = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
                 const uint32_t rmax = a.rec_run_max;
-                const bool start = valid && ((lane - first) % rmax) == 0;
-                const unsigned long long sm = __ballot(start);
+                bool start = start0;
+                unsigned long long sm = s0;
+                if (rmax < W) {                                           // (wave-uniform; a run of one occurrence is at most W windows)
+                    const unsigned long long below = s0 & (~0ull >> (63 - lane));
+                    const uint32_t first = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
+                    start = valid && ((lane - first) % rmax) == 0;
+                    sm = __ballot(start);
+                }
                 const unsigned long long after = lane == 63 ? 0ull : ((sm | ~vm) >> (lane + 1));
                 const uint32_t run = after ? 1u + (uint32_t)__builtin_ctzll(after) : 64u - lane;
                 if (sm) {
@@ -235,7 +255,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                         if (start && idx >= RC) {
                             const unsigned long long at = g0 + (unsigned long long)__popcll(om & ((1ull << lane) - 1));
                             if (at < a.rec_cap) a.rec_out[at] = rec;
-                            else kc_count_record(a.table, a.nbuckets, K, M, rec, a.err);
+                            else kc_count_record(a.table, a.nbuckets, K, M, a.fine_shift, rec, a.err);
                         }
                     }
                 }
@@ -277,7 +297,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             for (uint32_t i = tid; i < n; i += kKcThreads) {
                 const unsigned long long at = s_rec_base + i;
                 if (at < a.rec_cap) a.rec_out[at] = s_rec[i];
-                else kc_count_record(a.table, a.nbuckets, K, M, s_rec[i], a.err);          // (no room: counted on the spot)
+                else kc_count_record(a.table, a.nbuckets, K, M, a.fine_shift, s_rec[i], a.err);          // (no room: counted on the spot)
             }
         }
     }
@@ -342,6 +362,7 @@ struct KcPartGeom {
     uint32_t n_fine, n_l1, f2;   // fine bins, level-1 bins, fine bins per level-1 bin (n_l1 * f2 >= n_fine)
     uint32_t *err;
     uint32_t ob, rmax;           // kc_rec_off_bits, kc_run_max
+    uint32_t f2_shift;           // f2 == 1 << f2_shift
 };
 constexpr uint32_t kKcPartRecs = 8192, kKcPartThreads = 1024, kKcMaxFan = 1024;
 constexpr uint32_t kKcFillPad = kKcL1FillWords;                                // words between two level-1 fill counters
@@ -354,7 +375,7 @@ __device__ __forceinline__ void kc_spill(const KcPartGeom &g, unsigned long long
                                          unsigned long long *spill_n) {
     const unsigned long long at = atomicAdd(spill_n, 1ull);
     if (at < spill_cap) spill[at] = rec;
-    else kc_count_record(g.table, g.nbuckets, g.k, g.m, rec, g.err);
+    else kc_count_record(g.table, g.nbuckets, g.k, g.m, g.fine_shift, rec, g.err);
 }
 // LEVEL 1: in = the flat record buffer [0, n_flat); bin = fine / f2, region = bin.  LEVEL 2: blockIdx.y = a level-1 bin, in = its
 // region (in_cap records apart, in_fill / in_valid say how many are real); bin = fine - l1 * f2, region = fine.
@@ -394,7 +415,7 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
         if (i < nr) rec[q] = src[r0 + i];
         if (i < nr && rec[q] != ~0ull) {                                        // (all ones: a chunk's unused end, k_kc_count<EMIT>)
             const uint32_t fine = kc_rec_fine(g, rec[q]);
-            uint32_t b = LEVEL == 1 ? fine / g.f2 : fine - l1 * g.f2;
+            uint32_t b = LEVEL == 1 ? fine >> g.f2_shift : fine - (l1 << g.f2_shift);
             if (b >= n_bins) b = n_bins - 1;                                    // (cannot happen: a record lies where its bucket says)
             bin_of[q] = b;
             rank[q] = atomicAdd(&s_cnt[b], 1u);
@@ -524,8 +545,6 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             if (lane >= (uint32_t)off) incl += t;
         }
         const uint32_t P = incl - run, T = (uint32_t)__shfl((int)incl, 63, 64);
-        uint32_t home = 0;
-        if (has) home = bucket_of_minhash(kc_rec_minhash(rec, g.k, g.m, g.ob), g.nbuckets) - b0;
         for (uint32_t j = 0; j < run; ++j) s_map[P + j] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -534,20 +553,18 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             const bool act = w < T;
             const uint32_t src = act ? s_map[w] : lane;
             const unsigned long long rw = __shfl(rec, (int)src, 64);
-            const uint32_t hw = (uint32_t)__shfl((int)home, (int)src, 64), pw = (uint32_t)__shfl((int)P, (int)src, 64);
+            const uint32_t pw = (uint32_t)__shfl((int)P, (int)src, 64);
             const uint32_t parent = (uint32_t)(rw & 1), run_w = (uint32_t)((rw >> 1) & 31) + 1;
             const uint32_t jw = act ? w - pw : 0u;                                 // window jw of its record
             const unsigned long long raw = ((rw >> 6) >> (2 * (run_w - 1 - jw))) & kmask;
             const unsigned long long key = kmer_canon(raw, g.k);
-            bool done = !act, lost = false;
+            const uint32_t hw = kc_key_bucket(key, nb_here);
+            bool done = !act;
 #pragma unroll 1
-            for (uint32_t p = 0; p < 4; ++p) {                                     // (kc_probe: the bucket, then the next three)
+            for (uint32_t p = 0; p < 4; ++p) {                                     // (kc_probe: the key's bucket in the slice, then the next three)
                 if (!__ballot(!done)) break;
-                const uint32_t b = hw + p;
-                if (!done && b >= nb_here) {                                        // behind the slice (or wrapped): the atomic path's business
-                    lost = true;
-                    done = true;
-                }
+                uint32_t b = hw + p;
+                b = b >= nb_here ? b - nb_here : b;
                 if (!done) {
                     unsigned long long *bk = s_tab + (size_t)b * kKcLdsStride;
                     unsigned long long sl[kKcSlots];
@@ -570,7 +587,7 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
                     }
                 }
             }
-            lost = lost || !done;
+            const bool lost = !done;                                                // four full buckets: the atomic path's business
             // (one reservation per wave and step, not per window: adds to one address serialise at the memory side)
             const unsigned long long lm = __ballot(lost);
             if (lm) {
@@ -602,11 +619,11 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
 __global__ void __launch_bounds__(256) k_kc_spill(KcPartGeom g, const unsigned long long *spill, unsigned long long spill_cap, const unsigned long long *spill_n) {
     const unsigned long long n = *spill_n < spill_cap ? *spill_n : spill_cap;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-        kc_count_record(g.table, g.nbuckets, g.k, g.m, spill[i], g.err);
+        if (spill[i] != ~0ull) kc_count_record(g.table, g.nbuckets, g.k, g.m, g.fine_shift, spill[i], g.err);
 }
 
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
-    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m)};
+    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m), (uint32_t)__builtin_ctz(a.f2)};
     const size_t lds_part = (size_t)3 * kKcMaxFan * 4 + (size_t)kKcPartRecs * 8;
     const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcLdsStride * 8 + (size_t)(kKcApplyThreads / 64) * kc_apply_map_bytes(kc_run_max(a.k, a.m));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
@@ -619,7 +636,11 @@ hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_fill, 0, (size_t)a.n_fine * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_valid, 0xFF, (size_t)a.n_fine * 4, s);
     if (e != hipSuccess) return e;
-    if (a.n_records) {
+    if (a.n_records && (a.small_flush == 2 || (a.small_flush == 0 && a.n_records < (unsigned long long)a.nbuckets * (kKcBucketWords * 8) / 256))) {
+        // few records for this table (the sweep moves 2 x 128 B per bucket whatever there is to count, the atomic path ~40 G windows/s):
+        // count them where they lie
+        hipLaunchKernelGGL(k_kc_spill, dim3(256 * 8), dim3(256), 0, s, g, a.records, a.n_records, a.rec_cursor);
+    } else if (a.n_records) {
         hipLaunchKernelGGL(k_kc_part<1>, dim3((unsigned)((a.n_records + kKcPartRecs - 1) / kKcPartRecs)), dim3(kKcPartThreads), lds_part, s, g, a.records, a.n_records,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, a.l1_recs, a.l1_cap, a.l1_fill, a.l1_valid, a.spill, a.spill_cap, a.spill_n);
         // level 2 overwrites the flat buffer (its records are all in the level-1 regions by then)
@@ -694,33 +715,60 @@ __global__ void __launch_bounds__(256) k_kc_histo(const unsigned long long *tabl
 __global__ void __launch_bounds__(256) k_kc_select(const unsigned long long *table, size_t nbuckets, uint32_t parent, uint32_t lower,
                                                    uint32_t upper, int k, unsigned long long *out, size_t cap,
                                                    unsigned long long *cursor) {
+    // the selected keys of kSelRounds rounds are gathered in LDS and leave with ONE reservation per workgroup: with keys spread
+    // evenly over the buckets (kc_common.h PLACEMENT) every wave of every round holds one, and one add per wave on the one cursor
+    // word -- 58 M of them over a 60-GB table -- took 86 ms a pass where the scan itself takes 15
+    constexpr int kSelRounds = 8;
+    __shared__ unsigned long long s_buf[kSelRounds * 256];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_base;
     const size_t nslots = nbuckets * kKcSlots;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t rounds = (nslots + stride - 1) / stride;
-    for (size_t r = 0; r < rounds; ++r) {
-        const size_t i = r * stride + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-        bool take = false;
-        unsigned long long key = 0;
-        if (i < nslots) {
-            const unsigned long long *bk = table + (i / kKcSlots) * kKcBucketWords;
-            key = bk[i % kKcSlots];
-            if (key != kEmptySlot) {
-                const uint32_t *c = reinterpret_cast<const uint32_t *>(bk + kKcSlots) + i % kKcSlots;
-                const uint32_t mine = c[parent * kKcSlots], other = c[(1 - parent) * kKcSlots];
-                take = mine >= lower && mine <= upper && other == 0;
+    const size_t rounds = (nslots + stride - 1) / stride;                       // (the same for every thread)
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long n_mine = 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (size_t r0 = 0; r0 < rounds; r0 += kSelRounds) {
+        for (size_t r = r0; r < r0 + kSelRounds && r < rounds; ++r) {
+            const size_t i = r * stride + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+            bool take = false;
+            unsigned long long key = 0;
+            if (i < nslots) {
+                const unsigned long long *bk = table + (i / kKcSlots) * kKcBucketWords;
+                key = bk[i % kKcSlots];
+                if (key != kEmptySlot) {
+                    const uint32_t *c = reinterpret_cast<const uint32_t *>(bk + kKcSlots) + i % kKcSlots;
+                    const uint32_t mine = c[parent * kKcSlots], other = c[(1 - parent) * kKcSlots];
+                    take = mine >= lower && mine <= upper && other == 0;
+                }
             }
+            if (!out) {
+                n_mine += take;
+                continue;
+            }
+            const unsigned long long m = __ballot(take);
+            if (m == 0) continue;
+            const uint32_t first = (uint32_t)__ffsll((long long)m) - 1;
+            uint32_t at0 = 0;
+            if (lane == first) at0 = atomicAdd(&s_n, (uint32_t)__popcll(m));
+            at0 = (uint32_t)__shfl((int)at0, (int)first, 64);
+            if (take) s_buf[at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = kc_to_print_key(key, k);
         }
-        // one atomic per wave
-        const unsigned long long m = __ballot(take);
-        if (m == 0) continue;
-        const uint32_t lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == (uint32_t)__ffsll((long long)m) - 1) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (take && out) {
-            const size_t at = base + __popcll(m & ((1ull << lane) - 1));
-            if (at < cap) out[at] = kc_to_print_key(key, k);
-        }
+        if (!out) continue;
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (threadIdx.x == 0 && n) s_base = atomicAdd(cursor, (unsigned long long)n);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n; j += 256)
+            if (s_base + j < cap) out[s_base + j] = s_buf[j];
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    }
+    if (!out) {                                                                   // count only: one add per wave and launch
+        for (int off = 32; off > 0; off >>= 1) n_mine += __shfl_down(n_mine, off, 64);
+        if (lane == 0 && n_mine) atomicAdd(cursor, n_mine);
     }
 }
 

@@ -133,6 +133,7 @@ def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, t
     shared = random_stream(rng, 150_000, k)
     more = random_stream(rng, 100_000, k)
     monkeypatch.setenv("HAST_KC_COUNT", "partition")
+    monkeypatch.setenv("HAST_KC_FLUSH", "sweep")          # (few records for the table's size would take the atomic path where they lie)
     if record_mb:
         monkeypatch.setenv("HAST_KC_RECORD_MB", str(record_mb))
     with KmerCounter(k, table_bytes=table_mb << 20) as kc:
