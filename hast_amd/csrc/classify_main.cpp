@@ -611,6 +611,7 @@ int main(int argc, char **argv) {
             bool stop = false, eof_acquired = false;
             size_t held = 0;                                       // acquired and not yet committed
             size_t submitted = 0, opened = 0, acquired = 0;
+            size_t ctx_index = 0;                                  // a whole file on one context (not striped)
         };
         const int n_buf = stripe ? std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()) : fq_bufs;     // per context
         double t_create = 0;
@@ -644,6 +645,7 @@ int main(int argc, char **argv) {
             if (next_file < pre_fq.size() && pre_fq[next_file]) f->fq = pre_fq[next_file];     // set up while the table was built
             else CK(make_fq(next_file, &f->fq), "creating the FASTQ stream");
             t_create += now_s() - tc0;
+            f->ctx_index = next_file % ctxs.size();
             next_file++;
             Feed *fp = f.get();
             f->th = std::thread([fp, cap, &wake_mu, &wake_cv, &wake_gen] {
@@ -683,6 +685,7 @@ int main(int argc, char **argv) {
         const size_t max_active = stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size());
         while (next_file < read.size() && active.size() < max_active) open_next();
         uint64_t seen_gen = 0;
+        std::vector<uint64_t> whole_file_records(ctxs.size(), 0);      // records of files dealt whole, per context
         double t_gpu_wait = 0, t_names = 0, t_commit = 0, t_idle = 0;
         uint64_t total_named = 0;
         // names the barcodes of the oldest submitted block of a feed and commits it
@@ -697,6 +700,7 @@ int main(int argc, char **argv) {
                 exit(3);                                                                   // reference: assert abort (kmer.h:171)
             }
             const size_t n = (size_t)b.n_records;
+            if (hast_fq_lanes(f.fq) <= 1 || !stripe) whole_file_records[f.ctx_index] += n;
             // records the device-side name cache did not know (all of them without a cache): text -> id in the job's dictionary
             const size_t nu = b.unknown ? (size_t)b.n_unknown : n;
             if (!b.bytes) {
@@ -809,7 +813,7 @@ int main(int argc, char **argv) {
         if (stats && stripe) {
             std::string per;
             for (size_t g = 0; g < ctxs.size(); g++) {
-                uint64_t n = 0;
+                uint64_t n = whole_file_records[g];              // (.gz files inflated on the GPU stay on one context each)
                 for (hast_fq *q : done_fq) n += hast_fq_lane_records(q, (int)g);
                 per += (g ? "," : "") + std::to_string(n);
             }
@@ -867,8 +871,11 @@ int main(int argc, char **argv) {
     fprintf(stderr, "__END__\n");
     const double t_printed = now_s();
     // The output is complete.  Unpinning and freeing hundreds of MB of staging memory, the table and the streams takes ~0.1 s that the
-    // operating system does anyway when the process ends: leave at once (HAST_TEARDOWN=1 runs the destructors, for leak checks).
-    if (!getenv("HAST_TEARDOWN")) {
+    // operating system does anyway when the process ends: leave at once (HAST_TEARDOWN=1 runs the destructors, for leak checks) --
+    // unless a profiler is listening (rocprofv3 preloads its tool library and writes its files when the process ends in an orderly way).
+    const char *preload = getenv("LD_PRELOAD");
+    const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || (preload && strstr(preload, "rocprofiler"));
+    if (!getenv("HAST_TEARDOWN") && !profiled) {
         if (stats)
             fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=skipped total_s=%.3f\n",
                     t_ctx - t_start, t_loaded - t_ctx, t_scrubbed - t_loaded, t_read_done - t_scrubbed, t_classified - t_read_done, t_printed - t_classified, now_s() - t_start);

@@ -92,13 +92,19 @@ struct hast_gz {
     uint32_t slot_syms = 0;
     // device
     uint32_t *d_in = nullptr;
-    DevBuf jobs, carry_next;
-    ChunkJob *h_jobs = nullptr;               // pinned
+    // The nominal pass of segment k + 1 (search + decode of its chunks: where the time goes) is launched BEFORE segment k's results are
+    // walked, so that the GPU decodes while the host chains, the single-wave follow-up jobs run and the consumer translates: job
+    // arrays in two copies (segment k & 1), follow-up jobs in a third, three symbol arenas (segment k % 3: one being translated,
+    // one being chained, one being decoded), the work behind a nominal pass on a stream of its own.
+    DevBuf jobs[2], fjobs, carry_next;
+    ChunkJob *h_jobs[2] = {nullptr, nullptr}, *h_fjobs = nullptr;   // pinned
+    hipEvent_t nom_done[2] = {nullptr, nullptr};
     size_t h_jobs_cap = 0;
     uint32_t *h_crc = nullptr;                // pinned
     size_t h_crc_cap = 0;
-    Arena arena[2];
-    hipStream_t up_stream = nullptr, dec_stream = nullptr;
+    static constexpr int kArenas = 3;
+    Arena arena[kArenas];
+    hipStream_t up_stream = nullptr, dec_stream = nullptr, post_stream = nullptr;
     // threads
     std::thread uploader, producer;
     std::mutex mu;
@@ -208,8 +214,17 @@ void publish_error(hast_gz *g, const std::string &msg) {
     publish(g, std::move(b));
 }
 
-// one segment's passes; returns "" or what failed
-std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t first_bit, bool &finished) {
+// the nominal pass of one segment: search + decode of every chunk, asynchronous on dec_stream
+struct Nominal {
+    bool launched = false, all_in = false;
+    size_t k = 0, c0 = 0, c1 = 0, n_jobs = 0;
+    uint64_t input_bits = 0;
+    double t0 = 0;
+};
+
+// Launches segment k's nominal pass once its compressed bytes are on the device and its arena is free.  blocking = false: only if
+// both are the case right now (N.launched says).  Returns "" or what failed; stopped: the stream is being closed.
+std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first_bit, bool blocking, Nominal &N, bool &stopped) {
     const size_t C = g->chunk_bytes, S = g->seg_chunks;
     // the first pass is a short one: the reader (the FASTQ framer, the classification behind it) has nothing to do until it is through
     const size_t S0 = std::min<size_t>(S, 1024);
@@ -218,34 +233,44 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
     // the compressed bytes this segment's chunks may read: their own and a margin behind them (a chunk runs on to the first
     // block boundary behind its stop)
     const uint64_t need_up = all_in ? g->file_size : std::min<uint64_t>(g->file_size, (uint64_t)c1 * C + std::min<uint64_t>((uint64_t)S * C, 16u << 20));
-    Arena &A = g->arena[k & 1];
+    Arena &A = g->arena[k % hast_gz::kArenas];
     uint64_t have_up = 0;
+    N = Nominal{};
     {
         std::unique_lock<std::mutex> lk(g->mu);
+        if (!blocking) {
+            if (g->stop || !g->up_error.empty() || g->uploaded < need_up || A.busy) return "";
+            if (A.done_recorded && hipEventQuery(A.done) != hipSuccess) return "";
+        }
         const double t0 = now_s();
         g->cv.wait(lk, [&] { return g->stop || !g->up_error.empty() || g->uploaded >= need_up; });
         g->st.wait_upload_s += now_s() - t0;
-        if (g->stop) { finished = true; return ""; }
+        if (g->stop) { stopped = true; return ""; }
         if (!g->up_error.empty()) return g->up_error;
         have_up = g->uploaded;
         const double t1 = now_s();
         g->cv.wait(lk, [&] { return g->stop || !A.busy; });
         g->st.wait_consumer_s += now_s() - t1;
-        if (g->stop) { finished = true; return ""; }
+        if (g->stop) { stopped = true; return ""; }
     }
     if (A.done_recorded) {                                          // the batch that lived here: its last translate must be through
         GZ_HIP(hipEventSynchronize(A.done));
         A.done_recorded = false;
     }
     A.gap_used = 0;
-    const uint64_t input_bits = (all_in ? g->file_size : have_up) * 8;
-    const double t_seg0 = now_s();
-    // ---- nominal pass: search + decode of every chunk of the segment ---------------------------------------------------------
+    N.k = k;
+    N.c0 = c0;
+    N.c1 = c1;
+    N.all_in = all_in;
+    N.input_bits = (all_in ? g->file_size : have_up) * 8;
+    N.t0 = now_s();
+    const int jb = (int)(k & 1);
+    ChunkJob *hj = g->h_jobs[jb];
     size_t n_jobs = 0;
     GZ_HIP(A.syms.ensure((size_t)(c1 - c0) * g->slot_syms * sizeof(uint16_t) + 64));
     const uint64_t sym_base = reinterpret_cast<uintptr_t>(A.syms.p) / 2;      // job.sym_off counts u16 from address 0
     for (size_t c = c0; c < c1; ++c) {
-        ChunkJob &j = g->h_jobs[n_jobs];
+        ChunkJob &j = hj[n_jobs];
         memset(&j, 0, sizeof(j));
         const uint64_t nominal = (uint64_t)c * C * 8;
         if (nominal + C * 8 <= first_bit) continue;                           // nothing but the first member's header
@@ -259,15 +284,25 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
         j.sym_off = sym_base + (uint64_t)(c - c0) * g->slot_syms;
         ++n_jobs;
     }
+    N.n_jobs = n_jobs;
     if (n_jobs) {
-        GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(launch_search((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)n_jobs, g->d_in, input_bits, (uint16_t *)A.syms.p, g->dec_stream));
-        GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
-        GZ_HIP(hipStreamSynchronize(g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(g->jobs[jb].p, hj, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
+        GZ_HIP(launch_search((ChunkJob *)g->jobs[jb].p, (uint32_t)n_jobs, g->d_in, N.input_bits, g->dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->jobs[jb].p, (uint32_t)n_jobs, g->d_in, N.input_bits, (uint16_t *)A.syms.p, g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(hj, g->jobs[jb].p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
     }
-    g->st.chunks += n_jobs;
-    g->chain.add_candidates(g->h_jobs, n_jobs, all_in);
+    GZ_HIP(hipEventRecord(g->nom_done[jb], g->dec_stream));
+    N.launched = true;
+    return "";
+}
+
+// what is behind a nominal pass: the chain with its follow-up jobs, windows, CRC-32, member checks, hand-over; returns "" or what failed
+std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
+    Arena &A = g->arena[N.k % hast_gz::kArenas];
+    const uint64_t input_bits = N.input_bits;
+    const bool all_in = N.all_in;
+    g->st.chunks += N.n_jobs;
+    g->chain.add_candidates(g->h_jobs[N.k & 1], N.n_jobs, all_in);
     // ---- the chain, with its follow-up jobs ------------------------------------------------------------------------------------
     std::vector<Chain::Gap> gaps;
     while (g->chain.plan(gaps, input_bits)) {
@@ -283,25 +318,25 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
         GZ_HIP(gb.ensure(total * sizeof(uint16_t) + 64));
         const uint64_t gbase = reinterpret_cast<uintptr_t>(gb.p) / 2;
         for (size_t i = 0; i < gaps.size(); ++i) {
-            ChunkJob &j = g->h_jobs[i];
+            ChunkJob &j = g->h_fjobs[i];
             j = gaps[i].job;
             j.sym_cap = (uint32_t)std::min<uint64_t>(gaps[i].want_syms, 1ull << 26);
             j.sym_off = gbase + at[i];
             j.start_bit = j.from_bit;
             j.status = kStFound;
         }
-        GZ_HIP(hipMemcpyAsync(g->jobs.p, g->h_jobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, (uint16_t *)gb.p, g->dec_stream));
-        GZ_HIP(hipMemcpyAsync(g->h_jobs, g->jobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
-        GZ_HIP(hipStreamSynchronize(g->dec_stream));
-        g->chain.gap_done(g->h_jobs, gaps.size(), input_bits);
+        GZ_HIP(hipMemcpyAsync(g->fjobs.p, g->h_fjobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, g->post_stream));
+        GZ_HIP(launch_decode((ChunkJob *)g->fjobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, (uint16_t *)gb.p, g->post_stream));
+        GZ_HIP(hipMemcpyAsync(g->h_fjobs, g->fjobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->post_stream));
+        GZ_HIP(hipStreamSynchronize(g->post_stream));
+        g->chain.gap_done(g->h_fjobs, gaps.size(), input_bits);
         g->st.followup_jobs += gaps.size();
         g->st.followup_rounds++;
     }
-    g->st.decode_s += now_s() - t_seg0;
+    g->st.decode_s += now_s() - N.t0;
     // ---- what became final: windows, CRC-32, member checks, hand-over --------------------------------------------------------------
     std::unique_ptr<Batch> b(new Batch);
-    b->arena = (int)(k & 1);
+    b->arena = (int)(N.k % hast_gz::kArenas);
     g->chain.take_confirmed(b->acc);
     const size_t n = b->acc.size();
     std::string bad;
@@ -330,14 +365,14 @@ std::string produce_segment(hast_gz *g, size_t k, size_t n_chunks, uint64_t firs
             g->h_crc_cap = n + n / 2 + 64;
         }
         // (pageable source: the copy is done with `host` when the call returns)
-        GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(hipStreamSynchronize(g->dec_stream));
-        GZ_HIP(hipMemcpyAsync(A.carry.p, g->carry_next.p, kWindow, hipMemcpyDeviceToDevice, g->dec_stream));
-        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, A.need.p, g->dec_stream));
-        GZ_HIP(launch_crc((const AccDev *)A.acc.p, (uint32_t)n, (const uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.crc.p, g->dec_stream));
-        GZ_HIP(hipMemcpyAsync(g->carry_next.p, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToDevice, g->dec_stream));
-        GZ_HIP(hipMemcpyAsync(g->h_crc, A.crc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, g->dec_stream));
-        GZ_HIP(hipStreamSynchronize(g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, g->post_stream));
+        GZ_HIP(hipStreamSynchronize(g->post_stream));
+        GZ_HIP(hipMemcpyAsync(A.carry.p, g->carry_next.p, kWindow, hipMemcpyDeviceToDevice, g->post_stream));
+        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, A.need.p, g->post_stream));
+        GZ_HIP(launch_crc((const AccDev *)A.acc.p, (uint32_t)n, (const uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.crc.p, g->post_stream));
+        GZ_HIP(hipMemcpyAsync(g->carry_next.p, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToDevice, g->post_stream));
+        GZ_HIP(hipMemcpyAsync(g->h_crc, A.crc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, g->post_stream));
+        GZ_HIP(hipStreamSynchronize(g->post_stream));
         for (size_t i = 0; i < n && bad.empty(); ++i) {
             const Accepted &a = b->acc[i];
             const uint32_t len = a.job.n_out;
@@ -379,9 +414,22 @@ void produce_loop(hast_gz *g) {
     (void)hipSetDevice(g->device);
     const uint64_t first_bit = g->chain.first_deflate_bit();
     const size_t n_chunks = first_bit == ~0ull ? 0 : (size_t)((g->file_size + g->chunk_bytes - 1) / g->chunk_bytes);
-    bool finished = n_chunks == 0;
+    bool finished = n_chunks == 0, stopped = false;
     std::string bad;
-    for (size_t k = 0; !finished && bad.empty(); ++k) bad = produce_segment(g, k, n_chunks, first_bit, finished);
+    Nominal cur, next;
+    if (!finished) bad = launch_nominal(g, 0, n_chunks, first_bit, true, cur, stopped);
+    while (!finished && !stopped && bad.empty()) {
+        if (hipEventSynchronize(g->nom_done[cur.k & 1]) != hipSuccess) { bad = "gz: the decode pass failed"; break; }
+        next = Nominal{};
+        // the next segment's pass goes to the GPU now if its bytes and its arena are there (otherwise behind this segment's hand-over)
+        if (!cur.all_in) bad = launch_nominal(g, cur.k + 1, n_chunks, first_bit, false, next, stopped);
+        if (bad.empty() && !stopped) bad = finish_segment(g, cur, finished);
+        if (finished || stopped || !bad.empty()) break;
+        if (!next.launched) bad = launch_nominal(g, cur.k + 1, n_chunks, first_bit, true, next, stopped);
+        cur = next;
+    }
+    // (a pass that is still running when the loop is left early reads buffers hast_gz_close frees only after the streams have drained)
+    if (stopped) return;
     if (!bad.empty()) publish_error(g, bad);
     else {
         std::unique_ptr<Batch> b(new Batch);
@@ -442,15 +490,27 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
     if (e == hipSuccess) step(hipMemset(reinterpret_cast<uint8_t *>(g->d_in) + tail_from, 0, alloc - tail_from));
     step(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
     step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
+    {   // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass
+        int lo = 0, hi = 0;
+        if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+        step(hipStreamCreateWithPriority(&g->post_stream, hipStreamNonBlocking, hi));
+    }
     g->h_jobs_cap = seg + 8;
-    step(hipHostMalloc((void **)&g->h_jobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
-    step(g->jobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
+    for (int i = 0; i < 2; ++i) {
+        step(hipHostMalloc((void **)&g->h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+        step(g->jobs[i].ensure(g->h_jobs_cap * sizeof(ChunkJob)));
+        step(hipEventCreateWithFlags(&g->nom_done[i], hipEventDisableTiming));
+    }
+    step(hipHostMalloc((void **)&g->h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+    step(g->fjobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
     step(g->carry_next.ensure(kWindow));
     if (e == hipSuccess) step(hipMemset(g->carry_next.p, 0, kWindow));
     for (Arena &a : g->arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
-    // both symbol arenas up front: an allocation that fails later would fail in mid-file
-    for (int i = 0; i < 2 && e == hipSuccess; ++i)
-        if (i == 0 || n_chunks > seg) step(g->arena[i].syms.ensure(seg * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
+    // the symbol arenas up front: an allocation that fails later would fail in mid-file
+    const size_t s0 = std::min<size_t>(seg, 1024);
+    const size_t n_seg = n_chunks <= s0 ? 1 : 1 + (n_chunks - s0 + seg - 1) / seg;
+    for (int i = 0; i < hast_gz::kArenas && e == hipSuccess; ++i)
+        if ((size_t)i < n_seg) step(g->arena[i].syms.ensure((i == 0 && n_seg <= 3 ? std::min(seg, std::max(s0, n_chunks)) : seg) * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
     if (e != hipSuccess) {
         const hast_status st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_UNSUPPORTED : HAST_ERR_HIP, "device inflate of %s: %s", path, hipGetErrorString(e));
         (void)hipGetLastError();
@@ -479,6 +539,7 @@ void hast_gz_close(hast_gz *g) {
     if (g->producer.joinable()) g->producer.join();
     (void)hipSetDevice(g->device);
     if (g->dec_stream) (void)hipStreamSynchronize(g->dec_stream);
+    if (g->post_stream) (void)hipStreamSynchronize(g->post_stream);
     if (g->up_stream) (void)hipStreamSynchronize(g->up_stream);
     for (Arena &a : g->arena) {
         if (a.done_recorded) (void)hipEventSynchronize(a.done);
@@ -486,13 +547,19 @@ void hast_gz_close(hast_gz *g) {
         for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry}) b->release();
         for (DevBuf &b : a.gap) b.release();
     }
-    g->jobs.release();
+    for (int i = 0; i < 2; ++i) {
+        g->jobs[i].release();
+        if (g->h_jobs[i]) (void)hipHostFree(g->h_jobs[i]);
+        if (g->nom_done[i]) (void)hipEventDestroy(g->nom_done[i]);
+    }
+    g->fjobs.release();
+    if (g->h_fjobs) (void)hipHostFree(g->h_fjobs);
     g->carry_next.release();
     if (g->d_in) (void)hipFree(g->d_in);
-    if (g->h_jobs) (void)hipHostFree(g->h_jobs);
     if (g->h_crc) (void)hipHostFree(g->h_crc);
     if (g->up_stream) (void)hipStreamDestroy(g->up_stream);
     if (g->dec_stream) (void)hipStreamDestroy(g->dec_stream);
+    if (g->post_stream) (void)hipStreamDestroy(g->post_stream);
     if (g->fd >= 0) close(g->fd);
     delete g;
 }

@@ -336,10 +336,13 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
             c->est_records = std::min<uint64_t>(c->est_records, (uint64_t)*c->h_cursor + c->est_after);
             c->cur_pending = false;
         }
-        if (c->est_records + worst > c->rec_cap && c->cur_pending) {       // before the table is swept: what does the device say?
-            KC_TRY(hipEventSynchronize(c->cur_ev));
-            c->est_records = std::min<uint64_t>(c->est_records, (uint64_t)*c->h_cursor + c->est_after);
+        if (c->est_records + worst > c->rec_cap) {     // before the table is swept: what does the device say, now?  (a flush waits for
+            // everything launched so far as well)
+            KC_TRY(hipMemcpyAsync(c->h_cursor, c->d_small + kRecCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            KC_TRY(hipStreamSynchronize(c->stream));
+            c->est_records = std::min<uint64_t>(c->est_records, (uint64_t)*c->h_cursor);
             c->cur_pending = false;
+            c->est_after = 0;
         }
         if (c->est_records + worst > c->rec_cap)
             if (hast_status st = part_flush(c)) return st;

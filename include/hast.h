@@ -326,7 +326,7 @@ hast_status hast_fq_commit(hast_fq *);
  * also frames the records.  hast_gz inflates such a file on the GPU: the COMPRESSED bytes cross PCIe (5-6 x fewer than the
  * FASTQ text) and the inflated bytes are written where the caller wants them in HBM -- e.g. straight into a block of the FASTQ
  * framer (hast_fq_submit_device), which reads them where they lie.  Method (hast_amd/csrc/gz_core.h, gz_chain.h, gz_kernels.hip):
- * every 32-KB chunk of the compressed bytes searches its first dynamic-block header and is decoded by ONE LANE into 16-bit
+ * every 32-KB chunk of the compressed bytes searches its first dynamic-block header and is decoded by ONE WAVE into 16-bit
  * symbols with the 32 KB in front of it unknown ("marker" symbols); a chunk counts iff the chunk in front of it ended exactly
  * at its start (holes are decoded by follow-up jobs); windows are resolved in stream order, markers translated, and every
  * member's CRC-32 and ISIZE are checked (CRC by slices on the device, combined with GF(2) operators), so a decoding bug or a
@@ -420,16 +420,18 @@ hast_status hast_kc_count_device(hast_kc *, int parent, const uint8_t *d_bytes, 
 hast_status hast_kc_count(hast_kc *, int parent, const uint8_t *bytes, size_t n_bytes);
 /* wait for all counting submitted so far; HAST_ERR_TABLE_FULL when some k-mer found no slot */
 hast_status hast_kc_sync(hast_kc *);
-/* How the windows reach the table.  By default: find-or-insert in the window's minimizer bucket + one atomic add per minimizer run
- * (k_kc_count), which stands at the rate at which this part executes memory-side atomics.  HAST_KC_COUNT=partition in the
- * environment at hast_kc_create (K <= 29) counts by PARTITIONING instead (hast_amd/csrc/kc_kernels.hip): the windows are written out
- * as 8-byte records of a minimizer run each, the records are partitioned by bucket range in two levels down to slices of 512 or
- * 1024 buckets, and one workgroup per slice counts its records in LDS -- the table is read and written once per flush,
- * sequentially.  Same results (tests); opt-in because its last pass is still slower than the direct kernel (DESIGN.md section 9
- * has the measured breakdown).  Flushes happen at hast_kc_sync, before the table is read, and when the record buffer (what is left
- * of the device memory next to the table; HAST_KC_RECORD_MB caps the record buffer itself) is nearly full.  out[0] = 1: partitioned;
- * out[1] flushes; out[2] records applied; out[3] windows that took the atomic path after all (their bucket and the next three full
- * beyond the slice); out[4] record capacity. */
+/* How the windows reach the table.  Tables of >= 2^20 buckets (128 MB) with a K a record has room for (K <= 27 at the default
+ * minimizer length) count by PARTITIONING (hast_amd/csrc/kc_kernels.hip; kc_common.h "records", "PLACEMENT"): the windows are written
+ * out as 8-byte records of a minimizer run each, the records are partitioned by bucket range in two levels down to slices of 512 or
+ * 1024 buckets, and one workgroup per slice counts its records in LDS -- the table is read and written once per flush, sequentially,
+ * instead of one memory-side atomic per minimizer run (k_kc_count, the DIRECT path of smaller tables and larger K, which stands at
+ * the rate at which this part executes atomics).  Same counts, histograms and selections (tests); the two paths file a key in
+ * different buckets, so a table is filled by one of them only.  HAST_KC_COUNT=atomic|partition in the environment at hast_kc_create
+ * forces either.  Flushes happen at hast_kc_sync, before the table is read, and when the record buffer is nearly full (it takes what
+ * is left of the device memory next to the table, at most one record per slot of the table; HAST_KC_RECORD_MB caps it); a flush of
+ * few records for the table's size goes through the direct path where the records lie (HAST_KC_FLUSH=sweep|atomic pins that).
+ * out[0] = 1: partitioned; out[1] flushes; out[2] records applied; out[3] windows that took the direct path after all (their four
+ * buckets in the slice full); out[4] record capacity. */
 hast_status hast_kc_partition_info(hast_kc *, uint64_t out[5]);
 /* out[0..1] distinct k-mers per parent, out[2] keys in the table, out[3] table capacity (slots),
  * out[4..5] k-mer occurrences counted per parent */

@@ -162,23 +162,34 @@ def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, t
 
 def test_partitioned_and_atomic_counting_agree_on_a_trio(built, monkeypatch):
     """the synthetic trio of the bench (reads with errors over two parental genomes) through both paths: same histograms, same
-    selections, same distinct / total counts"""
+    selections, same distinct / total counts -- the partitioned path with its flushes swept through LDS, with every flush taken
+    through the direct path where the records lie (what few records for the table's size do by themselves), and as a table of this
+    size counts when nothing is forced"""
     g = hast_amd.KcSynth(0, 3_000_000, 150, 2, 20, 20)
     res = {}
-    for mode in ("atomic", "partition"):
-        monkeypatch.setenv("HAST_KC_COUNT", mode)
+    for mode in ("atomic", "partition", "partition/atomic-flush", "default"):
+        monkeypatch.delenv("HAST_KC_COUNT", raising=False)
+        monkeypatch.delenv("HAST_KC_FLUSH", raising=False)
+        if mode != "default":
+            monkeypatch.setenv("HAST_KC_COUNT", mode.split("/")[0])
+        if mode == "partition":
+            monkeypatch.setenv("HAST_KC_FLUSH", "sweep")
+        if mode == "partition/atomic-flush":
+            monkeypatch.setenv("HAST_KC_FLUSH", "atomic")
         with KmerCounter(21, table_bytes=1 << 30) as kc:
-            assert kc.partition_info()["partitioned"] == (mode == "partition")
+            assert kc.partition_info()["partitioned"] == (mode != "atomic")
             for parent in (0, 1):
                 for first in (0, 150_000):
                     kc.count(parent, hast_amd.kc_synth_host(g, parent, first, 150_000))
             kc.sync()
             st = kc.stats()
             res[mode] = (st["distinct"], st["total"], st["keys"], [kc.histo(p) for p in (0, 1)], [kc.select(p, 5, 60) for p in (0, 1)])
-    a, b = res["atomic"], res["partition"]
-    assert a[:3] == b[:3] and a[4] == b[4] and a[4][0] > 1000
-    for p in (0, 1):
-        assert np.array_equal(a[3][p], b[3][p])
+    a = res["atomic"]
+    for mode in ("partition", "partition/atomic-flush", "default"):
+        b = res[mode]
+        assert a[:3] == b[:3] and a[4] == b[4] and a[4][0] > 1000, mode
+        for p in (0, 1):
+            assert np.array_equal(a[3][p], b[3][p]), mode
 
 
 def test_slices_partition_the_key_space(built, oracle_lib):
