@@ -6,6 +6,7 @@
 // Replaces, for this path, gzstream.h:47 + classify.cpp:245-254 (one zlib stream per file on one host thread).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -14,6 +15,7 @@
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -87,7 +89,7 @@ struct hast_gz {
     int fd = -1;
     std::string path;
     uint64_t file_size = 0;
-    size_t chunk_bytes = 32768, seg_chunks = 8192;
+    size_t chunk_bytes = 32768, seg_chunks = 4096;
     double room = 12.0;
     uint32_t slot_syms = 0;
     // device
@@ -465,7 +467,11 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
     g->file_size = (uint64_t)sb.st_size;
     g->chunk_bytes = chunk_bytes ? std::max<size_t>(chunk_bytes, 64) : 32768;
     g->chunk_bytes = (g->chunk_bytes + 3) & ~(size_t)3;
-    g->seg_chunks = seg_chunks ? seg_chunks : 8192;
+    // 4096 chunks a pass x 786 KB of symbol room = 3.2 GB an arena, three arenas (measured against the tree before the pipelined
+    // producer, alternating on one box: passes of 2048 chunks were slower than that tree, 4096 10 % faster, 8192 no faster).  Keep the
+    // footprint small: on some boxes of the pool ONE HIP call of a process that starts right after another one freed tens of GB blocks
+    // for 0.7-6 s (hipMalloc or hipStreamCreate, whichever comes first -- tools/probe/malloc_probe.py; the tree before did the same there).
+    g->seg_chunks = seg_chunks ? seg_chunks : 4096;
     g->room = room > 0 ? room : 12.0;
     if (g->chunk_bytes > (1u << 26)) { close(fd); return set_error(HAST_ERR_INVALID, "chunk_bytes too large"); }
     g->slot_syms = (uint32_t)std::min<double>((double)(1u << 27), (double)g->chunk_bytes * g->room + 600);
@@ -484,17 +490,45 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
     g->seg_chunks = seg;
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    const bool trace = getenv("HAST_GZ_TRACE") != nullptr;
+    double t_tr = now_s();
+    auto tr = [&](const char *what) {
+        if (trace) fprintf(stderr, "gz open %s: %s %.3f s\n", path, what, now_s() - t_tr);
+        t_tr = now_s();
+    };
     // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
     const uint64_t alloc = ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
     step(hipMalloc((void **)&g->d_in, alloc));
     if (e == hipSuccess) step(hipMemset(reinterpret_cast<uint8_t *>(g->d_in) + tail_from, 0, alloc - tail_from));
+    tr("input buffer");
     step(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
-    step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
+    {
+        // The nominal passes keep some CUs FREE (HAST_GZ_FREE_CUS, default 32 of 256): a decode wave lives ~20 ms and the passes fill every
+        // LDS slot of the GPU, so whatever else wants to run -- this file's follow-up jobs, windows and CRC-32, the translate kernel, the
+        // FASTQ framer and the classifier of the blocks already inflated -- would wait for waves to retire, one short kernel after the
+        // other (measured: 0.2-0.35 s of "waiting for the GPU's framing" in a .gz run against 0.07 s on plain files).
+        int n_cu = 0, free_cus = 32;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (const char *fc = getenv("HAST_GZ_FREE_CUS")) free_cus = atoi(fc);
+        if (e == hipSuccess && n_cu > 0 && free_cus > 0 && free_cus < n_cu) {
+            std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+            for (int i = 0; i < n_cu - free_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&g->dec_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                g->dec_stream = nullptr;
+            }
+        }
+        if (!g->dec_stream) step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
+    }
     {   // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass
         int lo = 0, hi = 0;
         if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-        step(hipStreamCreateWithPriority(&g->post_stream, hipStreamNonBlocking, hi));
+        const char *pp = getenv("HAST_GZ_POST_PRIORITY");
+        if (pp && !atoi(pp)) step(hipStreamCreateWithFlags(&g->post_stream, hipStreamNonBlocking));
+        else step(hipStreamCreateWithPriority(&g->post_stream, hipStreamNonBlocking, hi));
     }
+    tr("streams");
     g->h_jobs_cap = seg + 8;
     for (int i = 0; i < 2; ++i) {
         step(hipHostMalloc((void **)&g->h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
@@ -506,11 +540,13 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
     step(g->carry_next.ensure(kWindow));
     if (e == hipSuccess) step(hipMemset(g->carry_next.p, 0, kWindow));
     for (Arena &a : g->arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    tr("job buffers");
     // the symbol arenas up front: an allocation that fails later would fail in mid-file
     const size_t s0 = std::min<size_t>(seg, 1024);
     const size_t n_seg = n_chunks <= s0 ? 1 : 1 + (n_chunks - s0 + seg - 1) / seg;
     for (int i = 0; i < hast_gz::kArenas && e == hipSuccess; ++i)
         if ((size_t)i < n_seg) step(g->arena[i].syms.ensure((i == 0 && n_seg <= 3 ? std::min(seg, std::max(s0, n_chunks)) : seg) * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
+    tr("arenas");
     if (e != hipSuccess) {
         const hast_status st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_UNSUPPORTED : HAST_ERR_HIP, "device inflate of %s: %s", path, hipGetErrorString(e));
         (void)hipGetLastError();

@@ -12,7 +12,7 @@
 //   k_gz_translate  symbols -> bytes (markers through the window in front of the chunk) straight into the caller's buffer,
 //                   e.g. a block buffer of the FASTQ framer
 // Bound: k_gz_decode by LATENCY per symbol (an LDS table look-up depends on the bits the look-up in front of it consumed), hence by
-// waves in flight (14 per CU: 11 KB of tables each); the other kernels stream (2 B read + 1 B written per byte of output).
+// waves in flight (14 per CU: 11 KB of tables + ring each, 128 VGPRs); the other kernels stream (2 B read + 1 B written per byte of output).
 #include <hip/hip_runtime.h>
 
 #include "gz_core.h"
@@ -147,11 +147,13 @@ __device__ __forceinline__ uint64_t wpos(const WBits &b) { return b.wp * 32 - b.
 __device__ __forceinline__ void sym_store(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ uint16_t sym_load_far(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (past the L1)
 
+// 4 waves per SIMD (128 VGPRs; the compiler took 180 = 2 waves per SIMD = 8 chunks per CU, and a chunk's time is latency -- far match
+// copies out of the symbol buffer, ~20 ms whatever else runs -- so chunks in flight are throughput): 14 per CU, the LDS's limit.
 // syms: the base of the symbol memory the jobs' buffers lie in (job.sym_off is an absolute address / 2: the buffer is reached as
 // syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
 // which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
 // symbol instead of ~300)
-__global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
     __shared__ uint32_t s_tab[kTabWords];
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
     // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the few records in front) is
@@ -246,6 +248,31 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
                 break;
             }
             wseek(in, (uint64_t)s_hdr[1] | ((uint64_t)s_hdr[2] << 32));
+            // ---- TWO literals per look-up where both codes fit the 9 root bits: bit 8 of a literal's entry says "a second literal in
+            // bits 24..31", the length is that of both codes.  The bases of a FASTQ record are literals of ~2.2 bits each (half of a file's
+            // bytes), quality values mostly fit in pairs too: a look-up -- the LDS round trip every symbol waits for -- then yields two
+            // symbols.  All 64 lanes, 8 root entries each: every entry is read (with the entry of the bits behind its code) before any is
+            // written (LDS operations of a wave execute in order).
+            {
+                uint32_t pe[(1u << kLitRoot) / 64];
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) {
+                    const uint32_t idx = q * 64 + lane, e1 = lit[idx], l1 = e1 & 0xFF;
+                    uint32_t ne = e1;
+                    if ((e1 & (kLit | kSub)) == kLit && l1 > 0 && l1 < (uint32_t)kLitRoot) {
+                        const uint32_t e2 = lit[idx >> l1], l2 = e2 & 0xFF;     // (the bits behind the first code, zeros above them: an
+                        // entry whose code is no longer than the bits that are really there does not depend on those zeros)
+                        if ((e2 & (kLit | kSub)) == kLit && l2 > 0 && l1 + l2 <= (uint32_t)kLitRoot)
+                            ne = kLit | (1u << 8) | (l1 + l2) | (e1 & 0x00FF0000u) | ((e2 & 0x00FF0000u) << 8);
+                    }
+                    pe[q] = ne;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) s_tab[q * 64 + lane] = pe[q];
+                __syncthreads();
+            }
             // ---- the block's symbols ----
             for (;;) {
                 if (n2 + 260 > cap) { rc = kStNoRoom; break; }
@@ -260,11 +287,13 @@ __global__ void __launch_bounds__(64) k_gz_decode(ChunkJob *jobs, uint32_t n_job
                 in.bb >>= (e & 0xFF);
                 in.bc -= (e & 0xFF);
                 if (e & kLit) {
-                    if (lane == 0) {
-                        s_ring[n2 & (kRing - 1)] = (uint16_t)(e >> 16);
-                        sym_store(sym + n2, (uint16_t)(e >> 16));
+                    const uint32_t two = (e >> 8) & 1;                                // a second literal rides along
+                    if (lane <= two) {
+                        const uint16_t v = (uint16_t)((e >> (16 + 8 * lane)) & 0xFF);
+                        s_ring[(n2 + lane) & (kRing - 1)] = v;
+                        sym_store(sym + n2 + lane, v);
                     }
-                    ++n2;
+                    n2 += 1 + two;
                     continue;
                 }
                 if ((e & 0xFF) == 0) { err = kErrLitCode; rc = kStError; break; }

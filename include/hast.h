@@ -347,10 +347,10 @@ typedef struct {
     double wait_upload_s;      /* the producer waited for compressed bytes to reach the device */
     double wait_consumer_s;    /* ... for the reader to be through with a symbol arena */
     double wait_decode_s;      /* the reader waited for decoded bytes */
-    double open_s;             /* hast_gz_open itself: device buffers (two symbol arenas of 8192 chunks each), streams, threads */
+    double open_s;             /* hast_gz_open itself: device buffers (three symbol arenas of 4096 chunks each), streams, threads */
 } hast_gz_stats;
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
-/* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 8192), symbols of room per compressed byte (0 = 12) */
+/* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 4096), symbols of room per compressed byte (0 = 12) */
 hast_status hast_gz_open_ex(hast_ctx *, const char *path, size_t chunk_bytes, size_t chunks_per_pass, double room, hast_gz **out);
 hast_status hast_gz_read_device(hast_gz *, uint8_t *d_dst, size_t cap, size_t *n_out, hast_stream);
 hast_status hast_gz_get_stats(hast_gz *, hast_gz_stats *out);
