@@ -805,7 +805,9 @@ int main(int argc, char **argv) {
             if (!progress) {                                       // everything waits for a reader thread
                 const double t0 = now_s();
                 std::unique_lock<std::mutex> g(wake_mu);
-                wake_cv.wait_for(g, std::chrono::microseconds(100), [&] { return wake_gen != seen_gen; });   // (a GPU event may be what we wait for)
+                // (a GPU event may be what we wait for; a striped stream relays the newline count in front of EVERY block through this loop:
+                // count kernel -> host -> framing launch, so its wait is short)
+                wake_cv.wait_for(g, std::chrono::microseconds(stripe ? 10 : 100), [&] { return wake_gen != seen_gen; });
                 seen_gen = wake_gen;
                 t_idle += now_s() - t0;
             }
