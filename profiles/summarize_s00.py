@@ -77,6 +77,8 @@ json.dump(summary, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
 json.dump({"workload": "s00", "partitioned": summary["partitioned"], "kernel_source_id": summary["kernel_source_id"],
            "hbm_bytes_per_read": summary["hbm_bytes_per_read"], "hbm_read_requests_per_read": summary["hbm_read_requests_per_read"],
            "hbm_write_requests_per_read": summary["hbm_write_requests_per_read"], "atomics_per_read": summary["atomics_per_read"],
+           "valu_lane_instructions_per_window": summary["valu_lane_instructions_per_window"],
+           "valu_lane_instructions_per_window_by_kernel": {k: c.get("SQ_INSTS_VALU", 0.0) * 64 / summary["windows_in_the_step"] for k, c in per_kernel.items()},
            "source": "profiles/%s_pmc.json: rocprofv3 --pmc, separate passes, summed over the counting kernels of one bench step; reads = requests by "
                      "size (all 128 B on gfx950), writes = WRITE_SIZE" % tag},
           open(os.path.join(dst, "pmc_traffic_s00%s.json" % ("" if summary["partitioned"] else "_atomic")), "w"), indent=1)
