@@ -274,6 +274,49 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 __syncthreads();
             }
             // ---- the block's symbols ----
+            // Symbols are decoded into a BATCH of tokens (literal(s), or match: length, distance) and written out 64 at a time: token i
+            // sits in lane i of two VGPRs, a 64-bit mask marks where in the batch each token starts, and a flush gives
+            // every lane ONE symbol of the batch -- its token by a bit count below it in the mask, its source in the ring, in the symbol
+            // buffer (a far match: one global load for all far symbols of the batch, behind ONE wait for the stores in flight) or in front
+            // of the chunk (a marker).  A match whose source reaches into the batch itself (a run, a copy of the symbols just decoded)
+            // closes the batch first.  Before: every match waited for its own copy -- random DNA is coded as short matches at random
+            // distances in the 32-KB window, ~12 000 a chunk, each a round trip to HBM (the symbol buffers of the chunks in flight are
+            // GBs: no cache holds them) -- and every literal was a global store of its own.
+            uint32_t tokA = 0, tokB = 0;                 // lane i: token i = offset | length << 6 | distance << 16 (0: literals), literal bytes
+            uint32_t nb_tok = 0, nb_sym = 0;             // (wave-uniform)
+            uint64_t smask = 0;
+            uint32_t bstart = n2;                        // position of the batch's first symbol
+            auto flush = [&]() {
+                if (!nb_sym) return;
+                const bool act = lane < nb_sym;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u));
+                const uint32_t ti = act ? below + (uint32_t)((smask >> lane) & 1) - 1 : 0u;      // (bit 0 is set: the first token starts the batch)
+                const uint32_t A = (uint32_t)__shfl((int)tokA, (int)ti, 64), B = (uint32_t)__shfl((int)tokB, (int)ti, 64);
+                const uint32_t off = A & 63, dist = A >> 16, k = lane - off;
+                const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;                  // positions the ring still holds while this batch is written
+                int64_t src = 0;
+                if (dist) src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)(k < dist ? k : k % dist);
+                const bool far = act && dist && src >= 0 && src < ring_lo;
+                // a copy out of the symbol buffer itself reads what this wave stored a while ago: the stores must have reached the L2
+                // (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache maintenance:
+                // an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the GPU 10 x slower
+                if (__ballot(far)) __builtin_amdgcn_s_waitcnt(0);
+                uint16_t v = 0;
+                if (act) {
+                    if (!dist) v = (uint16_t)((B >> (8 * k)) & 0xFF);
+                    else if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
+                    else if (far) v = sym_load_far(sym + src);
+                    else v = s_ring[(uint32_t)src & (kRing - 1)];
+                }
+                // (every lane has read before any lane writes: LDS operations of a wave execute in order)
+                if (act) {
+                    s_ring[(bstart + lane) & (kRing - 1)] = v;
+                    sym_store(sym + bstart + lane, v);
+                }
+                bstart += nb_sym;
+                nb_tok = nb_sym = 0;
+                smask = 0;
+            };
             for (;;) {
                 if (n2 + 260 > cap) { rc = kStNoRoom; break; }
                 if (wpos(in) > nbits) { rc = kStStarved; break; }
@@ -287,13 +330,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 in.bb >>= (e & 0xFF);
                 in.bc -= (e & 0xFF);
                 if (e & kLit) {
-                    const uint32_t two = (e >> 8) & 1;                                // a second literal rides along
-                    if (lane <= two) {
-                        const uint16_t v = (uint16_t)((e >> (16 + 8 * lane)) & 0xFF);
-                        s_ring[(n2 + lane) & (kRing - 1)] = v;
-                        sym_store(sym + n2 + lane, v);
-                    }
-                    n2 += 1 + two;
+                    const uint32_t cnt = 1 + ((e >> 8) & 1);                          // a second literal rides along
+                    if (nb_sym + cnt > 64 || nb_tok == 64) flush();
+                    tokA = lane == nb_tok ? (nb_sym | (cnt << 6)) : tokA;
+                    tokB = lane == nb_tok ? (e >> 16) : tokB;
+                    smask |= 1ull << nb_sym;
+                    ++nb_tok;
+                    nb_sym += cnt;
+                    n2 += cnt;
                     continue;
                 }
                 if ((e & 0xFF) == 0) { err = kErrLitCode; rc = kStError; break; }
@@ -317,14 +361,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 in.bb >>= deb;
                 in.bc -= deb;
                 if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; rc = kStError; break; }
-                // symbol n2 + k comes from n2 + k - distance, or -- periodic -- from the first `distance` of them; what lies in
-                // front of the chunk is a marker.  64 symbols per step: the lanes of a step read before any of them writes (LDS
-                // operations of a wave execute in order), and a later step reads what the earlier ones wrote.
+                if (len <= 64) {
+                    // its source must lie in front of the batch (what the batch holds is not written yet)
+                    const int64_t src_end = (int64_t)n2 - (int64_t)distance + (int64_t)(len < distance ? len : distance);
+                    if (src_end > (int64_t)bstart || nb_sym + len > 64 || nb_tok == 64) flush();
+                    tokA = lane == nb_tok ? (nb_sym | (len << 6) | (distance << 16)) : tokA;
+                    smask |= 1ull << nb_sym;
+                    ++nb_tok;
+                    nb_sym += len;
+                    n2 += len;
+                    continue;
+                }
+                // a long match, on its own: symbol n2 + k comes from n2 + k - distance, or -- periodic -- from the first `distance` of
+                // them; what lies in front of the chunk is a marker.  64 symbols per step: the lanes of a step read before any of them
+                // writes, and a later step reads what the earlier ones wrote.
+                flush();
                 const bool near = distance <= kRingReach;
-                // a copy out of the symbol buffer itself reads what this wave stored a moment ago: the stores must have reached the
-                // L2 (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache
-                // maintenance: an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the
-                // GPU 10 x slower while this one runs
                 if (!near) __builtin_amdgcn_s_waitcnt(0);
                 for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                     const uint32_t k = k0 + lane;
@@ -338,7 +390,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     }
                 }
                 n2 += len;
+                bstart = n2;
             }
+            if (!rc) flush();
             if (rc) {
                 status |= rc;
                 break;
