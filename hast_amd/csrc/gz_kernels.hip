@@ -101,10 +101,11 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
 // ---- decode: a WAVE per chunk -----------------------------------------------------------------------------------------------------
 // Huffman decoding is serial (no code boundary is known before the code in front of it is decoded), so one symbol at a time --
 // but by the whole wave in lockstep: every lane carries the same bit buffer and reads the same table entry (a broadcast read of
-// the tables in LDS, built per block by lane 0 with the code of gz_core.h), which keeps the control flow uniform, and the part
-// that IS parallel runs on all lanes: a match of length L is copied by L lanes at once -- out of a ring of the chunk's last 4096
-// symbols in LDS when it reaches back less than that (a global load per match would put ~1 us on the path of every symbol behind
-// it), out of the symbol buffer otherwise (behind a fence, past the L1).  Output symbols: literal byte, or kMarker + i = "byte i
+// the tables in LDS, built per block by lane 0 with the code of gz_core.h; the bit buffer and everything derived from it live in
+// SGPRs), which keeps the control flow uniform, and the part that IS parallel runs on all lanes: the symbols of a block are gathered
+// as tokens (literals, matches) and written out 64 at a time, every lane one symbol -- out of a ring of the chunk's last 2048
+// symbols in LDS when its source reaches back less than that, out of the symbol buffer otherwise (one global load for all far
+// symbols of a batch, past the L1, behind one wait for the stores in flight).  Output symbols: literal byte, or kMarker + i = "byte i
 // of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
 struct WBits {                     // wave-uniform bit input.  The next 64 words of the stream sit in a VGPR, one per lane (`win`,
     const uint32_t *w;             // word wbase + lane), the 64 behind them in `nxt` (loaded when `win` is taken into use, a few hundred
