@@ -107,6 +107,7 @@ struct hast_gz {
     static constexpr int kArenas = 3;
     Arena arena[kArenas];
     hipStream_t up_stream = nullptr, dec_stream = nullptr, post_stream = nullptr;
+    int dec_masked_free = 0;                  // != 0: dec_stream is a CU-masked stream out of the process's pool (goes back there)
     // threads
     std::thread uploader, producer;
     std::mutex mu;
@@ -136,6 +137,43 @@ namespace {
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) return std::string(#expr ": ") + hipGetErrorString(e_);          \
     } while (0)
+
+// CU-masked streams are created once per (device, free CUs) and handed from stream to stream of compressed input, never destroyed:
+// creating one right after another had been destroyed hung inside the runtime every other time (a stream closed early with passes
+// in flight, then the next file opened: tests/test_gz_gpu.py test_a_stream_closed_early_with_passes_in_flight).
+struct MaskedStreams {
+    std::mutex mu;
+    std::vector<std::pair<std::pair<int, int>, hipStream_t>> idle;      // ((device, free CUs), stream)
+};
+MaskedStreams &masked_streams() {
+    static MaskedStreams *p = new MaskedStreams();                       // (never destroyed: the process ends with it)
+    return *p;
+}
+hipStream_t masked_stream_get(int device, int n_cu, int free_cus) {
+    MaskedStreams &ms = masked_streams();
+    {
+        std::lock_guard<std::mutex> lk(ms.mu);
+        for (size_t i = 0; i < ms.idle.size(); ++i)
+            if (ms.idle[i].first == std::make_pair(device, free_cus)) {
+                hipStream_t s = ms.idle[i].second;
+                ms.idle.erase(ms.idle.begin() + (long)i);
+                return s;
+            }
+    }
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    for (int i = 0; i < n_cu - free_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return s;
+}
+void masked_stream_put(int device, int free_cus, hipStream_t s) {
+    MaskedStreams &ms = masked_streams();
+    std::lock_guard<std::mutex> lk(ms.mu);
+    ms.idle.push_back({{device, free_cus}, s});
+}
 
 bool read_at(int fd, uint64_t off, size_t n, uint8_t *dst, size_t *got) {
     size_t have = 0;
@@ -512,12 +550,8 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
         if (hipGetDeviceProperties(&prop, g->device) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (const char *fc = getenv("HAST_GZ_FREE_CUS")) free_cus = atoi(fc);
         if (e == hipSuccess && n_cu > 0 && free_cus > 0 && free_cus < n_cu) {
-            std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
-            for (int i = 0; i < n_cu - free_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-            if (hipExtStreamCreateWithCUMask(&g->dec_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                g->dec_stream = nullptr;
-            }
+            g->dec_stream = masked_stream_get(g->device, n_cu, free_cus);
+            if (g->dec_stream) g->dec_masked_free = free_cus;
         }
         if (!g->dec_stream) step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
     }
@@ -565,6 +599,11 @@ hast_status hast_gz_open(hast_ctx *ctx, const char *path, hast_gz **out) { retur
 
 void hast_gz_close(hast_gz *g) {
     if (!g) return;
+    const bool trace = getenv("HAST_GZ_TRACE") != nullptr;
+    auto tr = [&](const char *what) {
+        if (trace) fprintf(stderr, "gz close: %s\n", what);
+    };
+    tr("begin");
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->stop = true;
@@ -572,11 +611,14 @@ void hast_gz_close(hast_gz *g) {
         g->cv.notify_all();
     }
     if (g->uploader.joinable()) g->uploader.join();
+    tr("uploader joined");
     if (g->producer.joinable()) g->producer.join();
+    tr("producer joined");
     (void)hipSetDevice(g->device);
     if (g->dec_stream) (void)hipStreamSynchronize(g->dec_stream);
     if (g->post_stream) (void)hipStreamSynchronize(g->post_stream);
     if (g->up_stream) (void)hipStreamSynchronize(g->up_stream);
+    tr("streams drained");
     for (Arena &a : g->arena) {
         if (a.done_recorded) (void)hipEventSynchronize(a.done);
         if (a.done) (void)hipEventDestroy(a.done);
@@ -594,8 +636,10 @@ void hast_gz_close(hast_gz *g) {
     if (g->d_in) (void)hipFree(g->d_in);
     if (g->h_crc) (void)hipHostFree(g->h_crc);
     if (g->up_stream) (void)hipStreamDestroy(g->up_stream);
-    if (g->dec_stream) (void)hipStreamDestroy(g->dec_stream);
+    if (g->dec_stream && g->dec_masked_free) masked_stream_put(g->device, g->dec_masked_free, g->dec_stream);     // (drained above)
+    else if (g->dec_stream) (void)hipStreamDestroy(g->dec_stream);
     if (g->post_stream) (void)hipStreamDestroy(g->post_stream);
+    tr("freed");
     if (g->fd >= 0) close(g->fd);
     delete g;
 }

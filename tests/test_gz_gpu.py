@@ -1,7 +1,7 @@
 """The device inflate (include/hast.h hast_gz_*, hast_amd/csrc/gz_kernels.hip) against zlib's bytes, through the C ABI: the
 whole corpus of the host decoders' test (every block type, member layout, header field, flush point, level, window size),
 with chunks of 64 bytes to 1 MB (chunks in which no block starts, blocks larger than a chunk, stored / fixed blocks at chunk
-borders, members that end inside a chunk), passes of a few chunks (two symbol arenas taking turns), too little room per chunk
+borders, members that end inside a chunk), passes of a few chunks (three symbol arenas taking turns, the next pass launched before the current one is walked), too little room per chunk
 (follow-up jobs), reads of 1 byte to 4 MB; truncated and bit-flipped files are errors -- CRC-32 and ISIZE of every member are
 checked on the way -- never other data."""
 import gzip
@@ -154,7 +154,7 @@ def test_truncated_and_damaged_input_is_an_error_never_other_data(ctx, tmp_path)
 
 
 def test_a_level6_fastq_of_100_mb_with_default_geometry(ctx, tmp_path):
-    """default geometry (32-KB chunks, 8192 per pass) on a stream of several hundred chunks: every candidate the search
+    """default geometry (32-KB chunks, 4096 per pass) on a stream of several hundred chunks: every candidate the search
     finds is a real boundary or is skipped by the chain, few follow-up jobs, output == zlib's"""
     rng = np.random.default_rng(4)
     n = 300_000
@@ -172,3 +172,26 @@ def test_a_level6_fastq_of_100_mb_with_default_geometry(ctx, tmp_path):
         st = z.stats()
     assert got == data
     assert st["followup_jobs"] <= st["chunks"] // 20 + 2, st
+
+
+def test_a_stream_closed_early_with_passes_in_flight(ctx, tmp_path):
+    """the reader gives up after a few bytes (or after none) while the producer has the next segment's nominal pass on the GPU: close
+    must drain the streams, free the arenas and return -- with small passes (several segments in flight) and with the default ones.
+    (Found by this test: a CU-masked stream created right after another had been destroyed hung inside the runtime every other time;
+    such streams now come out of a pool and go back to it.)"""
+    rng = np.random.default_rng(5)
+    data = rng.choice(np.frombuffer(b"ACGT\n", np.uint8), 6_000_000).tobytes()
+    p = tmp_path / "early.gz"
+    p.write_bytes(gzip.compress(data, 6))
+    for chunk, seg, take in ((4096, 3, 1000), (4096, 3, 0), (0, 0, 70_000), (2048, 1, 5_000_000)):
+        with hast_amd.GzReader(ctx, str(p), chunk, seg) as z:
+            if take:
+                got = bytearray()
+                while len(got) < take:
+                    a = z.read(min(65536, take - len(got)))
+                    assert a.size
+                    got += a.tobytes()
+                assert bytes(got) == data[:take]
+    # and the context is still good for a whole stream
+    with hast_amd.GzReader(ctx, str(p)) as z:
+        assert z.read_all(1 << 20) == data
