@@ -555,13 +555,9 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
         }
         if (!g->dec_stream) step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
     }
-    {   // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass
-        int lo = 0, hi = 0;
-        if (e == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-        const char *pp = getenv("HAST_GZ_POST_PRIORITY");
-        if (pp && !atoi(pp)) step(hipStreamCreateWithFlags(&g->post_stream, hipStreamNonBlocking));
-        else step(hipStreamCreateWithPriority(&g->post_stream, hipStreamNonBlocking, hi));
-    }
+    // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass: a stream of its own
+    // (a high-priority one made no difference in an A/B: the free CUs are what lets its kernels start)
+    step(hipStreamCreateWithFlags(&g->post_stream, hipStreamNonBlocking));
     tr("streams");
     g->h_jobs_cap = seg + 8;
     for (int i = 0; i < 2; ++i) {

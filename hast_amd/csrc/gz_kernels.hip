@@ -320,8 +320,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             };
             for (;;) {
                 if (n2 + 260 > cap) { rc = kStNoRoom; break; }
-                if (wpos(in) > nbits) { rc = kStStarved; break; }
-                wrefill(in);
+                if (in.bc <= 32) {
+                    // (the end of the input is looked for when a word is taken, not per symbol: the buffer is padded with zeros, and the
+                    // block's end checks once more)
+                    if (wpos(in) > nbits) { rc = kStStarved; break; }
+                    wrefill(in);
+                }
                 uint32_t e = lit[in.bb & LM];
                 if (e & kSub) {
                     in.bb >>= kLitRoot;
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 in.bc -= (e & 0xFF);
                 if (e & kLit) {
                     const uint32_t cnt = 1 + ((e >> 8) & 1);                          // a second literal rides along
-                    if (nb_sym + cnt > 64 || nb_tok == 64) flush();
+                    if (nb_sym + cnt > 64) flush();                                   // (a token holds at least one symbol: never more than 64 tokens)
                     tokA = lane == nb_tok ? (nb_sym | (cnt << 6)) : tokA;
                     tokB = lane == nb_tok ? (e >> 16) : tokB;
                     smask |= 1ull << nb_sym;
@@ -365,7 +369,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 if (len <= 64) {
                     // its source must lie in front of the batch (what the batch holds is not written yet)
                     const int64_t src_end = (int64_t)n2 - (int64_t)distance + (int64_t)(len < distance ? len : distance);
-                    if (src_end > (int64_t)bstart || nb_sym + len > 64 || nb_tok == 64) flush();
+                    if (src_end > (int64_t)bstart || nb_sym + len > 64) flush();
                     tokA = lane == nb_tok ? (nb_sym | (len << 6) | (distance << 16)) : tokA;
                     smask |= 1ull << nb_sym;
                     ++nb_tok;
