@@ -24,10 +24,12 @@ namespace gz {
 // ---- search: the first position in [from_bit, from_bit + search_to_lo) that parses as a non-final dynamic block header -----
 // A wave per chunk, 64 bit positions per step, three sieves: (1) the 17 header bits every lane tests for itself (type bits 100b,
 // HLIT, HDIST in range: one position in 9 passes); (2) the survivors are queued (LDS, in position order) and, 64 at a time, tested
-// for a COMPLETE code-length code (one in ~100 passes); (3) what is left is parsed in full by one lane, lowest position first.
+// for a COMPLETE code-length code (one in ~100 passes); (3) what is left is queued again and parsed in full 64 at a time, a lane
+// per candidate; the lowest position that parses is the chunk's start.
 __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
-    __shared__ uint32_t s_q[128];                                             // positions (relative to from_bit) that passed sieve 1
-    __shared__ uint32_t s_pre[kPreTabCap];                                    // the strict parse's code-length table (one lane at a time)
+    __shared__ uint32_t s_q[1024];                                            // positions (relative to from_bit) that passed sieve 1
+    __shared__ uint32_t s_q3[128];                                            // ... that passed sieve 2 (position order)
+    __shared__ uint32_t s_pre[64 * kPreTabCap];                               // the strict parse's code-length table, one per lane
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob &job = jobs[j];
@@ -43,52 +45,90 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
     uint64_t to = from + job.search_to_lo;
     if (to > lim) to = lim;
     uint64_t found = ~0ull;
-    uint32_t qn = 0;
-    // sieves 2 + 3 over the first `cnt` queue entries (position order)
-    auto drain = [&](uint32_t cnt) {
-        bool c = false;
-        uint64_t bit = 0;
-        if (lane < cnt) {
-            bit = from + s_q[lane];
-            c = candidate(bits_at(w, bit), bits_at(w, bit + 56));
-        }
-        unsigned long long mask = __ballot(c);
-        while (mask && found == ~0ull) {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            int ok = 0;
-            if ((int)lane == l) ok = header_parses(w, nbits, bit, s_pre) ? 1 : 0;
-            ok = __shfl(ok, l);
-            if (ok) found = from + s_q[l];
-        }
-        // the rest of the queue moves to the front
-        const uint32_t rest = qn - cnt;
+    uint32_t qh = 0, qn = 0, q3n = 0;                                         // sieve-1 queue: s_q[qh, qh + qn)
+    // sieve 3 over the first `cnt` entries of s_q3, every lane its own candidate: a strict parse decodes ~290 code lengths one after
+    // the other (~50 us on a lane)
+    auto parse_batch = [&](uint32_t cnt) {
+        bool ok = false;
+        if (lane < cnt) ok = header_parses(w, nbits, from + s_q3[lane], s_pre + lane * kPreTabCap);
+        const unsigned long long m = __ballot(ok);
+        if (m) found = from + s_q3[__builtin_ctzll(m)];                       // the lowest position that parses
+        const uint32_t rest = q3n - cnt;
         uint32_t v = 0;
-        if (lane < rest) v = s_q[cnt + lane];
+        if (lane < rest) v = s_q3[cnt + lane];
         __syncthreads();
-        if (lane < rest) s_q[lane] = v;
-        qn = rest;
+        if (lane < rest) s_q3[lane] = v;
+        q3n = rest;
         __syncthreads();
     };
-    for (uint64_t base = from; base < to && found == ~0ull; base += 64) {
-        const uint64_t bit = base + lane;
-        bool pre = false;
-        if (bit < to) {
-            const uint64_t wi = bit >> 5;
-            const uint32_t sh = (uint32_t)(bit & 31);
-            const uint32_t v = (uint32_t)((((uint64_t)w[wi + 1] << 32) | w[wi]) >> sh);
-            pre = (v & 7) == 4 && ((v >> 3) & 31) <= 29 && ((v >> 8) & 31) <= 29;
+    // sieve 2 over the first `cnt` entries of the sieve-1 queue (position order); what passes is queued for sieve 3
+    auto drain = [&](uint32_t cnt) {
+        bool c = false;
+        uint32_t rel = 0;
+        if (lane < cnt) {
+            rel = s_q[qh + lane];
+            const uint64_t bit = from + rel;
+            c = candidate(bits_at(w, bit), bits_at(w, bit + 56));
         }
-        const unsigned long long pm = __ballot(pre);
-        if (pm) {
-            const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-            if (pre) s_q[at] = (uint32_t)(bit - from);
-            qn += (uint32_t)__popcll(pm);
+        const unsigned long long mask = __ballot(c);
+        if (mask) {
+            const uint32_t at = q3n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (c) s_q3[at] = rel;
+            q3n += (uint32_t)__popcll(mask);
+        }
+        qh += cnt;
+        qn -= cnt;
+        __syncthreads();
+        if (q3n >= 64) parse_batch(64);
+    };
+    // sieve 1, a WORD per lane and step (2048 bit positions a step: one pair of coalesced loads instead of 32 -- the wave used to take
+    // 64 positions a step and waited for the same two words 32 times over): the 13 header bits at each of the word's 32 offsets
+    const uint64_t w_first = from >> 5, w_end = (to + 31) >> 5;
+    for (uint64_t wb = w_first; wb < w_end && found == ~0ull; wb += 64) {
+        const uint64_t wi = wb + lane;
+        uint32_t m = 0;
+        if (wi < w_end) {
+            const uint64_t x = ((uint64_t)w[wi + 1] << 32) | w[wi];
+#pragma unroll
+            for (int o = 0; o < 32; ++o) {
+                const uint32_t v = (uint32_t)(x >> o);
+                const bool pre = (v & 7) == 4 && ((v >> 3) & 31) <= 29 && ((v >> 8) & 31) <= 29;
+                m |= (uint32_t)pre << o;
+            }
+            // positions in front of `from` and at or behind `to`
+            const uint64_t b0 = wi * 32;
+            if (b0 < from) m &= ~0u << (uint32_t)(from - b0);
+            if (b0 + 32 > to) m &= to > b0 ? ~0u >> (uint32_t)(b0 + 32 - to) : 0u;
+        }
+        // the survivors of all lanes into the queue, in position order: lane by lane, offset by offset
+        uint32_t cnt = (uint32_t)__popc(m), incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= (uint32_t)d) incl += t;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        if (total) {
+            // the remainder of the queue to its front (fewer than 64 entries), then this step's survivors behind it
+            uint32_t keep = 0;
+            if (lane < qn) keep = s_q[qh + lane];
             __syncthreads();
-            if (qn >= 64) drain(64);
+            if (lane < qn) s_q[lane] = keep;
+            qh = 0;
+            uint32_t at = qn + incl - cnt;
+            const uint32_t rel0 = (uint32_t)(wi * 32 - from);                 // (wraps for positions in front of `from`: those bits are masked off)
+            while (m) {
+                const uint32_t o = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                s_q[at++] = rel0 + o;
+            }
+            qn += total;
+            __syncthreads();
+            while (qn >= 64 && found == ~0ull) drain(64);
         }
     }
     while (qn && found == ~0ull) drain(qn < 64 ? qn : 64);
+    while (q3n && found == ~0ull) parse_batch(q3n < 64 ? q3n : 64);
     if (lane == 0) {
         job.start_bit = found == ~0ull ? from : found;
         job.end_bit = job.start_bit;
