@@ -6,6 +6,9 @@
 // Integer + HBM work only (no MFMA by design):
 //   k_kc_count   : byte stream -> 2-bit codes + validity mask in LDS -> canonical k-mer per window -> find-or-insert in
 //                  the window's minimizer bucket (128-B line: 8 keys + 8 paternal + 8 maternal counters) -> one atomic add
+//                  (the DIRECT path: small tables, K > 27); with EMIT the same front end writes 8-byte records of minimizer runs
+//   k_kc_part<1|2>, k_kc_apply, k_kc_spill : the PARTITIONED path of large tables (below): records -> two levels of bucket ranges
+//                  -> one slice of the table at a time in LDS, counted there
 //   k_kc_stats / k_kc_histo / k_kc_select : streaming passes over the table
 //   k_kc_format  : selected keys -> text lines
 #include <cstdlib>
@@ -349,11 +352,11 @@ hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s) {
 // except one reservation per (workgroup, bin) and the few windows whose buckets are full beyond the slice (k_kc_spill).
 //   HBM traffic per window: 8 B x 6 / ~3.3 windows per record + the sweep of the table (11 B at 30x) ~ 25 B, against one 128-B
 //   line read + one atomic per minimizer run before.
-// Measured (round 4, bench.py --workload s00, 10.4 G windows, 60-GB table): emit 76 ms + two partition passes
-// 61 ms + the sweep of the table 30 ms + record loads / minimizers / canonical keys 33 ms = 0.20 s = 59 Gbp/s -- and the LDS probes
-// of k_kc_apply on top of that 0.38 s (a lane per RECORD: runs of 1..9 windows and 1..32 slot probes diverge, 4-way bank
-// conflicts), 0.58 s in all against 0.27 s of the direct kernel.  Hence OPT-IN (HAST_KC_COUNT=partition) until the probes are
-// re-shaped (a lane per window, slot-major slices).
+// Measured (round 4, bench.py --workload s00, 10.4 G windows, 64-GB table; DESIGN.md section 9 has the steps): emit 51 ms + two
+// partition passes 22 + 17 ms + k_kc_apply 50 ms (+ 9 ms to clear the table) = 0.148 s a step = 81 Gbp/s against 0.271 s of the direct
+// kernel, 3.95 KB of HBM traffic per 150-bp read against 9.59 KB; every pass is bound by VALU issue.  The first version (a lane per
+// RECORD in the LDS pass, the minimizer recomputed in every pass, keys filed in their minimizer's bucket as in the direct layout,
+// one reservation per tile on one global word) took 0.58 s.
 struct KcPartGeom {
     unsigned long long *table;
     uint32_t nbuckets;
