@@ -366,11 +366,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     if (wpos(in) > nbits) { rc = kStStarved; break; }
                     wrefill(in);
                 }
-                uint32_t e = lit[in.bb & LM];
+                // (every lane reads the same entry: it is a wave-uniform value, and saying so keeps the tests on it scalar)
+                uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit[in.bb & LM]);
                 if (e & kSub) {
                     in.bb >>= kLitRoot;
                     in.bc -= kLitRoot;
-                    e = lit[(e >> 16) + (uint32_t)(in.bb & ((1u << ((e >> 8) & 31)) - 1))];
+                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit[(e >> 16) + (uint32_t)(in.bb & ((1u << ((e >> 8) & 31)) - 1))]);
                 }
                 in.bb >>= (e & 0xFF);
                 in.bc -= (e & 0xFF);
@@ -392,11 +393,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 in.bb >>= leb;
                 in.bc -= leb;
                 wrefill(in);
-                uint32_t d = dst[in.bb & DM];
+                uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst[in.bb & DM]);
                 if (d & kSub) {
                     in.bb >>= kDistRoot;
                     in.bc -= kDistRoot;
-                    d = dst[(d >> 16) + (uint32_t)(in.bb & ((1u << ((d >> 8) & 31)) - 1))];
+                    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst[(d >> 16) + (uint32_t)(in.bb & ((1u << ((d >> 8) & 31)) - 1))]);
                 }
                 if ((d & 0xFF) == 0) { err = kErrDistCode; rc = kStError; break; }
                 in.bb >>= (d & 0xFF);
