@@ -1,3 +1,4 @@
+# the early-close test of the device inflate six times in fresh processes (an intermittent hang: CU-masked stream re-created), then the whole file
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 for v in 1 2 3 4 5 6; do

@@ -1,3 +1,4 @@
+# stage 00, instrumented build of the first partitioned version: emit only / all passes but the LDS probes / everything
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out

@@ -1,3 +1,4 @@
+# device inflate on one box: default / no high-priority stream / no CU mask, with the open-time trace (where a 0.7-s stall of some boxes sits)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out
