@@ -12,7 +12,7 @@
 //   k_gz_translate  symbols -> bytes (markers through the window in front of the chunk) straight into the caller's buffer,
 //                   e.g. a block buffer of the FASTQ framer
 // Bound: k_gz_decode by LATENCY per symbol (an LDS table look-up depends on the bits the look-up in front of it consumed), hence by
-// waves in flight (14 per CU: 11 KB of tables + ring each, 128 VGPRs); the other kernels stream (2 B read + 1 B written per byte of output).
+// waves in flight (16 per CU: 8 KB of tables + ring each, 128 VGPRs); the other kernels stream (2 B read + 1 B written per byte of output).
 #include <hip/hip_runtime.h>
 
 #include "gz_core.h"
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
 // but by the whole wave in lockstep: every lane carries the same bit buffer and reads the same table entry (a broadcast read of
 // the tables in LDS, built per block by lane 0 with the code of gz_core.h; the bit buffer and everything derived from it live in
 // SGPRs), which keeps the control flow uniform, and the part that IS parallel runs on all lanes: the symbols of a block are gathered
-// as tokens (literals, matches) and written out 64 at a time, every lane one symbol -- out of a ring of the chunk's last 2048
+// as tokens (literals, matches) and written out 64 at a time, every lane one symbol -- out of a ring of the chunk's last 512
 // symbols in LDS when its source reaches back less than that, out of the symbol buffer otherwise (one global load for all far
 // symbols of a batch, past the L1, behind one wait for the stores in flight).  Output symbols: literal byte, or kMarker + i = "byte i
 // of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
@@ -199,7 +199,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
     // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the few records in front) is
     // copied out of LDS -- a global load per match would put ~1 us of latency on the path of every symbol behind it
-    constexpr uint32_t kRing = 2048, kRingReach = kRing - 320;
+    // (512 symbols: with the batched copies a far source costs little, and 8.3 KB of LDS a wave instead of 11.3 is 16 waves per CU
+    // instead of 14 -- read phase -3.5 % in an A/B on one box, profiles/round4_ab_gz_ring512.txt)
+    constexpr uint32_t kRing = 512, kRingReach = kRing - 320;
     __shared__ uint16_t s_ring[kRing];
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
