@@ -1,5 +1,6 @@
 """N>1 path on CPU (gloo, world_size 2): the read-shard arithmetic bench.py uses and the counter merge
-(one all_reduce(sum) over int32 views of the u32 counters) give exactly the single-process counts.
+(one all_reduce(sum) over int64 views of the 64-bit counters, the device layout since round 4) give exactly the single-process
+counts -- also for a barcode whose counters stand beyond 2^32 on every rank (the hot no-barcode bucket of real stLFR data).
 The per-shard classification here is done by the oracle (no GPU on this box); on the GPU box the same
 merge runs over RCCL inside bench.py."""
 import os
@@ -39,7 +40,8 @@ def _worker(rank, world, port, steps, R, out_dir):
     for h in (0, 1):
         keys = hast_amd.synth_keys_host(p, h, 0, n_keys)
         o.ho_load_keys(oc, keys.ctypes.data, keys.size, h, k)
-    counts = np.zeros((n_bc, 4), dtype=np.uint32)              # device layout {c0,c1,neg,reserved}
+    counts = np.zeros((n_bc, 4), dtype=np.uint64)              # device layout {c0,c1,neg,reserved}, 64-bit
+    counts[7, :3] = (1 << 32) + 5 + rank                        # a hot barcode: each rank already holds more than 2^32 of everything
     off = np.arange(R + 1, dtype=np.uint64) * L
     for s in range(steps):
         bases, ids = hast_amd.synth_reads_host(p, shard_first_read(s, world, rank, R), R)
@@ -47,12 +49,12 @@ def _worker(rank, world, port, steps, R, out_dir):
         o.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, R, e[0].ctypes.data, e[1].ctypes.data,
                           e[2].ctypes.data, None, 1)
         for c in range(3):
-            counts[:, c] += e[c]
+            counts[:, c] += e[c].astype(np.uint64)
     o.ho_free(oc)
-    t = torch.from_numpy(counts.view(np.int32))
+    t = torch.from_numpy(counts.view(np.int64))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)                   # what bench.py does over RCCL
     if rank == 0:
-        np.save(os.path.join(out_dir, "merged.npy"), t.numpy().view(np.uint32))
+        np.save(os.path.join(out_dir, "merged.npy"), t.numpy().view(np.uint64))
     dist.destroy_process_group()
 
 
@@ -78,6 +80,9 @@ def test_two_rank_shard_merge_equals_single_process(oracle_lib, tmp_path):
     oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, n, e[0].ctypes.data, e[1].ctypes.data,
                                e[2].ctypes.data, None, 2)
     oracle_lib.ho_free(oc)
+    hot = np.zeros(n_bc, np.uint64)
+    hot[7] = sum((1 << 32) + 5 + r for r in range(world))          # what the ranks held before the run, summed without a wrap
     for c in range(3):
-        assert np.array_equal(merged[:, c], e[c])
+        assert np.array_equal(merged[:, c], e[c].astype(np.uint64) + hot)
+    assert merged[7, 0] > (1 << 33)
     assert not merged[:, 3].any()
