@@ -92,6 +92,8 @@ def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, 
         res = subprocess.run(argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, HAST_INFLATE="host"))
         assert res.returncode == 0, res.stderr.decode()[-2000:]
         assert res.stdout == open(d / meta["expected"], "rb").read()
+    # --stats says which measurement switches the context was created with (none here: the environment sets none)
+    assert [l for l in res.stderr.decode().splitlines() if l.startswith("__stats_switches__")] == ["__stats_switches__ none"]
     line = [l for l in res.stderr.decode().splitlines() if l.startswith("__stats_devices__")]
     if deal == "files":
         assert not line
