@@ -144,11 +144,21 @@ GZ_HD bool complete(const uint8_t *lens, int n, bool lone_ok) {
     return left == 0 || (lone_ok && maxl == 1);
 }
 
+// What a header parse indexes by a value it has just read (code lengths, counts per length, next code per length): on the device a
+// private array indexed like that lives in scratch memory -- k_gz_decode keeps ONE of these in LDS for its lane 0 (no scratch, and
+// no registers held across the symbol loop), the search's strict parse and the host keep it on their stacks.
+struct HdrScratch {
+    uint8_t lens[286 + 30 + 4];
+    uint8_t pre[20];
+    int count[16];
+    uint32_t first[16], next[16];
+};
+
 // lens[0..n): code lengths (0 = unused).  kind 0: literal/length alphabet, 1: distance alphabet, 2: code-length alphabet.
 // tab: cap entries; first level = 2^root entries, sub-tables behind it.  No per-symbol scratch: the canonical codes are
 // regenerated in symbol order by every pass.  Returns kErrNone or what is wrong.
-GZ_HD uint32_t build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, uint32_t cap, int root) {
-    int count[16];
+GZ_HD uint32_t build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, uint32_t cap, int root, HdrScratch &scr) {
+    int *const count = scr.count;
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (int i = 0; i < n; ++i) count[lens[i]]++;
     count[0] = 0;
@@ -161,7 +171,7 @@ GZ_HD uint32_t build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, 
     const uint32_t nroot = 1u << root;
     for (uint32_t k = 0; k < nroot; ++k) tab[k] = 0;           // 0 = invalid code
     if (used == 0) return kErrNone;                             // e.g. a block without distance codes
-    uint32_t first[16], next[16];
+    uint32_t *const first = scr.first, *const next = scr.next;
     {
         uint32_t code = 0;
         first[0] = 0;
@@ -233,20 +243,20 @@ GZ_HD Tables tables_at(uint32_t *words) { return Tables{words, words + kLitTabCa
 // search demands of a candidate).  Returns kErrNone or the reason; the caller looks at overran() for "input ended".
 // build = false: only the checks (the search's strict parse of a candidate needs no literal / distance tables: building them is
 // most of the work -- ~300 candidates per chunk reach this point when no block starts in it)
-GZ_HD uint32_t read_dynamic(Bits &in, Tables &t, bool strict, bool build = true) {
+GZ_HD uint32_t read_dynamic(Bits &in, Tables &t, bool strict, bool build, HdrScratch &scr) {
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     refill(in);
     const int hlit = (int)take(in, 5) + 257, hdist = (int)take(in, 5) + 1, hclen = (int)take(in, 4) + 4;
     if (hlit > 286 || hdist > 30) return kErrCounts;
-    uint8_t pre[19];
+    uint8_t *const pre = scr.pre;
     for (int i = 0; i < 19; ++i) pre[i] = 0;
     for (int i = 0; i < hclen; ++i) {
         refill(in);
         pre[order[i]] = (uint8_t)take(in, 3);
     }
     if (strict && !complete(pre, 19, false)) return kErrPreCode;
-    if (uint32_t bad = build_table(pre, 19, 2, t.pre, kPreTabCap, 7)) return bad;
-    uint8_t lens[286 + 30 + 4];
+    if (uint32_t bad = build_table(pre, 19, 2, t.pre, kPreTabCap, 7, scr)) return bad;
+    uint8_t *const lens = scr.lens;
     int i = 0;
     const int total = hlit + hdist;
     while (i < total) {
@@ -274,19 +284,19 @@ GZ_HD uint32_t read_dynamic(Bits &in, Tables &t, bool strict, bool build = true)
     if (lens[256] == 0) return kErrNoEob;
     if (strict && (!complete(lens, hlit, true) || !complete(lens + hlit, hdist, true))) return kErrIncomplete;
     if (!build) return kErrNone;
-    if (uint32_t bad = build_table(lens, hlit, 0, t.lit, kLitTabCap, kLitRoot)) return bad;
-    if (uint32_t bad = build_table(lens + hlit, hdist, 1, t.dist, kDistTabCap, kDistRoot)) return bad;
+    if (uint32_t bad = build_table(lens, hlit, 0, t.lit, kLitTabCap, kLitRoot, scr)) return bad;
+    if (uint32_t bad = build_table(lens + hlit, hdist, 1, t.dist, kDistTabCap, kDistRoot, scr)) return bad;
     return kErrNone;
 }
-GZ_HD void fixed_tables(Tables &t) {
-    uint8_t l[288];
+GZ_HD void fixed_tables(Tables &t, HdrScratch &scr) {
+    uint8_t *const l = scr.lens;
     for (int i = 0; i < 144; ++i) l[i] = 8;
     for (int i = 144; i < 256; ++i) l[i] = 9;
     for (int i = 256; i < 280; ++i) l[i] = 7;
     for (int i = 280; i < 288; ++i) l[i] = 8;
-    (void)build_table(l, 288, 0, t.lit, kLitTabCap, kLitRoot);
+    (void)build_table(l, 288, 0, t.lit, kLitTabCap, kLitRoot, scr);
     for (int i = 0; i < 30; ++i) l[i] = 5;
-    (void)build_table(l, 30, 1, t.dist, kDistTabCap, kDistRoot);
+    (void)build_table(l, 30, 1, t.dist, kDistTabCap, kDistRoot, scr);
 }
 
 // Cheap test of bit position `bit` as the header of a non-final dynamic block: type bits, code counts, and a code-length code
@@ -365,10 +375,53 @@ GZ_HD uint32_t decode_huffman(Bits &in, const Tables &t, uint16_t *sym, uint32_t
     }
 }
 
+// ---- token-parallel decoding (k_gz_decode): what ONE LANE does with the 64 bits of the stream at its own bit offset ----------------
+// A token = one literal, one match (length code + extra bits + distance code + extra bits: at most 15 + 5 + 15 + 13 = 48 bits) or
+// the end-of-block code.  The wave parses a token at each of 64 consecutive bit offsets at once -- most of them are not token
+// starts -- and then walks the chain offset 0 -> 0 + its token's bits -> ... with one scalar read per token, instead of one
+// dependent table look-up per symbol.  info: bits 0-6 = the token's bits (1 .. 48), bits 7.. = kind (0 = a literal or a match
+// of at most 64 symbols: the chain walks on; others stop it).
+constexpr uint32_t kTokEob = 1, kTokLong = 2, kTokErrLit = 3, kTokErrDist = 4;
+struct Token {
+    uint32_t info;              // bits | kind << 7
+    uint32_t olen;              // symbols it stands for (literal 1, match 3 .. 258, end of block 0)
+    uint32_t val;               // the literal byte
+    uint32_t dist;              // match: distance (1 .. 32768), else 0
+};
+GZ_HD Token parse_token(uint64_t v, const uint32_t *lit, const uint32_t *dst) {
+    constexpr uint32_t LM = (1u << kLitRoot) - 1, DM = (1u << kDistRoot) - 1;
+    uint32_t e = lit[(uint32_t)v & LM], used = 0;
+    if (e & kSub) {
+        used = (uint32_t)kLitRoot;
+        e = lit[(e >> 16) + ((uint32_t)(v >> kLitRoot) & ((1u << ((e >> 8) & 31)) - 1))];
+    }
+    const uint32_t cl = e & 0xFF;
+    used += cl;
+    if (e & kLit) return Token{used, 1u, (e >> 16) & 0xFFu, 0u};
+    if (cl == 0) return Token{1u | (kTokErrLit << 7), 0u, 0u, 0u};
+    if (e & kEob) return Token{used | (kTokEob << 7), 0u, 0u, 0u};
+    const uint32_t leb = (e >> 8) & 31;
+    const uint32_t len = (e >> 16) + ((uint32_t)(v >> used) & ((1u << leb) - 1));
+    used += leb;
+    uint32_t d = dst[(uint32_t)(v >> used) & DM];
+    if (d & kSub) {
+        used += (uint32_t)kDistRoot;
+        d = dst[(d >> 16) + ((uint32_t)(v >> used) & ((1u << ((d >> 8) & 31)) - 1))];
+    }
+    const uint32_t dl = d & 0xFF;
+    if (dl == 0) return Token{1u | (kTokErrDist << 7), 0u, 0u, 0u};
+    used += dl;
+    const uint32_t deb = (d >> 8) & 31;
+    const uint32_t distance = (d >> 16) + ((uint32_t)(v >> used) & ((1u << deb) - 1));
+    used += deb;
+    return Token{used | (len > 64 ? kTokLong << 7 : 0u), len, 0u, distance};
+}
+
 // Blocks from job.start_bit on, until the first boundary >= job.stop_bit, a final block, or where room / input / validity end.
 // Everything is committed boundary by boundary.  w / nbits: the whole compressed buffer; tabs: this lane's kTabWords words.
 GZ_HD void decode_chunk(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32_t *tabs, uint16_t *sym) {
     Tables t = tables_at(tabs);
+    HdrScratch scr;
     const bool no_history = (job.flags & kJobNoHistory) != 0;
     uint64_t at = job.start_bit;
     uint32_t n = 0, status = kStFound, err = kErrNone;
@@ -408,8 +461,8 @@ GZ_HD void decode_chunk(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32
             err = kErrBlockType;
             break;
         } else {
-            if (type == 1) fixed_tables(t);
-            else bad = read_dynamic(in, t, false);
+            if (type == 1) fixed_tables(t, scr);
+            else bad = read_dynamic(in, t, false, true, scr);
             if (bad) {
                 if (overran(in)) status |= kStStarved;          // an "error" read out of the zero padding: the block is not all here
                 else { status |= kStError; err = bad; }
@@ -439,9 +492,10 @@ GZ_HD void decode_chunk(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32
 // pre: kPreTabCap words of scratch for the code-length code's table (LDS on the device: ~300 look-ups per parse)
 GZ_HD bool header_parses(const uint32_t *w, uint64_t nbits, uint64_t bit, uint32_t *pre) {
     Tables t{nullptr, nullptr, pre};
+    HdrScratch scr;
     Bits in{w, nbits, 0, 0, 0};
     seek(in, bit + 3);
-    return read_dynamic(in, t, true, false) == kErrNone && !overran(in);
+    return read_dynamic(in, t, true, false, scr) == kErrNone && !overran(in);
 }
 
 // ---- CRC-32 (IEEE, reflected) as polynomial arithmetic over GF(2), after zlib's crc32.c (x2nmodp / multmodp) -----------------

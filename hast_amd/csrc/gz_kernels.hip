@@ -4,8 +4,9 @@
 //   k_gz_search     a wave per chunk: 64 bit positions per step through the cheap header test (gz_core.h candidate), survivors
 //                   parsed in full by their own lane, lowest position first
 //   k_gz_decode     a WAVE per chunk: blocks -> 16-bit symbols (literal, or marker "byte i of the 32 KB in front of this chunk").
-//                   Serial by nature -- Huffman codes have no boundaries anyone wrote down -- so the parallelism is chunks (a
-//                   614-MB .fq.gz is 19 000 chunks of 32 KB) plus, inside a chunk, the lanes that copy a match together
+//                   Huffman codes have no boundaries anyone wrote down, so a token is parsed at each of 64 consecutive bit offsets
+//                   at once (a lane each) and the chain of real tokens is walked with one scalar read per token; the chain's
+//                   symbols are written by all lanes together
 //   k_gz_maps / k_gz_carry / k_gz_window   the 32 KB behind every accepted chunk (each depends on the one in front of it: maps
 //                   composed per group of 64 chunks in LDS, the groups chained by one workgroup, then everything at once)
 //   k_gz_crc        per chunk: CRC-32 of its bytes by 256 slices, combined with GF(2) operators (gz_core.h crc_*)
@@ -139,57 +140,65 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
 }
 
 // ---- decode: a WAVE per chunk -----------------------------------------------------------------------------------------------------
-// Huffman decoding is serial (no code boundary is known before the code in front of it is decoded), so one symbol at a time --
-// but by the whole wave in lockstep: every lane carries the same bit buffer and reads the same table entry (a broadcast read of
-// the tables in LDS, built per block by lane 0 with the code of gz_core.h; the bit buffer and everything derived from it live in
-// SGPRs), which keeps the control flow uniform, and the part that IS parallel runs on all lanes: the symbols of a block are gathered
-// as tokens (literals, matches) and written out 64 at a time, every lane one symbol -- out of a ring of the chunk's last 512
-// symbols in LDS when its source reaches back less than that, out of the symbol buffer otherwise (one global load for all far
-// symbols of a batch, past the L1, behind one wait for the stores in flight).  Output symbols: literal byte, or kMarker + i = "byte i
-// of the 32 KB in front of this chunk" for a copy that reaches in front of the chunk (gz_core.h).
-struct WBits {                     // wave-uniform bit input.  The next 64 words of the stream sit in a VGPR, one per lane (`win`,
-    const uint32_t *w;             // word wbase + lane), the 64 behind them in `nxt` (loaded when `win` is taken into use, a few hundred
-    uint64_t nwords;               // symbols before anyone needs them): a refill is a v_readlane, no memory access is on the
-    uint64_t bb;                   // path from one symbol to the next
-    uint64_t wp;                   // index of the next word to take
-    uint64_t wbase;                // index of win's lane 0
-    uint32_t bc, win, nxt;
+// Huffman codes have no boundaries anyone wrote down: where token i + 1 starts is known once token i is decoded.  Round 4's kernel
+// therefore decoded ONE symbol at a time, the whole wave in lockstep on a uniform bit buffer -- 80 instructions and two dependent LDS
+// round trips per token, 63 of 64 lanes idle except in copies (profiles/round4_gz_kernels_pmc.txt: 13 instructions per byte of
+// output).  This one decodes SPECULATIVELY AT EVERY BIT OFFSET: a step takes the 64 bit offsets pos .. pos + 63, lane i parses the
+// token that would start at pos + i (gz_core.h parse_token: literal / length look-up, extra bits, distance look-up, extra bits -- its
+// own 64 bits of the stream, the block's tables in LDS), and then the chain of REAL tokens is walked from offset 0 with one scalar
+// read per token (v_readlane of the token's bit count).  What the chain's tokens stand for is written out by all lanes together:
+// a prefix sum over the chain's tokens gives every token its place in the output, the tokens are handed to the lanes of their first
+// symbols through LDS, every lane finds the token it belongs to (the last start at or in front of it) and fetches its symbol -- a
+// literal, or a copy out of a ring of the chunk's last 512 symbols in LDS, out of the symbol buffer past the L1 (one global load for
+// all far symbols of a round, behind one wait for the stores in flight), or a marker kMarker + i = "byte i of the 32 KB in front of
+// this chunk" (gz_core.h).  A round holds at most 64 symbols; a match whose source reaches into its own round opens the next one;
+// matches longer than 64 symbols, the end-of-block code and invalid codes stop the chain and are dealt with on their own.  On FASTQ
+// a step yields 10 - 30 tokens (bases are 2-bit literals).  tests/native/test_gz_core.cpp -w runs the same steps with plain loops on
+// the CPU against zlib.
+struct WIn {                       // the compressed words around the read position: a ring of 128 words in LDS (s_in[word & 127]),
+    const uint32_t *w;             // always the 128 words from rb on (rb a multiple of 64, the position inside the first 64); the 64
+    uint64_t nwords;               // words behind them wait in a VGPR (nxt), loaded ~20 steps before they are put into the ring
+    uint64_t rb;
+    uint32_t nxt;
 };
-__device__ __forceinline__ uint32_t wload(const WBits &b, uint64_t i) { return i < b.nwords ? b.w[i] : 0u; }
-__device__ __forceinline__ uint32_t wword(WBits &b) {            // the word at wp
-    uint64_t idx = b.wp - b.wbase;
-    if (idx >= 64) {                                              // (uniform)
-        b.win = b.nxt;
-        b.wbase += 64;
-        b.nxt = wload(b, b.wbase + 64 + threadIdx.x);
-        idx -= 64;
-    }
-    return (uint32_t)__builtin_amdgcn_readlane((int)b.win, (int)idx);
-}
-__device__ __forceinline__ void wseek(WBits &b, uint64_t bit) {
-    const uint64_t wi = bit >> 5;
-    const uint32_t sh = (uint32_t)(bit & 31);
-    b.wbase = wi;
-    b.win = wload(b, wi + threadIdx.x);
-    b.nxt = wload(b, wi + 64 + threadIdx.x);
-    b.wp = wi;
-    b.bb = (uint64_t)wword(b) >> sh;
-    b.bc = 32 - sh;
-    b.wp = wi + 1;
-}
-__device__ __forceinline__ void wrefill(WBits &b) {
-    if (b.bc <= 32) {
-        b.bb |= (uint64_t)wword(b) << b.bc;
-        b.bc += 32;
-        b.wp++;
+__device__ __forceinline__ uint32_t wload(const WIn &b, uint64_t i) { return i < b.nwords ? b.w[i] : 0u; }
+__device__ __forceinline__ void win_at(WIn &b, uint32_t *s_in, uint64_t pos) {      // (uniform) the ring covers `pos` and the 4 words behind it
+    const uint64_t wi = pos >> 5;
+    const uint32_t lane = threadIdx.x;
+    if (wi < b.rb || wi >= b.rb + 128) {
+        b.rb = wi & ~63ull;
+        __builtin_amdgcn_wave_barrier();
+        s_in[(uint32_t)(b.rb + lane) & 127] = wload(b, b.rb + lane);
+        s_in[(uint32_t)(b.rb + 64 + lane) & 127] = wload(b, b.rb + 64 + lane);
+        b.nxt = wload(b, b.rb + 128 + lane);
+        __builtin_amdgcn_wave_barrier();
+    } else if (wi >= b.rb + 64) {
+        __builtin_amdgcn_wave_barrier();
+        s_in[(uint32_t)(b.rb + lane) & 127] = b.nxt;                          // (the words rb + 128 .. rb + 191 take the place of rb .. rb + 63)
+        b.rb += 64;
+        b.nxt = wload(b, b.rb + 128 + lane);
+        __builtin_amdgcn_wave_barrier();
     }
 }
-__device__ __forceinline__ uint64_t wpos(const WBits &b) { return b.wp * 32 - b.bc; }
+__device__ __forceinline__ uint64_t win_bits(const WIn &b, const uint32_t *s_in, uint64_t pos) {      // the 64 bits at pos + lane
+    const uint32_t rel = (uint32_t)(pos - b.rb * 32) + threadIdx.x, wi = (uint32_t)b.rb + (rel >> 5), sh = rel & 31;
+    const uint32_t w0 = s_in[wi & 127], w1 = s_in[(wi + 1) & 127], w2 = s_in[(wi + 2) & 127];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ void sym_store(uint16_t *p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ uint16_t sym_load_far(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (past the L1)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {              // inclusive prefix sum over the 64 lanes (DPP: rows, then row 15 -> next row, then 31 -> upper half)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
 
-// 4 waves per SIMD (128 VGPRs; the compiler took 180 = 2 waves per SIMD = 8 chunks per CU, and a chunk's time is latency -- far match
-// copies out of the symbol buffer, ~20 ms whatever else runs -- so chunks in flight are throughput): 14 per CU, the LDS's limit.
+// 4 waves per SIMD (128 VGPRs): a chunk's time is latency, so chunks in flight are throughput; 16 per CU (9 KB of LDS each).
 // syms: the base of the symbol memory the jobs' buffers lie in (job.sym_off is an absolute address / 2: the buffer is reached as
 // syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
 // which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
@@ -197,10 +206,11 @@ __device__ __forceinline__ uint16_t sym_load_far(const uint16_t *p) { return __h
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
     __shared__ uint32_t s_tab[kTabWords];
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
+    __shared__ HdrScratch s_scr;                                              // ... and what it indexes by values it has just read (no scratch memory)
+    __shared__ uint32_t s_in[128];                                            // compressed words around the read position (WIn)
+    __shared__ uint32_t s_tok[64];                                            // a round's tokens, each at the lane of its first symbol
     // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the few records in front) is
     // copied out of LDS -- a global load per match would put ~1 us of latency on the path of every symbol behind it
-    // (512 symbols: with the batched copies a far source costs little, and 8.3 KB of LDS a wave instead of 11.3 is 16 waves per CU
-    // instead of 14 -- read phase -3.5 % in an A/B on one box, profiles/round4_ab_gz_ring512.txt)
     constexpr uint32_t kRing = 512, kRingReach = kRing - 320;
     __shared__ uint16_t s_ring[kRing];
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
@@ -217,8 +227,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const uint32_t cap = job.sym_cap;
     const bool no_history = (job.flags & kJobNoHistory) != 0;
     const uint32_t *const lit = s_tab, *const dst = s_tab + kLitTabCap;
-    constexpr uint32_t LM = (1u << kLitRoot) - 1, DM = (1u << kDistRoot) - 1;
-    WBits in{w, ((nbits + 31) >> 5) + 2, 0, 0, 0, 0, 0, 0};
+    WIn in{w, ((nbits + 31) >> 5) + 2, ~0ull >> 1, 0};                       // (rb far away: the first win_at loads the ring)
     uint64_t at = job.start_bit;
     uint32_t n = 0, status = kStFound, err = kErrNone;
     bool any = false;
@@ -234,14 +243,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if (!hidden) { status |= kStStop; break; }
         }
         if (at + 3 > nbits) { status |= kStStarved; break; }
-        wseek(in, at);
-        wrefill(in);
-        const uint32_t final = (uint32_t)(in.bb & 1), type = (uint32_t)((in.bb >> 1) & 3);
-        in.bb >>= 3;
-        in.bc -= 3;
+        const uint32_t hdr3 = (uint32_t)(bits_at(w, at) & 7);
+        const uint32_t final = hdr3 & 1, type = hdr3 >> 1;
         uint32_t n2 = n, rc = 0;
         if (type == 0) {
-            const uint64_t byte = (wpos(in) + 7) >> 3;
+            const uint64_t byte = (at + 3 + 7) >> 3;
             if ((byte + 4) * 8 > nbits) { status |= kStStarved; break; }
             const uint8_t *bytes = reinterpret_cast<const uint8_t *>(w) + byte;
             const uint32_t len = bytes[0] | ((uint32_t)bytes[1] << 8), nlen = bytes[2] | ((uint32_t)bytes[3] << 8);
@@ -269,14 +275,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if (lane == 0) {
                 Tables t = tables_at(s_tab);
                 uint32_t bad = 0;
-                uint64_t behind = wpos(in);
-                if (type == 1) fixed_tables(t);
+                uint64_t behind = at + 3;
+                if (type == 1) fixed_tables(t, s_scr);
                 else {
                     Bits hb{w, nbits, 0, 0, 0};
                     seek(hb, behind);
-                    bad = read_dynamic(hb, t, false);
-                    if (bad && overran(hb)) bad = 0x80000000u;                // an "error" read out of the padding: the block is not all here
-                    if (!bad && overran(hb)) bad = 0x80000000u;
+                    bad = read_dynamic(hb, t, false, true, s_scr);
+                    if (overran(hb)) bad = 0x80000000u;                       // (also an "error" read out of the padding: the block is not all here)
                     behind = pos(hb);
                 }
                 s_hdr[0] = bad;
@@ -290,163 +295,139 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 else { status |= kStError; err = bad; }
                 break;
             }
-            wseek(in, (uint64_t)s_hdr[1] | ((uint64_t)s_hdr[2] << 32));
-            // ---- TWO literals per look-up where both codes fit the 9 root bits: bit 8 of a literal's entry says "a second literal in
-            // bits 24..31", the length is that of both codes.  The bases of a FASTQ record are literals of ~2.2 bits each (half of a file's
-            // bytes), quality values mostly fit in pairs too: a look-up -- the LDS round trip every symbol waits for -- then yields two
-            // symbols.  All 64 lanes, 8 root entries each: every entry is read (with the entry of the bits behind its code) before any is
-            // written (LDS operations of a wave execute in order).
-            {
-                uint32_t pe[(1u << kLitRoot) / 64];
-#pragma unroll
-                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) {
-                    const uint32_t idx = q * 64 + lane, e1 = lit[idx], l1 = e1 & 0xFF;
-                    uint32_t ne = e1;
-                    if ((e1 & (kLit | kSub)) == kLit && l1 > 0 && l1 < (uint32_t)kLitRoot) {
-                        const uint32_t e2 = lit[idx >> l1], l2 = e2 & 0xFF;     // (the bits behind the first code, zeros above them: an
-                        // entry whose code is no longer than the bits that are really there does not depend on those zeros)
-                        if ((e2 & (kLit | kSub)) == kLit && l2 > 0 && l1 + l2 <= (uint32_t)kLitRoot)
-                            ne = kLit | (1u << 8) | (l1 + l2) | (e1 & 0x00FF0000u) | ((e2 & 0x00FF0000u) << 8);
+            uint64_t pos = (uint64_t)s_hdr[1] | ((uint64_t)s_hdr[2] << 32);
+            // ---- the block's symbols, a step = the 64 bit offsets from pos on ----
+            bool block_done = false;
+            while (!block_done && !rc) {
+                if (pos >= nbits) { rc = kStStarved; break; }
+                const uint64_t avail = nbits - pos;
+                const uint32_t limit = avail < 64 ? (uint32_t)avail : 64u;
+                win_at(in, s_in, pos);
+                const Token tk = parse_token(win_bits(in, s_in, pos), lit, dst);
+                const uint32_t need = tk.dist ? (tk.dist > tk.olen ? tk.dist - tk.olen : 0u) : 0xFFFFu;      // symbols of the round that may stand in front of it
+                uint32_t p = 0;
+                for (;;) {                                                    // the chain, from one stop to the next
+                    uint64_t tokmask = 0;
+                    uint32_t stop = 0;
+                    while (p < limit) {
+                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tk.info, (int)p);
+                        if (t >= 128) { stop = t; break; }
+                        tokmask |= 1ull << p;
+                        p += t;
                     }
-                    pe[q] = ne;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) s_tab[q * 64 + lane] = pe[q];
-                __syncthreads();
-            }
-            // ---- the block's symbols ----
-            // Symbols are decoded into a BATCH of tokens (literal(s), or match: length, distance) and written out 64 at a time: token i
-            // sits in lane i of two VGPRs, a 64-bit mask marks where in the batch each token starts, and a flush gives
-            // every lane ONE symbol of the batch -- its token by a bit count below it in the mask, its source in the ring, in the symbol
-            // buffer (a far match: one global load for all far symbols of the batch, behind ONE wait for the stores in flight) or in front
-            // of the chunk (a marker).  A match whose source reaches into the batch itself (a run, a copy of the symbols just decoded)
-            // closes the batch first.  Before: every match waited for its own copy -- random DNA is coded as short matches at random
-            // distances in the 32-KB window, ~12 000 a chunk, each a round trip to HBM (the symbol buffers of the chunks in flight are
-            // GBs: no cache holds them) -- and every literal was a global store of its own.
-            uint32_t tokA = 0, tokB = 0;                 // lane i: token i = offset | length << 6 | distance << 16 (0: literals), literal bytes
-            uint32_t nb_tok = 0, nb_sym = 0;             // (wave-uniform)
-            uint64_t smask = 0;
-            uint32_t bstart = n2;                        // position of the batch's first symbol
-            auto flush = [&]() {
-                if (!nb_sym) return;
-                const bool act = lane < nb_sym;
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u));
-                const uint32_t ti = act ? below + (uint32_t)((smask >> lane) & 1) - 1 : 0u;      // (bit 0 is set: the first token starts the batch)
-                const uint32_t A = (uint32_t)__shfl((int)tokA, (int)ti, 64), B = (uint32_t)__shfl((int)tokB, (int)ti, 64);
-                const uint32_t off = A & 63, dist = A >> 16, k = lane - off;
-                const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;                  // positions the ring still holds while this batch is written
-                int64_t src = 0;
-                if (dist) src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)(k < dist ? k : k % dist);
-                const bool far = act && dist && src >= 0 && src < ring_lo;
-                // a copy out of the symbol buffer itself reads what this wave stored a while ago: the stores must have reached the L2
-                // (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache maintenance:
-                // an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the GPU 10 x slower
-                if (__ballot(far)) __builtin_amdgcn_s_waitcnt(0);
-                uint16_t v = 0;
-                if (act) {
-                    if (!dist) v = (uint16_t)((B >> (8 * k)) & 0xFF);
-                    else if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
-                    else if (far) v = sym_load_far(sym + src);
-                    else v = s_ring[(uint32_t)src & (kRing - 1)];
-                }
-                // (every lane has read before any lane writes: LDS operations of a wave execute in order)
-                if (act) {
-                    s_ring[(bstart + lane) & (kRing - 1)] = v;
-                    sym_store(sym + bstart + lane, v);
-                }
-                bstart += nb_sym;
-                nb_tok = nb_sym = 0;
-                smask = 0;
-            };
-            for (;;) {
-                if (n2 + 260 > cap) { rc = kStNoRoom; break; }
-                if (in.bc <= 32) {
-                    // (the end of the input is looked for when a word is taken, not per symbol: the buffer is padded with zeros, and the
-                    // block's end checks once more)
-                    if (wpos(in) > nbits) { rc = kStStarved; break; }
-                    wrefill(in);
-                }
-                // (every lane reads the same entry: it is a wave-uniform value, and saying so keeps the tests on it scalar)
-                uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit[in.bb & LM]);
-                if (e & kSub) {
-                    in.bb >>= kLitRoot;
-                    in.bc -= kLitRoot;
-                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lit[(e >> 16) + (uint32_t)(in.bb & ((1u << ((e >> 8) & 31)) - 1))]);
-                }
-                in.bb >>= (e & 0xFF);
-                in.bc -= (e & 0xFF);
-                if (e & kLit) {
-                    const uint32_t cnt = 1 + ((e >> 8) & 1);                          // a second literal rides along
-                    if (nb_sym + cnt > 64) flush();                                   // (a token holds at least one symbol: never more than 64 tokens)
-                    tokA = lane == nb_tok ? (nb_sym | (cnt << 6)) : tokA;
-                    tokB = lane == nb_tok ? (e >> 16) : tokB;
-                    smask |= 1ull << nb_sym;
-                    ++nb_tok;
-                    nb_sym += cnt;
-                    n2 += cnt;
-                    continue;
-                }
-                if ((e & 0xFF) == 0) { err = kErrLitCode; rc = kStError; break; }
-                if (e & kEob) break;
-                const uint32_t leb = (e >> 8) & 31;
-                const uint32_t len = (e >> 16) + (uint32_t)(in.bb & ((1u << leb) - 1));
-                in.bb >>= leb;
-                in.bc -= leb;
-                wrefill(in);
-                uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst[in.bb & DM]);
-                if (d & kSub) {
-                    in.bb >>= kDistRoot;
-                    in.bc -= kDistRoot;
-                    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst[(d >> 16) + (uint32_t)(in.bb & ((1u << ((d >> 8) & 31)) - 1))]);
-                }
-                if ((d & 0xFF) == 0) { err = kErrDistCode; rc = kStError; break; }
-                in.bb >>= (d & 0xFF);
-                in.bc -= (d & 0xFF);
-                const uint32_t deb = (d >> 8) & 31;
-                const uint32_t distance = (d >> 16) + (uint32_t)(in.bb & ((1u << deb) - 1));
-                in.bb >>= deb;
-                in.bc -= deb;
-                if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; rc = kStError; break; }
-                if (len <= 64) {
-                    // its source must lie in front of the batch (what the batch holds is not written yet)
-                    const int64_t src_end = (int64_t)n2 - (int64_t)distance + (int64_t)(len < distance ? len : distance);
-                    if (src_end > (int64_t)bstart || nb_sym + len > 64) flush();
-                    tokA = lane == nb_tok ? (nb_sym | (len << 6) | (distance << 16)) : tokA;
-                    smask |= 1ull << nb_sym;
-                    ++nb_tok;
-                    nb_sym += len;
+                    if (!stop && p > avail) { rc = kStStarved; break; }       // the last token reads past the input that is there
+                    if (tokmask) {
+                        const bool is_tok = (tokmask >> lane) & 1;
+                        const uint32_t incl = wave_incl_scan(is_tok ? tk.olen : 0u), start = incl - (is_tok ? tk.olen : 0u);
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        if (__ballot(is_tok && tk.dist > n2 + start && (no_history || tk.dist > kWindow))) { err = kErrTooFar; rc = kStError; break; }
+                        const uint32_t tokval = (tk.dist << 14) | ((tk.dist ? tk.olen : tk.val) << 6);     // + its first symbol's place in the round
+                        uint32_t base = 0;
+                        uint64_t rem = tokmask;
+                        while (rem) {
+                            const bool in_rem = (rem >> lane) & 1;
+                            const unsigned long long vm = __ballot(in_rem && (incl - base > 64 || need < start - base));
+                            uint64_t cur = rem;
+                            uint32_t nsym = total - base;
+                            if (vm) {
+                                const uint32_t fv = (uint32_t)__builtin_ctzll(vm);
+                                cur = rem & ((1ull << fv) - 1);
+                                nsym = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)fv) - base;
+                            }
+                            if (n2 + nsym > cap) { rc = kStNoRoom; break; }
+                            // every token to the lane of its first symbol; a lane's token is the last one that starts at or in front of it
+                            __builtin_amdgcn_wave_barrier();
+                            s_tok[lane] = 0;
+                            if ((cur >> lane) & 1) s_tok[start - base] = tokval | (start - base) | 0x80000000u;
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t mine = s_tok[lane];
+                            const unsigned long long smask = __ballot(mine != 0);
+                            const unsigned long long upto = smask & (~0ull >> (63 - lane));              // (bit 0 is set: a token starts the round)
+                            const uint32_t leader = 63u - (uint32_t)__builtin_clzll(upto | 1ull);
+                            const uint32_t tv = (uint32_t)__shfl((int)mine, (int)leader, 64);
+                            const bool act = lane < nsym;
+                            const uint32_t off = tv & 63, val = (tv >> 6) & 0xFF, dist = (tv >> 14) & 0xFFFF, k = lane - off;
+                            const uint32_t bstart = n2;
+                            const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;                  // positions the ring still holds while this round is written
+                            int64_t src = 0;
+                            if (dist) {
+                                uint32_t kk = k;
+                                if (k >= dist) {                               // a run: symbol k repeats symbol k mod dist (k < 64: exact in float)
+                                    const uint32_t q = (uint32_t)(((float)k + 0.5f) * __frcp_rn((float)dist));
+                                    kk = k - q * dist;
+                                }
+                                src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)kk;
+                            }
+                            const bool far = act && dist && src >= 0 && src < ring_lo;
+                            // a copy out of the symbol buffer itself reads what this wave stored a while ago: the stores must have reached the L2
+                            // (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache maintenance:
+                            // an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the GPU 10 x slower
+                            if (__ballot(far)) __builtin_amdgcn_s_waitcnt(0);
+                            uint16_t v = 0;
+                            if (act) {
+                                if (!dist) v = (uint16_t)val;
+                                else if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
+                                else if (far) v = sym_load_far(sym + src);
+                                else v = s_ring[(uint32_t)src & (kRing - 1)];
+                            }
+                            // (every lane has read before any lane writes: LDS operations of a wave execute in order)
+                            __builtin_amdgcn_wave_barrier();
+                            if (act) {
+                                s_ring[(bstart + lane) & (kRing - 1)] = v;
+                                sym_store(sym + bstart + lane, v);
+                            }
+                            base += nsym;
+                            n2 += nsym;
+                            rem &= ~cur;
+                        }
+                        if (rc) break;
+                    }
+                    if (!stop) break;
+                    const uint32_t kind = stop >> 7, tl = stop & 127;
+                    if (kind == kTokErrLit || kind == kTokErrDist) {
+                        if (p + 48 > avail) rc = kStStarved;                  // (read out of what is not there yet)
+                        else { err = kind == kTokErrLit ? kErrLitCode : kErrDistCode; rc = kStError; }
+                        break;
+                    }
+                    if (p + tl > avail) { rc = kStStarved; break; }
+                    if (kind == kTokEob) {
+                        pos += p + tl;
+                        block_done = true;
+                        break;
+                    }
+                    // a long match, on its own: symbol n2 + k comes from n2 + k - distance, or -- periodic -- from the first `distance` of
+                    // them; what lies in front of the chunk is a marker.  64 symbols per step: the lanes of a step read before any of them
+                    // writes, and a later step reads what the earlier ones wrote.
+                    const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)tk.olen, (int)p), distance = (uint32_t)__builtin_amdgcn_readlane((int)tk.dist, (int)p);
+                    if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; rc = kStError; break; }
+                    if (n2 + len > cap) { rc = kStNoRoom; break; }
+                    const bool near = distance <= kRingReach;
+                    if (!near) __builtin_amdgcn_s_waitcnt(0);
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        uint16_t v = 0;
+                        if (k < len) {
+                            const uint32_t kk = k < distance ? k : k % distance;
+                            const int64_t src = (int64_t)n2 - (int64_t)distance + (int64_t)kk;
+                            v = src < 0 ? (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src))
+                                        : near ? s_ring[(uint32_t)src & (kRing - 1)] : sym_load_far(sym + src);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (k < len) {
+                            s_ring[(n2 + k) & (kRing - 1)] = v;
+                            sym_store(sym + n2 + k, v);
+                        }
+                    }
                     n2 += len;
-                    continue;
+                    p += tl;
                 }
-                // a long match, on its own: symbol n2 + k comes from n2 + k - distance, or -- periodic -- from the first `distance` of
-                // them; what lies in front of the chunk is a marker.  64 symbols per step: the lanes of a step read before any of them
-                // writes, and a later step reads what the earlier ones wrote.
-                flush();
-                const bool near = distance <= kRingReach;
-                if (!near) __builtin_amdgcn_s_waitcnt(0);
-                for (uint32_t k0 = 0; k0 < len; k0 += 64) {
-                    const uint32_t k = k0 + lane;
-                    if (k < len) {
-                        const uint32_t kk = k < distance ? k : k % distance;
-                        const int64_t src = (int64_t)n2 - (int64_t)distance + (int64_t)kk;
-                        const uint16_t v = src < 0 ? (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src))
-                                                   : near ? s_ring[(uint32_t)src & (kRing - 1)] : sym_load_far(sym + src);
-                        s_ring[(n2 + k) & (kRing - 1)] = v;
-                        sym_store(sym + n2 + k, v);
-                    }
-                }
-                n2 += len;
-                bstart = n2;
+                if (!block_done && !rc) pos += p;
             }
-            if (!rc) flush();
             if (rc) {
                 status |= rc;
                 break;
             }
-            if (wpos(in) > nbits) { status |= kStStarved; break; }
-            at = wpos(in);
+            at = pos;
         }
         n = n2;
         any = true;

@@ -3,7 +3,8 @@
 // gz_kernels.hip -- search + decode per chunk, windows chunk after chunk, marker translation, CRC-32 by slices combined with
 // the GF(2) operators.  Decodes the file on the command line and writes the inflated bytes to stdout; exit 3 + message on a
 // decoding error.  -c compressed bytes per chunk, -s chunks per segment (candidates reach the chain segment by segment, the
-// "input on the device" grows with them), -r symbols of room per compressed byte of a chunk.
+// "input on the device" grows with them), -r symbols of room per compressed byte of a chunk, -w Huffman blocks decoded the way
+// k_gz_decode's wave does it (a token parsed at each of 64 bit offsets, the chain walked, rounds of at most 64 symbols).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +18,190 @@ using namespace hast::gz;
 
 static std::vector<uint32_t> g_words;       // the file, zero padded
 static uint64_t g_size = 0;
+
+static bool g_wave = false;      // -w: Huffman blocks decoded the way k_gz_decode does it (64 token parses per step, chain, rounds)
+
+// ---- the symbol loop of k_gz_decode (gz_kernels.hip), lane by lane: every lane parses a token at its own bit offset (parse_token),
+// the chain of real tokens is walked from offset 0, the chain's tokens are written out in rounds of at most 64 symbols (a token
+// whose source reaches into its own round waits for the next one), sources come out of a ring of the last 512 symbols, out of the
+// symbol buffer, or are markers.  Same arithmetic as the kernel, plain loops instead of lanes; the ring is modelled so that its
+// reach rule is checked (what the kernel would read there must be what the symbol buffer holds).
+static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &pos, const uint32_t *lit, const uint32_t *dst, uint16_t *sym,
+                                  uint32_t &n_out, uint32_t cap, bool no_history, uint32_t &err, uint16_t *ring) {
+    constexpr uint32_t kRing = 512, kRingReach = kRing - 320;
+    uint32_t n2 = n_out;
+    auto ring_at = [&](int64_t src) {
+        const uint16_t v = ring[(uint32_t)src & (kRing - 1)];
+        if (v != sym[src]) { fprintf(stderr, "ring reach rule broken at %lld\n", (long long)src); abort(); }
+        return v;
+    };
+    for (;;) {
+        if (pos >= nbits) return kStStarved;
+        const uint64_t avail = nbits - pos;
+        const uint32_t limit = avail < 64 ? (uint32_t)avail : 64u;
+        Token tk[64];
+        for (uint32_t lane = 0; lane < 64; ++lane) tk[lane] = parse_token(bits_at(w, pos + lane), lit, dst);
+        uint32_t p = 0;
+        for (;;) {
+            uint64_t tokmask = 0;
+            uint32_t stop = 0;
+            while (p < limit) {
+                const uint32_t t = tk[p].info;
+                if (t >= 128) { stop = t; break; }
+                tokmask |= 1ull << p;
+                p += t;
+            }
+            if (!stop && p > avail) return kStStarved;               // the last token reads past the input that is there
+            // where in the output every token of the chain starts
+            uint32_t start[64], incl[64], total = 0;
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                start[lane] = total;
+                if ((tokmask >> lane) & 1) total += tk[lane].olen;
+                incl[lane] = total;
+            }
+            for (uint32_t lane = 0; lane < 64; ++lane)
+                if (((tokmask >> lane) & 1) && tk[lane].dist && tk[lane].dist > n2 + start[lane] && (no_history || tk[lane].dist > kWindow)) { err = kErrTooFar; return kStError; }
+            uint32_t base = 0;
+            uint64_t rem = tokmask;
+            while (rem) {
+                uint32_t first_viol = 64;
+                for (uint32_t lane = 0; lane < 64 && first_viol == 64; ++lane) {
+                    if (!((rem >> lane) & 1)) continue;
+                    const uint32_t need = tk[lane].dist ? (tk[lane].dist > tk[lane].olen ? tk[lane].dist - tk[lane].olen : 0u) : 0xFFFFu;
+                    if (incl[lane] - base > 64 || need < start[lane] - base) first_viol = lane;
+                }
+                const uint64_t cur = first_viol < 64 ? rem & ((1ull << first_viol) - 1) : rem;
+                const uint32_t nsym = (first_viol < 64 ? start[first_viol] : total) - base;
+                if (!cur || !nsym || nsym > 64) { fprintf(stderr, "round logic broken\n"); abort(); }
+                if (n2 + nsym > cap) return kStNoRoom;
+                const uint32_t bstart = n2;
+                const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;
+                uint16_t outv[64];
+                for (uint32_t j = 0; j < nsym; ++j) {
+                    uint32_t L = 64;
+                    for (uint32_t lane = 0; lane < 64; ++lane)
+                        if (((cur >> lane) & 1) && start[lane] - base <= j) L = lane;      // the last token that starts at or in front of j
+                    const uint32_t off = start[L] - base, k = j - off, dist = tk[L].dist;
+                    if (k >= tk[L].olen) { fprintf(stderr, "leader logic broken\n"); abort(); }
+                    uint16_t v;
+                    if (!dist) v = (uint16_t)tk[L].val;
+                    else {
+                        const int64_t src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)(k < dist ? k : k % dist);
+                        if (src >= (int64_t)bstart) { fprintf(stderr, "source inside its own round\n"); abort(); }
+                        if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
+                        else if (src < ring_lo) v = sym[src];
+                        else v = ring_at(src);
+                    }
+                    outv[j] = v;
+                }
+                for (uint32_t j = 0; j < nsym; ++j) {
+                    ring[(bstart + j) & (kRing - 1)] = outv[j];
+                    sym[bstart + j] = outv[j];
+                }
+                base += nsym;
+                n2 += nsym;
+                rem &= ~cur;
+            }
+            if (!stop) break;
+            const uint32_t kind = stop >> 7, tl = stop & 127;
+            if (kind == kTokErrLit || kind == kTokErrDist) {
+                if (p + 48 > avail) return kStStarved;               // (read out of what is not there yet)
+                err = kind == kTokErrLit ? kErrLitCode : kErrDistCode;
+                return kStError;
+            }
+            if (p + tl > avail) return kStStarved;
+            if (kind == kTokEob) {
+                pos += p + tl;
+                n_out = n2;
+                return 0;
+            }
+            // a long match, on its own, 64 symbols a step
+            const uint32_t len = tk[p].olen, distance = tk[p].dist;
+            if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; return kStError; }
+            if (n2 + len > cap) return kStNoRoom;
+            const bool near = distance <= kRingReach;
+            for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                uint16_t outv[64];
+                for (uint32_t lane = 0; lane < 64 && k0 + lane < len; ++lane) {
+                    const uint32_t k = k0 + lane, kk = k < distance ? k : k % distance;
+                    const int64_t src = (int64_t)n2 - (int64_t)distance + (int64_t)kk;
+                    outv[lane] = src < 0 ? (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src)) : near ? ring_at(src) : sym[src];
+                }
+                for (uint32_t lane = 0; lane < 64 && k0 + lane < len; ++lane) {
+                    ring[(n2 + k0 + lane) & (kRing - 1)] = outv[lane];
+                    sym[n2 + k0 + lane] = outv[lane];
+                }
+            }
+            n2 += len;
+            p += tl;
+        }
+        pos += p;
+    }
+}
+
+// decode_chunk (gz_core.h) with its Huffman blocks decoded by decode_block_wave
+static void decode_chunk_wave(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32_t *tabs, uint16_t *sym) {
+    Tables t = tables_at(tabs);
+    HdrScratch scr;
+    static uint16_t ring[512];
+    const bool no_history = (job.flags & kJobNoHistory) != 0;
+    uint64_t at = job.start_bit;
+    uint32_t n = 0, status = kStFound, err = kErrNone;
+    bool any = false;
+    for (;;) {
+        if (at >= job.stop_bit && (any || !(job.flags & kJobKnown))) {
+            bool hidden = false;
+            if (any && at + 3 <= nbits) hidden = (bits_at(w, at) & 7) != 4;
+            if (!hidden) { status |= kStStop; break; }
+        }
+        if (at + 3 > nbits) { status |= kStStarved; break; }
+        Bits in{w, nbits, 0, 0, 0};
+        seek(in, at);
+        refill(in);
+        const uint32_t final = take(in, 1), type = take(in, 2);
+        uint32_t n2 = n, bad = 0;
+        if (type == 0) {
+            const uint64_t byte = (pos(in) + 7) >> 3;
+            if ((byte + 4) * 8 > nbits) { status |= kStStarved; break; }
+            const uint8_t *bytes = reinterpret_cast<const uint8_t *>(w) + byte;
+            const uint32_t len = bytes[0] | ((uint32_t)bytes[1] << 8), nlen = bytes[2] | ((uint32_t)bytes[3] << 8);
+            if ((len ^ 0xFFFFu) != nlen) { status |= kStError; err = kErrStoredLen; break; }
+            if ((byte + 4 + len) * 8 > nbits) { status |= kStStarved; break; }
+            if (n + len + 4 > job.sym_cap) { status |= kStNoRoom; break; }
+            for (uint32_t k = 0; k < len; ++k) {
+                sym[n + k] = bytes[4 + k];
+                ring[(n + k) & 511] = bytes[4 + k];
+            }
+            n2 = n + len;
+            at = (byte + 4 + len) * 8;
+        } else if (type == 3) {
+            status |= kStError;
+            err = kErrBlockType;
+            break;
+        } else {
+            if (type == 1) fixed_tables(t, scr);
+            else bad = read_dynamic(in, t, false, true, scr);
+            if (bad) {
+                if (overran(in)) status |= kStStarved;
+                else { status |= kStError; err = bad; }
+                break;
+            }
+            if (overran(in)) { status |= kStStarved; break; }
+            uint64_t p = pos(in);
+            const uint32_t rc = decode_block_wave(w, nbits, p, t.lit, t.dist, sym, n2, job.sym_cap, no_history, err, ring);
+            if (rc) { status |= rc; break; }
+            at = p;
+        }
+        n = n2;
+        any = true;
+        if (final) { status |= kStFinal; break; }
+    }
+    if (!any) status |= kStNoBlock;
+    job.end_bit = at;
+    job.n_out = n;
+    job.status = status;
+    job.err_code = (status & kStError) ? err : kErrNone;
+}
 
 static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std::vector<uint32_t> &tabs) {
     sym.assign((size_t)j.sym_cap + 8, 0);
@@ -39,7 +224,8 @@ static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std
             return;
         }
     }
-    decode_chunk(j, g_words.data(), nbits, tabs.data(), sym.data());
+    if (g_wave) decode_chunk_wave(j, g_words.data(), nbits, tabs.data(), sym.data());
+    else decode_chunk(j, g_words.data(), nbits, tabs.data(), sym.data());
 }
 
 int main(int argc, char **argv) {
@@ -50,6 +236,7 @@ int main(int argc, char **argv) {
         if (!strcmp(argv[i], "-c")) chunk = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-s")) seg = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-r")) room = atof(argv[++i]);
+        else if (!strcmp(argv[i], "-w")) g_wave = true;
         else path = argv[i];
     }
     FILE *f = fopen(path, "rb");

@@ -18,11 +18,28 @@ from tests.test_inflate_cpu import CASES, FQ, fastq, member
 
 
 @pytest.fixture(scope="module")
-def driver(tmp_path_factory):
+def driver_exe(tmp_path_factory):
     exe = tmp_path_factory.mktemp("gzcore") / "test_gz_core"
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
                     os.path.join(ROOT, "tests", "native", "test_gz_core.cpp")], check=True)
     return str(exe)
+
+
+class _Driver(str):
+    """the driver's path; subprocess.run([driver, ...]) below starts it with this decoder's flag in front of the other arguments"""
+    flag = None
+
+
+@pytest.fixture(params=["lane", "wave"])
+def driver(driver_exe, request, tmp_path):
+    """lane: gz_core.h's decode_chunk (a lane per chunk, one symbol at a time); wave: the symbol loop of k_gz_decode restated with plain
+    loops (-w: a token parsed at each of 64 bit offsets, the chain walked, rounds of at most 64 symbols, the ring of recent symbols)"""
+    if request.param == "lane":
+        return driver_exe
+    sh = tmp_path / "driver_wave.sh"
+    sh.write_text('#!/bin/sh\nexec "%s" -w "$@"\n' % driver_exe)
+    sh.chmod(0o755)
+    return str(sh)
 
 
 def inflate_all(blob):
