@@ -94,6 +94,7 @@ ABI_SYMBOLS = {
     "hast_fq_create": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(vp)]),
     "hast_fq_create_ex": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.c_int, C.POINTER(vp)]),
     "hast_fq_create_striped": (C.c_int, [C.POINTER(vp), C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(vp)]),
+    "hast_fq_create_striped_ex": (C.c_int, [C.POINTER(vp), C.c_int, C.c_size_t, C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp)]),
     "hast_fq_lanes": (C.c_int, [vp]),
     "hast_fq_lane_records": (C.c_uint64, [vp, C.c_int]),
     "hast_fq_destroy": (None, [vp]),
@@ -108,6 +109,9 @@ ABI_SYMBOLS = {
     "hast_fq_commit": (C.c_int, [vp]),
     "hast_gz_open": (C.c_int, [vp, C.c_char_p, C.POINTER(vp)]),
     "hast_gz_open_ex": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(vp)]),
+    "hast_gz_open_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(vp)]),
+    "hast_gz_open_multi_ex": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(vp)]),
+    "hast_gz_units": (C.c_int, [vp]),
     "hast_gz_read_device": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]),
     "hast_gz_get_stats": (C.c_int, [vp, C.POINTER(GzStats)]),
     "hast_gz_close": (None, [vp]),
@@ -491,11 +495,16 @@ class GzReader:
     """hast_gz: one .gz file inflated on the GPU (include/hast.h); read() returns the next bytes as a numpy array (test view:
     the product hands the bytes to the FASTQ framer on the device)."""
 
-    def __init__(self, ctx, path, chunk_bytes=0, chunks_per_pass=0, room=0.0):
+    def __init__(self, ctx, path, chunk_bytes=0, chunks_per_pass=0, room=0.0, ctxs=None):
+        """ctxs: several contexts -> hast_gz_open_multi_ex (the passes of the one stream go to their GPUs in turn); reads land on ctx"""
         self._lib = lib()
         self._ctx = ctx
         h = C.c_void_p()
-        _ck(self._lib.hast_gz_open_ex(ctx._h, os.fsencode(path), chunk_bytes, chunks_per_pass, room, C.byref(h)))
+        if ctxs:
+            arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+            _ck(self._lib.hast_gz_open_multi_ex(arr, len(ctxs), os.fsencode(path), chunk_bytes, chunks_per_pass, room, C.byref(h)))
+        else:
+            _ck(self._lib.hast_gz_open_ex(ctx._h, os.fsencode(path), chunk_bytes, chunks_per_pass, room, C.byref(h)))
         self._h = h
         self._d = None
         self._cap = 0
@@ -523,6 +532,9 @@ class GzReader:
                 break
             parts.append(a)
         return np.concatenate(parts).tobytes() if parts else b""
+
+    def units(self):
+        return self._lib.hast_gz_units(self._h)
 
     def stats(self):
         st = GzStats()

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <deque>
 #include <cstdio>
@@ -87,6 +88,11 @@ void print_usage() {                              // same flags as the reference
     _exit(code);
 }
 #define CK(call, what) do { if ((call) != HAST_OK) die(4, what); } while (0)
+[[noreturn]] void die_output() {
+    fprintf(stderr, "classify: ERROR: writing the result to stdout failed (%s)\n", strerror(errno));
+    fflush(stderr);
+    _exit(2);
+}
 
 // the whole input, front to back (also from a pipe, which has no size to ask for)
 bool slurp(const std::string &path, std::vector<char> &out) {
@@ -242,7 +248,7 @@ int main(int argc, char **argv) {
     // The FASTQ streams of the first files (pinned staging + device buffers: ~0.1 s of page pinning) are set up by a thread
     // of their own while this one reads the k-mer files and builds the table.
     std::vector<hast_fq *> pre_fq, done_fq;
-    std::vector<hast_gz *> done_gz;
+    std::vector<std::thread> gz_closers;
     std::vector<hast_names *> name_caches, own_caches;     // per context / per GPU: device-side cache barcode text -> id
     std::thread pre_thread;
     std::string pre_error;
@@ -269,8 +275,11 @@ int main(int argc, char **argv) {
         }
     }
     auto make_fq = [&](size_t file_index, hast_fq **out) -> hast_status {
-        if (stripe && !dev_gz[file_index])
-            return hast_fq_create_striped(ctxs.data(), (int)ctxs.size(), fq_cap, std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()), name_caches.data(), out);
+        // (a .gz file inflated on the GPUs: the passes of its one deflate stream go to the GPUs in turn, hast_gz_open_multi, and its
+        // inflated blocks -- written on the device -- are dealt to the contexts like a plain file's)
+        if (stripe)
+            return hast_fq_create_striped_ex(ctxs.data(), (int)ctxs.size(), fq_cap, std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()), name_caches.data(),
+                                             dev_gz[file_index] ? 1 : 0, out);
         return hast_fq_create_ex(ctxs[file_index % ctxs.size()], fq_cap, fq_bufs, name_caches[file_index % ctxs.size()], dev_gz[file_index] ? 1 : 0, out);
     };
     auto contexts_ready = [&]() {
@@ -601,11 +610,10 @@ int main(int argc, char **argv) {
             hast::BlockSource src;
             hast_fq *fq = nullptr;
             hast_gz *gz = nullptr;                                 // the file is inflated on the GPU: blocks are filled there
-            hast_stream fill_stream = nullptr;
             std::thread th;
             std::mutex mu;
             std::condition_variable cv;
-            std::deque<uint8_t *> empty;                           // acquired, waiting for the reader
+            std::deque<std::pair<uint8_t *, hast_stream>> empty;   // acquired, waiting for the reader (device blocks: the stream their writes go on)
             struct Filled { size_t n; bool last; std::string err; };
             std::deque<Filled> filled;                             // filled, in order, waiting for hast_fq_submit
             bool stop = false, eof_acquired = false;
@@ -627,7 +635,7 @@ int main(int argc, char **argv) {
             std::unique_ptr<Feed> f(new Feed());
             f->name = r;
             if (dev_gz[next_file]) {
-                const hast_status gs = hast_gz_open(ctxs[next_file % ctxs.size()], r.c_str(), &f->gz);
+                const hast_status gs = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), r.c_str(), &f->gz) : hast_gz_open(ctxs[next_file % ctxs.size()], r.c_str(), &f->gz);
                 if (gs == HAST_ERR_UNSUPPORTED) {                  // e.g. no room on the device: the host inflates
                     f->gz = nullptr;
                     dev_gz[next_file] = 0;
@@ -651,18 +659,28 @@ int main(int argc, char **argv) {
             f->th = std::thread([fp, cap, &wake_mu, &wake_cv, &wake_gen] {
                 for (;;) {
                     uint8_t *buf;
+                    hast_stream fill_stream;
                     {
                         std::unique_lock<std::mutex> g(fp->mu);
                         fp->cv.wait(g, [fp] { return fp->stop || !fp->empty.empty(); });
                         if (fp->stop) return;
-                        buf = fp->empty.front();
+                        buf = fp->empty.front().first;
+                        fill_stream = fp->empty.front().second;
                         fp->empty.pop_front();
                     }
                     Feed::Filled fl{0, false, std::string()};
                     const double tr0 = now_s();
                     if (fp->gz) {                                   // (buf is a DEVICE address: the translate kernel writes the block there)
                         size_t n = 0;
-                        if (hast_gz_read_device(fp->gz, buf, cap, &n, fp->fill_stream) != HAST_OK) fl.err = hast_last_error();
+                        if (hast_gz_read_device(fp->gz, buf, cap, &n, fill_stream) != HAST_OK) fl.err = hast_last_error();
+                        else if (n < cap) {
+                            // a short read is the end of the stream -- or what could be decoded in front of damage (delivered first, as
+                            // gzread does): the next call says which.  Without it a file damaged behind its first pass would end here
+                            // as if it were complete.
+                            size_t more = 0;
+                            if (hast_gz_read_device(fp->gz, buf + n, cap - n, &more, fill_stream) != HAST_OK) fl.err = hast_last_error();
+                            n += more;
+                        }
                         fl.n = n;
                     } else
                     fl.n = fp->src.read_into(reinterpret_cast<char *>(buf), cap, fl.err);
@@ -739,14 +757,15 @@ int main(int argc, char **argv) {
                 Feed &f = *active[fi];
                 // 1. hand empty buffers to the reader
                 // (device-side blocks: one buffer fewer may be in hand unsubmitted, include/hast.h)
-                while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq) && (!f.gz || f.acquired - f.submitted + 1 < (size_t)n_buf)) {
+                while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq) && (!f.gz || f.acquired - f.submitted + 1 < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq))) {
                     uint8_t *buf;
+                    hast_stream fill_stream = nullptr;
                     CK(hast_fq_acquire(f.fq, &buf), "staging a block");
-                    if (f.gz) CK(hast_fq_device_block(f.fq, &buf, &f.fill_stream), "staging a block");
+                    if (f.gz) CK(hast_fq_device_block(f.fq, &buf, &fill_stream), "staging a block");
                     f.held++;
                     f.acquired++;
                     std::lock_guard<std::mutex> g(f.mu);
-                    f.empty.push_back(buf);
+                    f.empty.push_back({buf, fill_stream});
                     f.cv.notify_one();
                     progress = true;
                 }
@@ -790,7 +809,10 @@ int main(int argc, char **argv) {
                                     f.name.c_str(), (unsigned long long)gs.compressed_bytes, (unsigned long long)gs.out_bytes, (unsigned long long)gs.chunks,
                                     (unsigned long long)gs.accepted, (unsigned long long)gs.followup_jobs, (unsigned long long)gs.followup_rounds, (unsigned long long)gs.members,
                                     gs.open_s, gs.decode_s, gs.windows_crc_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s);
-                        done_gz.push_back(f.gz);
+                        // its device memory (the compressed file, three symbol arenas, windows) goes back now, not at the end of the run: a
+                        // dozen finished .gz files would otherwise crowd the table out of HBM.  On a thread of its own: freeing synchronises.
+                        hast_gz *z = f.gz;
+                        gz_closers.emplace_back([z] { hast_gz_close(z); });
                     }
                     done_fq.push_back(f.fq);                       // (freed after the output: unpinning costs as much as pinning)
                     logtime();
@@ -815,7 +837,7 @@ int main(int argc, char **argv) {
         if (stats && stripe) {
             std::string per;
             for (size_t g = 0; g < ctxs.size(); g++) {
-                uint64_t n = whole_file_records[g];              // (.gz files inflated on the GPU stay on one context each)
+                uint64_t n = whole_file_records[g];              // (files dealt whole: HAST_DEAL=files)
                 for (hast_fq *q : done_fq) n += hast_fq_lane_records(q, (int)g);
                 per += (g ? "," : "") + std::to_string(n);
             }
@@ -850,12 +872,13 @@ int main(int argc, char **argv) {
         snprintf(num, sizeof(num), "\t%d\t%llu\t%llu\n", hap, (unsigned long long)c0, (unsigned long long)c1);
         out += num;
         if (out.size() > (1 << 20) - 256) {
-            fwrite(out.data(), 1, out.size(), stdout);
+            if (fwrite(out.data(), 1, out.size(), stdout) != out.size()) die_output();
             out.clear();
         }
     }
-    fwrite(out.data(), 1, out.size(), stdout);
-    fflush(stdout);
+    // (the wrapper redirects stdout into phased.barcodes and tests only the exit status, classify_stlfr_reads.sh:149: a full disk
+    // or a closed pipe must not leave a truncated table behind exit 0)
+    if (fwrite(out.data(), 1, out.size(), stdout) != out.size() || fflush(stdout) != 0) die_output();
     if (past_int)
         fprintf(stderr, " WARN : a barcode has more than INT_MAX hits: the reference's `int` counters overflow on this input; the exact counts were printed\n");
     logtime();
@@ -881,11 +904,11 @@ int main(int argc, char **argv) {
         if (stats)
             fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=skipped total_s=%.3f\n",
                     t_ctx - t_start, t_loaded - t_ctx, t_scrubbed - t_loaded, t_read_done - t_scrubbed, t_classified - t_read_done, t_printed - t_classified, now_s() - t_start);
-        fflush(stdout);
+        if (fflush(stdout) != 0) die_output();
         fflush(stderr);
         _exit(0);
     }
-    for (hast_gz *z : done_gz) hast_gz_close(z);
+    for (std::thread &t : gz_closers) t.join();
     for (hast_fq *f : done_fq) hast_fq_destroy(f);
     for (hast_names *nm : own_caches) hast_names_destroy(nm);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);

@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -308,6 +309,7 @@ int main(int argc, char **argv) {
         offsets[n] = part[T];
     };
     const size_t block_bytes = (size_t)std::max(1L, getenv("HAST_READ_BLOCK_BYTES") ? atol(getenv("HAST_READ_BLOCK_BYTES")) : (256L << 20));
+    bool output_failed = false;
     for (const auto &r : read) {
         fprintf(stderr, "__process read: %s\n", r.c_str());
         hast::BlockSource src;
@@ -406,10 +408,15 @@ int main(int argc, char **argv) {
             src.recycle(std::move(blk));
         }
         wait_bg();
-        fwrite(out_rows.data(), 1, out_rows.size(), stdout);
+        if (fwrite(out_rows.data(), 1, out_rows.size(), stdout) != out_rows.size()) output_failed = true;
         fprintf(stderr, "__process read done__\n");
     }
-    fflush(stdout);
+    // (mkoutput_by_fabulous2.0.sh redirects stdout into a file and goes on: a full disk or a closed pipe must not pass as exit 0)
+    if (fflush(stdout) != 0) output_failed = true;
+    if (output_failed) {
+        fprintf(stderr, "classify: ERROR: writing the result to stdout failed (%s)\n", strerror(errno));
+        return 2;
+    }
     fprintf(stderr, "__END__\n");
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     return 0;

@@ -52,6 +52,9 @@ struct Slot {
     size_t n_over = 0;                                 // bytes of the next block behind this block's own bytes
     bool over_ready = false, eof_view = false, first_of_file = false;
     uint8_t last_byte = 0;
+    uint8_t *h_last = nullptr;                         // pinned: the last byte of a block that was filled on the device (striped streams)
+    hipEvent_t over_read = nullptr;                    // ... and, behind the copy of its first bytes into the view of the block in front of it (on that
+    bool over_read_pending = false;                    //     block's GPU), the event the next filling of this buffer waits for
     bool dev_src = false;                              // the block's bytes were written on the device (hast_fq_submit_device): h_buf holds nothing
     bool host_view = false;                            // ... until hast_fq_block_host_bytes has fetched them
 };
@@ -120,6 +123,8 @@ static hast_status grow_records(Slot &s, size_t cap) {
 
 static void free_slot(Slot &s) {
     if (s.h_cnt) (void)hipHostFree(s.h_cnt);
+    if (s.h_last) (void)hipHostFree(s.h_last);
+    if (s.over_read) (void)hipEventDestroy(s.over_read);
     if (s.counted) (void)hipEventDestroy(s.counted);
     if (s.over_copied) (void)hipEventDestroy(s.over_copied);
     if (s.h_buf) (void)hipHostFree(s.h_buf);
@@ -177,7 +182,7 @@ static hast_status advance_striped_once(hast_fq *f, bool wait, size_t upto) {
                 if (q != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
             }
             nl_before = f->nl_before + pv.h_cnt->n_nl;
-            bol = pv.last_byte == '\n';
+            bol = (pv.dev_src ? (pv.n_bytes ? pv.h_last[0] : (uint8_t)'\n') : pv.last_byte) == '\n';      // (h_last landed in front of `counted`)
         }
         phase = (uint32_t)(nl_before & 3);
         FqLane &ln = f->lanes[(size_t)s.lane];
@@ -194,7 +199,7 @@ static hast_status advance_striped_once(hast_fq *f, bool wait, size_t upto) {
     return HAST_OK;
 }
 
-static hast_status submit_striped(hast_fq *f, size_t n_bytes, int last) {
+static hast_status submit_striped(hast_fq *f, size_t n_bytes, int last, bool dev_src) {
     const size_t i = f->n_submitted, S = f->slots.size();
     if (!last && n_bytes != f->block)
         return set_error(HAST_ERR_INVALID, "a striped stream takes full blocks (%zu bytes) except for the last one of a file, got %zu", f->block, n_bytes);
@@ -211,26 +216,32 @@ static hast_status submit_striped(hast_fq *f, size_t n_bytes, int last) {
     s.over_ready = last != 0;                      // the last block of a file has nothing behind it
     s.eof_view = last != 0;
     s.first_of_file = i == 0 || f->slots[(i - 1) % S].last != 0;
-    s.last_byte = n_bytes ? s.h_buf[f->pad + n_bytes - 1] : (uint8_t)'\n';
-    if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, ln.copy_stream));
-    FQ_TRY(hipEventRecord(s.copied, ln.copy_stream));
+    s.dev_src = dev_src;
+    s.host_view = !dev_src;
+    if (!dev_src) {
+        s.last_byte = n_bytes ? s.h_buf[f->pad + n_bytes - 1] : (uint8_t)'\n';
+        if (n_bytes) FQ_TRY(hipMemcpyAsync(s.d_buf + f->pad, s.h_buf + f->pad, n_bytes, hipMemcpyHostToDevice, ln.copy_stream));
+    }
+    FQ_TRY(hipEventRecord(s.copied, ln.copy_stream));      // (a device block: behind the caller's writes, which it put on this stream)
     FQ_TRY(hipStreamWaitEvent(ln.parse_stream, s.copied, 0));
     // newlines of the block's own bytes, for the blocks behind it
     FQ_TRY(launch_fq_count_own(s.d_buf, s.d_st, f->pad, n_bytes, s.d_tile, ln.parse_stream));
     FQ_TRY(hipMemcpyAsync(s.h_cnt, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, ln.parse_stream));
+    if (dev_src && n_bytes) FQ_TRY(hipMemcpyAsync(s.h_last, s.d_buf + f->pad + n_bytes - 1, 1, hipMemcpyDeviceToHost, ln.parse_stream));
     FQ_TRY(hipEventRecord(s.counted, ln.parse_stream));
     if (!s.first_of_file) {
         // the block in front gets the first bytes of this one behind its own: host copy (the barcode extents of its records may
-        // point there) + upload on ITS GPU
+        // point there) + upload on ITS GPU -- or, for blocks filled on the device, a copy from this block's GPU to that one
         Slot &pv = f->slots[(i - 1) % S];
         FqLane &pl = f->lanes[(size_t)pv.lane];
         // ... as far as its last record can reach: that record started in the block in front, so its header and base lines end at
         // the latest with the 4th newline of this block (a FASTQ record is four lines).  Copying the whole 1 MB a long read may
         // need cost ~0.15 ms of host memcpy per 16-MB block -- what made a file striped over several contexts slower than on one.
         // (Fewer than 4 newlines in the first over_cap bytes: long lines; then all of it, as before.  Too short a view would be a
-        // loud HAST_ERR_FORMAT from the framer, never a cut read.)
+        // loud HAST_ERR_FORMAT from the framer, never a cut read.  Device blocks: the host does not see the bytes, and a
+        // device-to-device megabyte costs microseconds: all of it.)
         size_t ov = std::min(f->over_cap, n_bytes);
-        {
+        if (!dev_src) {
             const uint8_t *p0 = s.h_buf + f->pad, *p = p0, *const pe = p0 + ov;
             int nl = 0;
             while (nl < 4 && p < pe && (p = static_cast<const uint8_t *>(memchr(p, '\n', (size_t)(pe - p))))) { ++nl; ++p; }
@@ -238,11 +249,19 @@ static hast_status submit_striped(hast_fq *f, size_t n_bytes, int last) {
         }
         pv.n_over = ov;
         pv.eof_view = last != 0 && ov == n_bytes;  // the whole rest of the file is in its view
-        if (ov) {
+        if (ov && !dev_src) {
             memcpy(pv.h_buf + f->pad + pv.n_bytes, s.h_buf + f->pad, ov);
             FQ_TRY(hipSetDevice(pl.device));
             FQ_TRY(hipMemcpyAsync(pv.d_buf + f->pad + pv.n_bytes, pv.h_buf + f->pad + pv.n_bytes, ov, hipMemcpyHostToDevice, pl.copy_stream));
             FQ_TRY(hipEventRecord(pv.over_copied, pl.copy_stream));
+        } else if (ov) {
+            FQ_TRY(hipSetDevice(pl.device));
+            FQ_TRY(hipStreamWaitEvent(pl.copy_stream, s.copied, 0));
+            if (pl.device == ln.device) FQ_TRY(hipMemcpyAsync(pv.d_buf + f->pad + pv.n_bytes, s.d_buf + f->pad, ov, hipMemcpyDeviceToDevice, pl.copy_stream));
+            else FQ_TRY(hipMemcpyPeerAsync(pv.d_buf + f->pad + pv.n_bytes, pl.device, s.d_buf + f->pad, ln.device, ov, pl.copy_stream));
+            FQ_TRY(hipEventRecord(pv.over_copied, pl.copy_stream));
+            FQ_TRY(hipEventRecord(s.over_read, pl.copy_stream));       // (this buffer's next filling waits for the copy out of it)
+            s.over_read_pending = true;
         }
         pv.over_ready = true;
     }
@@ -304,7 +323,8 @@ static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, s
     for (hipEvent_t *e : {&s.named, &s.copied, &s.parsed, &s.done}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (striped) {
         FQ_TRY(hipHostMalloc((void **)&s.h_cnt, sizeof(FqState), hipHostMallocDefault));
-        for (hipEvent_t *e : {&s.counted, &s.over_copied}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        FQ_TRY(hipHostMalloc((void **)&s.h_last, 16, hipHostMallocDefault));
+        for (hipEvent_t *e : {&s.counted, &s.over_copied, &s.over_read}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     (void)pad;
     return HAST_OK;
@@ -353,6 +373,9 @@ hast_status hast_fq_create_ex(hast_ctx *ctx, size_t block_bytes, int n_buffers, 
 // the reference spreads the reads of one file over all its workers (classify.cpp:211-219).  A block is framed on its own GPU
 // from the number of newlines in front of it in the file (fq_kernels.hip, "striped streams").
 hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx, hast_names *const *names, hast_fq **out) {
+    return hast_fq_create_striped_ex(ctxs, n_ctx, block_bytes, n_buffers_per_ctx, names, 0, out);
+}
+hast_status hast_fq_create_striped_ex(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx, hast_names *const *names, int device_blocks, hast_fq **out) {
     if (!ctxs || !out || n_ctx < 1) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
     if (block_bytes < 4096 || block_bytes > (1ull << 30)) return set_error(HAST_ERR_INVALID, "block_bytes %zu out of [4 KB, 1 GB]", block_bytes);
@@ -392,8 +415,9 @@ hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t bloc
         Slot &s = f->slots[si];
         s.lane = (int)(si % (size_t)n_ctx);
         if (hipSetDevice(f->lanes[(size_t)s.lane].device) != hipSuccess) st = set_error(HAST_ERR_HIP, "hipSetDevice failed");
-        else st = alloc_slot(s, buf, f->max_rec, f->pad, f->block, true);
+        else st = alloc_slot(s, buf, f->max_rec, f->pad, f->block, true, device_blocks != 0);
     }
+    if (device_blocks) f->source = 2;
     if (st != HAST_OK) {
         hast_fq_destroy(f);
         return st;
@@ -461,8 +485,28 @@ hast_status hast_fq_acquire(hast_fq *f, uint8_t **host_buf) {
 // kernels that still read this buffer's previous block is already on it.  Then hast_fq_submit_device instead of hast_fq_submit.
 hast_status hast_fq_device_block(hast_fq *f, uint8_t **d_block, hast_stream *fill_stream) {
     if (!f || !d_block || !fill_stream) return set_error(HAST_ERR_INVALID, "null argument");
-    if (f->striped) return set_error(HAST_ERR_INVALID, "device-side blocks are not available on striped streams");
     if (f->n_device_blocks >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_device_block without hast_fq_acquire");
+    if (f->striped) {
+        // block i of a striped stream lives on lane i % n: the address is on THAT GPU, the stream is that lane's copy stream.  What
+        // still reads this buffer's previous block: its framing and classification (waited for by hast_fq_acquire) and the copy of
+        // its first bytes into the view of the block in front of it, on that block's GPU (over_read).
+        if (f->source == 1) return set_error(HAST_ERR_INVALID, "a stream takes host blocks or device blocks, not both");
+        const size_t i = f->n_device_blocks, S = f->slots.size();
+        if (i >= S && f->n_submitted + S <= i + 1)
+            return set_error(HAST_ERR_INVALID, "hast_fq_device_block: %zu blocks are in hand and not submitted; a stream of %zu buffers allows %zu", i - f->n_submitted, S, S - 1);
+        Slot &s = f->slots[i % S];
+        FqLane &ln = f->lanes[(size_t)s.lane];
+        FQ_TRY(hipSetDevice(ln.device));
+        if (s.over_read_pending) {
+            FQ_TRY(hipStreamWaitEvent(ln.copy_stream, s.over_read, 0));
+            s.over_read_pending = false;
+        }
+        f->source = 2;
+        f->n_device_blocks++;
+        *d_block = s.d_buf + f->pad;
+        *fill_stream = (hast_stream)ln.copy_stream;
+        return HAST_OK;
+    }
     if (f->source == 1) return set_error(HAST_ERR_INVALID, "a stream takes host blocks or device blocks, not both");
     f->source = 2;
     const size_t i = f->n_device_blocks;
@@ -488,10 +532,10 @@ static hast_status submit_block(hast_fq *f, size_t n_bytes, int last, bool dev_s
     if (!f) return set_error(HAST_ERR_INVALID, "null argument");
     if (f->n_submitted >= f->n_acquired) return set_error(HAST_ERR_INVALID, "hast_fq_submit without hast_fq_acquire");
     if (n_bytes > f->block) return set_error(HAST_ERR_INVALID, "block of %zu bytes exceeds the capacity %zu", n_bytes, f->block);
-    if (dev_src ? (f->striped || f->source != 2 || f->n_device_blocks <= f->n_submitted) : (f->source == 2 || !f->slots[f->n_submitted % f->slots.size()].h_buf))
+    if (dev_src ? (f->source != 2 || f->n_device_blocks <= f->n_submitted) : (f->source == 2 || !f->slots[f->n_submitted % f->slots.size()].h_buf))
         return set_error(HAST_ERR_INVALID, dev_src ? "hast_fq_submit_device without hast_fq_device_block" : "a stream takes host blocks or device blocks, not both");
     if (!dev_src) f->source = 1;
-    if (f->striped) return submit_striped(f, n_bytes, last);
+    if (f->striped) return submit_striped(f, n_bytes, last, dev_src);
     const int si = (int)(f->n_submitted % f->slots.size());
     Slot &s = f->slots[(size_t)si];
     FQ_TRY(hipSetDevice(f->device));
@@ -535,7 +579,7 @@ hast_status hast_fq_block_host_bytes(hast_fq *f, const uint8_t **bytes) {
         FQ_TRY(hipSetDevice(dev_of(f, s)));
         if (!s.h_buf) FQ_TRY(hipHostMalloc((void **)&s.h_buf, s.h_buf_bytes, hipHostMallocDefault));
         hipStream_t hs = ctx_stream_of(ctx_of(f, s));
-        FQ_TRY(hipMemcpyAsync(s.h_buf, s.d_buf, f->pad + s.n_bytes, hipMemcpyDeviceToHost, hs));
+        FQ_TRY(hipMemcpyAsync(s.h_buf, s.d_buf, f->pad + s.n_bytes + s.n_over, hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipStreamSynchronize(hs));
         s.host_view = true;
     }

@@ -4,6 +4,11 @@
 // chunks with its follow-up jobs (gz_chain.h), windows, CRC-32 -- and checks every member's CRC-32 / ISIZE; the caller's thread
 // (hast_gz_read_device) only launches the translate kernel that writes the bytes it asks for where it wants them.
 // Replaces, for this path, gzstream.h:47 + classify.cpp:245-254 (one zlib stream per file on one host thread).
+// Several GPUs (hast_gz_open_multi; the reference deals the reads of ONE file to all its workers, classify.cpp:211-219): the PASSES
+// of the one deflate stream go to the GPUs in turn -- a chunk's marker-symbol decode needs nothing from its neighbours -- every GPU
+// ("unit") with its own copy of the compressed bytes, job arrays, symbol arenas and streams; the chain of accepted chunks stays one
+// (host), the 32 KB a pass hands to the next travel through pinned host memory, and the reader's bytes are translated on the unit
+// that decoded them and, when the reader's buffer lives on another GPU, copied there peer to peer.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -64,7 +69,7 @@ struct DevBuf {                               // a device allocation that only e
 };
 
 struct Batch {                                // accepted chunks the consumer may translate
-    int arena = -1;
+    int unit = 0, arena = -1;
     std::vector<Accepted> acc;
     uint64_t out_lo = 0, out_hi = 0;
     size_t next = 0;                          // consumer: first chunk not fully delivered
@@ -81,38 +86,46 @@ struct Arena {
     bool done_recorded = false;
 };
 
+// What ONE GPU holds of a stream.  The nominal pass of a unit's segment j + 1 (search + decode of its chunks: where the time goes) is
+// launched BEFORE its segment j's results are walked, so that the GPU decodes while the host chains, the single-wave follow-up jobs
+// run and the consumer translates: job arrays in two copies (j & 1), follow-up jobs in a third, three symbol arenas (j % 3: one being
+// translated, one being chained, one being decoded), the work behind a nominal pass on a stream of its own, the reader's translate
+// kernels (and the copies towards another GPU) on yet another.
+struct Unit {
+    int device = 0;
+    uint32_t *d_in = nullptr;                 // the compressed file + zero padding
+    DevBuf jobs[2], fjobs, bounce;            // (bounce: where the reader's bytes are translated to when its buffer is on another GPU)
+    ChunkJob *h_jobs[2] = {nullptr, nullptr}, *h_fjobs = nullptr;   // pinned
+    hipEvent_t nom_done[2] = {nullptr, nullptr};
+    uint32_t *h_crc = nullptr;                // pinned
+    size_t h_crc_cap = 0;
+    static constexpr int kArenas = 3;
+    Arena arena[kArenas];
+    hipStream_t up_stream = nullptr, dec_stream = nullptr, post_stream = nullptr, xl_stream = nullptr;
+    hipEvent_t xl_done = nullptr;             // behind the reader's last launches on xl_stream
+    int dec_masked_free = 0;                  // != 0: dec_stream is a CU-masked stream out of the process's pool (goes back there)
+};
+
 }  // namespace
 
 struct hast_gz {
     hast_ctx *ctx = nullptr;
-    int device = 0;
     int fd = -1;
     std::string path;
     uint64_t file_size = 0;
     size_t chunk_bytes = 32768, seg_chunks = 4096;
     double room = 12.0;
     uint32_t slot_syms = 0;
-    // device
-    uint32_t *d_in = nullptr;
-    // The nominal pass of segment k + 1 (search + decode of its chunks: where the time goes) is launched BEFORE segment k's results are
-    // walked, so that the GPU decodes while the host chains, the single-wave follow-up jobs run and the consumer translates: job
-    // arrays in two copies (segment k & 1), follow-up jobs in a third, three symbol arenas (segment k % 3: one being translated,
-    // one being chained, one being decoded), the work behind a nominal pass on a stream of its own.
-    DevBuf jobs[2], fjobs, carry_next;
-    ChunkJob *h_jobs[2] = {nullptr, nullptr}, *h_fjobs = nullptr;   // pinned
-    hipEvent_t nom_done[2] = {nullptr, nullptr};
     size_t h_jobs_cap = 0;
-    uint32_t *h_crc = nullptr;                // pinned
-    size_t h_crc_cap = 0;
-    static constexpr int kArenas = 3;
-    Arena arena[kArenas];
-    hipStream_t up_stream = nullptr, dec_stream = nullptr, post_stream = nullptr;
-    int dec_masked_free = 0;                  // != 0: dec_stream is a CU-masked stream out of the process's pool (goes back there)
+    std::vector<std::unique_ptr<Unit>> units; // segment k -> units[k % n]
+    bool split_same_device = false;           // test switch: one unit per context even where contexts share a GPU, bounce path forced
+    uint8_t *h_carry = nullptr;               // pinned: the 32 KB behind the last batch (in front of the next one, whichever unit has it)
+    std::vector<std::pair<int, hipEvent_t>> in_events;   // reader: (device, event recorded on the caller's stream in front of a translate)
     // threads
     std::thread uploader, producer;
     std::mutex mu;
     std::condition_variable cv;
-    uint64_t uploaded = 0;                    // bytes of the file on the device
+    uint64_t uploaded = 0;                    // bytes of the file on EVERY unit
     std::string up_error;
     bool stop = false;
     std::deque<std::unique_ptr<Batch>> ready; // producer -> consumer
@@ -128,6 +141,9 @@ struct hast_gz {
     bool crc_started = false;
     // stats
     hast_gz_stats st{};
+    Unit &unit_of(size_t k) { return *units[k % units.size()]; }
+    Arena &arena_of(size_t k) { return unit_of(k).arena[(k / units.size()) % Unit::kArenas]; }
+    int jobs_of(size_t k) const { return (int)((k / units.size()) & 1); }
 };
 
 namespace {
@@ -188,22 +204,28 @@ bool read_at(int fd, uint64_t off, size_t n, uint8_t *dst, size_t *got) {
     return true;
 }
 
-// compressed bytes -> HBM, piece by piece; `uploaded` moves on when a piece IS there
+// compressed bytes -> HBM of every unit, piece by piece; `uploaded` moves on when a piece IS there (on all of them: every GPU has
+// its own PCIe link, and a unit may be handed a follow-up job anywhere in front of its own segments)
 void upload_loop(hast_gz *g) {
-    (void)hipSetDevice(g->device);
+    const size_t nu = g->units.size();
+    (void)hipSetDevice(g->units[0]->device);
     uint8_t *h[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev[2];
     std::string bad;
     for (int i = 0; i < 2 && bad.empty(); ++i) {
-        if (hipHostMalloc((void **)&h[i], kPiece, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) bad = "gz: pinned staging allocation failed";
+        if (hipHostMalloc((void **)&h[i], kPiece, hipHostMallocPortable) != hipSuccess) bad = "gz: pinned staging allocation failed";
+        ev[i].assign(nu, nullptr);
+        for (size_t u = 0; u < nu && bad.empty(); ++u)
+            if (hipSetDevice(g->units[u]->device) != hipSuccess || hipEventCreateWithFlags(&ev[i][u], hipEventDisableTiming) != hipSuccess) bad = "gz: pinned staging allocation failed";
     }
     const int nthr = 8;
     WorkerPool pool(nthr);
     uint64_t end_of[2] = {0, 0};
     bool in_flight[2] = {false, false};
-    auto land = [&](int b) {                                       // piece in buffer b is on the device
+    auto land = [&](int b) {                                       // piece in buffer b is on the devices
         if (!in_flight[b]) return;
-        if (hipEventSynchronize(ev[b]) != hipSuccess && bad.empty()) bad = "gz: upload failed";
+        for (size_t u = 0; u < nu; ++u)
+            if ((hipSetDevice(g->units[u]->device) != hipSuccess || hipEventSynchronize(ev[b][u]) != hipSuccess) && bad.empty()) bad = "gz: upload failed";
         in_flight[b] = false;
         std::lock_guard<std::mutex> lk(g->mu);
         g->uploaded = std::max(g->uploaded, end_of[b]);
@@ -226,8 +248,13 @@ void upload_loop(hast_gz *g) {
             if (to > from && (!read_at(g->fd, off + from, to - from, h[b] + from, &got) || got != to - from)) short_read = true;
         });
         if (short_read) { bad = "gz: read failed (the file is shorter than its size says, or an I/O error)"; break; }
-        if (hipMemcpyAsync(reinterpret_cast<uint8_t *>(g->d_in) + off, h[b], n, hipMemcpyHostToDevice, g->up_stream) != hipSuccess ||
-            hipEventRecord(ev[b], g->up_stream) != hipSuccess) { bad = "gz: upload failed"; break; }
+        for (size_t u = 0; u < nu && bad.empty(); ++u) {
+            Unit &U = *g->units[u];
+            if (hipSetDevice(U.device) != hipSuccess ||
+                hipMemcpyAsync(reinterpret_cast<uint8_t *>(U.d_in) + off, h[b], n, hipMemcpyHostToDevice, U.up_stream) != hipSuccess ||
+                hipEventRecord(ev[b][u], U.up_stream) != hipSuccess) bad = "gz: upload failed";
+        }
+        if (!bad.empty()) break;
         end_of[b] = off + n;
         in_flight[b] = true;
         land(b ^ 1);                                               // (the piece before this one: usually there by now)
@@ -236,7 +263,8 @@ void upload_loop(hast_gz *g) {
     land(1);
     for (int k = 0; k < 2; ++k) {
         if (h[k]) (void)hipHostFree(h[k]);
-        if (ev[k]) (void)hipEventDestroy(ev[k]);
+        for (hipEvent_t e : ev[k])
+            if (e) (void)hipEventDestroy(e);
     }
     std::lock_guard<std::mutex> lk(g->mu);
     if (!bad.empty()) g->up_error = bad;
@@ -262,8 +290,9 @@ struct Nominal {
     double t0 = 0;
 };
 
-// Launches segment k's nominal pass once its compressed bytes are on the device and its arena is free.  blocking = false: only if
-// both are the case right now (N.launched says).  Returns "" or what failed; stopped: the stream is being closed.
+// Launches segment k's nominal pass (on the unit whose turn it is) once its compressed bytes are on the device and its arena is
+// free.  blocking = false: only if both are the case right now (N.launched says).  Returns "" or what failed; stopped: the stream
+// is being closed.
 std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first_bit, bool blocking, Nominal &N, bool &stopped) {
     const size_t C = g->chunk_bytes, S = g->seg_chunks;
     // the first pass is a short one: the reader (the FASTQ framer, the classification behind it) has nothing to do until it is through
@@ -273,9 +302,11 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     // the compressed bytes this segment's chunks may read: their own and a margin behind them (a chunk runs on to the first
     // block boundary behind its stop)
     const uint64_t need_up = all_in ? g->file_size : std::min<uint64_t>(g->file_size, (uint64_t)c1 * C + std::min<uint64_t>((uint64_t)S * C, 16u << 20));
-    Arena &A = g->arena[k % hast_gz::kArenas];
+    Unit &U = g->unit_of(k);
+    Arena &A = g->arena_of(k);
     uint64_t have_up = 0;
     N = Nominal{};
+    GZ_HIP(hipSetDevice(U.device));
     {
         std::unique_lock<std::mutex> lk(g->mu);
         if (!blocking) {
@@ -304,8 +335,8 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     N.all_in = all_in;
     N.input_bits = (all_in ? g->file_size : have_up) * 8;
     N.t0 = now_s();
-    const int jb = (int)(k & 1);
-    ChunkJob *hj = g->h_jobs[jb];
+    const int jb = g->jobs_of(k);
+    ChunkJob *hj = U.h_jobs[jb];
     size_t n_jobs = 0;
     GZ_HIP(A.syms.ensure((size_t)(c1 - c0) * g->slot_syms * sizeof(uint16_t) + 64));
     const uint64_t sym_base = reinterpret_cast<uintptr_t>(A.syms.p) / 2;      // job.sym_off counts u16 from address 0
@@ -326,23 +357,25 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     }
     N.n_jobs = n_jobs;
     if (n_jobs) {
-        GZ_HIP(hipMemcpyAsync(g->jobs[jb].p, hj, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, g->dec_stream));
-        GZ_HIP(launch_search((ChunkJob *)g->jobs[jb].p, (uint32_t)n_jobs, g->d_in, N.input_bits, g->dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->jobs[jb].p, (uint32_t)n_jobs, g->d_in, N.input_bits, (uint16_t *)A.syms.p, g->dec_stream));
-        GZ_HIP(hipMemcpyAsync(hj, g->jobs[jb].p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->dec_stream));
+        GZ_HIP(hipMemcpyAsync(U.jobs[jb].p, hj, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, U.dec_stream));
+        GZ_HIP(launch_search((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, U.dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, (uint16_t *)A.syms.p, U.dec_stream));
+        GZ_HIP(hipMemcpyAsync(hj, U.jobs[jb].p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, U.dec_stream));
     }
-    GZ_HIP(hipEventRecord(g->nom_done[jb], g->dec_stream));
+    GZ_HIP(hipEventRecord(U.nom_done[jb], U.dec_stream));
     N.launched = true;
     return "";
 }
 
 // what is behind a nominal pass: the chain with its follow-up jobs, windows, CRC-32, member checks, hand-over; returns "" or what failed
 std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
-    Arena &A = g->arena[N.k % hast_gz::kArenas];
+    Unit &U = g->unit_of(N.k);
+    Arena &A = g->arena_of(N.k);
+    GZ_HIP(hipSetDevice(U.device));
     const uint64_t input_bits = N.input_bits;
     const bool all_in = N.all_in;
     g->st.chunks += N.n_jobs;
-    g->chain.add_candidates(g->h_jobs[N.k & 1], N.n_jobs, all_in);
+    g->chain.add_candidates(U.h_jobs[g->jobs_of(N.k)], N.n_jobs, all_in);
     // ---- the chain, with its follow-up jobs ------------------------------------------------------------------------------------
     std::vector<Chain::Gap> gaps;
     while (g->chain.plan(gaps, input_bits)) {
@@ -358,25 +391,26 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         GZ_HIP(gb.ensure(total * sizeof(uint16_t) + 64));
         const uint64_t gbase = reinterpret_cast<uintptr_t>(gb.p) / 2;
         for (size_t i = 0; i < gaps.size(); ++i) {
-            ChunkJob &j = g->h_fjobs[i];
+            ChunkJob &j = U.h_fjobs[i];
             j = gaps[i].job;
             j.sym_cap = (uint32_t)std::min<uint64_t>(gaps[i].want_syms, 1ull << 26);
             j.sym_off = gbase + at[i];
             j.start_bit = j.from_bit;
             j.status = kStFound;
         }
-        GZ_HIP(hipMemcpyAsync(g->fjobs.p, g->h_fjobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, g->post_stream));
-        GZ_HIP(launch_decode((ChunkJob *)g->fjobs.p, (uint32_t)gaps.size(), g->d_in, input_bits, (uint16_t *)gb.p, g->post_stream));
-        GZ_HIP(hipMemcpyAsync(g->h_fjobs, g->fjobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, g->post_stream));
-        GZ_HIP(hipStreamSynchronize(g->post_stream));
-        g->chain.gap_done(g->h_fjobs, gaps.size(), input_bits);
+        GZ_HIP(hipMemcpyAsync(U.fjobs.p, U.h_fjobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, U.post_stream));
+        GZ_HIP(launch_decode((ChunkJob *)U.fjobs.p, (uint32_t)gaps.size(), U.d_in, input_bits, (uint16_t *)gb.p, U.post_stream));
+        GZ_HIP(hipMemcpyAsync(U.h_fjobs, U.fjobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, U.post_stream));
+        GZ_HIP(hipStreamSynchronize(U.post_stream));
+        g->chain.gap_done(U.h_fjobs, gaps.size(), input_bits);
         g->st.followup_jobs += gaps.size();
         g->st.followup_rounds++;
     }
     g->st.decode_s += now_s() - N.t0;
     // ---- what became final: windows, CRC-32, member checks, hand-over --------------------------------------------------------------
     std::unique_ptr<Batch> b(new Batch);
-    b->arena = (int)(N.k % hast_gz::kArenas);
+    b->unit = (int)(N.k % g->units.size());
+    b->arena = (int)((N.k / g->units.size()) % Unit::kArenas);
     g->chain.take_confirmed(b->acc);
     const size_t n = b->acc.size();
     std::string bad;
@@ -397,27 +431,29 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         GZ_HIP(A.need.ensure(windows_scratch_bytes((uint32_t)n)));
         GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
         GZ_HIP(A.carry.ensure(kWindow));
-        if (g->h_crc_cap < n) {
-            if (g->h_crc) (void)hipHostFree(g->h_crc);
-            g->h_crc = nullptr;
-            g->h_crc_cap = 0;
-            GZ_HIP(hipHostMalloc((void **)&g->h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
-            g->h_crc_cap = n + n / 2 + 64;
+        if (U.h_crc_cap < n) {
+            if (U.h_crc) (void)hipHostFree(U.h_crc);
+            U.h_crc = nullptr;
+            U.h_crc_cap = 0;
+            GZ_HIP(hipHostMalloc((void **)&U.h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            U.h_crc_cap = n + n / 2 + 64;
         }
         // (pageable source: the copy is done with `host` when the call returns)
-        GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, g->post_stream));
-        GZ_HIP(hipStreamSynchronize(g->post_stream));
-        GZ_HIP(hipMemcpyAsync(A.carry.p, g->carry_next.p, kWindow, hipMemcpyDeviceToDevice, g->post_stream));
-        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, A.need.p, g->post_stream));
-        GZ_HIP(launch_crc((const AccDev *)A.acc.p, (uint32_t)n, (const uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.crc.p, g->post_stream));
-        GZ_HIP(hipMemcpyAsync(g->carry_next.p, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToDevice, g->post_stream));
-        GZ_HIP(hipMemcpyAsync(g->h_crc, A.crc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, g->post_stream));
-        GZ_HIP(hipStreamSynchronize(g->post_stream));
+        GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, U.post_stream));
+        GZ_HIP(hipStreamSynchronize(U.post_stream));
+        // the 32 KB in front of this batch: what the batch before it left (pinned host memory: the batch before may live on another GPU)
+        GZ_HIP(hipMemcpyAsync(A.carry.p, g->h_carry, kWindow, hipMemcpyHostToDevice, U.post_stream));
+        GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, A.need.p, U.post_stream));
+        GZ_HIP(launch_crc((const AccDev *)A.acc.p, (uint32_t)n, (const uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, (uint32_t *)A.crc.p, U.post_stream));
+        GZ_HIP(hipMemcpyAsync(U.h_crc, A.crc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, U.post_stream));
+        GZ_HIP(hipStreamSynchronize(U.post_stream));                        // (h_carry has been read: the copy above is through)
+        GZ_HIP(hipMemcpyAsync(g->h_carry, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToHost, U.post_stream));
+        GZ_HIP(hipStreamSynchronize(U.post_stream));
         for (size_t i = 0; i < n && bad.empty(); ++i) {
             const Accepted &a = b->acc[i];
             const uint32_t len = a.job.n_out;
             if (len) {
-                g->crc_acc = g->crc_started ? crc_combine_op(g->crc_acc, g->h_crc[i], crc_x2nmodp(len, 3)) : g->h_crc[i];
+                g->crc_acc = g->crc_started ? crc_combine_op(g->crc_acc, U.h_crc[i], crc_x2nmodp(len, 3)) : U.h_crc[i];
                 g->crc_started = true;
                 g->isize_acc += len;
             }
@@ -451,22 +487,38 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
 }
 
 void produce_loop(hast_gz *g) {
-    (void)hipSetDevice(g->device);
     const uint64_t first_bit = g->chain.first_deflate_bit();
     const size_t n_chunks = first_bit == ~0ull ? 0 : (size_t)((g->file_size + g->chunk_bytes - 1) / g->chunk_bytes);
-    bool finished = n_chunks == 0, stopped = false;
+    const size_t nu = g->units.size();
+    bool finished = n_chunks == 0, stopped = false, all_launched = false;
     std::string bad;
-    Nominal cur, next;
-    if (!finished) bad = launch_nominal(g, 0, n_chunks, first_bit, true, cur, stopped);
+    // passes in flight, in stream order: while segment k is walked, k + 1 .. k + n_units are on the GPUs (each unit one of its own
+    // plus, for the unit of k, the one behind it)
+    std::deque<Nominal> fl;
+    size_t next_k = 0;
+    auto launch = [&](bool blocking) -> bool {                      // true: segment next_k went out
+        Nominal N;
+        bad = launch_nominal(g, next_k, n_chunks, first_bit, blocking, N, stopped);
+        if (!bad.empty() || stopped || !N.launched) return false;
+        fl.push_back(N);
+        all_launched = N.all_in;
+        ++next_k;
+        return true;
+    };
     while (!finished && !stopped && bad.empty()) {
-        if (hipEventSynchronize(g->nom_done[cur.k & 1]) != hipSuccess) { bad = "gz: the decode pass failed"; break; }
-        next = Nominal{};
-        // the next segment's pass goes to the GPU now if its bytes and its arena are there (otherwise behind this segment's hand-over)
-        if (!cur.all_in) bad = launch_nominal(g, cur.k + 1, n_chunks, first_bit, false, next, stopped);
-        if (bad.empty() && !stopped) bad = finish_segment(g, cur, finished);
-        if (finished || stopped || !bad.empty()) break;
-        if (!next.launched) bad = launch_nominal(g, cur.k + 1, n_chunks, first_bit, true, next, stopped);
-        cur = next;
+        if (fl.empty()) {
+            if (all_launched) { bad = "gz: internal: the chain of chunks stalled"; break; }
+            if (!launch(true)) break;
+        }
+        const Nominal cur = fl.front();
+        Unit &U = g->unit_of(cur.k);
+        if (hipSetDevice(U.device) != hipSuccess || hipEventSynchronize(U.nom_done[g->jobs_of(cur.k)]) != hipSuccess) { bad = "gz: the decode pass failed"; break; }
+        // the next segments' passes go to the GPUs now if their bytes and arenas are there (otherwise behind this segment's hand-over)
+        while (!all_launched && next_k <= cur.k + nu && bad.empty() && !stopped)
+            if (!launch(false)) break;
+        if (!bad.empty() || stopped) break;
+        bad = finish_segment(g, cur, finished);
+        fl.pop_front();
     }
     // (a pass that is still running when the loop is left early reads buffers hast_gz_close frees only after the streams have drained)
     if (stopped) return;
@@ -482,8 +534,10 @@ void produce_loop(hast_gz *g) {
 
 extern "C" {
 
-hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes, size_t seg_chunks, double room, hast_gz **out) {
-    if (!ctx || !path || !out) return set_error(HAST_ERR_INVALID, "null argument");
+hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *path, size_t chunk_bytes, size_t seg_chunks, double room, hast_gz **out) {
+    if (!ctxs || n_ctx < 1 || !path || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    for (int i = 0; i < n_ctx; ++i)
+        if (!ctxs[i]) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
     const double t_open0 = now_s();
     const int fd = open(path, O_RDONLY);
@@ -498,11 +552,34 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
         close(fd);
         return set_error(HAST_ERR_OOM, "host allocation failed");
     }
-    g->ctx = ctx;
-    g->device = hast_ctx_device(ctx);
+    g->ctx = ctxs[0];
     g->fd = fd;
     g->path = path;
     g->file_size = (uint64_t)sb.st_size;
+    // one unit per GPU: contexts that share a device share the unit (HAST_GZ_SPLIT=contexts: a unit per context all the same, and
+    // every reader's bytes through the bounce buffer + peer copy -- the several-GPU code on one GPU, for tests)
+    {
+        const char *e = getenv("HAST_GZ_SPLIT");
+        g->split_same_device = e && !strcmp(e, "contexts");
+    }
+    for (int i = 0; i < n_ctx; ++i) {
+        const int dev = hast_ctx_device(ctxs[i]);
+        bool have = false;
+        for (const auto &u : g->units) have = have || u->device == dev;
+        if (have && !g->split_same_device) continue;
+        std::unique_ptr<Unit> u(new (std::nothrow) Unit());
+        if (!u) {
+            close(fd);
+            return set_error(HAST_ERR_OOM, "host allocation failed");
+        }
+        u->device = dev;
+        g->units.push_back(std::move(u));
+    }
+    // (test switches for callers that cannot pass a geometry, e.g. the classify program: a small file then spans many passes)
+    if (!chunk_bytes)
+        if (const char *e = getenv("HAST_GZ_CHUNK_BYTES")) chunk_bytes = (size_t)std::max(0L, atol(e));
+    if (!seg_chunks)
+        if (const char *e = getenv("HAST_GZ_PASS_CHUNKS")) seg_chunks = (size_t)std::max(0L, atol(e));
     g->chunk_bytes = chunk_bytes ? std::max<size_t>(chunk_bytes, 64) : 32768;
     g->chunk_bytes = (g->chunk_bytes + 3) & ~(size_t)3;
     // 4096 chunks a pass x 786 KB of symbol room = 3.2 GB an arena, three arenas (measured against the tree before the pipelined
@@ -522,10 +599,13 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
         close(fd);
         return set_error(HAST_ERR_UNSUPPORTED, "%s: %s", path, why.c_str());
     }
-    if (hipSetDevice(g->device) != hipSuccess) { close(fd); return set_error(HAST_ERR_HIP, "hipSetDevice failed"); }
     const size_t n_chunks = (size_t)((g->file_size + g->chunk_bytes - 1) / g->chunk_bytes);
     const size_t seg = std::max<size_t>(1, std::min(g->seg_chunks, n_chunks));
     g->seg_chunks = seg;
+    const size_t s0 = std::min<size_t>(seg, 1024);
+    const size_t n_seg = n_chunks <= s0 ? 1 : 1 + (n_chunks - s0 + seg - 1) / seg;
+    if (g->units.size() > n_seg) g->units.resize(std::max<size_t>(1, n_seg));       // (a unit without a segment would hold memory for nothing)
+    const size_t nu = g->units.size();
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     const bool trace = getenv("HAST_GZ_TRACE") != nullptr;
@@ -534,49 +614,59 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
         if (trace) fprintf(stderr, "gz open %s: %s %.3f s\n", path, what, now_s() - t_tr);
         t_tr = now_s();
     };
-    // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
-    const uint64_t alloc = ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
-    step(hipMalloc((void **)&g->d_in, alloc));
-    if (e == hipSuccess) step(hipMemset(reinterpret_cast<uint8_t *>(g->d_in) + tail_from, 0, alloc - tail_from));
-    tr("input buffer");
-    step(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
-    {
-        // The nominal passes keep some CUs FREE (HAST_GZ_FREE_CUS, default 32 of 256): a decode wave lives ~20 ms and the passes fill every
-        // LDS slot of the GPU, so whatever else wants to run -- this file's follow-up jobs, windows and CRC-32, the translate kernel, the
-        // FASTQ framer and the classifier of the blocks already inflated -- would wait for waves to retire, one short kernel after the
-        // other (measured: 0.2-0.35 s of "waiting for the GPU's framing" in a .gz run against 0.07 s on plain files).
-        int n_cu = 0, free_cus = 32;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, g->device) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (const char *fc = getenv("HAST_GZ_FREE_CUS")) free_cus = atoi(fc);
-        if (e == hipSuccess && n_cu > 0 && free_cus > 0 && free_cus < n_cu) {
-            g->dec_stream = masked_stream_get(g->device, n_cu, free_cus);
-            if (g->dec_stream) g->dec_masked_free = free_cus;
-        }
-        if (!g->dec_stream) step(hipStreamCreateWithFlags(&g->dec_stream, hipStreamNonBlocking));
-    }
-    // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass: a stream of its own
-    // (a high-priority one made no difference in an A/B: the free CUs are what lets its kernels start)
-    step(hipStreamCreateWithFlags(&g->post_stream, hipStreamNonBlocking));
-    tr("streams");
     g->h_jobs_cap = seg + 8;
-    for (int i = 0; i < 2; ++i) {
-        step(hipHostMalloc((void **)&g->h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
-        step(g->jobs[i].ensure(g->h_jobs_cap * sizeof(ChunkJob)));
-        step(hipEventCreateWithFlags(&g->nom_done[i], hipEventDisableTiming));
+    step(hipSetDevice(g->units[0]->device));
+    step(hipHostMalloc((void **)&g->h_carry, kWindow, hipHostMallocPortable));
+    if (e == hipSuccess) memset(g->h_carry, 0, kWindow);
+    for (size_t ui = 0; ui < nu && e == hipSuccess; ++ui) {
+        Unit &U = *g->units[ui];
+        step(hipSetDevice(U.device));
+        // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
+        const uint64_t alloc = ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
+        step(hipMalloc((void **)&U.d_in, alloc));
+        if (e == hipSuccess) step(hipMemset(reinterpret_cast<uint8_t *>(U.d_in) + tail_from, 0, alloc - tail_from));
+        tr("input buffer");
+        step(hipStreamCreateWithFlags(&U.up_stream, hipStreamNonBlocking));
+        {
+            // The nominal passes keep some CUs FREE (HAST_GZ_FREE_CUS, default 32 of 256): a decode wave lives for milliseconds and the passes
+            // fill every LDS slot of the GPU, so whatever else wants to run -- this file's follow-up jobs, windows and CRC-32, the translate
+            // kernel, the FASTQ framer and the classifier of the blocks already inflated -- would wait for waves to retire, one short kernel
+            // after the other (measured: 0.2-0.35 s of "waiting for the GPU's framing" in a .gz run against 0.07 s on plain files).
+            int n_cu = 0, free_cus = 32;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, U.device) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (const char *fc = getenv("HAST_GZ_FREE_CUS")) free_cus = atoi(fc);
+            if (e == hipSuccess && n_cu > 0 && free_cus > 0 && free_cus < n_cu) {
+                U.dec_stream = masked_stream_get(U.device, n_cu, free_cus);
+                if (U.dec_stream) U.dec_masked_free = free_cus;
+            }
+            if (!U.dec_stream) step(hipStreamCreateWithFlags(&U.dec_stream, hipStreamNonBlocking));
+        }
+        // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass: a stream of its own
+        // (a high-priority one made no difference in an A/B: the free CUs are what lets its kernels start); the reader's translate kernels
+        // on another one
+        step(hipStreamCreateWithFlags(&U.post_stream, hipStreamNonBlocking));
+        step(hipStreamCreateWithFlags(&U.xl_stream, hipStreamNonBlocking));
+        step(hipEventCreateWithFlags(&U.xl_done, hipEventDisableTiming));
+        tr("streams");
+        for (int i = 0; i < 2; ++i) {
+            step(hipHostMalloc((void **)&U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+            step(U.jobs[i].ensure(g->h_jobs_cap * sizeof(ChunkJob)));
+            step(hipEventCreateWithFlags(&U.nom_done[i], hipEventDisableTiming));
+        }
+        step(hipHostMalloc((void **)&U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+        step(U.fjobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
+        for (Arena &a : U.arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+        tr("job buffers");
+        // the symbol arenas up front: an allocation that fails later would fail in mid-file (a unit's segments: ui, ui + nu, ...)
+        for (int i = 0; i < Unit::kArenas && e == hipSuccess; ++i) {
+            const size_t k = ui + (size_t)i * nu;
+            if (k >= n_seg) break;
+            const size_t chunks = k == 0 ? (n_seg == 1 ? std::max(s0, std::min(seg, n_chunks)) : s0) : seg;
+            step(U.arena[i].syms.ensure(chunks * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
+        }
+        tr("arenas");
     }
-    step(hipHostMalloc((void **)&g->h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
-    step(g->fjobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
-    step(g->carry_next.ensure(kWindow));
-    if (e == hipSuccess) step(hipMemset(g->carry_next.p, 0, kWindow));
-    for (Arena &a : g->arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
-    tr("job buffers");
-    // the symbol arenas up front: an allocation that fails later would fail in mid-file
-    const size_t s0 = std::min<size_t>(seg, 1024);
-    const size_t n_seg = n_chunks <= s0 ? 1 : 1 + (n_chunks - s0 + seg - 1) / seg;
-    for (int i = 0; i < hast_gz::kArenas && e == hipSuccess; ++i)
-        if ((size_t)i < n_seg) step(g->arena[i].syms.ensure((i == 0 && n_seg <= 3 ? std::min(seg, std::max(s0, n_chunks)) : seg) * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
-    tr("arenas");
     if (e != hipSuccess) {
         const hast_status st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_UNSUPPORTED : HAST_ERR_HIP, "device inflate of %s: %s", path, hipGetErrorString(e));
         (void)hipGetLastError();
@@ -591,7 +681,12 @@ hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes,
     return HAST_OK;
 }
 
-hast_status hast_gz_open(hast_ctx *ctx, const char *path, hast_gz **out) { return hast_gz_open_ex(ctx, path, 0, 0, 0, out); }
+hast_status hast_gz_open_multi(hast_ctx *const *ctxs, int n_ctx, const char *path, hast_gz **out) { return hast_gz_open_multi_ex(ctxs, n_ctx, path, 0, 0, 0, out); }
+hast_status hast_gz_open_ex(hast_ctx *ctx, const char *path, size_t chunk_bytes, size_t seg_chunks, double room, hast_gz **out) {
+    return hast_gz_open_multi_ex(&ctx, 1, path, chunk_bytes, seg_chunks, room, out);
+}
+hast_status hast_gz_open(hast_ctx *ctx, const char *path, hast_gz **out) { return hast_gz_open_multi_ex(&ctx, 1, path, 0, 0, 0, out); }
+int hast_gz_units(const hast_gz *g) { return g ? (int)g->units.size() : 0; }
 
 void hast_gz_close(hast_gz *g) {
     if (!g) return;
@@ -603,38 +698,48 @@ void hast_gz_close(hast_gz *g) {
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->stop = true;
-        for (Arena &a : g->arena) a.busy = false;
+        for (auto &u : g->units)
+            for (Arena &a : u->arena) a.busy = false;
         g->cv.notify_all();
     }
     if (g->uploader.joinable()) g->uploader.join();
     tr("uploader joined");
     if (g->producer.joinable()) g->producer.join();
     tr("producer joined");
-    (void)hipSetDevice(g->device);
-    if (g->dec_stream) (void)hipStreamSynchronize(g->dec_stream);
-    if (g->post_stream) (void)hipStreamSynchronize(g->post_stream);
-    if (g->up_stream) (void)hipStreamSynchronize(g->up_stream);
-    tr("streams drained");
-    for (Arena &a : g->arena) {
-        if (a.done_recorded) (void)hipEventSynchronize(a.done);
-        if (a.done) (void)hipEventDestroy(a.done);
-        for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry}) b->release();
-        for (DevBuf &b : a.gap) b.release();
+    for (auto &up : g->units) {
+        Unit &U = *up;
+        (void)hipSetDevice(U.device);
+        for (hipStream_t st : {U.dec_stream, U.post_stream, U.up_stream, U.xl_stream})
+            if (st) (void)hipStreamSynchronize(st);
+        tr("streams drained");
+        for (Arena &a : U.arena) {
+            if (a.done_recorded) (void)hipEventSynchronize(a.done);
+            if (a.done) (void)hipEventDestroy(a.done);
+            for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry}) b->release();
+            for (DevBuf &b : a.gap) b.release();
+        }
+        for (int i = 0; i < 2; ++i) {
+            U.jobs[i].release();
+            if (U.h_jobs[i]) (void)hipHostFree(U.h_jobs[i]);
+            if (U.nom_done[i]) (void)hipEventDestroy(U.nom_done[i]);
+        }
+        U.fjobs.release();
+        U.bounce.release();
+        if (U.h_fjobs) (void)hipHostFree(U.h_fjobs);
+        if (U.d_in) (void)hipFree(U.d_in);
+        if (U.h_crc) (void)hipHostFree(U.h_crc);
+        if (U.xl_done) (void)hipEventDestroy(U.xl_done);
+        if (U.up_stream) (void)hipStreamDestroy(U.up_stream);
+        if (U.dec_stream && U.dec_masked_free) masked_stream_put(U.device, U.dec_masked_free, U.dec_stream);     // (drained above)
+        else if (U.dec_stream) (void)hipStreamDestroy(U.dec_stream);
+        if (U.post_stream) (void)hipStreamDestroy(U.post_stream);
+        if (U.xl_stream) (void)hipStreamDestroy(U.xl_stream);
     }
-    for (int i = 0; i < 2; ++i) {
-        g->jobs[i].release();
-        if (g->h_jobs[i]) (void)hipHostFree(g->h_jobs[i]);
-        if (g->nom_done[i]) (void)hipEventDestroy(g->nom_done[i]);
+    for (auto &de : g->in_events) {
+        (void)hipSetDevice(de.first);
+        (void)hipEventDestroy(de.second);
     }
-    g->fjobs.release();
-    if (g->h_fjobs) (void)hipHostFree(g->h_fjobs);
-    g->carry_next.release();
-    if (g->d_in) (void)hipFree(g->d_in);
-    if (g->h_crc) (void)hipHostFree(g->h_crc);
-    if (g->up_stream) (void)hipStreamDestroy(g->up_stream);
-    if (g->dec_stream && g->dec_masked_free) masked_stream_put(g->device, g->dec_masked_free, g->dec_stream);     // (drained above)
-    else if (g->dec_stream) (void)hipStreamDestroy(g->dec_stream);
-    if (g->post_stream) (void)hipStreamDestroy(g->post_stream);
+    if (g->h_carry) (void)hipHostFree(g->h_carry);
     tr("freed");
     if (g->fd >= 0) close(g->fd);
     delete g;
@@ -644,8 +749,39 @@ hast_status hast_gz_read_device(hast_gz *g, uint8_t *d_dst, size_t cap, size_t *
     if (!g || !n_out || (cap && !d_dst)) return set_error(HAST_ERR_INVALID, "null argument");
     *n_out = 0;
     if (!g->err.empty()) return set_error(HAST_ERR_IO, "%s: %s", g->path.c_str(), g->err.c_str());
-    if (hipSetDevice(g->device) != hipSuccess) return set_error(HAST_ERR_HIP, "hipSetDevice failed");
+    // where the caller's buffer lives: the bytes are translated on the unit that decoded them, straight into the buffer when that is
+    // the same GPU, through the unit's bounce buffer and a peer copy otherwise
+    int dst_dev = g->units[0]->device;
+    if (cap && g->units.size() + (g->split_same_device ? 1 : 0) > 1) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_dst) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_error(HAST_ERR_INVALID, "hast_gz_read_device: the destination is not device memory");
+        }
+        dst_dev = at.device;
+    }
+    if (hipSetDevice(dst_dev) != hipSuccess) return set_error(HAST_ERR_HIP, "hipSetDevice failed");
     hipStream_t hs = s ? (hipStream_t)s : ctx_stream_of(g->ctx);
+    // the translate kernels run on the unit's own stream: it waits for what the caller's stream holds now (the buffer's previous
+    // readers), and the caller's stream waits for them in turn
+    hipEvent_t ev_in = nullptr;
+    for (auto &de : g->in_events)
+        if (de.first == dst_dev) ev_in = de.second;
+    if (!ev_in) {
+        if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventCreate failed");
+        g->in_events.push_back({dst_dev, ev_in});
+    }
+    bool in_recorded = false;
+    int last_unit = -1;
+    auto join_back = [&]() -> hast_status {                           // the caller's stream behind the launches on last_unit's stream
+        if (last_unit < 0) return HAST_OK;
+        Unit &U = *g->units[(size_t)last_unit];
+        if (hipSetDevice(U.device) != hipSuccess || hipEventRecord(U.xl_done, U.xl_stream) != hipSuccess || hipSetDevice(dst_dev) != hipSuccess ||
+            hipStreamWaitEvent(hs, U.xl_done, 0) != hipSuccess)
+            return set_error(HAST_ERR_HIP, "hast_gz_read_device: stream hand-over failed");
+        last_unit = -1;
+        return HAST_OK;
+    };
     size_t got = 0;
     while (got < cap && !g->done) {
         if (!g->cur) {
@@ -669,10 +805,29 @@ hast_status hast_gz_read_device(hast_gz *g, uint8_t *d_dst, size_t cap, size_t *
             g->cur.reset();
             break;
         }
-        Arena &A = g->arena[b.arena];
+        Unit &U = *g->units[(size_t)b.unit];
+        Arena &A = U.arena[b.arena];
+        const bool direct = U.device == dst_dev && !g->split_same_device;
+        if (last_unit >= 0 && last_unit != b.unit)
+            if (hast_status st = join_back()) return st;
+        if (!in_recorded) {
+            if (hipSetDevice(dst_dev) != hipSuccess || hipEventRecord(ev_in, hs) != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventRecord failed");
+            in_recorded = true;
+        }
+        if (hipSetDevice(U.device) != hipSuccess) return set_error(HAST_ERR_HIP, "hipSetDevice failed");
+        if (last_unit != b.unit && hipStreamWaitEvent(U.xl_stream, ev_in, 0) != hipSuccess) return set_error(HAST_ERR_HIP, "hipStreamWaitEvent failed");
+        last_unit = b.unit;
         // the bytes [cursor, cursor + want) out of this batch's chunks
         const uint64_t o_lo = g->cursor, o_hi = std::min<uint64_t>(b.out_hi, g->cursor + (cap - got));
         if (o_hi > o_lo) {
+            uint8_t *xl_dst = d_dst + got;
+            if (!direct) {
+                if (U.bounce.bytes < cap) {
+                    // (the stream still reads the old one: drained first; happens once per unit and reader block size)
+                    if (hipStreamSynchronize(U.xl_stream) != hipSuccess || U.bounce.ensure(cap) != hipSuccess) return set_error(HAST_ERR_OOM, "hast_gz_read_device: no room for the hand-over buffer");
+                }
+                xl_dst = static_cast<uint8_t *>(U.bounce.p);
+            }
             size_t c = b.next;
             while (c < b.acc.size()) {
                 // launches of at most 65535 chunks (grid.y)
@@ -684,17 +839,19 @@ hast_status hast_gz_read_device(hast_gz *g, uint8_t *d_dst, size_t cap, size_t *
                 }
                 if (c_end == c) break;
                 const hipError_t e = launch_translate((const AccDev *)A.acc.p, (uint32_t)c, (uint32_t)(c_end - c), max_syms, (const uint8_t *)A.windows.p,
-                                                      (const uint8_t *)A.carry.p, o_lo, o_hi, d_dst + got, hs);
+                                                      (const uint8_t *)A.carry.p, o_lo, o_hi, xl_dst, U.xl_stream);
                 if (e != hipSuccess) return set_error(HAST_ERR_HIP, "translate: %s", hipGetErrorString(e));
                 c = c_end;
             }
+            if (!direct && hipMemcpyPeerAsync(d_dst + got, dst_dev, xl_dst, U.device, (size_t)(o_hi - o_lo), U.xl_stream) != hipSuccess)
+                return set_error(HAST_ERR_HIP, "hast_gz_read_device: peer copy failed");
             got += (size_t)(o_hi - o_lo);
             g->cursor = o_hi;
             while (b.next < b.acc.size() && b.acc[b.next].out_off + b.acc[b.next].job.n_out <= g->cursor) b.next++;
         }
         if (g->cursor >= b.out_hi) {
-            // the batch is through: its arena is free once this stream has run the launches above
-            if (hipEventRecord(A.done, hs) != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventRecord failed");
+            // the batch is through: its arena is free once the unit's stream has run the launches above
+            if (hipEventRecord(A.done, U.xl_stream) != hipSuccess) return set_error(HAST_ERR_HIP, "hipEventRecord failed");
             {
                 std::lock_guard<std::mutex> lk(g->mu);
                 A.done_recorded = true;
@@ -704,6 +861,8 @@ hast_status hast_gz_read_device(hast_gz *g, uint8_t *d_dst, size_t cap, size_t *
             g->cur.reset();
         }
     }
+    if (hast_status st = join_back()) return st;
+    (void)hipSetDevice(dst_dev);
     *n_out = got;
     return HAST_OK;
 }

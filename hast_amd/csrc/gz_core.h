@@ -376,28 +376,47 @@ GZ_HD uint32_t decode_huffman(Bits &in, const Tables &t, uint16_t *sym, uint32_t
 }
 
 // ---- token-parallel decoding (k_gz_decode): what ONE LANE does with the 64 bits of the stream at its own bit offset ----------------
-// A token = one literal, one match (length code + extra bits + distance code + extra bits: at most 15 + 5 + 15 + 13 = 48 bits) or
-// the end-of-block code.  The wave parses a token at each of 64 consecutive bit offsets at once -- most of them are not token
-// starts -- and then walks the chain offset 0 -> 0 + its token's bits -> ... with one scalar read per token, instead of one
-// dependent table look-up per symbol.  info: bits 0-6 = the token's bits (1 .. 48), bits 7.. = kind (0 = a literal or a match
+// A token = one or two literals, one match (length code + extra bits + distance code + extra bits: at most 15 + 5 + 15 + 13 = 48
+// bits) or the end-of-block code.  The wave parses a token at each of 64 consecutive bit offsets at once -- most of them are not
+// token starts -- and then walks the chain offset 0 -> 0 + its token's bits -> ... with one scalar read per token, instead of one
+// dependent table look-up per symbol.  info: bits 0-6 = the token's bits (1 .. 48), bits 7.. = kind (0 = literal(s) or a match
 // of at most 64 symbols: the chain walks on; others stop it).
-constexpr uint32_t kTokEob = 1, kTokLong = 2, kTokErrLit = 3, kTokErrDist = 4;
+// TWO literals per look-up where both codes fit the root bits (pair_entry: bit 8 of a literal's first-level entry says "a second
+// literal in bits 24..31", the length is that of both codes): the bases of a FASTQ record are literals of ~2.2 bits each, quality
+// values mostly fit in pairs too -- half the tokens for the chain to walk.
+// parse_token_fast looks at the FIRST-LEVEL tables only (two dependent look-ups instead of four): a code longer than the root bits
+// -- rare by construction -- makes a kTokSlow token, which stops the chain; the step that starts at it parses in full.
+constexpr uint32_t kTokEob = 1, kTokLong = 2, kTokErrLit = 3, kTokErrDist = 4, kTokSlow = 5;
 struct Token {
     uint32_t info;              // bits | kind << 7
-    uint32_t olen;              // symbols it stands for (literal 1, match 3 .. 258, end of block 0)
-    uint32_t val;               // the literal byte
+    uint32_t olen;              // symbols it stands for (literals 1 or 2, match 3 .. 258, end of block 0)
+    uint32_t val;               // the literal byte(s): first | second << 8
     uint32_t dist;              // match: distance (1 .. 32768), else 0
 };
-GZ_HD Token parse_token(uint64_t v, const uint32_t *lit, const uint32_t *dst) {
+// what first-level entry idx of a literal/length table becomes: itself, or itself and the literal behind it (computed from the table
+// as build_table left it: every entry is worked out before any is replaced)
+GZ_HD uint32_t pair_entry(const uint32_t *lit, uint32_t idx) {
+    const uint32_t e1 = lit[idx], l1 = e1 & 0xFF;
+    if ((e1 & (kLit | kSub)) == kLit && l1 > 0 && l1 < (uint32_t)kLitRoot) {
+        const uint32_t e2 = lit[idx >> l1], l2 = e2 & 0xFF;     // (the bits behind the first code, zeros above them: an entry whose
+        // code is no longer than the bits that are really there does not depend on those zeros)
+        if ((e2 & (kLit | kSub)) == kLit && l2 > 0 && l1 + l2 <= (uint32_t)kLitRoot)
+            return kLit | (1u << 8) | (l1 + l2) | (e1 & 0x00FF0000u) | ((e2 & 0x00FF0000u) << 8);
+    }
+    return e1;
+}
+template <bool kFull>
+GZ_HD Token parse_token_t(uint64_t v, const uint32_t *lit, const uint32_t *dst) {
     constexpr uint32_t LM = (1u << kLitRoot) - 1, DM = (1u << kDistRoot) - 1;
     uint32_t e = lit[(uint32_t)v & LM], used = 0;
     if (e & kSub) {
+        if (!kFull) return Token{1u | (kTokSlow << 7), 0u, 0u, 0u};
         used = (uint32_t)kLitRoot;
         e = lit[(e >> 16) + ((uint32_t)(v >> kLitRoot) & ((1u << ((e >> 8) & 31)) - 1))];
     }
     const uint32_t cl = e & 0xFF;
     used += cl;
-    if (e & kLit) return Token{used, 1u, (e >> 16) & 0xFFu, 0u};
+    if (e & kLit) return Token{used, 1u + ((e >> 8) & 1u), e >> 16, 0u};
     if (cl == 0) return Token{1u | (kTokErrLit << 7), 0u, 0u, 0u};
     if (e & kEob) return Token{used | (kTokEob << 7), 0u, 0u, 0u};
     const uint32_t leb = (e >> 8) & 31;
@@ -405,6 +424,7 @@ GZ_HD Token parse_token(uint64_t v, const uint32_t *lit, const uint32_t *dst) {
     used += leb;
     uint32_t d = dst[(uint32_t)(v >> used) & DM];
     if (d & kSub) {
+        if (!kFull) return Token{1u | (kTokSlow << 7), 0u, 0u, 0u};
         used += (uint32_t)kDistRoot;
         d = dst[(d >> 16) + ((uint32_t)(v >> used) & ((1u << ((d >> 8) & 31)) - 1))];
     }
@@ -416,6 +436,8 @@ GZ_HD Token parse_token(uint64_t v, const uint32_t *lit, const uint32_t *dst) {
     used += deb;
     return Token{used | (len > 64 ? kTokLong << 7 : 0u), len, 0u, distance};
 }
+GZ_HD Token parse_token(uint64_t v, const uint32_t *lit, const uint32_t *dst) { return parse_token_t<true>(v, lit, dst); }
+GZ_HD Token parse_token_fast(uint64_t v, const uint32_t *lit, const uint32_t *dst) { return parse_token_t<false>(v, lit, dst); }
 
 // Blocks from job.start_bit on, until the first boundary >= job.stop_bit, a final block, or where room / input / validity end.
 // Everything is committed boundary by boundary.  w / nbits: the whole compressed buffer; tabs: this lane's kTabWords words.

@@ -198,21 +198,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {              //
     return x;
 }
 
-// 4 waves per SIMD (128 VGPRs): a chunk's time is latency, so chunks in flight are throughput; 16 per CU (9 KB of LDS each).
+// 4 waves per SIMD (128 VGPRs): a chunk's time is latency, so chunks in flight are throughput; 16 per CU (9.8 KB of LDS each).
 // syms: the base of the symbol memory the jobs' buffers lie in (job.sym_off is an absolute address / 2: the buffer is reached as
 // syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
 // which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
 // symbol instead of ~300)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
-    __shared__ uint32_t s_tab[kTabWords];
+    __shared__ uint32_t s_tab[kLitTabCap + kDistTabCap];
+    // two lives: while lane 0 parses a block's header, the code-length code's table (kPreTabCap words) and what the parse indexes by
+    // values it has just read (HdrScratch: no scratch memory); in the symbol loop, the compressed words around the read position
+    // (WIn: 128 words) and a round's tokens at the lanes of their symbols (64 words)
+    constexpr uint32_t kScrWords = (sizeof(HdrScratch) + 3) / 4;
+    __shared__ uint32_t s_misc[kPreTabCap + (kScrWords > 64 ? kScrWords : 64)];
     __shared__ uint32_t s_hdr[4];                                             // lane 0's header parse: error, bit position behind the header (lo, hi)
-    __shared__ HdrScratch s_scr;                                              // ... and what it indexes by values it has just read (no scratch memory)
-    __shared__ uint32_t s_in[128];                                            // compressed words around the read position (WIn)
-    __shared__ uint32_t s_tok[64];                                            // a round's tokens, each at the lane of its first symbol
-    // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the few records in front) is
+    uint32_t *const s_in = s_misc, *const s_tok = s_misc + kPreTabCap;
+    // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the record or two in front) is
     // copied out of LDS -- a global load per match would put ~1 us of latency on the path of every symbol behind it
-    constexpr uint32_t kRing = 512, kRingReach = kRing - 320;
+    constexpr uint32_t kRing = 1024, kRingReach = kRing - 320;
     __shared__ uint16_t s_ring[kRing];
+    constexpr uint32_t kIsLit = 0x40000000u, kIsMatch = 0x80000000u;
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob job = jobs[j];
@@ -227,7 +231,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const uint32_t cap = job.sym_cap;
     const bool no_history = (job.flags & kJobNoHistory) != 0;
     const uint32_t *const lit = s_tab, *const dst = s_tab + kLitTabCap;
-    WIn in{w, ((nbits + 31) >> 5) + 2, ~0ull >> 1, 0};                       // (rb far away: the first win_at loads the ring)
+    constexpr uint64_t kFarAway = ~0ull >> 1;
+    WIn in{w, ((nbits + 31) >> 5) + 2, kFarAway, 0};                         // (rb far away: the first win_at loads the ring)
     uint64_t at = job.start_bit;
     uint32_t n = 0, status = kStFound, err = kErrNone;
     bool any = false;
@@ -271,16 +276,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             break;
         } else {
             // tables for this block: lane 0 parses the header / builds them in LDS (gz_core.h), the wave waits
-            __syncthreads();                                                  // (everyone is done with the previous block's tables)
+            __syncthreads();                                                  // (everyone is done with the previous block's tables, words and tokens)
             if (lane == 0) {
-                Tables t = tables_at(s_tab);
+                Tables t{s_tab, s_tab + kLitTabCap, s_misc};
+                HdrScratch &scr = *reinterpret_cast<HdrScratch *>(s_misc + kPreTabCap);
                 uint32_t bad = 0;
                 uint64_t behind = at + 3;
-                if (type == 1) fixed_tables(t, s_scr);
+                if (type == 1) fixed_tables(t, scr);
                 else {
                     Bits hb{w, nbits, 0, 0, 0};
                     seek(hb, behind);
-                    bad = read_dynamic(hb, t, false, true, s_scr);
+                    bad = read_dynamic(hb, t, false, true, scr);
                     if (overran(hb)) bad = 0x80000000u;                       // (also an "error" read out of the padding: the block is not all here)
                     behind = pos(hb);
                 }
@@ -296,32 +302,58 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 break;
             }
             uint64_t pos = (uint64_t)s_hdr[1] | ((uint64_t)s_hdr[2] << 32);
+            in.rb = kFarAway;                                                 // (the header parse has used the words' place)
+            {   // two literals per first-level entry where both codes fit (gz_core.h pair_entry): all 64 lanes, 8 entries each, every
+                // entry worked out before any is replaced (LDS operations of a wave execute in order)
+                uint32_t pe[(1u << kLitRoot) / 64];
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) pe[q] = pair_entry(lit, q * 64 + lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) s_tab[q * 64 + lane] = pe[q];
+                __syncthreads();
+            }
             // ---- the block's symbols, a step = the 64 bit offsets from pos on ----
-            bool block_done = false;
+            bool block_done = false, full = false;
             while (!block_done && !rc) {
                 if (pos >= nbits) { rc = kStStarved; break; }
                 const uint64_t avail = nbits - pos;
                 const uint32_t limit = avail < 64 ? (uint32_t)avail : 64u;
                 win_at(in, s_in, pos);
-                const Token tk = parse_token(win_bits(in, s_in, pos), lit, dst);
+                const uint64_t bits = win_bits(in, s_in, pos);
+                // (first-level tables only; a step that starts at a code longer than those looks into the second level too)
+                const Token tk = full ? parse_token(bits, lit, dst) : parse_token_fast(bits, lit, dst);
+                full = false;
                 const uint32_t need = tk.dist ? (tk.dist > tk.olen ? tk.dist - tk.olen : 0u) : 0xFFFFu;      // symbols of the round that may stand in front of it
                 uint32_t p = 0;
                 for (;;) {                                                    // the chain, from one stop to the next
+                    // while (p < limit) { t = info of lane p; if (t >= 128) { stop = t; break; }  tokmask |= 1 << p;  p += t; } -- by hand: six
+                    // scalar instructions per token (the compiler turns the early exit into selects: sixteen)
                     uint64_t tokmask = 0;
-                    uint32_t stop = 0;
-                    while (p < limit) {
-                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tk.info, (int)p);
-                        if (t >= 128) { stop = t; break; }
-                        tokmask |= 1ull << p;
-                        p += t;
-                    }
+                    uint32_t stop;
+                    asm volatile("s_mov_b32 %[t], 0\n\t"
+                                 "s_cmp_lt_u32 %[p], %[limit]\n\t"
+                                 "s_cbranch_scc0 2f\n"
+                                 "1:\n\t"
+                                 "v_readlane_b32 %[t], %[info], %[p]\n\t"
+                                 "s_cmpk_ge_u32 %[t], 0x80\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_bitset1_b64 %[mask], %[p]\n\t"
+                                 "s_add_u32 %[p], %[p], %[t]\n\t"
+                                 "s_cmp_lt_u32 %[p], %[limit]\n\t"
+                                 "s_cbranch_scc1 1b\n\t"
+                                 "s_mov_b32 %[t], 0\n"
+                                 "2:\n"
+                                 : [t] "=&s"(stop), [mask] "+s"(tokmask), [p] "+s"(p)
+                                 : [info] "v"(tk.info), [limit] "s"(limit)
+                                 : "scc");
                     if (!stop && p > avail) { rc = kStStarved; break; }       // the last token reads past the input that is there
                     if (tokmask) {
                         const bool is_tok = (tokmask >> lane) & 1;
                         const uint32_t incl = wave_incl_scan(is_tok ? tk.olen : 0u), start = incl - (is_tok ? tk.olen : 0u);
                         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         if (__ballot(is_tok && tk.dist > n2 + start && (no_history || tk.dist > kWindow))) { err = kErrTooFar; rc = kStError; break; }
-                        const uint32_t tokval = (tk.dist << 14) | ((tk.dist ? tk.olen : tk.val) << 6);     // + its first symbol's place in the round
                         uint32_t base = 0;
                         uint64_t rem = tokmask;
                         while (rem) {
@@ -335,40 +367,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                 nsym = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)fv) - base;
                             }
                             if (n2 + nsym > cap) { rc = kStNoRoom; break; }
-                            // every token to the lane of its first symbol; a lane's token is the last one that starts at or in front of it
+                            // the round's tokens at the lanes of their symbols: literals as themselves, a match at its first symbol (the
+                            // lanes behind it find it: the last match that starts at or in front of them)
                             __builtin_amdgcn_wave_barrier();
                             s_tok[lane] = 0;
-                            if ((cur >> lane) & 1) s_tok[start - base] = tokval | (start - base) | 0x80000000u;
+                            if ((cur >> lane) & 1) {
+                                const uint32_t st = start - base;
+                                if (tk.dist) s_tok[st] = kIsMatch | st | (tk.dist << 14);
+                                else {
+                                    s_tok[st] = kIsLit | (tk.val & 0xFF);
+                                    if (tk.olen == 2) s_tok[st + 1] = kIsLit | (tk.val >> 8);
+                                }
+                            }
                             __builtin_amdgcn_wave_barrier();
                             const uint32_t mine = s_tok[lane];
-                            const unsigned long long smask = __ballot(mine != 0);
-                            const unsigned long long upto = smask & (~0ull >> (63 - lane));              // (bit 0 is set: a token starts the round)
-                            const uint32_t leader = 63u - (uint32_t)__builtin_clzll(upto | 1ull);
-                            const uint32_t tv = (uint32_t)__shfl((int)mine, (int)leader, 64);
+                            const unsigned long long mm = __ballot((mine & kIsMatch) != 0);
                             const bool act = lane < nsym;
-                            const uint32_t off = tv & 63, val = (tv >> 6) & 0xFF, dist = (tv >> 14) & 0xFFFF, k = lane - off;
                             const uint32_t bstart = n2;
-                            const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;                  // positions the ring still holds while this round is written
-                            int64_t src = 0;
-                            if (dist) {
+                            uint16_t v = (uint16_t)(mine & 0xFF);
+                            if (mm) {
+                                const unsigned long long upto = mm & (~0ull >> (63 - lane));
+                                const uint32_t leader = 63u - (uint32_t)__builtin_clzll(upto | 1ull);
+                                const uint32_t tv = (uint32_t)__shfl((int)mine, (int)leader, 64);
+                                const bool is_m = act && !(mine & kIsLit);
+                                const uint32_t off = tv & 63, dist = (tv >> 14) & 0xFFFF, k = lane - off;
+                                const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;              // positions the ring still holds while this round is written
                                 uint32_t kk = k;
                                 if (k >= dist) {                               // a run: symbol k repeats symbol k mod dist (k < 64: exact in float)
                                     const uint32_t q = (uint32_t)(((float)k + 0.5f) * __frcp_rn((float)dist));
                                     kk = k - q * dist;
                                 }
-                                src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)kk;
-                            }
-                            const bool far = act && dist && src >= 0 && src < ring_lo;
-                            // a copy out of the symbol buffer itself reads what this wave stored a while ago: the stores must have reached the L2
-                            // (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache maintenance:
-                            // an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the GPU 10 x slower
-                            if (__ballot(far)) __builtin_amdgcn_s_waitcnt(0);
-                            uint16_t v = 0;
-                            if (act) {
-                                if (!dist) v = (uint16_t)val;
-                                else if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
-                                else if (far) v = sym_load_far(sym + src);
-                                else v = s_ring[(uint32_t)src & (kRing - 1)];
+                                const int64_t src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)kk;
+                                const bool far = is_m && src >= 0 && src < ring_lo;
+                                // a copy out of the symbol buffer itself reads what this wave stored a while ago: the stores must have reached the L2
+                                // (s_waitcnt: every store of this wave acknowledged) and the loads go there (sc1, past the L1).  No cache maintenance:
+                                // an agent-scope fence here writes back and invalidates the L2 -- measured: every kernel on the GPU 10 x slower
+                                if (__ballot(far)) __builtin_amdgcn_s_waitcnt(0);
+                                if (is_m) {
+                                    if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
+                                    else if (far) v = sym_load_far(sym + src);
+                                    else v = s_ring[(uint32_t)src & (kRing - 1)];
+                                }
                             }
                             // (every lane has read before any lane writes: LDS operations of a wave execute in order)
                             __builtin_amdgcn_wave_barrier();
@@ -384,6 +423,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     }
                     if (!stop) break;
                     const uint32_t kind = stop >> 7, tl = stop & 127;
+                    if (kind == kTokSlow) {                                   // the step that starts here parses in full
+                        full = true;
+                        break;
+                    }
                     if (kind == kTokErrLit || kind == kTokErrDist) {
                         if (p + 48 > avail) rc = kStStarved;                  // (read out of what is not there yet)
                         else { err = kind == kTokErrLit ? kErrLitCode : kErrDistCode; rc = kStError; }

@@ -301,6 +301,11 @@ hast_status hast_fq_create_ex(hast_ctx *, size_t block_bytes, int n_buffers, has
  * cache per context, or NULL. */
 hast_status hast_fq_create_striped(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx,
                                    hast_names *const *names_or_null, hast_fq **out);
+/* device_blocks != 0: a striped stream of device-side blocks (hast_fq_device_block / hast_fq_submit_device) -- what a .gz file
+ * inflated on the GPUs feeds (hast_gz_open_multi): block i's bytes are written on GPU i % n_ctx by the caller's kernels, the first
+ * bytes of block i + 1 reach block i's view by a copy from that GPU to this one, no pinned host copy of the blocks is set up. */
+hast_status hast_fq_create_striped_ex(hast_ctx *const *ctxs, int n_ctx, size_t block_bytes, int n_buffers_per_ctx,
+                                      hast_names *const *names_or_null, int device_blocks, hast_fq **out);
 int         hast_fq_lanes(const hast_fq *);                      /* contexts the stream's blocks rotate over (1 for hast_fq_create) */
 uint64_t    hast_fq_lane_records(const hast_fq *, int lane);     /* records opened so far on that context (striped streams) */
 void        hast_fq_destroy(hast_fq *);
@@ -311,7 +316,8 @@ hast_status hast_fq_submit(hast_fq *, size_t n_bytes, int last);
  * hast_fq_acquire (its host buffer stays unused), hast_fq_device_block gives the device address the block's bytes belong at and
  * the stream the writes must be enqueued on; hast_fq_submit_device then frames them where they lie -- no upload.  At most
  * n_buffers - 1 blocks may be in hand (hast_fq_device_block called, not yet submitted) at a time.  A stream takes
- * host blocks or device blocks, not both; striped streams take host blocks only.  hast_fq_block.bytes is NULL for such a block:
+ * host blocks or device blocks, not both.  On a striped stream block i's address lies on GPU i % n_ctx and the stream is that
+ * GPU's.  hast_fq_block.bytes is NULL for such a block:
  * hast_fq_block_host_bytes (valid between hast_fq_next and hast_fq_commit, for any block) fetches the host copy when the caller
  * needs the text behind bc_pos / bc_len -- a barcode longer than the 15 bytes bc_text holds. */
 hast_status hast_fq_device_block(hast_fq *, uint8_t **d_block, hast_stream *fill_stream);
@@ -335,8 +341,11 @@ hast_status hast_fq_commit(hast_fq *);
  * hast_gz_open: HAST_ERR_UNSUPPORTED when the path is not a regular file, does not start with a gzip member (zlib passes such a
  * file through as it is) or the device has no room -- the caller then inflates on the host; HAST_ERR_IO when it cannot be read.
  * hast_gz_read_device: the next up to `cap` bytes of the inflated stream, written to d_dst by a kernel on `stream` (NULL: the
- * context's); *n_out < cap only at the end of the stream (0 = nothing left).  Blocks until those bytes are decoded.  A damaged or
- * truncated file is HAST_ERR_IO -- after what could be decoded in front of the damage has been delivered, as gzread does.
+ * context's); *n_out < cap at the end of the stream (0 = nothing left) -- or when damage follows what was delivered: a damaged or
+ * truncated file is HAST_ERR_IO only AFTER what could be decoded in front of the damage has been handed over, as gzread does, i.e.
+ * with the call behind a short one.  A caller must therefore read on until a call returns 0 bytes (or an error) before it takes the
+ * stream for complete.  Blocks until the bytes it returns are decoded.  HAST_GZ_CHUNK_BYTES / HAST_GZ_PASS_CHUNKS in the environment
+ * set the geometry of hast_gz_open (tests: many passes over a small file).
  * One reader per object; several of them -- one per input file -- run side by side. */
 typedef struct hast_gz hast_gz;
 typedef struct {
@@ -352,6 +361,19 @@ typedef struct {
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
 /* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 4096), symbols of room per compressed byte (0 = 12) */
 hast_status hast_gz_open_ex(hast_ctx *, const char *path, size_t chunk_bytes, size_t chunks_per_pass, double room, hast_gz **out);
+/* ONE .gz file inflated by several GPUs (the reference deals the reads of one file to all its workers whatever the file's encoding,
+ * classify.cpp:211-219,245-254; HAST's inputs are two .fq.gz files, HAST.sh:162-166): the passes of the one deflate stream (4096
+ * chunks each) go to the GPUs of ctxs[] in turn -- a chunk's decode into marker symbols needs nothing from its neighbours -- one
+ * "unit" per distinct device (contexts that share a GPU share it), each with the whole compressed file, its own symbol arenas and
+ * streams; the chain of accepted chunks is one, the 32-KB window a pass leaves travels to the next pass's GPU through pinned host
+ * memory, CRC-32 / ISIZE are checked as for one GPU.  hast_gz_read_device then takes a destination on ANY of those GPUs (it asks
+ * the runtime where the pointer lives): the bytes are translated on the unit that decoded them and, when that is another GPU,
+ * copied over peer to peer -- e.g. into the device-side blocks of a striped FASTQ stream (hast_fq_create_striped).
+ * HAST_GZ_SPLIT=contexts in the environment: one unit per CONTEXT even where contexts share a GPU, and every read through the
+ * hand-over buffer + peer copy (the several-GPU paths on one GPU, for tests).  hast_gz_units: how many units the stream has. */
+hast_status hast_gz_open_multi(hast_ctx *const *ctxs, int n_ctx, const char *path, hast_gz **out);
+hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *path, size_t chunk_bytes, size_t chunks_per_pass, double room, hast_gz **out);
+int         hast_gz_units(const hast_gz *);
 hast_status hast_gz_read_device(hast_gz *, uint8_t *d_dst, size_t cap, size_t *n_out, hast_stream);
 hast_status hast_gz_get_stats(hast_gz *, hast_gz_stats *out);
 void        hast_gz_close(hast_gz *);

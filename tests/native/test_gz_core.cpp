@@ -28,8 +28,10 @@ static bool g_wave = false;      // -w: Huffman blocks decoded the way k_gz_deco
 // reach rule is checked (what the kernel would read there must be what the symbol buffer holds).
 static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &pos, const uint32_t *lit, const uint32_t *dst, uint16_t *sym,
                                   uint32_t &n_out, uint32_t cap, bool no_history, uint32_t &err, uint16_t *ring) {
-    constexpr uint32_t kRing = 512, kRingReach = kRing - 320;
+    constexpr uint32_t kRing = 1024, kRingReach = kRing - 320;
+    constexpr uint32_t kIsLit = 0x40000000u, kIsMatch = 0x80000000u;
     uint32_t n2 = n_out;
+    bool full = false;                                               // this step parses with the second-level tables too
     auto ring_at = [&](int64_t src) {
         const uint16_t v = ring[(uint32_t)src & (kRing - 1)];
         if (v != sym[src]) { fprintf(stderr, "ring reach rule broken at %lld\n", (long long)src); abort(); }
@@ -40,8 +42,11 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
         const uint64_t avail = nbits - pos;
         const uint32_t limit = avail < 64 ? (uint32_t)avail : 64u;
         Token tk[64];
-        for (uint32_t lane = 0; lane < 64; ++lane) tk[lane] = parse_token(bits_at(w, pos + lane), lit, dst);
+        for (uint32_t lane = 0; lane < 64; ++lane) tk[lane] = full ? parse_token(bits_at(w, pos + lane), lit, dst) : parse_token_fast(bits_at(w, pos + lane), lit, dst);
+        const bool was_full = full;
+        full = false;
         uint32_t p = 0;
+        bool again = false;
         for (;;) {
             uint64_t tokmask = 0;
             uint32_t stop = 0;
@@ -76,23 +81,38 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
                 if (n2 + nsym > cap) return kStNoRoom;
                 const uint32_t bstart = n2;
                 const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;
+                // the round's tokens at the lanes of their symbols: literals as themselves, a match at its first symbol
+                uint32_t s_tok[64];
+                for (uint32_t j = 0; j < 64; ++j) s_tok[j] = 0;
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    if (!((cur >> lane) & 1)) continue;
+                    const uint32_t st = start[lane] - base;
+                    if (tk[lane].dist) s_tok[st] = kIsMatch | st | (tk[lane].dist << 14);
+                    else {
+                        s_tok[st] = kIsLit | (tk[lane].val & 0xFF);
+                        if (tk[lane].olen == 2) s_tok[st + 1] = kIsLit | (tk[lane].val >> 8);
+                    }
+                }
                 uint16_t outv[64];
                 for (uint32_t j = 0; j < nsym; ++j) {
+                    const uint32_t mine = s_tok[j];
+                    if (mine & kIsLit) { outv[j] = (uint16_t)(mine & 0xFF); continue; }
                     uint32_t L = 64;
-                    for (uint32_t lane = 0; lane < 64; ++lane)
-                        if (((cur >> lane) & 1) && start[lane] - base <= j) L = lane;      // the last token that starts at or in front of j
-                    const uint32_t off = start[L] - base, k = j - off, dist = tk[L].dist;
-                    if (k >= tk[L].olen) { fprintf(stderr, "leader logic broken\n"); abort(); }
-                    uint16_t v;
-                    if (!dist) v = (uint16_t)tk[L].val;
-                    else {
-                        const int64_t src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)(k < dist ? k : k % dist);
-                        if (src >= (int64_t)bstart) { fprintf(stderr, "source inside its own round\n"); abort(); }
-                        if (src < 0) v = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
-                        else if (src < ring_lo) v = sym[src];
-                        else v = ring_at(src);
+                    for (uint32_t q = 0; q <= j; ++q)
+                        if (s_tok[q] & kIsMatch) L = q;                  // the last match that starts at or in front of j
+                    if (L == 64) { fprintf(stderr, "a symbol without a token\n"); abort(); }
+                    const uint32_t tv = s_tok[L], off = tv & 63, dist = (tv >> 14) & 0xFFFF, k = j - off;
+                    uint32_t kk = k;
+                    if (k >= dist) {
+                        const uint32_t q = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)dist));
+                        kk = k - q * dist;
+                        if (kk != k % dist) { fprintf(stderr, "float modulo broken\n"); abort(); }
                     }
-                    outv[j] = v;
+                    const int64_t src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)kk;
+                    if (src >= (int64_t)bstart) { fprintf(stderr, "source inside its own round\n"); abort(); }
+                    if (src < 0) outv[j] = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
+                    else if (src < ring_lo) outv[j] = sym[src];
+                    else outv[j] = ring_at(src);
                 }
                 for (uint32_t j = 0; j < nsym; ++j) {
                     ring[(bstart + j) & (kRing - 1)] = outv[j];
@@ -104,6 +124,13 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
             }
             if (!stop) break;
             const uint32_t kind = stop >> 7, tl = stop & 127;
+            if (kind == kTokSlow) {
+                // a code longer than the first-level table: the step that starts at this token looks into the second level as well
+                if (was_full) { fprintf(stderr, "a slow token in a full parse\n"); abort(); }
+                full = true;
+                again = true;
+                break;
+            }
             if (kind == kTokErrLit || kind == kTokErrDist) {
                 if (p + 48 > avail) return kStStarved;               // (read out of what is not there yet)
                 err = kind == kTokErrLit ? kErrLitCode : kErrDistCode;
@@ -135,6 +162,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
             n2 += len;
             p += tl;
         }
+        (void)again;
         pos += p;
     }
 }
@@ -143,7 +171,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
 static void decode_chunk_wave(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32_t *tabs, uint16_t *sym) {
     Tables t = tables_at(tabs);
     HdrScratch scr;
-    static uint16_t ring[512];
+    static uint16_t ring[1024];
     const bool no_history = (job.flags & kJobNoHistory) != 0;
     uint64_t at = job.start_bit;
     uint32_t n = 0, status = kStFound, err = kErrNone;
@@ -170,7 +198,7 @@ static void decode_chunk_wave(ChunkJob &job, const uint32_t *w, uint64_t nbits, 
             if (n + len + 4 > job.sym_cap) { status |= kStNoRoom; break; }
             for (uint32_t k = 0; k < len; ++k) {
                 sym[n + k] = bytes[4 + k];
-                ring[(n + k) & 511] = bytes[4 + k];
+                ring[(n + k) & 1023] = bytes[4 + k];
             }
             n2 = n + len;
             at = (byte + 4 + len) * 8;
@@ -187,6 +215,11 @@ static void decode_chunk_wave(ChunkJob &job, const uint32_t *w, uint64_t nbits, 
                 break;
             }
             if (overran(in)) { status |= kStStarved; break; }
+            {   // two literals per first-level entry where both codes fit (every entry worked out before any is replaced)
+                uint32_t paired[1u << kLitRoot];
+                for (uint32_t i = 0; i < (1u << kLitRoot); ++i) paired[i] = pair_entry(t.lit, i);
+                memcpy(t.lit, paired, sizeof(paired));
+            }
             uint64_t p = pos(in);
             const uint32_t rc = decode_block_wave(w, nbits, p, t.lit, t.dist, sym, n2, job.sym_cap, no_history, err, ring);
             if (rc) { status |= rc; break; }

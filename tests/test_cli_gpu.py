@@ -245,6 +245,47 @@ def test_cli_gz_decoders_agree_and_damaged_gz_is_an_error(exe, golden_workdir, t
             assert r.returncode == 2 and r.stdout == b"", (len(damaged), r.stderr[-300:])
 
 
+def test_cli_gz_damaged_behind_the_first_pass_is_an_error(exe, golden_workdir, tmp_path):
+    """Damage that the device inflate meets AFTER it has delivered bytes (a later pass of a large file; here: passes of 4 chunks of
+    2 KB, so that the golden file spans dozens of them): hast_gz_read_device hands over what it had decoded in front of the damage
+    and reports the error with the NEXT call, as gzread does -- the program must make that call instead of taking the short block for
+    the end of the file (it printed a table of the reads in front of the damage and left with 0)."""
+    import shutil
+    d = tmp_path / "gz"
+    shutil.copytree(golden_workdir / "rand_k21", d)
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "r1.fq.gz", "--read", "r2.fq.gz"]
+    small = dict(os.environ, HAST_GZ_CHUNK_BYTES="2048", HAST_GZ_PASS_CHUNKS="4")
+    a = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([exe] + args + ["--stats"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=small)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 100
+    chunks = [int(l.split(b"chunks=")[1].split()[0]) for l in b.stderr.splitlines() if l.startswith(b"__stats_gz__")]
+    assert len(chunks) == 2 and min(chunks) > 40, chunks                          # many passes per file
+    whole = (d / "r2.fq.gz").read_bytes()
+    for frac in (0.5, 0.75, 0.97):
+        flipped = bytearray(whole)
+        flipped[int(len(whole) * frac)] ^= 0x10
+        for damaged in (whole[:int(len(whole) * frac)], bytes(flipped)):
+            (d / "r2.fq.gz").write_bytes(damaged)
+            for blocks in ([], ["--batch-reads", "200"], ["--devices", "0,0"]):
+                r = subprocess.run([exe] + args + blocks, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=small)
+                assert r.returncode == 2 and r.stdout == b"", (frac, len(damaged), blocks, r.returncode, r.stderr[-300:])
+
+
+def test_cli_output_errors_are_not_exit_0(exe, golden_workdir):
+    """stdout on a full device (the wrapper redirects it into phased.barcodes and tests only the exit status,
+    classify_stlfr_reads.sh:149): exit 2 and a message, not a truncated table behind exit 0 -- `classify` and `classify_read`"""
+    case, run = golden_cases("s01")[0]
+    meta = load_case(case)["runs"][run]
+    with open("/dev/full", "wb") as full:
+        r = subprocess.run([exe] + meta["argv"], cwd=golden_workdir / case, stdout=full, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 2 and b"writing the result to stdout failed" in r.stderr, r.stderr[-300:]
+    case, run = golden_cases("s03")[0]
+    meta = load_case(case)["runs"][run]
+    with open("/dev/full", "wb") as full:
+        r = subprocess.run([hast_amd.classify_read_exe()] + meta["argv"], cwd=golden_workdir / case, stdout=full, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 2 and b"writing the result to stdout failed" in r.stderr, r.stderr[-300:]
+
+
 def test_cli_device_inflate_long_barcodes_and_odd_files(exe, oracle_dir, tmp_path):
     """Device-side blocks hand the host no copy of their bytes: a barcode longer than the 15 bytes of the framer's compact copy makes
     the program fetch the block; a ".gz" that is not gzip, an empty .gz and a blocked-gzip (BGZF) file take the host route; == oracle."""

@@ -199,14 +199,29 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
     assert int(e[0].sum()) + int(e[1].sum()) > 100
 
 
-def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=4096, gz_pass=7):
+def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=4096, gz_pass=7, more_ctxs=()):
     """the same walk with DEVICE-side blocks: a .gz file inflated on the GPU (hast_gz_read_device) straight into the framer's block
-    buffers (hast_fq_device_block / hast_fq_submit_device); `lag` blocks are kept in hand, filled but not yet submitted"""
+    buffers (hast_fq_device_block / hast_fq_submit_device); `lag` blocks are kept in hand, filled but not yet submitted.
+    more_ctxs: a STRIPED stream of device blocks over those contexts as well (n_buffers per context), fed by ONE deflate stream whose
+    passes go to the contexts' GPUs in turn (hast_gz_open_multi_ex)"""
     lib = hast_amd.lib()
     fq, nm = C.c_void_p(), C.c_void_p()
-    if cache:
-        assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
-    assert lib.hast_fq_create_ex(ctx._h, block, n_buffers, nm, 1, C.byref(fq)) == 0, lib.hast_last_error()
+    ctxs = [ctx] + list(more_ctxs)
+    nms = []
+    if len(ctxs) > 1:
+        for c in ctxs:
+            h = C.c_void_p()
+            if cache:
+                assert lib.hast_names_create(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
+            nms.append(h)
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        narr = (C.c_void_p * len(ctxs))(*[h.value for h in nms])
+        assert lib.hast_fq_create_striped_ex(arr, len(ctxs), block, n_buffers, narr, 1, C.byref(fq)) == 0, lib.hast_last_error()
+        n_buffers *= len(ctxs)
+    else:
+        if cache:
+            assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
+        assert lib.hast_fq_create_ex(ctx._h, block, n_buffers, nm, 1, C.byref(fq)) == 0, lib.hast_last_error()
     names, got, st = {}, [], {"n_bases": 0, "fetched": 0}
     short = []
 
@@ -233,10 +248,13 @@ def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=40
         st["n_bases"] += b.n_bases
         assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
 
-    with hast_amd.GzReader(ctx, gz_path, gz_chunk, gz_pass) as z:
+    with hast_amd.GzReader(ctx, gz_path, gz_chunk, gz_pass, ctxs=ctxs if len(ctxs) > 1 else None) as z:
+        st["units"] = z.units()
         in_hand, submitted, opened, eof = [], 0, 0, False
         while not (eof and not in_hand and opened == submitted):
             in_use = (submitted - opened) + len(in_hand)
+            # (a block of a striped stream can be opened once the block behind it has been submitted, or it ends the file)
+            can_open = opened < submitted and (len(ctxs) == 1 or submitted - opened >= 2 or (eof and not in_hand))
             if not eof and len(in_hand) < lag and in_use < n_buffers:
                 buf = C.POINTER(C.c_uint8)()
                 assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
@@ -251,12 +269,17 @@ def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=40
                 assert lib.hast_fq_submit_device(fq, n, 1 if (eof and not in_hand) else 0) == 0, lib.hast_last_error()
                 submitted += 1
             else:
-                assert opened < submitted
+                assert can_open, (opened, submitted, in_hand, eof)
                 drain()
                 opened += 1
+    if len(ctxs) > 1:
+        st["lane_records"] = [lib.hast_fq_lane_records(fq, g) for g in range(len(ctxs))]
     lib.hast_fq_destroy(fq)
-    if nm:
-        lib.hast_names_destroy(nm)
+    for h in nms + [nm]:
+        if h:
+            lib.hast_names_destroy(h)
+    if len(ctxs) > 1:
+        return got, names, st["n_bases"], short, st["fetched"], st["lane_records"], st["units"]
     return got, names, st["n_bases"], short, st["fetched"]
 
 
@@ -297,6 +320,55 @@ def test_fq_device_blocks_filled_by_the_gpu_inflate(oracle_lib, tmp_path, tail, 
     oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, ids.size, e[0].ctypes.data, e[1].ctypes.data, e[2].ctypes.data, None, 2)
     oracle_lib.ho_free(oc)
     for a, b in zip(counts, e):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("block,n_ctx,n_buffers,lag", [(4096, 2, 2, 2), (4096, 3, 2, 4), (20480, 4, 2, 3), (65536, 2, 3, 1)])
+@pytest.mark.parametrize("tail", ["plain", "bases_no_newline"])
+def test_fq_striped_device_blocks_one_gz_stream_over_several_contexts(oracle_lib, tmp_path, monkeypatch, tail, block, n_ctx, n_buffers, lag, split):
+    """ONE .gz file over several contexts (the reference deals the reads of one file to all its workers whatever its
+    encoding, classify.cpp:211-219,245-254): the passes of the deflate stream rotate over the contexts' GPUs (hast_gz_open_multi_ex),
+    the inflated bytes are written on the device into the blocks of a STRIPED framer (block i on context i % n, framed from the
+    newline count in front of it, the first bytes of block i + 1 copied into block i's view device to device).  All contexts sit on
+    the test box's one GPU; split = HAST_GZ_SPLIT=contexts makes every context a decode unit of its own with its own copy of the
+    compressed bytes, the window handed from unit to unit, and every block translated into a hand-over buffer and copied "peer to
+    peer" -- the several-GPU code, on one GPU.  Records, barcode text, base counts, summed counters == the reference's framing."""
+    import gzip
+    if split:
+        monkeypatch.setenv("HAST_GZ_SPLIT", "contexts")
+    rng = random.Random(SEEDS[tail] * 131 + block + lag + n_ctx)
+    k, n_keys = 21, 3000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    data = make_fastq(rng, 3000, k, np.concatenate(keys), tail)
+    want = reference_framing(data, oracle_lib)
+    gz = tmp_path / "reads.fq.gz"
+    with gzip.open(gz, "wb", compresslevel=6) as f:
+        f.write(data)
+    lib = hast_amd.lib()
+    ctxs = [hast_amd.Context(k) for _ in range(n_ctx)]
+    try:
+        ctxs[0].table_reserve(2 * n_keys)
+        ctxs[0].table_insert_keys(0, keys[0])
+        ctxs[0].table_insert_keys(1, keys[1])
+        for c in ctxs[1:]:
+            assert lib.hast_table_clone(c._h, ctxs[0]._h) == 0, lib.hast_last_error()
+        for c in ctxs:
+            c.counts_resize(4096)
+        got, names, n_bases, short, fetched, lanes, units = stream_device_blocks(ctxs[0], str(gz), block, 1 << 16, n_buffers, lag, gz_chunk=2048, gz_pass=5,
+                                                                                 more_ctxs=ctxs[1:])
+        arr = (C.c_void_p * n_ctx)(*[c._h for c in ctxs])
+        assert lib.hast_counts_allreduce(arr, n_ctx) == 0, lib.hast_last_error()
+        counts = ctxs[0].counts_read(len(names))
+    finally:
+        for c in ctxs:
+            c.close()
+    assert units == (n_ctx if split else 1)
+    assert got == [bc for bc, _ in want] and fetched > 0
+    assert n_bases == sum(len(s) for _, s in want) and not any(short)
+    assert all(x > 0 for x in lanes), lanes
+    for a, b in zip(counts, _oracle_counts_of(oracle_lib, keys, k, want, names)):
         assert np.array_equal(a, b)
 
 

@@ -18,7 +18,7 @@ for q in const noisy; do
   (gzip -6 -c $D/r1.fq > $D/r1.fq.gz & gzip -6 -c $D/r2.fq > $D/r2.fq.gz & wait)
   echo "== quality lines: $q; $(stat -c %s $D/r1.fq) bytes per file, $(stat -c %s $D/r1.fq.gz) as gzip -6"
   cat $D/r1.fq.gz $D/r2.fq.gz > /dev/null
-  for rep in 1 2 3; do
+  for rep in 1 2; do
     run ${q}_new_$rep hast_amd/classify $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz -t 32 --stats
     run ${q}_r4_$rep tools/ab_old/classify $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz -t 32 --stats
   done
