@@ -79,6 +79,8 @@ ABI_SYMBOLS = {
     "hast_counts_bind": (C.c_int, [vp, vp, C.c_size_t]),
     "hast_counts_zero": (C.c_int, [vp, vp]),
     "hast_counts_read": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+    "hast_counts_pack": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "hast_counts_unpack": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "hast_counts_add_votes": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint32, vp]),
     "hast_counts_allreduce": (C.c_int, [C.POINTER(vp), C.c_int]),
     "hast_classify_timing": (C.c_int, [vp, C.c_int]),
@@ -417,6 +419,13 @@ class Context:
         neg = np.zeros(n, dtype=np.uint64)
         _ck(self._lib.hast_counts_read(self._h, _ptr(c0), _ptr(c1), _ptr(neg), n))
         return c0, c1, neg
+
+    def counts_pack(self, d_packed, n, stream=None):
+        """counts[n][4] -> d_packed = c0[n] | c1[n] | neg[n] (what a caller's own collective moves)"""
+        _ck(self._lib.hast_counts_pack(self._h, C.c_void_p(d_packed), n, stream))
+
+    def counts_unpack(self, d_packed, n, stream=None):
+        _ck(self._lib.hast_counts_unpack(self._h, C.c_void_p(d_packed), n, stream))
 
     def counts_add_votes(self, d_votes, d_barcode_ids, n_reads, max_votes, stream=None):
         _ck(self._lib.hast_counts_add_votes(self._h, C.c_void_p(d_votes), C.c_void_p(d_barcode_ids), n_reads, max_votes, stream))

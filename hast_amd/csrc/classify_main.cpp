@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <deque>
@@ -292,7 +293,9 @@ int main(int argc, char **argv) {
         if (host_parse) return;
         const char *deal = getenv("HAST_DEAL");
         stripe = ctxs.size() > 1 && !(deal && !strcmp(deal, "files"));
-        size_t name_cap = std::max<size_t>(initial_barcodes, 1u << 22);
+        // (2 x 32 B per barcode it can hold: 1 GB for 16M -- BASELINE config 3 has 10M barcodes, and a barcode that does not fit is named
+        // by the host for every one of its reads)
+        size_t name_cap = std::max<size_t>(initial_barcodes, 1u << 24);
         if (const char *e = getenv("HAST_NAME_CACHE")) name_cap = (size_t)atol(e);
         for (size_t i = 0; i < ctxs.size(); i++) {
             // one cache per GPU: contexts that share a device (--devices 0,0) share what it has learnt
@@ -850,35 +853,107 @@ int main(int argc, char **argv) {
     const double t_read_done = now_s();
     flush_counts(ctxs, acc, dict.size(), 1);
     const double t_classified = now_s();
-    const std::vector<std::string_view> names = dict.names();
+    std::vector<std::string_view> names(dict.size());
+    pool.run([&](int t) { dict.names_range(names, hast::BarcodeDict::n_shards() * (size_t)t / T, hast::BarcodeDict::n_shards() * (size_t)(t + 1) / T); });
 
     // ---- printBarcodeInfos (classify.cpp:93-102): byte-wise sorted rows ------------------------
+    // (the reference walks a std::map<std::string, ...>: byte-wise lexicographic order, a prefix in front of what it is a prefix of.
+    // BASELINE configs 2 / 3 have 1M / 10M barcodes: one std::sort of 10M names and one snprintf per row took seconds on one thread;
+    // the names are dealt into 65536 buckets by their first two bytes (bucket order = byte order), the buckets are sorted and the rows
+    // formatted by the parser threads)
     fprintf(stderr, "__print result__\n");
-    std::vector<uint32_t> order(names.size());
-    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
-    std::string out;
-    out.reserve(1 << 20);
-    char num[96];
-    bool past_int = false;
-    for (uint32_t i : order) {
-        const std::string_view bc = names[i];
-        const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
-        int hap = hast_get_hap(bc.data(), bc.size(), c0, c1, n_set[0], n_set[1], w0, w1);
-        out.append(bc.data(), bc.size());
-        // the reference prints `int` counters (classify.cpp:51,98-100): the same digits up to INT_MAX; past it the reference's
-        // counter has overflowed (undefined behaviour there) -- the exact count is printed and the run says so once
-        past_int = past_int || c0 > 0x7FFFFFFFull || c1 > 0x7FFFFFFFull;
-        snprintf(num, sizeof(num), "\t%d\t%llu\t%llu\n", hap, (unsigned long long)c0, (unsigned long long)c1);
-        out += num;
-        if (out.size() > (1 << 20) - 256) {
-            if (fwrite(out.data(), 1, out.size(), stdout) != out.size()) die_output();
-            out.clear();
+    const size_t nb = names.size();
+    std::vector<uint32_t> order(nb);
+    auto key16 = [&](uint32_t i) -> uint32_t {
+        const std::string_view v = names[i];
+        return (v.size() > 0 ? (uint32_t)(uint8_t)v[0] << 8 : 0u) | (v.size() > 1 ? (uint32_t)(uint8_t)v[1] : 0u);
+    };
+    if (nb < (1u << 16) || T == 1) {
+        for (uint32_t i = 0; i < nb; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
+    } else {
+        constexpr size_t kB = 65536;
+        std::vector<std::vector<uint32_t>> hist((size_t)T, std::vector<uint32_t>(kB, 0));
+        pool.run([&](int t) {
+            std::vector<uint32_t> &h = hist[(size_t)t];
+            for (size_t i = nb * (size_t)t / T, e = nb * (size_t)(t + 1) / T; i < e; i++) h[key16((uint32_t)i)]++;
+        });
+        std::vector<size_t> bucket_at(kB + 1, 0);
+        {
+            size_t at = 0;
+            for (size_t k = 0; k < kB; k++) {
+                bucket_at[k] = at;
+                for (int t = 0; t < T; t++) {
+                    const uint32_t c = hist[(size_t)t][k];
+                    hist[(size_t)t][k] = (uint32_t)at;              // (nb < 2^32: ids are 32-bit)
+                    at += c;
+                }
+            }
+            bucket_at[kB] = at;
         }
+        pool.run([&](int t) {
+            std::vector<uint32_t> &h = hist[(size_t)t];
+            for (size_t i = nb * (size_t)t / T, e = nb * (size_t)(t + 1) / T; i < e; i++) order[h[key16((uint32_t)i)]++] = (uint32_t)i;
+        });
+        std::atomic<size_t> next_bucket{0};
+        pool.run([&](int) {
+            for (;;) {
+                const size_t k0 = next_bucket.fetch_add(64);
+                if (k0 >= kB) break;
+                for (size_t k = k0; k < k0 + 64; k++)
+                    if (bucket_at[k + 1] - bucket_at[k] > 1)
+                        std::sort(order.begin() + (long)bucket_at[k], order.begin() + (long)bucket_at[k + 1], [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
+            }
+        });
     }
+    bool past_int = false;
+    // rows: formatted by all threads, each a contiguous share of the sorted order, written in that order
+    auto put_u64 = [](std::string &out, uint64_t v) {
+        char tmp[24];
+        int n = 0;
+        do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) out.push_back(tmp[--n]);
+    };
+    auto format_rows = [&](size_t lo, size_t hi, std::string &out, bool &past) {
+        for (size_t r = lo; r < hi; r++) {
+            const uint32_t i = order[r];
+            const std::string_view bc = names[i];
+            const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
+            const int hap = hast_get_hap(bc.data(), bc.size(), c0, c1, n_set[0], n_set[1], w0, w1);
+            out.append(bc.data(), bc.size());
+            // the reference prints `int` counters (classify.cpp:51,98-100): the same digits up to INT_MAX; past it the reference's
+            // counter has overflowed (undefined behaviour there) -- the exact count is printed and the run says so once
+            past = past || c0 > 0x7FFFFFFFull || c1 > 0x7FFFFFFFull;
+            out.push_back('\t');
+            if (hap < 0) out.append("-1");
+            else out.push_back((char)('0' + hap));
+            out.push_back('\t');
+            put_u64(out, c0);
+            out.push_back('\t');
+            put_u64(out, c1);
+            out.push_back('\n');
+        }
+    };
     // (the wrapper redirects stdout into phased.barcodes and tests only the exit status, classify_stlfr_reads.sh:149: a full disk
     // or a closed pipe must not leave a truncated table behind exit 0)
-    if (fwrite(out.data(), 1, out.size(), stdout) != out.size() || fflush(stdout) != 0) die_output();
+    const size_t kRowsPerPiece = 1u << 16;
+    for (size_t r0 = 0; r0 < nb; r0 += kRowsPerPiece * (size_t)T) {
+        const size_t r1 = std::min(nb, r0 + kRowsPerPiece * (size_t)T);
+        std::vector<std::string> piece((size_t)T);
+        std::vector<char> past((size_t)T, 0);
+        pool.run([&](int t) {
+            const size_t lo = r0 + (r1 - r0) * (size_t)t / T, hi = r0 + (r1 - r0) * (size_t)(t + 1) / T;
+            bool p = false;
+            piece[(size_t)t].reserve((hi - lo) * 24);
+            format_rows(lo, hi, piece[(size_t)t], p);
+            past[(size_t)t] = p;
+        });
+        for (int t = 0; t < T; t++) {
+            past_int = past_int || past[(size_t)t];
+            if (fwrite(piece[(size_t)t].data(), 1, piece[(size_t)t].size(), stdout) != piece[(size_t)t].size()) die_output();
+        }
+    }
+    if (fflush(stdout) != 0) die_output();
     if (past_int)
         fprintf(stderr, " WARN : a barcode has more than INT_MAX hits: the reference's `int` counters overflow on this input; the exact counts were printed\n");
     logtime();

@@ -157,6 +157,11 @@ struct HdrScratch {
 // lens[0..n): code lengths (0 = unused).  kind 0: literal/length alphabet, 1: distance alphabet, 2: code-length alphabet.
 // tab: cap entries; first level = 2^root entries, sub-tables behind it.  No per-symbol scratch: the canonical codes are
 // regenerated in symbol order by every pass.  Returns kErrNone or what is wrong.
+// (on the device a function of its own, called three times per block header by k_gz_decode's lane 0: inlined into the kernel its
+// registers would be the kernel's -- 4 of the symbol loop's values spilled to scratch memory)
+#if defined(__HIPCC__)
+__attribute__((noinline))
+#endif
 GZ_HD uint32_t build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, uint32_t cap, int root, HdrScratch &scr) {
     int *const count = scr.count;
     for (int l = 0; l < 16; ++l) count[l] = 0;
@@ -518,6 +523,106 @@ GZ_HD bool header_parses(const uint32_t *w, uint64_t nbits, uint64_t bit, uint32
     Bits in{w, nbits, 0, 0, 0};
     seek(in, bit + 3);
     return read_dynamic(in, t, true, false, scr) == kErrNone && !overran(in);
+}
+
+// The same verdict for a lane of k_gz_search, which runs 64 of these side by side: nothing is indexed by a value that was just read
+// except 128 BYTES of LDS (the code-length code's table: symbol << 3 | bits; header_parses keeps 512 bytes of table and 1.4 KB of
+// arrays per lane -- 37 KB of LDS and scratch memory for a wave, i.e. ONE wave per SIMD, and the search is a chain of dependent
+// instructions per lane).  The counts per code length that the completeness rules need are kept in packed words, the lengths
+// themselves are not kept at all (a repeat needs the previous one only).  pre8: 128 bytes of this lane's own.
+constexpr uint32_t kPre8Stride = 132;                   // bytes from one lane's table to the next (33 words: the lanes' tables start in different banks)
+struct LenCounts {                                      // how many codes of each length 1 .. 15: 12 bits each, five to a word
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+};
+GZ_HD void len_counts_add(LenCounts &c, uint32_t len, uint32_t n) {      // len in 1 .. 15
+    const uint32_t q = ((len - 1) * 13) >> 6, r = len - 1 - 5 * q;        // (len - 1) / 5 and the remainder
+    const uint64_t inc = (uint64_t)n << (12 * r);
+    c.w0 += q == 0 ? inc : 0;
+    c.w1 += q == 1 ? inc : 0;
+    c.w2 += q == 2 ? inc : 0;
+}
+GZ_HD bool len_counts_complete(const LenCounts &c) {     // complete(lens, n, true) from the counts
+    int left = 1;
+    uint32_t used = 0, ones = (uint32_t)(c.w0 & 0xFFF);
+    for (int l = 0; l < 15; ++l) {
+        const uint64_t wv = l < 5 ? c.w0 : l < 10 ? c.w1 : c.w2;
+        const int n = (int)((wv >> (12 * (l % 5))) & 0xFFF);
+        left = (left << 1) - n;
+        if (left < 0) return false;
+        used += (uint32_t)n;
+    }
+    return used == 0 || left == 0 || ones == used;
+}
+GZ_HD bool header_parses8(const uint32_t *w, uint64_t nbits, uint64_t bit, uint8_t *pre8) {
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    Bits in{w, nbits, 0, 0, 0};
+    seek(in, bit + 3);
+    refill(in);
+    const uint32_t hlit = take(in, 5) + 257, hdist = take(in, 5) + 1, hclen = take(in, 4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    // the code-length code: 19 lengths of 3 bits, packed; counts per length 1 .. 7 in bytes
+    uint64_t plen = 0, cnt = 0;
+    for (uint32_t i = 0; i < hclen; ++i) {
+        refill(in);
+        const uint32_t l = take(in, 3);
+        plen |= (uint64_t)l << (3 * order[i]);
+        if (l) cnt += 1ull << (8 * l);
+    }
+    {   // complete (zlib's rule for this code: no exceptions), and the first code of every length
+        int left = 1;
+        for (int l = 1; l <= 7; ++l) {
+            left = (left << 1) - (int)((cnt >> (8 * l)) & 0xFF);
+            if (left < 0) return false;
+        }
+        if (left != 0) return false;
+    }
+    uint64_t next = 0;                                  // next code of length l in byte l
+    {
+        uint32_t code = 0;
+        for (int l = 1; l <= 7; ++l) {
+            code = (code + (uint32_t)((cnt >> (8 * (l - 1))) & 0xFF)) << 1;      // (byte 0 of cnt is 0)
+            next |= (uint64_t)(code & 0xFF) << (8 * l);
+        }
+    }
+    for (uint32_t i = 0; i < 19; ++i) {
+        const uint32_t l = (uint32_t)(plen >> (3 * i)) & 7;
+        if (!l) continue;
+        const uint32_t code = (uint32_t)(next >> (8 * l)) & 0xFF;
+        next += 1ull << (8 * l);
+        const uint8_t e = (uint8_t)((i << 3) | l);
+        for (uint32_t k = rev_bits(code, (int)l); k < 128; k += 1u << l) pre8[k] = e;      // (a complete code fills all 128)
+    }
+    // the literal/length and distance code lengths: counted, not kept
+    LenCounts cl, cd;
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0, eob = 0;
+    while (i < total) {
+        if (overran(in)) return false;
+        refill(in);
+        const uint32_t e = pre8[in.bb & 127];
+        take(in, e & 7);
+        const uint32_t sym = e >> 3;
+        uint32_t v, rep;
+        if (sym < 16) { v = sym; rep = 1; }
+        else if (sym == 16) {
+            if (i == 0) return false;
+            v = prev;
+            rep = 3 + take(in, 2);
+        } else if (sym == 17) { v = 0; rep = 3 + take(in, 3); }
+        else { v = 0; rep = 11 + take(in, 7); }
+        if (i + rep > total) return false;
+        if (v) {
+            const uint32_t n_lit = i < hlit ? (rep < hlit - i ? rep : hlit - i) : 0u;
+            if (n_lit) len_counts_add(cl, v, n_lit);
+            if (rep - n_lit) len_counts_add(cd, v, rep - n_lit);
+        }
+        if (i <= 256 && 256 < i + rep) eob = v;
+        prev = v;
+        i += rep;
+    }
+    if (eob == 0) return false;
+    if (!len_counts_complete(cl) || !len_counts_complete(cd)) return false;
+    return !overran(in);
 }
 
 // ---- CRC-32 (IEEE, reflected) as polynomial arithmetic over GF(2), after zlib's crc32.c (x2nmodp / multmodp) -----------------

@@ -30,7 +30,10 @@ namespace gz {
 __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
     __shared__ uint32_t s_q[1024];                                            // positions (relative to from_bit) that passed sieve 1
     __shared__ uint32_t s_q3[128];                                            // ... that passed sieve 2 (position order)
-    __shared__ uint32_t s_pre[64 * kPreTabCap];                               // the strict parse's code-length table, one per lane
+    // the strict parse's code-length table, one per lane: 128 bytes (gz_core.h header_parses8 -- with header_parses' 512 bytes of
+    // table and 1.4 KB of scratch arrays per lane a CU held ONE wave per SIMD, and the search is a chain of dependent instructions
+    // per lane: profiles/round5 -- 13 KB of LDS a wave now, three waves per SIMD)
+    __shared__ uint8_t s_pre8[64 * kPre8Stride];
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     ChunkJob &job = jobs[j];
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
     // the other (~50 us on a lane)
     auto parse_batch = [&](uint32_t cnt) {
         bool ok = false;
-        if (lane < cnt) ok = header_parses(w, nbits, from + s_q3[lane], s_pre + lane * kPreTabCap);
+        if (lane < cnt) ok = header_parses8(w, nbits, from + s_q3[lane], s_pre8 + lane * kPre8Stride);
         const unsigned long long m = __ballot(ok);
         if (m) found = from + s_q3[__builtin_ctzll(m)];                       // the lowest position that parses
         const uint32_t rest = q3n - cnt;

@@ -71,6 +71,8 @@ struct hast_ctx {
     uint32_t nbuckets = 0;
     // counters
     unsigned long long *d_counts = nullptr;  // [n_barcodes][4] = {c0, c1, neg, reserved}, 64-bit words
+    unsigned long long *d_pack = nullptr;    // the three live words as arrays c0[n] | c1[n] | neg[n]: what is all-reduced and read back
+    size_t pack_words = 0;
     size_t n_barcodes = 0;
     bool counts_owned = false;
     // small scratch
@@ -273,6 +275,7 @@ void hast_ctx_destroy(hast_ctx *c) {
     }
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->counts_owned && c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_pack) (void)hipFree(c->d_pack);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -756,19 +759,45 @@ hast_status hast_counts_zero(hast_ctx *c, hast_stream s) {
     return HAST_OK;
 }
 
+static hast_status ensure_pack(hast_ctx *c, size_t n) {
+    if (c->pack_words >= 3 * n) return HAST_OK;
+    if (c->d_pack) HIP_TRY(hipFree(c->d_pack));
+    c->d_pack = nullptr;
+    c->pack_words = 0;
+    HIP_TRY(hipMalloc((void **)&c->d_pack, std::max<size_t>(3 * n, 1) * sizeof(unsigned long long)));
+    c->pack_words = 3 * n;
+    return HAST_OK;
+}
+
+hast_status hast_counts_pack(hast_ctx *c, uint64_t *d_packed, size_t n, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts || !d_packed) return fail(HAST_ERR_INVALID, "no counters");
+    if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
+    HIP_TRY(launch_counts_pack(c->d_counts, reinterpret_cast<unsigned long long *>(d_packed), n, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+hast_status hast_counts_unpack(hast_ctx *c, const uint64_t *d_packed, size_t n, hast_stream s) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts || !d_packed) return fail(HAST_ERR_INVALID, "no counters");
+    if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
+    HIP_TRY(launch_counts_unpack(c->d_counts, reinterpret_cast<const unsigned long long *>(d_packed), n, s ? (hipStream_t)s : c->stream));
+    return HAST_OK;
+}
+
 hast_status hast_counts_read(hast_ctx *c, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n) {
     if (hast_status st = use(c)) return st;
     if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters");
     if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
-    std::vector<uint64_t> h(n * 4);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (hast_status st = check_classify_err(c)) return st;
-    if (n) HIP_TRY(hipMemcpy(h.data(), c->d_counts, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) {
-        if (c0) c0[i] = h[4 * i];
-        if (c1) c1[i] = h[4 * i + 1];
-        if (neg) neg[i] = h[4 * i + 2];
-    }
+    if (!n) return HAST_OK;
+    // the three live words of every record, as three arrays: 24 bytes per barcode over PCIe, each array straight into the caller's
+    if (hast_status st = ensure_pack(c, n)) return st;
+    HIP_TRY(launch_counts_pack(c->d_counts, c->d_pack, n, c->stream));
+    uint64_t *dst[3] = {c0, c1, neg};
+    for (int a = 0; a < 3; a++)
+        if (dst[a]) HIP_TRY(hipMemcpyAsync(dst[a], c->d_pack + (size_t)a * n, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return HAST_OK;
 }
 
@@ -837,14 +866,23 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
     }
     const std::vector<comm_t> &comms = it->second;
     const int kUint64 = 5, kSum = 0;   // ncclUint64, ncclSum (nccl.h: ncclInt64 = 4, ncclUint64 = 5)
+    // what crosses xGMI: the three live words of every record (c0[n] | c1[n] | neg[n], 24 bytes per barcode), packed and unpacked on
+    // each GPU around the collective
+    const size_t nbc = ctxs[0]->n_barcodes;
+    for (int i = 0; i < n; i++) {
+        if (hast_status st = use(ctxs[i])) return st;
+        if (hast_status st = ensure_pack(ctxs[i], nbc)) return st;
+        HIP_TRY(launch_counts_pack(ctxs[i]->d_counts, ctxs[i]->d_pack, nbc, ctxs[i]->stream));
+    }
     int rc = gstart();
     for (int i = 0; i < n && !rc; i++) {
         (void)hipSetDevice(ctxs[i]->device);
-        rc = allreduce(ctxs[i]->d_counts, ctxs[i]->d_counts, ctxs[i]->n_barcodes * 4, kUint64, kSum, comms[i], ctxs[i]->stream);
+        rc = allreduce(ctxs[i]->d_pack, ctxs[i]->d_pack, nbc * 3, kUint64, kSum, comms[i], ctxs[i]->stream);
     }
     int rc2 = gend();
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(ctxs[i]->device);
+        if (!rc && !rc2 && launch_counts_unpack(ctxs[i]->d_counts, ctxs[i]->d_pack, nbc, ctxs[i]->stream) != hipSuccess) rc2 = -1;
         (void)hipStreamSynchronize(ctxs[i]->stream);
     }
     if (rc || rc2) {                   // a failed collective leaves the clique in an unknown state: drop it

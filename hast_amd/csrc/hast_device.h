@@ -76,6 +76,9 @@ size_t commit_partition_scratch_bytes(size_t n_reads, size_t n_barcodes, uint32_
 hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, unsigned long long *d_counts, size_t n_barcodes, size_t n_reads,
                                      void *d_scratch, hipStream_t s);
 hipError_t launch_add_u64(unsigned long long *d_dst, const unsigned long long *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]
+// counts[n][4] -> packed = c0[n] | c1[n] | neg[n] and back (the reserved word stays where it is)
+hipError_t launch_counts_pack(const unsigned long long *d_counts, unsigned long long *d_packed, size_t n, hipStream_t s);
+hipError_t launch_counts_unpack(unsigned long long *d_counts, const unsigned long long *d_packed, size_t n, hipStream_t s);
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s);
 hipError_t launch_synth_reads(const SynthParams &p, uint64_t first, size_t n, uint8_t *d_bases, uint32_t *d_bc, hipStream_t s);
 

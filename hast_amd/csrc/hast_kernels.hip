@@ -1015,6 +1015,37 @@ hipError_t launch_add_u64(unsigned long long *d_dst, const unsigned long long *d
     return hipGetLastError();
 }
 
+// the three live words of the 32-byte counter records as three arrays (c0[n], c1[n], neg[n]) and back: what crosses xGMI in the
+// one all-reduce and PCIe on the way to the host is 24 bytes per barcode, not 32 (the fourth word only pads the records the commit
+// kernels update to one 32-byte sector)
+__global__ void __launch_bounds__(256) k_counts_pack(const unsigned long long *counts, unsigned long long *packed, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(counts + 4 * i);
+        packed[i] = a.x;
+        packed[n + i] = a.y;
+        packed[2 * n + i] = counts[4 * i + 2];
+    }
+}
+__global__ void __launch_bounds__(256) k_counts_unpack(unsigned long long *counts, const unsigned long long *packed, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        ulonglong2 a;
+        a.x = packed[i];
+        a.y = packed[n + i];
+        *reinterpret_cast<ulonglong2 *>(counts + 4 * i) = a;
+        counts[4 * i + 2] = packed[2 * n + i];
+    }
+}
+hipError_t launch_counts_pack(const unsigned long long *d_counts, unsigned long long *d_packed, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_counts_pack, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_counts, d_packed, n);
+    return hipGetLastError();
+}
+hipError_t launch_counts_unpack(unsigned long long *d_counts, const unsigned long long *d_packed, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_counts_unpack, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_counts, d_packed, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth_keys(const SynthParams &p, int hap, uint64_t first, size_t n, uint64_t *d_out, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_keys, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, p, hap, first, n, d_out);

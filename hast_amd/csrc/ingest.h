@@ -99,7 +99,13 @@ class BarcodeDict {
         if (len <= 16) memcpy(ce.inl, p, len);
     }
     size_t size() const { return next_id_.load(std::memory_order_relaxed); }
-    // names by id (call when no thread is inserting)
+    // names by id (call when no thread is inserting); names_range: the share of shards [lo, hi) of n_shards(), for several threads
+    static constexpr size_t n_shards() { return kShards; }
+    void names_range(std::vector<std::string_view> &out, size_t lo, size_t hi) const {
+        for (size_t k = lo; k < hi && k < shards_.size(); ++k)
+            for (const Slot &sl : shards_[k].slots)
+                if (sl.p) out[sl.id] = std::string_view(sl.p, sl.len);
+    }
     std::vector<std::string_view> names() const {
         std::vector<std::string_view> out(size());
         for (const Shard &s : shards_)

@@ -159,7 +159,8 @@ hast_status hast_filter_info(const hast_ctx *, int *enabled, int *m, int *t, int
 hast_status hast_filter_request_ceiling(hast_ctx *, double *requests_per_s);
 
 /* ---- per-barcode counters: BarcodeCache (classify.cpp:50-64) -------------------------------
- * Device layout: uint64 counts[n_barcodes][4] = { c0, c1, neg, reserved } (32-byte records):
+ * Device layout: uint64 counts[n_barcodes][4] = { c0, c1, neg, reserved } (32-byte records: a record is one sector for the commit
+ * kernels' updates; what leaves the GPU -- the all-reduce, the copy to the host -- is the three live words, see hast_counts_pack):
  *   c0/c1 = sum of per-read votes for key 0/1 (classify.cpp:203-206), neg = key -1 (:191,:207-208).
  * A barcode was "seen" (gets an output row, classify.cpp:94) iff c0|c1|neg != 0.
  * 64-bit accumulation on the device, narrowed by whoever prints ("Hot barcode"): the reference counts in `int`
@@ -176,6 +177,12 @@ hast_status hast_counts_resize(hast_ctx *, size_t n_barcodes);                 /
 hast_status hast_counts_bind(hast_ctx *, uint64_t *d_counts, size_t n_barcodes); /* caller-owned buffer, 32-byte aligned */
 hast_status hast_counts_zero(hast_ctx *, hast_stream);
 hast_status hast_counts_read(hast_ctx *, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n_barcodes);
+/* The three live words of the first n_barcodes records as three arrays, d_packed = c0[n] | c1[n] | neg[n] (3 x n_barcodes u64, device),
+ * and back (the records' three words are overwritten, the reserved one is left alone): what a caller that runs its own collective --
+ * bench.py: one torch.distributed all_reduce over RCCL -- moves is 24 bytes per barcode, not the 32 of the padded records;
+ * hast_counts_read and hast_counts_allreduce do the same inside.  Asynchronous on `stream`. */
+hast_status hast_counts_pack(hast_ctx *, uint64_t *d_packed, size_t n_barcodes, hast_stream);
+hast_status hast_counts_unpack(hast_ctx *, const uint64_t *d_packed, size_t n_barcodes, hast_stream);
 /* The bookkeeping alone (classify.cpp:203-208) for per-read votes the caller holds: d_votes[n_reads][2] = (vote0, vote1), 8-byte
  * aligned; d_barcode_ids[n_reads] < n_barcodes; max_votes = an upper bound on any single vote (reads of up to 255 windows may take
  * the partitioned path).  Asynchronous on `stream`. */

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -247,7 +248,11 @@ static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std
         const uint64_t lim = nbits > 192 ? nbits - 192 : 0;
         for (uint64_t bit = j.from_bit; bit < j.from_bit + j.search_to_lo && bit < lim; ++bit) {
             if (!candidate(bits_at(g_words.data(), bit), bits_at(g_words.data(), bit + 56))) continue;
-            if (!header_parses(g_words.data(), nbits, bit, tabs.data() + kLitTabCap + kDistTabCap)) continue;
+            // (the search kernel's register-only version of the strict parse must give the same verdict at every candidate)
+            uint8_t pre8[128];
+            const bool ok = header_parses(g_words.data(), nbits, bit, tabs.data() + kLitTabCap + kDistTabCap);
+            if (ok != header_parses8(g_words.data(), nbits, bit, pre8)) { fprintf(stderr, "header_parses8 differs at bit %llu\n", (unsigned long long)bit); abort(); }
+            if (!ok) continue;
             j.start_bit = bit;
             found = true;
             break;
@@ -264,13 +269,61 @@ static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std
 int main(int argc, char **argv) {
     size_t chunk = 32768, seg = 64;
     double room = 12;
+    long fuzz = 0;
     const char *path = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-c")) chunk = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-s")) seg = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-r")) room = atof(argv[++i]);
         else if (!strcmp(argv[i], "-w")) g_wave = true;
+        else if (!strcmp(argv[i], "-f")) fuzz = atol(argv[++i]);
         else path = argv[i];
+    }
+    if (fuzz) {
+        // header_parses8 against header_parses on random bits (most fail at the counts or at the code-length code; a few per cent get into
+        // the length loop) and on random bits behind a code-length code that IS complete
+        uint64_t x = 0x9E3779B97F4A7C15ull, agree_true = 0;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        std::vector<uint32_t> buf(64);
+        std::vector<uint32_t> tabs(kTabWords);
+        for (long it = 0; it < fuzz; ++it) {
+            for (uint32_t &v : buf) v = (uint32_t)rnd();
+            if (it & 1) {
+                // 3 type bits, HLIT, HDIST, HCLEN = 15 (19 lengths), then a complete code: lengths from a random full binary tree
+                uint8_t lens[19] = {0};
+                int n = 1; lens[0] = 0;
+                uint8_t depth[19] = {0};
+                while (n < 19 && (rnd() % 8)) {             // split a random leaf that is not at depth 7
+                    const int k = (int)(rnd() % (uint64_t)n);
+                    if (depth[k] >= 7) continue;
+                    depth[k]++;
+                    depth[n++] = depth[k];
+                }
+                if (n == 1) depth[0] = 1, depth[n++] = 1;
+                int perm[19];
+                for (int i = 0; i < 19; ++i) perm[i] = i;
+                for (int i = 18; i > 0; --i) std::swap(perm[i], perm[rnd() % (uint64_t)(i + 1)]);
+                for (int i = 0; i < n; ++i) lens[perm[i]] = depth[i];
+                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint64_t hdr = 4 | ((rnd() % 30) << 3) | ((rnd() % 30) << 8) | (15ull << 13);
+                int at = 17;
+                std::vector<uint8_t> bits(17 + 57);
+                for (int i = 0; i < 17; ++i) bits[i] = (hdr >> i) & 1;
+                for (int i = 0; i < 19; ++i)
+                    for (int b = 0; b < 3; ++b) bits[at++] = (lens[order[i]] >> b) & 1;
+                for (int i = 0; i < at; ++i) {
+                    buf[i >> 5] &= ~(1u << (i & 31));
+                    buf[i >> 5] |= (uint32_t)bits[i] << (i & 31);
+                }
+            }
+            uint8_t pre8[128];
+            const uint64_t nb = (it % 7 == 0) ? 64 * 8 + (rnd() % 600) : 64 * 32 - 192;
+            const bool a = header_parses(buf.data(), nb, 0, tabs.data() + kLitTabCap + kDistTabCap), b = header_parses8(buf.data(), nb, 0, pre8);
+            if (a != b) { fprintf(stderr, "header_parses8 differs (trial %ld: %d vs %d)\n", it, (int)a, (int)b); return 3; }
+            agree_true += a;
+        }
+        printf("%llu accepted\n", (unsigned long long)agree_true);
+        return 0;
     }
     FILE *f = fopen(path, "rb");
     if (!f) return 2;

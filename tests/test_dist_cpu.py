@@ -1,5 +1,6 @@
 """N>1 path on CPU (gloo, world_size 2): the read-shard arithmetic bench.py uses and the counter merge
-(one all_reduce(sum) over int64 views of the 64-bit counters, the device layout since round 4) give exactly the single-process
+(one all_reduce(sum) over the int64 view of the counters' three live words as arrays c0[n] | c1[n] | neg[n] -- hast_counts_pack: what
+bench.py and hast_counts_allreduce move since round 5, 24 bytes per barcode) give exactly the single-process
 counts -- also for a barcode whose counters stand beyond 2^32 on every rank (the hot no-barcode bucket of real stLFR data).
 The per-shard classification here is done by the oracle (no GPU on this box); on the GPU box the same
 merge runs over RCCL inside bench.py."""
@@ -51,10 +52,12 @@ def _worker(rank, world, port, steps, R, out_dir):
         for c in range(3):
             counts[:, c] += e[c].astype(np.uint64)
     o.ho_free(oc)
-    t = torch.from_numpy(counts.view(np.int64))
+    packed = np.ascontiguousarray(counts[:, :3].T)              # hast_counts_pack: c0[n] | c1[n] | neg[n], the reserved word stays home
+    t = torch.from_numpy(packed.view(np.int64))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)                   # what bench.py does over RCCL
+    counts[:, :3] = t.numpy().view(np.uint64).T                # hast_counts_unpack
     if rank == 0:
-        np.save(os.path.join(out_dir, "merged.npy"), t.numpy().view(np.uint64))
+        np.save(os.path.join(out_dir, "merged.npy"), counts)
     dist.destroy_process_group()
 
 

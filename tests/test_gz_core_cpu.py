@@ -65,6 +65,14 @@ def test_same_bytes_as_zlib(driver, tmp_path, name):
         assert got.stdout == want, (name, chunk, seg, room)
 
 
+def test_search_kernels_strict_parse_equals_the_full_one(driver_exe):
+    """header_parses8 (what a lane of k_gz_search runs: counts in packed words, a 128-byte table) == header_parses (gz_core.h's
+    read_dynamic with zlib's completeness rules) on 400 000 random bit strings, half of them behind a valid code-length code"""
+    r = subprocess.run([driver_exe, "-f", "400000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr[-300:]
+    assert int(r.stdout.split()[0]) >= 0
+
+
 def test_not_gzip_is_refused(driver, tmp_path):
     p = tmp_path / "plain.gz"
     p.write_bytes(CASES["not_gzip"])
