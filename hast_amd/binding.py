@@ -129,6 +129,7 @@ ABI_SYMBOLS = {
     "hast_synth_table_build": (C.c_int, [vp, C.POINTER(SynthParams)]),
     # stage 00: parent-unique k-mer sets
     "hast_kc_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "hast_kc_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_uint64, C.POINTER(vp)]),
     "hast_kc_destroy": (None, [vp]),
     "hast_kc_stream": (vp, [vp]),
     "hast_kc_set_slice": (C.c_int, [vp, C.c_uint32, C.c_uint32]),

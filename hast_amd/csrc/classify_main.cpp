@@ -184,7 +184,9 @@ int main(int argc, char **argv) {
     std::vector<std::string> read;
     int t_num = 8, device = 0;
     std::vector<int> devices;
-    size_t batch_reads = 0, block_mb = 256, initial_barcodes = 1u << 20;
+    // (counters for 16M barcodes from the start: 512 MB of HBM and a fill -- a regrowth reads everything back and allocates anew, four
+    // times on the way to BASELINE config 3's 10M barcodes)
+    size_t batch_reads = 0, block_mb = 256, initial_barcodes = 1u << 24;
     bool stats = false, host_parse = false;
     double w0 = 1.0, w1 = 1.0;
     for (;;) {
@@ -895,14 +897,47 @@ int main(int argc, char **argv) {
             std::vector<uint32_t> &h = hist[(size_t)t];
             for (size_t i = nb * (size_t)t / T, e = nb * (size_t)(t + 1) / T; i < e; i++) order[h[key16((uint32_t)i)]++] = (uint32_t)i;
         });
+        // the buckets, largest first, one at a time to whoever is free (stLFR barcodes are digits: a hundred buckets hold everything, and
+        // ten of them sit next to each other -- dealt in runs of 64 keys, one thread got a tenth of the job); inside a bucket: by the next
+        // byte, and the next (the ids are moved, the names are looked at once per level), std::sort below 2048 names
+        std::vector<uint32_t> big;
+        for (size_t k = 0; k < kB; k++)
+            if (bucket_at[k + 1] - bucket_at[k] > 1) big.push_back((uint32_t)k);
+        std::sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { return bucket_at[a + 1] - bucket_at[a] > bucket_at[b + 1] - bucket_at[b]; });
         std::atomic<size_t> next_bucket{0};
         pool.run([&](int) {
+            std::vector<uint32_t> tmp;
+            struct Range { size_t lo, hi, depth; };
+            std::vector<Range> todo;
             for (;;) {
-                const size_t k0 = next_bucket.fetch_add(64);
-                if (k0 >= kB) break;
-                for (size_t k = k0; k < k0 + 64; k++)
-                    if (bucket_at[k + 1] - bucket_at[k] > 1)
-                        std::sort(order.begin() + (long)bucket_at[k], order.begin() + (long)bucket_at[k + 1], [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
+                const size_t bi = next_bucket.fetch_add(1);
+                if (bi >= big.size()) break;
+                todo.push_back({bucket_at[big[bi]], bucket_at[big[bi] + 1], 2});
+                while (!todo.empty()) {
+                    const Range r = todo.back();
+                    todo.pop_back();
+                    const size_t n = r.hi - r.lo;
+                    if (n < 2048 || r.depth > 64) {
+                        std::sort(order.begin() + (long)r.lo, order.begin() + (long)r.hi, [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
+                        continue;
+                    }
+                    // counting sort by the byte at r.depth; names that end here (shorter: a prefix of the others) come first
+                    size_t cnt[257] = {0};
+                    auto byte_at = [&](uint32_t id) -> size_t { const std::string_view v = names[id]; return v.size() > r.depth ? (size_t)(uint8_t)v[r.depth] + 1 : 0; };
+                    for (size_t i = r.lo; i < r.hi; i++) cnt[byte_at(order[i])]++;
+                    size_t at[258];
+                    at[0] = 0;
+                    for (int b = 0; b < 257; b++) at[b + 1] = at[b] + cnt[b];
+                    tmp.resize(n);
+                    {
+                        size_t pos[257];
+                        for (int b = 0; b < 257; b++) pos[b] = at[b];
+                        for (size_t i = r.lo; i < r.hi; i++) tmp[pos[byte_at(order[i])]++] = order[i];
+                    }
+                    std::copy(tmp.begin(), tmp.begin() + (long)n, order.begin() + (long)r.lo);
+                    for (int b = 1; b < 257; b++)                          // (slot 0: identical names cannot be, ids are one per name)
+                        if (cnt[b] > 1) todo.push_back({r.lo + at[b], r.lo + at[b + 1], r.depth + 1});
+                }
             }
         });
     }

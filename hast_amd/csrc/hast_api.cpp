@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -71,6 +72,7 @@ struct hast_ctx {
     uint32_t nbuckets = 0;
     // counters
     unsigned long long *d_counts = nullptr;  // [n_barcodes][4] = {c0, c1, neg, reserved}, 64-bit words
+    uint32_t *h_errword = nullptr;           // pinned: where d_err[1] is read to
     unsigned long long *d_pack = nullptr;    // the three live words as arrays c0[n] | c1[n] | neg[n]: what is all-reduced and read back
     size_t pack_words = 0;
     size_t n_barcodes = 0;
@@ -163,11 +165,16 @@ hast_status check_err_word(hast_ctx *c, hipStream_t s) {
 }
 
 // d_err[1]: raised by kernels of the (asynchronous) classification path; looked at wherever the caller waits for results
-hast_status check_classify_err(hast_ctx *c) {
-    uint32_t e = 0;
-    HIP_TRY(hipMemcpy(&e, c->d_err + 1, sizeof(e), hipMemcpyDeviceToHost));
-    if (!e) return HAST_OK;
-    HIP_TRY(hipMemset(c->d_err + 1, 0, sizeof(uint32_t)));
+// (read into a pinned word on the stream the caller has just waited for: a pageable hipMemcpy goes through the NULL stream, which
+// synchronises with every blocking stream of the device -- ADVICE r4)
+hast_status check_classify_err(hast_ctx *c, hipStream_t hs) {
+    if (!hs) hs = c->stream;
+    *c->h_errword = 0;
+    HIP_TRY(hipMemcpyAsync(c->h_errword, c->d_err + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
+    if (!*c->h_errword) return HAST_OK;
+    HIP_TRY(hipMemsetAsync(c->d_err + 1, 0, sizeof(uint32_t), hs));
+    HIP_TRY(hipStreamSynchronize(hs));
     return fail(HAST_ERR_INVALID, "read offsets overlap or are not monotonic (their lengths add up to more than bases_bytes): rows were dropped");
 }
 
@@ -215,12 +222,22 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     if (!out) return fail(HAST_ERR_INVALID, "out is null");
     *out = nullptr;
     if (k < 1 || k > 32) return fail(HAST_ERR_INVALID, "K=%d out of [1,32]", k);
+    // HAST_TRACE_INIT=1: which call of the context's creation a box makes wait (0.07 - 0.26 s from run to run on one box)
+    const bool trace = getenv("HAST_TRACE_INIT") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_tr = now_s();
+    auto tr = [&](const char *what) {
+        if (trace) fprintf(stderr, "__trace_init__ device %d: %s %.4f s\n", device, what, now_s() - t_tr);
+        t_tr = now_s();
+    };
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
+    tr("hipGetDeviceCount (loads the runtime)");
     if (e != hipSuccess || n <= 0)
         return fail(HAST_ERR_NO_DEVICE, "no HIP device (%s); libhast has no CPU path", hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(HAST_ERR_NO_DEVICE, "device %d not in [0,%d)", device, n);
     HIP_TRY(hipSetDevice(device));
+    tr("hipSetDevice");
     hast_ctx *c = new (std::nothrow) hast_ctx();
     if (!c) return fail(HAST_ERR_OOM, "host allocation failed");
     c->device = device;
@@ -241,17 +258,23 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    tr("hipGetDeviceProperties");
     hast_status st = HAST_OK;
     auto bail = [&](hipError_t he, const char *what) {
         if (he != hipSuccess && st == HAST_OK) st = fail(HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
     };
     bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    tr("hipStreamCreate");
     bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
+    tr("first hipMalloc");
     bail(hipMalloc(&c->d_cnt, 8 * sizeof(unsigned long long)), "hipMalloc(cnt)");
+    bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_errword), 64, hipHostMallocDefault), "hipHostMalloc(err word)");
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
     if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    tr("first fill + synchronize");
     for (auto &s : c->stage)
         if (st == HAST_OK) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+    tr("events");
     if (st != HAST_OK) {
         hast_ctx_destroy(c);
         return st;
@@ -276,6 +299,7 @@ void hast_ctx_destroy(hast_ctx *c) {
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->counts_owned && c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_pack) (void)hipFree(c->d_pack);
+    if (c->h_errword) (void)hipHostFree(c->h_errword);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -309,7 +333,7 @@ hast_stream hast_ctx_stream(const hast_ctx *c) { return c ? (hast_stream)c->stre
 hast_status hast_stream_sync(hast_ctx *c, hast_stream s) {
     if (hast_status st = use(c)) return st;
     HIP_TRY(hipStreamSynchronize(s ? (hipStream_t)s : c->stream));
-    return check_classify_err(c);
+    return check_classify_err(c, s ? (hipStream_t)s : c->stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -789,7 +813,7 @@ hast_status hast_counts_read(hast_ctx *c, uint64_t *c0, uint64_t *c1, uint64_t *
     if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters");
     if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (hast_status st = check_classify_err(c)) return st;
+    if (hast_status st = check_classify_err(c, c->stream)) return st;
     if (!n) return HAST_OK;
     // the three live words of every record, as three arrays: 24 bytes per barcode over PCIe, each array straight into the caller's
     if (hast_status st = ensure_pack(c, n)) return st;
@@ -1313,7 +1337,7 @@ hast_status hast_classify_perread(hast_ctx *c, const uint8_t *bases, const uint6
     if (hast_status st = hast_classify_perread_device(c, d_b, nbytes ? nbytes : 1, d_o, n_reads, d_v, c->stream)) return st;
     HIP_TRY(hipMemcpyAsync(votes_out, d_v, vb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return check_classify_err(c);
+    return check_classify_err(c, c->stream);
 }
 
 static hast_status stage_reserve(hast_ctx *c, Staging &s, size_t nbytes, size_t nreads) {

@@ -40,6 +40,7 @@ struct hast_kc {
     unsigned long long *d_table = nullptr;
     uint32_t nbuckets = 0;
     uint32_t slice = 0, n_slices = 1;
+    uint64_t expected_windows = 0;                 // what the caller expects to count (0 = unknown): bounds the record buffers
     uint32_t tile_bases = 4096;
     unsigned long long *d_small = nullptr;
     uint32_t *d_err = nullptr;
@@ -129,6 +130,9 @@ static void part_setup(hast_kc *c) {
     // ... and no more records than the table has slots: a caller sizes the table for its input, and device memory that another
     // process has just given back is slow to get (seconds per 100 GB: the stage-00 program run back to back)
     R = std::min<uint64_t>(R, std::max<uint64_t>((uint64_t)c->nbuckets * kKcSlots, 64ull << 20));
+    // ... nor more than the input can write (a record holds 3.3 windows on average, never fewer than one per two here: the bound the
+    // flush logic works with): a 20-Mbp trio then takes 16 GB of record buffers, not the 60 GB that happened to be free
+    if (c->expected_windows) R = std::min<uint64_t>(R, std::max<uint64_t>(c->expected_windows / 2 + (1u << 20), 16ull << 20));
     if (const char *m = getenv("HAST_KC_RECORD_MB")) R = std::min<uint64_t>(R, ((uint64_t)atol(m) << 20) / 8);     // (the record buffer itself)
     if (R < (forced ? 4096u : (16u << 20))) return;
     c->rec_cap = R;
@@ -194,7 +198,8 @@ static hast_status part_flush(hast_kc *c) {
     return HAST_OK;
 }
 
-hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out) {
+hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out) { return hast_kc_create_ex(device, k, table_bytes, 0, out); }
+hast_status hast_kc_create_ex(int device, int k, size_t table_bytes, uint64_t expected_windows, hast_kc **out) {
     if (!out) return set_error(HAST_ERR_INVALID, "out is null");
     *out = nullptr;
     if (k < 1 || k > 32) return set_error(HAST_ERR_INVALID, "K=%d out of [1,32]", k);
@@ -209,6 +214,7 @@ hast_status hast_kc_create(int device, int k, size_t table_bytes, hast_kc **out)
     c->device = device;
     c->k = k;
     c->m = default_minimizer_for(k);
+    c->expected_windows = expected_windows;
     if (const char *t = getenv("HAST_KC_TILE")) {
         const long v = atol(t);
         if (v >= 256 && v <= 16384) c->tile_bases = (uint32_t)(v & ~31l);

@@ -443,8 +443,12 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
             if (c) {
                 const uint32_t region = LEVEL == 1 ? tid : l1 * g.f2 + tid;
                 // (level 1: every workgroup adds to every one of <= 1024 counters -- a line apart, or they share 32 lines)
-                const uint32_t at = atomicAdd(&out_fill[LEVEL == 1 ? region * kKcFillPad : region], c);
-                if (at + c <= out_cap) dst = at;
+                // (a region that has failed takes no more adds: its fill word would otherwise keep growing with every workgroup that comes
+                // by and, on a flush of billions of records into one bin -- poly-A -- wrap past 2^32 and hand out room again)
+                const uint32_t fi = LEVEL == 1 ? region * kKcFillPad : region;
+                const uint32_t at = __hip_atomic_load(&out_valid[fi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu ? 0xFFFFFFFFu : atomicAdd(&out_fill[fi], c);
+                if (at != 0xFFFFFFFFu && (uint64_t)at + c <= out_cap) dst = at;
+                else if (at == 0xFFFFFFFFu) dst = 0x80000000u;
                 else {
                     atomicMin(&out_valid[LEVEL == 1 ? region * kKcFillPad : region], at);                          // records [0, first failed reservation) of a region are real
                     dst = 0x80000000u;
@@ -485,6 +489,16 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
 // compare-and-swap on the first slot that looked empty.  The first version gave a lane a RECORD and walked the slots one LDS
 // round trip at a time: runs of 1..9 windows x 1..32 slots, every wave as slow as its slowest lane -- 0.38 s of LDS probes per
 // flush against 0.20 s for everything else.
+// tag of a key in a slice's LDS copy: 7 bits of a hash of the key under a set top bit (0 = the slot is empty)
+__device__ __forceinline__ uint32_t kc_tag(unsigned long long key) {
+    if (key == kEmptySlot) return 0u;
+    const uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
+    return ((x * 0x9E3779B1u) >> 25) | 0x80u;
+}
+__device__ __forceinline__ unsigned long long kc_zero_bytes64(unsigned long long x) {      // 0x80 in every byte of x that is zero (exact)
+    const unsigned long long m = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((x & m) + m) | x | m);
+}
 constexpr int kKcApplyThreads = 1024;
 constexpr uint32_t kKcLdsStride = kKcBucketWords + 1;                            // words per bucket in LDS (k_kc_apply)
 constexpr uint32_t kKcMapMax = 1024;                                             // bytes of window -> record map per wave, at most
@@ -522,6 +536,9 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
                     unsigned long long *d = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
                     d[0] = t[q].x;
                     d[1] = t[q].y;
+                    // the bucket's 17th word: a TAG byte per key slot (0 = empty), so that a probe reads 8 bytes, not 8 keys
+                    if ((i & 7) < kKcSlots / 2)
+                        reinterpret_cast<uint16_t *>(s_tab + (size_t)(i >> 3) * kKcLdsStride + kKcBucketWords)[i & 7] = (uint16_t)(kc_tag(t[q].x) | (kc_tag(t[q].y) << 8));
                 }
             }
         }
@@ -562,6 +579,8 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             const unsigned long long raw = ((rw >> 6) >> (2 * (run_w - 1 - jw))) & kmask;
             const unsigned long long key = kmer_canon(raw, g.k);
             const uint32_t hw = kc_key_bucket(key, nb_here);
+            const uint32_t tag = kc_tag(key);
+            const unsigned long long tagx = 0x0101010101010101ull * tag;
             bool done = !act;
 #pragma unroll 1
             for (uint32_t p = 0; p < 4; ++p) {                                     // (kc_probe: the key's bucket in the slice, then the next three)
@@ -570,19 +589,27 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
                 b = b >= nb_here ? b - nb_here : b;
                 if (!done) {
                     unsigned long long *bk = s_tab + (size_t)b * kKcLdsStride;
-                    unsigned long long sl[kKcSlots];
-#pragma unroll
-                    for (int i = 0; i < kKcSlots; ++i) sl[i] = bk[i];
-                    int idx = -1, fe = kKcSlots;
-#pragma unroll
-                    for (int i = kKcSlots - 1; i >= 0; --i) {
-                        if (sl[i] == key) idx = i;
-                        if (sl[i] == kEmptySlot) fe = i;
+                    // ONE 8-byte read of the bucket's tags instead of its eight keys (round 4: 8 LDS reads and 16 compare + select per
+                    // window and probe -- 158 lane-instructions per window, 4.3 bank-conflict cycles per LDS instruction): a slot whose tag
+                    // matches is read and compared (one in 128 occupied slots matches by chance), a key that is not there goes in by
+                    // compare-and-swap from the first slot whose tag says empty, and writes its tag behind itself.  A tag that is not
+                    // written yet only sends another lane with the same key into the same compare-and-swap, which then finds it there.
+                    const unsigned long long tg = bk[kKcBucketWords];
+                    int idx = -1;
+                    unsigned long long mt = kc_zero_bytes64(tg ^ tagx);
+                    while (mt) {
+                        const int i = __builtin_ctzll(mt) >> 3;
+                        mt &= mt - 1;
+                        if (bk[i] == key) { idx = i; break; }
                     }
-                    // slots fill in order and never change: a key not seen is settled by compare-and-swap from the first slot that looked empty
-                    for (int i = fe; idx < 0 && i < kKcSlots; ++i) {
-                        const unsigned long long old = atomicCAS(&bk[i], (unsigned long long)kEmptySlot, key);
-                        if (old == kEmptySlot || old == key) idx = i;
+                    if (idx < 0) {
+                        const unsigned long long em = kc_zero_bytes64(tg);
+                        // slots fill in order and never change: a key not seen is settled by compare-and-swap from the first slot that looked empty
+                        for (int i = em ? __builtin_ctzll(em) >> 3 : kKcSlots; idx < 0 && i < kKcSlots; ++i) {
+                            const unsigned long long old = atomicCAS(&bk[i], (unsigned long long)kEmptySlot, key);
+                            if (old == kEmptySlot) reinterpret_cast<uint8_t *>(bk + kKcBucketWords)[i] = (uint8_t)tag;
+                            if (old == kEmptySlot || old == key) idx = i;
+                        }
                     }
                     if (idx >= 0) {
                         atomicAdd(reinterpret_cast<uint32_t *>(bk + kKcSlots) + parent * kKcSlots + idx, 1u);

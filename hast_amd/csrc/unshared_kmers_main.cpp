@@ -301,12 +301,15 @@ int main(int argc, char **argv) {
     const double t_start = now();
     double t_ingest = 0;
 
-    // Table size when not given: room for every window of the input being a different k-mer at load factor 1/2 (an
-    // upper bound from the file sizes: about half the bytes of a FASTQ are bases, a gz file holds at most ~3 bases per
-    // byte), capped by the library at 85 % of the free HBM.  Too small a guess only costs a restart with more slices.
+    // Table size when not given: from the input -- an upper bound on its windows from the file sizes (about half the bytes of a
+    // FASTQ are bases, a gz file holds at most ~3 bases per byte) and a slot (16 B) per window: every window a different k-mer would
+    // fill the table to the brim, sequencing data (30 x coverage, 15 % error k-mers) fills a quarter to a third of it.  Round 4 took
+    // twice that, and the record buffers "what is left of the device": 100 GB for a 20-Mbp job, which a box that had just freed
+    // them took 6 s to hand out (profiles/round4_measure.txt).  Too small a guess only costs a restart with more slices; capped by
+    // the library at 85 % of the free HBM.
     size_t table_bytes = (size_t)(o.table_gb * (double)(1ull << 30));
-    if (table_bytes == 0) {
-        double windows = 0;
+    double windows = 0;
+    {
         for (int p = 0; p < 2; ++p)
             for (const auto &f : o.files[p]) {
                 struct stat sb;
@@ -320,7 +323,7 @@ int main(int argc, char **argv) {
                 }
                 windows += ends_gz(f) ? 3.0 * (double)sb.st_size : fasta ? (double)sb.st_size : 0.55 * (double)sb.st_size;
             }
-        table_bytes = (size_t)std::max(256.0 * (1 << 20), windows * 2.0 * 16.0);
+        if (table_bytes == 0) table_bytes = (size_t)std::max(256.0 * (1 << 20), windows * 16.0);
     }
     if (o.devices.empty()) o.devices.push_back(0);
     const long n_dev = (long)o.devices.size();
@@ -329,7 +332,7 @@ int main(int argc, char **argv) {
         hast_kc *k = nullptr;
         // --table-gb is per GPU; the automatic size is for the whole key space, i.e. divided between the GPUs
         const size_t per_dev = o.table_gb > 0 ? table_bytes : table_bytes / (size_t)n_dev + 1;
-        if (hast_kc_create(dev, (int)o.mer, per_dev, &k) != HAST_OK) {
+        if (hast_kc_create_ex(dev, (int)o.mer, per_dev, (uint64_t)(windows / (double)n_dev * 1.1) + 1, &k) != HAST_OK) {
             fprintf(stderr, "unshared_kmers: device %d: %s\n", dev, hast_last_error());
             gpu.destroy();
             return 4;

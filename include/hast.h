@@ -437,6 +437,11 @@ typedef struct hast_kc hast_kc;
 
 /* table_bytes == 0 (or more than that): 85 % of the free device memory.  k in [1,32]. */
 hast_status hast_kc_create(int device_ordinal, int k, size_t table_bytes, hast_kc **out);
+/* expected_windows: an upper bound on the k-mer occurrences the caller is going to count into this table (0 = unknown), e.g. from
+ * the input files' sizes: the record buffers of the partitioned path then take room for that many windows' records instead of what
+ * happens to be free on the device (tens of GB that a 20-Mbp job never fills, and that are slow to get right after another process
+ * gave them back). */
+hast_status hast_kc_create_ex(int device_ordinal, int k, size_t table_bytes, uint64_t expected_windows, hast_kc **out);
 void        hast_kc_destroy(hast_kc *);
 hast_stream hast_kc_stream(hast_kc *);
 /* empties the table and restricts counting to slice `slice` of `n_slices` (1 slice = everything) */

@@ -460,3 +460,38 @@ def test_cli_baseline_config1_full_size_vs_oracle(exe, oracle_dir, tmp_path):
             assert got.stdout == ref.stdout, extra
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.heavy
+def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
+    """BASELINE config 2's barcode cardinality through the boundary (classify.cpp:50-64,93-102: one map entry and one output row per
+    barcode): 600k synthetic read pairs over 1M barcodes -- some 700k of them seen -- as plain FASTQ and as one .gz, one context and
+    two.  What only such a run reaches: the host dictionary under ~10^6 inserts, a device-side name cache that keeps learning, the
+    bucketed parallel sort of the rows (below 65536 barcodes the program sorts on one thread) and their parallel formatting.
+    stdout == the oracle's line-by-line restatement of classify.cpp, byte for byte (tools/gpu/cli_cardinality.sh measures the same
+    at 20M reads over 1M and 10M barcodes, with the real reference binary on a subsample: profiles/round5_cli_cardinality.txt)."""
+    import gzip
+    import shutil
+    from tests.conftest import ROOT
+    gen = os.path.join(ROOT, "tools", "gen_fastq")
+    if not os.path.exists(gen):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tools"), "gen_fastq"], check=True)
+    d = tmp_path / "c2"
+    d.mkdir()
+    try:
+        subprocess.run([gen, str(d), "600000", "200000", "1000000", "21", "150", "8"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=900)
+        with open(d / "r2.fq", "rb") as f, gzip.open(d / "r2.fq.gz", "wb", compresslevel=1) as g:
+            shutil.copyfileobj(f, g, 1 << 24)
+        args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--thread", "16", "--weight0", "1.04", "--read", "r1.fq"]
+        ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args + ["--read", "r2.fq"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert ref.returncode == 0, ref.stderr.decode()[-500:]
+        rows = ref.stdout.splitlines()
+        assert 600_000 < len(rows) < 1_000_000
+        assert rows == sorted(rows, key=lambda r: r.split(b"\t")[0])                       # byte order of the barcodes, as std::map's
+        for extra in (["--read", "r2.fq"], ["--read", "r2.fq.gz"], ["--read", "r2.fq.gz", "--devices", "0,0"], ["--read", "r2.fq", "--thread", "1"]):
+            got = subprocess.run([exe] + args + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            assert got.returncode == 0, got.stderr.decode()[-2000:]
+            assert got.stdout == ref.stdout, extra
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
