@@ -35,8 +35,9 @@ constexpr uint32_t kLit = 1u << 13, kEob = 1u << 14, kSub = 1u << 15;
 // first-level table sizes as zlib's (9 / 6 bits): the tables of a block live in LDS on the device, 7 KB per wave, and the number of
 // waves a CU holds is what the decode kernel's throughput scales with
 constexpr int kLitRoot = 9, kDistRoot = 6;
-constexpr uint32_t kLitTabCap = 1024, kDistTabCap = 640, kPreTabCap = 128;      // entries (u32): first level + sub-tables (zlib's own bounds for complete codes
-                                                                                 // are 852 and 592 at these roots); a code that needs more is refused (kErrTableSize)
+constexpr uint32_t kLitTabCap = 856, kDistTabCap = 592, kPreTabCap = 128;       // entries (u32): first level + sub-tables (zlib's own bounds for complete codes
+                                                                                 // are 852 and 592 at these roots -- inftrees.h ENOUGH_LENS / ENOUGH_DISTS; an
+                                                                                 // incomplete code is a lone one); a code that needs more is refused (kErrTableSize)
 constexpr uint32_t kTabWords = kLitTabCap + kDistTabCap + kPreTabCap;           // a lane's tables, back to back
 constexpr uint32_t kWindow = 32768;
 constexpr uint16_t kMarker = 0x8000;
@@ -379,6 +380,14 @@ GZ_HD uint32_t decode_huffman(Bits &in, const Tables &t, uint16_t *sym, uint32_t
         n += len;
     }
 }
+
+// The ring of a chunk's most recent symbols (k_gz_decode keeps it in LDS; tests/native/test_gz_core.cpp models it): kRing
+// symbols, position p in slot p & (kRing - 1).  A round of <= 64 symbols reads its sources before it writes: everything from
+// kRing positions back is there.  A long match is written 64 symbols a step, each step reading before it writes: symbol k comes
+// from k - distance when the match does not overlap itself (distance >= length: there while distance <= kRing), from the first
+// `distance` symbols over and over when it does (those must survive the up to 256 symbols written before the last step).
+constexpr uint32_t kRing = 512;
+GZ_HD bool ring_holds_long_match(uint32_t distance, uint32_t len) { return distance >= len ? distance <= kRing : distance <= kRing - 256; }
 
 // ---- token-parallel decoding (k_gz_decode): what ONE LANE does with the 64 bits of the stream at its own bit offset ----------------
 // A token = one or two literals, one match (length code + extra bits + distance code + extra bits: at most 15 + 5 + 15 + 13 = 48

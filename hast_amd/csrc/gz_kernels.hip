@@ -201,12 +201,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {              //
     return x;
 }
 
-// 4 waves per SIMD (128 VGPRs): a chunk's time is latency, so chunks in flight are throughput; 16 per CU (9.8 KB of LDS each).
+// 5 waves per SIMD (96 VGPRs): a chunk's time is latency, so chunks in flight are throughput; 20 per CU (7.9 KB of LDS each: tables
+// at zlib's own bounds, a ring of 512 symbols).
 // syms: the base of the symbol memory the jobs' buffers lie in (job.sym_off is an absolute address / 2: the buffer is reached as
 // syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
 // which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
 // symbol instead of ~300)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
     __shared__ uint32_t s_tab[kLitTabCap + kDistTabCap];
     // two lives: while lane 0 parses a block's header, the code-length code's table (kPreTabCap words) and what the parse indexes by
     // values it has just read (HdrScratch: no scratch memory); in the symbol loop, the compressed words around the read position
@@ -217,8 +218,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     uint32_t *const s_in = s_misc, *const s_tok = s_misc + kPreTabCap;
     // the chunk's last kRing symbols: a match that reaches back less than that (in FASTQ most: the record or two in front) is
     // copied out of LDS -- a global load per match would put ~1 us of latency on the path of every symbol behind it
-    constexpr uint32_t kRing = 1024, kRingReach = kRing - 320;
-    __shared__ uint16_t s_ring[kRing];
+    __shared__ uint16_t s_ring[kRing];                                        // (gz_core.h: 512 symbols, and what a copy may take out of them)
     constexpr uint32_t kIsLit = 0x40000000u, kIsMatch = 0x80000000u;
     const uint32_t j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
@@ -309,12 +309,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             {   // two literals per first-level entry where both codes fit (gz_core.h pair_entry): all 64 lanes, 8 entries each, every
                 // entry worked out before any is replaced (LDS operations of a wave execute in order)
                 uint32_t pe[(1u << kLitRoot) / 64];
+                uint32_t l2 = lane;
+                asm volatile("" : "+v"(l2));                                  // (or the eight q * 64 + lane live in registers for the whole kernel: hoisted, one of them spilled)
 #pragma unroll
-                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) pe[q] = pair_entry(lit, q * 64 + lane);
+                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) pe[q] = pair_entry(lit, q * 64 + l2);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) s_tab[q * 64 + lane] = pe[q];
+                for (uint32_t q = 0; q < (1u << kLitRoot) / 64; ++q) s_tab[q * 64 + l2] = pe[q];
                 __syncthreads();
             }
             // ---- the block's symbols, a step = the 64 bit offsets from pos on ----
@@ -394,7 +396,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                 const uint32_t tv = (uint32_t)__shfl((int)mine, (int)leader, 64);
                                 const bool is_m = act && !(mine & kIsLit);
                                 const uint32_t off = tv & 63, dist = (tv >> 14) & 0xFFFF, k = lane - off;
-                                const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;              // positions the ring still holds while this round is written
+                                const int64_t ring_lo = (int64_t)bstart - (int64_t)kRing;                   // what the ring holds (the round reads before it writes)
                                 uint32_t kk = k;
                                 if (k >= dist) {                               // a run: symbol k repeats symbol k mod dist (k < 64: exact in float)
                                     const uint32_t q = (uint32_t)(((float)k + 0.5f) * __frcp_rn((float)dist));
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)tk.olen, (int)p), distance = (uint32_t)__builtin_amdgcn_readlane((int)tk.dist, (int)p);
                     if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; rc = kStError; break; }
                     if (n2 + len > cap) { rc = kStNoRoom; break; }
-                    const bool near = distance <= kRingReach;
+                    const bool near = ring_holds_long_match(distance, len);
                     if (!near) __builtin_amdgcn_s_waitcnt(0);
                     for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                         const uint32_t k = k0 + lane;

@@ -29,7 +29,6 @@ static bool g_wave = false;      // -w: Huffman blocks decoded the way k_gz_deco
 // reach rule is checked (what the kernel would read there must be what the symbol buffer holds).
 static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &pos, const uint32_t *lit, const uint32_t *dst, uint16_t *sym,
                                   uint32_t &n_out, uint32_t cap, bool no_history, uint32_t &err, uint16_t *ring) {
-    constexpr uint32_t kRing = 1024, kRingReach = kRing - 320;
     constexpr uint32_t kIsLit = 0x40000000u, kIsMatch = 0x80000000u;
     uint32_t n2 = n_out;
     bool full = false;                                               // this step parses with the second-level tables too
@@ -81,7 +80,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
                 if (!cur || !nsym || nsym > 64) { fprintf(stderr, "round logic broken\n"); abort(); }
                 if (n2 + nsym > cap) return kStNoRoom;
                 const uint32_t bstart = n2;
-                const int64_t ring_lo = (int64_t)bstart + 64 - (int64_t)kRing;
+                const int64_t ring_lo = (int64_t)bstart - (int64_t)kRing;
                 // the round's tokens at the lanes of their symbols: literals as themselves, a match at its first symbol
                 uint32_t s_tok[64];
                 for (uint32_t j = 0; j < 64; ++j) s_tok[j] = 0;
@@ -147,7 +146,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
             const uint32_t len = tk[p].olen, distance = tk[p].dist;
             if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; return kStError; }
             if (n2 + len > cap) return kStNoRoom;
-            const bool near = distance <= kRingReach;
+            const bool near = ring_holds_long_match(distance, len);
             for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                 uint16_t outv[64];
                 for (uint32_t lane = 0; lane < 64 && k0 + lane < len; ++lane) {
@@ -172,7 +171,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
 static void decode_chunk_wave(ChunkJob &job, const uint32_t *w, uint64_t nbits, uint32_t *tabs, uint16_t *sym) {
     Tables t = tables_at(tabs);
     HdrScratch scr;
-    static uint16_t ring[1024];
+    static uint16_t ring[kRing];
     const bool no_history = (job.flags & kJobNoHistory) != 0;
     uint64_t at = job.start_bit;
     uint32_t n = 0, status = kStFound, err = kErrNone;
@@ -199,7 +198,7 @@ static void decode_chunk_wave(ChunkJob &job, const uint32_t *w, uint64_t nbits, 
             if (n + len + 4 > job.sym_cap) { status |= kStNoRoom; break; }
             for (uint32_t k = 0; k < len; ++k) {
                 sym[n + k] = bytes[4 + k];
-                ring[(n + k) & 1023] = bytes[4 + k];
+                ring[(n + k) & (kRing - 1)] = bytes[4 + k];
             }
             n2 = n + len;
             at = (byte + 4 + len) * 8;

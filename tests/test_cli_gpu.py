@@ -465,7 +465,7 @@ def test_cli_baseline_config1_full_size_vs_oracle(exe, oracle_dir, tmp_path):
 @pytest.mark.heavy
 def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
     """BASELINE config 2's barcode cardinality through the boundary (classify.cpp:50-64,93-102: one map entry and one output row per
-    barcode): 600k synthetic read pairs over 1M barcodes -- some 700k of them seen -- as plain FASTQ and as one .gz, one context and
+    barcode): 600k synthetic read pairs over 1M barcodes -- some 450k of them seen -- as plain FASTQ and as one .gz, one context and
     two.  What only such a run reaches: the host dictionary under ~10^6 inserts, a device-side name cache that keeps learning, the
     bucketed parallel sort of the rows (below 65536 barcodes the program sorts on one thread) and their parallel formatting.
     stdout == the oracle's line-by-line restatement of classify.cpp, byte for byte (tools/gpu/cli_cardinality.sh measures the same
@@ -487,7 +487,7 @@ def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
         ref = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args + ["--read", "r2.fq"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         assert ref.returncode == 0, ref.stderr.decode()[-500:]
         rows = ref.stdout.splitlines()
-        assert 600_000 < len(rows) < 1_000_000
+        assert 400_000 < len(rows) < 500_000                  # 1M x (1 - exp(-0.6)): a pair shares its barcode
         assert rows == sorted(rows, key=lambda r: r.split(b"\t")[0])                       # byte order of the barcodes, as std::map's
         for extra in (["--read", "r2.fq"], ["--read", "r2.fq.gz"], ["--read", "r2.fq.gz", "--devices", "0,0"], ["--read", "r2.fq", "--thread", "1"]):
             got = subprocess.run([exe] + args + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
