@@ -45,6 +45,7 @@
 
 #include "../../include/hast.h"
 #include "ingest.h"
+#include "quartering.h"
 
 namespace {
 
@@ -251,6 +252,9 @@ int main(int argc, char **argv) {
     // The FASTQ streams of the first files (pinned staging + device buffers: ~0.1 s of page pinning) are set up by a thread
     // of their own while this one reads the k-mer files and builds the table.
     std::vector<hast_fq *> pre_fq, done_fq;
+    std::vector<hast_gz *> pre_gz;                         // .gz inputs opened (and being inflated) while the table is built
+    std::vector<hast_status> pre_gz_status;
+    std::vector<std::string> pre_gz_error;
     std::vector<std::thread> gz_closers;
     std::vector<hast_names *> name_caches, own_caches;     // per context / per GPU: device-side cache barcode text -> id
     std::thread pre_thread;
@@ -311,7 +315,18 @@ int main(int argc, char **argv) {
             name_caches.push_back(nm);
         }
         pre_fq.assign(std::min<size_t>(read.size(), stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size())), nullptr);
+        pre_gz.assign(pre_fq.size(), nullptr);
+        pre_gz_status.assign(pre_fq.size(), HAST_OK);
         pre_thread = std::thread([&] {
+            // the first .gz files are opened NOW: their compressed bytes go to the device and their first passes are decoded while the
+            // k-mer files are loaded and the table is built (an inflated stream needs a GPU, not the table; the symbols wait in the
+            // stream's arenas) -- ~0.1 s of decode that used to start when the read phase did
+            for (size_t i = 0; i < pre_gz.size(); i++)
+                if (dev_gz[i]) {
+                    pre_gz_status[i] = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), read[i].c_str(), &pre_gz[i])
+                                              : hast_gz_open(ctxs[i % ctxs.size()], read[i].c_str(), &pre_gz[i]);
+                    if (pre_gz_status[i] != HAST_OK) pre_gz_error.push_back(hast_last_error());
+                }
             for (size_t i = 0; i < pre_fq.size(); i++)
                 if (make_fq(i, &pre_fq[i]) != HAST_OK) {
                     pre_error = hast_last_error();
@@ -417,6 +432,7 @@ int main(int argc, char **argv) {
     // the other GPUs get a copy of the finished table (after the adaptor scrub), peer to peer
     for (size_t i = 1; i < ctxs.size(); i++) CK(hast_table_clone(ctxs[i], ctx), "copying the k-mer table to another GPU");
     size_t next_ctx = 0;
+    const double t_pre_wait0 = now_s();
     if (pre_thread.joinable()) {
         pre_thread.join();
         if (!pre_error.empty()) {
@@ -424,6 +440,7 @@ int main(int argc, char **argv) {
             return 4;
         }
     }
+    const double t_pre_waited = now_s() - t_pre_wait0;
     logtime();
     const double t_scrubbed = now_s();
 
@@ -640,7 +657,12 @@ int main(int argc, char **argv) {
             std::unique_ptr<Feed> f(new Feed());
             f->name = r;
             if (dev_gz[next_file]) {
-                const hast_status gs = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), r.c_str(), &f->gz) : hast_gz_open(ctxs[next_file % ctxs.size()], r.c_str(), &f->gz);
+                hast_status gs;
+                if (next_file < pre_gz.size()) {                   // opened ahead, by the set-up thread
+                    gs = pre_gz_status[next_file];
+                    f->gz = pre_gz[next_file];
+                } else
+                    gs = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), r.c_str(), &f->gz) : hast_gz_open(ctxs[next_file % ctxs.size()], r.c_str(), &f->gz);
                 if (gs == HAST_ERR_UNSUPPORTED) {                  // e.g. no room on the device: the host inflates
                     f->gz = nullptr;
                     dev_gz[next_file] = 0;
@@ -989,6 +1011,97 @@ int main(int argc, char **argv) {
         }
     }
     if (fflush(stdout) != 0) die_output();
+    // ---- HAST_PHASE_READS=1: steps 10 and 11 of the wrapper (classify_stlfr_reads.sh:155-190) done here -------------------------
+    // The wrapper derives three barcode lists from the table above with awk and then routes every record of every input to
+    // <name>.{paternal,maternal,homozygous,nobarcode}.fastq with a single-threaded awk program, re-reading (and re-inflating) every
+    // input.  This program has the barcodes' classes in memory and a GPU that inflates .gz inputs: with HAST_PHASE_READS set it writes the
+    // lists, routes the records (quartering.h: the same bytes as the awk program's, incl. filter_reads.log and the ERROR lines) and
+    // leaves the marker files step_10_done / step_11_done, at which the UNCHANGED wrapper skips its own steps 10 and 11.
+    if (const char *pr = getenv("HAST_PHASE_READS"); pr && *pr && strcmp(pr, "0") != 0) {
+        const double t_ph0 = now_s();
+        namespace hq = hast::quartering;
+        hq::ClassMap cls_of;
+        const char *list_name[3] = {"paternal.unique.barcodes", "maternal.unique.barcodes", "homozygous.unique.barcodes"};
+        const int list_hap[3] = {0, 1, -1};
+        for (int l = 0; l < 3; l++) {
+            std::string text;
+            for (size_t r = 0; r < nb; r++) {
+                const uint32_t i = order[r];
+                const std::string_view bc = names[i];
+                const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
+                if (hast_get_hap(bc.data(), bc.size(), c0, c1, n_set[0], n_set[1], w0, w1) != list_hap[l]) continue;
+                text.append(bc.data(), bc.size());
+                text.push_back('\n');
+                cls_of.emplace(std::string(hq::field(bc, 0)), (uint8_t)(l + 1));          // (a list line's first field, first list wins: awk :12-16)
+            }
+            FILE *lf = fopen(list_name[l], "wb");
+            if (!lf || fwrite(text.data(), 1, text.size(), lf) != text.size() || fclose(lf) != 0) die(2, (std::string("cannot write ") + list_name[l]).c_str());
+        }
+        // a .gz input inflated on the GPU, as a block source for the router: the bytes come back over PCIe block by block
+        constexpr size_t kFrontPad = hast::BlockSource::kFrontPad;     // (room in front of a block's data: what route() expects)
+        struct DevGzSource {
+            hast_ctx *ctx = nullptr;
+            hast_gz *gz = nullptr;
+            void *d_buf = nullptr;
+            size_t cap = 0;
+            std::string err;
+            std::vector<std::vector<char>> spare;
+            ~DevGzSource() {
+                if (gz) hast_gz_close(gz);
+                if (d_buf) hast_dev_free(ctx, d_buf);
+            }
+            std::vector<char> next() {
+                if (!err.empty()) return {};
+                std::vector<char> blk;
+                if (!spare.empty()) { blk = std::move(spare.back()); spare.pop_back(); }
+                blk.resize(kFrontPad + cap);
+                size_t n = 0;
+                if (hast_gz_read_device(gz, static_cast<uint8_t *>(d_buf), cap, &n, nullptr) != HAST_OK ||
+                    (n && hast_memcpy_d2h(ctx, blk.data() + kFrontPad, d_buf, n) != HAST_OK)) {
+                    err = hast_last_error();
+                    return {};
+                }
+                if (n == 0) return {};                       // (a short block is followed by another call: damage behind it is reported then)
+                blk.resize(kFrontPad + n);
+                return blk;
+            }
+            void recycle(std::vector<char> &&b) { spare.push_back(std::move(b)); }
+            const std::string &error() const { return err; }
+        };
+        for (size_t fi = 0; fi < read.size(); fi++) {
+            const std::string &x = read[fi];
+            std::string name = x.substr(x.find_last_of('/') == std::string::npos ? 0 : x.find_last_of('/') + 1);
+            const bool gz_name = name.size() >= 3 && name.compare(name.size() - 3, 3, ".gz") == 0;      // (the wrapper's ${name: -3} == ".gz")
+            if (gz_name) name.resize(name.size() - 3);
+            int rc;
+            if (gz_name && dev_gz[fi]) {
+                DevGzSource src;
+                src.ctx = ctx;
+                src.cap = 64u << 20;
+                if (hast_gz_open(ctx, x.c_str(), &src.gz) != HAST_OK || hast_dev_alloc(ctx, src.cap, &src.d_buf) != HAST_OK) {
+                    src.gz = nullptr;                        // (no room on the device, ...: the host inflates)
+                    hast::BlockSource hsrc;
+                    if (!hsrc.open(x, 64u << 20)) die(2, ("cannot open " + x).c_str());
+                    rc = hq::route(name, cls_of, hsrc, "-", t_num, "classify");
+                } else rc = hq::route(name, cls_of, src, "-", t_num, "classify");
+            } else {
+                hast::BlockSource hsrc;
+                if (!hsrc.open(x, 64u << 20)) die(2, ("cannot open " + x).c_str());
+                rc = hq::route(name, cls_of, hsrc, gz_name ? "-" : x, t_num, "classify");       // (awk's FILENAME behind `gzip -dc` is "-")
+            }
+            if (rc) {
+                fprintf(stderr, "classify: ERROR: routing the reads of %s failed\n", x.c_str());
+                fflush(stderr);
+                _exit(rc);
+            }
+        }
+        for (const char *marker : {"step_10_done", "step_11_done"}) {
+            FILE *mf = fopen(marker, "ab");                   // (the wrapper appends `date` to them and only tests that they exist)
+            time_t now = time(0);
+            if (!mf || fprintf(mf, "%s", ctime(&now)) < 0 || fclose(mf) != 0) die(2, (std::string("cannot write ") + marker).c_str());
+        }
+        if (stats) fprintf(stderr, "__stats_phase_reads__ lists_and_routing_s=%.3f inputs=%zu\n", now_s() - t_ph0, read.size());
+    }
     if (past_int)
         fprintf(stderr, " WARN : a barcode has more than INT_MAX hits: the reference's `int` counters overflow on this input; the exact counts were printed\n");
     logtime();
@@ -998,6 +1111,7 @@ int main(int argc, char **argv) {
                 K, (unsigned long long)n_set[0], (unsigned long long)n_set[1], (unsigned long long)total_reads,
                 (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
+    if (stats) fprintf(stderr, "__stats_setup__ waited_for_stream_setup_s=%.3f (inside scrub_sizes_clone_s: .gz inputs opened, FASTQ streams created while the table was built)\n", t_pre_waited);
     if (stats) {
         char sw[512] = "";
         (void)hast_ctx_options(ctx, sw, sizeof(sw));          // measurement switches this context was created with (none by default)

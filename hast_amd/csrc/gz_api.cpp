@@ -658,12 +658,22 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         step(U.fjobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
         for (Arena &a : U.arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
         tr("job buffers");
-        // the symbol arenas up front: an allocation that fails later would fail in mid-file (a unit's segments: ui, ui + nu, ...)
+        // the unit's first symbol arena now, the other two when their first pass is launched (launch_nominal) -- 3.2 GB each, 5-10 ms
+        // of hipMalloc that the caller's thread need not wait for; that there IS room for them is checked here, so that a device
+        // without it is refused at the door (the caller then inflates on the host) instead of failing in mid-file
+        size_t later = 0;
         for (int i = 0; i < Unit::kArenas && e == hipSuccess; ++i) {
             const size_t k = ui + (size_t)i * nu;
             if (k >= n_seg) break;
             const size_t chunks = k == 0 ? (n_seg == 1 ? std::max(s0, std::min(seg, n_chunks)) : s0) : seg;
-            step(U.arena[i].syms.ensure(chunks * (size_t)g->slot_syms * sizeof(uint16_t) + 64));
+            const size_t bytes = chunks * (size_t)g->slot_syms * sizeof(uint16_t) + 64;
+            if (i == 0) step(U.arena[i].syms.ensure(bytes));
+            else later += bytes + chunks * ((size_t)kWindow * 3 + 64);              // (+ windows, maps, per-chunk words of a batch)
+        }
+        if (e == hipSuccess && later) {
+            size_t free_b = 0, total_b = 0;
+            step(hipMemGetInfo(&free_b, &total_b));
+            if (e == hipSuccess && free_b < later + (later >> 2) + (1ull << 30)) e = hipErrorOutOfMemory;
         }
         tr("arenas");
     }

@@ -55,10 +55,23 @@ HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
 // inside the slice), then the same overflow walk.  A minimizer's keys (~8.5 per occupied minimizer at 30x, error k-mers included)
 // then no longer pile up in one bucket while seven in eight stay empty, and a wave's 64 windows rarely need a second bucket.
 // A table is filled by one of the two ways only (hast_kc_create decides), and its readers are scans.
-HAST_HD uint32_t kc_key_bucket(uint64_t key, uint32_t n_here) {
-    const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) * 0x85EBCA6Bu;
-    return (uint32_t)(((uint64_t)(h ^ (h >> 15)) * n_here) >> 32);
+// The hash: 24-bit multiplies only.  k_kc_apply is bound by VALU issue (2.99e10 VALU instructions x 4 cycles = its 50 ms), and a
+// 32 x 32-bit multiply takes a quarter-rate instruction on this part where a 24-bit one (v_mul_u32_u24) takes a full-rate one: the
+// 64-bit product + remix + range reduction of round 4 were five quarter-rate multiplies per window, 80 of its ~570 cycles.
+HAST_HD uint32_t kc_mul24(uint32_t a, uint32_t b) { return mul24_forced(a, b); }      // (hast_common.h: the instruction by name -- where the
+                                                                                         // compiler proves an operand below 2^24 it rewrites the product as a
+                                                                                         // plain 32-bit multiply and selects the quarter-rate instruction)
+HAST_HD uint32_t kc_key_hash(uint64_t key) {
+    const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
+    uint32_t h = kc_mul24(a, 0x9E3779u) ^ kc_mul24(a >> 8, 0x85EBCBu) ^ kc_mul24(b, 0xC2B2AFu) ^ (kc_mul24(b >> 8, 0x27D4EBu) << 7);
+    h ^= h >> 15;
+    h = kc_mul24(h, 0x2C1B3Du) ^ kc_mul24(h >> 9, 0x7FEB35u);
+    return h ^ (h >> 13);
 }
+HAST_HD uint32_t kc_bucket_of_hash(uint32_t h, uint32_t n_here) { return kc_mul24(h >> 16, n_here) >> 16; }      // n_here <= 2^16: slices of 512 or 1024 buckets
+HAST_HD uint32_t kc_key_bucket(uint64_t key, uint32_t n_here) { return kc_bucket_of_hash(kc_key_hash(key), n_here); }
+// the tag of a key in a slice's LDS copy (k_kc_apply): 7 other bits of the same hash under a set top bit (0 = the slot is empty)
+HAST_HD uint32_t kc_tag_of_hash(uint32_t h) { return ((h >> 3) & 0x7Fu) | 0x80u; }
 
 // slice of the key space a window belongs to (decided by its minimizer, so a bucket never mixes slices)
 HAST_HD uint32_t kc_slice_of(uint32_t minh, uint32_t n_slices) {

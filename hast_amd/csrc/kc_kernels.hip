@@ -490,11 +490,12 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
 // round trip at a time: runs of 1..9 windows x 1..32 slots, every wave as slow as its slowest lane -- 0.38 s of LDS probes per
 // flush against 0.20 s for everything else.
 // tag of a key in a slice's LDS copy: 7 bits of a hash of the key under a set top bit (0 = the slot is empty)
-__device__ __forceinline__ uint32_t kc_tag(unsigned long long key) {
-    if (key == kEmptySlot) return 0u;
-    const uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
-    return ((x * 0x9E3779B1u) >> 25) | 0x80u;
+__device__ __forceinline__ uint32_t kc_tag(unsigned long long key) { return key == kEmptySlot ? 0u : kc_tag_of_hash(kc_key_hash(key)); }
+// a bucket of the slice's LDS copy: 17 words = 136 bytes from the next (shifts: a 32-bit multiply is a quarter-rate instruction)
+__device__ __forceinline__ unsigned long long *kc_lds_bucket(unsigned char *smem, uint32_t b) {
+    return reinterpret_cast<unsigned long long *>(smem + (b << 7) + (b << 3));
 }
+static_assert(kKcBucketWords + 1 == 17, "kc_lds_bucket assumes 17-word buckets");
 __device__ __forceinline__ unsigned long long kc_zero_bytes64(unsigned long long x) {      // 0x80 in every byte of x that is zero (exact)
     const unsigned long long m = 0x7F7F7F7F7F7F7F7Full;
     return ~(((x & m) + m) | x | m);
@@ -509,7 +510,6 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
     // [buckets of the slice][kKcLdsStride]: a bucket is 16 words = 128 B = exactly the 32 LDS banks, so slot i of EVERY bucket would sit
     // in the same bank and the 64 lanes of a probe (64 different buckets, the same slot) would take 64 turns at it; one word of
     // padding per bucket spreads them
-    unsigned long long *s_tab = reinterpret_cast<unsigned long long *>(smem);
     const uint32_t fine = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t f = fill[fine], v = valid[fine];
     const uint32_t n = f < v ? (f < cap ? f : cap) : v;
@@ -533,12 +533,12 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             for (int q = 0; q < 4; ++q) {
                 const uint32_t i = i0 + (uint32_t)q * kKcApplyThreads;
                 if (i < nvec) {
-                    unsigned long long *d = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
+                    unsigned long long *d = kc_lds_bucket(smem, i >> 3) + 2 * (i & 7);
                     d[0] = t[q].x;
                     d[1] = t[q].y;
                     // the bucket's 17th word: a TAG byte per key slot (0 = empty), so that a probe reads 8 bytes, not 8 keys
                     if ((i & 7) < kKcSlots / 2)
-                        reinterpret_cast<uint16_t *>(s_tab + (size_t)(i >> 3) * kKcLdsStride + kKcBucketWords)[i & 7] = (uint16_t)(kc_tag(t[q].x) | (kc_tag(t[q].y) << 8));
+                        reinterpret_cast<uint16_t *>(kc_lds_bucket(smem, i >> 3) + kKcBucketWords)[i & 7] = (uint16_t)(kc_tag(t[q].x) | (kc_tag(t[q].y) << 8));
                 }
             }
         }
@@ -558,13 +558,15 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             rec_next = lane < RS && nx < n ? mine[nx] : 0ull;
         }
         const uint32_t run = has ? (uint32_t)((rec >> 1) & 31) + 1 : 0u;
+        // (prefix sum in the VALU's own data path: six ds_bpermute rounds queued behind the probes' LDS traffic)
         uint32_t incl = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-            if (lane >= (uint32_t)off) incl += t;
-        }
-        const uint32_t P = incl - run, T = (uint32_t)__shfl((int)incl, 63, 64);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);
+        const uint32_t P = incl - run, T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         for (uint32_t j = 0; j < run; ++j) s_map[P + j] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -578,9 +580,12 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             const uint32_t jw = act ? w - pw : 0u;                                 // window jw of its record
             const unsigned long long raw = ((rw >> 6) >> (2 * (run_w - 1 - jw))) & kmask;
             const unsigned long long key = kmer_canon(raw, g.k);
-            const uint32_t hw = kc_key_bucket(key, nb_here);
-            const uint32_t tag = kc_tag(key);
-            const unsigned long long tagx = 0x0101010101010101ull * tag;
+            const uint32_t kh = kc_key_hash(key);
+            const uint32_t hw = kc_bucket_of_hash(kh, nb_here);
+            const uint32_t tag = kc_tag_of_hash(kh);
+            uint32_t t32 = tag | (tag << 8);
+            t32 |= t32 << 16;
+            const unsigned long long tagx = ((unsigned long long)t32 << 32) | t32;
             bool done = !act;
 #pragma unroll 1
             for (uint32_t p = 0; p < 4; ++p) {                                     // (kc_probe: the key's bucket in the slice, then the next three)
@@ -588,18 +593,22 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
                 uint32_t b = hw + p;
                 b = b >= nb_here ? b - nb_here : b;
                 if (!done) {
-                    unsigned long long *bk = s_tab + (size_t)b * kKcLdsStride;
+                    unsigned long long *bk = kc_lds_bucket(smem, b);
                     // ONE 8-byte read of the bucket's tags instead of its eight keys (round 4: 8 LDS reads and 16 compare + select per
                     // window and probe -- 158 lane-instructions per window, 4.3 bank-conflict cycles per LDS instruction): a slot whose tag
                     // matches is read and compared (one in 128 occupied slots matches by chance), a key that is not there goes in by
                     // compare-and-swap from the first slot whose tag says empty, and writes its tag behind itself.  A tag that is not
                     // written yet only sends another lane with the same key into the same compare-and-swap, which then finds it there.
                     const unsigned long long tg = bk[kKcBucketWords];
-                    int idx = -1;
-                    unsigned long long mt = kc_zero_bytes64(tg ^ tagx);
-                    while (mt) {
-                        const int i = __builtin_ctzll(mt) >> 3;
-                        mt &= mt - 1;
+                    const unsigned long long mt = kc_zero_bytes64(tg ^ tagx);
+                    // the first slot whose tag matches, in straight-line code (a key that is there is found here; a second matching tag
+                    // -- one occupied slot in 128 matches by chance -- is the loop's business)
+                    const int i0 = __builtin_ctzll(mt | (1ull << 63)) >> 3;
+                    int idx = (mt != 0 && bk[i0] == key) ? i0 : -1;
+                    unsigned long long rest = idx < 0 ? (mt & (mt - 1)) : 0ull;
+                    while (rest) {
+                        const int i = __builtin_ctzll(rest) >> 3;
+                        rest &= rest - 1;
                         if (bk[i] == key) { idx = i; break; }
                     }
                     if (idx < 0) {
@@ -640,7 +649,7 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
     {
         u64x2 *gdst = reinterpret_cast<u64x2 *>(g.table + (size_t)b0 * kKcBucketWords);
         for (uint32_t i = tid; i < nb_here * (kKcBucketWords / 2); i += kKcApplyThreads) {
-            const unsigned long long *sp = s_tab + (size_t)(i >> 3) * kKcLdsStride + 2 * (i & 7);
+            const unsigned long long *sp = kc_lds_bucket(smem, i >> 3) + 2 * (i & 7);
             gdst[i] = u64x2{sp[0], sp[1]};
         }
     }

@@ -495,3 +495,40 @@ def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
             assert got.stdout == ref.stdout, extra
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_cli_phase_reads_does_the_wrappers_steps_10_and_11(exe, golden_workdir, tmp_path):
+    """HAST_PHASE_READS=1: `classify` writes the three barcode lists and routes every record of every input itself -- steps 10 and 11
+    of classify_stlfr_reads.sh:155-190, which the unchanged wrapper then skips (step_10_done / step_11_done) -- with .gz inputs
+    inflated on the GPU a second time instead of `gzip -dc | awk`.  Expected files: the lists as the wrapper's awk one-liners derive
+    them from stdout, the routing as the stand-alone quartering_fastq does it from those lists (tests/test_quartering_cpu.py pins that
+    program to the reference's awk program byte for byte), one input plain and one .gz, as the wrapper would call it."""
+    import gzip
+    import shutil
+    from tests.conftest import ROOT
+    qf = os.path.join(ROOT, "hast_amd", "quartering_fastq")
+    a, b = tmp_path / "a", tmp_path / "b"
+    for d in (a, b):
+        shutil.copytree(golden_workdir / "rand_k21", d)
+        with gzip.open(d / "r1.fq.gz") as f, open(d / "r1.fq", "wb") as g:
+            shutil.copyfileobj(f, g)
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--weight0", "1.04", "--read", "r1.fq", "--read", "r2.fq.gz", "--thread", "5"]
+    ref = subprocess.run([exe] + args, cwd=b, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert ref.returncode == 0 and not (b / "step_10_done").exists()
+    got = subprocess.run([exe] + args + ["--stats"], cwd=a, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_PHASE_READS="1"))
+    assert got.returncode == 0, got.stderr.decode()[-1000:]
+    assert got.stdout == ref.stdout and b"__stats_phase_reads__" in got.stderr
+    assert (a / "step_10_done").exists() and (a / "step_11_done").exists()
+    # the wrapper's own steps, in b
+    rows = [r.split(b"\t") for r in ref.stdout.splitlines()]
+    for name, hap in (("paternal", b"0"), ("maternal", b"1"), ("homozygous", b"-1")):
+        (b / (name + ".unique.barcodes")).write_bytes(b"".join(r[0] + b"\n" for r in rows if r[1] == hap))
+    lists = ["paternal.unique.barcodes", "maternal.unique.barcodes", "homozygous.unique.barcodes"]
+    r1 = subprocess.run([qf, "--prefix", "r1.fq"] + lists + ["r1.fq"], cwd=b, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r2 = subprocess.run([qf, "--prefix", "r2.fq"] + lists + ["-"], cwd=b, input=gzip.open(b / "r2.fq.gz").read(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r1.returncode == 0 and r2.returncode == 0
+    made = sorted(p.name for p in b.iterdir() if p.name.endswith((".fastq", ".barcodes", "filter_reads.log")))
+    assert len([m for m in made if m.endswith(".fastq")]) >= 6
+    for m in made:
+        assert (a / m).exists() and (a / m).read_bytes() == (b / m).read_bytes(), m
+    assert sorted(p.name for p in a.iterdir() if p.name.endswith(".fastq")) == [m for m in made if m.endswith(".fastq")]
