@@ -320,18 +320,26 @@ int main(int argc, char **argv) {
         pre_thread = std::thread([&] {
             // the first .gz files are opened NOW: their compressed bytes go to the device and their first passes are decoded while the
             // k-mer files are loaded and the table is built (an inflated stream needs a GPU, not the table; the symbols wait in the
-            // stream's arenas) -- ~0.1 s of decode that used to start when the read phase did
-            for (size_t i = 0; i < pre_gz.size(); i++)
-                if (dev_gz[i]) {
-                    pre_gz_status[i] = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), read[i].c_str(), &pre_gz[i])
-                                              : hast_gz_open(ctxs[i % ctxs.size()], read[i].c_str(), &pre_gz[i]);
-                    if (pre_gz_status[i] != HAST_OK) pre_gz_error.push_back(hast_last_error());
-                }
+            // stream's arenas) -- ~0.1 s of decode that used to start when the read phase did.  A thread per input: opening a stream and
+            // creating its FASTQ framer is mostly page pinning and device allocation, which the inputs need not queue up for.
+            std::mutex err_mu;
+            std::vector<std::thread> per_file;
             for (size_t i = 0; i < pre_fq.size(); i++)
-                if (make_fq(i, &pre_fq[i]) != HAST_OK) {
-                    pre_error = hast_last_error();
-                    return;
-                }
+                per_file.emplace_back([&, i] {
+                    if (dev_gz[i]) {
+                        pre_gz_status[i] = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), read[i].c_str(), &pre_gz[i])
+                                                  : hast_gz_open(ctxs[i % ctxs.size()], read[i].c_str(), &pre_gz[i]);
+                        if (pre_gz_status[i] != HAST_OK) {
+                            std::lock_guard<std::mutex> g(err_mu);
+                            pre_gz_error.push_back(hast_last_error());
+                        }
+                    }
+                    if (make_fq(i, &pre_fq[i]) != HAST_OK) {
+                        std::lock_guard<std::mutex> g(err_mu);
+                        pre_error = hast_last_error();
+                    }
+                });
+            for (std::thread &t : per_file) t.join();
         });
     };
     double t_loaded = 0, t_ctx = 0;

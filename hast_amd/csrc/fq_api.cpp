@@ -317,7 +317,9 @@ static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, s
     FQ_TRY(hipMalloc((void **)&s.d_off, max_rec * sizeof(uint64_t)));
     for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) FQ_TRY(hipMalloc((void **)p, max_rec * sizeof(uint32_t)));
     FQ_TRY(hipMalloc((void **)&s.d_votes, max_rec * 2 * sizeof(uint32_t)));
-    size_t cap = block / 96 + 4096;                    // a record of 150-bp reads is ~340 bytes; shorter ones take the copy path
+    // records the pinned per-record arrays hold (34 B each: page pinning is ~0.7 ms per MB, six slots a stream): a record of 100-bp
+    // reads is ~240 bytes, of 150-bp reads ~340; a block of shorter ones takes the copy path and grows the arrays (hast_fq_next)
+    size_t cap = block / 224 + 4096;
     if (const char *e = getenv("HAST_FQ_HOST_RECORDS")) cap = (size_t)std::max(1L, atol(e));           // (tests: force the copy path)
     if (hast_status st = grow_records(s, cap)) return st;
     for (hipEvent_t *e : {&s.named, &s.copied, &s.parsed, &s.done}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
