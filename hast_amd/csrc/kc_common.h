@@ -42,10 +42,39 @@ HAST_HD uint32_t kc_run_max(int k, int m) {
     const int c = r < w ? r : w;
     return c < 1 ? 0u : (c > 16 ? 16u : (uint32_t)c);
 }
+// THE ORDER OF M-MERS (which of a window's m-mers is its minimizer) and what names a record's slice of the table: 28 hash bits above
+// four zero bits.  The emit kernel (k_kc_emit4) puts a position into those four bits and takes ONE unsigned minimum per m-mer for
+// "smallest hash, leftmost on ties"; everything placed by a minimizer is placed by this VALUE, never by the m-mer itself, so two
+// different m-mers with the same value in one window -- each strand would pick its own leftmost -- still name the same slice.
+// 24-bit multiplies (full-rate instructions, kc_mul24 below): the 64-bit multiply-shift of stage 01's table (mmer_hash32) is two
+// quarter-rate multiplies per position on a kernel that is bound by VALU issue.
+HAST_HD uint32_t kc_mul24(uint32_t a, uint32_t b) { return mul24_forced(a, b); }      // (hast_common.h: the instruction by name -- where the
+                                                                                         // compiler proves an operand below 2^24 it rewrites the product as a
+                                                                                         // plain 32-bit multiply and selects the quarter-rate instruction)
+HAST_HD uint32_t kc_mmer_hash32(uint32_t canon_mmer) {                                  // m <= 16
+    uint32_t h = kc_mul24(canon_mmer, 0x9E3779u) ^ kc_mul24(canon_mmer >> 8, 0x85EBCBu);
+    h ^= h >> 15;
+    return h & ~15u;
+}
+HAST_HD uint32_t kc_mmer_hash(uint64_t canon_mmer) {                                    // any m; == kc_mmer_hash32 where the m-mer fits 32 bits
+    const uint32_t a = (uint32_t)canon_mmer, b = (uint32_t)(canon_mmer >> 32);
+    uint32_t h = kc_mul24(a, 0x9E3779u) ^ kc_mul24(a >> 8, 0x85EBCBu) ^ kc_mul24(b, 0xC2B2AFu) ^ (kc_mul24(b >> 8, 0x27D4EBu) << 7);
+    h ^= h >> 15;
+    return h & ~15u;
+}
+// the minimizer value of a k-mer (any strand): the smallest kc_mmer_hash over its canonical m-mers
+HAST_HD uint32_t kc_minimizer_hash(uint64_t kmer, int k, int m) {
+    uint32_t best = 0xFFFFFFFFu;
+    for (int j = 0; j + m <= k; ++j) {
+        const uint32_t h = kc_mmer_hash(kmer_canon((kmer >> (2 * (k - m - j))) & kmer_mask(m), m));
+        best = h < best ? h : best;
+    }
+    return best;
+}
 HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
     const uint32_t run = (uint32_t)((rec >> 1) & 31) + 1, off = ob ? (uint32_t)(rec >> (64 - ob)) : 0u;
     const uint64_t first = ((rec >> 6) >> (2 * (run - 1))) & kmer_mask(k);
-    return mmer_hash32(kmer_canon((first >> (2 * ((uint32_t)(k - m) - off))) & kmer_mask(m), m));
+    return kc_mmer_hash(kmer_canon((first >> (2 * ((uint32_t)(k - m) - off))) & kmer_mask(m), m));
 }
 
 // PLACEMENT.  Direct counting (one atomic per minimizer run) files a key in its minimizer's bucket, then the next three, then from a
@@ -58,9 +87,6 @@ HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
 // The hash: 24-bit multiplies only.  k_kc_apply is bound by VALU issue (2.99e10 VALU instructions x 4 cycles = its 50 ms), and a
 // 32 x 32-bit multiply takes a quarter-rate instruction on this part where a 24-bit one (v_mul_u32_u24) takes a full-rate one: the
 // 64-bit product + remix + range reduction of round 4 were five quarter-rate multiplies per window, 80 of its ~570 cycles.
-HAST_HD uint32_t kc_mul24(uint32_t a, uint32_t b) { return mul24_forced(a, b); }      // (hast_common.h: the instruction by name -- where the
-                                                                                         // compiler proves an operand below 2^24 it rewrites the product as a
-                                                                                         // plain 32-bit multiply and selects the quarter-rate instruction)
 HAST_HD uint32_t kc_key_hash(uint64_t key) {
     const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
     uint32_t h = kc_mul24(a, 0x9E3779u) ^ kc_mul24(a >> 8, 0x85EBCBu) ^ kc_mul24(b, 0xC2B2AFu) ^ (kc_mul24(b >> 8, 0x27D4EBu) << 7);

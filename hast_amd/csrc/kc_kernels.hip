@@ -96,6 +96,43 @@ __device__ __forceinline__ void kc_count_record(unsigned long long *table, uint3
     }
 }
 
+// phase A of a tile (both front ends): 16 bytes per lane -> 32 bits of 2-bit codes + 16 validity bits, into LDS.  Bytes in front of
+// the buffer and behind its end read as separators.
+__device__ __forceinline__ void kc_tile_pack(uintptr_t base_addr, uintptr_t end_addr, uint64_t t0, uint32_t NW, unsigned long long *s_pack, uint32_t *s_inv, uint32_t tid) {
+    const uint32_t HW = NW * 2;
+    for (uint32_t j = tid; j < HW; j += kKcThreads) {
+        const uintptr_t addr = base_addr + t0 + 16 * (uint64_t)j;
+        const uintptr_t a4 = addr & ~(uintptr_t)3;
+        const uint32_t bsh = (uint32_t)(addr & 3);
+        uint32_t d[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uintptr_t p = a4 + 4 * i;
+            uint32_t x = 0x0A0A0A0Au;
+            if (p + 4 <= end_addr && p >= base_addr) x = *reinterpret_cast<const uint32_t *>(p);
+            else if (p < end_addr && p + 4 > base_addr) {        // dword straddles an end of the buffer: byte-wise
+                x = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const uintptr_t pb = p + q;
+                    const uint32_t c = (pb >= base_addr && pb < end_addr) ? *reinterpret_cast<const uint8_t *>(pb) : 0x0Au;
+                    x |= c << (8 * q);
+                }
+            }
+            d[i] = x;
+        }
+        uint32_t packed = 0, invalid = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], bsh);
+            invalid = (invalid << 4) | not_acgt4_anycase(x);
+            packed = (packed << 8) | pack4(x);
+        }
+        // word w = bases 32w..32w+31, first base most significant: the even half-word is the high half
+        reinterpret_cast<uint32_t *>(s_pack + (j >> 1))[1 - (j & 1)] = packed;
+        reinterpret_cast<uint16_t *>(s_inv + (j >> 1))[1 - (j & 1)] = (uint16_t)invalid;
+    }
+}
+
 // EMIT: instead of updating the table, write the windows out as records (a.rec_out; what finds no room there is counted on the spot)
 template <int WT, bool EMIT>
 __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
@@ -142,38 +179,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
         }
 
         // ---- A: 16 bytes per lane -> 32 bits of codes + 16 validity bits -----------------------------------
-        const uint32_t HW = NW * 2;
-        for (uint32_t j = tid; j < HW; j += kKcThreads) {
-            const uintptr_t addr = base_addr + t0 + 16 * (uint64_t)j;
-            const uintptr_t a4 = addr & ~(uintptr_t)3;
-            const uint32_t bsh = (uint32_t)(addr & 3);
-            uint32_t d[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const uintptr_t p = a4 + 4 * i;
-                uint32_t x = 0x0A0A0A0Au;
-                if (p + 4 <= end_addr && p >= base_addr) x = *reinterpret_cast<const uint32_t *>(p);
-                else if (p < end_addr && p + 4 > base_addr) {        // dword straddles an end of the buffer: byte-wise
-                    x = 0;
-                    for (int q = 0; q < 4; ++q) {
-                        const uintptr_t pb = p + q;
-                        const uint32_t c = (pb >= base_addr && pb < end_addr) ? *reinterpret_cast<const uint8_t *>(pb) : 0x0Au;
-                        x |= c << (8 * q);
-                    }
-                }
-                d[i] = x;
-            }
-            uint32_t packed = 0, invalid = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], bsh);
-                invalid = (invalid << 4) | not_acgt4_anycase(x);
-                packed = (packed << 8) | pack4(x);
-            }
-            // word w = bases 32w..32w+31, first base most significant: the even half-word is the high half
-            reinterpret_cast<uint32_t *>(s_pack + (j >> 1))[1 - (j & 1)] = packed;
-            reinterpret_cast<uint16_t *>(s_inv + (j >> 1))[1 - (j & 1)] = (uint16_t)invalid;
-        }
+        kc_tile_pack(base_addr, end_addr, t0, NW, s_pack, s_inv, tid);
         __syncthreads();
 
         // ---- M: hash of the canonical m-mer at every position --------------------------------------------
@@ -182,11 +188,11 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                 const uint32_t f = (uint32_t)window_bits(s_pack, q, mshift);
                 uint32_t r = __brev(f ^ 0xAAAAAAAAu);
                 r = (((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u)) >> (32 - 2 * M);
-                s_mh[q] = mmer_hash32((unsigned long long)(f < r ? f : r));
+                s_mh[q] = kc_mmer_hash32(f < r ? f : r);
             }
         } else {
             for (uint32_t q = tid; q < TB + W - 1; q += kKcThreads)
-                s_mh[q] = mmer_hash32(kmer_canon(window_bits(s_pack, q, mshift), M));
+                s_mh[q] = kc_mmer_hash(kmer_canon(window_bits(s_pack, q, mshift), M));
         }
         __syncthreads();
 
@@ -312,6 +318,208 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
     if ((tid & 63) == 0 && counted) atomicAdd(a.total + a.parent, counted);
 }
 
+// ---- the emit front end of the default geometries (m = 16, W = K - 15 = 2 .. 6: K = 17 .. 21) -------------------------------------
+// k_kc_count<W, EMIT> above spends 152 lane-instructions per window, a lane per position and then a lane per window.  Here a lane
+// takes FOUR consecutive positions, then four consecutive windows:
+//   M: the 32 bases behind position 4i as one 64-bit word and its reverse complement, computed ONCE; the four 16-mers and their
+//      reverse complements are 32-bit funnel shifts of the two; canonical = min; kc_mmer_hash32 (24-bit multiplies); one 16-byte store.
+//   B: the 9 = W + 3 hashes behind window 4g (three LDS reads) get their index in the block ORed into the four zero bits at their
+//      bottom -- ONE unsigned minimum then orders by (hash, position) -- and the four window minima share their middle; a window
+//      continues the run of the one in front of it iff both are valid and name the same position (one neighbour lane for the first
+//      of the four); a run's length comes from the continuation bits of this lane and the next two (a run is at most W <= 6 windows);
+//      the STARTS of runs are counted over the wave step (256 windows) with four ballots and written as 4-byte descriptors
+//      (window, run, offset of the m-mer) -- one LDS atomic per wave step.
+//   C: a lane per DESCRIPTOR, densely: the run's bases out of the packed tile, the 8-byte record straight to its place in HBM.
+// Records are what k_kc_count<W, true> writes (kc_common.h), cut at steps of 256 windows instead of 64.
+constexpr uint32_t kKcE4Pad = 80;                                              // words of s_mh behind the tile's window starts
+__host__ __device__ inline size_t kc_emit4_mh_at(uint32_t nw) { return (16 + (size_t)nw * 12 + 15) & ~(size_t)15; }
+template <int WT>
+__global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
+    static_assert(WT >= 2 && WT <= 6, "a run must end inside the next two lanes");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t TB = a.tile_bases;                                // a multiple of 1024: four waves x 256 windows a round
+    const uint32_t K = (uint32_t)a.k;
+    const uint32_t span = TB + K - 1, NW = (span + 31) / 32 + 2;
+    unsigned long long *s_tile = reinterpret_cast<unsigned long long *>(smem);
+    unsigned long long *s_pack = s_tile + 2;                         // [NW]
+    uint32_t *s_inv = reinterpret_cast<uint32_t *>(s_pack + NW);     // [NW] invalid-byte masks (bit 31 = first base)
+    uint32_t *s_mh = reinterpret_cast<uint32_t *>(smem + kc_emit4_mh_at(NW));   // [TB + kKcE4Pad], 16-byte aligned
+    uint32_t *s_desc = s_mh + TB + kKcE4Pad;                         // [TB]: a tile cannot hold more runs than windows
+    __shared__ uint32_t s_nrec;
+    __shared__ unsigned long long s_rec_base, s_chunk_at, s_chunk_end, s_fill_lo, s_fill_hi;     // (chunks: as in k_kc_count)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t n_tiles = (a.n_starts + TB - 1) / TB;
+    const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bytes);
+    const uintptr_t end_addr = base_addr + a.n_bytes;
+    const uint32_t ob = a.rec_off_bits;
+    unsigned long long counted = 0;
+
+    if (tid == 0) {
+        *s_tile = (unsigned long long)blockIdx.x;
+        s_chunk_at = s_chunk_end = 0;
+    }
+    __syncthreads();
+    for (;;) {
+        const uint64_t tile = *s_tile;
+        if (tile >= n_tiles) break;
+        const uint64_t t0 = tile * TB;
+        __syncthreads();
+        if (tid == 0) {
+            *s_tile = tile + gridDim.x;
+            s_nrec = 0;
+        }
+        kc_tile_pack(base_addr, end_addr, t0, NW, s_pack, s_inv, tid);
+        __syncthreads();
+
+        // ---- M ---------------------------------------------------------------------------------------------------------------
+        for (uint32_t q0 = 4 * tid; q0 < TB + WT - 1; q0 += 4 * kKcThreads) {
+            const unsigned long long x = window_bits(s_pack, q0, 0);                               // bases q0 .. q0 + 31
+            unsigned long long y = __brevll(x ^ 0xAAAAAAAAAAAAAAAAull);
+            y = ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);           // their reverse complement
+            const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x, yh = (uint32_t)(y >> 32), yl = (uint32_t)y;
+            uint4 h;
+            {
+                const uint32_t f = xh, r = yl;
+                h.x = kc_mmer_hash32(f < r ? f : r);
+            }
+            {
+                const uint32_t f = __builtin_amdgcn_alignbit(xh, xl, 30), r = __builtin_amdgcn_alignbit(yh, yl, 2);
+                h.y = kc_mmer_hash32(f < r ? f : r);
+            }
+            {
+                const uint32_t f = __builtin_amdgcn_alignbit(xh, xl, 28), r = __builtin_amdgcn_alignbit(yh, yl, 4);
+                h.z = kc_mmer_hash32(f < r ? f : r);
+            }
+            {
+                const uint32_t f = __builtin_amdgcn_alignbit(xh, xl, 26), r = __builtin_amdgcn_alignbit(yh, yl, 6);
+                h.w = kc_mmer_hash32(f < r ? f : r);
+            }
+            *reinterpret_cast<uint4 *>(s_mh + q0) = h;
+        }
+        __syncthreads();
+
+        // ---- B ---------------------------------------------------------------------------------------------------------------
+        const uint64_t left = a.n_starts - t0;
+        const uint32_t nwin = left < TB ? (uint32_t)left : TB;
+        for (uint32_t base = wave * 256; base < nwin; base += (kKcThreads / 64) * 256) {          // wave-uniform
+            const uint32_t p0 = base + 4 * lane;
+            uint32_t c[9];
+            {
+                const uint4 u0 = *reinterpret_cast<const uint4 *>(s_mh + p0), u1 = *reinterpret_cast<const uint4 *>(s_mh + p0 + 4);
+                c[0] = u0.x; c[1] = u0.y | 1u; c[2] = u0.z | 2u; c[3] = u0.w | 3u;
+                c[4] = u1.x | 4u; c[5] = u1.y | 5u; c[6] = u1.z | 6u; c[7] = u1.w | 7u;
+                c[8] = s_mh[p0 + 8] | 8u;
+            }
+            uint32_t w[4];
+            if (WT == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = min(c[k], c[k + 1]);
+            } else {
+                uint32_t mid = 0xFFFFFFFFu;                                                          // positions 3 .. W - 1: in all four windows
+#pragma unroll
+                for (int j = 3; j < WT; ++j) mid = min(mid, c[j]);
+                const uint32_t s2 = c[2], s1 = min(c[1], s2), s0 = min(c[0], s1);
+                const uint32_t q1 = c[WT], q2 = min(q1, c[WT + 1]), q3 = min(q2, c[WT + 2]);
+                w[0] = min(s0, mid);
+                w[1] = min(min(s1, mid), q1);
+                w[2] = min(min(s2, mid), q2);
+                w[3] = min(mid, q3);
+            }
+            uint32_t at[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) at[k] = w[k] & 15u;                                          // where in the block the window's minimizer starts
+            // validity: no separator in the K bytes of the window
+            const uint32_t *iw = s_inv + (p0 >> 5);
+            const uint32_t ihi = (uint32_t)(((((unsigned long long)iw[0]) << 32) | iw[1]) >> (32 - (p0 & 31)));   // bases p0 .. p0 + 31
+            uint32_t vm = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool v = p0 + k < nwin && ((ihi << k) >> (32 - K)) == 0;
+                if (a.n_slices > 1 && kc_slice_of(w[k] & ~15u, a.n_slices) != a.slice) v = false;
+                vm |= (uint32_t)v << k;
+            }
+            counted += (unsigned long long)__popc(vm);
+            // continuation bits: window k goes on with the run of window k - 1
+            const uint32_t mine = at[3] | ((vm >> 3) << 4);
+            const uint32_t prev = (uint32_t)__shfl_up((int)mine, 1, 64);
+            uint32_t cn = 0;
+            if (lane > 0 && (vm & 1u) && (prev >> 4) && (prev & 15u) == at[0] + 4u) cn = 1u;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (((vm >> k) & 1u) && ((vm >> (k - 1)) & 1u) && at[k] == at[k - 1]) cn |= 1u << k;
+            const uint32_t n1 = (uint32_t)__shfl_down((int)cn, 1, 64), n2 = (uint32_t)__shfl_down((int)cn, 2, 64);
+            const uint32_t C = cn | (lane < 63 ? n1 << 4 : 0u) | (lane < 62 ? n2 << 8 : 0u);
+            const uint32_t sn = vm & ~cn;                                                            // windows that start a run
+            const unsigned long long b0 = __ballot(sn & 1u), b1 = __ballot(sn & 2u), b2 = __ballot(sn & 4u), b3 = __ballot(sn & 8u);
+            const uint32_t total = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (total) {                                                                             // (wave-uniform)
+                uint32_t idx = 0;
+                if (lane == 0) idx = atomicAdd(&s_nrec, total);
+                idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+                idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, idx));
+                idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, idx));
+                idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, idx));
+                idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, idx));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((sn >> k) & 1u) {
+                        const uint32_t runm1 = (uint32_t)__builtin_ctz(~(C >> (k + 1)));             // windows that go on behind it
+                        s_desc[idx] = (p0 + k) | (runm1 << 14) | ((at[k] - (uint32_t)k) << 18);
+                        ++idx;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- C ---------------------------------------------------------------------------------------------------------------
+        const uint32_t n = s_nrec;
+        if (tid == 0) {
+            s_fill_lo = s_fill_hi = 0;
+            if (s_chunk_at + n > s_chunk_end) {                                        // (n <= TB <= a.rec_chunk)
+                s_fill_lo = s_chunk_at;
+                s_fill_hi = s_chunk_end;
+                s_chunk_at = atomicAdd(a.rec_cursor, (unsigned long long)a.rec_chunk);
+                s_chunk_end = s_chunk_at + a.rec_chunk;
+            }
+            s_rec_base = s_chunk_at;
+            s_chunk_at += n;
+        }
+        __syncthreads();
+        for (unsigned long long o = s_fill_lo + tid; o < s_fill_hi && o < a.rec_cap; o += kKcThreads) a.rec_out[o] = ~0ull;
+        for (uint32_t i = tid; i < n; i += kKcThreads) {
+            const uint32_t d = s_desc[i], p = d & 0x3FFFu, runm1 = (d >> 14) & 15u, off = d >> 18;
+            const unsigned long long rec = (ob ? (unsigned long long)off << (64 - ob) : 0ull) | (window_bits(s_pack, p, 64 - 2 * (K + runm1)) << 6) |
+                                           ((unsigned long long)runm1 << 1) | a.parent;
+            const unsigned long long o = s_rec_base + i;
+            if (o < a.rec_cap) a.rec_out[o] = rec;
+            else kc_count_record(a.table, a.nbuckets, (int)K, a.m, a.fine_shift, rec, a.err);          // (no room: counted on the spot)
+        }
+    }
+    __syncthreads();
+    for (unsigned long long o = s_chunk_at + tid; o < s_chunk_end && o < a.rec_cap; o += kKcThreads) a.rec_out[o] = ~0ull;
+    for (int off = 32; off > 0; off >>= 1) counted += __shfl_down(counted, off, 64);
+    if (lane == 0 && counted) atomicAdd(a.total + a.parent, counted);
+}
+// does k_kc_emit4 take this launch?  (HAST_KC_EMIT=lanes keeps k_kc_count<W, true>: A/B runs, and the tests of that kernel)
+static bool kc_emit4_takes(const KcCountArgs &a) {
+    static const bool off = [] { const char *e = getenv("HAST_KC_EMIT"); return e && !strcmp(e, "lanes"); }();
+    const int w = a.k - a.m + 1;
+    return !off && a.rec_out && a.m == 16 && w >= 2 && w <= 6 && a.rec_run_max >= (uint32_t)w && a.k + w + 2 <= 32 && a.tile_bases % 1024 == 0 &&
+           a.tile_bases <= 16384 && a.rec_chunk >= a.tile_bases;
+}
+template <int WT>
+static hipError_t launch_kc_emit4(const KcCountArgs &a, unsigned grid, hipStream_t s) {
+    const uint32_t nw = (a.tile_bases + (uint32_t)a.k - 1 + 31) / 32 + 2;
+    const size_t smem = kc_emit4_mh_at(nw) + ((size_t)a.tile_bases + kKcE4Pad) * 4 + (size_t)a.tile_bases * 4;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_emit4<WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_kc_emit4<WT>), dim3(grid), dim3(kKcThreads), smem, s, a);
+    return hipGetLastError();
+}
+
 template <int WT, bool EMIT>
 static hipError_t launch_kc_count_e(const KcCountArgs &a, unsigned grid, size_t smem0, hipStream_t s) {
     const size_t smem = EMIT ? ((smem0 + 15) & ~(size_t)15) + (size_t)(a.tile_bases / 2) * 8 + 16 : smem0;
@@ -332,6 +540,15 @@ size_t kc_count_smem(uint32_t tile_bases, int k, int m) {
     return 16 + (size_t)nw * 8 + (size_t)nw * 4 + (size_t)(tile_bases + w + 64) * 4 + 16;
 }
 hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s) {
+    if (kc_emit4_takes(a)) {
+        switch (a.k - a.m + 1) {
+        case 2: return launch_kc_emit4<2>(a, grid, s);
+        case 3: return launch_kc_emit4<3>(a, grid, s);
+        case 4: return launch_kc_emit4<4>(a, grid, s);
+        case 5: return launch_kc_emit4<5>(a, grid, s);
+        default: return launch_kc_emit4<6>(a, grid, s);
+        }
+    }
     const size_t smem = kc_count_smem(a.tile_bases, a.k, a.m);
     switch (a.k - a.m + 1) {
     case 1: return launch_kc_count_t<1>(a, grid, smem, s);

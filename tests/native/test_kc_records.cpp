@@ -67,12 +67,12 @@ int main() {
                 fwd[p] = f & kmer_mask(k);
                 uint32_t best = 0xFFFFFFFFu, bo = 0;
                 for (uint32_t j = 0; j < W; ++j) {
-                    const uint32_t h = mmer_hash32(kmer_canon((fwd[p] >> (2 * ((uint32_t)(k - m) - j))) & kmer_mask(m), m));
+                    const uint32_t h = kc_mmer_hash(kmer_canon((fwd[p] >> (2 * ((uint32_t)(k - m) - j))) & kmer_mask(m), m));
                     if (h < best) { best = h; bo = j; }
                 }
                 mn[p] = best;
                 off[p] = bo;
-                if (best != minimizer_hash(fwd[p], k, m)) { printf("k=%d m=%d: window minimum differs from minimizer_hash\n", k, m); return 1; }
+                if (best != kc_minimizer_hash(fwd[p], k, m)) { printf("k=%d m=%d: window minimum differs from kc_minimizer_hash\n", k, m); return 1; }
                 truth.insert({kmer_canon(fwd[p], k), p});
                 ++n_windows;
             }
