@@ -243,6 +243,10 @@ hast_status hast_kc_create_ex(int device, int k, size_t table_bytes, uint64_t ex
         if (table_bytes == 0 || table_bytes > most) table_bytes = most;      // never more than 85 % of what is free
         size_t nb = table_bytes / (kKcBucketWords * sizeof(unsigned long long));
         nb = std::min<size_t>(std::max<size_t>(nb, 64), 0xFFFFFFF0u);
+        // whole slices of the partitioned path (512 or 1024 buckets, kc_common.h kc_fine_of_hash): a minimizer names every slice with the
+        // same probability, so a last slice of a few buckets would take a whole slice's keys
+        if (nb > 1024) nb &= ~(size_t)1023;
+        else if (nb > 512) nb = 512;
         c->nbuckets = (uint32_t)nb;
         bail(hipMalloc(&c->d_table, nb * kKcBucketWords * sizeof(unsigned long long)), "hipMalloc(count table)");
     }

@@ -62,6 +62,22 @@ HAST_HD uint32_t kc_mmer_hash(uint64_t canon_mmer) {                            
     h ^= h >> 15;
     return h & ~15u;
 }
+// bits 24 .. 47 of the 48-bit product of two 24-bit numbers, i.e. floor(a x b / 2^24) for a, b < 2^24: two full-rate instructions
+// + a funnel shift (a 32 x 32 -> 64-bit product is two quarter-rate ones)
+HAST_HD uint32_t kc_mul24_shr24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t lo, hi;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    return __builtin_amdgcn_alignbit(hi, lo, 24);
+#else
+    return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) >> 24);
+#endif
+}
+// the SLICE (fine bin) of the table a minimizer value names, of n_fine < 2^24 slices.  The minimum of W hashes leans towards zero: the
+// value's 24 low bits (they do not) are spread by an odd multiplier first, then range-reduced.  Every slice must hold the same
+// number of buckets for this to load them evenly: hast_kc_create rounds the table down to whole slices.
+HAST_HD uint32_t kc_fine_of_hash(uint32_t minh, uint32_t n_fine) { return kc_mul24_shr24(kc_mul24(minh >> 4, 0x9E3779u) & 0xFFFFFFu, n_fine); }
 // the minimizer value of a k-mer (any strand): the smallest kc_mmer_hash over its canonical m-mers
 HAST_HD uint32_t kc_minimizer_hash(uint64_t kmer, int k, int m) {
     uint32_t best = 0xFFFFFFFFu;

@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t *kc_slot(unsigned long long *table, uint32_t
 __device__ __forceinline__ void kc_count_record(unsigned long long *table, uint32_t nb, int k, int m, uint32_t fine_shift, unsigned long long rec, uint32_t *err) {
     const uint32_t parent = (uint32_t)(rec & 1), run = (uint32_t)((rec >> 1) & 31) + 1;
     const unsigned long long bases = rec >> 6, kmask = kmer_mask(k);           // (the offset bits lie above every window's bits)
-    const uint32_t lo = (bucket_of_minhash(kc_rec_minhash(rec, k, m, kc_rec_off_bits(k, m)), nb) >> fine_shift) << fine_shift;
+    const uint32_t lo = kc_fine_of_hash(kc_rec_minhash(rec, k, m, kc_rec_off_bits(k, m)), (nb + (1u << fine_shift) - 1) >> fine_shift) << fine_shift;
     const uint32_t n_here = nb - lo < (1u << fine_shift) ? nb - lo : (1u << fine_shift);
     for (uint32_t j = 0; j < run; ++j) {
         const unsigned long long key = kmer_canon((bases >> (2 * (run - 1 - j))) & kmask, k);
@@ -587,7 +587,14 @@ struct KcPartGeom {
 constexpr uint32_t kKcPartRecs = 8192, kKcPartThreads = 1024, kKcMaxFan = 1024;
 constexpr uint32_t kKcFillPad = kKcL1FillWords;                                // words between two level-1 fill counters
 __device__ __forceinline__ uint32_t kc_rec_fine(const KcPartGeom &g, unsigned long long rec) {
-    return bucket_of_minhash(kc_rec_minhash(rec, g.k, g.m, g.ob), g.nbuckets) >> g.fine_shift;
+    if (g.m <= 16) {                                                             // (wave-uniform) the m-mer is one dword: a third of the instructions
+        const uint32_t runm1 = (uint32_t)(rec >> 1) & 31u, off = g.ob ? (uint32_t)(rec >> (64 - g.ob)) : 0u;
+        const uint32_t f = (uint32_t)(rec >> (6 + 2 * ((uint32_t)(g.k - g.m) + runm1 - off))) & (uint32_t)kmer_mask(g.m);
+        uint32_t r = __brev(f ^ 0xAAAAAAAAu);
+        r = (((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u)) >> (32 - 2 * g.m);
+        return kc_fine_of_hash(kc_mmer_hash32(f < r ? f : r), g.n_fine);
+    }
+    return kc_fine_of_hash(kc_rec_minhash(rec, g.k, g.m, g.ob), g.n_fine);
 }
 // records that found no room in a bin: to the spill list, or -- that one full too -- through the atomic path at once (no slice
 // of the table is held in LDS while a partition kernel runs)
@@ -597,19 +604,33 @@ __device__ __forceinline__ void kc_spill(const KcPartGeom &g, unsigned long long
     if (at < spill_cap) spill[at] = rec;
     else kc_count_record(g.table, g.nbuckets, g.k, g.m, g.fine_shift, rec, g.err);
 }
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global access in flight (its fence is for
+// all memory), which is exactly what k_kc_part wants to keep in flight across its barriers
+__device__ __forceinline__ void kc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // LEVEL 1: in = the flat record buffer [0, n_flat); bin = fine / f2, region = bin.  LEVEL 2: blockIdx.y = a level-1 bin, in = its
 // region (in_cap records apart, in_fill / in_valid say how many are real); bin = fine - l1 * f2, region = fine.
+// A workgroup takes 8192 records: (1) their bins, counted in LDS (a record's rank in its bin is what the LDS add returns); (2) a scan
+// of the counts and ONE reservation per (workgroup, bin) in the bin's region -- issued here, looked at after (3), so that the
+// round trip to the memory side runs beside the scatter; (3) the records to their bin's place in LDS, with the low byte of the bin
+// beside them; (4) a lane per RECORD in bin order: consecutive lanes write consecutive records of a region.
+// Round 4 - 5a: the bin from the canonical m-mer by 64-bit arithmetic and two quarter-rate multiplies (60 instructions), the records out
+// by 16 lanes per bin (8 records a bin: half the lanes idle, 25 instructions per bin and lane): 115 lane-instructions per record, and
+// the reservation's round trip in front of a barrier -- 22 + 16 ms a step at 41 % VALU issue.
 template <int LEVEL>
 __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) k_kc_part(KcPartGeom g, const unsigned long long *in, unsigned long long n_flat, const uint32_t *in_fill,
                                                             const uint32_t *in_valid, uint32_t in_cap, unsigned long long *out, uint32_t out_cap,
                                                             uint32_t *out_fill, uint32_t *out_valid, unsigned long long *spill, unsigned long long spill_cap,
                                                             unsigned long long *spill_n) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);                       // [kKcMaxFan] records of this tile per bin
-    uint32_t *s_off = s_cnt + kKcMaxFan;                                        // where the bin starts in s_rec
-    uint32_t *s_dst = s_off + kKcMaxFan;                                        // where the bin's run goes (bit 31: spill)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);                       // [kKcMaxFan] records of this tile per bin        } later: the bins' low
+    uint32_t *s_off = s_cnt + kKcMaxFan;                                        // where the bin starts in s_rec                   } bytes, [kKcPartRecs]
+    uint8_t *s_bin8 = reinterpret_cast<uint8_t *>(smem);
+    uint32_t *s_dst = s_off + kKcMaxFan;                                        // (place of the bin's run in its region) - (its start in s_rec); all ones: no room
     unsigned long long *s_rec = reinterpret_cast<unsigned long long *>(s_dst + kKcMaxFan);   // [kKcPartRecs], grouped by bin
+    static_assert(kKcPartRecs <= 2 * kKcMaxFan * 4, "the bins' low bytes take the place of s_cnt and s_off");
     __shared__ uint32_t s_scan[kKcPartThreads / 64];
+    __shared__ uint32_t s_first[3];                                             // first slot of bins 256, 512, 768
+    __shared__ uint32_t s_lost[kKcMaxFan / 32 + 1];                             // [0]: some bin of this tile found no room; [1 + b / 32] bit b % 32: bin b did not
     const uint32_t tid = threadIdx.x;
     const uint32_t l1 = LEVEL == 2 ? blockIdx.y : 0;
     const uint32_t n_bins = LEVEL == 1 ? g.n_l1 : g.f2;
@@ -623,17 +644,21 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
     const unsigned long long r0 = (unsigned long long)blockIdx.x * kKcPartRecs;
     if (r0 >= n_in) return;
     const uint32_t nr = (uint32_t)(n_in - r0 < kKcPartRecs ? n_in - r0 : kKcPartRecs);
-    for (uint32_t b = tid; b < n_bins; b += kKcPartThreads) s_cnt[b] = 0;
-    __syncthreads();
     constexpr int PER = kKcPartRecs / kKcPartThreads;                           // 8 records per thread
     unsigned long long rec[PER];
-    uint32_t bin_of[PER], rank[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const uint32_t i = (uint32_t)q * kKcPartThreads + tid;                  // coalesced
+        rec[q] = i < nr ? src[r0 + i] : ~0ull;                                  // (all ones: a chunk's unused end, k_kc_count<EMIT>)
+    }
+    for (uint32_t b = tid; b < kKcMaxFan; b += kKcPartThreads) s_cnt[b] = 0;
+    if (tid <= kKcMaxFan / 32) s_lost[tid] = 0;
+    __syncthreads();
+    uint32_t bin_of[PER], rank[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
         bin_of[q] = 0xFFFFFFFFu;
-        if (i < nr) rec[q] = src[r0 + i];
-        if (i < nr && rec[q] != ~0ull) {                                        // (all ones: a chunk's unused end, k_kc_count<EMIT>)
+        if (rec[q] != ~0ull) {
             const uint32_t fine = kc_rec_fine(g, rec[q]);
             uint32_t b = LEVEL == 1 ? fine >> g.f2_shift : fine - (l1 << g.f2_shift);
             if (b >= n_bins) b = n_bins - 1;                                    // (cannot happen: a record lies where its bucket says)
@@ -642,56 +667,80 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
         }
     }
     __syncthreads();
-    {   // exclusive scan of s_cnt (one bin per thread), and one reservation per (workgroup, bin)
-        const uint32_t c = tid < n_bins ? s_cnt[tid] : 0;
+    // exclusive scan of s_cnt (one bin per thread), and one reservation per (workgroup, bin)
+    const uint32_t c = s_cnt[tid];                                              // (zero behind n_bins)
+    uint32_t base;
+    {
         uint32_t incl = c;
-        const uint32_t lane = tid & 63;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= (uint32_t)off) incl += t;
-        }
-        if (lane == 63) s_scan[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t base = incl - c;
-        for (uint32_t w = 0; w < (tid >> 6); ++w) base += s_scan[w];
-        if (tid < n_bins) {
-            s_off[tid] = base;
-            uint32_t dst = 0;
-            if (c) {
-                const uint32_t region = LEVEL == 1 ? tid : l1 * g.f2 + tid;
-                // (level 1: every workgroup adds to every one of <= 1024 counters -- a line apart, or they share 32 lines)
-                // (a region that has failed takes no more adds: its fill word would otherwise keep growing with every workgroup that comes
-                // by and, on a flush of billions of records into one bin -- poly-A -- wrap past 2^32 and hand out room again)
-                const uint32_t fi = LEVEL == 1 ? region * kKcFillPad : region;
-                const uint32_t at = __hip_atomic_load(&out_valid[fi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu ? 0xFFFFFFFFu : atomicAdd(&out_fill[fi], c);
-                if (at != 0xFFFFFFFFu && (uint64_t)at + c <= out_cap) dst = at;
-                else if (at == 0xFFFFFFFFu) dst = 0x80000000u;
-                else {
-                    atomicMin(&out_valid[LEVEL == 1 ? region * kKcFillPad : region], at);                          // records [0, first failed reservation) of a region are real
-                    dst = 0x80000000u;
-                }
-            }
-            s_dst[tid] = dst;
-        }
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);
+        if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+        base = incl - c;
     }
-    __syncthreads();
+    const uint32_t region = LEVEL == 1 ? tid : l1 * g.f2 + tid;
+    const uint32_t fi = LEVEL == 1 ? region * kKcFillPad : region;
+    uint32_t at = 0;
+    // (level 1: every workgroup adds to every one of <= 1024 counters -- a line apart, or they share 32 lines)
+    // (a region that has failed takes no more adds: its fill word would otherwise keep growing with every workgroup that comes
+    // by and, on a flush of billions of records into one bin -- poly-A -- wrap past 2^32 and hand out room again)
+    if (c) at = __hip_atomic_load(&out_valid[fi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFFFFFu ? 0xFFFFFFFFu : atomicAdd(&out_fill[fi], c);
+    kc_lds_barrier();
+    {
+        const uint32_t wv = tid >> 6;
+        uint32_t add = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kKcPartThreads / 64; ++w) add += w < wv ? s_scan[w] : 0u;       // (broadcast reads)
+        base += add;
+    }
+    uint32_t off_of[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) off_of[q] = 0;
+    s_off[tid] = base;
+    if ((tid & 255) == 0 && tid) s_first[(tid >> 8) - 1] = base;
+    kc_lds_barrier();
 #pragma unroll
     for (int q = 0; q < PER; ++q)
-        if (bin_of[q] != 0xFFFFFFFFu) s_rec[s_off[bin_of[q]] + rank[q]] = rec[q];
-    __syncthreads();
-    // runs out: 16 lanes per bin
-    const uint32_t grp = tid >> 4, gl = tid & 15;
-    for (uint32_t b = grp; b < n_bins; b += kKcPartThreads / 16) {
-        const uint32_t cnt = s_cnt[b];
-        if (!cnt) continue;
-        const uint32_t dst = s_dst[b], off = s_off[b];
-        if (!(dst & 0x80000000u)) {
-            const uint32_t region = LEVEL == 1 ? b : l1 * g.f2 + b;
-            unsigned long long *o = out + (size_t)region * out_cap + dst;
-            for (uint32_t j = gl; j < cnt; j += 16) o[j] = s_rec[off + j];
-        } else {
-            for (uint32_t j = gl; j < cnt; j += 16) kc_spill(g, s_rec[off + j], spill, spill_cap, spill_n);
+        if (bin_of[q] != 0xFFFFFFFFu) off_of[q] = s_off[bin_of[q]] + rank[q];
+    kc_lds_barrier();                                                           // s_cnt and s_off are free: the bins' low bytes go there
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (bin_of[q] != 0xFFFFFFFFu) {
+            s_rec[off_of[q]] = rec[q];
+            s_bin8[off_of[q]] = (uint8_t)bin_of[q];
         }
+    {   // the reservation has had the scatter's time to come back
+        uint32_t dst = 0;
+        if (c) {
+            if (at != 0xFFFFFFFFu && (uint64_t)at + c <= out_cap) dst = at - base;
+            else {
+                if (at != 0xFFFFFFFFu) atomicMin(&out_valid[fi], at);           // records [0, first failed reservation) of a region are real
+                s_lost[0] = 1;
+                atomicOr(&s_lost[1 + (tid >> 5)], 1u << (tid & 31));
+            }
+        }
+        s_dst[tid] = dst;
+    }
+    __syncthreads();
+    // a lane per record, in bin order
+    const uint32_t f1 = s_first[0], f2 = s_first[1], f3 = s_first[2];
+    uint32_t n_valid = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kKcPartThreads / 64; ++w) n_valid += s_scan[w];
+    const bool lost = s_lost[0] != 0;
+    for (uint32_t i = tid; i < n_valid; i += kKcPartThreads) {
+        const unsigned long long r = s_rec[i];
+        const uint32_t b = (uint32_t)s_bin8[i] + ((i >= f1 ? 256u : 0u) + (i >= f2 ? 256u : 0u) + (i >= f3 ? 256u : 0u));
+        const uint32_t d = s_dst[b];
+        if (lost && ((s_lost[1 + (b >> 5)] >> (b & 31)) & 1u)) {               // (wave-uniform test first: regions rarely fill up)
+            kc_spill(g, r, spill, spill_cap, spill_n);
+            continue;
+        }
+        const uint32_t reg = LEVEL == 1 ? b : l1 * g.f2 + b;
+        out[(size_t)reg * out_cap + (uint32_t)(d + i)] = r;
     }
 }
 
