@@ -55,6 +55,7 @@ struct hast_kc {
     // flushes -- at hast_kc_sync, before the table is read, and when the record buffer is nearly full
     bool part_on = false;
     uint32_t fine_shift = 9, n_fine = 0, n_l1 = 0, f2 = 0;
+    uint32_t l1_split = 8;                     // a level-1 bin's records lie in l1_split regions (KcFlushArgs)
     int small_flush = 0;                       // HAST_KC_FLUSH=sweep|atomic pins how a flush is applied (1 | 2); default: by size
     unsigned long long *d_rec = nullptr, *d_l1 = nullptr, *d_spill = nullptr;
     uint32_t *d_fills = nullptr;               // [n_l1 fill | n_l1 valid] (kKcL1FillWords apart) [n_fine fill | n_fine valid]
@@ -120,9 +121,10 @@ static void part_setup(hast_kc *c) {
     c->f2 = 1;                                                         // fine bins per level-1 bin: a power of two (a shift in the kernels)
     while ((n_fine + c->f2 - 1) / c->f2 > 1024) c->f2 <<= 1;
     c->n_l1 = (uint32_t)((n_fine + c->f2 - 1) / c->f2);
+    if (const char *sp = getenv("HAST_KC_L1_SPLIT")) c->l1_split = (uint32_t)std::min(32l, std::max(1l, atol(sp)));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-    const uint64_t fixed = 8ull * (64ull * c->n_fine + 4096ull * c->n_l1 + (1u << 20)) + 8ull * ((uint64_t)c->n_l1 * kKcL1FillWords + c->n_fine) + (64u << 20);
+    const uint64_t fixed = 8ull * (64ull * c->n_fine + 4096ull * c->n_l1 * c->l1_split + (1u << 20)) + 8ull * ((uint64_t)c->n_l1 * c->l1_split * kKcL1FillWords + c->n_fine) + (64u << 20);
     const uint64_t budget = (uint64_t)((double)free_b * 0.8);
     if (budget <= fixed + (16u << 20)) return;
     uint64_t R = (uint64_t)((double)(budget - fixed) / 22.6);
@@ -137,12 +139,12 @@ static void part_setup(hast_kc *c) {
     if (R < (forced ? 4096u : (16u << 20))) return;
     c->rec_cap = R;
     c->a_cap = R + R / 2 + 64ull * c->n_fine + 1024;
-    c->b_cap = R + R / 4 + 4096ull * c->n_l1 + 1024;
+    c->b_cap = R + R / 4 + 4096ull * c->n_l1 * c->l1_split + 1024;
     c->spill_cap = R / 16 + (1u << 20);
     hipError_t h = hipMalloc(reinterpret_cast<void **>(&c->d_rec), c->a_cap * 8);
     if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_l1), c->b_cap * 8);
     if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_spill), c->spill_cap * 8);
-    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_fills), 8ull * ((uint64_t)c->n_l1 * kKcL1FillWords + c->n_fine));
+    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_fills), 8ull * ((uint64_t)c->n_l1 * c->l1_split * kKcL1FillWords + c->n_fine));
     if (h != hipSuccess) {                                             // no room: count with atomics, as before
         (void)hipGetLastError();
         for (void *p : {(void *)c->d_rec, (void *)c->d_l1, (void *)c->d_spill, (void *)c->d_fills})
@@ -175,11 +177,13 @@ static hast_status part_flush(hast_kc *c) {
     a.rec_cursor = c->d_small + kRecCursor;
     a.small_flush = c->small_flush;
     a.l1_recs = c->d_l1;
-    a.l1_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->b_cap / c->n_l1, n / c->n_l1 + n / c->n_l1 / 4 + 4096));
+    a.l1_split = c->l1_split;
+    const uint64_t n_reg = (uint64_t)c->n_l1 * c->l1_split;
+    a.l1_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->b_cap / n_reg, n / n_reg + n / n_reg / 4 + 4096));
     a.fine_cap = (uint32_t)std::min<uint64_t>(0x7FFFFFFFu, std::min<uint64_t>(c->a_cap / c->n_fine, n / c->n_fine + n / c->n_fine / 2 + 64));
     a.l1_fill = c->d_fills;
-    a.l1_valid = c->d_fills + (size_t)c->n_l1 * kKcL1FillWords;
-    a.fine_fill = c->d_fills + 2 * (size_t)c->n_l1 * kKcL1FillWords;
+    a.l1_valid = c->d_fills + (size_t)n_reg * kKcL1FillWords;
+    a.fine_fill = c->d_fills + 2 * (size_t)n_reg * kKcL1FillWords;
     a.fine_valid = a.fine_fill + c->n_fine;
     a.spill = c->d_spill;
     a.spill_cap = c->spill_cap;

@@ -40,7 +40,8 @@ struct KcFlushArgs {
     unsigned long long n_records;
     const unsigned long long *rec_cursor;   // device word behind n_records (>= n_records)
     int small_flush;                 // 0: few records for the table's size go through the atomic path where they lie; 1: never; 2: always
-    unsigned long long *l1_recs;     // n_l1 regions of l1_cap records
+    unsigned long long *l1_recs;     // n_l1 x l1_split regions of l1_cap records: region s * n_l1 + b = level-1 bin b as the workgroups with blockIdx % l1_split == s wrote it
+    uint32_t l1_split;
     uint32_t l1_cap, fine_cap;
     uint32_t *l1_fill, *l1_valid, *fine_fill, *fine_valid;
     unsigned long long *spill;       // spill_cap records

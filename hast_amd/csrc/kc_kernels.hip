@@ -583,6 +583,7 @@ struct KcPartGeom {
     uint32_t *err;
     uint32_t ob, rmax;           // kc_rec_off_bits, kc_run_max
     uint32_t f2_shift;           // f2 == 1 << f2_shift
+    uint32_t l1_split;           // regions per level-1 bin (KcFlushArgs)
 };
 constexpr uint32_t kKcPartRecs = 8192, kKcPartThreads = 1024, kKcMaxFan = 1024;
 constexpr uint32_t kKcFillPad = kKcL1FillWords;                                // words between two level-1 fill counters
@@ -632,14 +633,16 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
     __shared__ uint32_t s_first[3];                                             // first slot of bins 256, 512, 768
     __shared__ uint32_t s_lost[kKcMaxFan / 32 + 1];                             // [0]: some bin of this tile found no room; [1 + b / 32] bit b % 32: bin b did not
     const uint32_t tid = threadIdx.x;
-    const uint32_t l1 = LEVEL == 2 ? blockIdx.y : 0;
+    // LEVEL 1 writes a bin's records to ONE OF l1_split regions (by workgroup): every workgroup of the pass adds to the fill words of all
+    // bins -- 385 k workgroups x 960 adds on 30 lines of memory with one region per bin; level 2 takes the regions one by one
+    const uint32_t l1 = LEVEL == 2 ? blockIdx.y % g.n_l1 : 0;
     const uint32_t n_bins = LEVEL == 1 ? g.n_l1 : g.f2;
     unsigned long long n_in = n_flat;
     const unsigned long long *src = in;
     if (LEVEL == 2) {
-        const uint32_t f = in_fill[l1 * kKcFillPad], v = in_valid[l1 * kKcFillPad];
+        const uint32_t f = in_fill[blockIdx.y * kKcFillPad], v = in_valid[blockIdx.y * kKcFillPad];
         n_in = f < v ? (f < in_cap ? f : in_cap) : v;
-        src = in + (size_t)l1 * in_cap;
+        src = in + (size_t)blockIdx.y * in_cap;
     }
     const unsigned long long r0 = (unsigned long long)blockIdx.x * kKcPartRecs;
     if (r0 >= n_in) return;
@@ -681,7 +684,8 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
         if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
         base = incl - c;
     }
-    const uint32_t region = LEVEL == 1 ? tid : l1 * g.f2 + tid;
+    const uint32_t sub = LEVEL == 1 ? (blockIdx.x % g.l1_split) * g.n_l1 : 0;
+    const uint32_t region = LEVEL == 1 ? sub + tid : l1 * g.f2 + tid;
     const uint32_t fi = LEVEL == 1 ? region * kKcFillPad : region;
     uint32_t at = 0;
     // (level 1: every workgroup adds to every one of <= 1024 counters -- a line apart, or they share 32 lines)
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(kKcPartThreads) __attribute__((amdgpu_waves_pe
             kc_spill(g, r, spill, spill_cap, spill_n);
             continue;
         }
-        const uint32_t reg = LEVEL == 1 ? b : l1 * g.f2 + b;
+        const uint32_t reg = LEVEL == 1 ? sub + b : l1 * g.f2 + b;
         out[(size_t)reg * out_cap + (uint32_t)(d + i)] = r;
     }
 }
@@ -928,7 +932,7 @@ __global__ void __launch_bounds__(256) k_kc_spill(KcPartGeom g, const unsigned l
 }
 
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
-    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m), (uint32_t)__builtin_ctz(a.f2)};
+    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m), (uint32_t)__builtin_ctz(a.f2), a.l1_split};
     const size_t lds_part = (size_t)3 * kKcMaxFan * 4 + (size_t)kKcPartRecs * 8;
     const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcLdsStride * 8 + (size_t)(kKcApplyThreads / 64) * kc_apply_map_bytes(kc_run_max(a.k, a.m));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
@@ -936,8 +940,8 @@ hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply);
     if (e != hipSuccess) return e;
     // fills to zero, "valid" marks to all ones: [l1 fill | l1 valid | fine fill | fine valid]
-    e = hipMemsetAsync(a.l1_fill, 0, (size_t)a.n_l1 * kKcFillPad * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(a.l1_valid, 0xFF, (size_t)a.n_l1 * kKcFillPad * 4, s);
+    e = hipMemsetAsync(a.l1_fill, 0, (size_t)a.n_l1 * a.l1_split * kKcFillPad * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(a.l1_valid, 0xFF, (size_t)a.n_l1 * a.l1_split * kKcFillPad * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_fill, 0, (size_t)a.n_fine * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_valid, 0xFF, (size_t)a.n_fine * 4, s);
     if (e != hipSuccess) return e;
@@ -949,7 +953,7 @@ hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(k_kc_part<1>, dim3((unsigned)((a.n_records + kKcPartRecs - 1) / kKcPartRecs)), dim3(kKcPartThreads), lds_part, s, g, a.records, a.n_records,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, a.l1_recs, a.l1_cap, a.l1_fill, a.l1_valid, a.spill, a.spill_cap, a.spill_n);
         // level 2 overwrites the flat buffer (its records are all in the level-1 regions by then)
-        hipLaunchKernelGGL(k_kc_part<2>, dim3((a.l1_cap + kKcPartRecs - 1) / kKcPartRecs, a.n_l1), dim3(kKcPartThreads), lds_part, s, g, a.l1_recs, 0ull, a.l1_fill,
+        hipLaunchKernelGGL(k_kc_part<2>, dim3((a.l1_cap + kKcPartRecs - 1) / kKcPartRecs, a.n_l1 * a.l1_split), dim3(kKcPartThreads), lds_part, s, g, a.l1_recs, 0ull, a.l1_fill,
                            a.l1_valid, a.l1_cap, a.records, a.fine_cap, a.fine_fill, a.fine_valid, a.spill, a.spill_cap, a.spill_n);
         hipLaunchKernelGGL(k_kc_apply, dim3(a.n_fine), dim3(kKcApplyThreads), lds_apply, s, g, a.records, a.fine_cap, a.fine_fill, a.fine_valid, a.spill, a.spill_cap, a.spill_n);
     }
