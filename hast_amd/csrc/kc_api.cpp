@@ -55,6 +55,7 @@ struct hast_kc {
     // flushes -- at hast_kc_sync, before the table is read, and when the record buffer is nearly full
     bool part_on = false;
     uint32_t fine_shift = 9, n_fine = 0, n_l1 = 0, f2 = 0;
+    bool fresh = false;                        // the table holds nothing and has NOT been cleared: the first flush writes every slice (KcFlushArgs.fresh)
     uint32_t l1_split = 8;                     // a level-1 bin's records lie in l1_split regions (KcFlushArgs)
     int small_flush = 0;                       // HAST_KC_FLUSH=sweep|atomic pins how a flush is applied (1 | 2); default: by size
     unsigned long long *d_rec = nullptr, *d_l1 = nullptr, *d_spill = nullptr;
@@ -156,9 +157,26 @@ static void part_setup(hast_kc *c) {
     c->part_on = true;
 }
 
+// a table that is empty by declaration only (c->fresh) is cleared for real
+static hast_status table_real(hast_kc *c) {
+    if (!c->fresh) return HAST_OK;
+    KC_TRY(launch_kc_clear(c->d_table, c->nbuckets, c->stream));
+    c->fresh = false;
+    return HAST_OK;
+}
+// an empty table: the partitioned path's first flush writes every slice anyway, so it is only DECLARED empty (the clear is 9 ms of a
+// 110-ms step on the bench's 64-GB table; HAST_KC_FRESH=0: always cleared)
+static hast_status table_empty(hast_kc *c) {
+    static const bool lazy = [] { const char *e = getenv("HAST_KC_FRESH"); return !(e && !strcmp(e, "0")); }();
+    c->fresh = c->part_on && lazy;
+    if (c->fresh) return HAST_OK;
+    KC_TRY(launch_kc_clear(c->d_table, c->nbuckets, c->stream));
+    return HAST_OK;
+}
+
 // apply what has been written out since the last flush (no-op when there is nothing)
 static hast_status part_flush(hast_kc *c) {
-    if (!c->part_on || c->est_records == 0) return HAST_OK;
+    if (!c->part_on || c->est_records == 0) return table_real(c);
     unsigned long long cur = 0;
     KC_TRY(hipMemcpyAsync(&cur, c->d_small + kRecCursor, sizeof(cur), hipMemcpyDeviceToHost, c->stream));
     KC_TRY(hipStreamSynchronize(c->stream));
@@ -189,7 +207,14 @@ static hast_status part_flush(hast_kc *c) {
     a.spill_cap = c->spill_cap;
     a.spill_n = c->d_small + kSpillN;
     a.err = c->d_err;
+    a.fresh = 0;
+    if (c->fresh) {
+        if (n == 0 || kc_flush_is_small(a)) {          // (no sweep: the records are counted where they lie, into a real table)
+            if (hast_status st = table_real(c)) return st;
+        } else a.fresh = 1;
+    }
     KC_TRY(launch_kc_flush(a, c->stream));
+    c->fresh = false;
     unsigned long long sp = 0;
     KC_TRY(hipMemcpyAsync(&sp, c->d_small + kSpillN, sizeof(sp), hipMemcpyDeviceToHost, c->stream));
     KC_TRY(hipMemsetAsync(c->d_small + kRecCursor, 0, 2 * sizeof(unsigned long long), c->stream));      // cursor and spill count
@@ -257,7 +282,7 @@ hast_status hast_kc_create_ex(int device, int k, size_t table_bytes, uint64_t ex
     if (st == HAST_OK) part_setup(c);
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream), "hipMemset");
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
-    if (st == HAST_OK) bail(launch_kc_clear(c->d_table, c->nbuckets, c->stream), "clear table");
+    if (st == HAST_OK && table_empty(c) != HAST_OK) st = HAST_ERR_HIP;
     if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     if (st != HAST_OK) {
         hast_kc_destroy(c);
@@ -299,7 +324,7 @@ hast_status hast_kc_set_slice(hast_kc *c, uint32_t slice, uint32_t n_slices) {
     if (n_slices < 1 || slice >= n_slices) return set_error(HAST_ERR_INVALID, "slice %u of %u", slice, n_slices);
     c->slice = slice;
     c->n_slices = n_slices;
-    KC_TRY(launch_kc_clear(c->d_table, c->nbuckets, c->stream));
+    if (hast_status st = table_empty(c)) return st;
     KC_TRY(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream));
     KC_TRY(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream));
     if (c->err_pending) {                          // a copy of the old word may still be in flight
@@ -337,6 +362,12 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
     a.rec_cursor = nullptr;
     a.rec_chunk = 0;
     a.rec_run_max = a.rec_off_bits = a.fine_shift = 0;
+    a.fresh = 0;
+    a.spill = nullptr;
+    a.spill_cap = 0;
+    a.spill_n = nullptr;
+    if (!c->part_on)
+        if (hast_status st = table_real(c)) return st;
     if (c->part_on) {
         // (an upper bound of one record per two windows; a minimizer run holds ~3.5.  What does not fit the buffer after all is
         // counted on the spot, by the kernel itself)
@@ -363,6 +394,10 @@ static hast_status count_launch(hast_kc *c, int parent, const uint8_t *d_bytes, 
         a.rec_out = c->d_rec;
         a.rec_cap = c->rec_cap;
         a.rec_cursor = c->d_small + kRecCursor;
+        a.fresh = c->fresh ? 1u : 0u;                  // (after a flush above: no longer)
+        a.spill = c->d_spill;
+        a.spill_cap = c->spill_cap;
+        a.spill_n = c->d_small + kSpillN;
         c->est_records += worst;
     }
     const size_t n_tiles = (n_starts + a.tile_bases - 1) / a.tile_bases;

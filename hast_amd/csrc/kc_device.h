@@ -28,6 +28,10 @@ struct KcCountArgs {
     uint32_t fine_shift;             // log2(buckets of a slice): where a record that finds no room in the buffer is counted (kc_common.h PLACEMENT)
     uint32_t rec_run_max, rec_off_bits;   // kc_run_max / kc_rec_off_bits of (k, m)
     uint32_t rec_chunk;              // records a workgroup reserves at a time (>= tile_bases / 2); unused ends are filled with null records
+    // a table that has not been written yet (`fresh`: its first flush writes every slice without reading it, KcFlushArgs) cannot count a
+    // record on the spot: what finds no room in the record buffer goes to the spill list, which the flush applies last
+    uint32_t fresh;
+    unsigned long long *spill, spill_cap, *spill_n;
 };
 
 // one flush of the partitioned path: records -> level-1 regions -> fine regions (in the flat buffer's place) -> slices in LDS -> spill
@@ -40,6 +44,8 @@ struct KcFlushArgs {
     unsigned long long n_records;
     const unsigned long long *rec_cursor;   // device word behind n_records (>= n_records)
     int small_flush;                 // 0: few records for the table's size go through the atomic path where they lie; 1: never; 2: always
+    uint32_t fresh;                  // the table holds nothing (and has not been cleared): k_kc_apply starts every slice empty instead of reading it,
+                                     // and writes slices without records too.  Never with a flush that kc_flush_is_small() (it skips the sweep)
     unsigned long long *l1_recs;     // n_l1 x l1_split regions of l1_cap records: region s * n_l1 + b = level-1 bin b as the workgroups with blockIdx % l1_split == s wrote it
     uint32_t l1_split;
     uint32_t l1_cap, fine_cap;
@@ -54,6 +60,7 @@ constexpr uint32_t kKcL1FillWords = 1;    // words between two level-1 fill / va
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s);
 size_t kc_count_smem(uint32_t tile_bases, int k, int m);
 hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s);
+bool kc_flush_is_small(const KcFlushArgs &a);
 hipError_t launch_kc_clear(unsigned long long *table, size_t nbuckets, hipStream_t s);
 hipError_t launch_kc_stats(const unsigned long long *table, size_t nbuckets, unsigned long long *d_out3, hipStream_t s);
 hipError_t launch_kc_histo(const unsigned long long *table, size_t nbuckets, uint32_t parent, unsigned long long *d_out, hipStream_t s);

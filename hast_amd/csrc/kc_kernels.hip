@@ -96,6 +96,17 @@ __device__ __forceinline__ void kc_count_record(unsigned long long *table, uint3
     }
 }
 
+// a record of the emit kernels that found no room in the record buffer
+__device__ __forceinline__ void kc_emit_overflow(const KcCountArgs &a, unsigned long long rec) {
+    if (!a.fresh) {
+        kc_count_record(a.table, a.nbuckets, a.k, a.m, a.fine_shift, rec, a.err);          // counted on the spot
+        return;
+    }
+    const unsigned long long at = atomicAdd(a.spill_n, 1ull);                              // (nothing to count into yet: KcCountArgs)
+    if (at < a.spill_cap) a.spill[at] = rec;
+    else atomicOr(a.err, 1u);
+}
+
 // phase A of a tile (both front ends): 16 bytes per lane -> 32 bits of 2-bit codes + 16 validity bits, into LDS.  Bytes in front of
 // the buffer and behind its end read as separators.
 __device__ __forceinline__ void kc_tile_pack(uintptr_t base_addr, uintptr_t end_addr, uint64_t t0, uint32_t NW, unsigned long long *s_pack, uint32_t *s_inv, uint32_t tid) {
@@ -264,7 +275,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
                         if (start && idx >= RC) {
                             const unsigned long long at = g0 + (unsigned long long)__popcll(om & ((1ull << lane) - 1));
                             if (at < a.rec_cap) a.rec_out[at] = rec;
-                            else kc_count_record(a.table, a.nbuckets, K, M, a.fine_shift, rec, a.err);
+                            else kc_emit_overflow(a, rec);
                         }
                     }
                 }
@@ -306,7 +317,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_count(KcCountArgs a) {
             for (uint32_t i = tid; i < n; i += kKcThreads) {
                 const unsigned long long at = s_rec_base + i;
                 if (at < a.rec_cap) a.rec_out[at] = s_rec[i];
-                else kc_count_record(a.table, a.nbuckets, K, M, a.fine_shift, s_rec[i], a.err);          // (no room: counted on the spot)
+                else kc_emit_overflow(a, s_rec[i]);                                                        // (no room)
             }
         }
     }
@@ -493,7 +504,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
                                            ((unsigned long long)runm1 << 1) | a.parent;
             const unsigned long long o = s_rec_base + i;
             if (o < a.rec_cap) a.rec_out[o] = rec;
-            else kc_count_record(a.table, a.nbuckets, (int)K, a.m, a.fine_shift, rec, a.err);          // (no room: counted on the spot)
+            else kc_emit_overflow(a, rec);                                                             // (no room)
         }
     }
     __syncthreads();
@@ -584,6 +595,7 @@ struct KcPartGeom {
     uint32_t ob, rmax;           // kc_rec_off_bits, kc_run_max
     uint32_t f2_shift;           // f2 == 1 << f2_shift
     uint32_t l1_split;           // regions per level-1 bin (KcFlushArgs)
+    uint32_t fresh;              // KcFlushArgs
 };
 constexpr uint32_t kKcPartRecs = 8192, kKcPartThreads = 1024, kKcMaxFan = 1024;
 constexpr uint32_t kKcFillPad = kKcL1FillWords;                                // words between two level-1 fill counters
@@ -603,6 +615,7 @@ __device__ __forceinline__ void kc_spill(const KcPartGeom &g, unsigned long long
                                          unsigned long long *spill_n) {
     const unsigned long long at = atomicAdd(spill_n, 1ull);
     if (at < spill_cap) spill[at] = rec;
+    else if (g.fresh) atomicOr(g.err, 1u);                                      // (no table to count into yet: as good as full)
     else kc_count_record(g.table, g.nbuckets, g.k, g.m, g.fine_shift, rec, g.err);
 }
 // a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global access in flight (its fence is for
@@ -783,7 +796,7 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
     const uint32_t fine = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t f = fill[fine], v = valid[fine];
     const uint32_t n = f < v ? (f < cap ? f : cap) : v;
-    if (n == 0) return;
+    if (n == 0 && !g.fresh) return;
     const uint32_t b0 = fine << g.fine_shift;
     const uint32_t nb_here = g.nbuckets - b0 < (1u << g.fine_shift) ? g.nbuckets - b0 : (1u << g.fine_shift);
     const uint32_t map_bytes = kc_apply_map_bytes(g.rmax);
@@ -797,7 +810,8 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t i = i0 + (uint32_t)q * kKcApplyThreads;
-                if (i < nvec) t[q] = gsrc[i];
+                if (g.fresh) t[q] = (i & 7) < kKcSlots / 2 ? u64x2{kEmptySlot, kEmptySlot} : u64x2{0ull, 0ull};      // (wave-uniform) a table nobody has written: k_kc_clear's pattern
+                else if (i < nvec) t[q] = gsrc[i];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -931,8 +945,11 @@ __global__ void __launch_bounds__(256) k_kc_spill(KcPartGeom g, const unsigned l
         if (spill[i] != ~0ull) kc_count_record(g.table, g.nbuckets, g.k, g.m, g.fine_shift, spill[i], g.err);
 }
 
+bool kc_flush_is_small(const KcFlushArgs &a) {
+    return a.n_records && (a.small_flush == 2 || (a.small_flush == 0 && a.n_records < (unsigned long long)a.nbuckets * (kKcBucketWords * 8) / 256));
+}
 hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
-    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m), (uint32_t)__builtin_ctz(a.f2), a.l1_split};
+    KcPartGeom g{a.table, a.nbuckets, a.k, a.m, a.fine_shift, a.n_fine, a.n_l1, a.f2, a.err, kc_rec_off_bits(a.k, a.m), kc_run_max(a.k, a.m), (uint32_t)__builtin_ctz(a.f2), a.l1_split, a.fresh};
     const size_t lds_part = (size_t)3 * kKcMaxFan * 4 + (size_t)kKcPartRecs * 8;
     const size_t lds_apply = ((size_t)1 << a.fine_shift) * kKcLdsStride * 8 + (size_t)(kKcApplyThreads / 64) * kc_apply_map_bytes(kc_run_max(a.k, a.m));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
@@ -945,7 +962,7 @@ hipError_t launch_kc_flush(const KcFlushArgs &a, hipStream_t s) {
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_fill, 0, (size_t)a.n_fine * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(a.fine_valid, 0xFF, (size_t)a.n_fine * 4, s);
     if (e != hipSuccess) return e;
-    if (a.n_records && (a.small_flush == 2 || (a.small_flush == 0 && a.n_records < (unsigned long long)a.nbuckets * (kKcBucketWords * 8) / 256))) {
+    if (kc_flush_is_small(a)) {
         // few records for this table (the sweep moves 2 x 128 B per bucket whatever there is to count, the atomic path ~40 G windows/s):
         // count them where they lie
         hipLaunchKernelGGL(k_kc_spill, dim3(256 * 8), dim3(256), 0, s, g, a.records, a.n_records, a.rec_cursor);
