@@ -167,7 +167,8 @@ static hast_status table_real(hast_kc *c) {
 // an empty table: the partitioned path's first flush writes every slice anyway, so it is only DECLARED empty (the clear is 9 ms of a
 // 110-ms step on the bench's 64-GB table; HAST_KC_FRESH=0: always cleared)
 static hast_status table_empty(hast_kc *c) {
-    static const bool lazy = [] { const char *e = getenv("HAST_KC_FRESH"); return !(e && !strcmp(e, "0")); }();
+    const char *e = getenv("HAST_KC_FRESH");
+    const bool lazy = !(e && !strcmp(e, "0"));
     c->fresh = c->part_on && lazy;
     if (c->fresh) return HAST_OK;
     KC_TRY(launch_kc_clear(c->d_table, c->nbuckets, c->stream));

@@ -106,9 +106,7 @@ HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
 HAST_HD uint32_t kc_key_hash(uint64_t key) {
     const uint32_t a = (uint32_t)key, b = (uint32_t)(key >> 32);
     uint32_t h = kc_mul24(a, 0x9E3779u) ^ kc_mul24(a >> 8, 0x85EBCBu) ^ kc_mul24(b, 0xC2B2AFu) ^ (kc_mul24(b >> 8, 0x27D4EBu) << 7);
-    h ^= h >> 15;
-    h = kc_mul24(h, 0x2C1B3Du) ^ kc_mul24(h >> 9, 0x7FEB35u);
-    return h ^ (h >> 13);
+    return h ^ (h >> 15);         // (a second round of multiplies, round 5a, bought nothing: 12 instead of 8 windows of 10 G find their four buckets full without it)
 }
 HAST_HD uint32_t kc_bucket_of_hash(uint32_t h, uint32_t n_here) { return kc_mul24(h >> 16, n_here) >> 16; }      // n_here <= 2^16: slices of 512 or 1024 buckets
 HAST_HD uint32_t kc_key_bucket(uint64_t key, uint32_t n_here) { return kc_bucket_of_hash(kc_key_hash(key), n_here); }

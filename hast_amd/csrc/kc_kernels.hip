@@ -514,7 +514,8 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
 }
 // does k_kc_emit4 take this launch?  (HAST_KC_EMIT=lanes keeps k_kc_count<W, true>: A/B runs, and the tests of that kernel)
 static bool kc_emit4_takes(const KcCountArgs &a) {
-    static const bool off = [] { const char *e = getenv("HAST_KC_EMIT"); return e && !strcmp(e, "lanes"); }();
+    const char *e = getenv("HAST_KC_EMIT");
+    const bool off = e && !strcmp(e, "lanes");
     const int w = a.k - a.m + 1;
     return !off && a.rec_out && a.m == 16 && w >= 2 && w <= 6 && a.rec_run_max >= (uint32_t)w && a.k + w + 2 <= 32 && a.tile_bases % 1024 == 0 &&
            a.tile_bases <= 16384 && a.rec_chunk >= a.tile_bases;
@@ -867,8 +868,7 @@ __global__ void __launch_bounds__(kKcApplyThreads) __attribute__((amdgpu_waves_p
             const uint32_t kh = kc_key_hash(key);
             const uint32_t hw = kc_bucket_of_hash(kh, nb_here);
             const uint32_t tag = kc_tag_of_hash(kh);
-            uint32_t t32 = tag | (tag << 8);
-            t32 |= t32 << 16;
+            const uint32_t t32 = __builtin_amdgcn_perm(tag, tag, 0u);              // the tag in all four bytes (shifts + ors become a quarter-rate multiply)
             const unsigned long long tagx = ((unsigned long long)t32 << 32) | t32;
             bool done = !act;
 #pragma unroll 1

@@ -119,8 +119,19 @@ def test_counts_histograms_selections_vs_oracle(built, oracle_lib, k):
     o.ho_s00_free(c)
 
 
-@pytest.mark.parametrize("k,table_mb,record_mb", [(21, 64, 0), (21, 256, 2), (11, 64, 1), (29, 64, 0), (5, 64, 0), (27, 1024, 0), (31, 64, 0)])
-def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, table_mb, record_mb):
+@pytest.mark.parametrize("k,table_mb,record_mb,switches", [
+    (21, 64, 0, {}), (21, 256, 2, {}), (11, 64, 1, {}), (29, 64, 0, {}), (5, 64, 0, {}), (27, 1024, 0, {}), (31, 64, 0, {}),
+    # K = 17 .. 21 (m = 16, W = 2 .. 6) go through k_kc_emit4 (four windows per lane); the other K and HAST_KC_EMIT=lanes through k_kc_count<W, EMIT>
+    (17, 64, 0, {}), (18, 64, 1, {}), (19, 64, 0, {}), (20, 256, 2, {}),
+    (21, 64, 0, {"HAST_KC_EMIT": "lanes"}), (21, 256, 2, {"HAST_KC_EMIT": "lanes", "HAST_KC_FRESH": "0"}),
+    # a table cleared before it is counted into (default: declared empty, the first flush writes every slice), with records that find no room
+    (21, 256, 2, {"HAST_KC_FRESH": "0"}), (19, 64, 1, {"HAST_KC_FRESH": "0"}),
+    # one region per level-1 bin, and a number that does not divide anything
+    (21, 64, 0, {"HAST_KC_L1_SPLIT": "1"}), (21, 256, 2, {"HAST_KC_L1_SPLIT": "3"}),
+    # tiles of 1024 and 8192 window starts
+    (21, 64, 0, {"HAST_KC_TILE": "1024"}), (20, 64, 1, {"HAST_KC_TILE": "8192"}),
+])
+def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, table_mb, record_mb, switches):
     """The counting path of large tables (kc_kernels.hip "partitioned counting": windows written out as records of a minimizer run,
     partitioned by bucket range in two levels, counted per slice in LDS), forced on small ones: counts, histograms and selections ==
     oracle -- with an ample record buffer (one flush at sync), with a tiny one (HAST_KC_RECORD_MB: many flushes, records that find
@@ -136,6 +147,8 @@ def test_partitioned_counting_equals_oracle(built, oracle_lib, monkeypatch, k, t
     monkeypatch.setenv("HAST_KC_FLUSH", "sweep")          # (few records for the table's size would take the atomic path where they lie)
     if record_mb:
         monkeypatch.setenv("HAST_KC_RECORD_MB", str(record_mb))
+    for name, value in switches.items():
+        monkeypatch.setenv(name, value)
     with KmerCounter(k, table_bytes=table_mb << 20) as kc:
         info = kc.partition_info()
         assert info["partitioned"] == (k <= 27), info

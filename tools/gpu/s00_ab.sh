@@ -12,7 +12,7 @@ fi
 line() { python3 -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[2], '%.1f Gbp/s' % (d['value']/1e9), '%.1f ms/step' % d['ms_per_step'], {k:(round(v,1) if isinstance(v,float) else v) for k,v in d.get('seconds',{}).items()} if isinstance(d.get('seconds'),dict) else '')
+print(sys.argv[2], '%.1f Gbp/s' % (d['value']/1e9), '%.1f ms/step' % d['ms_per_step'], d.get('counting'))
 " "$1" "$2"; }
 for i in 1 2; do
   timeout -k 10 300 python3 bench.py --workload s00 --cpu-seconds 0 > $O/new_$i.json 2> $O/new_$i.err && line $O/new_$i.json "tree_$i" || { tail -5 $O/new_$i.err; exit 1; }
