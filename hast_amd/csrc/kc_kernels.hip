@@ -7,6 +7,7 @@
 //   k_kc_count   : byte stream -> 2-bit codes + validity mask in LDS -> canonical k-mer per window -> find-or-insert in
 //                  the window's minimizer bucket (128-B line: 8 keys + 8 paternal + 8 maternal counters) -> one atomic add
 //                  (the DIRECT path: small tables, K > 27); with EMIT the same front end writes 8-byte records of minimizer runs
+//   k_kc_emit4   : the emit front end of K = 17 .. 21 (m = 16): four positions, then four windows per lane (round 5)
 //   k_kc_part<1|2>, k_kc_apply, k_kc_spill : the PARTITIONED path of large tables (below): records -> two levels of bucket ranges
 //                  -> one slice of the table at a time in LDS, counted there
 //   k_kc_stats / k_kc_histo / k_kc_select : streaming passes over the table
@@ -583,7 +584,9 @@ hipError_t launch_kc_count(const KcCountArgs &a, unsigned grid, hipStream_t s) {
 //   line read + one atomic per minimizer run before.
 // Measured (round 4, bench.py --workload s00, 10.4 G windows, 64-GB table; DESIGN.md section 9 has the steps): emit 51 ms + two
 // partition passes 22 + 17 ms + k_kc_apply 50 ms (+ 9 ms to clear the table) = 0.148 s a step = 81 Gbp/s against 0.271 s of the direct
-// kernel, 3.95 KB of HBM traffic per 150-bp read against 9.59 KB; every pass is bound by VALU issue.  The first version (a lane per
+// kernel, 3.95 KB of HBM traffic per 150-bp read against 9.59 KB; every pass is bound by VALU issue.  Round 5: emit 28 ms (k_kc_emit4) + 12 +
+// 13 ms (a level-1 bin in 8 regions: the workgroups no longer all add to the same fill words) + 47 ms, nothing cleared (a table that
+// holds nothing is declared empty, KcFlushArgs.fresh) = 0.101 s = 119 Gbp/s, 3.0 KB per read.  The first version (a lane per
 // RECORD in the LDS pass, the minimizer recomputed in every pass, keys filed in their minimizer's bucket as in the direct layout,
 // one reservation per tile on one global word) took 0.58 s.
 struct KcPartGeom {

@@ -19,7 +19,7 @@ tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 mode = open(os.path.join(src, "mode.txt")).read().strip()
-COUNTING = ("k_kc_count", "k_kc_part", "k_kc_apply", "k_kc_spill")
+COUNTING = ("k_kc_count", "k_kc_emit4", "k_kc_part", "k_kc_apply", "k_kc_spill")
 
 
 def short(name):
