@@ -93,6 +93,74 @@ HAST_HD uint32_t kc_rec_minhash(uint64_t rec, int k, int m, uint32_t ob) {
     return kc_mmer_hash(kmer_canon((first >> (2 * ((uint32_t)(k - m) - off))) & kmer_mask(m), m));
 }
 
+// ---- the per-lane arithmetic of k_kc_emit4 (kc_kernels.hip), shared with its host model (tests/native/test_kc_records.cpp) -----------
+// the m-mer hashes of positions q .. q + 3 (m = 16) from x = the 32 bases behind q, first base most significant
+HAST_HD uint32_t kc_e4_funnel(uint32_t hi, uint32_t lo, uint32_t sh) {           // the low dword of (hi:lo) >> sh, 0 < sh < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+}
+HAST_HD void kc_e4_mmer_hashes(uint64_t x, uint32_t h[4]) {
+    uint64_t y = x ^ 0xAAAAAAAAAAAAAAAAull;                                       // the reverse complement of all 32 bases (kmer_revcomp without its shift)
+#if defined(__HIP_DEVICE_COMPILE__)
+    y = __brevll(y);
+    y = ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
+#else
+    y = ((y & 0x3333333333333333ull) << 2) | ((y >> 2) & 0x3333333333333333ull);
+    y = ((y & 0x0F0F0F0F0F0F0F0Full) << 4) | ((y >> 4) & 0x0F0F0F0F0F0F0F0Full);
+    y = __builtin_bswap64(y);
+#endif
+    const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x, yh = (uint32_t)(y >> 32), yl = (uint32_t)y;
+    uint32_t f = xh, r = yl;
+    h[0] = kc_mmer_hash32(f < r ? f : r);
+    f = kc_e4_funnel(xh, xl, 30), r = kc_e4_funnel(yh, yl, 2);
+    h[1] = kc_mmer_hash32(f < r ? f : r);
+    f = kc_e4_funnel(xh, xl, 28), r = kc_e4_funnel(yh, yl, 4);
+    h[2] = kc_mmer_hash32(f < r ? f : r);
+    f = kc_e4_funnel(xh, xl, 26), r = kc_e4_funnel(yh, yl, 6);
+    h[3] = kc_mmer_hash32(f < r ? f : r);
+}
+// the minima of the four windows of W hashes that start at c[0] .. c[3]; c[j] = hash | j: the minimum names its place in the block
+template <int WT>
+HAST_HD void kc_e4_minima(const uint32_t c[9], uint32_t w[4]) {
+    static_assert(WT >= 2 && WT <= 6, "nine values");
+    auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+    if (WT == 2) {
+        for (int k = 0; k < 4; ++k) w[k] = mn(c[k], c[k + 1]);
+        return;
+    }
+    uint32_t mid = 0xFFFFFFFFu;                                                  // positions 3 .. W - 1: in all four windows
+    for (int j = 3; j < WT; ++j) mid = mn(mid, c[j]);
+    const uint32_t s2 = c[2], s1 = mn(c[1], s2), s0 = mn(c[0], s1);
+    const uint32_t q1 = c[WT], q2 = mn(q1, c[WT + 1]), q3 = mn(q2, c[WT + 2]);
+    w[0] = mn(s0, mid);
+    w[1] = mn(mn(s1, mid), q1);
+    w[2] = mn(mn(s2, mid), q2);
+    w[3] = mn(mid, q3);
+}
+// bit k: window k goes on with the run of the window in front of it (both valid, the same minimizer position).  vm = the lane's four
+// validity bits, at[k] = where in the lane's block window k's minimizer starts, prev = (at[3] | valid[3] << 4) of the lane in front
+HAST_HD uint32_t kc_e4_cont(uint32_t vm, const uint32_t at[4], bool has_prev, uint32_t prev) {
+    uint32_t cn = 0;
+    if (has_prev && (vm & 1u) && (prev >> 4) && (prev & 15u) == at[0] + 4u) cn = 1u;
+    for (int k = 1; k < 4; ++k)
+        if (((vm >> k) & 1u) && ((vm >> (k - 1)) & 1u) && at[k] == at[k - 1]) cn |= 1u << k;
+    return cn;
+}
+// windows that go on behind window k of a lane: C = the continuation bits of this lane | the next << 4 | the one after << 8
+HAST_HD uint32_t kc_e4_run_minus_1(uint32_t C, int k) {
+    const uint32_t x = ~(C >> (k + 1));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctz(x);
+#else
+    return (uint32_t)__builtin_ctz(x);
+#endif
+}
+// a run's descriptor: window (tile-relative, < 2^14) | run - 1 << 14 | offset of the minimizer in the run's first window << 18
+HAST_HD uint32_t kc_e4_desc(uint32_t p, uint32_t runm1, uint32_t off) { return p | (runm1 << 14) | (off << 18); }
+
 // PLACEMENT.  Direct counting (one atomic per minimizer run) files a key in its minimizer's bucket, then the next three, then from a
 // bucket of the key's own hash on (kc_kernels.hip kc_probe): the windows of a read that share a minimizer touch one 128-B line.
 // Partitioned counting only needs the minimizer to pick the SLICE of 2^fine_shift buckets a record goes to -- the slice is in LDS

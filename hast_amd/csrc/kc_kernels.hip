@@ -385,27 +385,9 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
 
         // ---- M ---------------------------------------------------------------------------------------------------------------
         for (uint32_t q0 = 4 * tid; q0 < TB + WT - 1; q0 += 4 * kKcThreads) {
-            const unsigned long long x = window_bits(s_pack, q0, 0);                               // bases q0 .. q0 + 31
-            unsigned long long y = __brevll(x ^ 0xAAAAAAAAAAAAAAAAull);
-            y = ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);           // their reverse complement
-            const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x, yh = (uint32_t)(y >> 32), yl = (uint32_t)y;
-            uint4 h;
-            {
-                const uint32_t f = xh, r = yl;
-                h.x = kc_mmer_hash32(f < r ? f : r);
-            }
-            {
-                const uint32_t f = __builtin_amdgcn_alignbit(xh, xl, 30), r = __builtin_amdgcn_alignbit(yh, yl, 2);
-                h.y = kc_mmer_hash32(f < r ? f : r);
-            }
-            {
-                const uint32_t f = __builtin_amdgcn_alignbit(xh, xl, 28), r = __builtin_amdgcn_alignbit(yh, yl, 4);
-                h.z = kc_mmer_hash32(f < r ? f : r);
-            }
-            {
-                const uint32_t f = __builtin_amdgcn_alignbit(xh, xl, 26), r = __builtin_amdgcn_alignbit(yh, yl, 6);
-                h.w = kc_mmer_hash32(f < r ? f : r);
-            }
+            uint32_t hh[4];
+            kc_e4_mmer_hashes(window_bits(s_pack, q0, 0), hh);                                     // from bases q0 .. q0 + 31
+            const uint4 h{hh[0], hh[1], hh[2], hh[3]};
             *reinterpret_cast<uint4 *>(s_mh + q0) = h;
         }
         __syncthreads();
@@ -423,20 +405,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
                 c[8] = s_mh[p0 + 8] | 8u;
             }
             uint32_t w[4];
-            if (WT == 2) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = min(c[k], c[k + 1]);
-            } else {
-                uint32_t mid = 0xFFFFFFFFu;                                                          // positions 3 .. W - 1: in all four windows
-#pragma unroll
-                for (int j = 3; j < WT; ++j) mid = min(mid, c[j]);
-                const uint32_t s2 = c[2], s1 = min(c[1], s2), s0 = min(c[0], s1);
-                const uint32_t q1 = c[WT], q2 = min(q1, c[WT + 1]), q3 = min(q2, c[WT + 2]);
-                w[0] = min(s0, mid);
-                w[1] = min(min(s1, mid), q1);
-                w[2] = min(min(s2, mid), q2);
-                w[3] = min(mid, q3);
-            }
+            kc_e4_minima<WT>(c, w);
             uint32_t at[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) at[k] = w[k] & 15u;                                          // where in the block the window's minimizer starts
@@ -454,11 +423,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
             // continuation bits: window k goes on with the run of window k - 1
             const uint32_t mine = at[3] | ((vm >> 3) << 4);
             const uint32_t prev = (uint32_t)__shfl_up((int)mine, 1, 64);
-            uint32_t cn = 0;
-            if (lane > 0 && (vm & 1u) && (prev >> 4) && (prev & 15u) == at[0] + 4u) cn = 1u;
-#pragma unroll
-            for (int k = 1; k < 4; ++k)
-                if (((vm >> k) & 1u) && ((vm >> (k - 1)) & 1u) && at[k] == at[k - 1]) cn |= 1u << k;
+            const uint32_t cn = kc_e4_cont(vm, at, lane > 0, prev);
             const uint32_t n1 = (uint32_t)__shfl_down((int)cn, 1, 64), n2 = (uint32_t)__shfl_down((int)cn, 2, 64);
             const uint32_t C = cn | (lane < 63 ? n1 << 4 : 0u) | (lane < 62 ? n2 << 8 : 0u);
             const uint32_t sn = vm & ~cn;                                                            // windows that start a run
@@ -475,8 +440,7 @@ __global__ void __launch_bounds__(kKcThreads) k_kc_emit4(KcCountArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if ((sn >> k) & 1u) {
-                        const uint32_t runm1 = (uint32_t)__builtin_ctz(~(C >> (k + 1)));             // windows that go on behind it
-                        s_desc[idx] = (p0 + k) | (runm1 << 14) | ((at[k] - (uint32_t)k) << 18);
+                        s_desc[idx] = kc_e4_desc(p0 + (uint32_t)k, kc_e4_run_minus_1(C, k), at[k] - (uint32_t)k);
                         ++idx;
                     }
                 }

@@ -6,6 +6,9 @@
 //     kernel's bucket_of_minhash would pick for each of them, and a k-mer has one slice wherever and on whichever strand it occurs);
 //   * the record fits 64 bits for every K the path accepts (kc_run_max), the offset field never overlaps the bases;
 //   * kc_key_bucket stays inside the slice.
+//   * k_kc_emit4's lanes (K = 17 .. 21: four positions, then four windows per lane, steps of 256 windows) restated with plain loops over
+//     the shared per-lane arithmetic (kc_common.h kc_e4_*): the hashes of phase M equal kc_mmer_hash of the canonical 16-mers, and the
+//     descriptors of phase B are exactly the runs of the definition above, cut at the steps' borders.
 // TEST INFRASTRUCTURE: no product code is called besides the shared integer header.
 #include <cstdint>
 #include <cstdio>
@@ -21,9 +24,76 @@ using namespace hast;
 
 static bool is_base(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't'; }
 
+
+// k_kc_emit4's phases M and B over one "tile" = the whole stream (a multiple of 256 windows is not required: the last step is partial)
+template <int WT>
+static int emit4_model(const std::string &s, int k, const std::vector<char> &valid, const std::vector<uint32_t> &off, std::mt19937_64 &rng, size_t *n_desc) {
+    const size_t n = s.size();
+    // the packed tile: 2 bits per byte whatever it is (the validity mask is separate), padded with junk
+    std::vector<uint8_t> code(n + 96);
+    for (size_t i = 0; i < code.size(); ++i) code[i] = i < n ? (uint8_t)base_code((uint8_t)s[i]) : (uint8_t)(rng() & 3);
+    auto bits64 = [&](size_t q) { uint64_t x = 0; for (int i = 0; i < 32; ++i) x = (x << 2) | code[q + (size_t)i]; return x; };
+    // phase M: a "lane" per four positions
+    std::vector<uint32_t> H(n + 64);
+    for (size_t q0 = 0; q0 < n + 60; q0 += 4) {
+        uint32_t h[4];
+        kc_e4_mmer_hashes(bits64(q0), h);
+        for (int i = 0; i < 4; ++i) H[q0 + (size_t)i] = h[i];
+    }
+    for (size_t q = 0; q + 16 <= n; ++q) {                       // == the definition, wherever the 16 bytes are bases
+        bool ok = true;
+        uint64_t f = 0;
+        for (int i = 0; i < 16; ++i) { ok = ok && is_base((uint8_t)s[q + (size_t)i]); f = (f << 2) | base_code((uint8_t)s[q + (size_t)i]); }
+        if (ok && H[q] != kc_mmer_hash(kmer_canon(f, 16))) { printf("K=%d: phase M's hash of position %zu differs from kc_mmer_hash\n", k, q); return 1; }
+        if (H[q] & 15u) { printf("K=%d: a hash with low bits\n", k); return 1; }
+    }
+    // phase B: steps of 256 windows, 64 lanes of four
+    std::vector<uint32_t> desc;
+    for (size_t base = 0; base < n; base += 256) {
+        uint32_t vm[64], cn[64], at[64][4];
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            const size_t p0 = base + 4 * lane;
+            uint32_t c[9], w[4];
+            for (int j = 0; j < 9; ++j) c[j] = (p0 + (size_t)j < H.size() ? H[p0 + (size_t)j] : (uint32_t)rng() & ~15u) | (uint32_t)j;
+            kc_e4_minima<WT>(c, w);
+            vm[lane] = 0;
+            for (int q = 0; q < 4; ++q) {
+                at[lane][q] = w[q] & 15u;
+                if (p0 + (size_t)q < n && valid[p0 + (size_t)q]) vm[lane] |= 1u << q;
+            }
+        }
+        for (uint32_t lane = 0; lane < 64; ++lane)
+            cn[lane] = kc_e4_cont(vm[lane], at[lane], lane > 0, lane ? at[lane - 1][3] | ((vm[lane - 1] >> 3) << 4) : 0u);
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            const uint32_t C = cn[lane] | (lane < 63 ? cn[lane + 1] << 4 : 0u) | (lane < 62 ? cn[lane + 2] << 8 : 0u);
+            const uint32_t sn = vm[lane] & ~cn[lane];
+            for (int q = 0; q < 4; ++q)
+                if ((sn >> q) & 1u) desc.push_back(kc_e4_desc((uint32_t)(base + 4 * lane) + (uint32_t)q, kc_e4_run_minus_1(C, q), at[lane][q] - (uint32_t)q));
+        }
+    }
+    // the definition: runs of consecutive valid windows that name the same minimizer occurrence, cut where a step of 256 windows ends
+    std::vector<uint32_t> want;
+    for (size_t p = 0; p < n;) {
+        if (!valid[p]) { ++p; continue; }
+        size_t q = p + 1;
+        while (q < n && valid[q] && (q & 255) != 0 && q + off[q] == p + off[p]) ++q;
+        want.push_back(kc_e4_desc((uint32_t)p, (uint32_t)(q - p - 1), off[p]));
+        p = q;
+    }
+    if (desc != want) {
+        printf("K=%d: k_kc_emit4's lanes cut %zu runs, the definition %zu", k, desc.size(), want.size());
+        for (size_t i = 0; i < desc.size() && i < want.size(); ++i)
+            if (desc[i] != want[i]) { printf("; first difference at run %zu: window %u run %u offset %u against window %u run %u offset %u", i, desc[i] & 0x3FFF, ((desc[i] >> 14) & 15) + 1, desc[i] >> 18, want[i] & 0x3FFF, ((want[i] >> 14) & 15) + 1, want[i] >> 18); break; }
+        printf("\n");
+        return 1;
+    }
+    *n_desc += desc.size();
+    return 0;
+}
+
 int main() {
     std::mt19937_64 rng(20260404);
-    size_t n_records = 0, n_windows = 0, n_cases = 0;
+    size_t n_records = 0, n_windows = 0, n_cases = 0, n_e4 = 0;
     for (int k = 1; k <= 32; ++k) {
         for (int m : {k <= 16 ? k : (k - 8 > 16 ? k - 8 : 16), k > 4 ? k - 3 : k, k}) {
             if (m < 1 || m > k) continue;
@@ -105,6 +175,17 @@ int main() {
                 p = q;
             }
             if (back != truth) { printf("k=%d m=%d: the windows out of the records are not the windows of the stream\n", k, m); return 1; }
+            if (m == 16 && W >= 2 && W <= 6 && rmax >= W && n < (1u << 14)) {
+                int bad = 0;
+                switch (W) {
+                case 2: bad = emit4_model<2>(s, k, valid, off, rng, &n_e4); break;
+                case 3: bad = emit4_model<3>(s, k, valid, off, rng, &n_e4); break;
+                case 4: bad = emit4_model<4>(s, k, valid, off, rng, &n_e4); break;
+                case 5: bad = emit4_model<5>(s, k, valid, off, rng, &n_e4); break;
+                default: bad = emit4_model<6>(s, k, valid, off, rng, &n_e4); break;
+                }
+                if (bad) return 1;
+            }
         }
     }
     // placement inside a slice
@@ -113,6 +194,7 @@ int main() {
         const uint32_t nh = 1 + (uint32_t)(rng() % 1024);
         if (kc_key_bucket(key, nh) >= nh) { printf("kc_key_bucket leaves the slice\n"); return 1; }
     }
-    printf("ok %zu (K, m) cases, %zu windows in %zu records\n", n_cases, n_windows, n_records);
+    if (n_e4 == 0) { printf("k_kc_emit4's model has not run\n"); return 1; }
+    printf("ok %zu (K, m) cases, %zu windows in %zu records; %zu runs through the model of k_kc_emit4\n", n_cases, n_windows, n_records, n_e4);
     return 0;
 }
