@@ -44,6 +44,7 @@ ABI_SYMBOLS = {
     "hast_last_error": (C.c_char_p, []),
     "hast_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
     "hast_ctx_destroy": (None, [vp]),
+    "hast_release_parked": (None, []),
     "hast_ctx_k": (C.c_int, [vp]),
     "hast_ctx_minimizer": (C.c_int, [vp]),
     "hast_ctx_set_minimizer": (C.c_int, [vp, C.c_int]),

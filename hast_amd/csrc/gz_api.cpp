@@ -53,7 +53,7 @@ struct DevBuf {                               // a device allocation that only e
     size_t bytes = 0;
     hipError_t ensure(size_t need) {
         if (need <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
+        park_device(p, bytes);                                 // (not hipFree: it waits for every stream of the device, hast_internal.h)
         p = nullptr;
         bytes = 0;
         const hipError_t e = hipMalloc(&p, need);
@@ -62,7 +62,7 @@ struct DevBuf {                               // a device allocation that only e
         return e;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        park_device(p, bytes);
         p = nullptr;
         bytes = 0;
     }
@@ -262,7 +262,7 @@ void upload_loop(hast_gz *g) {
     land(0);
     land(1);
     for (int k = 0; k < 2; ++k) {
-        if (h[k]) (void)hipHostFree(h[k]);
+        park_pinned(h[k], kPiece);                                 // (the other streams are in mid-file: hast_internal.h)
         for (hipEvent_t e : ev[k])
             if (e) (void)hipEventDestroy(e);
     }
@@ -432,7 +432,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
         GZ_HIP(A.carry.ensure(kWindow));
         if (U.h_crc_cap < n) {
-            if (U.h_crc) (void)hipHostFree(U.h_crc);
+            park_pinned(U.h_crc, 0);
             U.h_crc = nullptr;
             U.h_crc_cap = 0;
             GZ_HIP(hipHostMalloc((void **)&U.h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
@@ -730,14 +730,14 @@ void hast_gz_close(hast_gz *g) {
         }
         for (int i = 0; i < 2; ++i) {
             U.jobs[i].release();
-            if (U.h_jobs[i]) (void)hipHostFree(U.h_jobs[i]);
+            park_pinned(U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob));
             if (U.nom_done[i]) (void)hipEventDestroy(U.nom_done[i]);
         }
         U.fjobs.release();
         U.bounce.release();
-        if (U.h_fjobs) (void)hipHostFree(U.h_fjobs);
-        if (U.d_in) (void)hipFree(U.d_in);
-        if (U.h_crc) (void)hipHostFree(U.h_crc);
+        park_pinned(U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob));
+        park_device(U.d_in, (size_t)g->file_size + kInPad);
+        park_pinned(U.h_crc, 0);
         if (U.xl_done) (void)hipEventDestroy(U.xl_done);
         if (U.up_stream) (void)hipStreamDestroy(U.up_stream);
         if (U.dec_stream && U.dec_masked_free) masked_stream_put(U.device, U.dec_masked_free, U.dec_stream);     // (drained above)
@@ -749,7 +749,7 @@ void hast_gz_close(hast_gz *g) {
         (void)hipSetDevice(de.first);
         (void)hipEventDestroy(de.second);
     }
-    if (g->h_carry) (void)hipHostFree(g->h_carry);
+    park_pinned(g->h_carry, kWindow);
     tr("freed");
     if (g->fd >= 0) close(g->fd);
     delete g;

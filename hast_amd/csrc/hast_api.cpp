@@ -208,6 +208,52 @@ hast_status set_error(hast_status st, const char *fmt, ...) {
     va_end(ap);
     return st;
 }
+namespace {
+struct Parked {
+    std::mutex mu;
+    std::vector<void *> device, pinned;
+    size_t bytes = 0;
+};
+Parked &parked() {
+    static Parked *p = new Parked();                       // (never destroyed: streams may be closed from threads that outlive main's statics)
+    return *p;
+}
+size_t park_limit() {
+    const char *e = getenv("HAST_PARK_GB");
+    return (size_t)((e ? atof(e) : 96.0) * 1073741824.0);
+}
+}  // namespace
+void release_parked() {
+    std::vector<void *> d, h;
+    {
+        Parked &pk = parked();
+        std::lock_guard<std::mutex> lk(pk.mu);
+        d.swap(pk.device);
+        h.swap(pk.pinned);
+        pk.bytes = 0;
+    }
+    for (void *p : d) (void)hipFree(p);
+    for (void *p : h) (void)hipHostFree(p);
+}
+static void park(void *p, size_t bytes, bool pinned) {
+    if (!p) return;
+    const size_t limit = park_limit();
+    if (limit == 0) {
+        (void)(pinned ? hipHostFree(p) : hipFree(p));
+        return;
+    }
+    bool over = false;
+    {
+        Parked &pk = parked();
+        std::lock_guard<std::mutex> lk(pk.mu);
+        (pinned ? pk.pinned : pk.device).push_back(p);
+        pk.bytes += bytes;
+        over = pk.bytes > limit;
+    }
+    if (over) release_parked();
+}
+void park_device(void *p, size_t bytes) { park(p, bytes, false); }
+void park_pinned(void *p, size_t bytes) { park(p, bytes, true); }
 int default_minimizer_for(int k) { return default_minimizer(k); }
 }  // namespace hast
 
@@ -283,10 +329,13 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     return HAST_OK;
 }
 
+void hast_release_parked(void) { release_parked(); }
+
 void hast_ctx_destroy(hast_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    release_parked();                                      // (what closed streams left behind: a context that goes returns its memory)
     for (auto &s : c->stage) {
         if (s.h_bases) (void)hipHostFree(s.h_bases);
         if (s.h_off) (void)hipHostFree(s.h_off);

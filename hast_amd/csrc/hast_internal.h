@@ -14,4 +14,12 @@ hast_status classify_framed(hast_ctx *c, const uint8_t *d_buf, size_t buf_bytes,
 hast_status commit_framed(hast_ctx *c, const uint32_t *d_votes, const uint32_t *d_ids, size_t n_reads, hipStream_t hs);
 hipStream_t ctx_stream_of(hast_ctx *c);
 size_t ctx_n_barcodes(const hast_ctx *c);
+// FREES THAT DO NOT STOP THE DEVICE.  hipFree and hipHostFree wait for every stream of the device and hold the runtime's lock while
+// they do: a stream that is closed while another one still decodes (the reader threads of `classify`, the upload thread of a .gz stream
+// that has sent its last byte) made every HIP call of the process wait 20-50 ms, 0.3 s on some boxes of the pool (tools/hipstall,
+// profiles/round5_hipstall_slow_box.txt).  The streams' buffers are PARKED instead and freed for real by hast_release_parked(), by
+// hast_ctx_destroy, or when more than HAST_PARK_GB (default 96; 0 = free at once, as before) are waiting.
+void park_device(void *p, size_t bytes);
+void park_pinned(void *p, size_t bytes);
+void release_parked();
 }  // namespace hast
