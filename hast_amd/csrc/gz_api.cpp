@@ -56,7 +56,12 @@ struct DevBuf {                               // a device allocation that only e
         park_device(p, bytes);                                 // (not hipFree: it waits for every stream of the device, hast_internal.h)
         p = nullptr;
         bytes = 0;
-        const hipError_t e = hipMalloc(&p, need);
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipErrorOutOfMemory) {                        // (what closed streams left parked may be what is missing)
+            (void)hipGetLastError();
+            release_parked();
+            e = hipMalloc(&p, need);
+        }
         if (e == hipSuccess) bytes = need;
         else p = nullptr;
         return e;

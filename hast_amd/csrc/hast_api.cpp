@@ -220,7 +220,7 @@ Parked &parked() {
 }
 size_t park_limit() {
     const char *e = getenv("HAST_PARK_GB");
-    return (size_t)((e ? atof(e) : 96.0) * 1073741824.0);
+    return (size_t)((e ? atof(e) : 32.0) * 1073741824.0);
 }
 }  // namespace
 void release_parked() {

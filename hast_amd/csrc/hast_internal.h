@@ -18,7 +18,8 @@ size_t ctx_n_barcodes(const hast_ctx *c);
 // they do: a stream that is closed while another one still decodes (the reader threads of `classify`, the upload thread of a .gz stream
 // that has sent its last byte) made every HIP call of the process wait 20-50 ms, 0.3 s on some boxes of the pool (tools/hipstall,
 // profiles/round5_hipstall_slow_box.txt).  The streams' buffers are PARKED instead and freed for real by hast_release_parked(), by
-// hast_ctx_destroy, or when more than HAST_PARK_GB (default 96; 0 = free at once, as before) are waiting.
+// hast_ctx_destroy, when more than HAST_PARK_GB (default 32: two .gz streams of `classify` park 21; 0 = free at once, as before)
+// are waiting, or when an allocation of a stream fails.
 void park_device(void *p, size_t bytes);
 void park_pinned(void *p, size_t bytes);
 void release_parked();

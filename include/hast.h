@@ -57,7 +57,7 @@ hast_status hast_ctx_create(int device_ordinal, int k, hast_ctx **out);
 void        hast_ctx_destroy(hast_ctx *);
 /* Streams that are closed (hast_fq_destroy, hast_gz_close) PARK their device and pinned buffers instead of freeing them: a free waits
  * for every stream of the device, i.e. stalls the streams that are still at work.  The parked memory is freed for real here, by
- * hast_ctx_destroy, or when more than HAST_PARK_GB (environment, default 96; 0 = free at once) are waiting.  No reference
+ * hast_ctx_destroy, when more than HAST_PARK_GB (environment, default 32; 0 = free at once) are waiting, or when a stream's allocation fails.  No reference
  * counterpart (the reference's streams are host objects). */
 void        hast_release_parked(void);
 int         hast_ctx_k(const hast_ctx *);
