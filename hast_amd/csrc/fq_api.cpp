@@ -105,11 +105,11 @@ struct hast_fq {
 // h_bc + 2*h_cap and d_text[4*i]; k_fq_name writes up to n + 1 words of h_unknown; hast_fq_commit fills up to n h_pubs.
 static hast_status grow_records(Slot &s, size_t cap) {
     // (parked, not freed: hipFree / hipHostFree wait for every stream of the device, hast_internal.h)
-    park_pinned(s.h_bc, 6 * s.h_cap * sizeof(uint32_t));
-    park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t));
-    park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t));
-    park_pinned(s.h_pubs, s.h_cap * sizeof(NamePub));
-    park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t));
+    park_pinned(s.h_bc, 6 * s.h_cap * sizeof(uint32_t), 3);
+    park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t), 3);
+    park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), 3);
+    park_pinned(s.h_pubs, s.h_cap * sizeof(NamePub), 3);
+    park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t), 3);
     s.h_bc = s.h_ids = s.h_unknown = s.d_text = nullptr;
     s.h_pubs = nullptr;
     s.h_cap = 0;
@@ -123,22 +123,22 @@ static hast_status grow_records(Slot &s, size_t cap) {
 }
 
 static void free_slot(Slot &s) {
-    park_pinned(s.h_cnt, 64);
-    park_pinned(s.h_last, 64);
+    park_pinned(s.h_cnt, 64, 3);
+    park_pinned(s.h_last, 64, 3);
     if (s.over_read) (void)hipEventDestroy(s.over_read);
     if (s.counted) (void)hipEventDestroy(s.counted);
     if (s.over_copied) (void)hipEventDestroy(s.over_copied);
-    park_pinned(s.h_buf, s.h_buf_bytes);
-    park_pinned(s.h_st, 64);
-    park_pinned(s.h_bc, 6 * s.h_cap * sizeof(uint32_t));
-    park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t));
-    park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t));
-    park_pinned(s.h_pubs, s.h_cap * sizeof(NamePub));
-    park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t));
+    park_pinned(s.h_buf, s.h_buf_bytes, 3);
+    park_pinned(s.h_st, 64, 3);
+    park_pinned(s.h_bc, 6 * s.h_cap * sizeof(uint32_t), 3);
+    park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t), 3);
+    park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), 3);
+    park_pinned(s.h_pubs, s.h_cap * sizeof(NamePub), 3);
+    park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t), 3);
     if (s.named) (void)hipEventDestroy(s.named);
     for (void *p : {(void *)s.d_buf, (void *)s.d_st, (void *)s.d_tile, (void *)s.d_nl, (void *)s.d_off, (void *)s.d_len, (void *)s.d_bcpos,
                     (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes})
-        park_device(p, p == (void *)s.d_buf ? s.h_buf_bytes : 0);
+        park_device(p, p == (void *)s.d_buf ? s.h_buf_bytes : 0, 3);
     if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.parsed) (void)hipEventDestroy(s.parsed);
     if (s.done) (void)hipEventDestroy(s.done);

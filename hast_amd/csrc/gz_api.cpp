@@ -53,7 +53,7 @@ struct DevBuf {                               // a device allocation that only e
     size_t bytes = 0;
     hipError_t ensure(size_t need) {
         if (need <= bytes) return hipSuccess;
-        park_device(p, bytes);                                 // (not hipFree: it waits for every stream of the device, hast_internal.h)
+        park_device(p, bytes, 2);                              // (not hipFree: it waits for every stream of the device, hast_internal.h)
         p = nullptr;
         bytes = 0;
         hipError_t e = hipMalloc(&p, need);
@@ -67,7 +67,7 @@ struct DevBuf {                               // a device allocation that only e
         return e;
     }
     void release() {
-        park_device(p, bytes);
+        park_device(p, bytes, 1);
         p = nullptr;
         bytes = 0;
     }
@@ -147,7 +147,8 @@ struct hast_gz {
     // stats
     hast_gz_stats st{};
     Unit &unit_of(size_t k) { return *units[k % units.size()]; }
-    Arena &arena_of(size_t k) { return unit_of(k).arena[(k / units.size()) % Unit::kArenas]; }
+    int n_arenas = 2;                         // symbol arenas a unit takes turns with (HAST_GZ_ARENAS: 2 or 3)
+    Arena &arena_of(size_t k) { return unit_of(k).arena[(k / units.size()) % (size_t)n_arenas]; }
     int jobs_of(size_t k) const { return (int)((k / units.size()) & 1); }
 };
 
@@ -267,7 +268,7 @@ void upload_loop(hast_gz *g) {
     land(0);
     land(1);
     for (int k = 0; k < 2; ++k) {
-        park_pinned(h[k], kPiece);                                 // (the other streams are in mid-file: hast_internal.h)
+        park_pinned(h[k], kPiece, 0);                               // (the other streams are in mid-file: hast_internal.h)
         for (hipEvent_t e : ev[k])
             if (e) (void)hipEventDestroy(e);
     }
@@ -415,7 +416,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
     // ---- what became final: windows, CRC-32, member checks, hand-over --------------------------------------------------------------
     std::unique_ptr<Batch> b(new Batch);
     b->unit = (int)(N.k % g->units.size());
-    b->arena = (int)((N.k / g->units.size()) % Unit::kArenas);
+    b->arena = (int)((N.k / g->units.size()) % (size_t)g->n_arenas);
     g->chain.take_confirmed(b->acc);
     const size_t n = b->acc.size();
     std::string bad;
@@ -437,7 +438,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
         GZ_HIP(A.carry.ensure(kWindow));
         if (U.h_crc_cap < n) {
-            park_pinned(U.h_crc, 0);
+            park_pinned(U.h_crc, 0, 2);
             U.h_crc = nullptr;
             U.h_crc_cap = 0;
             GZ_HIP(hipHostMalloc((void **)&U.h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
@@ -592,6 +593,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     // footprint small: on some boxes of the pool ONE HIP call of a process that starts right after another one freed tens of GB blocks
     // for 0.7-6 s (hipMalloc or hipStreamCreate, whichever comes first -- tools/probe/malloc_probe.py; the tree before did the same there).
     g->seg_chunks = seg_chunks ? seg_chunks : 4096;
+    if (const char *e = getenv("HAST_GZ_ARENAS")) g->n_arenas = std::min((int)Unit::kArenas, std::max(2, atoi(e)));
     g->room = room > 0 ? room : 12.0;
     if (g->chunk_bytes > (1u << 26)) { close(fd); return set_error(HAST_ERR_INVALID, "chunk_bytes too large"); }
     g->slot_syms = (uint32_t)std::min<double>((double)(1u << 27), (double)g->chunk_bytes * g->room + 600);
@@ -629,9 +631,11 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
         const uint64_t alloc = ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
         step(hipMalloc((void **)&U.d_in, alloc));
-        if (e == hipSuccess) step(hipMemset(reinterpret_cast<uint8_t *>(U.d_in) + tail_from, 0, alloc - tail_from));
         tr("input buffer");
         step(hipStreamCreateWithFlags(&U.up_stream, hipStreamNonBlocking));
+        // (on the stream the file's pieces will come in on: a hipMemset of device memory does not wait for the host, and nothing orders
+        // the legacy stream it runs on against a non-blocking one -- the zeros could land on the file's last bytes after the upload)
+        if (e == hipSuccess) step(hipMemsetAsync(reinterpret_cast<uint8_t *>(U.d_in) + tail_from, 0, alloc - tail_from, U.up_stream));
         {
             // The nominal passes keep some CUs FREE (HAST_GZ_FREE_CUS, default 32 of 256): a decode wave lives for milliseconds and the passes
             // fill every LDS slot of the GPU, so whatever else wants to run -- this file's follow-up jobs, windows and CRC-32, the translate
@@ -663,14 +667,18 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         step(U.fjobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
         for (Arena &a : U.arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
         tr("job buffers");
-        // the unit's first symbol arena now, the other two when their first pass is launched (launch_nominal) -- 3.2 GB each, 5-10 ms
-        // of hipMalloc that the caller's thread need not wait for; that there IS room for them is checked here, so that a device
-        // without it is refused at the door (the caller then inflates on the host) instead of failing in mid-file
+        // the unit's first symbol arena now, the other one when its first pass is launched (launch_nominal) -- 3.2 GB each: 5-10 ms of
+        // hipMalloc on most boxes of the pool, 0.6 s on some (profiles/round5_hipstall_slow_box_parked.txt), so there are as few of them
+        // as the pipeline needs (TWO arenas decode as fast as three: profiles/round5_ab_gz_two_arenas.txt) and the first one has its
+        // final size at once although the file's first pass is a short one (it would be parked and allocated again two passes on).
+        // That there IS room for the later one is checked here, so that a device without it is refused at the door (the caller then
+        // inflates on the host) instead of failing in mid-file
         size_t later = 0;
-        for (int i = 0; i < Unit::kArenas && e == hipSuccess; ++i) {
+        for (int i = 0; i < g->n_arenas && e == hipSuccess; ++i) {
             const size_t k = ui + (size_t)i * nu;
             if (k >= n_seg) break;
-            const size_t chunks = k == 0 ? (n_seg == 1 ? std::max(s0, std::min(seg, n_chunks)) : s0) : seg;
+            const size_t first = n_seg == 1 ? std::max(s0, std::min(seg, n_chunks)) : s0;
+            const size_t chunks = k == 0 ? (n_seg > (size_t)g->n_arenas * nu ? std::max(first, seg) : first) : seg;
             const size_t bytes = chunks * (size_t)g->slot_syms * sizeof(uint16_t) + 64;
             if (i == 0) step(U.arena[i].syms.ensure(bytes));
             else later += bytes + chunks * ((size_t)kWindow * 3 + 64);              // (+ windows, maps, per-chunk words of a batch)
@@ -735,14 +743,14 @@ void hast_gz_close(hast_gz *g) {
         }
         for (int i = 0; i < 2; ++i) {
             U.jobs[i].release();
-            park_pinned(U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob));
+            park_pinned(U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), 1);
             if (U.nom_done[i]) (void)hipEventDestroy(U.nom_done[i]);
         }
         U.fjobs.release();
         U.bounce.release();
-        park_pinned(U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob));
-        park_device(U.d_in, (size_t)g->file_size + kInPad);
-        park_pinned(U.h_crc, 0);
+        park_pinned(U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), 1);
+        park_device(U.d_in, (size_t)g->file_size + kInPad, 1);
+        park_pinned(U.h_crc, 0, 1);
         if (U.xl_done) (void)hipEventDestroy(U.xl_done);
         if (U.up_stream) (void)hipStreamDestroy(U.up_stream);
         if (U.dec_stream && U.dec_masked_free) masked_stream_put(U.device, U.dec_masked_free, U.dec_stream);     // (drained above)
@@ -754,7 +762,7 @@ void hast_gz_close(hast_gz *g) {
         (void)hipSetDevice(de.first);
         (void)hipEventDestroy(de.second);
     }
-    park_pinned(g->h_carry, kWindow);
+    park_pinned(g->h_carry, kWindow, 1);
     tr("freed");
     if (g->fd >= 0) close(g->fd);
     delete g;

@@ -235,9 +235,10 @@ void release_parked() {
     for (void *p : d) (void)hipFree(p);
     for (void *p : h) (void)hipHostFree(p);
 }
-static void park(void *p, size_t bytes, bool pinned) {
+static void park(void *p, size_t bytes, bool pinned, int site) {
     if (!p) return;
-    const size_t limit = park_limit();
+    size_t limit = park_limit();
+    if (const char *e = getenv("HAST_PARK_SITES")) if (!((atoi(e) >> site) & 1)) limit = 0;      // (bisecting: only these sites park)
     if (limit == 0) {
         (void)(pinned ? hipHostFree(p) : hipFree(p));
         return;
@@ -252,8 +253,8 @@ static void park(void *p, size_t bytes, bool pinned) {
     }
     if (over) release_parked();
 }
-void park_device(void *p, size_t bytes) { park(p, bytes, false); }
-void park_pinned(void *p, size_t bytes) { park(p, bytes, true); }
+void park_device(void *p, size_t bytes, int site) { park(p, bytes, false, site); }
+void park_pinned(void *p, size_t bytes, int site) { park(p, bytes, true, site); }
 int default_minimizer_for(int k) { return default_minimizer(k); }
 }  // namespace hast
 
@@ -763,7 +764,11 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
     dst->m = src->m;
     const size_t bytes = table_slots(src) * sizeof(uint64_t);
     HIP_TRY(hipMalloc(&dst->d_slots, bytes));
-    HIP_TRY(hipMemcpyPeer(dst->d_slots, dst->device, src->d_slots, src->device, bytes));
+    // ON dst's stream, and waited for below: hipMemcpyPeer between two contexts of ONE GPU is a device-to-device copy, which does not
+    // wait for the host -- and dst's stream is a non-blocking one, so nothing would order the reads classified on it behind the copy
+    // (seen with --devices 0,0,0 HAST_DEAL=files: a context's first blocks probed a table that was still arriving and lost hits; until
+    // round 5 a hipHostFree elsewhere in the process happened to stop the device at the right moment)
+    HIP_TRY(hipMemcpyPeerAsync(dst->d_slots, dst->device, src->d_slots, src->device, bytes, dst->stream));
     dst->nbuckets = src->nbuckets;
     if (src->filter_valid && dst->use_filter) {
         if (dst->filter_bytes != src->filter_bytes) {
@@ -774,11 +779,12 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
                 (void)hipGetLastError();
                 dst->d_filter = nullptr;
                 dst->use_filter = false;                   // no room: this device probes the table directly
+                HIP_TRY(hipStreamSynchronize(dst->stream));
                 return HAST_OK;
             }
             dst->filter_bytes = src->filter_bytes;
         }
-        HIP_TRY(hipMemcpyPeer(dst->d_filter, dst->device, src->d_filter, src->device, src->filter_bytes));
+        HIP_TRY(hipMemcpyPeerAsync(dst->d_filter, dst->device, src->d_filter, src->device, src->filter_bytes, dst->stream));
         dst->fg = src->fg;
         dst->filter_m = src->filter_m;
         dst->filter_exact = src->filter_exact;
@@ -786,6 +792,7 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
         dst->filter_kp = src->filter_kp;
         dst->filter_valid = true;
     }
+    HIP_TRY(hipStreamSynchronize(dst->stream));            // (src may change once this returns)
     return HAST_OK;
 }
 

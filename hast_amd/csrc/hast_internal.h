@@ -20,7 +20,10 @@ size_t ctx_n_barcodes(const hast_ctx *c);
 // profiles/round5_hipstall_slow_box.txt).  The streams' buffers are PARKED instead and freed for real by hast_release_parked(), by
 // hast_ctx_destroy, when more than HAST_PARK_GB (default 32: two .gz streams of `classify` park 21; 0 = free at once, as before)
 // are waiting, or when an allocation of a stream fails.
-void park_device(void *p, size_t bytes);
-void park_pinned(void *p, size_t bytes);
+// (site: 0 a .gz stream's upload staging, 1 hast_gz_close, 2 a buffer of a .gz stream that grows, 3 a FASTQ stream's slots;
+// HAST_PARK_SITES=<bit mask> parks at those sites only -- how the race that hast_table_clone's device-to-device copy had was found:
+// with the device no longer stopped by the frees, `classify --devices 0,0,0` lost hits until the copy was put on the clone's stream)
+void park_device(void *p, size_t bytes, int site = 0);
+void park_pinned(void *p, size_t bytes, int site = 0);
 void release_parked();
 }  // namespace hast

@@ -1254,3 +1254,32 @@ def test_kernels_with_geometry_and_row_length_compiled_in_vs_oracle(built, oracl
             ctx.classify_device(d_r, rag.size, n_reads, L, d_offsets=d_o, d_barcode_ids=d_i)
             for a, b in zip(ctx.counts_read(n_bc), exp_rag):
                 assert np.array_equal(a, b), (L, geo, "ragged")
+
+
+def test_table_clone_is_ordered_in_front_of_what_the_copy_is_asked_next(built):
+    """hast_table_clone between two contexts of ONE GPU is a device-to-device copy: it does not wait for the host, and the copy's
+    stream is a non-blocking one -- nothing used to order the first reads classified on the new context behind the arrival of its
+    table (round 5: `classify --devices 0,0,0` lost hits in one run of three once nothing else in the process stopped the device
+    at the right moment).  A table large enough for the copy to take milliseconds, reads that hit it, classified on the copy the
+    moment the clone returns: the same counters as on the original, every time."""
+    k, L, n_keys, n_reads, n_bc = 21, 150, 30_000_000, 200_000, 1000
+    p = make_params(k, L, n_keys, n_bc)
+    with hast_amd.Context(k) as a:
+        a.table_reserve(2 * n_keys)
+        a.synth_table_build(p)
+        a.counts_resize(n_bc)
+        d_b, d_i = a.alloc(n_reads * L), a.alloc(n_reads * 4)
+        a.synth_reads_device(p, 0, n_reads, d_b, d_i)
+        a.classify_device(d_b, n_reads * L, n_reads, L, d_barcode_ids=d_i)
+        a.sync()
+        want = a.counts_read(n_bc)
+        assert int(want[0].sum()) + int(want[1].sum()) > n_reads // 10
+        for _ in range(6):
+            with hast_amd.Context(k) as b:
+                b.counts_resize(n_bc)
+                b.table_clone_from(a)
+                b.classify_device(d_b, n_reads * L, n_reads, L, d_barcode_ids=d_i)
+                b.sync()
+                got = b.counts_read(n_bc)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w)
