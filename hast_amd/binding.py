@@ -33,7 +33,8 @@ class FqBlock(C.Structure):
 
 class GzStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("compressed_bytes", "out_bytes", "chunks", "accepted", "followup_jobs", "followup_rounds", "followup_accepted", "members")] + \
-               [(n, C.c_double) for n in ("decode_s", "windows_crc_s", "wait_upload_s", "wait_consumer_s", "wait_decode_s", "open_s")]
+               [(n, C.c_double) for n in ("decode_s", "windows_crc_s", "wait_upload_s", "wait_consumer_s", "wait_decode_s", "open_s")] + \
+               [(n, C.c_uint64) for n in ("ring_bytes", "upload_waited_for_ring")]
 
 
 KC_HISTO_HIGH = 10000

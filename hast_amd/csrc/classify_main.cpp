@@ -840,10 +840,11 @@ int main(int argc, char **argv) {
                         hast_gz_stats gs;
                         if (stats && hast_gz_get_stats(f.gz, &gs) == HAST_OK)
                             fprintf(stderr, "__stats_gz__ file=%s compressed_bytes=%llu inflated_bytes=%llu chunks=%llu accepted=%llu followup_jobs=%llu followup_rounds=%llu members=%llu "
-                                            "open_s=%.3f decode_s=%.3f windows_crc_s=%.3f producer_waited_for_upload_s=%.3f producer_waited_for_reader_s=%.3f reader_waited_for_decode_s=%.3f\n",
+                                            "open_s=%.3f decode_s=%.3f windows_crc_s=%.3f producer_waited_for_upload_s=%.3f producer_waited_for_reader_s=%.3f reader_waited_for_decode_s=%.3f ring_bytes=%llu upload_waited_for_ring=%llu\n",
                                     f.name.c_str(), (unsigned long long)gs.compressed_bytes, (unsigned long long)gs.out_bytes, (unsigned long long)gs.chunks,
                                     (unsigned long long)gs.accepted, (unsigned long long)gs.followup_jobs, (unsigned long long)gs.followup_rounds, (unsigned long long)gs.members,
-                                    gs.open_s, gs.decode_s, gs.windows_crc_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s);
+                                    gs.open_s, gs.decode_s, gs.windows_crc_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s, (unsigned long long)gs.ring_bytes,
+                                    (unsigned long long)gs.upload_waited_for_ring);
                         // its device memory (the compressed file, three symbol arenas, windows) goes back now, not at the end of the run: a
                         // dozen finished .gz files would otherwise crowd the table out of HBM.  On a thread of its own: freeing synchronises.
                         hast_gz *z = f.gz;

@@ -43,7 +43,7 @@ using namespace hast::gz;
 
 namespace {
 
-constexpr size_t kPiece = 16u << 20;         // upload granule
+constexpr size_t kPiece = 16u << 20;         // upload granule (HAST_GZ_PIECE_BYTES: tests)
 constexpr size_t kInPad = 256;               // zero bytes behind the file's last byte on the device
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -131,6 +131,14 @@ struct hast_gz {
     std::mutex mu;
     std::condition_variable cv;
     uint64_t uploaded = 0;                    // bytes of the file on EVERY unit
+    // THE RING.  A file larger than `ring` bytes (default: 2 GB, or what the passes in flight need) is not kept whole on the device:
+    // byte x of the file lies at x % ring, and the first `piece` bytes of every lap also behind the ring's end, so that what a job reads
+    // -- from its start to a block boundary at most one piece behind the lap's end -- is contiguous (ChunkJob.in_adj_words /
+    // limit_bits say where).  The uploader waits before it overwrites what may still be read: bytes behind `released` = the chain's
+    // end, and no further than the first chunk of the oldest pass in flight.  ring == 0: the whole file (every file of this
+    // repo's benchmarks; HAST_GZ_RING_BYTES forces a ring, tests)
+    size_t piece = kPiece;
+    uint64_t ring = 0, released = 0;
     std::string up_error;
     bool stop = false;
     std::deque<std::unique_ptr<Batch>> ready; // producer -> consumer
@@ -150,6 +158,14 @@ struct hast_gz {
     int n_arenas = 2;                         // symbol arenas a unit takes turns with (HAST_GZ_ARENAS: 2 or 3)
     Arena &arena_of(size_t k) { return unit_of(k).arena[(k / units.size()) % (size_t)n_arenas]; }
     int jobs_of(size_t k) const { return (int)((k / units.size()) & 1); }
+    void job_view(ChunkJob &j) const {         // where job j finds the file's words (ring: the lap its first bit lies in)
+        j.in_adj_words = 0;
+        j.limit_bits = 0;
+        if (!ring) return;
+        const uint64_t lap = (j.from_bit >> 3) / ring;
+        j.in_adj_words = lap * (ring / 4);
+        j.limit_bits = ((lap + 1) * ring + piece) * 8;
+    }
 };
 
 namespace {
@@ -219,7 +235,7 @@ void upload_loop(hast_gz *g) {
     std::vector<hipEvent_t> ev[2];
     std::string bad;
     for (int i = 0; i < 2 && bad.empty(); ++i) {
-        if (hipHostMalloc((void **)&h[i], kPiece, hipHostMallocPortable) != hipSuccess) bad = "gz: pinned staging allocation failed";
+        if (hipHostMalloc((void **)&h[i], g->piece + kInPad, hipHostMallocPortable) != hipSuccess) bad = "gz: pinned staging allocation failed";
         ev[i].assign(nu, nullptr);
         for (size_t u = 0; u < nu && bad.empty(); ++u)
             if (hipSetDevice(g->units[u]->device) != hipSuccess || hipEventCreateWithFlags(&ev[i][u], hipEventDisableTiming) != hipSuccess) bad = "gz: pinned staging allocation failed";
@@ -238,14 +254,30 @@ void upload_loop(hast_gz *g) {
         g->cv.notify_all();
     };
     size_t i = 0;
-    for (uint64_t off = 0; off < g->file_size && bad.empty(); off += kPiece, ++i) {
+    const size_t P = g->piece;
+    for (uint64_t off = 0; off < g->file_size && bad.empty(); off += P, ++i) {
+        const size_t n = (size_t)std::min<uint64_t>(P, g->file_size - off);
+        // (a ring: the bytes this piece overwrites must be behind everything that may still be read.  What is in flight is booked
+        // first: the producer may be waiting for exactly those bytes in order to move `released` on)
+        bool must_wait = false;
         {
             std::lock_guard<std::mutex> lk(g->mu);
+            must_wait = g->ring && !g->stop && !(off + n <= g->released + g->ring);
+        }
+        if (must_wait) {
+            land(0);
+            land(1);
+        }
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            if (must_wait) {
+                g->st.upload_waited_for_ring++;
+                g->cv.wait(lk, [&] { return g->stop || off + n <= g->released + g->ring; });
+            }
             if (g->stop) break;
         }
         const int b = (int)(i & 1);
         land(b);
-        const size_t n = (size_t)std::min<uint64_t>(kPiece, g->file_size - off);
         const size_t share = ((n / nthr) + 4095) & ~(size_t)4095;
         std::atomic<bool> short_read{false};
         pool.run([&](int t) {
@@ -254,11 +286,21 @@ void upload_loop(hast_gz *g) {
             if (to > from && (!read_at(g->fd, off + from, to - from, h[b] + from, &got) || got != to - from)) short_read = true;
         });
         if (short_read) { bad = "gz: read failed (the file is shorter than its size says, or an I/O error)"; break; }
+        // (a ring has no zeros behind the file's last byte waiting: they travel with the last piece)
+        const bool last_piece = off + n >= g->file_size;
+        size_t n_up = n;
+        if (g->ring && last_piece) {
+            memset(h[b] + n, 0, kInPad);
+            n_up = n + kInPad;
+        }
+        const uint64_t pos = g->ring ? off % g->ring : off;
         for (size_t u = 0; u < nu && bad.empty(); ++u) {
             Unit &U = *g->units[u];
-            if (hipSetDevice(U.device) != hipSuccess ||
-                hipMemcpyAsync(reinterpret_cast<uint8_t *>(U.d_in) + off, h[b], n, hipMemcpyHostToDevice, U.up_stream) != hipSuccess ||
-                hipEventRecord(ev[b][u], U.up_stream) != hipSuccess) bad = "gz: upload failed";
+            uint8_t *const d = reinterpret_cast<uint8_t *>(U.d_in);
+            if (hipSetDevice(U.device) != hipSuccess || hipMemcpyAsync(d + pos, h[b], n_up, hipMemcpyHostToDevice, U.up_stream) != hipSuccess) bad = "gz: upload failed";
+            // the first piece of a lap also behind the ring's end: the jobs of the lap in front read on into it
+            if (bad.empty() && g->ring && pos == 0 && off && hipMemcpyAsync(d + g->ring, h[b], n_up, hipMemcpyHostToDevice, U.up_stream) != hipSuccess) bad = "gz: upload failed";
+            if (bad.empty() && hipEventRecord(ev[b][u], U.up_stream) != hipSuccess) bad = "gz: upload failed";
         }
         if (!bad.empty()) break;
         end_of[b] = off + n;
@@ -268,7 +310,7 @@ void upload_loop(hast_gz *g) {
     land(0);
     land(1);
     for (int k = 0; k < 2; ++k) {
-        park_pinned(h[k], kPiece, 0);                               // (the other streams are in mid-file: hast_internal.h)
+        park_pinned(h[k], g->piece + kInPad, 0);                              // (the other streams are in mid-file: hast_internal.h)
         for (hipEvent_t e : ev[k])
             if (e) (void)hipEventDestroy(e);
     }
@@ -320,6 +362,13 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
             if (A.done_recorded && hipEventQuery(A.done) != hipSuccess) return "";
         }
         const double t0 = now_s();
+        // (a ring: a blocking launch means that no pass is in flight, i.e. nothing will move `released` on -- bytes the uploader may not
+        // write before it does move will never come: a block longer than the ring's margin lies between the chain's end and this segment)
+        if (g->ring && blocking && need_up + (uint64_t)g->piece > g->released + g->ring && need_up > g->uploaded)
+            return "gz: the ring of compressed bytes on the device is too small for this stream (a deflate block of more than " + std::to_string(g->piece >> 10) + " KB?): segment " +
+                   std::to_string(k) + " needs byte " + std::to_string(need_up) + ", the chain stands at " + std::to_string(g->chain.proven_end_bit() >> 3) + ", released " +
+                   std::to_string(g->released) + ", uploaded " + std::to_string(g->uploaded) + ", ring " + std::to_string(g->ring) + ", chunks " + std::to_string(g->st.chunks) + " accepted " + std::to_string(g->st.accepted) +
+                   " follow-up jobs " + std::to_string(g->st.followup_jobs) + " in " + std::to_string(g->st.followup_rounds) + " rounds";
         g->cv.wait(lk, [&] { return g->stop || !g->up_error.empty() || g->uploaded >= need_up; });
         g->st.wait_upload_s += now_s() - t0;
         if (g->stop) { stopped = true; return ""; }
@@ -359,6 +408,7 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
         j.search_to_lo = (uint32_t)(j.stop_bit - j.from_bit);
         j.sym_cap = g->slot_syms;
         j.sym_off = sym_base + (uint64_t)(c - c0) * g->slot_syms;
+        g->job_view(j);
         ++n_jobs;
     }
     N.n_jobs = n_jobs;
@@ -381,6 +431,14 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
     const uint64_t input_bits = N.input_bits;
     const bool all_in = N.all_in;
     g->st.chunks += N.n_jobs;
+    if (getenv("HAST_GZ_TRACE_JOBS"))
+        for (size_t i = 0; i < N.n_jobs; ++i) {
+            const ChunkJob &j = U.h_jobs[g->jobs_of(N.k)][i];
+            if (!(j.status & kStFound) && N.k >= 1) continue;
+            fprintf(stderr, "gz job k=%zu i=%zu from=%llu stop=%llu flags=%u status=%u start=%llu end=%llu n_out=%u err=%u adj=%llu limit=%llu input_bits=%llu\n", N.k, i, (unsigned long long)j.from_bit,
+                    (unsigned long long)j.stop_bit, j.flags, j.status, (unsigned long long)j.start_bit, (unsigned long long)j.end_bit, j.n_out, j.err_code, (unsigned long long)j.in_adj_words,
+                    (unsigned long long)j.limit_bits, (unsigned long long)input_bits);
+        }
     g->chain.add_candidates(U.h_jobs[g->jobs_of(N.k)], N.n_jobs, all_in);
     // ---- the chain, with its follow-up jobs ------------------------------------------------------------------------------------
     std::vector<Chain::Gap> gaps;
@@ -403,6 +461,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
             j.sym_off = gbase + at[i];
             j.start_bit = j.from_bit;
             j.status = kStFound;
+            g->job_view(j);
         }
         GZ_HIP(hipMemcpyAsync(U.fjobs.p, U.h_fjobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, U.post_stream));
         GZ_HIP(launch_decode((ChunkJob *)U.fjobs.p, (uint32_t)gaps.size(), U.d_in, input_bits, (uint16_t *)gb.p, U.post_stream));
@@ -525,6 +584,17 @@ void produce_loop(hast_gz *g) {
         if (!bad.empty() || stopped) break;
         bad = finish_segment(g, cur, finished);
         fl.pop_front();
+        if (g->ring) {
+            // what no job will read again: everything in front of the chain's end -- and of the first chunk of the oldest pass in flight
+            const size_t S0 = std::min<size_t>(g->seg_chunks, 1024);
+            const uint64_t next_c0 = S0 + (uint64_t)cur.k * g->seg_chunks;          // (first chunk of segment cur.k + 1)
+            const uint64_t rel = std::min<uint64_t>(g->chain.proven_end_bit() >> 3, next_c0 * g->chunk_bytes);
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (rel > g->released) {
+                g->released = rel;
+                g->cv.notify_all();
+            }
+        }
     }
     // (a pass that is still running when the loop is left early reads buffers hast_gz_close frees only after the streams have drained)
     if (stopped) return;
@@ -598,6 +668,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     if (g->chunk_bytes > (1u << 26)) { close(fd); return set_error(HAST_ERR_INVALID, "chunk_bytes too large"); }
     g->slot_syms = (uint32_t)std::min<double>((double)(1u << 27), (double)g->chunk_bytes * g->room + 600);
     g->slot_syms = (g->slot_syms + 7) & ~7u;
+    if (const char *e = getenv("HAST_GZ_PIECE_BYTES")) g->piece = (size_t)std::min<long>((long)kPiece, std::max(4096L, atol(e) & ~4095L));
     const int cfd = fd;
     g->chain.begin(g->file_size, [cfd](uint64_t off, size_t n, uint8_t *dst, size_t *got) { return read_at(cfd, off, n, dst, got); });
     if (g->chain.failed()) {
@@ -613,6 +684,20 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     const size_t n_seg = n_chunks <= s0 ? 1 : 1 + (n_chunks - s0 + seg - 1) / seg;
     if (g->units.size() > n_seg) g->units.resize(std::max<size_t>(1, n_seg));       // (a unit without a segment would hold memory for nothing)
     const size_t nu = g->units.size();
+    {
+        // the ring (hast_gz): at least what the passes in flight span -- the segment being walked, one per unit in front of it, the
+        // margin a pass waits for behind its last chunk -- plus how far the chain's end may lie in front of the segment being walked
+        // (a deflate block: at most a piece, or the stream is refused), the piece in flight, the piece being filled and one of slack;
+        // by default 2 GB, so that only files beyond that (HAST's real inputs: 50-100 GB) go round
+        const uint64_t pass = (uint64_t)seg * g->chunk_bytes;
+        const uint64_t need = (uint64_t)(nu + 2) * pass + std::min<uint64_t>(pass, 16u << 20) + 4 * (uint64_t)g->piece;
+        uint64_t ring = 2ull << 30;
+        if (const char *e = getenv("HAST_GZ_RING_BYTES")) ring = (uint64_t)std::max(0L, atol(e));
+        ring = std::max(ring, need);
+        ring = (ring + g->piece - 1) / g->piece * g->piece;
+        if (g->file_size + kInPad > ring + g->piece) g->ring = ring;
+        g->chain.set_eager(g->ring != 0);
+    }
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     const bool trace = getenv("HAST_GZ_TRACE") != nullptr;
@@ -629,13 +714,13 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         Unit &U = *g->units[ui];
         step(hipSetDevice(U.device));
         // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
-        const uint64_t alloc = ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
+        const uint64_t alloc = g->ring ? g->ring + g->piece + 2 * kInPad : ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
         step(hipMalloc((void **)&U.d_in, alloc));
         tr("input buffer");
         step(hipStreamCreateWithFlags(&U.up_stream, hipStreamNonBlocking));
         // (on the stream the file's pieces will come in on: a hipMemset of device memory does not wait for the host, and nothing orders
         // the legacy stream it runs on against a non-blocking one -- the zeros could land on the file's last bytes after the upload)
-        if (e == hipSuccess) step(hipMemsetAsync(reinterpret_cast<uint8_t *>(U.d_in) + tail_from, 0, alloc - tail_from, U.up_stream));
+        if (e == hipSuccess && !g->ring) step(hipMemsetAsync(reinterpret_cast<uint8_t *>(U.d_in) + tail_from, 0, alloc - tail_from, U.up_stream));
         {
             // The nominal passes keep some CUs FREE (HAST_GZ_FREE_CUS, default 32 of 256): a decode wave lives for milliseconds and the passes
             // fill every LDS slot of the GPU, so whatever else wants to run -- this file's follow-up jobs, windows and CRC-32, the translate
@@ -698,6 +783,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     }
     hast_gz *raw = g.release();
     raw->st.open_s = now_s() - t_open0;
+    raw->st.ring_bytes = raw->ring;
     raw->uploader = std::thread(upload_loop, raw);
     raw->producer = std::thread(produce_loop, raw);
     *out = raw;
@@ -749,7 +835,7 @@ void hast_gz_close(hast_gz *g) {
         U.fjobs.release();
         U.bounce.release();
         park_pinned(U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), 1);
-        park_device(U.d_in, (size_t)g->file_size + kInPad, 1);
+        park_device(U.d_in, g->ring ? (size_t)(g->ring + g->piece) : (size_t)g->file_size + kInPad, 1);
         park_pinned(U.h_crc, 0, 1);
         if (U.xl_done) (void)hipEventDestroy(U.xl_done);
         if (U.up_stream) (void)hipStreamDestroy(U.up_stream);

@@ -48,6 +48,7 @@ class Chain {
         out_confirmed_ = 0;
         waiting_gaps_ = false;
         all_in_ = false;
+        searched_to_ = 0;
         (void)parse_member_header();                 // the first member's header: first_deflate_bit() is where chunk 0 starts
     }
     // after begin(): the first bit of the first member's deflate data (the owner decodes its first chunk from there, as a
@@ -60,8 +61,13 @@ class Chain {
             st_.ci = 0;
         }
         cands_.insert(cands_.end(), j, j + n);
+        for (size_t i = 0; i < n; ++i) searched_to_ = std::max(searched_to_, j[i].stop_bit);
         all_in_ = all_in;
     }
+    // eager: where the search has found no block start between the chain's end and the end of what it has looked at (stored blocks,
+    // fixed-Huffman blocks: a member of incompressible bytes), a follow-up job decodes on through that stretch at once instead of
+    // waiting for a candidate behind it.  For an owner that cannot keep the input until one comes (gz_api.cpp: the ring)
+    void set_eager(bool on) { eager_ = on; }
     // Walks on.  Follow-up jobs to run now are appended to `gaps` (from_bit, stop_bit, flags set; `want_syms` says how much
     // room to give; the owner fills sym_off / sym_cap and runs them, then calls gap_done with the results in the same order).
     // input_bits: compressed bits present on the device.  false = nothing to run (finished, waiting for candidates, or failed).
@@ -76,7 +82,12 @@ class Chain {
                 if (st_.eos) break;
             }
             // the next candidate at or behind the chain's end
-            while (st_.ci < cands_.size() && (!(cands_[st_.ci].status & kStFound) || (cands_[st_.ci].status & kStNoBlock) || cands_[st_.ci].start_bit < st_.end)) st_.ci++;
+            // (a candidate whose first block did not fit its room holds no data, but where it starts is as good a target for a follow-up
+            // job as any: waiting for the next one that DID fit is waiting for the end of the input when every block of a stream is
+            // that large -- and a ring on the device never sees the end of the input before the chain has moved on)
+            while (st_.ci < cands_.size() && (!(cands_[st_.ci].status & kStFound) || cands_[st_.ci].start_bit < st_.end ||
+                                              ((cands_[st_.ci].status & kStNoBlock) && cands_[st_.ci].start_bit == st_.end)))
+                st_.ci++;
             const bool have = st_.ci < cands_.size();
             if (have && cands_[st_.ci].start_bit == st_.end) {
                 // (a member's first chunk decoded with markers allowed holds none if the stream is valid; if it is not, the
@@ -91,7 +102,11 @@ class Chain {
                 items_.push_back(it);
                 continue;
             }
-            if (!have && !all_in_) break;                          // more candidates to come
+            uint64_t open_stop = ~0ull;                            // (no candidate: the follow-up job runs to the end of the input ...)
+            if (!have && !all_in_) {
+                if (!eager_ || searched_to_ <= st_.end) break;     // more candidates to come
+                open_stop = searched_to_;                          // (... or, eager, through what has been searched)
+            }
             // a hole: from the chain's end to the next candidate (or to the end of the input)
             if (st_.retry_bits && input_bits <= st_.retry_bits) break;   // starved before: wait for more input
             Item it;
@@ -100,12 +115,12 @@ class Chain {
             ChunkJob &g = it.acc.job;
             memset(&g, 0, sizeof(g));
             g.from_bit = g.start_bit = st_.end;
-            g.stop_bit = have ? cands_[st_.ci].start_bit : ~0ull;
+            g.stop_bit = have ? cands_[st_.ci].start_bit : open_stop;
             g.flags = kJobKnown | (st_.no_history_next ? kJobNoHistory : 0u);
             it.acc.no_history = st_.no_history_next;
             it.acc.is_gap = true;
-            it.target = g.stop_bit;
-            const uint64_t span_bytes = ((have ? g.stop_bit : std::min<uint64_t>(input_bits, st_.end + (8ull << 23))) - st_.end) / 8 + 64;
+            it.target = have ? g.stop_bit : ~0ull;                 // (no candidate, no landing: where it ends is where the walk goes on)
+            const uint64_t span_bytes = ((g.stop_bit != ~0ull ? g.stop_bit : std::min<uint64_t>(input_bits, st_.end + (8ull << 23))) - st_.end) / 8 + 64;
             uint64_t want = std::max<uint64_t>(span_bytes * 16, 1u << 16);
             if (st_.grow) want = std::max<uint64_t>(want, st_.grow);
             gaps.push_back(Gap{g, want});
@@ -285,7 +300,8 @@ class Chain {
     uint64_t file_size_ = 0;
     ReadFn read_;
     std::vector<ChunkJob> cands_;
-    bool all_in_ = false;
+    bool all_in_ = false, eager_ = false;
+    uint64_t searched_to_ = 0;       // the nominal passes have looked for block starts up to this bit
     std::vector<Item> items_;
     size_t handed_ = 0, confirmed_ = 0;
     uint64_t out_confirmed_ = 0;

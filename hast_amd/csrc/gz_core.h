@@ -57,7 +57,7 @@ enum : uint32_t {
     kErrIncomplete, kErrTableSize, kErrLitCode, kErrDistCode, kErrTooFar
 };
 
-struct ChunkJob {               // 64 bytes; one per chunk, device memory
+struct ChunkJob {               // 80 bytes; one per chunk, device memory
     uint64_t from_bit;          // in: known start (flags & 1) or where the search starts
     uint64_t stop_bit;          // in: decode until the first block boundary >= this
     uint64_t sym_off;           // in: first symbol of this chunk's buffer in the arena (u16 units)
@@ -69,7 +69,12 @@ struct ChunkJob {               // 64 bytes; one per chunk, device memory
     uint32_t status;            // out
     uint32_t err_code;          // out
     uint32_t search_to_lo;      // in: the search gives up at from_bit + this many bits
+    // in: where the compressed bytes lie when the device holds a RING of them, not the whole file (gz_api.cpp "ring"): word i of the
+    // file is w[i - in_adj_words] for this job, and bits at and behind limit_bits (0: no such limit) are not there for it
+    uint64_t in_adj_words;
+    uint64_t limit_bits;
 };
+static_assert(sizeof(ChunkJob) == 80, "ChunkJob is copied to and from the device as it is");
 constexpr uint32_t kJobKnown = 1, kJobNoHistory = 2;
 
 // ---- bit input: aligned 32-bit words, LSB first; the buffer holds >= 2 zero words behind its last real bit -------------------

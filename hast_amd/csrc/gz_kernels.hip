@@ -27,7 +27,7 @@ namespace gz {
 // HLIT, HDIST in range: one position in 9 passes); (2) the survivors are queued (LDS, in position order) and, 64 at a time, tested
 // for a COMPLETE code-length code (one in ~100 passes); (3) what is left is queued again and parsed in full 64 at a time, a lane
 // per candidate; the lowest position that parses is the chunk's start.
-__global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w, uint64_t nbits) {
+__global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *w_file, uint64_t nbits_up) {
     __shared__ uint32_t s_q[1024];                                            // positions (relative to from_bit) that passed sieve 1
     __shared__ uint32_t s_q3[128];                                            // ... that passed sieve 2 (position order)
     // the strict parse's code-length table, one per lane: 128 bytes (gz_core.h header_parses8 -- with header_parses' 512 bytes of
@@ -44,6 +44,9 @@ __global__ void __launch_bounds__(64) k_gz_search(ChunkJob *jobs, uint32_t n_job
         }
         return;
     }
+    // (a ring of the file on the device: this job's view of it, ChunkJob)
+    const uint32_t *const w = w_file - (ptrdiff_t)job.in_adj_words;
+    const uint64_t nbits = job.limit_bits && job.limit_bits < nbits_up ? job.limit_bits : nbits_up;
     const uint64_t from = job.from_bit;
     const uint64_t lim = nbits > 192 ? nbits - 192 : 0;                       // (bits_at reads 12 bytes, the strict parse more: the buffer is padded)
     uint64_t to = from + job.search_to_lo;
@@ -207,7 +210,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {              //
 // syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
 // which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
 // symbol instead of ~300)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w, uint64_t nbits, uint16_t *__restrict__ syms) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w_file, uint64_t nbits_up, uint16_t *__restrict__ syms) {
     __shared__ uint32_t s_tab[kLitTabCap + kDistTabCap];
     // two lives: while lane 0 parses a block's header, the code-length code's table (kPreTabCap words) and what the parse indexes by
     // values it has just read (HdrScratch: no scratch memory); in the symbol loop, the compressed words around the read position
@@ -230,6 +233,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
         }
         return;
     }
+    const uint32_t *__restrict__ const w = w_file - (ptrdiff_t)job.in_adj_words;           // (a ring of the file on the device: this job's view, ChunkJob)
+    const uint64_t nbits = job.limit_bits && job.limit_bits < nbits_up ? job.limit_bits : nbits_up;
     uint16_t *const sym = syms + (ptrdiff_t)((long long)job.sym_off - (long long)(reinterpret_cast<uintptr_t>(syms) >> 1));
     const uint32_t cap = job.sym_cap;
     const bool no_history = (job.flags & kJobNoHistory) != 0;

@@ -368,7 +368,10 @@ typedef struct {
     double wait_upload_s;      /* the producer waited for compressed bytes to reach the device */
     double wait_consumer_s;    /* ... for the reader to be through with a symbol arena */
     double wait_decode_s;      /* the reader waited for decoded bytes */
-    double open_s;             /* hast_gz_open itself: device buffers (three symbol arenas of 4096 chunks each), streams, threads */
+    double open_s;             /* hast_gz_open itself: device buffers (the first symbol arena), streams, threads */
+    uint64_t ring_bytes;       /* 0: the whole compressed file lies on the device; else the size of the ring it goes round in
+                                * (files beyond 2 GB; HAST_GZ_RING_BYTES / HAST_GZ_PIECE_BYTES set the geometry in tests) */
+    uint64_t upload_waited_for_ring;   /* pieces whose upload had to wait for the chain to move on */
 } hast_gz_stats;
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
 /* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 4096), symbols of room per compressed byte (0 = 12) */

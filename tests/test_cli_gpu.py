@@ -271,6 +271,54 @@ def test_cli_gz_damaged_behind_the_first_pass_is_an_error(exe, golden_workdir, t
                 assert r.returncode == 2 and r.stdout == b"", (frac, len(damaged), blocks, r.returncode, r.stderr[-300:])
 
 
+def test_cli_gz_file_larger_than_its_ring_on_the_device(exe, tmp_path):
+    """A .gz file beyond 2 GB is not kept whole on the device: its bytes go round a ring whose first piece is mirrored behind its
+    end (gz_api.cpp "THE RING"), every job is told in which lap its words lie, and the uploader waits for the chain before it
+    overwrites anything.  Here with chunks of 16 KB, passes of 2 chunks, pieces of 64 KB (a deflate block of zlib's is at most about
+    that long, and a job may read one piece past its lap) and a ring of 384-448 KB, so that two files of ~1.2 MB go round it three
+    times: stdout == the same program with the whole files on the device (whose parity with the reference the golden tests pin),
+    alone, with small blocks, with --devices 0,0 (striped blocks), with a decode unit per context (every piece goes to both rings),
+    with whole files dealt to contexts; the ring was in use and the uploader did wait for it; damage in a later lap is an error."""
+    import gzip
+    rng = np.random.default_rng(2026)
+    k = 21
+    keys = ["".join(rng.choice(list("ACGT"), k)) for _ in range(600)]
+    (tmp_path / "hap0.mer").write_text("\n".join(keys[:300]) + "\n")
+    (tmp_path / "hap1.mer").write_text("\n".join(keys[300:]) + "\n")
+    for name in ("r1", "r2"):
+        recs = []
+        for i in range(18000):
+            seq = "".join(rng.choice(list("ACGT"), 100))
+            if i % 3 == 0:
+                at = int(rng.integers(0, 100 - k))
+                seq = seq[:at] + keys[int(rng.integers(0, 600))] + seq[at + k:]
+            qual = "".join(rng.choice(list("FFFFF:,#"), 100))
+            recs.append("@r%d#%d_%d_%d/1\n%s\n+\n%s\n" % (i, rng.integers(1, 40), rng.integers(1, 40), rng.integers(1, 40), seq, qual))
+        with gzip.open(tmp_path / (name + ".fq.gz"), "wb", compresslevel=6) as f:
+            f.write("".join(recs).encode())
+    assert min((tmp_path / n).stat().st_size for n in ("r1.fq.gz", "r2.fq.gz")) > 900_000
+    args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "r1.fq.gz", "--read", "r2.fq.gz"]
+    ring = dict(os.environ, HAST_GZ_CHUNK_BYTES="16384", HAST_GZ_PASS_CHUNKS="2", HAST_GZ_PIECE_BYTES="65536", HAST_GZ_RING_BYTES="131072")
+    a = subprocess.run([exe] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and len(a.stdout) > 1000, a.stderr[-300:]
+    for extra, env in (([], ring), (["--batch-reads", "500"], ring), (["--devices", "0,0"], ring),
+                       (["--devices", "0,0"], dict(ring, HAST_GZ_SPLIT="contexts")), (["--devices", "0,0,0"], dict(ring, HAST_DEAL="files"))):
+        b = subprocess.run([exe] + args + extra + ["--stats"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+        assert b.returncode == 0 and b.stdout == a.stdout, (extra, b.returncode, b.stderr[-400:])
+        st = [l for l in b.stderr.splitlines() if l.startswith(b"__stats_gz__")]
+        rings = [int(l.split(b"ring_bytes=")[1].split()[0]) for l in st]
+        waits = [int(l.split(b"upload_waited_for_ring=")[1].split()[0]) for l in st]
+        assert len(st) == 2 and all(131072 <= r <= 524288 for r in rings) and all(w > 0 for w in waits), (extra, rings, waits)
+    whole = (tmp_path / "r2.fq.gz").read_bytes()
+    for frac in (0.5, 0.9):
+        flipped = bytearray(whole)
+        flipped[int(len(whole) * frac)] ^= 0x10
+        for damaged in (whole[:int(len(whole) * frac)], bytes(flipped)):
+            (tmp_path / "r2.fq.gz").write_bytes(damaged)
+            r = subprocess.run([exe] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=ring, timeout=300)
+            assert r.returncode == 2 and r.stdout == b"", (frac, len(damaged), r.returncode, r.stderr[-300:])
+
+
 def test_cli_output_errors_are_not_exit_0(exe, golden_workdir):
     """stdout on a full device (the wrapper redirects it into phased.barcodes and tests only the exit status,
     classify_stlfr_reads.sh:149): exit 2 and a message, not a truncated table behind exit 0 -- `classify` and `classify_read`"""

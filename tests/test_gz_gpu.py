@@ -100,6 +100,36 @@ def test_big_stream_long_runs_and_many_members(ctx, tmp_path):
             assert z.stats()["members"] == 2000
 
 
+def test_a_file_larger_than_its_ring_on_the_device(ctx, tmp_path, monkeypatch):
+    """the compressed bytes go round a ring on the device (gz_api.cpp "THE RING"; by default for files beyond 2 GB): pieces of 64 KB,
+    a ring of 192-320 KB, files of 1-3 MB -- a FASTQ at levels 1, 6 and 9, members back to back, stored blocks (random bytes) in
+    between; chunks of 1 to 32 KB, passes of 2 to 16 chunks, reads of 977 bytes to 4 MB: the same bytes as zlib, the ring in
+    use, the uploader made to wait for the chain"""
+    rng = random.Random(77)
+    monkeypatch.setenv("HAST_GZ_PIECE_BYTES", "65536")
+    monkeypatch.setenv("HAST_GZ_RING_BYTES", "131072")
+    fq = fastq(rng, 30_000)
+    noise = bytes(rng.getrandbits(8) for _ in range(300_000))
+    blobs = {
+        "l6": (fq, member(fq, 6)),
+        "l1": (fq, member(fq, 1)),
+        "l9_members": (fq[:1_000_000] + fq[1_000_000:], member(fq[:1_000_000], 9) + member(fq[1_000_000:], 9)),
+        "stored_between": (fq[:700_000] + noise + fq[700_000:], member(fq[:700_000], 6) + member(noise, 6) + member(fq[700_000:], 4)),
+    }
+    for name, (data, blob) in blobs.items():
+        assert len(blob) > 900_000, (name, len(blob))
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        # (the last geometries: a block of these streams is 100-250 k symbols of output and does NOT fit a chunk's slot -- every block is
+        # decoded by a follow-up job with more room, whose target is the next candidate's start although that candidate holds no data)
+        for chunk, seg, room, piece in ((4096, 4, 50, 1 << 22), (1024, 16, 200, 977), (32768, 2, 0, 65537), (0, 3, 0, 1 << 20), (16384, 5, 12, 4099), (4096, 4, 0, 1 << 22)):
+            with hast_amd.GzReader(ctx, str(p), chunk, seg, room) as z:
+                got = z.read_all(piece)
+                st = z.stats()
+            assert got == data, (name, chunk, seg, len(got), len(data))
+            assert st["ring_bytes"] >= 131072 and st["upload_waited_for_ring"] > 0, (name, chunk, seg, st)
+
+
 def test_random_streams_with_flush_points(ctx, tmp_path):
     rng = random.Random(11)
     for it in range(12):
