@@ -431,7 +431,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
     const uint64_t input_bits = N.input_bits;
     const bool all_in = N.all_in;
     g->st.chunks += N.n_jobs;
-    if (getenv("HAST_GZ_TRACE_JOBS"))
+    if (getenv("HAST_GZ_TRACE_JOBS"))                               // (debugging: every pass's first jobs and all its candidates, as they came back)
         for (size_t i = 0; i < N.n_jobs; ++i) {
             const ChunkJob &j = U.h_jobs[g->jobs_of(N.k)][i];
             if (!(j.status & kStFound) && N.k >= 1) continue;

@@ -358,6 +358,7 @@ hast_status hast_fq_commit(hast_fq *);
  * with the call behind a short one.  A caller must therefore read on until a call returns 0 bytes (or an error) before it takes the
  * stream for complete.  Blocks until the bytes it returns are decoded.  HAST_GZ_CHUNK_BYTES / HAST_GZ_PASS_CHUNKS in the environment
  * set the geometry of hast_gz_open (tests: many passes over a small file).
+ * A file of more than 2 GB is not kept whole on the device: its compressed bytes go round a ring there (hast_gz_stats.ring_bytes).
  * One reader per object; several of them -- one per input file -- run side by side. */
 typedef struct hast_gz hast_gz;
 typedef struct {
