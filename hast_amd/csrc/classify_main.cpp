@@ -845,7 +845,7 @@ int main(int argc, char **argv) {
                                     (unsigned long long)gs.accepted, (unsigned long long)gs.followup_jobs, (unsigned long long)gs.followup_rounds, (unsigned long long)gs.members,
                                     gs.open_s, gs.decode_s, gs.windows_crc_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s, (unsigned long long)gs.ring_bytes,
                                     (unsigned long long)gs.upload_waited_for_ring);
-                        // its device memory (the compressed file, three symbol arenas, windows) goes back now, not at the end of the run: a
+                        // its device memory (the compressed file, the symbol arenas, windows) goes back now, not at the end of the run: a
                         // dozen finished .gz files would otherwise crowd the table out of HBM.  On a thread of its own: freeing synchronises.
                         hast_gz *z = f.gz;
                         gz_closers.emplace_back([z] { hast_gz_close(z); });

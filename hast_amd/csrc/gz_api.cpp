@@ -93,8 +93,8 @@ struct Arena {
 
 // What ONE GPU holds of a stream.  The nominal pass of a unit's segment j + 1 (search + decode of its chunks: where the time goes) is
 // launched BEFORE its segment j's results are walked, so that the GPU decodes while the host chains, the single-wave follow-up jobs
-// run and the consumer translates: job arrays in two copies (j & 1), follow-up jobs in a third, three symbol arenas (j % 3: one being
-// translated, one being chained, one being decoded), the work behind a nominal pass on a stream of its own, the reader's translate
+// run and the consumer translates: job arrays in two copies (j & 1), follow-up jobs in a third, two symbol arenas taking turns (three until
+// round 5: no faster, hast_gz::n_arenas), the work behind a nominal pass on a stream of its own, the reader's translate
 // kernels (and the copies towards another GPU) on yet another.
 struct Unit {
     int device = 0;
@@ -658,7 +658,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         if (const char *e = getenv("HAST_GZ_PASS_CHUNKS")) seg_chunks = (size_t)std::max(0L, atol(e));
     g->chunk_bytes = chunk_bytes ? std::max<size_t>(chunk_bytes, 64) : 32768;
     g->chunk_bytes = (g->chunk_bytes + 3) & ~(size_t)3;
-    // 4096 chunks a pass x 786 KB of symbol room = 3.2 GB an arena, three arenas (measured against the tree before the pipelined
+    // 4096 chunks a pass x 786 KB of symbol room = 3.2 GB an arena (measured against the tree before the pipelined
     // producer, alternating on one box: passes of 2048 chunks were slower than that tree, 4096 10 % faster, 8192 no faster).  Keep the
     // footprint small: on some boxes of the pool ONE HIP call of a process that starts right after another one freed tens of GB blocks
     // for 0.7-6 s (hipMalloc or hipStreamCreate, whichever comes first -- tools/probe/malloc_probe.py; the tree before did the same there).

@@ -1,7 +1,7 @@
 """The device inflate (include/hast.h hast_gz_*, hast_amd/csrc/gz_kernels.hip) against zlib's bytes, through the C ABI: the
 whole corpus of the host decoders' test (every block type, member layout, header field, flush point, level, window size),
 with chunks of 64 bytes to 1 MB (chunks in which no block starts, blocks larger than a chunk, stored / fixed blocks at chunk
-borders, members that end inside a chunk), passes of a few chunks (three symbol arenas taking turns, the next pass launched before the current one is walked), too little room per chunk
+borders, members that end inside a chunk), passes of a few chunks (the symbol arenas taking turns, the next pass launched before the current one is walked), too little room per chunk
 (follow-up jobs), reads of 1 byte to 4 MB; truncated and bit-flipped files are errors -- CRC-32 and ISIZE of every member are
 checked on the way -- never other data."""
 import gzip
