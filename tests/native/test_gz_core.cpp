@@ -265,6 +265,12 @@ static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std
     else decode_chunk(j, g_words.data(), nbits, tabs.data(), sym.data());
 }
 
+// -e BYTES: the walk as gz_api.cpp drives it for a file that goes round a RING on the device: the chain is eager (set_eager), and what a
+// ring needs of it is checked after every segment -- the chain's end lies at most BYTES in front of the segment's end unless it waits
+// for input that is not there (a ring can keep a few passes and a piece of the file, not more); "the end of the input" is never
+// announced before the last segment, as the ring's uploader never gets there before the chain has moved on
+static uint64_t g_ring_lag = 0;
+
 int main(int argc, char **argv) {
     size_t chunk = 32768, seg = 64;
     double room = 12;
@@ -276,6 +282,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-r")) room = atof(argv[++i]);
         else if (!strcmp(argv[i], "-w")) g_wave = true;
         else if (!strcmp(argv[i], "-f")) fuzz = atol(argv[++i]);
+        else if (!strcmp(argv[i], "-e")) g_ring_lag = (uint64_t)atol(argv[++i]);     // a ring on the device: see below
         else path = argv[i];
     }
     if (fuzz) {
@@ -411,6 +418,7 @@ int main(int argc, char **argv) {
     };
     const uint64_t first = chain.first_deflate_bit();
     const size_t n_chunks = first == ~0ull ? 0 : (size_t)((g_size + chunk - 1) / chunk);
+    chain.set_eager(g_ring_lag != 0);
     std::vector<Chain::Gap> gaps;
     for (size_t c0 = 0; c0 < n_chunks || c0 == 0; c0 += seg) {
         const size_t c1 = std::min(n_chunks, c0 + seg);
@@ -452,6 +460,14 @@ int main(int argc, char **argv) {
         if (!consume()) return 3;
         if (chain.failed()) break;
         if (all_in) break;
+        if (g_ring_lag) {
+            const uint64_t end_byte = chain.proven_end_bit() >> 3, seg_end = (uint64_t)c1 * chunk;
+            if (end_byte + g_ring_lag < seg_end) {
+                fprintf(stderr, "ring: the chain stands at byte %llu, %llu behind the end of the segment (allowed: %llu)\n", (unsigned long long)end_byte,
+                        (unsigned long long)(seg_end - end_byte), (unsigned long long)g_ring_lag);
+                return 4;
+            }
+        }
     }
     if (chain.failed()) {
         if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);

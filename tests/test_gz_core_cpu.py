@@ -65,6 +65,24 @@ def test_same_bytes_as_zlib(driver, tmp_path, name):
         assert got.stdout == want, (name, chunk, seg, room)
 
 
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n not in ("not_gzip",)))
+def test_the_chain_keeps_up_with_a_ring(driver, tmp_path, name):
+    """What a file that goes round a ring on the device (gz_api.cpp "THE RING") needs of the chain: its end never falls further behind
+    the segment being walked than a deflate block is long -- with slots that hold a block and with slots too small for ANY block of
+    the stream (every block decoded by a follow-up job whose target is a candidate that holds no data), through members of stored
+    blocks in which no search finds a start (the eager walk decodes on through them) -- while the end of the input is not in sight.
+    The driver (-e) checks the distance after every segment; the bytes are zlib's."""
+    p = tmp_path / (name + ".gz")
+    p.write_bytes(CASES[name])
+    want = inflate_all(CASES[name])
+    for chunk, seg, room in ((4096, 3, 12), (4096, 4, 0.5), (1024, 16, 200), (32768, 2, 12), (700, 50, 1.0)):
+        if chunk < 1000 and len(CASES[name]) > 200_000:
+            continue
+        got = subprocess.run([driver, "-e", str(262144 + chunk * seg), "-c", str(chunk), "-s", str(seg), "-r", str(room), str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, (name, chunk, seg, room, got.stderr[-300:])
+        assert got.stdout == want, (name, chunk, seg, room)
+
+
 def test_search_kernels_strict_parse_equals_the_full_one(driver_exe):
     """header_parses8 (what a lane of k_gz_search runs: counts in packed words, a 128-byte table) == header_parses (gz_core.h's
     read_dynamic with zlib's completeness rules) on 400 000 random bit strings, half of them behind a valid code-length code"""
