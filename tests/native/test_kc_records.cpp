@@ -9,6 +9,9 @@
 //   * k_kc_emit4's lanes (K = 17 .. 21: four positions, then four windows per lane, steps of 256 windows) restated with plain loops over
 //     the shared per-lane arithmetic (kc_common.h kc_e4_*): the hashes of phase M equal kc_mmer_hash of the canonical 16-mers, and the
 //     descriptors of phase B are exactly the runs of the definition above, cut at the steps' borders.
+//   * k_kc_part's tile (8192 records: counts per bin, a scan, the records grouped by bin with the bin's low byte beside them, then a lane
+//     per record in bin order that finds its bin from that byte and the first slots of bins 256 / 512 / 768) restated with plain loops:
+//     every record arrives in its bin's region, the regions hold exactly the tile's records, in the order the kernel's ranks give.
 // TEST INFRASTRUCTURE: no product code is called besides the shared integer header.
 #include <cstdint>
 #include <cstdio>
@@ -89,6 +92,48 @@ static int emit4_model(const std::string &s, int k, const std::vector<char> &val
     }
     *n_desc += desc.size();
     return 0;
+}
+
+// k_kc_part's steps on one tile: bins[i] = the bin of record i (or -1: a null record).  Returns false and prints on a mismatch.
+static bool part_tile_model(const std::vector<int> &bins, uint32_t n_bins, std::mt19937_64 &rng) {
+    const uint32_t n = (uint32_t)bins.size();
+    std::vector<uint32_t> cnt(1024, 0), rank(n, 0), off(1024, 0);
+    // (1) counts; the LDS add hands every record its rank in its bin -- in whatever order the lanes get there: a random one here
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    for (uint32_t i = n; i > 1; --i) std::swap(order[i - 1], order[rng() % i]);
+    for (uint32_t i : order)
+        if (bins[i] >= 0) rank[i] = cnt[(size_t)bins[i]]++;
+    // (2) exclusive scan, one bin per "thread"; the first slots of bins 256, 512, 768
+    uint32_t run = 0, first[3] = {0, 0, 0};
+    for (uint32_t b = 0; b < 1024; ++b) {
+        if (b && (b & 255) == 0) first[(b >> 8) - 1] = run;
+        off[b] = run;
+        run += cnt[b];
+    }
+    const uint32_t n_valid = run;
+    // (3) scatter: record and the low byte of its bin
+    std::vector<uint64_t> rec(n_valid, ~0ull);
+    std::vector<uint8_t> bin8(n_valid, 0);
+    for (uint32_t i = 0; i < n; ++i)
+        if (bins[i] >= 0) {
+            const uint32_t at = off[(size_t)bins[i]] + rank[i];
+            if (at >= n_valid || rec[at] != ~0ull) { printf("k_kc_part model: two records in one slot\n"); return false; }
+            rec[at] = i;
+            bin8[at] = (uint8_t)bins[i];
+        }
+    // (4) a lane per slot: the bin from the byte and the three thresholds; the place in the region = slot - off[bin] (the kernel adds
+    //     the region's reservation, which is the same for all records of the bin)
+    std::vector<uint32_t> seen(1024, 0);
+    for (uint32_t i = 0; i < n_valid; ++i) {
+        const uint32_t b = (uint32_t)bin8[i] + ((i >= first[0] ? 256u : 0u) + (i >= first[1] ? 256u : 0u) + (i >= first[2] ? 256u : 0u));
+        const uint64_t r = rec[i];
+        if (b >= n_bins || bins[(size_t)r] != (int)b) { printf("k_kc_part model: slot %u holds a record of bin %d, the lane says bin %u\n", i, bins[(size_t)r], b); return false; }
+        if (i - off[b] != seen[b]++) { printf("k_kc_part model: a bin's records do not leave in slot order\n"); return false; }
+    }
+    for (uint32_t b = 0; b < 1024; ++b)
+        if (seen[b] != cnt[b]) { printf("k_kc_part model: bin %u lost records\n", b); return false; }
+    return true;
 }
 
 int main() {
@@ -187,6 +232,21 @@ int main() {
                 if (bad) return 1;
             }
         }
+    }
+    // k_kc_part's tile: few and many bins, empty bins (also at the thresholds 256 / 512 / 768), all records in one bin, null records
+    for (int it = 0; it < 200; ++it) {
+        const uint32_t n_bins = it < 5 ? 1u + (uint32_t)it : (it % 3 == 0 ? 1024u : 1u + (uint32_t)(rng() % 1024));
+        const uint32_t n = it % 7 == 0 ? 8192u : (uint32_t)(rng() % 8193);
+        const int mode = it % 5;
+        std::vector<int> bins(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t b = (uint32_t)(rng() % n_bins);
+            if (mode == 1) b = b / 2 * 2 % n_bins;                                   // half the bins stay empty
+            if (mode == 2) b = n_bins - 1;                                           // one bin takes everything
+            if (mode == 3 && n_bins > 300) b = 250u + (uint32_t)(rng() % 20);        // around a threshold: 250 .. 269
+            bins[i] = (mode == 4 && (rng() & 3) == 0) ? -1 : (int)b;                 // null records (a chunk's unused end)
+        }
+        if (!part_tile_model(bins, n_bins, rng)) return 1;
     }
     // placement inside a slice
     for (int i = 0; i < 200000; ++i) {
