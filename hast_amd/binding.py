@@ -31,10 +31,16 @@ class FqBlock(C.Structure):
                 ("n_unknown", C.c_uint64)]
 
 
+class FqRouted(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("count", C.c_uint64 * 4), ("run", C.POINTER(C.c_uint8) * 4), ("run_bytes", C.c_uint64 * 4),
+                ("host_block", C.c_int), ("bytes", C.POINTER(C.c_uint8)), ("rec_start", C.POINTER(C.c_uint32)), ("rec_len", C.POINTER(C.c_uint32)),
+                ("rec_class", C.POINTER(C.c_uint8)), ("n_slots", C.c_uint64), ("tail", C.POINTER(C.c_uint8)), ("tail_bytes", C.c_uint64)]
+
+
 class GzStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("compressed_bytes", "out_bytes", "chunks", "accepted", "followup_jobs", "followup_rounds", "followup_accepted", "members")] + \
                [(n, C.c_double) for n in ("decode_s", "windows_crc_s", "wait_upload_s", "wait_consumer_s", "wait_decode_s", "open_s")] + \
-               [(n, C.c_uint64) for n in ("ring_bytes", "upload_waited_for_ring")]
+               [(n, C.c_uint64) for n in ("ring_bytes", "upload_waited_for_ring")] + [("chain_walk_s", C.c_double), ("ring_laps", C.c_uint64)]
 
 
 KC_HISTO_HIGH = 10000
@@ -111,6 +117,10 @@ ABI_SYMBOLS = {
     "hast_fq_poll": (C.c_int, [vp]),
     "hast_fq_next": (C.c_int, [vp, C.POINTER(FqBlock)]),
     "hast_fq_commit": (C.c_int, [vp]),
+    "hast_dev_mem_info": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "hast_names_insert": (C.c_int, [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_size_t]),
+    "hast_fq_set_route": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
+    "hast_fq_next_routed": (C.c_int, [vp, C.POINTER(FqRouted)]),
     "hast_gz_open": (C.c_int, [vp, C.c_char_p, C.POINTER(vp)]),
     "hast_gz_open_ex": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(vp)]),
     "hast_gz_open_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.POINTER(vp)]),

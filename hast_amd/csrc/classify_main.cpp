@@ -30,6 +30,7 @@
 #include <cerrno>
 #include <chrono>
 #include <deque>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,16 @@ void print_usage() {                              // same flags as the reference
           "      --save-table FILE write the built k-mer table (after the adaptor scrub) as a binary key set\n"
           "      --load-table FILE use such a file instead of --hap0/--hap1\n"
           "      --stats           timings and set sizes on stderr\n"
+          "      --stats-json FILE the same as one JSON object (- = stderr)\n"
+          "      --phase-reads     also do the wrapper's steps 10-11: write the three barcode lists and route every record of every\n"
+          "                        input to <name>.{paternal,maternal,homozygous,nobarcode}.fastq (HAST_PHASE_READS=1)\n"
+          "      --route MODE      device (default): records routed on the GPU; host: parsed again by host threads\n"
+          "      --inflate MODE    device (default) | host | zlib: who inflates .gz inputs (HAST_INFLATE)\n"
+          "      --gz-ring-bytes N compressed bytes of a .gz input kept on the device at a time (default: whole files up to 2 GB;\n"
+          "                        HAST_GZ_RING_BYTES)\n"
+          "      --park-gb X       device memory of closed streams kept for reuse instead of freed (default 32; HAST_PARK_GB)\n"
+          "      --name-cache N    barcodes the device-side dictionary holds (default 16M; HAST_NAME_CACHE)\n"
+          "      --deal MODE       with --devices: blocks (default) | files (HAST_DEAL)\n"
           "  -h, --help            this text\n\n"
           "stdout: barcode <TAB> haplotype(0/1/-1) <TAB> hits_hap0 <TAB> hits_hap1, sorted by barcode\n\n",
           stderr);
@@ -94,6 +105,93 @@ void print_usage() {                              // same flags as the reference
     fprintf(stderr, "classify: ERROR: writing the result to stdout failed (%s)\n", strerror(errno));
     fflush(stderr);
     _exit(2);
+}
+
+// --stats: every "__stats_<section>__ key=value ..." line goes to stderr and is kept for --stats-json FILE, which writes the same
+// numbers as ONE JSON object {"section": {"key": value, ...}, ...} (a section printed several times, e.g. one line per .gz input,
+// becomes an array) -- SURVEY section 5's machine-readable summary.
+struct StatLog {
+    std::mutex mu;
+    std::vector<std::string> lines;
+};
+StatLog &stat_log() {
+    static StatLog *l = new StatLog();
+    return *l;
+}
+void stat_line(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void stat_line(const char *fmt, ...) {
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    fputs(buf, stderr);
+    std::string l(buf);
+    while (!l.empty() && l.back() == '\n') l.pop_back();
+    std::lock_guard<std::mutex> g(stat_log().mu);
+    stat_log().lines.push_back(std::move(l));
+}
+bool write_stats_json(const std::string &path) {
+    std::vector<std::string> lines;
+    {
+        std::lock_guard<std::mutex> g(stat_log().mu);
+        lines = stat_log().lines;
+    }
+    auto quote = [](const std::string &v) {
+        std::string o = "\"";
+        for (char c : v) {
+            if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back(c); }
+            else if ((unsigned char)c < 0x20) { char t[8]; snprintf(t, sizeof(t), "\\u%04x", c); o += t; }
+            else o.push_back(c);
+        }
+        return o + "\"";
+    };
+    auto is_number = [](const std::string &v) {
+        if (v.empty()) return false;
+        char *end = nullptr;
+        (void)strtod(v.c_str(), &end);
+        if (*end) return false;
+        const char c0 = v[0] == '-' ? (v.size() > 1 ? v[1] : 'x') : v[0];        // (JSON numbers: no hex, inf, nan, leading '+' or '.')
+        return c0 >= '0' && c0 <= '9' && v.find_first_of("xXnN") == std::string::npos && !(v.size() > 1 && v[0] == '0' && v[1] >= '0' && v[1] <= '9');
+    };
+    std::vector<std::pair<std::string, std::vector<std::string>>> sections;       // name -> one object per line, in order of appearance
+    for (const std::string &l : lines) {
+        size_t sp = l.find(' ');
+        std::string name = l.substr(0, sp);
+        while (!name.empty() && name.front() == '_') name.erase(name.begin());
+        while (!name.empty() && name.back() == '_') name.pop_back();
+        std::string obj = "{";
+        bool first = true;
+        while (sp != std::string::npos) {
+            const size_t a = sp + 1, b = l.find(' ', a);
+            const std::string tok = l.substr(a, b == std::string::npos ? std::string::npos : b - a);
+            sp = b;
+            const size_t eq = tok.find('=');
+            if (eq == std::string::npos || eq == 0) continue;                     // (free text inside a line)
+            const std::string k = tok.substr(0, eq), v = tok.substr(eq + 1);
+            obj += (first ? "" : ", ") + quote(k) + ": " + (is_number(v) ? v : quote(v));
+            first = false;
+        }
+        obj += "}";
+        size_t i = 0;
+        while (i < sections.size() && sections[i].first != name) ++i;
+        if (i == sections.size()) sections.push_back({name, {}});
+        sections[i].second.push_back(obj);
+    }
+    std::string js = "{";
+    for (size_t i = 0; i < sections.size(); i++) {
+        js += (i ? ", " : "") + quote(sections[i].first) + ": ";
+        if (sections[i].second.size() == 1) js += sections[i].second[0];
+        else {
+            js += "[";
+            for (size_t j = 0; j < sections[i].second.size(); j++) js += (j ? ", " : "") + sections[i].second[j];
+            js += "]";
+        }
+    }
+    js += "}\n";
+    if (path == "-") return fputs(js.c_str(), stderr) >= 0;
+    FILE *f = fopen(path.c_str(), "wb");
+    return f && fwrite(js.data(), 1, js.size(), f) == js.size() && fclose(f) == 0;
 }
 
 // the whole input, front to back (also from a pipe, which has no size to ask for)
@@ -177,6 +275,10 @@ int main(int argc, char **argv) {
         {"block-mb", required_argument, NULL, 1004},    {"initial-barcodes", required_argument, NULL, 1005},
         {"save-table", required_argument, NULL, 1006},  {"load-table", required_argument, NULL, 1007},
         {"devices", required_argument, NULL, 1008},     {"host-parse", no_argument, NULL, 1009},
+        {"phase-reads", no_argument, NULL, 1010},       {"inflate", required_argument, NULL, 1011},
+        {"gz-ring-bytes", required_argument, NULL, 1012}, {"stats-json", required_argument, NULL, 1013},
+        {"park-gb", required_argument, NULL, 1014},     {"name-cache", required_argument, NULL, 1015},
+        {"deal", required_argument, NULL, 1016},        {"route", required_argument, NULL, 1017},
         {0, 0, 0, 0}};
     static char optstring[] = "p:m:l:r:t:w:u:f:q:h";             // classify.cpp:387
     std::string hap0, hap1, save_table, load_table;
@@ -189,6 +291,14 @@ int main(int argc, char **argv) {
     // times on the way to BASELINE config 3's 10M barcodes)
     size_t batch_reads = 0, block_mb = 256, initial_barcodes = 1u << 24;
     bool stats = false, host_parse = false;
+    // What changes what a production run allocates or writes is a FLAG; the environment variable each one replaces stays as an alias
+    // (a flag wins).  The library reads its switches from the environment, once: a flag is put there before the first library call.
+    bool phase_reads = false;
+    std::string stats_json, route_mode;
+    {
+        const char *pr = getenv("HAST_PHASE_READS");
+        phase_reads = pr && *pr && strcmp(pr, "0") != 0;
+    }
     double w0 = 1.0, w1 = 1.0;
     for (;;) {
         int c = getopt_long(argc, argv, optstring, long_options, NULL);
@@ -210,6 +320,23 @@ int main(int argc, char **argv) {
         case 1006: save_table = optarg; break;
         case 1007: load_table = optarg; break;
         case 1009: host_parse = true; break;
+        case 1010: phase_reads = true; break;
+        case 1011:
+            if (strcmp(optarg, "host") && strcmp(optarg, "device") && strcmp(optarg, "zlib")) { print_usage(); return -1; }
+            setenv("HAST_INFLATE", optarg, 1);
+            break;
+        case 1012: setenv("HAST_GZ_RING_BYTES", optarg, 1); break;
+        case 1013: stats_json = optarg; stats = true; break;
+        case 1014: setenv("HAST_PARK_GB", optarg, 1); break;
+        case 1015: setenv("HAST_NAME_CACHE", optarg, 1); break;
+        case 1016:
+            if (strcmp(optarg, "files") && strcmp(optarg, "blocks")) { print_usage(); return -1; }
+            setenv("HAST_DEAL", optarg, 1);
+            break;
+        case 1017:
+            if (strcmp(optarg, "host") && strcmp(optarg, "device")) { print_usage(); return -1; }
+            route_mode = optarg;
+            break;
         case 1008:
             for (const char *q = optarg; *q;) {
                 char *end;
@@ -289,7 +416,22 @@ int main(int argc, char **argv) {
                                              dev_gz[file_index] ? 1 : 0, out);
         return hast_fq_create_ex(ctxs[file_index % ctxs.size()], fq_cap, fq_bufs, name_caches[file_index % ctxs.size()], dev_gz[file_index] ? 1 : 0, out);
     };
+    // --stats: the device's free memory, sampled every 20 ms from here to the end (the HBM head-room line)
+    std::atomic<bool> hbm_stop{false};
+    std::atomic<size_t> hbm_free_min{~(size_t)0}, hbm_total{0};
+    std::thread hbm_thread;
     auto contexts_ready = [&]() {
+        if (stats)
+            hbm_thread = std::thread([&hbm_stop, &hbm_free_min, &hbm_total, ctx] {
+                while (!hbm_stop.load()) {
+                    size_t f = 0, t = 0;
+                    if (hast_dev_mem_info(ctx, &f, &t, nullptr) == HAST_OK) {
+                        hbm_total = t;
+                        if (f < hbm_free_min.load()) hbm_free_min = f;
+                    }
+                    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+                }
+            });
         ctxs.push_back(ctx);
         for (size_t i = 1; i < devices.size(); i++) {
             hast_ctx *c2 = nullptr;
@@ -445,7 +587,8 @@ int main(int argc, char **argv) {
         pre_thread.join();
         if (!pre_error.empty()) {
             fprintf(stderr, "classify: ERROR: creating the FASTQ stream (%s)\n", pre_error.c_str());
-            return 4;
+            fflush(stderr);
+            _exit(4);                                          // (threads of this program and of the library are at work: no destructors)
         }
     }
     const double t_pre_waited = now_s() - t_pre_wait0;
@@ -839,7 +982,7 @@ int main(int argc, char **argv) {
                     if (f.gz) {
                         hast_gz_stats gs;
                         if (stats && hast_gz_get_stats(f.gz, &gs) == HAST_OK)
-                            fprintf(stderr, "__stats_gz__ file=%s compressed_bytes=%llu inflated_bytes=%llu chunks=%llu accepted=%llu followup_jobs=%llu followup_rounds=%llu members=%llu "
+                            stat_line("__stats_gz__ file=%s compressed_bytes=%llu inflated_bytes=%llu chunks=%llu accepted=%llu followup_jobs=%llu followup_rounds=%llu members=%llu "
                                             "open_s=%.3f decode_s=%.3f windows_crc_s=%.3f producer_waited_for_upload_s=%.3f producer_waited_for_reader_s=%.3f reader_waited_for_decode_s=%.3f ring_bytes=%llu upload_waited_for_ring=%llu\n",
                                     f.name.c_str(), (unsigned long long)gs.compressed_bytes, (unsigned long long)gs.out_bytes, (unsigned long long)gs.chunks,
                                     (unsigned long long)gs.accepted, (unsigned long long)gs.followup_jobs, (unsigned long long)gs.followup_rounds, (unsigned long long)gs.members,
@@ -877,10 +1020,10 @@ int main(int argc, char **argv) {
                 for (hast_fq *q : done_fq) n += hast_fq_lane_records(q, (int)g);
                 per += (g ? "," : "") + std::to_string(n);
             }
-            fprintf(stderr, "__stats_devices__ blocks_of_every_file_dealt_to=%zu records_per_context=%s\n", ctxs.size(), per.c_str());
+            stat_line("__stats_devices__ blocks_of_every_file_dealt_to=%zu records_per_context=%s\n", ctxs.size(), per.c_str());
         }
         if (stats)
-            fprintf(stderr, "__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f records_named_on_host=%llu\n",
+            stat_line("__stats_read_phase__ waiting_for_file_bytes_s=%.3f waiting_for_gpu_framing_s=%.3f naming_barcodes_s=%.3f commit_s=%.3f stream_setup_s=%.3f records_named_on_host=%llu\n",
                     t_idle, t_gpu_wait, t_names, t_commit, t_create, (unsigned long long)total_named);
     }
     const double t_read_done = now_s();
@@ -1026,26 +1169,402 @@ int main(int argc, char **argv) {
     // input.  This program has the barcodes' classes in memory and a GPU that inflates .gz inputs: with HAST_PHASE_READS set it writes the
     // lists, routes the records (quartering.h: the same bytes as the awk program's, incl. filter_reads.log and the ERROR lines) and
     // leaves the marker files step_10_done / step_11_done, at which the UNCHANGED wrapper skips its own steps 10 and 11.
-    if (const char *pr = getenv("HAST_PHASE_READS"); pr && *pr && strcmp(pr, "0") != 0) {
+    if (phase_reads) {
         const double t_ph0 = now_s();
         namespace hq = hast::quartering;
-        hq::ClassMap cls_of;
         const char *list_name[3] = {"paternal.unique.barcodes", "maternal.unique.barcodes", "homozygous.unique.barcodes"};
-        const int list_hap[3] = {0, 1, -1};
+        // the call of every barcode once (getHap, classify.cpp:66-86): list 1 paternal (hap 0), 2 maternal (hap 1), 3 homozygous (-1)
+        std::vector<uint8_t> list_of(nb);
+        std::vector<char> has_sep((size_t)T, 0);
+        pool.run([&](int t) {
+            for (size_t i = nb * (size_t)t / T, e = nb * (size_t)(t + 1) / T; i < e; i++) {
+                const std::string_view bc = names[i];
+                const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
+                const int hap = hast_get_hap(bc.data(), bc.size(), c0, c1, n_set[0], n_set[1], w0, w1);
+                list_of[i] = hap == 0 ? 1 : hap == 1 ? 2 : 3;
+                if (bc.find('#') != std::string_view::npos || bc.find('/') != std::string_view::npos) has_sep[(size_t)t] = 1;
+            }
+        });
         for (int l = 0; l < 3; l++) {
             std::string text;
             for (size_t r = 0; r < nb; r++) {
                 const uint32_t i = order[r];
-                const std::string_view bc = names[i];
-                const uint64_t c0 = i < acc.c0.size() ? acc.c0[i] : 0, c1 = i < acc.c1.size() ? acc.c1[i] : 0;
-                if (hast_get_hap(bc.data(), bc.size(), c0, c1, n_set[0], n_set[1], w0, w1) != list_hap[l]) continue;
-                text.append(bc.data(), bc.size());
+                if (list_of[i] != l + 1) continue;
+                text.append(names[i].data(), names[i].size());
                 text.push_back('\n');
-                cls_of.emplace(std::string(hq::field(bc, 0)), (uint8_t)(l + 1));          // (a list line's first field, first list wins: awk :12-16)
             }
             FILE *lf = fopen(list_name[l], "wb");
             if (!lf || fwrite(text.data(), 1, text.size(), lf) != text.size() || fclose(lf) != 0) die(2, (std::string("cannot write ") + list_name[l]).c_str());
         }
+        const double t_lists = now_s();
+        // awk's three arrays as one map: a list line's first field under -F '#|/', first list wins (awk :12-16,23-35).  10M insertions of
+        // std::string take seconds: built only when the host has to route something
+        hq::ClassMap cls_of;
+        bool cls_ready = false;
+        auto need_cls = [&]() {
+            if (cls_ready) return;
+            for (int l = 0; l < 3; l++)
+                for (size_t r = 0; r < nb; r++) {
+                    const uint32_t i = order[r];
+                    if (list_of[i] == l + 1) cls_of.emplace(std::string(hq::field(names[i], 0)), (uint8_t)(l + 1));
+                }
+            cls_ready = true;
+        };
+        bool any_sep = false;
+        for (char c : has_sep) any_sep = any_sep || c;
+        // On the GPU (default): the inputs go through the framer once more (.gz inputs inflated there again), a kernel sorts the records
+        // of every block into four runs by the class of their barcode, the runs come back over PCIe and are written as they are -- no
+        // host thread looks at a record.  On the host (--route host; --host-parse; a barcode that itself holds '#' or '/', whose list
+        // line awk cuts short): the inputs are parsed again by the worker threads, quartering.h.
+        const bool route_on_device = !host_parse && route_mode != "host" && !any_sep;
+        uint64_t blocks_routed = 0, blocks_host = 0, bytes_routed = 0;
+        double t_wait_write = 0, t_wait_gpu = 0;
+        if (route_on_device) {
+            // the table text -> class of every GPU
+            std::vector<hast_names *> tabs(ctxs.size(), nullptr), own_tabs;
+            {
+                std::vector<uint8_t> text16;
+                std::vector<uint32_t> cls;
+                text16.reserve(nb * 16);
+                cls.reserve(nb);
+                for (size_t i = 0; i < nb; i++) {
+                    const std::string_view bc = names[i];
+                    if (bc.size() > 15) continue;                    // (a field that long is the host's: the kernel hands the block over)
+                    uint8_t rec[16] = {0};
+                    rec[0] = (uint8_t)bc.size();
+                    memcpy(rec + 1, bc.data(), bc.size());
+                    text16.insert(text16.end(), rec, rec + 16);
+                    cls.push_back(list_of[i]);
+                }
+                for (size_t i = 0; i < ctxs.size(); i++) {
+                    for (size_t j = 0; j < i && !tabs[i]; j++)
+                        if (devices[j] == devices[i]) tabs[i] = tabs[j];
+                    if (tabs[i]) continue;
+                    CK(hast_names_create(ctxs[i], std::max<size_t>(cls.size(), 1024), &tabs[i]), "creating the routing table");
+                    own_tabs.push_back(tabs[i]);
+                    CK(hast_names_insert(tabs[i], text16.data(), cls.data(), cls.size()), "filling the routing table");
+                }
+            }
+            struct WriteJob { const uint8_t *p[4]; size_t n[4]; std::shared_ptr<std::vector<std::string>> own; };
+            struct RFeed {
+                std::string name, prefix, log_name;
+                size_t file_index = 0;
+                hast::BlockSource src;
+                hast_fq *fq = nullptr;
+                hast_gz *gz = nullptr;
+                std::thread th, wth;
+                std::mutex mu, wmu;
+                std::condition_variable cv, wcv;
+                std::deque<std::pair<uint8_t *, hast_stream>> empty;
+                struct Filled { size_t n; bool last; std::string err; };
+                std::deque<Filled> filled;
+                std::deque<WriteJob> wq;
+                bool stop = false, eof_acquired = false, wstop = false, write_failed = false, block_open = false;
+                size_t held = 0, submitted = 0, opened = 0, acquired = 0, jobs = 0, written = 0;
+                FILE *out[4] = {nullptr, nullptr, nullptr, nullptr};
+                long long counts[5] = {0, 0, 0, 0, 0};
+                bool any_input = false;
+                std::string err_lines;
+            };
+            static const char *suffix[4] = {".nobarcode.fastq", ".paternal.fastq", ".maternal.fastq", ".homozygous.fastq"};
+            const int n_buf = stripe ? std::max(2, (fq_bufs + (int)ctxs.size() - 1) / (int)ctxs.size()) : fq_bufs;
+            std::mutex wake_mu;
+            std::condition_variable wake_cv;
+            uint64_t wake_gen = 0, seen_gen = 0;
+            auto wake = [&] {
+                { std::lock_guard<std::mutex> g(wake_mu); ++wake_gen; }
+                wake_cv.notify_one();
+            };
+            std::vector<std::unique_ptr<RFeed>> active;
+            std::vector<std::unique_ptr<RFeed>> finished(read.size());
+            std::vector<hast_fq *> spare(done_fq);                      // the streams of the first pass, ready to be used again
+            done_fq.clear();
+            std::vector<std::thread> closers;
+            size_t next_file = 0;
+            const size_t cap = fq_cap;
+            // inputs with one basename write the same four files: the awk loop lets the later one overwrite the earlier -- one at a time then
+            bool same_prefix = false;
+            {
+                std::vector<std::string> pf;
+                for (const std::string &x : read) {
+                    std::string nm = x.substr(x.find_last_of('/') == std::string::npos ? 0 : x.find_last_of('/') + 1);
+                    if (nm.size() >= 3 && nm.compare(nm.size() - 3, 3, ".gz") == 0) nm.resize(nm.size() - 3);
+                    same_prefix = same_prefix || std::find(pf.begin(), pf.end(), nm) != pf.end();
+                    pf.push_back(nm);
+                }
+            }
+            auto open_next = [&]() {
+                const std::string &x = read[next_file];
+                std::unique_ptr<RFeed> f(new RFeed());
+                f->name = x;
+                f->file_index = next_file;
+                f->prefix = x.substr(x.find_last_of('/') == std::string::npos ? 0 : x.find_last_of('/') + 1);
+                const bool gz_name = f->prefix.size() >= 3 && f->prefix.compare(f->prefix.size() - 3, 3, ".gz") == 0;   // (the wrapper's ${name: -3} == ".gz")
+                if (gz_name) f->prefix.resize(f->prefix.size() - 3);
+                f->log_name = gz_name ? "-" : x;                        // (awk's FILENAME behind `gzip -dc` is "-")
+                if (dev_gz[next_file]) {
+                    const hast_status gs = stripe ? hast_gz_open_multi(ctxs.data(), (int)ctxs.size(), x.c_str(), &f->gz) : hast_gz_open(ctxs[next_file % ctxs.size()], x.c_str(), &f->gz);
+                    if (gs == HAST_ERR_UNSUPPORTED) {
+                        f->gz = nullptr;
+                        dev_gz[next_file] = 0;
+                    } else if (gs != HAST_OK) die(2, ("cannot open " + x).c_str());
+                }
+                if (!f->gz) {
+                    if (!f->src.open(x, cap, false)) die(2, ("cannot open " + x).c_str());
+                    f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
+                }
+                // a stream of the first pass whose kind fits (device blocks or host blocks; on this file's context), or a new one
+                const size_t want_ctx = next_file % ctxs.size();
+                (void)want_ctx;
+                CK(make_fq(next_file, &f->fq), "creating the FASTQ stream");
+                std::vector<hast_names *> lane_tabs;
+                if (stripe) lane_tabs = tabs;
+                else lane_tabs.push_back(tabs[next_file % ctxs.size()]);
+                CK(hast_fq_set_route(f->fq, lane_tabs.data(), (int)lane_tabs.size()), "switching the FASTQ stream to routing");
+                next_file++;
+                RFeed *fp = f.get();
+                f->th = std::thread([fp, cap, &wake] {
+                    for (;;) {
+                        uint8_t *buf;
+                        hast_stream fill_stream;
+                        {
+                            std::unique_lock<std::mutex> g(fp->mu);
+                            fp->cv.wait(g, [fp] { return fp->stop || !fp->empty.empty(); });
+                            if (fp->stop) return;
+                            buf = fp->empty.front().first;
+                            fill_stream = fp->empty.front().second;
+                            fp->empty.pop_front();
+                        }
+                        RFeed::Filled fl{0, false, std::string()};
+                        if (fp->gz) {
+                            size_t n = 0;
+                            if (hast_gz_read_device(fp->gz, buf, cap, &n, fill_stream) != HAST_OK) fl.err = hast_last_error();
+                            else if (n < cap) {                      // (a short read: the end, or damage behind it -- the next call says which)
+                                size_t more = 0;
+                                if (hast_gz_read_device(fp->gz, buf + n, cap - n, &more, fill_stream) != HAST_OK) fl.err = hast_last_error();
+                                n += more;
+                            }
+                            fl.n = n;
+                        } else fl.n = fp->src.read_into(reinterpret_cast<char *>(buf), cap, fl.err);
+                        fl.last = fl.n < cap || !fl.err.empty();
+                        {
+                            std::lock_guard<std::mutex> g(fp->mu);
+                            fp->filled.push_back(fl);
+                        }
+                        wake();
+                        if (fl.last) return;
+                    }
+                });
+                f->wth = std::thread([fp, &wake] {                      // the runs of a block to the four files, in order
+                    for (;;) {
+                        WriteJob j;
+                        {
+                            std::unique_lock<std::mutex> g(fp->wmu);
+                            fp->wcv.wait(g, [fp] { return fp->wstop || !fp->wq.empty(); });
+                            if (fp->wq.empty()) return;
+                            j = std::move(fp->wq.front());
+                            fp->wq.pop_front();
+                        }
+                        for (int c = 0; c < 4 && !fp->write_failed; c++) {
+                            if (!j.n[c]) continue;
+                            if (!fp->out[c]) fp->out[c] = fopen((fp->prefix + suffix[c]).c_str(), "wb");
+                            if (!fp->out[c] || fwrite(j.p[c], 1, j.n[c], fp->out[c]) != j.n[c]) fp->write_failed = true;
+                        }
+                        {
+                            std::lock_guard<std::mutex> g(fp->wmu);
+                            fp->written++;
+                        }
+                        wake();
+                    }
+                });
+                active.push_back(std::move(f));
+            };
+            // a block the device handed over: every record by the host's rules, in input order (quartering.h's classify)
+            auto host_class = [&](std::string_view head, std::string &err) -> int {
+                std::string_view f2 = hq::field(head, 1);
+                if (f2.data() == nullptr || f2 == "0_0_0") return 0;
+                need_cls();
+                auto it = cls_of.find(std::string(f2));
+                if (it != cls_of.end()) return it->second;
+                err.append("ERROR : unclassify barcode : ").append(f2).append("\n");
+                return -1;
+            };
+            auto open_block = [&](RFeed &f) {
+                hast_fq_routed b;
+                const double t0 = now_s();
+                CK(hast_fq_next_routed(f.fq, &b), "routing a block");
+                t_wait_gpu += now_s() - t0;
+                WriteJob j;
+                for (int c = 0; c < 4; c++) { j.p[c] = nullptr; j.n[c] = 0; }
+                if (!b.host_block) {
+                    for (int c = 0; c < 4; c++) {
+                        j.p[c] = b.run[c];
+                        j.n[c] = (size_t)b.run_bytes[c];
+                        f.counts[c] += (long long)b.count[c];
+                        bytes_routed += b.run_bytes[c];
+                    }
+                    f.counts[4] += (long long)b.n_records;
+                    if (b.n_records) f.any_input = true;
+                    blocks_routed++;
+                } else {
+                    j.own = std::make_shared<std::vector<std::string>>(4);
+                    for (uint64_t i = 0; i < b.n_slots; i++) {
+                        if (b.rec_class[i] == 0xFD) continue;
+                        const char *r0 = reinterpret_cast<const char *>(b.bytes) + b.rec_start[i];
+                        const size_t len = b.rec_len[i];
+                        int c = b.rec_class[i];
+                        if (c > 3) {
+                            const void *nlp = memchr(r0, '\n', len);
+                            c = host_class(std::string_view(r0, nlp ? (size_t)((const char *)nlp - r0) : len), f.err_lines);
+                        }
+                        f.counts[4]++;
+                        f.any_input = true;
+                        if (c >= 0) { (*j.own)[(size_t)c].append(r0, len); f.counts[c]++; }
+                    }
+                    for (int c = 0; c < 4; c++) { j.p[c] = reinterpret_cast<const uint8_t *>((*j.own)[(size_t)c].data()); j.n[c] = (*j.own)[(size_t)c].size(); }
+                    blocks_host++;
+                }
+                if (b.tail_bytes) {
+                    // the end of the file inside a record: awk still takes every remaining line as the record's (:21,41-49)
+                    if (!j.own) {
+                        j.own = std::make_shared<std::vector<std::string>>(4);
+                        for (int c = 0; c < 4; c++) (*j.own)[(size_t)c].assign(reinterpret_cast<const char *>(j.p[c]), j.n[c]);
+                    }
+                    std::string_view rest(reinterpret_cast<const char *>(b.tail), (size_t)b.tail_bytes);
+                    const size_t e = rest.find('\n');
+                    const int c = host_class(rest.substr(0, e == std::string_view::npos ? rest.size() : e), f.err_lines);
+                    f.counts[4]++;
+                    f.any_input = true;
+                    if (c >= 0) {
+                        (*j.own)[(size_t)c].append(rest);
+                        if (rest.back() != '\n') (*j.own)[(size_t)c].push_back('\n');
+                        f.counts[c]++;
+                    }
+                    for (int c2 = 0; c2 < 4; c2++) { j.p[c2] = reinterpret_cast<const uint8_t *>((*j.own)[(size_t)c2].data()); j.n[c2] = (*j.own)[(size_t)c2].size(); }
+                }
+                {
+                    std::lock_guard<std::mutex> g(f.wmu);
+                    f.wq.push_back(std::move(j));
+                    f.jobs++;
+                }
+                f.wcv.notify_one();
+                f.block_open = true;
+                f.opened++;
+            };
+            const size_t max_active = same_prefix ? 1 : (stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size()));
+            while (next_file < read.size() && active.size() < max_active) open_next();
+            while (!active.empty()) {
+                bool progress = false;
+                for (size_t fi = 0; fi < active.size(); ++fi) {
+                    RFeed &f = *active[fi];
+                    while (!f.eof_acquired && f.held < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq) && (!f.gz || f.acquired - f.submitted + 1 < (size_t)n_buf * (size_t)hast_fq_lanes(f.fq))) {
+                        uint8_t *buf;
+                        hast_stream fill_stream = nullptr;
+                        CK(hast_fq_acquire(f.fq, &buf), "staging a block");
+                        if (f.gz) CK(hast_fq_device_block(f.fq, &buf, &fill_stream), "staging a block");
+                        f.held++;
+                        f.acquired++;
+                        std::lock_guard<std::mutex> g(f.mu);
+                        f.empty.push_back({buf, fill_stream});
+                        f.cv.notify_one();
+                        progress = true;
+                    }
+                    for (;;) {
+                        RFeed::Filled fl;
+                        {
+                            std::lock_guard<std::mutex> g(f.mu);
+                            if (f.filled.empty()) break;
+                            fl = f.filled.front();
+                            f.filled.pop_front();
+                        }
+                        if (!fl.err.empty()) die(2, (f.name + ": " + fl.err).c_str());
+                        CK(f.gz ? hast_fq_submit_device(f.fq, fl.n, fl.last ? 1 : 0) : hast_fq_submit(f.fq, fl.n, fl.last ? 1 : 0), "framing a block");
+                        f.submitted++;
+                        if (fl.last) f.eof_acquired = true;
+                        progress = true;
+                    }
+                }
+                for (size_t fi = 0; fi < active.size();) {
+                    RFeed &f = *active[fi];
+                    if (f.block_open) {                                // its runs written: the buffer goes back
+                        bool done;
+                        {
+                            std::lock_guard<std::mutex> g(f.wmu);
+                            done = f.written == f.jobs;
+                        }
+                        if (done) {
+                            if (f.write_failed) {
+                                fprintf(stderr, "classify: cannot write %s.*.fastq\n", f.prefix.c_str());
+                                fflush(stderr);
+                                _exit(2);
+                            }
+                            CK(hast_fq_commit(f.fq), "releasing a block");
+                            f.block_open = false;
+                            f.held--;
+                            progress = true;
+                        }
+                    }
+                    if (!f.block_open && f.opened < f.submitted && hast_fq_poll(f.fq)) {
+                        open_block(f);
+                        progress = true;
+                    }
+                    if (f.eof_acquired && f.opened == f.submitted && !f.block_open) {
+                        {
+                            std::lock_guard<std::mutex> g(f.mu);
+                            f.stop = true;
+                        }
+                        f.cv.notify_all();
+                        f.th.join();
+                        {
+                            std::lock_guard<std::mutex> g(f.wmu);
+                            f.wstop = true;
+                        }
+                        f.wcv.notify_all();
+                        f.wth.join();
+                        for (FILE *&o : f.out)
+                            if (o && fclose(o) != 0) { fprintf(stderr, "classify: cannot write %s.*.fastq\n", f.prefix.c_str()); fflush(stderr); _exit(2); }
+                        if (f.gz) {
+                            hast_gz *z = f.gz;
+                            closers.emplace_back([z] { hast_gz_close(z); });
+                        }
+                        done_fq.push_back(f.fq);
+                        const size_t idx = f.file_index;
+                        finished[idx] = std::move(active[fi]);
+                        active.erase(active.begin() + (long)fi);
+                        if (next_file < read.size()) open_next();
+                        progress = true;
+                        continue;
+                    }
+                    ++fi;
+                }
+                if (!progress) {
+                    const double t0 = now_s();
+                    std::unique_lock<std::mutex> g(wake_mu);
+                    wake_cv.wait_for(g, std::chrono::microseconds(stripe ? 10 : 100), [&] { return wake_gen != seen_gen; });
+                    seen_gen = wake_gen;
+                    t_wait_write += now_s() - t0;
+                }
+            }
+            // stderr and filter_reads.log in the order of the inputs, as the wrapper's loop leaves them (awk :18-20,51-57)
+            for (std::unique_ptr<RFeed> &fp : finished) {
+                if (!fp) continue;
+                fputs(fp->err_lines.c_str(), stderr);
+                FILE *lg = fopen("filter_reads.log", "ab");
+                if (lg) {
+                    if (fp->any_input) fprintf(lg, "%s\n", fp->log_name.c_str());
+                    fprintf(lg, "#Total reads                : %lld \n", fp->counts[4]);
+                    fprintf(lg, "#Reads without barcode      : %lld \n", fp->counts[0]);
+                    fprintf(lg, "#Paternal reads             : %lld \n", fp->counts[1]);
+                    fprintf(lg, "#Maternal reads             : %lld \n", fp->counts[2]);
+                    fprintf(lg, "#Homozygous reads           : %lld \n", fp->counts[3]);
+                    fclose(lg);
+                }
+            }
+            for (std::thread &t : closers) gz_closers.push_back(std::move(t));
+            (void)spare;
+            (void)own_tabs;
+        } else {
+        need_cls();
         // a .gz input inflated on the GPU, as a block source for the router: the bytes come back over PCIe block by block
         constexpr size_t kFrontPad = hast::BlockSource::kFrontPad;     // (room in front of a block's data: what route() expects)
         struct DevGzSource {
@@ -1104,27 +1623,53 @@ int main(int argc, char **argv) {
                 _exit(rc);
             }
         }
+        }
         for (const char *marker : {"step_10_done", "step_11_done"}) {
             FILE *mf = fopen(marker, "ab");                   // (the wrapper appends `date` to them and only tests that they exist)
             time_t now = time(0);
             if (!mf || fprintf(mf, "%s", ctime(&now)) < 0 || fclose(mf) != 0) die(2, (std::string("cannot write ") + marker).c_str());
         }
-        if (stats) fprintf(stderr, "__stats_phase_reads__ lists_and_routing_s=%.3f inputs=%zu\n", now_s() - t_ph0, read.size());
+        if (stats)
+            stat_line("__stats_phase_reads__ lists_and_routing_s=%.3f lists_s=%.3f routing_s=%.3f route=%s inputs=%zu blocks_routed_on_device=%llu blocks_routed_by_host=%llu "
+                            "bytes_routed_on_device=%llu waiting_for_gpu_s=%.3f idle_s=%.3f\n",
+                    now_s() - t_ph0, t_lists - t_ph0, now_s() - t_lists, route_on_device ? "device" : "host", read.size(), (unsigned long long)blocks_routed,
+                    (unsigned long long)blocks_host, (unsigned long long)bytes_routed, t_wait_gpu, t_wait_write);
     }
     if (past_int)
         fprintf(stderr, " WARN : a barcode has more than INT_MAX hits: the reference's `int` counters overflow on this input; the exact counts were printed\n");
     logtime();
     if (stats) {
         double dt = t_classified - t_loaded;
-        fprintf(stderr, "__stats__ K=%zu set0=%llu set1=%llu reads=%llu bases=%llu barcodes=%zu load_s=%.3f classify_s=%.3f Mbp_per_s=%.1f\n",
+        stat_line("__stats__ K=%zu set0=%llu set1=%llu reads=%llu bases=%llu barcodes=%zu load_s=%.3f classify_s=%.3f Mbp_per_s=%.1f\n",
                 K, (unsigned long long)n_set[0], (unsigned long long)n_set[1], (unsigned long long)total_reads,
                 (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
-    if (stats) fprintf(stderr, "__stats_setup__ waited_for_stream_setup_s=%.3f (inside scrub_sizes_clone_s: .gz inputs opened, FASTQ streams created while the table was built)\n", t_pre_waited);
+    if (stats) stat_line("__stats_setup__ waited_for_stream_setup_s=%.3f (inside scrub_sizes_clone_s: .gz inputs opened, FASTQ streams created while the table was built)\n", t_pre_waited);
+    // a context that could not get room for its filter probes the table directly (the round-1 kernel: 1.6 x the HBM requests per read):
+    // same results, never silently
+    for (size_t i = 0; i < ctxs.size(); i++) {
+        char sw[512] = "";
+        (void)hast_ctx_options(ctxs[i], sw, sizeof(sw));
+        if (strstr(sw, "filter_fallback"))
+            fprintf(stderr, " WARN : GPU %d (context %zu) had no room for the k-mer filter and probed the table directly (%s)\n", devices[i], i, sw);
+    }
     if (stats) {
         char sw[512] = "";
         (void)hast_ctx_options(ctx, sw, sizeof(sw));          // measurement switches this context was created with (none by default)
-        fprintf(stderr, "__stats_switches__ %s\n", sw[0] ? sw : "none");
+        stat_line("__stats_switches__ %s\n", sw[0] ? sw : "none");
+        int f_on = 0, f_m = 0, f_t = 0, f_kp = 0;
+        uint64_t f_bytes = 0;
+        (void)hast_filter_info(ctx, &f_on, &f_m, &f_t, &f_kp, &f_bytes);
+        stat_line("__stats_filter__ mode=%s m=%d t=%d kp=%d bytes=%llu\n", f_on == 2 ? "exact_entries" : f_on == 1 ? "prints" : "off_table_only", f_m, f_t, f_kp,
+                  (unsigned long long)f_bytes);
+    }
+    if (hbm_thread.joinable()) {
+        hbm_stop = true;
+        hbm_thread.join();
+        size_t parked = 0;
+        (void)hast_dev_mem_info(ctx, nullptr, nullptr, &parked);
+        const size_t fm = hbm_free_min.load(), tot = hbm_total.load();
+        if (tot) stat_line("__stats_hbm__ total_bytes=%zu free_min_bytes=%zu in_use_peak_bytes=%zu parked_bytes_at_end=%zu\n", tot, fm, tot - std::min(fm, tot), parked);
     }
     fprintf(stderr, "__END__\n");
     const double t_printed = now_s();
@@ -1135,8 +1680,9 @@ int main(int argc, char **argv) {
     const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || (preload && strstr(preload, "rocprofiler"));
     if (!getenv("HAST_TEARDOWN") && !profiled) {
         if (stats)
-            fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=skipped total_s=%.3f\n",
+            stat_line("__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=skipped total_s=%.3f\n",
                     t_ctx - t_start, t_loaded - t_ctx, t_scrubbed - t_loaded, t_read_done - t_scrubbed, t_classified - t_read_done, t_printed - t_classified, now_s() - t_start);
+        if (!stats_json.empty() && !write_stats_json(stats_json)) fprintf(stderr, "classify: cannot write %s\n", stats_json.c_str());
         if (fflush(stdout) != 0) die_output();
         fflush(stderr);
         _exit(0);
@@ -1146,8 +1692,9 @@ int main(int argc, char **argv) {
     for (hast_names *nm : own_caches) hast_names_destroy(nm);
     for (hast_ctx *c : ctxs) hast_ctx_destroy(c);
     if (stats)                 // where a run's wall time goes, phase by phase (sums to the process's own lifetime from main() on)
-        fprintf(stderr, "__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=%.3f total_s=%.3f\n",
+        stat_line("__stats_phases__ gpu_context_s=%.3f load_kmers_s=%.3f scrub_sizes_clone_s=%.3f read_phase_s=%.3f counters_back_s=%.3f sort_print_s=%.3f teardown_s=%.3f total_s=%.3f\n",
                 t_ctx - t_start, t_loaded - t_ctx, t_scrubbed - t_loaded, t_read_done - t_scrubbed, t_classified - t_read_done,
                 t_printed - t_classified, now_s() - t_printed, now_s() - t_start);
+    if (!stats_json.empty() && !write_stats_json(stats_json)) fprintf(stderr, "classify: cannot write %s\n", stats_json.c_str());
     return 0;
 }

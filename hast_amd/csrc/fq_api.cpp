@@ -57,6 +57,13 @@ struct Slot {
     bool over_read_pending = false;                    //     block's GPU), the event the next filling of this buffer waits for
     bool dev_src = false;                              // the block's bytes were written on the device (hast_fq_submit_device): h_buf holds nothing
     bool host_view = false;                            // ... until hast_fq_block_host_bytes has fetched them
+    // routing streams (hast_fq_set_route): class + extent of every record, the tiles' prefix sums, the routed bytes and their host copy
+    uint32_t *d_rstart = nullptr, *d_rlen = nullptr, *d_rtile = nullptr;
+    uint8_t *d_rcls = nullptr, *d_out = nullptr, *h_out = nullptr;
+    RouteState *d_rs = nullptr, *h_rs = nullptr;       // h_rs pinned
+    size_t route_rec = 0;                              // record slots the routing arrays hold
+    std::vector<uint32_t> v_rstart, v_rlen;            // host copies for a block the caller routes itself (rare)
+    std::vector<uint8_t> v_rcls, v_tail;
 };
 }  // namespace
 
@@ -98,6 +105,9 @@ struct hast_fq {
     // front of the (short) per-block work hast_fq_next / hast_fq_commit put on the context's stream
     hipStream_t copy_stream = nullptr, parse_stream = nullptr;     // H2D of block k+1 runs while block k is framed
     std::vector<uint8_t> carry;                                // host copy of the previous block's tail (barcodes may lie in it)
+    // routing (hast_fq_set_route): the blocks are not classified; their records leave the GPU as four runs by barcode class
+    bool route = false;
+    std::vector<hast_names *> route_tab;                       // per lane (one for a plain stream): barcode text -> class on that GPU
 };
 
 // Every per-record array of a slot has ONE capacity, h_cap, and is only ever resized here: h_bc = [pos | len | 4 words of
@@ -113,11 +123,11 @@ static hast_status grow_records(Slot &s, size_t cap) {
     s.h_bc = s.h_ids = s.h_unknown = s.d_text = nullptr;
     s.h_pubs = nullptr;
     s.h_cap = 0;
-    FQ_TRY(hipHostMalloc((void **)&s.h_bc, (2 + 4) * cap * sizeof(uint32_t), hipHostMallocDefault));
-    FQ_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
-    FQ_TRY(hipMalloc((void **)&s.d_text, 4 * cap * sizeof(uint32_t)));
-    FQ_TRY(hipHostMalloc((void **)&s.h_unknown, (1 + cap) * sizeof(uint32_t), hipHostMallocDefault));
-    FQ_TRY(hipHostMalloc((void **)&s.h_pubs, cap * sizeof(NamePub), hipHostMallocDefault));
+    FQ_TRY(pinned_malloc((void **)&s.h_bc, (2 + 4) * cap * sizeof(uint32_t), hipHostMallocDefault));
+    FQ_TRY(pinned_malloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
+    FQ_TRY(dev_malloc((void **)&s.d_text, 4 * cap * sizeof(uint32_t)));
+    FQ_TRY(pinned_malloc((void **)&s.h_unknown, (1 + cap) * sizeof(uint32_t), hipHostMallocDefault));
+    FQ_TRY(pinned_malloc((void **)&s.h_pubs, cap * sizeof(NamePub), hipHostMallocDefault));
     s.h_cap = cap;
     return HAST_OK;
 }
@@ -137,8 +147,11 @@ static void free_slot(Slot &s) {
     park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t), 3);
     if (s.named) (void)hipEventDestroy(s.named);
     for (void *p : {(void *)s.d_buf, (void *)s.d_st, (void *)s.d_tile, (void *)s.d_nl, (void *)s.d_off, (void *)s.d_len, (void *)s.d_bcpos,
-                    (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes})
-        park_device(p, p == (void *)s.d_buf ? s.h_buf_bytes : 0, 3);
+                    (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes, (void *)s.d_rstart, (void *)s.d_rlen, (void *)s.d_rtile, (void *)s.d_rcls,
+                    (void *)s.d_out, (void *)s.d_rs})
+        park_device(p, (p == (void *)s.d_buf || p == (void *)s.d_out) ? s.h_buf_bytes : 0, 3);
+    park_pinned(s.h_out, s.h_buf_bytes, 3);
+    park_pinned(s.h_rs, 64, 3);
     if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.parsed) (void)hipEventDestroy(s.parsed);
     if (s.done) (void)hipEventDestroy(s.done);
@@ -148,6 +161,17 @@ static void free_slot(Slot &s) {
 static int dev_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].device : f->device; }
 static hast_ctx *ctx_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].ctx : f->ctx; }
 static hast_names *names_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].names : f->names; }
+
+// Routing streams: behind the framing of a block, on the same stream -- class and extent of every record, prefix sums, the records copied
+// into four runs, the runs and their sizes to pinned host memory (fq_kernels.hip, "routing").  view_bytes bounds what the runs can hold.
+static hast_status enqueue_route(hast_fq *f, Slot &s, hast_names *tab, bool striped, int last, size_t view_bytes, hipStream_t hs) {
+    (void)f;
+    FQ_TRY(launch_fq_route(s.d_buf, s.d_st, s.d_nl, striped ? 1 : 0, last, tab ? tab->d_tab : nullptr, tab ? tab->mask : 0, s.d_rstart, s.d_rlen, s.d_rcls, s.d_rtile,
+                           (uint32_t)s.route_rec, s.d_rs, s.d_out, hs));
+    FQ_TRY(hipMemcpyAsync(s.h_rs, s.d_rs, sizeof(RouteState), hipMemcpyDeviceToHost, hs));
+    if (view_bytes) FQ_TRY(hipMemcpyAsync(s.h_out, s.d_out, std::min(view_bytes, s.h_buf_bytes), hipMemcpyDeviceToHost, hs));
+    return HAST_OK;
+}
 
 // Striped streams: launch the framing of every block that can be framed now, in order.  Block j needs (a) the bytes of block
 // j + 1 that its records may reach into (there once j + 1 has been submitted, or j ends its file) and (b) the number of
@@ -193,6 +217,8 @@ static hast_status advance_striped_once(hast_fq *f, bool wait, size_t upto) {
                                        s.d_bcpos, s.d_bclen, s.h_bc, s.d_text, (uint32_t)s.h_cap, (uint32_t)f->k, ln.parse_stream));
         s.k_cap = s.h_cap;
         FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, ln.parse_stream));
+        if (f->route)
+            if (hast_status st = enqueue_route(f, s, f->route_tab[(size_t)s.lane], true, s.eof_view ? 1 : 0, f->pad + s.n_bytes + s.n_over, ln.parse_stream)) return st;
         FQ_TRY(hipEventRecord(s.parsed, ln.parse_stream));
         f->nl_before = nl_before;
         f->n_framed++;
@@ -283,7 +309,7 @@ hast_status hast_names_create(hast_ctx *ctx, size_t max_barcodes, hast_names **o
     if (!nm) return set_error(HAST_ERR_OOM, "host allocation failed");
     nm->ctx = ctx;
     nm->device = hast_ctx_device(ctx);
-    hipError_t e = hipMalloc((void **)&nm->d_tab, slots * sizeof(NameEntry));
+    hipError_t e = dev_malloc((void **)&nm->d_tab, slots * sizeof(NameEntry));
     if (e == hipSuccess) e = hipMemsetAsync(nm->d_tab, 0, slots * sizeof(NameEntry), ctx_stream_of(ctx));
     if (e != hipSuccess) {
         if (nm->d_tab) (void)hipFree(nm->d_tab);
@@ -304,20 +330,52 @@ void hast_names_destroy(hast_names *nm) {
     delete nm;
 }
 
+// Entries the CALLER knows (text record -> id), e.g. a table barcode -> class for a routing stream (hast_fq_set_route): copied to the
+// device and filed by k_names_insert on the context's stream; returns when they are in.  Texts longer than 15 bytes have no record.
+hast_status hast_names_insert(hast_names *nm, const uint8_t *text16, const uint32_t *ids, size_t n) {
+    if (!nm || (n && (!text16 || !ids))) return set_error(HAST_ERR_INVALID, "null argument");
+    if (nm->count + n > nm->limit) return set_error(HAST_ERR_INVALID, "hast_names_insert: %zu entries + %zu do not fit a table made for %zu", nm->count, n, nm->limit);
+    FQ_TRY(hipSetDevice(nm->device));
+    hipStream_t hs = ctx_stream_of(nm->ctx);
+    const size_t kPiece = 1u << 20;
+    NamePub *h = nullptr, *d = nullptr;
+    FQ_TRY(pinned_malloc((void **)&h, std::min(n, kPiece) * sizeof(NamePub) + 64));
+    if (dev_malloc((void **)&d, std::min(n, kPiece) * sizeof(NamePub) + 64) != hipSuccess) {
+        (void)hipHostFree(h);
+        return set_error(HAST_ERR_OOM, "hast_names_insert: device allocation failed");
+    }
+    hast_status st = HAST_OK;
+    for (size_t at = 0; at < n && st == HAST_OK; at += kPiece) {
+        const size_t m = std::min(kPiece, n - at);
+        for (size_t i = 0; i < m; ++i) {
+            memcpy(h[i].key, text16 + 16 * (at + i), 16);
+            h[i].id = ids[at + i];
+        }
+        hipError_t e = hipMemcpyAsync(d, h, m * sizeof(NamePub), hipMemcpyHostToDevice, hs);
+        if (e == hipSuccess) e = launch_names_insert(d, (uint32_t)m, nm->d_tab, nm->mask, hs);
+        if (e == hipSuccess) e = hipStreamSynchronize(hs);
+        if (e != hipSuccess) st = set_error(HAST_ERR_HIP, "hast_names_insert: %s", hipGetErrorString(e));
+    }
+    (void)hipHostFree(h);
+    (void)hipFree(d);
+    if (st == HAST_OK) nm->count += n;
+    return st;
+}
+
 // buffers + events of one slot, on the current device
 static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, size_t block, bool striped, bool device_blocks = false) {
     // (a stream of device-side blocks pins no host copy of its blocks: ~0.7 ms per MB, 6 x 17 MB per stream -- the copy is made
     // if and when hast_fq_block_host_bytes asks for one)
     s.h_buf_bytes = buf;
-    if (!device_blocks) FQ_TRY(hipHostMalloc((void **)&s.h_buf, buf, hipHostMallocDefault));
-    FQ_TRY(hipHostMalloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault));
-    FQ_TRY(hipMalloc((void **)&s.d_buf, buf));
-    FQ_TRY(hipMalloc((void **)&s.d_st, sizeof(FqState)));
-    FQ_TRY(hipMalloc((void **)&s.d_tile, (buf / 4096 + 2) * sizeof(uint32_t)));
-    FQ_TRY(hipMalloc((void **)&s.d_nl, (buf + 16) * sizeof(uint32_t)));
-    FQ_TRY(hipMalloc((void **)&s.d_off, max_rec * sizeof(uint64_t)));
-    for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) FQ_TRY(hipMalloc((void **)p, max_rec * sizeof(uint32_t)));
-    FQ_TRY(hipMalloc((void **)&s.d_votes, max_rec * 2 * sizeof(uint32_t)));
+    if (!device_blocks) FQ_TRY(pinned_malloc((void **)&s.h_buf, buf, hipHostMallocDefault));
+    FQ_TRY(pinned_malloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault));
+    FQ_TRY(dev_malloc((void **)&s.d_buf, buf));
+    FQ_TRY(dev_malloc((void **)&s.d_st, sizeof(FqState)));
+    FQ_TRY(dev_malloc((void **)&s.d_tile, (buf / 4096 + 2) * sizeof(uint32_t)));
+    FQ_TRY(dev_malloc((void **)&s.d_nl, (buf + 16) * sizeof(uint32_t)));
+    FQ_TRY(dev_malloc((void **)&s.d_off, max_rec * sizeof(uint64_t)));
+    for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) FQ_TRY(dev_malloc((void **)p, max_rec * sizeof(uint32_t)));
+    FQ_TRY(dev_malloc((void **)&s.d_votes, max_rec * 2 * sizeof(uint32_t)));
     // records the pinned per-record arrays hold (34 B each: page pinning is ~0.7 ms per MB, six slots a stream): a record of 100-bp
     // reads is ~240 bytes, of 150-bp reads ~340; a block of shorter ones takes the copy path and grows the arrays (hast_fq_next)
     size_t cap = block / 224 + 4096;
@@ -325,8 +383,8 @@ static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, s
     if (hast_status st = grow_records(s, cap)) return st;
     for (hipEvent_t *e : {&s.named, &s.copied, &s.parsed, &s.done}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (striped) {
-        FQ_TRY(hipHostMalloc((void **)&s.h_cnt, sizeof(FqState), hipHostMallocDefault));
-        FQ_TRY(hipHostMalloc((void **)&s.h_last, 16, hipHostMallocDefault));
+        FQ_TRY(pinned_malloc((void **)&s.h_cnt, sizeof(FqState), hipHostMallocDefault));
+        FQ_TRY(pinned_malloc((void **)&s.h_last, 16, hipHostMallocDefault));
         for (hipEvent_t *e : {&s.counted, &s.over_copied, &s.over_read}) FQ_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     (void)pad;
@@ -560,6 +618,8 @@ static hast_status submit_block(hast_fq *f, size_t n_bytes, int last, bool dev_s
                            s.d_len, s.d_bcpos, s.d_bclen, s.h_bc, s.d_text, (uint32_t)s.h_cap, (uint32_t)f->k, last, hs));
     s.k_cap = s.h_cap;
     FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, hs));
+    if (f->route)
+        if (hast_status st = enqueue_route(f, s, f->route_tab[0], false, last, f->pad + n_bytes, hs)) return st;
     FQ_TRY(hipEventRecord(s.parsed, hs));
     s.state = Slot::SUBMITTED;
     f->n_submitted++;
@@ -580,7 +640,7 @@ hast_status hast_fq_block_host_bytes(hast_fq *f, const uint8_t **bytes) {
     if (s.state != Slot::OPEN) return set_error(HAST_ERR_INVALID, "no open block");
     if (!s.host_view) {
         FQ_TRY(hipSetDevice(dev_of(f, s)));
-        if (!s.h_buf) FQ_TRY(hipHostMalloc((void **)&s.h_buf, s.h_buf_bytes, hipHostMallocDefault));
+        if (!s.h_buf) FQ_TRY(pinned_malloc((void **)&s.h_buf, s.h_buf_bytes, hipHostMallocDefault));
         hipStream_t hs = ctx_stream_of(ctx_of(f, s));
         FQ_TRY(hipMemcpyAsync(s.h_buf, s.d_buf, f->pad + s.n_bytes + s.n_over, hipMemcpyDeviceToHost, hs));
         FQ_TRY(hipStreamSynchronize(hs));
@@ -605,6 +665,7 @@ int hast_fq_poll(hast_fq *f) {
 hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     if (!f || !out) return set_error(HAST_ERR_INVALID, "null argument");
     memset(out, 0, sizeof(*out));
+    if (f->route) return set_error(HAST_ERR_INVALID, "hast_fq_next: the stream routes (hast_fq_next_routed)");
     if (f->n_opened >= f->n_submitted) return set_error(HAST_ERR_INVALID, "hast_fq_next: no submitted block");
     Slot &s = f->slots[f->n_opened % f->slots.size()];
     if (s.state != Slot::SUBMITTED || (f->n_opened && f->slots[(f->n_opened - 1) % f->slots.size()].state == Slot::OPEN))
@@ -669,6 +730,109 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     return HAST_OK;
 }
 
+// From here on the stream ROUTES: its blocks are framed as before but not classified; behind the framing the records of a block are
+// sorted into four runs by the class of their barcode (fq_kernels.hip "routing": steps 10-11 of the wrapper, quartering_fastq.awk) and
+// the runs are copied to pinned host memory; hast_fq_next_routed hands them out.  tables: barcode text -> class (1 paternal, 2 maternal,
+// 3 homozygous), one per lane of a striped stream (contexts of one GPU may share one), made with hast_names_create / hast_names_insert.
+// Only between files: no block may be acquired and not committed.  tables == NULL: back to classifying.
+hast_status hast_fq_set_route(hast_fq *f, hast_names *const *tables, int n_tables) {
+    if (!f) return set_error(HAST_ERR_INVALID, "null argument");
+    for (const Slot &s : f->slots)
+        if (s.state != Slot::FREE) return set_error(HAST_ERR_INVALID, "hast_fq_set_route: a block is in hand (commit it first)");
+    if (!tables) {
+        f->route = false;
+        f->route_tab.clear();
+        return HAST_OK;
+    }
+    const int lanes = f->striped ? (int)f->lanes.size() : 1;
+    if (n_tables != lanes) return set_error(HAST_ERR_INVALID, "hast_fq_set_route: %d tables for a stream of %d lanes", n_tables, lanes);
+    for (int i = 0; i < lanes; ++i)
+        if (!tables[i] || tables[i]->device != (f->striped ? f->lanes[(size_t)i].device : f->device))
+            return set_error(HAST_ERR_INVALID, "hast_fq_set_route: table %d is missing or lives on another device", i);
+    for (Slot &s : f->slots) {
+        if (s.d_out) continue;
+        FQ_TRY(hipSetDevice(dev_of(f, s)));
+        s.route_rec = f->max_rec;
+        FQ_TRY(dev_malloc(&s.d_rstart, s.route_rec * sizeof(uint32_t)));
+        FQ_TRY(dev_malloc(&s.d_rlen, s.route_rec * sizeof(uint32_t)));
+        FQ_TRY(dev_malloc(&s.d_rcls, s.route_rec));
+        FQ_TRY(dev_malloc(&s.d_rtile, (s.route_rec / kRouteTile + 2) * 8 * sizeof(uint32_t)));
+        FQ_TRY(dev_malloc(&s.d_rs, sizeof(RouteState)));
+        FQ_TRY(dev_malloc(&s.d_out, s.h_buf_bytes));
+        FQ_TRY(pinned_malloc(&s.h_out, s.h_buf_bytes));
+        FQ_TRY(pinned_malloc(&s.h_rs, sizeof(RouteState)));
+    }
+    f->route_tab.assign(tables, tables + lanes);
+    f->route = true;
+    // (the next block starts a file: a routing pass reads its inputs from their first byte)
+    f->prev_submitted = -1;
+    f->carry.clear();
+    return HAST_OK;
+}
+
+hast_status hast_fq_next_routed(hast_fq *f, hast_fq_routed *out) {
+    if (!f || !out) return set_error(HAST_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (!f->route) return set_error(HAST_ERR_INVALID, "hast_fq_next_routed: the stream does not route (hast_fq_set_route)");
+    if (f->n_opened >= f->n_submitted) return set_error(HAST_ERR_INVALID, "hast_fq_next_routed: no submitted block");
+    Slot &s = f->slots[f->n_opened % f->slots.size()];
+    if (s.state != Slot::SUBMITTED || (f->n_opened && f->slots[(f->n_opened - 1) % f->slots.size()].state == Slot::OPEN))
+        return set_error(HAST_ERR_INVALID, "hast_fq_next_routed: commit the previous block first");
+    if (f->striped) {
+        if (hast_status a = advance_striped(f, true, f->n_opened + 1)) return a;
+        if (f->n_framed <= f->n_opened)
+            return set_error(HAST_ERR_INVALID, "hast_fq_next_routed: a block of a striped stream is framed once the block behind it has been submitted (or it ends the file)");
+    }
+    FQ_TRY(hipSetDevice(dev_of(f, s)));
+    FQ_TRY(hipEventSynchronize(s.parsed));
+    const FqState st = *s.h_st;
+    const RouteState rs = *s.h_rs;
+    if ((st.flags & 2) || (rs.flags & 2)) return set_error(HAST_ERR_FORMAT, "a FASTQ record is larger than %zu bytes", f->striped ? f->over_cap : f->pad);
+    hipStream_t hs = ctx_stream_of(ctx_of(f, s));
+    uint64_t at = 0;
+    for (int c = 0; c < 4; ++c) {
+        out->count[c] = rs.count[c];
+        out->run[c] = s.h_out + at;
+        out->run_bytes[c] = rs.bytes[c];
+        out->n_records += rs.count[c];
+        at += rs.bytes[c];
+    }
+    if (at > s.h_buf_bytes) return set_error(HAST_ERR_INVALID, "routed runs overflow their buffer");
+    if (rs.flags & 1) {
+        // a record the device could not route: the caller gets the view and every record's extent + class and routes the block itself
+        if (!s.h_buf) FQ_TRY(pinned_malloc(&s.h_buf, s.h_buf_bytes));
+        const size_t view = std::min<size_t>(st.parse_hi, s.h_buf_bytes);
+        s.v_rstart.resize(rs.n_cand);
+        s.v_rlen.resize(rs.n_cand);
+        s.v_rcls.resize(rs.n_cand);
+        FQ_TRY(hipMemcpyAsync(s.h_buf, s.d_buf, view, hipMemcpyDeviceToHost, hs));
+        if (rs.n_cand) {
+            FQ_TRY(hipMemcpyAsync(s.v_rstart.data(), s.d_rstart, rs.n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+            FQ_TRY(hipMemcpyAsync(s.v_rlen.data(), s.d_rlen, rs.n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+            FQ_TRY(hipMemcpyAsync(s.v_rcls.data(), s.d_rcls, rs.n_cand, hipMemcpyDeviceToHost, hs));
+        }
+        FQ_TRY(hipStreamSynchronize(hs));
+        s.host_view = true;
+        out->host_block = 1;
+        out->bytes = s.h_buf;
+        out->rec_start = s.v_rstart.data();
+        out->rec_len = s.v_rlen.data();
+        out->rec_class = s.v_rcls.data();
+        out->n_slots = rs.n_cand;
+    }
+    if (rs.tail_hi > rs.tail_lo) {                         // the partial record at the end of the file: the caller's, by awk's rules
+        s.v_tail.resize(rs.tail_hi - rs.tail_lo);
+        FQ_TRY(hipMemcpyAsync(s.v_tail.data(), s.d_buf + rs.tail_lo, s.v_tail.size(), hipMemcpyDeviceToHost, hs));
+        FQ_TRY(hipStreamSynchronize(hs));
+        out->tail = s.v_tail.data();
+        out->tail_bytes = s.v_tail.size();
+    }
+    if (f->striped) f->records_per_lane[(size_t)s.lane] += out->n_records;
+    s.state = Slot::OPEN;
+    f->n_opened++;
+    return HAST_OK;
+}
+
 hast_status hast_fq_commit(hast_fq *f) {
     if (!f) return set_error(HAST_ERR_INVALID, "null argument");
     if (f->n_opened == 0) return set_error(HAST_ERR_INVALID, "hast_fq_commit without hast_fq_next");
@@ -678,6 +842,11 @@ hast_status hast_fq_commit(hast_fq *f) {
     FQ_TRY(hipSetDevice(dev_of(f, s)));
     hipStream_t hs = ctx_stream_of(sctx);
     const size_t n = s.h_st->n_rec;
+    if (f->route) {                                        // a routed block: the caller is through with its runs, nothing to book
+        s.done_pending = false;
+        s.state = Slot::FREE;
+        return HAST_OK;
+    }
     if (n && !(s.h_st->flags & 1)) {
         const size_t nbc = ctx_n_barcodes(sctx);
         if (s.use_cache) {

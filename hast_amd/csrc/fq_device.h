@@ -45,6 +45,24 @@ hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
                            uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last, hipStream_t s);
 
+// ---- routing (the wrapper's steps 10-11: every record to the file of its barcode's class, quartering_fastq.awk) ----------------
+struct RouteState {            // one per buffer slot, device + a pinned host copy behind the routing kernels
+    uint64_t bytes[4];         // bytes of this block's records per class: 0 nobarcode, 1 paternal, 2 maternal, 3 homozygous
+    uint64_t tail_lo, tail_hi; // the partial record at the end of the FILE (fewer than four newlines): the host routes it, awk's rules
+    uint32_t count[4];         // records per class
+    uint32_t n_cand;           // record slots the kernels walked (records, and candidates of a striped block that are not its own)
+    uint32_t flags;            // 1: a record only the host can route (field longer than 15 bytes, or a barcode no list holds: the ERROR
+                               //    line needs its text); 2: a record that does not end inside the view
+    uint32_t reserved[2];
+};
+constexpr uint8_t kRouteUnclassified = 0xFE, kRouteHost = 0xFF, kRouteSkip = 0xFD;
+constexpr int kRouteTile = 256;                  // records per tile of the per-class prefix sums
+// class + extent of every record of a framed block (d_nl, FqState of the framing kernels), the per-class exclusive prefix sums of the
+// record lengths, and the records copied whole, in input order, into d_out = [class 0 | class 1 | class 2 | class 3]
+hipError_t launch_fq_route(const uint8_t *d_buf, const FqState *d_st, const uint32_t *d_nl, int striped, int last, const NameEntry *tab, uint32_t mask,
+                           uint32_t *d_rstart, uint32_t *d_rlen, uint8_t *d_rcls, uint32_t *d_rtile, uint32_t max_rec, RouteState *d_rs, uint8_t *d_out,
+                           hipStream_t s);
+
 // ---- striped streams: a block is framed on its own, from the number of newlines in front of it ----------------------------
 // newlines of the block's own bytes [pad, pad + n_bytes) -> d_st->n_nl (the host adds them up over the blocks of the file)
 hipError_t launch_fq_count_own(const uint8_t *d_buf, FqState *d_st, uint64_t pad, uint64_t n_bytes, uint32_t *d_tile_cnt, hipStream_t s);

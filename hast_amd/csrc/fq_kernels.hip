@@ -294,6 +294,210 @@ __global__ void __launch_bounds__(256) k_names_insert(const NamePub *pubs, uint3
         }
     }
 }
+
+// ---- routing: steps 10-11 of the wrapper on the GPU (classify_stlfr_reads.sh:155-190, quartering_fastq.awk) -------------------------
+// After `classify` the wrapper runs a single-threaded awk program over every input once more: a record (four lines) goes to
+// <name>.{nobarcode,paternal,maternal,homozygous}.fastq by the class of its barcode.  awk splits a header at every '#' or '/'
+// (-F '#|/'); NF > 1 and $2 != "0_0_0" -> $2 is looked up in the three lists (:22-35), otherwise the read has no barcode (:36-39).
+// Here a lane does that for a record of a framed block: field 2 as a 16-byte text record (length byte + up to 15 bytes, the format of
+// the name cache), looked up in a table text -> class the host filled from its barcode lists.  What the table cannot answer -- a field
+// longer than 15 bytes, a barcode in no list (awk prints an ERROR line with its text and drops the record) -- flags the BLOCK for the
+// host, which then routes that block itself from the same bytes; every other block leaves the GPU as four runs of whole records in
+// input order.
+template <bool STRIPED>
+__device__ __forceinline__ bool route_extent(const FqState *st, const uint32_t *nl, uint32_t c, uint32_t n_cand, int last, uint64_t &h0, uint64_t &h1, uint64_t &end,
+                                             RouteState *rs) {
+    const uint64_t lo = st->parse_lo, hi = st->parse_hi;
+    const uint32_t n_nl = st->n_nl;
+    if (!STRIPED) {                                         // records are lines 4c .. 4c+3 of the parse range (it starts at a record boundary)
+        h0 = c ? (uint64_t)nl[4 * c - 1] + 1 : lo;
+        h1 = nl[4 * c];
+        end = (uint64_t)nl[4 * c + 3] + 1;
+        if (c + 1 == n_cand && last && end < hi) { rs->tail_lo = end; rs->tail_hi = hi; }
+        return true;
+    }
+    const uint32_t s0 = (3u - st->phase) & 3u, has0 = (st->phase == 0 && st->bol) ? 1u : 0u;
+    const uint32_t j = s0 + 4 * (c - has0);
+    h0 = c < has0 ? lo : (uint64_t)nl[j] + 1;
+    if (h0 >= st->own_hi) return false;                     // starts in the next block: not this block's
+    const uint32_t hidx = c < has0 ? 0u : j + 1;
+    if (hidx + 3 >= n_nl) {                                 // fewer than four newlines left in the view
+        if (st->eof) { rs->tail_lo = h0; rs->tail_hi = hi; }    // the end of the file: the host's (at most one candidate gets here)
+        else atomicOr(&rs->flags, 2u);
+        return false;
+    }
+    h1 = nl[hidx];
+    end = (uint64_t)nl[hidx + 3] + 1;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t route_candidates(const FqState *st, bool striped) {
+    const uint32_t n_nl = st->n_nl;
+    if (!striped) return n_nl / 4;
+    const uint32_t s0 = (3u - st->phase) & 3u, has0 = (st->phase == 0 && st->bol) ? 1u : 0u;
+    return has0 + (n_nl > s0 ? (n_nl - s0 + 3) / 4 : 0);
+}
+
+template <bool STRIPED>
+__global__ void __launch_bounds__(kRouteTile) k_route_class(const uint8_t *buf, const FqState *st, const uint32_t *nl, int last, const NameEntry *tab, uint32_t mask,
+                                                            uint32_t *r_start, uint32_t *r_len, uint8_t *r_cls, uint32_t *tile_sum, uint32_t max_rec, RouteState *rs) {
+    uint32_t n_cand = route_candidates(st, STRIPED);
+    if (n_cand > max_rec) n_cand = max_rec;                 // (cannot be: a record holds four newlines; the arrays hold view / 4)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        rs->n_cand = n_cand;
+        if (!STRIPED && last && n_cand == 0 && st->parse_lo < st->parse_hi) { rs->tail_lo = st->parse_lo; rs->tail_hi = st->parse_hi; }
+    }
+    __shared__ uint32_t s_sum[8];
+    const uint32_t n_tiles = (n_cand + kRouteTile - 1) / kRouteTile;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x < 8) s_sum[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t c = tile * kRouteTile + threadIdx.x;
+        if (c < n_cand) {
+            uint64_t h0 = 0, h1 = 0, end = 0;
+            uint8_t cls = kRouteSkip;
+            uint32_t len = 0;
+            if (route_extent<STRIPED>(st, nl, c, n_cand, last, h0, h1, end, rs)) {
+                len = (uint32_t)(end - h0);
+                // awk's $2 under -F '#|/': the text between the first separator and the next one (or the end of the line)
+                uint64_t a = h1;
+                for (uint64_t p = h0; p < h1; ++p) {
+                    const uint8_t ch = buf[p];
+                    if (ch == '#' || ch == '/') { a = p; break; }
+                }
+                if (a == h1) cls = 0;                       // NF <= 1 (:22,36-39)
+                else {
+                    uint64_t b = h1;
+                    for (uint64_t p = a + 1; p < h1; ++p) {
+                        const uint8_t ch = buf[p];
+                        if (ch == '#' || ch == '/') { b = p; break; }
+                    }
+                    const uint32_t fl = (uint32_t)(b - a - 1);
+                    if (fl > 15) cls = kRouteHost;
+                    else {
+                        uint32_t w[4] = {fl, 0, 0, 0};
+                        for (uint32_t q = 0; q < fl; ++q) w[(q + 1) >> 2] |= (uint32_t)buf[a + 1 + q] << (8 * ((q + 1) & 3));
+                        if (w[0] == 0x305F3005u && w[1] == 0x0000305Fu) cls = 0;       // "0_0_0" (:22): length 5, then the text
+                        else {
+                            cls = kRouteUnclassified;
+                            uint32_t at = name_hash(w) & mask;
+                            for (uint32_t probe = 0; tab && probe <= mask; ++probe, at = (at + 1) & mask) {
+                                const NameEntry &e = tab[at];
+                                if (e.state == 0) break;
+                                if (e.state == 2 && e.key[0] == w[0] && e.key[1] == w[1] && e.key[2] == w[2] && e.key[3] == w[3]) { cls = (uint8_t)e.id; break; }
+                            }
+                        }
+                    }
+                }
+                if (cls >= kRouteUnclassified) atomicOr(&rs->flags, 1u);
+                else {
+                    atomicAdd(&s_sum[cls], len);
+                    atomicAdd(&s_sum[4 + cls], 1u);
+                }
+            }
+            r_start[c] = (uint32_t)h0;
+            r_len[c] = len;
+            r_cls[c] = cls;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) tile_sum[(size_t)tile * 8 + threadIdx.x] = s_sum[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// exclusive scan of the tiles' byte sums per class, in place; totals and class counts -> rs.  One workgroup.
+__global__ void __launch_bounds__(1024) k_route_scan(uint32_t *tile_sum, RouteState *rs) {
+    __shared__ uint32_t s_part[4][1024];
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t n = (rs->n_cand + kRouteTile - 1) / kRouteTile;
+    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    uint32_t sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+    for (uint32_t i = lo; i < hi; ++i)
+        for (int c = 0; c < 4; ++c) { sum[c] += tile_sum[(size_t)i * 8 + c]; cnt[c] += tile_sum[(size_t)i * 8 + 4 + c]; }
+    for (int c = 0; c < 4; ++c) s_part[c][threadIdx.x] = sum[c];
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) if (cnt[c]) atomicAdd(&s_cnt[c], cnt[c]);
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v[4];
+        for (int c = 0; c < 4; ++c) v[c] = threadIdx.x >= d ? s_part[c][threadIdx.x - d] : 0;
+        __syncthreads();
+        for (int c = 0; c < 4; ++c) s_part[c][threadIdx.x] += v[c];
+        __syncthreads();
+    }
+    // class c's run starts behind the runs of the classes in front of it
+    uint32_t base[4];
+    base[0] = 0;
+    for (int c = 1; c < 4; ++c) base[c] = base[c - 1] + s_part[c - 1][1023];
+    uint32_t run[4];
+    for (int c = 0; c < 4; ++c) run[c] = base[c] + (threadIdx.x ? s_part[c][threadIdx.x - 1] : 0);
+    for (uint32_t i = lo; i < hi; ++i)
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t v = tile_sum[(size_t)i * 8 + c];
+            tile_sum[(size_t)i * 8 + c] = run[c];
+            run[c] += v;
+        }
+    if (threadIdx.x < 4) {
+        rs->bytes[threadIdx.x] = s_part[threadIdx.x][1023];
+        rs->count[threadIdx.x] = s_cnt[threadIdx.x];
+    }
+}
+
+// the records of a tile to their places: a lane per record finds its offset (prefix sum over the records of its class in front of
+// it in the tile), then every wave copies its 64 records one after the other, 64 bytes per step
+__global__ void __launch_bounds__(kRouteTile) k_route_copy(const uint8_t *buf, const uint32_t *r_start, const uint32_t *r_len, const uint8_t *r_cls,
+                                                           const uint32_t *tile_base, const RouteState *rs, uint8_t *out) {
+    __shared__ uint32_t s_src[kRouteTile], s_dst[kRouteTile], s_n[kRouteTile];
+    __shared__ uint32_t s_wave[4][4];
+    const uint32_t n_cand = rs->n_cand, n_tiles = (n_cand + kRouteTile - 1) / kRouteTile;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t c = tile * kRouteTile + threadIdx.x;
+        const uint8_t cls = c < n_cand ? r_cls[c] : kRouteSkip;
+        const uint32_t len = (c < n_cand && cls < 4) ? r_len[c] : 0;
+        uint32_t incl[4];
+        for (int k = 0; k < 4; ++k) {
+            uint32_t v = cls == k ? len : 0;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(v, off, 64);
+                if (lane >= (uint32_t)off) v += u;
+            }
+            incl[k] = v;
+            if (lane == 63) s_wave[wave][k] = v;
+        }
+        __syncthreads();
+        uint32_t dst = 0;
+        if (cls < 4) {
+            dst = tile_base[(size_t)tile * 8 + cls] + incl[cls] - len;
+            for (uint32_t w = 0; w < wave; ++w) dst += s_wave[w][cls];
+        }
+        s_src[threadIdx.x] = c < n_cand ? r_start[c] : 0;
+        s_dst[threadIdx.x] = dst;
+        s_n[threadIdx.x] = len;
+        __syncthreads();
+        for (uint32_t r = 0; r < 64; ++r) {
+            const uint32_t i = wave * 64 + r;
+            const uint32_t n = s_n[i];
+            const uint8_t *src = buf + s_src[i];
+            uint8_t *d = out + s_dst[i];
+            for (uint32_t b = lane; b < n; b += 64) d[b] = src[b];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_fq_route(const uint8_t *d_buf, const FqState *d_st, const uint32_t *d_nl, int striped, int last, const NameEntry *tab, uint32_t mask,
+                           uint32_t *d_rstart, uint32_t *d_rlen, uint8_t *d_rcls, uint32_t *d_rtile, uint32_t max_rec, RouteState *d_rs, uint8_t *d_out,
+                           hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_rs, 0, sizeof(RouteState), s);
+    if (e != hipSuccess) return e;
+    if (striped) hipLaunchKernelGGL(k_route_class<true>, dim3(1024), dim3(kRouteTile), 0, s, d_buf, d_st, d_nl, last, tab, mask, d_rstart, d_rlen, d_rcls, d_rtile, max_rec, d_rs);
+    else hipLaunchKernelGGL(k_route_class<false>, dim3(1024), dim3(kRouteTile), 0, s, d_buf, d_st, d_nl, last, tab, mask, d_rstart, d_rlen, d_rcls, d_rtile, max_rec, d_rs);
+    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, d_rtile, d_rs);
+    hipLaunchKernelGGL(k_route_copy, dim3(2048), dim3(kRouteTile), 0, s, d_buf, d_rstart, d_rlen, d_rcls, d_rtile, d_rs, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_fq_name(const uint32_t *d_text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fq_name, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, tab, mask, h_ids, h_unknown);

@@ -56,11 +56,11 @@ struct DevBuf {                               // a device allocation that only e
         park_device(p, bytes, 2);                              // (not hipFree: it waits for every stream of the device, hast_internal.h)
         p = nullptr;
         bytes = 0;
-        hipError_t e = hipMalloc(&p, need);
+        hipError_t e = dev_malloc(&p, need);
         if (e == hipErrorOutOfMemory) {                        // (what closed streams left parked may be what is missing)
             (void)hipGetLastError();
             release_parked();
-            e = hipMalloc(&p, need);
+            e = dev_malloc(&p, need);
         }
         if (e == hipSuccess) bytes = need;
         else p = nullptr;
@@ -235,7 +235,7 @@ void upload_loop(hast_gz *g) {
     std::vector<hipEvent_t> ev[2];
     std::string bad;
     for (int i = 0; i < 2 && bad.empty(); ++i) {
-        if (hipHostMalloc((void **)&h[i], g->piece + kInPad, hipHostMallocPortable) != hipSuccess) bad = "gz: pinned staging allocation failed";
+        if (pinned_malloc((void **)&h[i], g->piece + kInPad, hipHostMallocPortable) != hipSuccess) bad = "gz: pinned staging allocation failed";
         ev[i].assign(nu, nullptr);
         for (size_t u = 0; u < nu && bad.empty(); ++u)
             if (hipSetDevice(g->units[u]->device) != hipSuccess || hipEventCreateWithFlags(&ev[i][u], hipEventDisableTiming) != hipSuccess) bad = "gz: pinned staging allocation failed";
@@ -294,6 +294,10 @@ void upload_loop(hast_gz *g) {
             n_up = n + kInPad;
         }
         const uint64_t pos = g->ring ? off % g->ring : off;
+        if (g->ring && off && pos < P) {                          // (this piece starts a new lap)
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->st.ring_laps++;
+        }
         for (size_t u = 0; u < nu && bad.empty(); ++u) {
             Unit &U = *g->units[u];
             uint8_t *const d = reinterpret_cast<uint8_t *>(U.d_in);
@@ -439,10 +443,16 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
                     (unsigned long long)j.stop_bit, j.flags, j.status, (unsigned long long)j.start_bit, (unsigned long long)j.end_bit, j.n_out, j.err_code, (unsigned long long)j.in_adj_words,
                     (unsigned long long)j.limit_bits, (unsigned long long)input_bits);
         }
+    // (chain_walk_s: what the host does ALONE between the kernels -- accepting chunks, planning follow-up jobs, combining CRCs: the
+    // serial share of one deflate stream however many GPUs decode its passes)
+    double t_cw = now_s();
     g->chain.add_candidates(U.h_jobs[g->jobs_of(N.k)], N.n_jobs, all_in);
     // ---- the chain, with its follow-up jobs ------------------------------------------------------------------------------------
     std::vector<Chain::Gap> gaps;
-    while (g->chain.plan(gaps, input_bits)) {
+    for (;;) {
+        const bool more = g->chain.plan(gaps, input_bits);
+        g->st.chain_walk_s += now_s() - t_cw;
+        if (!more) break;
         if (gaps.size() > g->h_jobs_cap) return "gz: internal: more follow-up jobs than chunks";
         size_t total = 0;
         std::vector<size_t> at(gaps.size());
@@ -467,6 +477,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         GZ_HIP(launch_decode((ChunkJob *)U.fjobs.p, (uint32_t)gaps.size(), U.d_in, input_bits, (uint16_t *)gb.p, U.post_stream));
         GZ_HIP(hipMemcpyAsync(U.h_fjobs, U.fjobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, U.post_stream));
         GZ_HIP(hipStreamSynchronize(U.post_stream));
+        t_cw = now_s();
         g->chain.gap_done(U.h_fjobs, gaps.size(), input_bits);
         g->st.followup_jobs += gaps.size();
         g->st.followup_rounds++;
@@ -476,7 +487,9 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
     std::unique_ptr<Batch> b(new Batch);
     b->unit = (int)(N.k % g->units.size());
     b->arena = (int)((N.k / g->units.size()) % (size_t)g->n_arenas);
+    t_cw = now_s();
     g->chain.take_confirmed(b->acc);
+    g->st.chain_walk_s += now_s() - t_cw;
     const size_t n = b->acc.size();
     std::string bad;
     if (n) {
@@ -500,7 +513,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
             park_pinned(U.h_crc, 0, 2);
             U.h_crc = nullptr;
             U.h_crc_cap = 0;
-            GZ_HIP(hipHostMalloc((void **)&U.h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
+            GZ_HIP(pinned_malloc((void **)&U.h_crc, (n + n / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
             U.h_crc_cap = n + n / 2 + 64;
         }
         // (pageable source: the copy is done with `host` when the call returns)
@@ -514,6 +527,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         GZ_HIP(hipStreamSynchronize(U.post_stream));                        // (h_carry has been read: the copy above is through)
         GZ_HIP(hipMemcpyAsync(g->h_carry, (uint8_t *)A.windows.p + (n - 1) * (size_t)kWindow, kWindow, hipMemcpyDeviceToHost, U.post_stream));
         GZ_HIP(hipStreamSynchronize(U.post_stream));
+        t_cw = now_s();
         for (size_t i = 0; i < n && bad.empty(); ++i) {
             const Accepted &a = b->acc[i];
             const uint32_t len = a.job.n_out;
@@ -532,6 +546,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
             }
             if (a.is_gap) g->st.followup_accepted++;
         }
+        g->st.chain_walk_s += now_s() - t_cw;
         g->st.accepted += n;
         g->st.out_bytes = b->out_hi;
         g->st.windows_crc_s += now_s() - t_w0;
@@ -708,14 +723,14 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     };
     g->h_jobs_cap = seg + 8;
     step(hipSetDevice(g->units[0]->device));
-    step(hipHostMalloc((void **)&g->h_carry, kWindow, hipHostMallocPortable));
+    step(pinned_malloc((void **)&g->h_carry, kWindow, hipHostMallocPortable));
     if (e == hipSuccess) memset(g->h_carry, 0, kWindow);
     for (size_t ui = 0; ui < nu && e == hipSuccess; ++ui) {
         Unit &U = *g->units[ui];
         step(hipSetDevice(U.device));
         // the file's bytes, then zeros: the kernels read whole words and a little past the last real bit
         const uint64_t alloc = g->ring ? g->ring + g->piece + 2 * kInPad : ((g->file_size + 3) & ~(uint64_t)3) + kInPad, tail_from = g->file_size & ~(uint64_t)3;
-        step(hipMalloc((void **)&U.d_in, alloc));
+        step(dev_malloc((void **)&U.d_in, alloc));
         tr("input buffer");
         step(hipStreamCreateWithFlags(&U.up_stream, hipStreamNonBlocking));
         // (on the stream the file's pieces will come in on: a hipMemset of device memory does not wait for the host, and nothing orders
@@ -744,11 +759,11 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         step(hipEventCreateWithFlags(&U.xl_done, hipEventDisableTiming));
         tr("streams");
         for (int i = 0; i < 2; ++i) {
-            step(hipHostMalloc((void **)&U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+            step(pinned_malloc((void **)&U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
             step(U.jobs[i].ensure(g->h_jobs_cap * sizeof(ChunkJob)));
             step(hipEventCreateWithFlags(&U.nom_done[i], hipEventDisableTiming));
         }
-        step(hipHostMalloc((void **)&U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
+        step(pinned_malloc((void **)&U.h_fjobs, g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
         step(U.fjobs.ensure(g->h_jobs_cap * sizeof(ChunkJob)));
         for (Arena &a : U.arena) step(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
         tr("job buffers");

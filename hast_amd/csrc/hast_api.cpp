@@ -106,6 +106,9 @@ struct hast_ctx {
     FilterGeom fg{};
     bool filter_valid = false;
     bool use_filter = true;                 // HAST_CLASSIFY=exact: probe the exact table directly (the round-1 kernel)
+    size_t filter_fallback_bytes = 0;       // != 0: the filter was wanted, this many bytes could not be had (also after the parked memory was
+                                            // freed), and the context probes the table directly -- hast_ctx_options / --stats say so
+    bool test_filter_oom = false;           // HAST_TEST_FILTER_OOM=1 (tests): the filter's allocation fails
     int filter_m = 0, filter_t = 0, filter_kp = 0;   // overrides (0 = by K and key count)
     int filter_exact = -1;                           // -1: exact entries where they fit (hast_common.h), 0: prints always
     int text_acgt_only = 0;                          // k-mer text lines must be upper-case A/C/G/T (hast_ctx_set_text_check)
@@ -146,7 +149,7 @@ hast_status ensure_scratch(hast_ctx *c, size_t bytes) {
     if (c->d_scratch) HIP_TRY(hipFree(c->d_scratch));
     c->d_scratch = nullptr;
     c->scratch_bytes = 0;
-    HIP_TRY(hipMalloc(&c->d_scratch, bytes));
+    HIP_TRY(dev_malloc(&c->d_scratch, bytes));
     c->scratch_bytes = bytes;
     return HAST_OK;
 }
@@ -218,11 +221,44 @@ Parked &parked() {
     static Parked *p = new Parked();                       // (never destroyed: streams may be closed from threads that outlive main's statics)
     return *p;
 }
-size_t park_limit() {
-    const char *e = getenv("HAST_PARK_GB");
-    return (size_t)((e ? atof(e) : 32.0) * 1073741824.0);
+size_t park_limit() {                                      // (the environment is read once, like every other switch: INTEGRATION.md)
+    static const size_t limit = [] {
+        const char *e = getenv("HAST_PARK_GB");
+        return (size_t)((e ? atof(e) : 32.0) * 1073741824.0);
+    }();
+    return limit;
+}
+int park_sites() {
+    static const int sites = [] {
+        const char *e = getenv("HAST_PARK_SITES");
+        return e ? atoi(e) : -1;
+    }();
+    return sites;
 }
 }  // namespace
+size_t parked_bytes() {
+    Parked &pk = parked();
+    std::lock_guard<std::mutex> lk(pk.mu);
+    return pk.bytes;
+}
+hipError_t dev_malloc(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && parked_bytes()) {          // (what closed streams left parked may be exactly what is missing)
+        (void)hipGetLastError();
+        release_parked();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+hipError_t pinned_malloc(void **p, size_t bytes, unsigned flags) {
+    hipError_t e = hipHostMalloc(p, bytes, flags);
+    if (e == hipErrorOutOfMemory && parked_bytes()) {
+        (void)hipGetLastError();
+        release_parked();
+        e = hipHostMalloc(p, bytes, flags);
+    }
+    return e;
+}
 void release_parked() {
     std::vector<void *> d, h;
     {
@@ -238,7 +274,7 @@ void release_parked() {
 static void park(void *p, size_t bytes, bool pinned, int site) {
     if (!p) return;
     size_t limit = park_limit();
-    if (const char *e = getenv("HAST_PARK_SITES")) if (!((atoi(e) >> site) & 1)) limit = 0;      // (bisecting: only these sites park)
+    if (!((park_sites() >> site) & 1)) limit = 0;              // (HAST_PARK_SITES, bisecting: only these sites park)
     if (limit == 0) {
         (void)(pinned ? hipHostFree(p) : hipFree(p));
         return;
@@ -291,6 +327,7 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     c->k = k;
     c->m = default_minimizer(k);
     if (const char *e = getenv("HAST_CLASSIFY")) c->use_filter = strcmp(e, "exact") != 0;
+    if (const char *e = getenv("HAST_TEST_FILTER_OOM")) c->test_filter_oom = atoi(e) != 0;
     if (const char *e = getenv("HAST_FILTER_M")) c->filter_m = atoi(e);
     if (const char *e = getenv("HAST_FILTER_T")) c->filter_t = atoi(e);
     if (const char *e = getenv("HAST_FILTER_KP")) c->filter_kp = atoi(e);
@@ -312,10 +349,10 @@ hast_status hast_ctx_create(int device, int k, hast_ctx **out) {
     };
     bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
     tr("hipStreamCreate");
-    bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
+    bail(dev_malloc(&c->d_err, 4 * sizeof(uint32_t)), "dev_malloc(err)");
     tr("first hipMalloc");
-    bail(hipMalloc(&c->d_cnt, 8 * sizeof(unsigned long long)), "hipMalloc(cnt)");
-    bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_errword), 64, hipHostMallocDefault), "hipHostMalloc(err word)");
+    bail(dev_malloc(&c->d_cnt, 8 * sizeof(unsigned long long)), "dev_malloc(cnt)");
+    bail(pinned_malloc(reinterpret_cast<void **>(&c->h_errword), 64, hipHostMallocDefault), "pinned_malloc(err word)");
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), c->stream), "hipMemset");
     if (st == HAST_OK) bail(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     tr("first fill + synchronize");
@@ -390,12 +427,22 @@ hast_status hast_stream_sync(hast_ctx *c, hast_stream s) {
 hast_status hast_dev_alloc(hast_ctx *c, size_t bytes, void **d_out) {
     if (hast_status st = use(c)) return st;
     if (!d_out) return fail(HAST_ERR_INVALID, "d_out is null");
-    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    HIP_TRY(dev_malloc(d_out, bytes ? bytes : 1));
     return HAST_OK;
 }
 hast_status hast_dev_free(hast_ctx *c, void *p) {
     if (hast_status st = use(c)) return st;
     if (p) HIP_TRY(hipFree(p));
+    return HAST_OK;
+}
+// free / total memory of the context's device as the runtime sees it, and what the library holds parked (hast_release_parked)
+hast_status hast_dev_mem_info(hast_ctx *c, size_t *free_bytes, size_t *total_bytes, size_t *parked) {
+    if (hast_status st = use(c)) return st;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (parked) *parked = parked_bytes();
     return HAST_OK;
 }
 hast_status hast_memcpy_h2d(hast_ctx *c, void *d, const void *s, size_t n) {
@@ -432,7 +479,7 @@ hast_status hast_table_reserve(hast_ctx *c, uint64_t max_keys, double lf) {
     c->filter_valid = false;
     // K == 32: two tag-less tables (one per haplotype) back to back, each sized for all the keys
     size_t bytes = (size_t)nb * kSlotsPerBucket * sizeof(uint64_t) * (c->k == 32 ? 2 : 1);
-    HIP_TRY(hipMalloc(&c->d_slots, bytes));
+    HIP_TRY(dev_malloc(&c->d_slots, bytes));
     HIP_TRY(hipMemsetAsync(c->d_slots, 0xFF, bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->nbuckets = (uint32_t)nb;
@@ -519,8 +566,8 @@ static hast_status stream_file_region(hast_ctx *c, int fd, const char *path, uin
     hipError_t e = hipSuccess;
     bool short_read = false;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        if (!h_buf[i]) e = hipHostMalloc((void **)&h_buf[i], kPieceBytes, hipHostMallocDefault);
-        if (e == hipSuccess && !d_buf[i]) e = hipMalloc((void **)&d_buf[i], kPieceBytes + 16);
+        if (!h_buf[i]) e = pinned_malloc((void **)&h_buf[i], kPieceBytes, hipHostMallocDefault);
+        if (e == hipSuccess && !d_buf[i]) e = dev_malloc((void **)&d_buf[i], kPieceBytes + 16);
         if (e == hipSuccess && !done[i]) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) {
@@ -653,7 +700,7 @@ hast_status hast_table_save(hast_ctx *c, const char *path) {
     if (hast_status st = hast_table_sizes(c, &n0, &n1)) return st;
     const size_t cap = (size_t)(n0 + n1) + 16;                    // distinct live keys <= n0 + n1
     uint64_t *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, cap * sizeof(uint64_t)));
+    HIP_TRY(dev_malloc((void **)&d_out, cap * sizeof(uint64_t)));
     unsigned long long n = 0;
     hipError_t e = hipMemsetAsync(c->d_cnt, 0, sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = launch_export_slots(c->d_slots, (size_t)c->nbuckets * kSlotsPerBucket, d_out, cap, c->d_cnt, c->stream);
@@ -667,8 +714,8 @@ hast_status hast_table_save(hast_ctx *c, const char *path) {
         void *d_tmp = nullptr;
         size_t tmp_bytes = 0;
         if (n) e = kc_sort_keys(nullptr, &tmp_bytes, (unsigned long long *)d_out, nullptr, (size_t)n, 32, c->stream);
-        if (e == hipSuccess && n) e = hipMalloc((void **)&d_sorted, (size_t)n * sizeof(uint64_t));
-        if (e == hipSuccess && n) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
+        if (e == hipSuccess && n) e = dev_malloc((void **)&d_sorted, (size_t)n * sizeof(uint64_t));
+        if (e == hipSuccess && n) e = dev_malloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
         if (e == hipSuccess && n) e = kc_sort_keys(d_tmp, &tmp_bytes, (unsigned long long *)d_out, (unsigned long long *)d_sorted, (size_t)n, 32, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         host.resize((size_t)n);
@@ -763,7 +810,7 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
     dst->filter_valid = false;
     dst->m = src->m;
     const size_t bytes = table_slots(src) * sizeof(uint64_t);
-    HIP_TRY(hipMalloc(&dst->d_slots, bytes));
+    HIP_TRY(dev_malloc(&dst->d_slots, bytes));
     // ON dst's stream, and waited for below: hipMemcpyPeer between two contexts of ONE GPU is a device-to-device copy, which does not
     // wait for the host -- and dst's stream is a non-blocking one, so nothing would order the reads classified on it behind the copy
     // (seen with --devices 0,0,0 HAST_DEAL=files: a context's first blocks probed a table that was still arriving and lost hits; until
@@ -775,10 +822,11 @@ hast_status hast_table_clone(hast_ctx *dst, hast_ctx *src) {
             if (dst->d_filter) HIP_TRY(hipFree(dst->d_filter));
             dst->d_filter = nullptr;
             dst->filter_bytes = 0;
-            if (hipMalloc(&dst->d_filter, src->filter_bytes) != hipSuccess) {
+            if (dst->test_filter_oom || dev_malloc(&dst->d_filter, src->filter_bytes) != hipSuccess) {
                 (void)hipGetLastError();
                 dst->d_filter = nullptr;
                 dst->use_filter = false;                   // no room: this device probes the table directly
+                dst->filter_fallback_bytes = src->filter_bytes;
                 HIP_TRY(hipStreamSynchronize(dst->stream));
                 return HAST_OK;
             }
@@ -812,7 +860,7 @@ hast_status hast_counts_resize(hast_ctx *c, size_t n) {
     c->n_barcodes = 0;
     c->counts_owned = false;
     size_t bytes = (n ? n : 1) * 4 * sizeof(unsigned long long);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_counts), bytes));
+    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&c->d_counts), bytes));
     c->counts_owned = true;
     c->n_barcodes = n;
     HIP_TRY(hipMemsetAsync(c->d_counts, 0, bytes, c->stream));
@@ -844,7 +892,7 @@ static hast_status ensure_pack(hast_ctx *c, size_t n) {
     if (c->d_pack) HIP_TRY(hipFree(c->d_pack));
     c->d_pack = nullptr;
     c->pack_words = 0;
-    HIP_TRY(hipMalloc((void **)&c->d_pack, std::max<size_t>(3 * n, 1) * sizeof(unsigned long long)));
+    HIP_TRY(dev_malloc((void **)&c->d_pack, std::max<size_t>(3 * n, 1) * sizeof(unsigned long long)));
     c->pack_words = 3 * n;
     return HAST_OK;
 }
@@ -882,30 +930,52 @@ hast_status hast_counts_read(hast_ctx *c, uint64_t *c0, uint64_t *c1, uint64_t *
 }
 
 // RCCL, resolved lazily so that single-GPU users never load it.
+// Any device list: contexts that share a GPU (a logical split, e.g. classify --devices 0,0 on a single-GPU box, or 0,0,1,1) are summed
+// by a kernel on that GPU into its first context (the leader), the leaders of DISTINCT GPUs then run the one RCCL all-reduce (a
+// communicator has one rank per GPU), and every leader hands the totals back to the contexts behind it.
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
     if (!ctxs || n < 1) return fail(HAST_ERR_INVALID, "no contexts");
-    // contexts that all sit on ONE device (a logical split, e.g. classify --devices 0,0 on a single-GPU box) need no
-    // exchange between GPUs: their counters are summed by a kernel on that device
-    if (n > 1 && ctxs[0]) {
-        bool same = true;
-        for (int i = 1; i < n; i++) same = same && ctxs[i] && ctxs[i]->device == ctxs[0]->device;
-        if (same) {
-            if (hast_status st = use(ctxs[0])) return st;
-            for (int i = 0; i < n; i++) {
-                if (!ctxs[i]->d_counts || ctxs[i]->n_barcodes != ctxs[0]->n_barcodes) return fail(HAST_ERR_INVALID, "contexts need equal-size counters");
-                HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
-            }
-            const size_t nw = ctxs[0]->n_barcodes * 4;
-            for (int i = 1; i < n; i++) HIP_TRY(launch_add_u64(ctxs[0]->d_counts, ctxs[i]->d_counts, nw, ctxs[0]->stream));
-            for (int i = 1; i < n; i++)
-                HIP_TRY(hipMemcpyAsync(ctxs[i]->d_counts, ctxs[0]->d_counts, nw * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctxs[0]->stream));
-            HIP_TRY(hipStreamSynchronize(ctxs[0]->stream));
-            return HAST_OK;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i] || !ctxs[i]->d_counts || ctxs[i]->n_barcodes != ctxs[0]->n_barcodes) return fail(HAST_ERR_INVALID, "contexts need equal-size counters");
+    const size_t nbc = ctxs[0]->n_barcodes, nw = nbc * 4;
+    // leaders: the first context of every device, in the order of the list; members[l] = the contexts behind leader l
+    std::vector<hast_ctx *> lead;
+    std::vector<std::vector<hast_ctx *>> members;
+    for (int i = 0; i < n; i++) {
+        size_t l = 0;
+        while (l < lead.size() && lead[l]->device != ctxs[i]->device) ++l;
+        if (l == lead.size()) {
+            lead.push_back(ctxs[i]);
+            members.emplace_back();
+        } else {
+            for (hast_ctx *m : members[l]) if (m == ctxs[i]) return fail(HAST_ERR_INVALID, "hast_counts_allreduce: a context is named twice");
+            if (lead[l] == ctxs[i]) return fail(HAST_ERR_INVALID, "hast_counts_allreduce: a context is named twice");
+            members[l].push_back(ctxs[i]);
         }
     }
-    // a single context needs no exchange; HAST_FORCE_RCCL=1 still runs the RCCL path (1-rank communicator), which
+    // 1. per device: the members' counters into the leader's
+    for (size_t l = 0; l < lead.size(); l++) {
+        if (members[l].empty()) continue;
+        if (hast_status st = use(lead[l])) return st;
+        HIP_TRY(hipStreamSynchronize(lead[l]->stream));
+        for (hast_ctx *m : members[l]) HIP_TRY(hipStreamSynchronize(m->stream));
+        for (hast_ctx *m : members[l]) HIP_TRY(launch_add_u64(lead[l]->d_counts, m->d_counts, nw, lead[l]->stream));
+    }
+    // 3. (after the exchange) per device: the totals back to the members
+    auto hand_back = [&]() -> hast_status {
+        for (size_t l = 0; l < lead.size(); l++) {
+            if (members[l].empty()) continue;
+            if (hast_status st = use(lead[l])) return st;
+            for (hast_ctx *m : members[l])
+                HIP_TRY(hipMemcpyAsync(m->d_counts, lead[l]->d_counts, nw * sizeof(unsigned long long), hipMemcpyDeviceToDevice, lead[l]->stream));
+            HIP_TRY(hipStreamSynchronize(lead[l]->stream));
+        }
+        return HAST_OK;
+    };
+    // a single GPU needs no exchange; HAST_FORCE_RCCL=1 still runs the RCCL path (1-rank communicator), which
     // is how a 1-GPU box checks the library loading, symbols and enum values used for N > 1
-    if (n == 1 && !getenv("HAST_FORCE_RCCL")) return HAST_OK;
+    const int nl = (int)lead.size();
+    if (nl == 1 && !getenv("HAST_FORCE_RCCL")) return hand_back();
     typedef void *comm_t;
     typedef int (*init_all_t)(comm_t *, int, const int *);
     typedef int (*allreduce_t)(const void *, void *, size_t, int, int, comm_t, hipStream_t);
@@ -921,18 +991,8 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
     auto gend = (group_t)dlsym(lib, "ncclGroupEnd");
     auto destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
     if (!init_all || !allreduce || !gstart || !gend || !destroy) return fail(HAST_ERR_RCCL, "librccl lacks symbols");
-    std::vector<int> devs(n);
-    for (int i = 0; i < n; i++) {
-        if (!ctxs[i] || !ctxs[i]->d_counts || ctxs[i]->n_barcodes != ctxs[0]->n_barcodes)
-            return fail(HAST_ERR_INVALID, "contexts need equal-size counters");
-        devs[i] = ctxs[i]->device;
-    }
-    {
-        std::vector<int> sorted(devs);
-        std::sort(sorted.begin(), sorted.end());
-        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
-            return fail(HAST_ERR_INVALID, "hast_counts_allreduce: two contexts on one device (a communicator has one rank per GPU)");
-    }
+    std::vector<int> devs(nl);
+    for (int i = 0; i < nl; i++) devs[i] = lead[(size_t)i]->device;
     // one communicator clique per device list, kept for the life of the process: ncclCommInitAll costs hundreds of ms on 8
     // GPUs, and the CLI merges at every counter regrowth (classify_main.cpp) as well as at the end
     static std::mutex comm_mu;
@@ -940,37 +1000,39 @@ hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n) {
     std::lock_guard<std::mutex> lock(comm_mu);
     auto it = comm_cache.find(devs);
     if (it == comm_cache.end()) {
-        std::vector<comm_t> fresh(n);
-        if (int rc = init_all(fresh.data(), n, devs.data())) return fail(HAST_ERR_RCCL, "ncclCommInitAll failed (%d)", rc);
+        std::vector<comm_t> fresh(nl);
+        if (int rc = init_all(fresh.data(), nl, devs.data())) return fail(HAST_ERR_RCCL, "ncclCommInitAll failed (%d)", rc);
         it = comm_cache.emplace(devs, std::move(fresh)).first;
     }
     const std::vector<comm_t> &comms = it->second;
     const int kUint64 = 5, kSum = 0;   // ncclUint64, ncclSum (nccl.h: ncclInt64 = 4, ncclUint64 = 5)
-    // what crosses xGMI: the three live words of every record (c0[n] | c1[n] | neg[n], 24 bytes per barcode), packed and unpacked on
+    // 2. what crosses xGMI: the three live words of every record (c0[n] | c1[n] | neg[n], 24 bytes per barcode), packed and unpacked on
     // each GPU around the collective
-    const size_t nbc = ctxs[0]->n_barcodes;
-    for (int i = 0; i < n; i++) {
-        if (hast_status st = use(ctxs[i])) return st;
-        if (hast_status st = ensure_pack(ctxs[i], nbc)) return st;
-        HIP_TRY(launch_counts_pack(ctxs[i]->d_counts, ctxs[i]->d_pack, nbc, ctxs[i]->stream));
+    for (int i = 0; i < nl; i++) {
+        hast_ctx *c = lead[(size_t)i];
+        if (hast_status st = use(c)) return st;
+        if (hast_status st = ensure_pack(c, nbc)) return st;
+        HIP_TRY(launch_counts_pack(c->d_counts, c->d_pack, nbc, c->stream));
     }
     int rc = gstart();
-    for (int i = 0; i < n && !rc; i++) {
-        (void)hipSetDevice(ctxs[i]->device);
-        rc = allreduce(ctxs[i]->d_pack, ctxs[i]->d_pack, nbc * 3, kUint64, kSum, comms[i], ctxs[i]->stream);
+    for (int i = 0; i < nl && !rc; i++) {
+        hast_ctx *c = lead[(size_t)i];
+        (void)hipSetDevice(c->device);
+        rc = allreduce(c->d_pack, c->d_pack, nbc * 3, kUint64, kSum, comms[(size_t)i], c->stream);
     }
     int rc2 = gend();
-    for (int i = 0; i < n; i++) {
-        (void)hipSetDevice(ctxs[i]->device);
-        if (!rc && !rc2 && launch_counts_unpack(ctxs[i]->d_counts, ctxs[i]->d_pack, nbc, ctxs[i]->stream) != hipSuccess) rc2 = -1;
-        (void)hipStreamSynchronize(ctxs[i]->stream);
+    for (int i = 0; i < nl; i++) {
+        hast_ctx *c = lead[(size_t)i];
+        (void)hipSetDevice(c->device);
+        if (!rc && !rc2 && launch_counts_unpack(c->d_counts, c->d_pack, nbc, c->stream) != hipSuccess) rc2 = -1;
+        (void)hipStreamSynchronize(c->stream);
     }
     if (rc || rc2) {                   // a failed collective leaves the clique in an unknown state: drop it
         for (auto cm : comms) destroy(cm);
         comm_cache.erase(it);
     }
     if (rc || rc2) return fail(HAST_ERR_RCCL, "ncclAllReduce failed (%d/%d)", rc, rc2);
-    return HAST_OK;
+    return hand_back();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -988,20 +1050,23 @@ static hast_status ensure_filter(hast_ctx *c, hipStream_t hs) {
         if (c->d_filter) HIP_TRY(hipFree(c->d_filter));
         c->d_filter = nullptr;
         c->filter_bytes = 0;
-        hipError_t got = hipMalloc(&c->d_filter, bytes);
+        // (dev_malloc: what closed streams parked is freed and the allocation tried again before anything smaller or slower is taken)
+        hipError_t got = c->test_filter_oom ? hipErrorOutOfMemory : dev_malloc(&c->d_filter, bytes);
         if (got != hipSuccess && !c->filter_m && fg.m == kFilterMaxM) {
             // no room for 4^15 blocks (137 GB, what 800M keys ask for): 4^14 with two choices per print, as up to round 2
             (void)hipGetLastError();
             fg = filter_geom_for(c->k, h[0] + h[1], kFilterMaxM - 1, c->filter_t, c->filter_kp, c->k == 32 ? 0 : c->filter_exact);
             bytes = (size_t)filter_nblocks(fg) * 128;
-            got = hipMalloc(&c->d_filter, bytes);
+            got = dev_malloc(&c->d_filter, bytes);
         }
         if (got != hipSuccess) {
             // no room for the filter next to the table (34 GB at 14-mers): probe the table directly, as round 1 did -- the same
-            // GPU path minus the front end, same results (hast_filter_info tells)
+            // GPU path minus the front end, same results -- NOT silently: hast_filter_info says 0, hast_ctx_options (the CLI's
+            // __stats_switches__ line and its WARN) name the fallback and the bytes that were missing
             (void)hipGetLastError();
             c->d_filter = nullptr;
             c->use_filter = false;
+            c->filter_fallback_bytes = bytes;
             return HAST_OK;
         }
         c->filter_bytes = bytes;
@@ -1030,7 +1095,7 @@ static hast_status commit_votes(hast_ctx *c, const uint32_t *d_votes, const uint
             if (c->d_part) HIP_TRY(hipFree(c->d_part));
             c->d_part = nullptr;
             c->part_bytes = 0;
-            if (hipMalloc(&c->d_part, need + need / 8) == hipSuccess) c->part_bytes = need + need / 8;
+            if (dev_malloc(&c->d_part, need + need / 8) == hipSuccess) c->part_bytes = need + need / 8;
             else {
                 (void)hipGetLastError();
                 c->d_part = nullptr;
@@ -1078,7 +1143,7 @@ static hast_status classify_rows(hast_ctx *c, const uint8_t *d_bases, size_t bas
             if (c->d_votes_scratch) HIP_TRY(hipFree(c->d_votes_scratch));
             c->d_votes_scratch = nullptr;
             c->votes_bytes = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_votes_scratch), need + need / 8));
+            HIP_TRY(dev_malloc(reinterpret_cast<void **>(&c->d_votes_scratch), need + need / 8));
             c->votes_bytes = need + need / 8;
         }
         votes_buf = c->d_votes_scratch;
@@ -1172,6 +1237,7 @@ hast_status hast_ctx_set_filter(hast_ctx *c, int enable, int m, int t, int kp) {
     if (t < 0 || (m && t > m)) return fail(HAST_ERR_INVALID, "filter t=%d out of [0,m]", t);
     if (kp < 0 || kp > c->k || (kp && m && (kp < m || kp - m >= 32))) return fail(HAST_ERR_INVALID, "filter kp=%d out of [m,K]", kp);
     c->use_filter = enable != 0;
+    c->filter_fallback_bytes = 0;
     c->filter_exact = (enable == 2 || c->exact_env_off) ? 0 : -1;
     c->filter_m = m;
     c->filter_t = t;
@@ -1200,6 +1266,7 @@ hast_status hast_ctx_options(const hast_ctx *c, char *out, size_t cap) {
     std::string s;
     auto add = [&](const char *n, long v) { s += (s.empty() ? "" : " "); s += n; s += "=" + std::to_string(v); };
     if (!c->use_filter) add("filter", 0);
+    if (c->filter_fallback_bytes) add("filter_fallback_table_only_no_room_for_bytes", (long)c->filter_fallback_bytes);
     if (c->filter_exact == 0) add("filter_exact", 0);
     if (c->filter_m) add("filter_m", c->filter_m);
     if (c->filter_t) add("filter_t", c->filter_t);
@@ -1335,7 +1402,7 @@ static hast_status classify_segmented(hast_ctx *c, const uint8_t *d_bases, size_
         if (c->d_seg) HIP_TRY(hipFree(c->d_seg));
         c->d_seg = nullptr;
         c->seg_bytes = 0;
-        HIP_TRY(hipMalloc(&c->d_seg, need + need / 4));
+        HIP_TRY(dev_malloc(&c->d_seg, need + need / 4));
         c->seg_bytes = need + need / 4;
     }
     uint32_t *acc = (uint32_t *)c->d_seg;                                  // per-read vote accumulator
@@ -1404,8 +1471,8 @@ static hast_status stage_reserve(hast_ctx *c, Staging &s, size_t nbytes, size_t 
         s.h_bases = s.d_bases = nullptr;
         s.cap_bases = 0;
         size_t cap = nbytes + nbytes / 4 + 64;
-        HIP_TRY(hipHostMalloc((void **)&s.h_bases, cap, hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&s.d_bases, cap));
+        HIP_TRY(pinned_malloc((void **)&s.h_bases, cap, hipHostMallocDefault));
+        HIP_TRY(dev_malloc((void **)&s.d_bases, cap));
         s.cap_bases = cap;
     }
     if (s.cap_reads < nreads) {
@@ -1417,10 +1484,10 @@ static hast_status stage_reserve(hast_ctx *c, Staging &s, size_t nbytes, size_t 
         s.h_ids = s.d_ids = nullptr;
         s.cap_reads = 0;
         size_t cap = nreads + nreads / 4 + 16;
-        HIP_TRY(hipHostMalloc((void **)&s.h_off, (cap + 1) * sizeof(uint64_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **)&s.d_off, (cap + 1) * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void **)&s.d_ids, cap * sizeof(uint32_t)));
+        HIP_TRY(pinned_malloc((void **)&s.h_off, (cap + 1) * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(pinned_malloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(dev_malloc((void **)&s.d_off, (cap + 1) * sizeof(uint64_t)));
+        HIP_TRY(dev_malloc((void **)&s.d_ids, cap * sizeof(uint32_t)));
         s.cap_reads = cap;
     }
     return HAST_OK;

@@ -26,4 +26,12 @@ size_t ctx_n_barcodes(const hast_ctx *c);
 void park_device(void *p, size_t bytes, int site = 0);
 void park_pinned(void *p, size_t bytes, int site = 0);
 void release_parked();
+// ALLOCATIONS THAT KNOW ABOUT THE PARKED MEMORY.  Up to HAST_PARK_GB of closed streams' buffers stay allocated; whoever then asks for
+// more than what is left must not be told "out of memory" (or quietly take a slower path) while tens of GB wait to be freed: every
+// device and pinned allocation of the library goes through these two, which on hipErrorOutOfMemory free what is parked and ask once more.
+hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t pinned_malloc(void **p, size_t bytes, unsigned flags = hipHostMallocDefault);
+template <class T> inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc(reinterpret_cast<void **>(p), bytes); }
+template <class T> inline hipError_t pinned_malloc(T **p, size_t bytes, unsigned flags = hipHostMallocDefault) { return pinned_malloc(reinterpret_cast<void **>(p), bytes, flags); }
+size_t parked_bytes();                                                                               // what is waiting right now
 }  // namespace hast

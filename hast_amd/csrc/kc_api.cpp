@@ -142,10 +142,10 @@ static void part_setup(hast_kc *c) {
     c->a_cap = R + R / 2 + 64ull * c->n_fine + 1024;
     c->b_cap = R + R / 4 + 4096ull * c->n_l1 * c->l1_split + 1024;
     c->spill_cap = R / 16 + (1u << 20);
-    hipError_t h = hipMalloc(reinterpret_cast<void **>(&c->d_rec), c->a_cap * 8);
-    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_l1), c->b_cap * 8);
-    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_spill), c->spill_cap * 8);
-    if (h == hipSuccess) h = hipMalloc(reinterpret_cast<void **>(&c->d_fills), 8ull * ((uint64_t)c->n_l1 * c->l1_split * kKcL1FillWords + c->n_fine));
+    hipError_t h = dev_malloc(reinterpret_cast<void **>(&c->d_rec), c->a_cap * 8);
+    if (h == hipSuccess) h = dev_malloc(reinterpret_cast<void **>(&c->d_l1), c->b_cap * 8);
+    if (h == hipSuccess) h = dev_malloc(reinterpret_cast<void **>(&c->d_spill), c->spill_cap * 8);
+    if (h == hipSuccess) h = dev_malloc(reinterpret_cast<void **>(&c->d_fills), 8ull * ((uint64_t)c->n_l1 * c->l1_split * kKcL1FillWords + c->n_fine));
     if (h != hipSuccess) {                                             // no room: count with atomics, as before
         (void)hipGetLastError();
         for (void *p : {(void *)c->d_rec, (void *)c->d_l1, (void *)c->d_spill, (void *)c->d_fills})
@@ -257,14 +257,14 @@ hast_status hast_kc_create_ex(int device, int k, size_t table_bytes, uint64_t ex
             st = set_error(he == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(he));
     };
     bail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
-    bail(hipMalloc(&c->d_small, kSmallWords * sizeof(unsigned long long)), "hipMalloc(small)");
-    bail(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)), "hipMalloc(err)");
-    bail(hipMalloc(&c->d_histo, (HAST_KC_HISTO_HIGH + 2) * sizeof(unsigned long long)), "hipMalloc(histo)");
+    bail(dev_malloc(&c->d_small, kSmallWords * sizeof(unsigned long long)), "dev_malloc(small)");
+    bail(dev_malloc(&c->d_err, 4 * sizeof(uint32_t)), "dev_malloc(err)");
+    bail(dev_malloc(&c->d_histo, (HAST_KC_HISTO_HIGH + 2) * sizeof(unsigned long long)), "dev_malloc(histo)");
     for (auto &s : c->stage) bail(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
     bail(hipEventCreateWithFlags(&c->err_ev, hipEventDisableTiming), "hipEventCreate");
-    bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc(err)");
+    bail(pinned_malloc(reinterpret_cast<void **>(&c->h_err), sizeof(uint32_t), hipHostMallocDefault), "pinned_malloc(err)");
     bail(hipEventCreateWithFlags(&c->cur_ev, hipEventDisableTiming), "hipEventCreate");
-    bail(hipHostMalloc(reinterpret_cast<void **>(&c->h_cursor), sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(cursor)");
+    bail(pinned_malloc(reinterpret_cast<void **>(&c->h_cursor), sizeof(unsigned long long), hipHostMallocDefault), "pinned_malloc(cursor)");
     if (c->h_err) *c->h_err = 0;
     if (st == HAST_OK) {
         size_t free_b = 0, total_b = 0;
@@ -278,7 +278,7 @@ hast_status hast_kc_create_ex(int device, int k, size_t table_bytes, uint64_t ex
         if (nb > 1024) nb &= ~(size_t)1023;
         else if (nb > 512) nb = 512;
         c->nbuckets = (uint32_t)nb;
-        bail(hipMalloc(&c->d_table, nb * kKcBucketWords * sizeof(unsigned long long)), "hipMalloc(count table)");
+        bail(dev_malloc(&c->d_table, nb * kKcBucketWords * sizeof(unsigned long long)), "dev_malloc(count table)");
     }
     if (st == HAST_OK) part_setup(c);
     if (st == HAST_OK) bail(hipMemsetAsync(c->d_small, 0, kSmallWords * sizeof(unsigned long long), c->stream), "hipMemset");
@@ -437,8 +437,8 @@ hast_status hast_kc_count(hast_kc *c, int parent, const uint8_t *bytes, size_t n
     for (size_t at = 0; at < n_bytes; at += chunk) {
         KcStage &s = c->stage[c->turn++ & 1];
         if (!s.h) {
-            KC_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h), kStageBytes, hipHostMallocDefault));
-            KC_TRY(hipMalloc(reinterpret_cast<void **>(&s.d), kStageBytes));
+            KC_TRY(pinned_malloc(reinterpret_cast<void **>(&s.h), kStageBytes, hipHostMallocDefault));
+            KC_TRY(dev_malloc(reinterpret_cast<void **>(&s.d), kStageBytes));
         }
         if (s.busy) {
             KC_TRY(hipEventSynchronize(s.done));
@@ -546,7 +546,7 @@ hast_status hast_kc_select(hast_kc *c, int parent, uint32_t lower, uint32_t uppe
     KC_TRY(hipStreamSynchronize(c->stream));
     if (n == 0) return HAST_OK;
     unsigned long long *d_out = nullptr;
-    KC_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long)));
+    KC_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long)));
     hast_status st = HAST_OK;
     auto step = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && st == HAST_OK) st = set_error(HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
@@ -641,11 +641,11 @@ hast_status hast_kc_selection_sort(hast_kc *c, int parent, size_t *n_out) {
         if (e != hipSuccess && st == HAST_OK)
             st = set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     };
-    step(hipMalloc(reinterpret_cast<void **>(&d_in), n * sizeof(unsigned long long)), "hipMalloc(sort in)");
-    if (st == HAST_OK) step(hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long)), "hipMalloc(sort out)");
+    step(dev_malloc(reinterpret_cast<void **>(&d_in), n * sizeof(unsigned long long)), "dev_malloc(sort in)");
+    if (st == HAST_OK) step(dev_malloc(reinterpret_cast<void **>(&d_out), n * sizeof(unsigned long long)), "dev_malloc(sort out)");
     if (st == HAST_OK) step(hipMemcpyAsync(d_in, v.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream), "H2D");
     if (st == HAST_OK) step(kc_sort_keys(nullptr, &tmp_bytes, d_in, d_out, n, c->k, c->stream), "sort (size query)");
-    if (st == HAST_OK) step(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16), "hipMalloc(sort temp)");
+    if (st == HAST_OK) step(dev_malloc(&d_tmp, tmp_bytes ? tmp_bytes : 16), "dev_malloc(sort temp)");
     if (st == HAST_OK) step(kc_sort_keys(d_tmp, &tmp_bytes, d_in, d_out, n, c->k, c->stream), "sort");
     if (st == HAST_OK) step(hipStreamSynchronize(c->stream), "sync");
     if (d_tmp) (void)hipFree(d_tmp);
@@ -674,7 +674,7 @@ hast_status hast_kc_selection_text(hast_kc *c, int parent, size_t first, size_t 
     if (!out) return set_error(HAST_ERR_INVALID, "out is null");
     const size_t bytes = count * (size_t)(c->k + 1);
     char *d_text = nullptr;
-    KC_TRY(hipMalloc(reinterpret_cast<void **>(&d_text), bytes));
+    KC_TRY(dev_malloc(reinterpret_cast<void **>(&d_text), bytes));
     hipError_t e = launch_kc_format(c->d_sorted[parent] + first, count, c->k, d_text, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_text, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -688,7 +688,7 @@ hast_status hast_kc_selection_keys(hast_kc *c, int parent, size_t first, size_t 
     if (count == 0) return HAST_OK;
     if (!out) return set_error(HAST_ERR_INVALID, "out is null");
     unsigned long long *d_keys = nullptr;
-    KC_TRY(hipMalloc(reinterpret_cast<void **>(&d_keys), count * sizeof(unsigned long long)));
+    KC_TRY(dev_malloc(reinterpret_cast<void **>(&d_keys), count * sizeof(unsigned long long)));
     hipError_t e = launch_kc_to_table_keys(c->d_sorted[parent] + first, count, c->k, d_keys, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_keys, count * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

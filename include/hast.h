@@ -79,6 +79,9 @@ hast_status hast_stream_sync(hast_ctx *, hast_stream);
 /* ---- raw device memory (for callers without another allocator, e.g. ctypes tests) ---------- */
 hast_status hast_dev_alloc(hast_ctx *, size_t bytes, void **d_out);
 hast_status hast_dev_free(hast_ctx *, void *d_ptr);
+/* free and total memory of the context's device, and the bytes closed streams have parked (hast_release_parked): what `classify --stats`
+ * samples for its HBM head-room line.  Any of the three may be NULL. */
+hast_status hast_dev_mem_info(hast_ctx *, size_t *free_bytes, size_t *total_bytes, size_t *parked_bytes);
 hast_status hast_memcpy_h2d(hast_ctx *, void *d_dst, const void *src, size_t bytes);
 hast_status hast_memcpy_d2h(hast_ctx *, void *dst, const void *d_src, size_t bytes);
 hast_status hast_memset_d(hast_ctx *, void *d_dst, int byte, size_t bytes, hast_stream);
@@ -195,8 +198,9 @@ hast_status hast_counts_add_votes(hast_ctx *, const uint32_t *d_votes, const uin
                                   uint32_t max_votes, hast_stream);
 /* Thread-merge of the reference (collectBarcodes/BarcodeCache::Add, classify.cpp:57-63,226-229)
  * across the GPUs of ONE process: a single in-place RCCL all-reduce(sum,u64) over the counters of
- * n_ctx contexts (one per device, same n_barcodes).  Contexts that all share ONE device (a logical split) are summed
- * by a kernel on that device instead; a mix of shared and distinct devices is refused.  The communicators of a device list
+ * n_ctx contexts (same n_barcodes).  Contexts that share a device (a logical split: --devices 0,0 or 0,0,1,1) are summed by a kernel
+ * on that device into its first context first; the all-reduce then runs over one context per distinct device (none when there is
+ * only one), and the totals are handed back to every context.  The communicators of a device list
  * are created by the first call that names it and kept until the process ends (later calls only enqueue the all-reduce). */
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
 
@@ -297,6 +301,9 @@ typedef struct {
 typedef struct hast_names hast_names;
 hast_status hast_names_create(hast_ctx *, size_t max_barcodes, hast_names **out);
 void        hast_names_destroy(hast_names *);
+/* Entries the caller knows: n text records (16 bytes each: length byte + up to 15 bytes of text, the format of hast_fq_block.bc_text)
+ * with their ids -- e.g. a table barcode -> class for a routing stream (hast_fq_set_route).  Returns when they are on the device. */
+hast_status hast_names_insert(hast_names *, const uint8_t *text16, const uint32_t *ids, size_t n);
 hast_status hast_fq_create(hast_ctx *, size_t block_bytes, int n_buffers, hast_names *names_or_null, hast_fq **out);
 /* device_blocks != 0: a stream of device-side blocks only (hast_fq_device_block / hast_fq_submit_device, below): no pinned host
  * copy of the block buffers is set up (hast_fq_acquire hands out NULL), which saves ~0.1 s of page pinning per stream. */
@@ -339,6 +346,39 @@ int         hast_fq_poll(hast_fq *);      /* 1: hast_fq_next would not have to w
 hast_status hast_fq_next(hast_fq *, hast_fq_block *out);
 hast_status hast_fq_commit(hast_fq *);
 
+/* ---- routing: steps 10 and 11 of the wrapper (classify_stlfr_reads.sh:155-190, quartering_fastq.awk:12-61) --------------------
+ * After `classify` the wrapper runs a single-threaded awk program over every input once more: each record (four lines) goes to
+ * <name>.{nobarcode,paternal,maternal,homozygous}.fastq by the list its barcode is in.  awk splits the header at every '#' or '/'
+ * (-F '#|/'): NF > 1 and $2 != "0_0_0" -> $2 is looked up in the paternal, maternal, homozygous list (:22-35; in none: an ERROR
+ * line, the record is dropped), otherwise the read has no barcode (:36-39).  A stream put into routing mode frames its blocks as
+ * before (plain or striped, host or device blocks), does not classify them, and sorts the records of a block on the GPU into four
+ * runs of whole records in input order, which arrive in pinned host memory:
+ *     hast_fq_set_route     tables: text record of $2 -> class (1 paternal, 2 maternal, 3 homozygous; hast_names_create +
+ *                           hast_names_insert), one per lane of a striped stream.  Between files only.  NULL: classify again.
+ *     hast_fq_acquire / _submit / _device_block / _submit_device     as before
+ *     hast_fq_next_routed   oldest submitted block: waits for its runs
+ *     hast_fq_commit        the caller is through with the runs: the buffer is free again
+ * What the device cannot decide stays exact because the caller decides it: a block holding a record whose $2 is longer than the 15
+ * bytes a text record holds, or is in no table entry, comes back with host_block != 0 -- the view's bytes and every record's extent
+ * and class (0..3; 0xFE: in no list; 0xFF: longer than 15 bytes; 0xFD: not a record of this block) -- and the caller routes that
+ * block itself (the ERROR line needs the text); the partial record at the end of a file (fewer than four newlines; awk still
+ * prints its lines) is handed over as `tail`. */
+typedef struct {
+    uint64_t n_records;            /* records in the four runs */
+    uint64_t count[4];             /* per class: 0 nobarcode, 1 paternal, 2 maternal, 3 homozygous */
+    const uint8_t *run[4];         /* pinned host memory, valid until hast_fq_commit */
+    uint64_t run_bytes[4];
+    int host_block;                /* != 0: route this block from bytes / rec_* instead (the runs hold the decided records only) */
+    const uint8_t *bytes;
+    const uint32_t *rec_start, *rec_len;
+    const uint8_t *rec_class;
+    uint64_t n_slots;
+    const uint8_t *tail;           /* the partial record at the end of the file, or NULL */
+    uint64_t tail_bytes;
+} hast_fq_routed;
+hast_status hast_fq_set_route(hast_fq *, hast_names *const *tables, int n_tables);
+hast_status hast_fq_next_routed(hast_fq *, hast_fq_routed *out);
+
 /* ---- gzip input decoded on the device (gzstream.h:47, classify.cpp:245-254: one zlib stream per .gz file) -----------------
  * HAST's real inputs are ordinary .fq.gz files: ONE deflate stream per file, which the reference inflates on the thread that
  * also frames the records.  hast_gz inflates such a file on the GPU: the COMPRESSED bytes cross PCIe (5-6 x fewer than the
@@ -373,6 +413,9 @@ typedef struct {
     uint64_t ring_bytes;       /* 0: the whole compressed file lies on the device; else the size of the ring it goes round in
                                 * (files beyond 2 GB; HAST_GZ_RING_BYTES / HAST_GZ_PIECE_BYTES set the geometry in tests) */
     uint64_t upload_waited_for_ring;   /* pieces whose upload had to wait for the chain to move on */
+    double chain_walk_s;       /* host time between the kernels: accepting chunks, planning follow-up jobs, combining CRC-32s -- the part
+                                * of ONE deflate stream that stays serial however many GPUs decode its passes */
+    uint64_t ring_laps;        /* times the upload position wrapped round the ring */
 } hast_gz_stats;
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
 /* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 4096), symbols of room per compressed byte (0 = 12) */

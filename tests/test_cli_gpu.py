@@ -545,12 +545,18 @@ def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def test_cli_phase_reads_does_the_wrappers_steps_10_and_11(exe, golden_workdir, tmp_path):
-    """HAST_PHASE_READS=1: `classify` writes the three barcode lists and routes every record of every input itself -- steps 10 and 11
-    of classify_stlfr_reads.sh:155-190, which the unchanged wrapper then skips (step_10_done / step_11_done) -- with .gz inputs
-    inflated on the GPU a second time instead of `gzip -dc | awk`.  Expected files: the lists as the wrapper's awk one-liners derive
-    them from stdout, the routing as the stand-alone quartering_fastq does it from those lists (tests/test_quartering_cpu.py pins that
-    program to the reference's awk program byte for byte), one input plain and one .gz, as the wrapper would call it."""
+@pytest.mark.parametrize("extra,env", [([], {}), (["--route", "host"], {}), (["--devices", "0,0"], {}), (["--devices", "0,0,0", "--batch-reads", "150"], {}),
+                                       (["--batch-reads", "40"], {}), ([], {"HAST_PHASE_READS": "1", "_no_flag": "1"}),
+                                       (["--inflate", "host"], {})])
+def test_cli_phase_reads_does_the_wrappers_steps_10_and_11(exe, golden_workdir, tmp_path, extra, env):
+    """--phase-reads (HAST_PHASE_READS=1): `classify` writes the three barcode lists and routes every record of every input itself --
+    steps 10 and 11 of classify_stlfr_reads.sh:155-190, which the unchanged wrapper then skips (step_10_done / step_11_done) -- ON THE
+    GPU: the inputs go through the framer a second time (.gz inputs inflated on the device again), k_route_class / _scan / _copy sort
+    the records of a block into four runs by the class of their barcode, the host only writes (--route host: the worker threads parse
+    every record again, quartering.h).  Expected files: the lists as the wrapper's awk one-liners derive them from stdout, the routing
+    as the stand-alone quartering_fastq does it from those lists (tests/test_quartering_cpu.py pins that program to the reference's
+    awk program byte for byte), one input plain and one .gz, as the wrapper would call it; blocks of 40 records (every block border
+    inside a record), several contexts of one GPU (the blocks of a file dealt to them in turn)."""
     import gzip
     import shutil
     from tests.conftest import ROOT
@@ -563,9 +569,19 @@ def test_cli_phase_reads_does_the_wrappers_steps_10_and_11(exe, golden_workdir, 
     args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--weight0", "1.04", "--read", "r1.fq", "--read", "r2.fq.gz", "--thread", "5"]
     ref = subprocess.run([exe] + args, cwd=b, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert ref.returncode == 0 and not (b / "step_10_done").exists()
-    got = subprocess.run([exe] + args + ["--stats"], cwd=a, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HAST_PHASE_READS="1"))
+    env = dict(env)
+    flag = [] if env.pop("_no_flag", None) else ["--phase-reads"]
+    got = subprocess.run([exe] + args + ["--stats"] + flag + extra, cwd=a, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
     assert got.returncode == 0, got.stderr.decode()[-1000:]
     assert got.stdout == ref.stdout and b"__stats_phase_reads__" in got.stderr
+    line = [l for l in got.stderr.decode().splitlines() if l.startswith("__stats_phase_reads__")][0]
+    kv = dict(x.split("=") for x in line.split()[1:])
+    if "--route" in extra:
+        assert kv["route"] == "host"
+    else:
+        assert kv["route"] == "device" and int(kv["blocks_routed_on_device"]) >= 2 and int(kv["blocks_routed_by_host"]) == 0, line
+        if "--batch-reads" in extra:
+            assert int(kv["blocks_routed_on_device"]) >= 10, line
     assert (a / "step_10_done").exists() and (a / "step_11_done").exists()
     # the wrapper's own steps, in b
     rows = [r.split(b"\t") for r in ref.stdout.splitlines()]
@@ -580,3 +596,71 @@ def test_cli_phase_reads_does_the_wrappers_steps_10_and_11(exe, golden_workdir, 
     for m in made:
         assert (a / m).exists() and (a / m).read_bytes() == (b / m).read_bytes(), m
     assert sorted(p.name for p in a.iterdir() if p.name.endswith(".fastq")) == [m for m in made if m.endswith(".fastq")]
+
+
+def _edge_fastq(k=21, seed=5):
+    """records whose headers take every branch of quartering_fastq.awk:21-49 and the places where awk's field rule ('#' or '/' splits)
+    and parseName's (last '#', last '/': classify.cpp:112-119) part ways"""
+    rng = np.random.default_rng(seed)
+    def seq(n=60):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    heads = ["@a1#1_2_3/1", "@a2#0_0_0/1", "@a3", "@a4/x#5_6_7/1", "@a5#averyveryverylongbarcode_123/1", "@a6#1_2_3", "@a7#/1", "@a8#7_8_9/2\t5\t1",
+             "@a9#1_2_3/1", "@b1/1", "@b2#0_0/1", "@b3#0/1", "@b4#exactly15bytes_/1", "@b5#sixteen_bytes_xx/1", "@b6#4_4_4#5_5_5/1", "@b7#0_0_0"]
+    recs = []
+    for i in range(400):
+        h = heads[i % len(heads)]
+        recs.append("%s\n%s\n+\n%s\n" % (h, seq(), "F" * 60))
+    return recs
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch-reads", "7"], ["--devices", "0,0"], ["--devices", "0,0,0", "--batch-reads", "16"]])
+@pytest.mark.parametrize("tail", ["", "@t1#1_2_3/1\nACGTACGTACGTACGTACGTACGTACGT", "@t2#9_9_9/1\nACGTACGTACGTACGTACGTACGTACGT\n+\nFFFF", "@t3#1_2_3/1"])
+def test_cli_phase_reads_device_equals_host_router_on_every_awk_branch(exe, golden_workdir, tmp_path, extra, tail):
+    """the device router against the host router (which tests/test_quartering_cpu.py pins to the awk program) on headers without a
+    field 2, with "0_0_0", with a field 2 that parseName does not take for the barcode (in no list: the ERROR line and the dropped
+    record), with fields of 15 and 16 bytes and longer (a block with such a record comes back to the host), an empty field, and a
+    file that ends inside a record (awk prints the lines it has) -- plain and .gz, small blocks, several contexts"""
+    import gzip
+    import shutil
+    recs = _edge_fastq()
+    text = ("".join(recs) + tail).encode()
+    outs = {}
+    for mode in ("device", "host"):
+        d = tmp_path / mode
+        shutil.copytree(golden_workdir / "rand_k21", d)
+        (d / "e1.fq").write_bytes(text)
+        with gzip.open(d / "e2.fq.gz", "wb") as g:
+            g.write("".join(recs[:150]).encode() if not tail else text)
+        args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "e1.fq", "--read", "e2.fq.gz", "--thread", "3", "--stats", "--phase-reads", "--route", mode]
+        r = subprocess.run([exe] + args + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            # (a file that ends in a header line without its bases: classify itself refuses nothing here; anything else is a failure)
+            assert False, r.stderr.decode()[-1500:]
+        err = [l for l in r.stderr.decode().splitlines() if l.startswith("ERROR : unclassify")]
+        files = {p.name: p.read_bytes() for p in d.iterdir() if p.name.endswith((".fastq", ".barcodes", "filter_reads.log"))}
+        outs[mode] = (r.stdout, err, files)
+        line = [l for l in r.stderr.decode().splitlines() if l.startswith("__stats_phase_reads__")][0]
+        assert ("route=" + mode) in line, line
+        if mode == "device":
+            assert "blocks_routed_by_host=0" not in line, line          # (long fields and unlisted barcodes: those blocks are the host's)
+    assert outs["device"][0] == outs["host"][0]
+    assert outs["device"][1] == outs["host"][1] and len(outs["host"][1]) >= 20          # "x" of @a4/x#... is in no list
+    assert sorted(outs["device"][2]) == sorted(outs["host"][2])
+    for name, data in outs["host"][2].items():
+        assert outs["device"][2][name] == data, name
+    assert any(n.endswith(".nobarcode.fastq") for n in outs["host"][2]) and any(n.endswith(".homozygous.fastq") for n in outs["host"][2])
+
+
+def test_cli_phase_reads_barcode_with_a_separator_goes_to_the_host_router(exe, golden_workdir, tmp_path):
+    """a barcode that itself holds '/' ("#1_2_3/1/2": parseName takes "1_2_3/1") makes a list line that awk cuts at its first field:
+    the device's table text -> class cannot stand for awk's three arrays then, and the whole run is routed by the host"""
+    import shutil
+    d = tmp_path / "w"
+    shutil.copytree(golden_workdir / "rand_k21", d)
+    recs = _edge_fastq()
+    recs.append("@c1#1_2_3/1/2\n" + "ACGT" * 15 + "\n+\n" + "F" * 60 + "\n")
+    (d / "e1.fq").write_bytes("".join(recs).encode())
+    r = subprocess.run([exe, "--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", "e1.fq", "--stats", "--phase-reads"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    line = [l for l in r.stderr.decode().splitlines() if l.startswith("__stats_phase_reads__")][0]
+    assert "route=host" in line and (d / "e1.fq.homozygous.fastq").exists()
