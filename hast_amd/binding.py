@@ -28,7 +28,7 @@ class FqBlock(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("max_read_len", C.c_uint32), ("short_read", C.c_uint32),
                 ("bytes", C.POINTER(C.c_uint8)), ("bc_pos", C.POINTER(C.c_uint32)), ("bc_len", C.POINTER(C.c_uint32)),
                 ("bc_text", C.POINTER(C.c_uint8)), ("ids", C.POINTER(C.c_uint32)), ("unknown", C.POINTER(C.c_uint32)),
-                ("n_unknown", C.c_uint64)]
+                ("n_unknown", C.c_uint64), ("dict_ids", C.c_uint64)]
 
 
 class FqRouted(C.Structure):
@@ -118,6 +118,12 @@ ABI_SYMBOLS = {
     "hast_fq_next": (C.c_int, [vp, C.POINTER(FqBlock)]),
     "hast_fq_commit": (C.c_int, [vp]),
     "hast_dev_mem_info": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "hast_names_create_dict": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "hast_names_limit": (C.c_size_t, [vp]),
+    "hast_names_count": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "hast_names_texts": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8)]),
+    "hast_counts_read_range": (C.c_int, [vp, C.c_size_t, C.c_size_t, u64p, u64p, u64p]),
+    "hast_counts_permute": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t]),
     "hast_names_insert": (C.c_int, [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_size_t]),
     "hast_fq_set_route": (C.c_int, [vp, C.POINTER(vp), C.c_int]),
     "hast_fq_next_routed": (C.c_int, [vp, C.POINTER(FqRouted)]),

@@ -229,29 +229,95 @@ bool self_test() {
 }
 
 struct Counts {                                    // host accumulators behind the device counters
-    std::vector<uint64_t> c0, c1, neg;
+    std::vector<uint64_t> c0, c1, neg;             // by device-dictionary id (one dictionary), by merged id (several), by host id (no device dictionary)
+    std::vector<uint64_t> h0, h1, hneg;            // by host-dictionary id, for what a device dictionary left to the host
     size_t device_cap = 0;
 };
 
-void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, size_t n_known, size_t new_cap) {
+// Who numbers the barcodes.  Round 6: the GPU's own dictionary (hast_names_create_dict) -- ids 0 .. limit-1 in the order in which its
+// naming kernel meets new texts; the host's dictionary only names what the device leaves to it (texts longer than 15 bytes, and what
+// arrives when every device id is out) in the range [host_base, ...) above.  One dictionary per GPU (contexts of one GPU share it): with
+// several GPUs the dictionaries number independently and their counters are MERGED BY TEXT -- a host map text -> merged id filled from
+// the dictionaries' texts, the counters of every context renumbered on its device (hast_counts_permute), then the one all-reduce.
+struct Naming {
+    bool device_dict = false;
+    size_t host_base = 0;                          // ids of the host dictionary start here in the device counters
+    std::vector<hast_names *> groups;              // the distinct dictionaries
+    std::vector<int> group_of;                     // per context
+    hast::BarcodeDict merged;                      // several dictionaries: text -> merged id
+    std::vector<hast::BarcodeDict::Cache> merged_caches;
+    std::vector<std::vector<uint8_t>> texts;       // per group: the text records read so far (16 bytes each)
+    double merge_s = 0;
+};
+
+inline void add_into(std::vector<uint64_t> &dst, const std::vector<uint64_t> &src, size_t n) {
+    if (dst.size() < n) dst.resize(n);
+    for (size_t i = 0; i < n; i++) dst[i] += src[i];       // (64-bit on the device and here: nothing wraps)
+}
+
+void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, Naming &nm, hast::WorkerPool &pool, size_t n_host, size_t new_cap) {
     // fold what the devices have counted so far into the host sums, then (re)size the device arrays.  Several GPUs: ONE
     // all-reduce(sum,u64) over RCCL/xGMI leaves the totals on every device (collectBarcodes + data.Add, classify.cpp:226-229,277)
     hast_ctx *ctx = ctxs[0];
     if (acc.device_cap) {
-        if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
-        // (only the barcodes that exist: the counters are sized ahead of the dictionary, 1M records = 32 MB at the start)
-        const size_t n_read = std::min(acc.device_cap, n_known);
-        std::vector<uint64_t> a(n_read), b(n_read), c(n_read);
-        CK(hast_counts_read(ctx, a.data(), b.data(), c.data(), n_read), "reading counters");
-        if (acc.c0.size() < n_read) {
-            acc.c0.resize(n_read);
-            acc.c1.resize(n_read);
-            acc.neg.resize(n_read);
-        }
-        for (size_t i = 0; i < n_read; i++) {                // (64-bit on the device and here: nothing wraps)
-            acc.c0[i] += a[i];
-            acc.c1[i] += b[i];
-            acc.neg[i] += c[i];
+        std::vector<uint64_t> a, b, c;
+        auto read_range = [&](size_t first, size_t n, std::vector<uint64_t> &d0, std::vector<uint64_t> &d1, std::vector<uint64_t> &d2) {
+            n = first < acc.device_cap ? std::min(n, acc.device_cap - first) : 0;
+            a.assign(n, 0); b.assign(n, 0); c.assign(n, 0);
+            if (n) CK(hast_counts_read_range(ctx, first, n, a.data(), b.data(), c.data()), "reading counters");
+            add_into(d0, a, n); add_into(d1, b, n); add_into(d2, c, n);
+        };
+        if (!nm.device_dict) {
+            if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
+            read_range(0, n_host, acc.c0, acc.c1, acc.neg);      // (only the barcodes that exist: the counters are sized ahead of the dictionary)
+        } else if (nm.groups.size() == 1) {
+            if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
+            size_t n_dev = 0;
+            CK(hast_names_count(nm.groups[0], &n_dev), "asking the dictionary for its size");
+            read_range(0, n_dev, acc.c0, acc.c1, acc.neg);
+            read_range(nm.host_base, n_host, acc.h0, acc.h1, acc.hneg);
+        } else {
+            // several dictionaries: every context's counters into the merged numbering, on its device, then the all-reduce
+            const double t0 = now_s();
+            const int T = pool.size();
+            if (nm.merged_caches.empty()) nm.merged_caches.resize((size_t)T);
+            nm.texts.resize(nm.groups.size());
+            std::vector<std::vector<uint32_t>> perm(nm.groups.size());
+            for (size_t g = 0; g < nm.groups.size(); g++) {
+                size_t n_dev = 0;
+                CK(hast_names_count(nm.groups[g], &n_dev), "asking a dictionary for its size");
+                const size_t have = nm.texts[g].size() / 16;
+                nm.texts[g].resize(16 * n_dev);
+                if (n_dev > have) CK(hast_names_texts(nm.groups[g], have, n_dev - have, nm.texts[g].data() + 16 * have), "reading a dictionary's texts");
+                perm[g].resize(n_dev);
+                const uint8_t *tx = nm.texts[g].data();
+                pool.run([&](int t) {
+                    for (size_t i = n_dev * (size_t)t / T, e = n_dev * (size_t)(t + 1) / T; i < e; i++)
+                        perm[g][i] = nm.merged.get(std::string_view(reinterpret_cast<const char *>(tx) + 16 * i + 1, tx[16 * i]), nm.merged_caches[(size_t)t]);
+                });
+            }
+            const size_t n_merged = nm.merged.size(), n_new = n_merged + n_host;
+            for (size_t i = 0; i < ctxs.size(); i++) {
+                std::vector<uint32_t> &p = perm[(size_t)nm.group_of[i]];
+                std::vector<uint32_t> full;
+                const uint32_t *use = p.data();
+                size_t n_old = std::min(p.size(), acc.device_cap);
+                if (n_host) {                                   // the host's ids keep their order behind the merged ones
+                    full.assign(std::min(nm.host_base + n_host, acc.device_cap), 0xFFFFFFFFu);
+                    std::copy(p.begin(), p.begin() + (long)std::min(p.size(), full.size()), full.begin());
+                    for (size_t j = 0; j < n_host && nm.host_base + j < full.size(); j++) full[nm.host_base + j] = (uint32_t)(n_merged + j);
+                    use = full.data();
+                    n_old = full.size();
+                }
+                CK(hast_counts_permute(ctxs[i], use, n_old, std::max<size_t>(n_new, 1)), "renumbering the counters of a GPU");
+            }
+            CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
+            const size_t cap_was = acc.device_cap;
+            acc.device_cap = std::max<size_t>(n_new, 1);
+            read_range(0, n_merged, acc.c0, acc.c1, acc.neg);
+            read_range(n_merged, n_host, acc.h0, acc.h1, acc.hneg);
+            acc.device_cap = cap_was;
+            nm.merge_s += now_s() - t0;
         }
     }
     for (hast_ctx *c : ctxs) CK(hast_counts_resize(c, new_cap), "allocating counters");
@@ -383,7 +449,8 @@ int main(int argc, char **argv) {
     std::vector<hast_status> pre_gz_status;
     std::vector<std::string> pre_gz_error;
     std::vector<std::thread> gz_closers;
-    std::vector<hast_names *> name_caches, own_caches;     // per context / per GPU: device-side cache barcode text -> id
+    std::vector<hast_names *> name_caches, own_caches;     // per context / per GPU: device-side dictionary barcode text -> id
+    Naming naming;
     std::thread pre_thread;
     std::string pre_error;
     // several GPUs: the blocks of every file go to all of them in turn (a striped stream); HAST_DEAL=files deals whole files
@@ -441,21 +508,31 @@ int main(int argc, char **argv) {
         if (host_parse) return;
         const char *deal = getenv("HAST_DEAL");
         stripe = ctxs.size() > 1 && !(deal && !strcmp(deal, "files"));
-        // (2 x 32 B per barcode it can hold: 1 GB for 16M -- BASELINE config 3 has 10M barcodes, and a barcode that does not fit is named
-        // by the host for every one of its reads)
+        // (2 x 32 B per barcode it can hold + 16 B of text by id: 1.3 GB for 16M -- BASELINE config 3 has 10M barcodes; what does not fit
+        // is named by the host, in an id range of its own)
         size_t name_cap = std::max<size_t>(initial_barcodes, 1u << 24);
         if (const char *e = getenv("HAST_NAME_CACHE")) name_cap = (size_t)atol(e);
+        // HAST_NAME_DICT=0: the table only caches what the host's dictionary names (up to round 5); HAST_NAME_DICT=context: a dictionary
+        // per CONTEXT even where contexts share a GPU (tests: the merge by text of several GPUs' dictionaries, on one GPU)
+        const char *nd = getenv("HAST_NAME_DICT");
+        naming.device_dict = name_cap && !(nd && !strcmp(nd, "0"));
+        const bool per_context = nd && !strcmp(nd, "context");
         for (size_t i = 0; i < ctxs.size(); i++) {
-            // one cache per GPU: contexts that share a device (--devices 0,0) share what it has learnt
+            // one per GPU: contexts that share a device (--devices 0,0) share it
             hast_names *nm = nullptr;
-            for (size_t j = 0; j < i && !nm; j++)
-                if (devices[j] == devices[i]) nm = name_caches[j];
+            int group = -1;
+            for (size_t j = 0; j < i && !nm && !per_context; j++)
+                if (devices[j] == devices[i]) { nm = name_caches[j]; group = naming.group_of[j]; }
             if (!nm && name_cap) {
-                CK(hast_names_create(ctxs[i], name_cap, &nm), "creating the barcode name cache");
+                CK(naming.device_dict ? hast_names_create_dict(ctxs[i], name_cap, &nm) : hast_names_create(ctxs[i], name_cap, &nm), "creating the barcode dictionary");
                 own_caches.push_back(nm);
+                group = (int)naming.groups.size();
+                naming.groups.push_back(nm);
             }
             name_caches.push_back(nm);
+            naming.group_of.push_back(group);
         }
+        if (naming.device_dict) naming.host_base = hast_names_limit(naming.groups[0]);
         pre_fq.assign(std::min<size_t>(read.size(), stripe ? 2 : std::max<size_t>(4, 2 * ctxs.size())), nullptr);
         pre_gz.assign(pre_fq.size(), nullptr);
         pre_gz_status.assign(pre_fq.size(), HAST_OK);
@@ -602,7 +679,9 @@ int main(int argc, char **argv) {
     hast::BarcodeDict dict;
     std::vector<hast::BarcodeDict::Cache> caches(pool.size());
     Counts acc;
-    flush_counts(ctxs, acc, 0, initial_barcodes);
+    // (a device dictionary hands out ids below host_base; the first id the host has to give lies there: counters for both from the start,
+    // unless --initial-barcodes asks for less, tests)
+    flush_counts(ctxs, acc, naming, pool, 0, initial_barcodes == (1u << 24) && naming.device_dict ? naming.host_base + 4096 : initial_barcodes);
     const int T = pool.size();
     uint64_t total_reads = 0, total_bases = 0;
     std::vector<std::vector<uint32_t>> nl(T);          // per-worker newline positions of the current block
@@ -670,7 +749,7 @@ int main(int argc, char **argv) {
                 exit(3);                                                                   // reference: assert abort
             }
         }
-        if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
+        if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, naming, pool, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
         CK(hast_batch_submit(bctx, n_rec, mx), "classifying a batch");
         total_reads += n_rec;
         total_bases += part_bytes[T];
@@ -910,9 +989,10 @@ int main(int argc, char **argv) {
                 for (size_t j = lo; j < hi_; j++) {
                     const size_t i = b.unknown ? b.unknown[j] : j;
                     const uint8_t *txt = b.bc_text ? b.bc_text + 16 * i : nullptr;      // the framer's compact copy of the barcode text
-                    b.ids[i] = txt && txt[0] != 0xFF
-                                   ? dict.get(std::string_view(reinterpret_cast<const char *>(txt) + 1, txt[0]), caches[t])
-                                   : dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]);
+                    b.ids[i] = (uint32_t)naming.host_base +
+                               (txt && txt[0] != 0xFF
+                                    ? dict.get(std::string_view(reinterpret_cast<const char *>(txt) + 1, txt[0]), caches[t])
+                                    : dict.get(std::string_view(reinterpret_cast<const char *>(b.bytes) + b.bc_pos[i], b.bc_len[i]), caches[t]));
                 }
             };
             if (nu < 4096) name_range(0, 0, nu);
@@ -920,7 +1000,12 @@ int main(int argc, char **argv) {
             total_named += nu;
             const double t2 = now_s();
             t_names += t2 - t1;
-            if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
+            // the counters must hold every id of this block: the device dictionary's (below dict_ids) and the host's (from host_base on)
+            {
+                const size_t need = std::max<size_t>(naming.device_dict ? (size_t)b.dict_ids : 0, dict.size() ? naming.host_base + dict.size() : 0);
+                if (need > acc.device_cap)
+                    flush_counts(ctxs, acc, naming, pool, dict.size(), std::max(dict.size() ? naming.host_base + 2 * dict.size() + 4096 : 2 * need, acc.device_cap * 2));
+            }
             CK(hast_fq_commit(f.fq), "classifying a block");
             t_commit += now_s() - t2;
             if (getenv("HAST_TRACE_BLOCKS")) fprintf(stderr, "trace %s open wait %.3f name %.3f commit %.3f ms at %.4f (sub %zu open %zu)\n", f.name.c_str() + (f.name.size() > 5 ? f.name.size() - 5 : 0), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3, now_s(), f.submitted, f.opened);
@@ -983,11 +1068,11 @@ int main(int argc, char **argv) {
                         hast_gz_stats gs;
                         if (stats && hast_gz_get_stats(f.gz, &gs) == HAST_OK)
                             stat_line("__stats_gz__ file=%s compressed_bytes=%llu inflated_bytes=%llu chunks=%llu accepted=%llu followup_jobs=%llu followup_rounds=%llu members=%llu "
-                                            "open_s=%.3f decode_s=%.3f windows_crc_s=%.3f producer_waited_for_upload_s=%.3f producer_waited_for_reader_s=%.3f reader_waited_for_decode_s=%.3f ring_bytes=%llu upload_waited_for_ring=%llu\n",
+                                            "open_s=%.3f decode_s=%.3f windows_crc_s=%.3f chain_walk_s=%.3f producer_waited_for_upload_s=%.3f producer_waited_for_reader_s=%.3f reader_waited_for_decode_s=%.3f ring_bytes=%llu ring_laps=%llu upload_waited_for_ring=%llu\n",
                                     f.name.c_str(), (unsigned long long)gs.compressed_bytes, (unsigned long long)gs.out_bytes, (unsigned long long)gs.chunks,
                                     (unsigned long long)gs.accepted, (unsigned long long)gs.followup_jobs, (unsigned long long)gs.followup_rounds, (unsigned long long)gs.members,
-                                    gs.open_s, gs.decode_s, gs.windows_crc_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s, (unsigned long long)gs.ring_bytes,
-                                    (unsigned long long)gs.upload_waited_for_ring);
+                                    gs.open_s, gs.decode_s, gs.windows_crc_s, gs.chain_walk_s, gs.wait_upload_s, gs.wait_consumer_s, gs.wait_decode_s, (unsigned long long)gs.ring_bytes,
+                                    (unsigned long long)gs.ring_laps, (unsigned long long)gs.upload_waited_for_ring);
                         // its device memory (the compressed file, the symbol arenas, windows) goes back now, not at the end of the run: a
                         // dozen finished .gz files would otherwise crowd the table out of HBM.  On a thread of its own: freeing synchronises.
                         hast_gz *z = f.gz;
@@ -1027,10 +1112,37 @@ int main(int argc, char **argv) {
                     t_idle, t_gpu_wait, t_names, t_commit, t_create, (unsigned long long)total_named);
     }
     const double t_read_done = now_s();
-    flush_counts(ctxs, acc, dict.size(), 1);
+    flush_counts(ctxs, acc, naming, pool, dict.size(), 1);
     const double t_classified = now_s();
-    std::vector<std::string_view> names(dict.size());
-    pool.run([&](int t) { dict.names_range(names, hast::BarcodeDict::n_shards() * (size_t)t / T, hast::BarcodeDict::n_shards() * (size_t)(t + 1) / T); });
+    // the names by row: the device dictionary's texts by id (read once, now), then what the host named
+    std::vector<uint8_t> dev_texts;
+    size_t n_dev_names = 0;
+    if (naming.device_dict && naming.groups.size() == 1) {
+        CK(hast_names_count(naming.groups[0], &n_dev_names), "asking the dictionary for its size");
+        dev_texts.resize(16 * n_dev_names);
+        CK(hast_names_texts(naming.groups[0], 0, n_dev_names, dev_texts.data()), "reading the dictionary's texts");
+    } else if (naming.device_dict) n_dev_names = naming.merged.size();
+    const size_t n_host_names = dict.size();
+    std::vector<std::string_view> names(n_dev_names + n_host_names);
+    if (naming.device_dict && naming.groups.size() == 1)
+        pool.run([&](int t) {
+            for (size_t i = n_dev_names * (size_t)t / T, e = n_dev_names * (size_t)(t + 1) / T; i < e; i++)
+                names[i] = std::string_view(reinterpret_cast<const char *>(dev_texts.data()) + 16 * i + 1, dev_texts[16 * i]);
+        });
+    else if (naming.device_dict)
+        pool.run([&](int t) { naming.merged.names_range(names, hast::BarcodeDict::n_shards() * (size_t)t / T, hast::BarcodeDict::n_shards() * (size_t)(t + 1) / T); });
+    {
+        std::vector<std::string_view> hn(n_host_names);
+        pool.run([&](int t) { dict.names_range(hn, hast::BarcodeDict::n_shards() * (size_t)t / T, hast::BarcodeDict::n_shards() * (size_t)(t + 1) / T); });
+        std::copy(hn.begin(), hn.end(), names.begin() + (long)n_dev_names);
+    }
+    // one run of counters in the order of `names`
+    if (naming.device_dict) {
+        acc.c0.resize(n_dev_names); acc.c1.resize(n_dev_names); acc.neg.resize(n_dev_names);
+        acc.h0.resize(n_host_names); acc.h1.resize(n_host_names);
+        acc.c0.insert(acc.c0.end(), acc.h0.begin(), acc.h0.end());
+        acc.c1.insert(acc.c1.end(), acc.h1.begin(), acc.h1.end());
+    }
 
     // ---- printBarcodeInfos (classify.cpp:93-102): byte-wise sorted rows ------------------------
     // (the reference walks a std::map<std::string, ...>: byte-wise lexicographic order, a prefix in front of what it is a prefix of.
@@ -1252,14 +1364,15 @@ int main(int argc, char **argv) {
                 hast::BlockSource src;
                 hast_fq *fq = nullptr;
                 hast_gz *gz = nullptr;
-                std::thread th, wth;
+                std::thread th, wth[4];
                 std::mutex mu, wmu;
                 std::condition_variable cv, wcv;
                 std::deque<std::pair<uint8_t *, hast_stream>> empty;
                 struct Filled { size_t n; bool last; std::string err; };
                 std::deque<Filled> filled;
-                std::deque<WriteJob> wq;
-                bool stop = false, eof_acquired = false, wstop = false, write_failed = false, block_open = false;
+                std::deque<WriteJob> wq[4];                             // per class: a writer thread per output file
+                std::atomic<bool> write_failed{false};
+                bool stop = false, eof_acquired = false, wstop = false, block_open = false;
                 size_t held = 0, submitted = 0, opened = 0, acquired = 0, jobs = 0, written = 0;
                 FILE *out[4] = {nullptr, nullptr, nullptr, nullptr};
                 long long counts[5] = {0, 0, 0, 0, 0};
@@ -1355,28 +1468,28 @@ int main(int argc, char **argv) {
                         if (fl.last) return;
                     }
                 });
-                f->wth = std::thread([fp, &wake] {                      // the runs of a block to the four files, in order
-                    for (;;) {
-                        WriteJob j;
-                        {
-                            std::unique_lock<std::mutex> g(fp->wmu);
-                            fp->wcv.wait(g, [fp] { return fp->wstop || !fp->wq.empty(); });
-                            if (fp->wq.empty()) return;
-                            j = std::move(fp->wq.front());
-                            fp->wq.pop_front();
+                for (int c = 0; c < 4; c++)
+                    f->wth[c] = std::thread([fp, c, &wake] {            // the runs of class c to its file, in order (a thread per file: what
+                        for (;;) {                                      // bounds the routing is the write, 17 GB per file at BASELINE config 2)
+                            WriteJob j;
+                            {
+                                std::unique_lock<std::mutex> g(fp->wmu);
+                                fp->wcv.wait(g, [fp, c] { return fp->wstop || !fp->wq[c].empty(); });
+                                if (fp->wq[c].empty()) return;
+                                j = std::move(fp->wq[c].front());
+                                fp->wq[c].pop_front();
+                            }
+                            if (j.n[c] && !fp->write_failed.load()) {
+                                if (!fp->out[c]) fp->out[c] = fopen((fp->prefix + suffix[c]).c_str(), "wb");
+                                if (!fp->out[c] || fwrite(j.p[c], 1, j.n[c], fp->out[c]) != j.n[c]) fp->write_failed = true;
+                            }
+                            {
+                                std::lock_guard<std::mutex> g(fp->wmu);
+                                fp->written++;
+                            }
+                            wake();
                         }
-                        for (int c = 0; c < 4 && !fp->write_failed; c++) {
-                            if (!j.n[c]) continue;
-                            if (!fp->out[c]) fp->out[c] = fopen((fp->prefix + suffix[c]).c_str(), "wb");
-                            if (!fp->out[c] || fwrite(j.p[c], 1, j.n[c], fp->out[c]) != j.n[c]) fp->write_failed = true;
-                        }
-                        {
-                            std::lock_guard<std::mutex> g(fp->wmu);
-                            fp->written++;
-                        }
-                        wake();
-                    }
-                });
+                    });
                 active.push_back(std::move(f));
             };
             // a block the device handed over: every record by the host's rules, in input order (quartering.h's classify)
@@ -1444,10 +1557,10 @@ int main(int argc, char **argv) {
                 }
                 {
                     std::lock_guard<std::mutex> g(f.wmu);
-                    f.wq.push_back(std::move(j));
-                    f.jobs++;
+                    for (int c = 0; c < 4; c++) f.wq[c].push_back(j);
+                    f.jobs += 4;
                 }
-                f.wcv.notify_one();
+                f.wcv.notify_all();
                 f.block_open = true;
                 f.opened++;
             };
@@ -1493,7 +1606,7 @@ int main(int argc, char **argv) {
                             done = f.written == f.jobs;
                         }
                         if (done) {
-                            if (f.write_failed) {
+                            if (f.write_failed.load()) {
                                 fprintf(stderr, "classify: cannot write %s.*.fastq\n", f.prefix.c_str());
                                 fflush(stderr);
                                 _exit(2);
@@ -1520,7 +1633,7 @@ int main(int argc, char **argv) {
                             f.wstop = true;
                         }
                         f.wcv.notify_all();
-                        f.wth.join();
+                        for (std::thread &w : f.wth) w.join();
                         for (FILE *&o : f.out)
                             if (o && fclose(o) != 0) { fprintf(stderr, "classify: cannot write %s.*.fastq\n", f.prefix.c_str()); fflush(stderr); _exit(2); }
                         if (f.gz) {

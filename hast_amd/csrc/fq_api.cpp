@@ -33,6 +33,7 @@ struct Slot {
     uint64_t *d_off = nullptr;
     uint32_t *d_len = nullptr, *d_bcpos = nullptr, *d_bclen = nullptr, *d_ids = nullptr, *d_votes = nullptr;
     uint32_t *d_text = nullptr;                        // [h_cap][4]: the barcode text records, for the device-side name cache
+    uint32_t *h_nids = nullptr;                        // pinned: ids the device dictionary had handed out when this block was named
     uint32_t *h_unknown = nullptr;                     // pinned [1 + h_cap]: count, then the records the cache did not know
     NamePub *h_pubs = nullptr;                         // pinned [h_cap]: what this block teaches the cache
     hipEvent_t named = nullptr;
@@ -73,6 +74,10 @@ struct hast_names {            // device-side cache barcode text -> id of one GP
     NameEntry *d_tab = nullptr;
     uint32_t mask = 0;
     size_t count = 0, limit = 0;                       // entries published / published at most (half the slots)
+    // dictionary mode (hast_names_create_dict): the table hands out the ids itself -- ids 0 .. limit-1, one counter, the texts by id
+    bool dict = false;
+    uint32_t *d_n_ids = nullptr;
+    void *d_text_of_id = nullptr;                      // [limit][16]
 };
 
 struct FqLane {                // what a striped stream keeps per context: its GPU's streams and name cache
@@ -140,6 +145,7 @@ static void free_slot(Slot &s) {
     if (s.over_copied) (void)hipEventDestroy(s.over_copied);
     park_pinned(s.h_buf, s.h_buf_bytes, 3);
     park_pinned(s.h_st, 64, 3);
+    park_pinned(s.h_nids, 64, 3);
     park_pinned(s.h_bc, 6 * s.h_cap * sizeof(uint32_t), 3);
     park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t), 3);
     park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), 3);
@@ -303,7 +309,7 @@ hast_status hast_names_create(hast_ctx *ctx, size_t max_barcodes, hast_names **o
     if (!ctx || !out) return set_error(HAST_ERR_INVALID, "null argument");
     *out = nullptr;
     FQ_TRY(hipSetDevice(hast_ctx_device(ctx)));
-    size_t slots = 1024;
+    size_t slots = 64;
     while (slots < 2 * std::max<size_t>(max_barcodes, 1) && slots < (1ull << 31)) slots <<= 1;
     hast_names *nm = new (std::nothrow) hast_names();
     if (!nm) return set_error(HAST_ERR_OOM, "host allocation failed");
@@ -322,11 +328,52 @@ hast_status hast_names_create(hast_ctx *ctx, size_t max_barcodes, hast_names **o
     return HAST_OK;
 }
 
+// The table as the job's DICTIONARY on this GPU: it hands out the dense ids itself (0 .. hast_names_limit - 1, in the order in which its
+// kernels meet new texts), so that no first sighting of a barcode goes through the host (classify.cpp:52-56: the map insert of
+// BarcodeCache::IncrBarcodeHaps).  The host reads the texts by id once, at the end (hast_names_texts), for printing.
+hast_status hast_names_create_dict(hast_ctx *ctx, size_t max_barcodes, hast_names **out) {
+    if (hast_status st = hast_names_create(ctx, max_barcodes, out)) return st;
+    hast_names *nm = *out;
+    hipError_t e = dev_malloc((void **)&nm->d_n_ids, 64);
+    if (e == hipSuccess) e = dev_malloc(&nm->d_text_of_id, nm->limit * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(nm->d_n_ids, 0, 64, ctx_stream_of(ctx));
+    if (e != hipSuccess) {
+        hast_names_destroy(nm);
+        *out = nullptr;
+        return set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "name dictionary: %s", hipGetErrorString(e));
+    }
+    nm->dict = true;
+    return HAST_OK;
+}
+size_t hast_names_limit(const hast_names *nm) { return nm ? nm->limit : 0; }
+// ids handed out so far (waits for the naming kernels queued on the context's stream)
+hast_status hast_names_count(hast_names *nm, size_t *n_ids) {
+    if (!nm || !n_ids) return set_error(HAST_ERR_INVALID, "null argument");
+    *n_ids = 0;
+    if (!nm->dict) { *n_ids = nm->count; return HAST_OK; }
+    FQ_TRY(hipSetDevice(nm->device));
+    uint32_t v = 0;
+    FQ_TRY(hipMemcpy(&v, nm->d_n_ids, sizeof(v), hipMemcpyDeviceToHost));
+    *n_ids = std::min<size_t>(v, nm->limit);
+    return HAST_OK;
+}
+// the text records (16 bytes each: length byte + text) of ids [first, first + n)
+hast_status hast_names_texts(hast_names *nm, size_t first, size_t n, uint8_t *out16) {
+    if (!nm || (n && !out16)) return set_error(HAST_ERR_INVALID, "null argument");
+    if (!nm->dict) return set_error(HAST_ERR_INVALID, "hast_names_texts: not a dictionary (hast_names_create_dict)");
+    if (first + n > nm->limit) return set_error(HAST_ERR_INVALID, "hast_names_texts: ids [%zu, %zu) beyond the %zu the dictionary can hand out", first, first + n, nm->limit);
+    FQ_TRY(hipSetDevice(nm->device));
+    if (n) FQ_TRY(hipMemcpy(out16, static_cast<const uint8_t *>(nm->d_text_of_id) + 16 * first, 16 * n, hipMemcpyDeviceToHost));
+    return HAST_OK;
+}
+
 void hast_names_destroy(hast_names *nm) {
     if (!nm) return;
     (void)hipSetDevice(nm->device);
     (void)hipStreamSynchronize(ctx_stream_of(nm->ctx));
     if (nm->d_tab) (void)hipFree(nm->d_tab);
+    if (nm->d_n_ids) (void)hipFree(nm->d_n_ids);
+    if (nm->d_text_of_id) (void)hipFree(nm->d_text_of_id);
     delete nm;
 }
 
@@ -369,6 +416,8 @@ static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, s
     s.h_buf_bytes = buf;
     if (!device_blocks) FQ_TRY(pinned_malloc((void **)&s.h_buf, buf, hipHostMallocDefault));
     FQ_TRY(pinned_malloc((void **)&s.h_st, sizeof(FqState), hipHostMallocDefault));
+    FQ_TRY(pinned_malloc((void **)&s.h_nids, 64, hipHostMallocDefault));
+    s.h_nids[0] = 0;
     FQ_TRY(dev_malloc((void **)&s.d_buf, buf));
     FQ_TRY(dev_malloc((void **)&s.d_st, sizeof(FqState)));
     FQ_TRY(dev_malloc((void **)&s.d_tile, (buf / 4096 + 2) * sizeof(uint32_t)));
@@ -696,7 +745,11 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     s.use_cache = snames && n && !by_copy;
     if (s.use_cache) {
         s.h_unknown[0] = 0;
-        FQ_TRY(launch_fq_name(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, s.h_ids, s.h_unknown, hs));
+        if (snames->dict) {
+            FQ_TRY(launch_fq_name_claim(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, snames->d_n_ids, (uint32_t)snames->limit, snames->d_text_of_id, s.h_ids,
+                                        s.h_unknown, hs));
+            FQ_TRY(hipMemcpyAsync(s.h_nids, snames->d_n_ids, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+        } else FQ_TRY(launch_fq_name(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, s.h_ids, s.h_unknown, hs));
         FQ_TRY(hipEventRecord(s.named, hs));
     }
     // the reads are classified where they lie in the raw block WHILE the host names the barcodes
@@ -725,6 +778,7 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     out->ids = s.h_ids;
     out->unknown = s.use_cache ? s.h_unknown + 1 : nullptr;
     out->n_unknown = s.use_cache ? s.h_unknown[0] : n;
+    out->dict_ids = (s.use_cache && snames->dict) ? std::min<uint64_t>(s.h_nids[0], snames->limit) : 0;
     s.state = Slot::OPEN;
     f->n_opened++;
     return HAST_OK;
@@ -859,6 +913,7 @@ hast_status hast_fq_commit(hast_fq *f) {
                 const uint32_t i = s.h_unknown[1 + j];
                 if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %u is outside the %zu counters", s.h_ids[i], i, nbc);
                 const uint32_t *t = s.h_bc + 2 * s.h_cap + 4 * (size_t)i;
+                if (nm->dict) continue;                                                       // (a dictionary names by itself: what it left is the host's for good)
                 if ((t[0] & 0xFFu) == 0xFFu || nm->count + np >= nm->limit) continue;          // long barcodes stay with the host
                 NamePub &p = s.h_pubs[np++];
                 p.key[0] = t[0]; p.key[1] = t[1]; p.key[2] = t[2]; p.key[3] = t[3];

@@ -498,6 +498,73 @@ hipError_t launch_fq_route(const uint8_t *d_buf, const FqState *d_st, const uint
     return hipGetLastError();
 }
 
+
+// The DICTIONARY variant (round 6): the table hands out the ids itself.  classify.cpp:52-56 gives a barcode its map entry at its first
+// sighting; until round 5 that first sighting went to the host (a dictionary insert there, the id taught back to this table): a third
+// of a read phase at 10M barcodes.  Here the lane that meets an unknown text claims its slot (compare-and-swap empty -> being written),
+// takes the next id from one counter, writes text and id, files the text under its id for the host (text_of_id: read once, at the
+// end, for printing) and publishes.  The same state machine as k_names_insert, for the same reason: two lanes of one wave may meet the
+// same new barcode.  Left to the host: texts longer than 15 bytes and what arrives once `limit` ids are out (the host names those in an
+// id range of its own, above `limit`).  Streams of several contexts of ONE GPU may run this on one table at the same time.
+__global__ void __launch_bounds__(256) k_fq_name_claim(const uint32_t *text, uint32_t n, NameEntry *tab, uint32_t mask, uint32_t *n_ids, uint32_t limit,
+                                                       uint4 *text_of_id, uint32_t *h_ids, uint32_t *h_unknown) {
+    const uint32_t n_round = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t r = 0; r < n_round; ++r) {
+        const uint32_t i = r * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
+        bool busy = i < n;
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (busy) t = reinterpret_cast<const uint4 *>(text)[i];
+        const uint32_t k[4] = {t.x, t.y, t.z, t.w};
+        uint32_t id = kNameUnknown;
+        if (busy && (t.x & 0xFFu) == 0xFFu) busy = false;              // longer than a text record: the host's
+        const bool mine = i < n;
+        uint32_t at = busy ? name_hash(k) & mask : 0, probes = 0;
+        while (__any(busy)) {
+            if (busy) {
+                NameEntry *e = &tab[at];
+                uint32_t st = __hip_atomic_load(&e->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (st == 0) {
+                    if (__hip_atomic_load(n_ids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit) busy = false;       // every id is out
+                    else {
+                        st = atomicCAS(&e->state, 0u, 1u);
+                        if (st == 0) {                                    // claimed
+                            const uint32_t got = atomicAdd(n_ids, 1u);
+                            if (got >= limit) {                           // (the last ids went while this lane claimed: give the slot back)
+                                __hip_atomic_store(&e->state, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                e->key[0] = k[0]; e->key[1] = k[1]; e->key[2] = k[2]; e->key[3] = k[3];
+                                e->id = got;
+                                text_of_id[got] = t;
+                                __hip_atomic_store(&e->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                id = got;
+                            }
+                            busy = false;
+                        }
+                    }
+                }
+                if (busy && st == 2) {
+                    if (e->key[0] == k[0] && e->key[1] == k[1] && e->key[2] == k[2] && e->key[3] == k[3]) { id = e->id; busy = false; }
+                    else {
+                        at = (at + 1) & mask;
+                        if (++probes > mask) busy = false;
+                    }
+                }
+                // st == 1: being written by another lane (of this wave, or of another stream's kernel) -- look again next round
+            }
+        }
+        if (mine) {
+            h_ids[i] = id;
+            if (id == kNameUnknown) h_unknown[1 + atomicAdd(&h_unknown[0], 1u)] = i;             // (pinned host memory)
+        }
+    }
+}
+hipError_t launch_fq_name_claim(const uint32_t *d_text, uint32_t n, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit, void *d_text_of_id,
+                                uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fq_name_claim, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, tab, mask, d_n_ids, limit,
+                       reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown);
+    return hipGetLastError();
+}
 hipError_t launch_fq_name(const uint32_t *d_text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fq_name, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, tab, mask, h_ids, h_unknown);

@@ -868,6 +868,33 @@ hast_status hast_counts_resize(hast_ctx *c, size_t n) {
     return HAST_OK;
 }
 
+hast_status hast_counts_permute(hast_ctx *c, const uint32_t *perm, size_t n_old, size_t n_new) {
+    if (hast_status st = use(c)) return st;
+    if (!c->d_counts || !c->counts_owned) return fail(HAST_ERR_INVALID, "hast_counts_permute: library-owned counters only (hast_counts_resize)");
+    if (n_old > c->n_barcodes || (n_old && !perm)) return fail(HAST_ERR_INVALID, "hast_counts_permute: n_old %zu > %zu counters", n_old, c->n_barcodes);
+    for (size_t i = 0; i < n_old; i++)
+        if (perm[i] >= n_new && perm[i] != 0xFFFFFFFFu) return fail(HAST_ERR_INVALID, "hast_counts_permute: perm[%zu] = %u is outside the %zu new records", i, perm[i], n_new);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long *d_new = nullptr;
+    uint32_t *d_perm = nullptr;
+    const size_t bytes = (n_new ? n_new : 1) * 4 * sizeof(unsigned long long);
+    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_new), bytes));
+    hipError_t e = dev_malloc(reinterpret_cast<void **>(&d_perm), (n_old ? n_old : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_new, 0, bytes, c->stream);
+    if (e == hipSuccess && n_old) e = hipMemcpyAsync(d_perm, perm, n_old * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_counts_permute(d_new, c->d_counts, d_perm, n_old, n_new, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_perm) (void)hipFree(d_perm);
+    if (e != hipSuccess) {
+        (void)hipFree(d_new);
+        return fail(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "hast_counts_permute: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(hipFree(c->d_counts));
+    c->d_counts = d_new;
+    c->n_barcodes = n_new;
+    return HAST_OK;
+}
+
 hast_status hast_counts_bind(hast_ctx *c, uint64_t *d_counts, size_t n) {
     if (hast_status st = use(c)) return st;
     if (!d_counts) return fail(HAST_ERR_INVALID, "d_counts is null");
@@ -912,22 +939,23 @@ hast_status hast_counts_unpack(hast_ctx *c, const uint64_t *d_packed, size_t n, 
     return HAST_OK;
 }
 
-hast_status hast_counts_read(hast_ctx *c, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n) {
+hast_status hast_counts_read_range(hast_ctx *c, size_t first, size_t n, uint64_t *c0, uint64_t *c1, uint64_t *neg) {
     if (hast_status st = use(c)) return st;
     if (!c->d_counts) return fail(HAST_ERR_INVALID, "no counters");
-    if (n > c->n_barcodes) return fail(HAST_ERR_INVALID, "n_barcodes %zu > %zu", n, c->n_barcodes);
+    if (first > c->n_barcodes || n > c->n_barcodes - first) return fail(HAST_ERR_INVALID, "records [%zu, %zu) of %zu counters", first, first + n, c->n_barcodes);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (hast_status st = check_classify_err(c, c->stream)) return st;
     if (!n) return HAST_OK;
     // the three live words of every record, as three arrays: 24 bytes per barcode over PCIe, each array straight into the caller's
     if (hast_status st = ensure_pack(c, n)) return st;
-    HIP_TRY(launch_counts_pack(c->d_counts, c->d_pack, n, c->stream));
+    HIP_TRY(launch_counts_pack(c->d_counts + 4 * first, c->d_pack, n, c->stream));
     uint64_t *dst[3] = {c0, c1, neg};
     for (int a = 0; a < 3; a++)
         if (dst[a]) HIP_TRY(hipMemcpyAsync(dst[a], c->d_pack + (size_t)a * n, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HAST_OK;
 }
+hast_status hast_counts_read(hast_ctx *c, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n) { return hast_counts_read_range(c, 0, n, c0, c1, neg); }
 
 // RCCL, resolved lazily so that single-GPU users never load it.
 // Any device list: contexts that share a GPU (a logical split, e.g. classify --devices 0,0 on a single-GPU box, or 0,0,1,1) are summed

@@ -185,6 +185,9 @@ hast_status hast_counts_resize(hast_ctx *, size_t n_barcodes);                 /
 hast_status hast_counts_bind(hast_ctx *, uint64_t *d_counts, size_t n_barcodes); /* caller-owned buffer, 32-byte aligned */
 hast_status hast_counts_zero(hast_ctx *, hast_stream);
 hast_status hast_counts_read(hast_ctx *, uint64_t *c0, uint64_t *c1, uint64_t *neg, size_t n_barcodes);
+/* the same for records [first, first + n): a job whose ids come from two numberings (a device dictionary from 0, the host's above
+ * hast_names_limit) reads the two ranges that exist */
+hast_status hast_counts_read_range(hast_ctx *, size_t first, size_t n, uint64_t *c0, uint64_t *c1, uint64_t *neg);
 /* The three live words of the first n_barcodes records as three arrays, d_packed = c0[n] | c1[n] | neg[n] (3 x n_barcodes u64, device),
  * and back (the records' three words are overwritten, the reserved one is left alone): what a caller that runs its own collective --
  * bench.py: one torch.distributed all_reduce over RCCL -- moves is 24 bytes per barcode, not the 32 of the padded records;
@@ -203,6 +206,10 @@ hast_status hast_counts_add_votes(hast_ctx *, const uint32_t *d_votes, const uin
  * only one), and the totals are handed back to every context.  The communicators of a device list
  * are created by the first call that names it and kept until the process ends (later calls only enqueue the all-reduce). */
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
+/* New counters of n_new records (zeroed), record i of the old ones (i < n_old <= the old size) ADDED to record perm[i] (perm: host array;
+ * several old records may name one new record; 0xFFFFFFFF: the record is dropped): how contexts whose dictionaries numbered the barcodes differently -- one device dictionary
+ * per GPU -- are brought into one id space before hast_counts_allreduce sums them. */
+hast_status hast_counts_permute(hast_ctx *, const uint32_t *perm, size_t n_old, size_t n_new);
 
 /* ---- classification: MultiThread::process_reads (classify.cpp:186-209) ---------------------
  * For each read: whole-read skip when it holds an upper-case 'N' (containN, :182-185,190-193);
@@ -292,6 +299,8 @@ typedef struct {
     uint32_t *ids;             /* [n_records]: ids the device-side name cache knew are filled in; the caller fills the others */
     const uint32_t *unknown;   /* [n_unknown] indices of the records whose ids the caller has to fill in, or NULL: all of them */
     uint64_t n_unknown;
+    uint64_t dict_ids;         /* a stream over a device dictionary (hast_names_create_dict): ids it had handed out when this block was
+                                  named -- every id of the block is below; the caller's counters must hold them before hast_fq_commit */
 } hast_fq_block;
 /* Device-side cache barcode text -> id of one GPU, shared by the FASTQ streams of all contexts on that GPU: barcodes repeat (hundreds of
  * reads each), so after the first blocks the framer names almost every record itself and the host only sees new barcodes
@@ -300,6 +309,17 @@ typedef struct {
  * barcodes than that are simply not cached. */
 typedef struct hast_names hast_names;
 hast_status hast_names_create(hast_ctx *, size_t max_barcodes, hast_names **out);
+/* The table as the job's DICTIONARY on its GPU (round 6; classify.cpp:52-56: a barcode gets its map entry at its first sighting): the
+ * framer's naming kernel hands out the dense ids itself -- 0 .. hast_names_limit() - 1 in the order in which new texts are met, one atomic
+ * counter -- so no first sighting goes through the host.  Left to the caller (hast_fq_block.unknown, as before): texts longer than 15
+ * bytes and what arrives once every id is out; the caller names those in an id range of its own at or above hast_names_limit().
+ * hast_names_count: ids handed out so far; hast_names_texts: the text records (16 bytes: length byte + text) of ids [first, first + n),
+ * read once at the end for printing.  Dictionaries of different GPUs number independently: their counters are merged by text
+ * (hast_counts_permute, then hast_counts_allreduce). */
+hast_status hast_names_create_dict(hast_ctx *, size_t max_barcodes, hast_names **out);
+size_t      hast_names_limit(const hast_names *);
+hast_status hast_names_count(hast_names *, size_t *n_ids);
+hast_status hast_names_texts(hast_names *, size_t first, size_t n, uint8_t *out16);
 void        hast_names_destroy(hast_names *);
 /* Entries the caller knows: n text records (16 bytes each: length byte + up to 15 bytes of text, the format of hast_fq_block.bc_text)
  * with their ids -- e.g. a table barcode -> class for a routing stream (hast_fq_set_route).  Returns when they are on the device. */

@@ -105,6 +105,33 @@ def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, 
         assert all(x > 0 for x in per), line
 
 
+@pytest.mark.parametrize("env,extra", [({"HAST_NAME_DICT": "0"}, []), ({"HAST_NAME_CACHE": "64"}, []), ({"HAST_NAME_CACHE": "64"}, ["--initial-barcodes", "3", "--batch-reads", "97"]),
+                                       ({"HAST_NAME_DICT": "context"}, ["--devices", "0,0,0"]),
+                                       ({"HAST_NAME_DICT": "context"}, ["--devices", "0,0,0", "--batch-reads", "50", "--initial-barcodes", "50"]),
+                                       ({"HAST_NAME_DICT": "context", "HAST_NAME_CACHE": "64"}, ["--devices", "0,0", "--batch-reads", "120", "--initial-barcodes", "7"]),
+                                       ({"HAST_NAME_DICT": "context", "HAST_DEAL": "files"}, ["--devices", "0,0"]),
+                                       ({}, ["--initial-barcodes", "3", "--batch-reads", "31"])])
+@pytest.mark.parametrize("case,run", golden_cases("s01"))
+def test_cli_who_numbers_the_barcodes(exe, golden_workdir, case, run, env, extra):
+    """The ids of the barcodes come from the GPU's own dictionary (round 6; classify.cpp:52-56 on the device: the naming kernel claims
+    a slot for a new text and takes the next id from one counter), the host reads the texts by id once, for printing.  Same stdout
+    as the real reference binary with: the host's dictionary as up to round 5 (HAST_NAME_DICT=0); a dictionary of 64 ids, so that
+    most barcodes are named by the host in its own id range above the device's (and the counters regrow under both numberings);
+    one dictionary per CONTEXT (what several GPUs have: each numbers in its own order), the counters merged by text -- at the end, and
+    at every regrowth in the middle of the run; whole files dealt to the contexts."""
+    if case not in ("rand_k21", "edge_k7") and (extra or len(env) > 1):
+        pytest.skip("the combinations run on two cases (suite time)")
+    meta = load_case(case)["runs"][run]
+    d = golden_workdir / case
+    res = subprocess.run([exe] + meta["argv"] + extra + ["--stats"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, **env))
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert res.stdout == open(d / meta["expected"], "rb").read()
+    line = [l for l in res.stderr.decode().splitlines() if l.startswith("__stats_read_phase__")][0]
+    kv = dict(x.split("=") for x in line.split()[1:])
+    if not env and case.startswith("rand_"):
+        assert int(kv["records_named_on_host"]) == 0, line       # stLFR barcodes fit a text record: nothing is left to the host
+
+
 @pytest.mark.parametrize("extra", [["--batch-reads", "257"], ["--batch-reads", "13"], ["--batch-reads", "257", "--host-parse"]])
 def test_cli_small_batches_and_counter_growth(exe, golden_workdir, extra, monkeypatch):
     """Tiny blocks (82 KB / 4 KB: every other record straddles a block border of the GPU framer) force many launches and the

@@ -59,9 +59,12 @@ def make_fastq(rng, n, k, keys, tail):
     return text.encode()
 
 
-def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=(), eager=False):
+def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=(), eager=False, dict_mode=False):
     """feed `data` to hast_fq_* in pieces of lo..hi bytes, name the records the way the CLI does; returns the barcodes in record
     order, the dictionary, the base count, the per-block short-read flags and how many records the host had to name.
+    dict_mode: the table is the DICTIONARY (hast_names_create_dict): the device hands out the ids below hast_names_limit itself, the
+    caller names what is left to it (long texts, and what arrives when every id is out) from the limit upwards; checked here: one id
+    per text, dense from 0, below dict_ids, and the texts the dictionary files under its ids are the barcodes.
     more_ctxs: further contexts -> a striped stream (block i on context i % n; n_buffers per context; lo == hi: full blocks);
     eager: open a block as soon as the one behind it has been submitted (else: as late as the buffers allow)"""
     lib = hast_amd.lib()
@@ -73,7 +76,7 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=
         for c in ctxs:
             h = C.c_void_p()
             if cache:
-                assert lib.hast_names_create(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
+                assert (lib.hast_names_create_dict if dict_mode else lib.hast_names_create)(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
             nms.append(h)
         arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
         narr = (C.c_void_p * len(ctxs))(*[h.value for h in nms])
@@ -81,11 +84,13 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=
         assert lib.hast_fq_lanes(fq) == len(ctxs) and lib.hast_fq_block_bytes(fq) == hi
     else:
         if cache:
-            assert lib.hast_names_create(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
+            assert (lib.hast_names_create_dict if dict_mode else lib.hast_names_create)(ctx._h, cache, C.byref(nm)) == 0, lib.hast_last_error()
         assert lib.hast_fq_create(ctx._h, hi, n_buffers, nm, C.byref(fq)) == 0, lib.hast_last_error()
     names, got, pos, pending = {}, [], 0, 0
     st = {"host_named": 0, "n_bases": 0}
     short = []
+    limit = lib.hast_names_limit(nms[0] if nms else nm) if dict_mode else 0
+    host_names = {}
 
     def drain():
         b = FqBlock()
@@ -97,6 +102,21 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=
                 t = bytes(b.bc_text[16 * i:16 * i + 16])
                 assert (t[0] == 0xFF and len(bc) > 15) or (t[0] == len(bc) and t[1:1 + t[0]] == bc), (bc, t)
             got.append(bc)
+        if b.unknown and dict_mode:
+            todo = [b.unknown[j] for j in range(b.n_unknown)]
+            base = len(got) - b.n_records
+            for i in set(range(b.n_records)) - set(todo):      # the dictionary's own ids: one per text, below what it says it has handed out
+                bc = got[base + i]
+                assert b.ids[i] < b.dict_ids <= limit and len(bc) <= 15, (bc, b.ids[i], b.dict_ids)
+                assert names.setdefault(bc, b.ids[i]) == b.ids[i], (bc, b.ids[i], names[bc])
+            for i in todo:                           # left to the caller: longer than a text record, or every id was out
+                bc = got[base + i]
+                assert len(bc) > 15 or b.dict_ids >= limit or bc in host_names, (bc, b.dict_ids, limit)
+                b.ids[i] = names.setdefault(bc, limit + host_names.setdefault(bc, len(host_names)))
+            st["host_named"] += len(todo)
+            st["n_bases"] += b.n_bases
+            assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
+            return
         if b.unknown:
             assert cache and b.n_unknown <= b.n_records
             todo = [b.unknown[j] for j in range(b.n_unknown)]
@@ -138,6 +158,17 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=
         st["lane_records"] = [lib.hast_fq_lane_records(fq, g) for g in range(len(ctxs))]
         assert sum(st["lane_records"]) == len(got)
     lib.hast_fq_destroy(fq)
+    if dict_mode and len(ctxs) == 1:
+        # the ids are dense from 0, and what the dictionary filed under them is the text
+        n = C.c_size_t()
+        assert lib.hast_names_count(nm, C.byref(n)) == 0
+        dev = {bc: i for bc, i in names.items() if i < limit}
+        assert sorted(dev.values()) == list(range(n.value)), (n.value, len(dev))
+        txt = (C.c_uint8 * (16 * max(n.value, 1)))()
+        assert lib.hast_names_texts(nm, 0, n.value, txt) == 0, lib.hast_last_error()
+        raw = bytes(txt)
+        for bc, i in dev.items():
+            assert raw[16 * i] == len(bc) and raw[16 * i + 1:16 * i + 1 + len(bc)] == bc, (bc, i)
     for h in nms + [nm]:
         if h:
             lib.hast_names_destroy(h)
@@ -149,12 +180,14 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=
 SEEDS = {"plain": 11, "no_final_newline": 23, "header_only": 37, "unterminated_header": 41, "bases_no_newline": 59}
 
 
-@pytest.mark.parametrize("cache", [0, 64, 1 << 16])
+@pytest.mark.parametrize("cache", [0, 64, 1 << 16, -64, -(1 << 16)])
 @pytest.mark.parametrize("tail", ["plain", "no_final_newline", "header_only", "unterminated_header", "bases_no_newline"])
 @pytest.mark.parametrize("chunk", [(700, 4096), (4096, 4096), (50_000, 65536)])
 def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
     """cache: size of the device-side barcode name cache (0: none, the caller names every record; 64: far too small for the
-    ~300 barcodes of the input, so it fills up and stops learning; 65536: ample)"""
+    ~300 barcodes of the input, so it fills up and stops learning; 65536: ample; negative: the table is the DICTIONARY of that size --
+    it hands out the ids itself, -64: 64 of them, the rest is the caller's, in its own id range above)"""
+    dict_mode, cache = cache < 0, abs(cache)
     lo, hi = chunk
     rng = random.Random(SEEDS[tail] * 1000 + chunk[0] % 997)       # literal seeds: a failure can be replayed
     k, n_keys = 21, 3000
@@ -166,10 +199,13 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
         ctx.table_reserve(2 * n_keys)
         ctx.table_insert_keys(0, keys[0])
         ctx.table_insert_keys(1, keys[1])
-        ctx.counts_resize(4096)
-        got, names, n_bases, short, host_named = stream_through_framer(ctx, data, lo, hi, cache, rng)
-        counts = ctx.counts_read(len(names))
-    if cache >= 1 << 16 and chunk[0] < 5000:
+        ctx.counts_resize((cache if dict_mode else 0) + 4096)
+        got, names, n_bases, short, host_named = stream_through_framer(ctx, data, lo, hi, cache, rng, dict_mode=dict_mode)
+        n_ids = max(names.values()) + 1 if names else 0
+        counts = ctx.counts_read(n_ids)
+    if dict_mode and cache >= 1 << 16:
+        assert host_named == sum(1 for bc in got if len(bc) > 15)          # only what does not fit a text record
+    elif cache >= 1 << 16 and chunk[0] < 5000:
         # many small blocks: the cache learns early; what stays with the host are the barcodes longer than 15 bytes (a quarter of
         # the records here) and first sightings
         n_long = sum(1 for bc in got if len(bc) > 15)
@@ -190,7 +226,7 @@ def test_fq_framing_and_counts(oracle_lib, tail, chunk, cache):
     off = np.zeros(len(want) + 1, np.uint64)
     off[1:] = np.cumsum([len(s) for _, s in want])
     ids = np.array([names[bc] for bc, _ in want], dtype=np.uint32)
-    e = [np.zeros(len(names), np.uint32) for _ in range(3)]
+    e = [np.zeros(n_ids, np.uint32) for _ in range(3)]
     oracle_lib.ho_classify_ids(oc, bases.ctypes.data, off.ctypes.data, ids.ctypes.data, ids.size, e[0].ctypes.data, e[1].ctypes.data,
                                e[2].ctypes.data, None, 2)
     oracle_lib.ho_free(oc)
@@ -212,7 +248,7 @@ def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=40
         for c in ctxs:
             h = C.c_void_p()
             if cache:
-                assert lib.hast_names_create(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
+                assert (lib.hast_names_create_dict if dict_mode else lib.hast_names_create)(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
             nms.append(h)
         arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
         narr = (C.c_void_p * len(ctxs))(*[h.value for h in nms])
