@@ -576,6 +576,26 @@ hipError_t launch_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, 
     return hipGetLastError();
 }
 
+// counters renumbered: record i of `src` (4 x u64, three live words) is added to record perm[i] of `dst` (several may name one: atomics).
+// Dictionaries of different GPUs number the barcodes in their own order: hast_counts_permute brings every context's counters into the
+// merged numbering before the one all-reduce.  (Lives here, with the dictionary, not with the classification kernels.)
+__global__ void __launch_bounds__(256) k_counts_permute(unsigned long long *dst, const unsigned long long *src, const uint32_t *perm, size_t n_old, size_t n_new) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_old; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t to = perm[i];
+        if (to >= n_new) continue;
+        for (int w = 0; w < 3; ++w) {
+            const unsigned long long v = src[4 * i + w];
+            if (v) atomicAdd(&dst[4 * to + w], v);
+        }
+    }
+}
+hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_old, size_t n_new, hipStream_t s) {
+    if (n_old == 0) return hipSuccess;
+    const size_t blocks = (n_old + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(k_counts_permute, dim3((unsigned)(blocks < 1 ? 1 : blocks > 65535 ? 65535 : blocks)), dim3(256), 0, s, d_dst, d_src, d_perm, n_old, n_new);
+    return hipGetLastError();
+}
+
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
                            uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last, hipStream_t s) {

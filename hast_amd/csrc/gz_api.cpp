@@ -83,7 +83,7 @@ struct Batch {                                // accepted chunks the consumer ma
 };
 
 struct Arena {
-    DevBuf syms, windows, acc, need, crc, carry;   // (need: scratch of the windows pass)
+    DevBuf syms, windows, acc, need, crc, carry, cursor;   // (need: scratch of the windows pass; cursor: slots of `syms` taken by the pass in flight)
     std::vector<DevBuf> gap;                  // follow-up jobs' symbols (reused from batch to batch)
     size_t gap_used = 0;
     bool busy = false;                        // a published batch lives in it
@@ -120,6 +120,11 @@ struct hast_gz {
     uint64_t file_size = 0;
     size_t chunk_bytes = 32768, seg_chunks = 4096;
     double room = 12.0;
+    double slot_fraction = 0.70;              // slots of a pass's arena per chunk of the pass (HAST_GZ_SLOT_FRACTION): 4 chunks in 10 of a FASTQ hold no
+                                              // block start and need none; a chunk that finds the pool empty is decoded by a follow-up job
+    bool slot_adaptive = true;                // ... and the share follows what the passes walked so far have found (upwards only: a stream of small
+                                              // blocks has a start in every chunk); a file of one pass takes a slot per chunk
+    size_t pool_slots(size_t chunks) const { return std::min(chunks, std::max<size_t>(4, (size_t)((double)chunks * slot_fraction + 0.999))); }
     uint32_t slot_syms = 0;
     size_t h_jobs_cap = 0;
     std::vector<std::unique_ptr<Unit>> units; // segment k -> units[k % n]
@@ -397,7 +402,9 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     const int jb = g->jobs_of(k);
     ChunkJob *hj = U.h_jobs[jb];
     size_t n_jobs = 0;
-    GZ_HIP(A.syms.ensure((size_t)(c1 - c0) * g->slot_syms * sizeof(uint16_t) + 64));
+    const size_t n_slots = g->pool_slots(c1 - c0);
+    GZ_HIP(A.syms.ensure(n_slots * g->slot_syms * sizeof(uint16_t) + 64));
+    GZ_HIP(A.cursor.ensure(64));
     const uint64_t sym_base = reinterpret_cast<uintptr_t>(A.syms.p) / 2;      // job.sym_off counts u16 from address 0
     for (size_t c = c0; c < c1; ++c) {
         ChunkJob &j = hj[n_jobs];
@@ -411,15 +418,17 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
         j.stop_bit = (uint64_t)(c + 1) * C * 8;
         j.search_to_lo = (uint32_t)(j.stop_bit - j.from_bit);
         j.sym_cap = g->slot_syms;
-        j.sym_off = sym_base + (uint64_t)(c - c0) * g->slot_syms;
+        j.sym_off = sym_base;                                                 // (the pool: the kernel hands the slots out, ChunkJob)
+        j.flags |= kJobPoolSlot;
         g->job_view(j);
         ++n_jobs;
     }
     N.n_jobs = n_jobs;
     if (n_jobs) {
         GZ_HIP(hipMemcpyAsync(U.jobs[jb].p, hj, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, U.dec_stream));
+        GZ_HIP(hipMemsetAsync(A.cursor.p, 0, 64, U.dec_stream));
         GZ_HIP(launch_search((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, U.dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, (uint16_t *)A.syms.p, U.dec_stream));
+        GZ_HIP(launch_decode((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, (uint16_t *)A.syms.p, (uint32_t *)A.cursor.p, (uint32_t)n_slots, U.dec_stream));
         GZ_HIP(hipMemcpyAsync(hj, U.jobs[jb].p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, U.dec_stream));
     }
     GZ_HIP(hipEventRecord(U.nom_done[jb], U.dec_stream));
@@ -446,6 +455,12 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
     // (chain_walk_s: what the host does ALONE between the kernels -- accepting chunks, planning follow-up jobs, combining CRCs: the
     // serial share of one deflate stream however many GPUs decode its passes)
     double t_cw = now_s();
+    if (g->slot_adaptive && N.n_jobs >= 64) {                       // the share of chunks that had a block start: the later passes' pools follow it
+        size_t found = 0;
+        for (size_t i = 0; i < N.n_jobs; ++i) found += (U.h_jobs[g->jobs_of(N.k)][i].status & kStFound) ? 1 : 0;
+        const double want = std::min(1.0, (double)found / (double)N.n_jobs * 1.08 + 0.02);
+        if (want > g->slot_fraction) g->slot_fraction = want;
+    }
     g->chain.add_candidates(U.h_jobs[g->jobs_of(N.k)], N.n_jobs, all_in);
     // ---- the chain, with its follow-up jobs ------------------------------------------------------------------------------------
     std::vector<Chain::Gap> gaps;
@@ -474,7 +489,7 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
             g->job_view(j);
         }
         GZ_HIP(hipMemcpyAsync(U.fjobs.p, U.h_fjobs, gaps.size() * sizeof(ChunkJob), hipMemcpyHostToDevice, U.post_stream));
-        GZ_HIP(launch_decode((ChunkJob *)U.fjobs.p, (uint32_t)gaps.size(), U.d_in, input_bits, (uint16_t *)gb.p, U.post_stream));
+        GZ_HIP(launch_decode((ChunkJob *)U.fjobs.p, (uint32_t)gaps.size(), U.d_in, input_bits, (uint16_t *)gb.p, nullptr, 0, U.post_stream));
         GZ_HIP(hipMemcpyAsync(U.h_fjobs, U.fjobs.p, gaps.size() * sizeof(ChunkJob), hipMemcpyDeviceToHost, U.post_stream));
         GZ_HIP(hipStreamSynchronize(U.post_stream));
         t_cw = now_s();
@@ -671,15 +686,28 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         if (const char *e = getenv("HAST_GZ_CHUNK_BYTES")) chunk_bytes = (size_t)std::max(0L, atol(e));
     if (!seg_chunks)
         if (const char *e = getenv("HAST_GZ_PASS_CHUNKS")) seg_chunks = (size_t)std::max(0L, atol(e));
-    g->chunk_bytes = chunk_bytes ? std::max<size_t>(chunk_bytes, 64) : 32768;
+    // Round 6: 16-KB chunks, 6144 a pass, 20 symbols of room per compressed byte (until then 32 KB / 4096 / 12).  A decode pass lasts as long
+    // as its slowest wave and its waves issue for 39 % of their lifetime (profiles/round5_gz_kernels_pmc.txt): what it loses is occupancy,
+    // so a pass wants more and finer work units than the GPU has wave slots (4480).  With 16-KB chunks a wave's work is ~one deflate block
+    // instead of one to two, 42 % of the chunks hold no block start and cost nothing, and the hardware hands a freed wave slot the
+    // next chunk: the decode kernels' time on 20M reads 247 -> 180 ms (constant quality lines) / 339 -> 268 ms (noisy ones), with an arena of
+    // 2.8 GB instead of 3.2 GB because its slots are handed out on the device (slot_fraction; profiles/round6_gz_geom.txt).
+    const bool default_geometry = !chunk_bytes && !seg_chunks && room <= 0;
+    g->chunk_bytes = chunk_bytes ? std::max<size_t>(chunk_bytes, 64) : 16384;
     g->chunk_bytes = (g->chunk_bytes + 3) & ~(size_t)3;
     // 4096 chunks a pass x 786 KB of symbol room = 3.2 GB an arena (measured against the tree before the pipelined
     // producer, alternating on one box: passes of 2048 chunks were slower than that tree, 4096 10 % faster, 8192 no faster).  Keep the
     // footprint small: on some boxes of the pool ONE HIP call of a process that starts right after another one freed tens of GB blocks
     // for 0.7-6 s (hipMalloc or hipStreamCreate, whichever comes first -- tools/probe/malloc_probe.py; the tree before did the same there).
-    g->seg_chunks = seg_chunks ? seg_chunks : 4096;
+    g->seg_chunks = seg_chunks ? seg_chunks : (chunk_bytes ? 4096 : 6144);
     if (const char *e = getenv("HAST_GZ_ARENAS")) g->n_arenas = std::min((int)Unit::kArenas, std::max(2, atoi(e)));
-    g->room = room > 0 ? room : 12.0;
+    if (room <= 0)
+        if (const char *e = getenv("HAST_GZ_ROOM")) room = atof(e);          // (measurements: symbols of room per compressed byte of a chunk)
+    if (const char *e = getenv("HAST_GZ_SLOT_FRACTION")) {
+        g->slot_fraction = std::min(1.0, std::max(0.01, atof(e)));
+        g->slot_adaptive = false;
+    }
+    g->room = room > 0 ? room : (default_geometry ? 20.0 : 12.0);
     if (g->chunk_bytes > (1u << 26)) { close(fd); return set_error(HAST_ERR_INVALID, "chunk_bytes too large"); }
     g->slot_syms = (uint32_t)std::min<double>((double)(1u << 27), (double)g->chunk_bytes * g->room + 600);
     g->slot_syms = (g->slot_syms + 7) & ~7u;
@@ -698,6 +726,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     const size_t s0 = std::min<size_t>(seg, 1024);
     const size_t n_seg = n_chunks <= s0 ? 1 : 1 + (n_chunks - s0 + seg - 1) / seg;
     if (g->units.size() > n_seg) g->units.resize(std::max<size_t>(1, n_seg));       // (a unit without a segment would hold memory for nothing)
+    if (n_seg <= 2 && g->slot_adaptive) g->slot_fraction = 1.0;                      // (a file of one or two passes: nothing to learn from, little to save)
     const size_t nu = g->units.size();
     {
         // the ring (hast_gz): at least what the passes in flight span -- the segment being walked, one per unit in front of it, the
@@ -779,7 +808,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
             if (k >= n_seg) break;
             const size_t first = n_seg == 1 ? std::max(s0, std::min(seg, n_chunks)) : s0;
             const size_t chunks = k == 0 ? (n_seg > (size_t)g->n_arenas * nu ? std::max(first, seg) : first) : seg;
-            const size_t bytes = chunks * (size_t)g->slot_syms * sizeof(uint16_t) + 64;
+            const size_t bytes = g->pool_slots(chunks) * (size_t)g->slot_syms * sizeof(uint16_t) + 64;
             if (i == 0) step(U.arena[i].syms.ensure(bytes));
             else later += bytes + chunks * ((size_t)kWindow * 3 + 64);              // (+ windows, maps, per-chunk words of a batch)
         }
@@ -839,7 +868,7 @@ void hast_gz_close(hast_gz *g) {
         for (Arena &a : U.arena) {
             if (a.done_recorded) (void)hipEventSynchronize(a.done);
             if (a.done) (void)hipEventDestroy(a.done);
-            for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry}) b->release();
+            for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry, &a.cursor}) b->release();
             for (DevBuf &b : a.gap) b.release();
         }
         for (int i = 0; i < 2; ++i) {

@@ -60,7 +60,8 @@ enum : uint32_t {
 struct ChunkJob {               // 80 bytes; one per chunk, device memory
     uint64_t from_bit;          // in: known start (flags & 1) or where the search starts
     uint64_t stop_bit;          // in: decode until the first block boundary >= this
-    uint64_t sym_off;           // in: first symbol of this chunk's buffer in the arena (u16 units)
+    uint64_t sym_off;           // in: first symbol of this chunk's buffer in the arena (u16 units); with kJobPoolSlot: the first symbol of the
+                                //     pass's slot POOL -- the decode kernel takes the next slot of sym_cap symbols and writes the chunk's own offset back
     uint32_t sym_cap;           // in: symbols of room
     uint32_t flags;             // in: 1 = from_bit is a proven block start (no search), 2 = nothing in front may be copied (a member starts here)
     uint64_t start_bit;         // out
@@ -75,7 +76,10 @@ struct ChunkJob {               // 80 bytes; one per chunk, device memory
     uint64_t limit_bits;
 };
 static_assert(sizeof(ChunkJob) == 80, "ChunkJob is copied to and from the device as it is");
-constexpr uint32_t kJobKnown = 1, kJobNoHistory = 2;
+// kJobPoolSlot (round 6): 4 chunks in 10 of a FASTQ hold no block start and decode nothing; a pass's arena therefore holds fewer slots than
+// the pass has chunks, and a chunk that HAS a start takes the next free one (one atomic per chunk).  When the pool is empty the chunk
+// reports "found, no room, no block decoded", which the chain already knows: a follow-up job decodes from its start with room of its own.
+constexpr uint32_t kJobKnown = 1, kJobNoHistory = 2, kJobPoolSlot = 4;
 
 // ---- bit input: aligned 32-bit words, LSB first; the buffer holds >= 2 zero words behind its last real bit -------------------
 struct Bits {

@@ -18,7 +18,9 @@ struct AccDev {                  // an accepted chunk, in stream order
 
 hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, hipStream_t s);
 // a wave per job; job.sym_off = the device address of the job's symbol buffer / 2; d_syms: the allocation those buffers lie in
-hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint16_t *d_syms, hipStream_t s);
+// jobs with kJobPoolSlot take their symbol buffer out of a pool of pool_slots slots of job.sym_cap symbols from job.sym_off on (*d_pool_cursor
+// = slots taken, zeroed by the caller in front of the launch)
+hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint16_t *d_syms, uint32_t *d_pool_cursor, uint32_t pool_slots, hipStream_t s);
 // d_windows[c] = the 32 KB behind chunk c; d_carry = the 32 KB in front of chunk 0; d_scratch: windows_scratch_bytes(n)
 size_t windows_scratch_bytes(uint32_t n);
 hipError_t launch_windows(const AccDev *d_acc, uint32_t n, uint8_t *d_windows, const uint8_t *d_carry, void *d_scratch, hipStream_t s);

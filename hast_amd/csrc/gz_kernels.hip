@@ -210,7 +210,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {              //
 // syms + offset, so that the compiler knows it for GLOBAL memory -- through a generic pointer the stores are FLAT instructions,
 // which count as LDS operations too, and every table look-up then waits for the symbol stores in flight: measured 2000 cycles per
 // symbol instead of ~300)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w_file, uint64_t nbits_up, uint16_t *__restrict__ syms) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) k_gz_decode(ChunkJob *jobs, uint32_t n_jobs, const uint32_t *__restrict__ w_file, uint64_t nbits_up, uint16_t *__restrict__ syms, uint32_t *pool_cursor, uint32_t pool_slots) {
     __shared__ uint32_t s_tab[kLitTabCap + kDistTabCap];
     // two lives: while lane 0 parses a block's header, the code-length code's table (kPreTabCap words) and what the parse indexes by
     // values it has just read (HdrScratch: no scratch memory); in the symbol loop, the compressed words around the read position
@@ -232,6 +232,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
             jobs[j].end_bit = job.start_bit;
         }
         return;
+    }
+    if (job.flags & kJobPoolSlot) {                                           // (wave-uniform) the next free slot of the pass's pool
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(pool_cursor, 1u);
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot >= pool_slots) {                                             // none left: a follow-up job's business (gz_chain.h)
+            if (lane == 0) {
+                jobs[j].n_out = 0;
+                jobs[j].end_bit = job.start_bit;
+                jobs[j].status = kStFound | kStNoRoom | kStNoBlock;
+                jobs[j].err_code = kErrNone;
+            }
+            return;
+        }
+        job.sym_off += (uint64_t)slot * job.sym_cap;
+        if (lane == 0) jobs[j].sym_off = job.sym_off;
     }
     const uint32_t *__restrict__ const w = w_file - (ptrdiff_t)job.in_adj_words;           // (a ring of the file on the device: this job's view, ChunkJob)
     const uint64_t nbits = job.limit_bits && job.limit_bits < nbits_up ? job.limit_bits : nbits_up;
@@ -654,9 +670,9 @@ hipError_t launch_search(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint
     hipLaunchKernelGGL(k_gz_search, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits);
     return hipGetLastError();
 }
-hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint16_t *d_syms, hipStream_t s) {
+hipError_t launch_decode(ChunkJob *d_jobs, uint32_t n, const uint32_t *d_w, uint64_t nbits, uint16_t *d_syms, uint32_t *d_pool_cursor, uint32_t pool_slots, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_decode, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits, d_syms);
+    hipLaunchKernelGGL(k_gz_decode, dim3(n), dim3(64), 0, s, d_jobs, n, d_w, nbits, d_syms, d_pool_cursor, pool_slots);
     return hipGetLastError();
 }
 size_t windows_scratch_bytes(uint32_t n) { return (size_t)n * kWindow * sizeof(uint16_t) + (size_t)((n + kGroup - 1) / kGroup) * kWindow; }

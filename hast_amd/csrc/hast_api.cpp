@@ -25,6 +25,7 @@
 #include "hast_common.h"
 #include "hast_device.h"
 #include "kc_device.h"
+#include "fq_device.h"
 #include "hast_internal.h"
 #include "worker_pool.h"
 

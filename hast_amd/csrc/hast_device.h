@@ -75,7 +75,6 @@ bool commit_partition_usable(size_t n_reads, size_t n_barcodes, uint32_t max_vot
 size_t commit_partition_scratch_bytes(size_t n_reads, size_t n_barcodes, uint32_t *n_bins_out, uint32_t *cap_out);
 hipError_t launch_commit_partitioned(const uint32_t *d_votes, const uint32_t *d_barcode_ids, unsigned long long *d_counts, size_t n_barcodes, size_t n_reads,
                                      void *d_scratch, hipStream_t s);
-hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_old, size_t n_new, hipStream_t s);
 hipError_t launch_add_u64(unsigned long long *d_dst, const unsigned long long *d_src, size_t n, hipStream_t s);          // dst[i] += src[i]
 // counts[n][4] -> packed = c0[n] | c1[n] | neg[n] and back (the reserved word stays where it is)
 hipError_t launch_counts_pack(const unsigned long long *d_counts, unsigned long long *d_packed, size_t n, hipStream_t s);

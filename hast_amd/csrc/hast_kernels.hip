@@ -1009,23 +1009,6 @@ hipError_t launch_build_segments(const uint64_t *d_offsets, const uint32_t *d_le
 __global__ void __launch_bounds__(256) k_add_u64(unsigned long long *dst, const unsigned long long *src, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
-// counters renumbered: record i of `src` is added to record perm[i] of `dst` (several may name one: atomics; dictionaries of different
-// GPUs number the barcodes in their own order, hast_counts_permute)
-__global__ void __launch_bounds__(256) k_counts_permute(unsigned long long *dst, const unsigned long long *src, const uint32_t *perm, size_t n_old, size_t n_new) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_old; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t to = perm[i];
-        if (to >= n_new) continue;
-        for (int w = 0; w < 3; ++w) {
-            const unsigned long long v = src[4 * i + w];
-            if (v) atomicAdd(&dst[4 * to + w], v);
-        }
-    }
-}
-hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_old, size_t n_new, hipStream_t s) {
-    if (n_old == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_counts_permute, dim3(grid_for(n_old, 256, 256 * 16)), dim3(256), 0, s, d_dst, d_src, d_perm, n_old, n_new);
-    return hipGetLastError();
-}
 hipError_t launch_add_u64(unsigned long long *d_dst, const unsigned long long *d_src, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_add_u64, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_dst, d_src, n);

@@ -572,6 +572,66 @@ def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def _free_bytes(path):
+    st = os.statvfs(path)
+    return st.f_bavail * st.f_frsize
+
+
+@pytest.mark.heavy
+@pytest.mark.skipif(not os.environ.get("HAST_HEAVY_FILES"), reason="opt-in (HAST_HEAVY_FILES=1 or =<read pairs>): tens of GB of files and minutes of host time")
+def test_cli_baseline_size_files_through_the_boundary(exe, oracle_dir):
+    """The boundary at the size the reference is built for (classify.cpp:238-278 streams inputs of any size; HAST.sh:162-166: two .fq.gz;
+    BASELINE config 2: 200M reads): HAST_HEAVY_FILES=1 writes 100M read pairs (68.6 GB of FASTQ, 50M + 50M k-mers as text, 1M barcodes)
+    into /dev/shm, compresses each file into ONE gzip member of 6.3 GB (tools/pgzip1: the device inflate's ring engages at its 2-GB
+    default and a stream hands out > 4 GiB), and runs `classify` on the plain files, on the .gz files, over two contexts, and with
+    --phase-reads (every byte routed: the routed files add up to the inputs).  HAST_HEAVY_FILES=<pairs> scales it; HAST_HEAVY_ORACLE=1
+    adds the oracle's program over the same files (minutes on the host's cores).  Skipped where /dev/shm lacks the room.
+    tools/gpu/cli_c2.sh is the same job with timings (profiles/round6_cli_c2.txt)."""
+    import shutil
+    import tempfile
+    from tests.conftest import ROOT
+    v = os.environ["HAST_HEAVY_FILES"]
+    pairs = 100_000_000 if v == "1" else int(v)
+    need = pairs * 2 * 343 * 2.3 + 3e9                       # FASTQ + .gz + one routed copy
+    if _free_bytes("/dev/shm") < need:
+        pytest.skip("needs %.0f GB in /dev/shm" % (need / 1e9))
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tools"), "gen_fastq", "pgzip1"], check=True)
+    d = tempfile.mkdtemp(prefix="hast_heavy.", dir="/dev/shm")
+    try:
+        keys = min(50_000_000, max(1000, pairs // 2))
+        subprocess.run([os.path.join(ROOT, "tools", "gen_fastq"), d, str(pairs), str(keys), "1000000", "21", "150", "32"], check=True, timeout=1200,
+                       env=dict(os.environ, GEN_FASTQ_MAX_GB="90"))
+        for f in ("r1.fq", "r2.fq"):
+            subprocess.run([os.path.join(ROOT, "tools", "pgzip1"), os.path.join(d, f), os.path.join(d, f + ".gz"), "6", "16", "32"], check=True, timeout=1800)
+        args = ["--hap0", "hap0.mer", "--hap1", "hap1.mer", "--thread", "32", "--weight0", "1.04", "--stats"]
+        plain, gz = ["--read", "r1.fq", "--read", "r2.fq"], ["--read", "r1.fq.gz", "--read", "r2.fq.gz"]
+        ref = subprocess.run([exe] + args + plain, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+        assert ref.returncode == 0, ref.stderr.decode()[-2000:]
+        assert len(ref.stdout.splitlines()) > 1000
+        for extra in (gz, gz + ["--devices", "0,0"]):
+            got = subprocess.run([exe] + args + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+            assert got.returncode == 0, got.stderr.decode()[-2000:]
+            assert got.stdout == ref.stdout, extra
+            if os.path.getsize(os.path.join(d, "r1.fq.gz")) > 2 << 30:
+                lines = [l for l in got.stderr.decode().splitlines() if l.startswith("__stats_gz__")]
+                assert len(lines) == 2 and all("ring_bytes=2147483648" in l and "ring_laps=0 " not in l for l in lines), lines
+        w = os.path.join(d, "w")
+        os.mkdir(w)
+        got = subprocess.run([exe] + args + [a if not a.endswith(".gz") else os.path.join("..", a) for a in gz] + ["--phase-reads", "--hap0", "../hap0.mer", "--hap1", "../hap1.mer"],
+                             cwd=w, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+        assert got.returncode == 0, got.stderr.decode()[-2000:]
+        assert got.stdout == ref.stdout
+        for f in ("r1.fq", "r2.fq"):
+            routed = sum(os.path.getsize(os.path.join(w, n)) for n in os.listdir(w) if n.startswith(f + ".") and n.endswith(".fastq"))
+            assert routed == os.path.getsize(os.path.join(d, f)), f
+        shutil.rmtree(w)
+        if os.environ.get("HAST_HEAVY_ORACLE"):
+            o = subprocess.run([os.path.join(oracle_dir, "oracle_classify")] + args[:-1] + plain, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=3000)
+            assert o.returncode == 0 and o.stdout == ref.stdout
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 @pytest.mark.parametrize("extra,env", [([], {}), (["--route", "host"], {}), (["--devices", "0,0"], {}), (["--devices", "0,0,0", "--batch-reads", "150"], {}),
                                        (["--batch-reads", "40"], {}), ([], {"HAST_PHASE_READS": "1", "_no_flag": "1"}),
                                        (["--inflate", "host"], {})])

@@ -248,7 +248,7 @@ def stream_device_blocks(ctx, gz_path, block, cache, n_buffers, lag, gz_chunk=40
         for c in ctxs:
             h = C.c_void_p()
             if cache:
-                assert (lib.hast_names_create_dict if dict_mode else lib.hast_names_create)(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
+                assert lib.hast_names_create(c._h, cache, C.byref(h)) == 0, lib.hast_last_error()
             nms.append(h)
         arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
         narr = (C.c_void_p * len(ctxs))(*[h.value for h in nms])

@@ -184,7 +184,7 @@ def test_truncated_and_damaged_input_is_an_error_never_other_data(ctx, tmp_path)
 
 
 def test_a_level6_fastq_of_100_mb_with_default_geometry(ctx, tmp_path):
-    """default geometry (32-KB chunks, 4096 per pass) on a stream of several hundred chunks: every candidate the search
+    """default geometry (16-KB chunks, 6144 per pass, 20 symbols of room per compressed byte) on a stream of ~1900 chunks: every candidate the search
     finds is a real boundary or is skipped by the chain, few follow-up jobs, output == zlib's"""
     rng = np.random.default_rng(4)
     n = 300_000
@@ -202,6 +202,28 @@ def test_a_level6_fastq_of_100_mb_with_default_geometry(ctx, tmp_path):
         st = z.stats()
     assert got == data
     assert st["followup_jobs"] <= st["chunks"] // 20 + 2, st
+
+
+def test_a_pass_with_fewer_slots_than_chunks_with_a_block_start(ctx, tmp_path, monkeypatch):
+    """the symbol arena of a pass holds slots for 70 % of its chunks (4 in 10 chunks of a FASTQ hold no block start), handed out by the
+    decode kernel itself; with slots for 20 % most chunks find the pool empty, report "found, no room" and are decoded by follow-up
+    jobs: same bytes, many follow-up jobs"""
+    rng = np.random.default_rng(9)
+    n = 60_000
+    bases = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n, 150))
+    qual = rng.choice(np.frombuffer(b"FFFFF:F,F#", np.uint8), (n, 150))
+    data = b"".join(b"@V300R%09d#%d_%d_%d/1\n" % (i, i % 1536 + 1, (i * 7) % 1536 + 1, (i * 13) % 1536 + 1) + bases[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n" for i in range(n))
+    p = tmp_path / "fq20.gz"
+    with gzip.open(p, "wb", compresslevel=6) as f:
+        f.write(data)
+    jobs = {}
+    for frac in ("0.2", "1.0"):
+        monkeypatch.setenv("HAST_GZ_SLOT_FRACTION", frac)
+        with hast_amd.GzReader(ctx, str(p), 8192, 64, 24) as z:
+            got = z.read_all(1 << 20)
+            jobs[frac] = z.stats()["followup_jobs"]
+        assert got == data, frac
+    assert jobs["0.2"] > jobs["1.0"] + 20, jobs
 
 
 def test_a_stream_closed_early_with_passes_in_flight(ctx, tmp_path):

@@ -6,9 +6,12 @@
 # The files live in /dev/shm (the box's / has 79 GB; /dev/shm is RAM, the job's memory limit is 300 GB): 68 GB of FASTQ + 13 GB of .gz
 # + 68 GB of routed output at a time.
 # A gpurun call lasts 20 minutes at most and nothing stays on the box between calls, so the job comes in two halves over the same
-# (deterministic) files:   STEPS="runs route prof"  the measurements;   STEPS="check"  the plain run once more + the checkers.
+# (deterministic) files:   STEPS="runs route prof"  the measurements;   STEPS="check1" / STEPS="check2"  the checkers: the oracle's
+# multi-threaded program takes ~13 minutes per 100M reads on the box's 16-core quota, so it is run over ONE input file per call and
+# compared with `classify` on that file; that the two files' counts add up to the run over both is checked with merge_counts (check1);
+# check2 also runs the REAL reference binary on a 2M-read subsample.
 # usage: gpurun --timeout 1200 -- 'STEPS="runs route prof" bash tools/gpu/cli_c2.sh > gpurun_out/round6_cli_c2.txt 2>&1'
-#        gpurun --timeout 1200 -- 'STEPS=check bash tools/gpu/cli_c2.sh > gpurun_out/round6_cli_c2_check.txt 2>&1'
+#        gpurun --timeout 1200 -- 'STEPS=check1 bash tools/gpu/cli_c2.sh > gpurun_out/round6_cli_c2_check1.txt 2>&1'      (and check2)
 #   NPAIRS (default 100000000 = 200M reads), KEYS (50000000 per haplotype), BARCODES (1000000), LEVEL (6)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -47,6 +50,21 @@ EOF
   if [ -n "$KEEP" ] && [ "$KEEP" = "$name" ]; then :; else rm -rf $w; fi; }
 PY=$PWD/hast_amd/classify
 run plain $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+for half in 1 2; do
+  if has check$half; then
+    run only_r$half $PY $ARGS --read $D/r$half.fq
+    cp $D/out.only_r$half $D/half$half.tsv
+    if [ $half = 1 ]; then
+      # additivity: the rows of r1 alone + the rows of r2 alone, merged by barcode, must be the rows of the run over both
+      run only_r2 $PY $ARGS --read $D/r2.fq
+      n0=$(grep -o "set0=[0-9]*" $D/err.plain | head -1 | cut -d= -f2); n1=$(grep -o "set1=[0-9]*" $D/err.plain | head -1 | cut -d= -f2)
+      hast_amd/merge_counts --set0 $n0 --set1 $n1 --weight0 1.04 $D/out.only_r1 $D/out.only_r2 > $D/out.merged 2> $D/err.merged
+      echo "-- merge_counts(r1 alone, r2 alone) rc=$? rows=$(wc -l < $D/out.merged) md5=$(md5sum < $D/out.merged | cut -c1-12)   (the run over both files: $(md5sum < $D/out.plain | cut -c1-12))"
+    fi
+    t0=$(now); oracle/oracle_classify --hap0 $D/hap0.mer --hap1 $D/hap1.mer --weight0 1.04 --read $D/r$half.fq -t 32 > $D/out.oracle 2> /dev/null; t1=$(now)
+    echo "-- oracle_classify -t 32 over r$half.fq ($NPAIRS reads): $(el $t0 $t1) s rows=$(wc -l < $D/out.oracle) md5=$(md5sum < $D/out.oracle | cut -c1-12)   (classify on the same file: $(md5sum < $D/half$half.tsv | cut -c1-12))"
+  fi
+done
 if has runs; then
 run plain_again $PY $ARGS --read $D/r1.fq --read $D/r2.fq
 run gz $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
@@ -70,14 +88,13 @@ fi
 # kernel statistics of one .gz run (rocprofv3 on the program itself)
 if has prof; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/round6_prof_c2 -- $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz > $D/out.prof 2> $D/err.prof
-echo "-- under rocprofv3 (gz): md5=$(md5sum < $D/out.prof | cut -c1-12) $(grep -h __stats_phases__ $D/err.prof | cut -c1-300)"
+echo "-- under rocprofv3 (gz): rc=$? md5=$(md5sum < $D/out.prof | cut -c1-12) $(grep -h __stats_phases__ $D/err.prof | cut -c1-300)"
+grep -v "^[EW]2026" $D/err.prof | tail -4 | cut -c1-300 | sed 's/^/     /'
 f=$(ls $O/round6_prof_c2/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/round6_cli_c2_gz_kernel_stats.csv && head -16 $f
 rm -rf $O/round6_prof_c2
 fi
 # the checkers: the oracle's program over all the reads; the real reference binary on the first 2M reads of each file
-if has check; then
-  t0=$(now); oracle/oracle_classify --hap0 $D/hap0.mer --hap1 $D/hap1.mer --weight0 1.04 --read $D/r1.fq --read $D/r2.fq -t 32 > $D/out.oracle 2> /dev/null; t1=$(now)
-  echo "-- oracle_classify -t 32 over the same files: $(el $t0 $t1) s rows=$(wc -l < $D/out.oracle) md5=$(md5sum < $D/out.oracle | cut -c1-12)"
+if has check2; then
 head -n 4000000 $D/r1.fq > $D/s1.fq; head -n 4000000 $D/r2.fq > $D/s2.fq
 if [ -x oracle/_ref/classify_O2 ]; then
   t0=$(now); timeout -k 5 420 oracle/_ref/classify_O2 --hap0 $D/hap0.mer --hap1 $D/hap1.mer --weight0 1.04 --read $D/s1.fq --read $D/s2.fq -t 32 > $D/out.ref 2> /dev/null; t1=$(now)
