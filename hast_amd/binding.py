@@ -123,6 +123,7 @@ ABI_SYMBOLS = {
     "hast_names_count": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "hast_names_texts": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8)]),
     "hast_counts_read_range": (C.c_int, [vp, C.c_size_t, C.c_size_t, u64p, u64p, u64p]),
+    "hast_names_merge": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32)]),
     "hast_counts_permute": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t]),
     "hast_names_insert": (C.c_int, [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_size_t]),
     "hast_fq_set_route": (C.c_int, [vp, C.POINTER(vp), C.c_int]),

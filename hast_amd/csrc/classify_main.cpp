@@ -237,16 +237,15 @@ struct Counts {                                    // host accumulators behind t
 // Who numbers the barcodes.  Round 6: the GPU's own dictionary (hast_names_create_dict) -- ids 0 .. limit-1 in the order in which its
 // naming kernel meets new texts; the host's dictionary only names what the device leaves to it (texts longer than 15 bytes, and what
 // arrives when every device id is out) in the range [host_base, ...) above.  One dictionary per GPU (contexts of one GPU share it): with
-// several GPUs the dictionaries number independently and their counters are MERGED BY TEXT -- a host map text -> merged id filled from
-// the dictionaries' texts, the counters of every context renumbered on its device (hast_counts_permute), then the one all-reduce.
+// several GPUs the dictionaries number independently and their counters are MERGED BY TEXT, on the GPUs: the texts another dictionary has
+// learnt go through the FIRST dictionary's naming kernel (hast_names_merge: their ids there, new ones claimed), the counters of that
+// dictionary's contexts are renumbered on their device (hast_counts_permute), then the one all-reduce runs over one id space.
 struct Naming {
     bool device_dict = false;
     size_t host_base = 0;                          // ids of the host dictionary start here in the device counters
     std::vector<hast_names *> groups;              // the distinct dictionaries
     std::vector<int> group_of;                     // per context
-    hast::BarcodeDict merged;                      // several dictionaries: text -> merged id
-    std::vector<hast::BarcodeDict::Cache> merged_caches;
-    std::vector<std::vector<uint8_t>> texts;       // per group: the text records read so far (16 bytes each)
+    std::vector<std::vector<uint32_t>> perm;       // per dictionary but the first: its ids in the first one's numbering, as far as merged
     double merge_s = 0;
 };
 
@@ -255,7 +254,7 @@ inline void add_into(std::vector<uint64_t> &dst, const std::vector<uint64_t> &sr
     for (size_t i = 0; i < n; i++) dst[i] += src[i];       // (64-bit on the device and here: nothing wraps)
 }
 
-void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, Naming &nm, hast::WorkerPool &pool, size_t n_host, size_t new_cap) {
+void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, Naming &nm, hast::WorkerPool &, size_t n_host, size_t new_cap) {
     // fold what the devices have counted so far into the host sums, then (re)size the device arrays.  Several GPUs: ONE
     // all-reduce(sum,u64) over RCCL/xGMI leaves the totals on every device (collectBarcodes + data.Add, classify.cpp:226-229,277)
     hast_ctx *ctx = ctxs[0];
@@ -267,57 +266,41 @@ void flush_counts(std::vector<hast_ctx *> &ctxs, Counts &acc, Naming &nm, hast::
             if (n) CK(hast_counts_read_range(ctx, first, n, a.data(), b.data(), c.data()), "reading counters");
             add_into(d0, a, n); add_into(d1, b, n); add_into(d2, c, n);
         };
-        if (!nm.device_dict) {
-            if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
-            read_range(0, n_host, acc.c0, acc.c1, acc.neg);      // (only the barcodes that exist: the counters are sized ahead of the dictionary)
-        } else if (nm.groups.size() == 1) {
-            if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
+        if (nm.device_dict && nm.groups.size() > 1) {
+            // several dictionaries: what each has learnt since the last merge into the first one's numbering, its contexts' counters with it
+            const double t0 = now_s();
+            nm.perm.resize(nm.groups.size());
+            for (size_t g = 1; g < nm.groups.size(); g++) {
+                size_t n_g = 0;
+                CK(hast_names_count(nm.groups[g], &n_g), "asking a dictionary for its size");
+                const size_t have = nm.perm[g].size();
+                if (n_g > have) {
+                    nm.perm[g].resize(n_g);
+                    if (hast_names_merge(nm.groups[0], nm.groups[g], have, n_g - have, nm.perm[g].data() + have) != HAST_OK)
+                        die(4, "merging the GPUs' barcode dictionaries (more barcodes than --name-cache allows?)");
+                }
+            }
+            // (the first dictionary may have grown past what the counters were sized for -- they follow the ids of each dictionary's own
+            // blocks: every context's counters move into arrays that hold the merged numbering)
+            size_t n_merged = 0;
+            CK(hast_names_count(nm.groups[0], &n_merged), "asking the dictionary for its size");
+            const size_t need_cap = std::max(acc.device_cap, n_merged);
+            for (size_t i = 0; i < ctxs.size(); i++) {
+                const size_t g = (size_t)nm.group_of[i];
+                if (g == 0 && need_cap == acc.device_cap) continue;
+                const size_t n_perm = g ? std::min(nm.perm[g].size(), acc.device_cap) : 0;
+                CK(hast_counts_permute(ctxs[i], g ? nm.perm[g].data() : nullptr, n_perm, need_cap), "renumbering the counters of a GPU");
+            }
+            acc.device_cap = need_cap;
+            nm.merge_s += now_s() - t0;
+        }
+        if (ctxs.size() > 1) CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
+        if (!nm.device_dict) read_range(0, n_host, acc.c0, acc.c1, acc.neg);      // (only the barcodes that exist: the counters are sized ahead of the dictionary)
+        else {
             size_t n_dev = 0;
             CK(hast_names_count(nm.groups[0], &n_dev), "asking the dictionary for its size");
             read_range(0, n_dev, acc.c0, acc.c1, acc.neg);
             read_range(nm.host_base, n_host, acc.h0, acc.h1, acc.hneg);
-        } else {
-            // several dictionaries: every context's counters into the merged numbering, on its device, then the all-reduce
-            const double t0 = now_s();
-            const int T = pool.size();
-            if (nm.merged_caches.empty()) nm.merged_caches.resize((size_t)T);
-            nm.texts.resize(nm.groups.size());
-            std::vector<std::vector<uint32_t>> perm(nm.groups.size());
-            for (size_t g = 0; g < nm.groups.size(); g++) {
-                size_t n_dev = 0;
-                CK(hast_names_count(nm.groups[g], &n_dev), "asking a dictionary for its size");
-                const size_t have = nm.texts[g].size() / 16;
-                nm.texts[g].resize(16 * n_dev);
-                if (n_dev > have) CK(hast_names_texts(nm.groups[g], have, n_dev - have, nm.texts[g].data() + 16 * have), "reading a dictionary's texts");
-                perm[g].resize(n_dev);
-                const uint8_t *tx = nm.texts[g].data();
-                pool.run([&](int t) {
-                    for (size_t i = n_dev * (size_t)t / T, e = n_dev * (size_t)(t + 1) / T; i < e; i++)
-                        perm[g][i] = nm.merged.get(std::string_view(reinterpret_cast<const char *>(tx) + 16 * i + 1, tx[16 * i]), nm.merged_caches[(size_t)t]);
-                });
-            }
-            const size_t n_merged = nm.merged.size(), n_new = n_merged + n_host;
-            for (size_t i = 0; i < ctxs.size(); i++) {
-                std::vector<uint32_t> &p = perm[(size_t)nm.group_of[i]];
-                std::vector<uint32_t> full;
-                const uint32_t *use = p.data();
-                size_t n_old = std::min(p.size(), acc.device_cap);
-                if (n_host) {                                   // the host's ids keep their order behind the merged ones
-                    full.assign(std::min(nm.host_base + n_host, acc.device_cap), 0xFFFFFFFFu);
-                    std::copy(p.begin(), p.begin() + (long)std::min(p.size(), full.size()), full.begin());
-                    for (size_t j = 0; j < n_host && nm.host_base + j < full.size(); j++) full[nm.host_base + j] = (uint32_t)(n_merged + j);
-                    use = full.data();
-                    n_old = full.size();
-                }
-                CK(hast_counts_permute(ctxs[i], use, n_old, std::max<size_t>(n_new, 1)), "renumbering the counters of a GPU");
-            }
-            CK(hast_counts_allreduce(ctxs.data(), (int)ctxs.size()), "summing the counters of the GPUs");
-            const size_t cap_was = acc.device_cap;
-            acc.device_cap = std::max<size_t>(n_new, 1);
-            read_range(0, n_merged, acc.c0, acc.c1, acc.neg);
-            read_range(n_merged, n_host, acc.h0, acc.h1, acc.hneg);
-            acc.device_cap = cap_was;
-            nm.merge_s += now_s() - t0;
         }
     }
     for (hast_ctx *c : ctxs) CK(hast_counts_resize(c, new_cap), "allocating counters");
@@ -1117,20 +1100,18 @@ int main(int argc, char **argv) {
     // the names by row: the device dictionary's texts by id (read once, now), then what the host named
     std::vector<uint8_t> dev_texts;
     size_t n_dev_names = 0;
-    if (naming.device_dict && naming.groups.size() == 1) {
+    if (naming.device_dict) {                       // (several dictionaries: the first one holds every text since the merge)
         CK(hast_names_count(naming.groups[0], &n_dev_names), "asking the dictionary for its size");
         dev_texts.resize(16 * n_dev_names);
         CK(hast_names_texts(naming.groups[0], 0, n_dev_names, dev_texts.data()), "reading the dictionary's texts");
-    } else if (naming.device_dict) n_dev_names = naming.merged.size();
+    }
     const size_t n_host_names = dict.size();
     std::vector<std::string_view> names(n_dev_names + n_host_names);
-    if (naming.device_dict && naming.groups.size() == 1)
+    if (naming.device_dict)
         pool.run([&](int t) {
             for (size_t i = n_dev_names * (size_t)t / T, e = n_dev_names * (size_t)(t + 1) / T; i < e; i++)
                 names[i] = std::string_view(reinterpret_cast<const char *>(dev_texts.data()) + 16 * i + 1, dev_texts[16 * i]);
         });
-    else if (naming.device_dict)
-        pool.run([&](int t) { naming.merged.names_range(names, hast::BarcodeDict::n_shards() * (size_t)t / T, hast::BarcodeDict::n_shards() * (size_t)(t + 1) / T); });
     {
         std::vector<std::string_view> hn(n_host_names);
         pool.run([&](int t) { dict.names_range(hn, hast::BarcodeDict::n_shards() * (size_t)t / T, hast::BarcodeDict::n_shards() * (size_t)(t + 1) / T); });
@@ -1297,16 +1278,26 @@ int main(int argc, char **argv) {
                 if (bc.find('#') != std::string_view::npos || bc.find('/') != std::string_view::npos) has_sep[(size_t)t] = 1;
             }
         });
-        for (int l = 0; l < 3; l++) {
-            std::string text;
-            for (size_t r = 0; r < nb; r++) {
-                const uint32_t i = order[r];
-                if (list_of[i] != l + 1) continue;
-                text.append(names[i].data(), names[i].size());
-                text.push_back('\n');
+        {
+            // (one walk over the sorted rows, each thread a contiguous share: the three lists are the rows' first columns in row order)
+            std::vector<std::string> part((size_t)T * 3);
+            pool.run([&](int t) {
+                for (size_t r = nb * (size_t)t / T, e = nb * (size_t)(t + 1) / T; r < e; r++) {
+                    const uint32_t i = order[r];
+                    std::string &text = part[(size_t)t * 3 + (size_t)(list_of[i] - 1)];
+                    text.append(names[i].data(), names[i].size());
+                    text.push_back('\n');
+                }
+            });
+            for (int l = 0; l < 3; l++) {
+                FILE *lf = fopen(list_name[l], "wb");
+                bool ok = lf != nullptr;
+                for (int t = 0; ok && t < T; t++) {
+                    const std::string &text = part[(size_t)t * 3 + (size_t)l];
+                    ok = fwrite(text.data(), 1, text.size(), lf) == text.size();
+                }
+                if (!ok || fclose(lf) != 0) die(2, (std::string("cannot write ") + list_name[l]).c_str());
             }
-            FILE *lf = fopen(list_name[l], "wb");
-            if (!lf || fwrite(text.data(), 1, text.size(), lf) != text.size() || fclose(lf) != 0) die(2, (std::string("cannot write ") + list_name[l]).c_str());
         }
         const double t_lists = now_s();
         // awk's three arrays as one map: a list line's first field under -F '#|/', first list wins (awk :12-16,23-35).  10M insertions of
@@ -1757,6 +1748,8 @@ int main(int argc, char **argv) {
                 K, (unsigned long long)n_set[0], (unsigned long long)n_set[1], (unsigned long long)total_reads,
                 (unsigned long long)total_bases, names.size(), t_loaded - t_start, dt, dt > 0 ? total_bases / dt / 1e6 : 0.0);
     }
+    if (stats && naming.device_dict)
+        stat_line("__stats_dictionary__ on=device dictionaries=%zu ids_from_device=%zu ids_from_host=%zu merge_by_text_s=%.3f\n", naming.groups.size(), n_dev_names, n_host_names, naming.merge_s);
     if (stats) stat_line("__stats_setup__ waited_for_stream_setup_s=%.3f (inside scrub_sizes_clone_s: .gz inputs opened, FASTQ streams created while the table was built)\n", t_pre_waited);
     // a context that could not get room for its filter probes the table directly (the round-1 kernel: 1.6 x the HBM requests per read):
     // same results, never silently

@@ -367,6 +367,41 @@ hast_status hast_names_texts(hast_names *nm, size_t first, size_t n, uint8_t *ou
     return HAST_OK;
 }
 
+// src's texts [first, first + n) through dst's naming kernel: their ids in dst's numbering, new texts claimed there.
+hast_status hast_names_merge(hast_names *dst, hast_names *src, size_t first, size_t n, uint32_t *ids_out) {
+    if (!dst || !src || (n && !ids_out)) return set_error(HAST_ERR_INVALID, "null argument");
+    if (!dst->dict || !src->dict) return set_error(HAST_ERR_INVALID, "hast_names_merge: both must be dictionaries (hast_names_create_dict)");
+    if (first + n > src->limit) return set_error(HAST_ERR_INVALID, "hast_names_merge: ids [%zu, %zu) beyond the source's %zu", first, first + n, src->limit);
+    if (!n) return HAST_OK;
+    FQ_TRY(hipSetDevice(src->device));
+    FQ_TRY(hipStreamSynchronize(ctx_stream_of(src->ctx)));                     // (its naming kernels have filed the texts)
+    FQ_TRY(hipSetDevice(dst->device));
+    hipStream_t hs = ctx_stream_of(dst->ctx);
+    uint8_t *d_text = nullptr;
+    uint32_t *d_ids = nullptr, *d_unknown = nullptr;
+    hipError_t e = dev_malloc(&d_text, 16 * n);
+    if (e == hipSuccess) e = dev_malloc(&d_ids, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_malloc(&d_unknown, (n + 1) * sizeof(uint32_t));
+    const uint8_t *from = static_cast<const uint8_t *>(src->d_text_of_id) + 16 * first;
+    if (e == hipSuccess) e = src->device == dst->device ? hipMemcpyAsync(d_text, from, 16 * n, hipMemcpyDeviceToDevice, hs)
+                                                        : hipMemcpyPeerAsync(d_text, dst->device, from, src->device, 16 * n, hs);
+    if (e == hipSuccess) e = hipMemsetAsync(d_unknown, 0, sizeof(uint32_t), hs);
+    for (size_t at = 0; e == hipSuccess && at < n; at += 1u << 24) {           // (the kernel counts records in 32 bits: 16M a launch)
+        const uint32_t m = (uint32_t)std::min<size_t>(n - at, 1u << 24);
+        e = launch_fq_name_claim(reinterpret_cast<const uint32_t *>(d_text + 16 * at), m, dst->d_tab, dst->mask, dst->d_n_ids, (uint32_t)dst->limit, dst->d_text_of_id,
+                                 d_ids + at, d_unknown, hs);
+    }
+    uint32_t n_unknown = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(ids_out, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_unknown, d_unknown, sizeof(uint32_t), hipMemcpyDeviceToHost, hs);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs);
+    for (void *p : {(void *)d_text, (void *)d_ids, (void *)d_unknown})
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "hast_names_merge: %s", hipGetErrorString(e));
+    if (n_unknown) return set_error(HAST_ERR_TABLE_FULL, "hast_names_merge: the dictionary has no id left for %u of the other one's texts (its limit is %zu)", n_unknown, dst->limit);
+    return HAST_OK;
+}
+
 void hast_names_destroy(hast_names *nm) {
     if (!nm) return;
     (void)hipSetDevice(nm->device);

@@ -48,8 +48,9 @@ hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,
                            uint32_t *h_bc, uint32_t *d_text, uint32_t h_cap, uint32_t k, int last, hipStream_t s);
 
-// counters renumbered (dictionaries of several GPUs merged by text): record i of d_src added to record d_perm[i] of d_dst
-hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_old, size_t n_new, hipStream_t s);
+// counters renumbered (dictionaries of several GPUs merged by text): record i < n_perm of d_src added to record d_perm[i] of d_dst, the
+// records from n_perm to n_old keep their places
+hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_perm, size_t n_old, size_t n_new, hipStream_t s);
 
 // ---- routing (the wrapper's steps 10-11: every record to the file of its barcode's class, quartering_fastq.awk) ----------------
 struct RouteState {            // one per buffer slot, device + a pinned host copy behind the routing kernels

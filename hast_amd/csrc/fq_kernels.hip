@@ -576,12 +576,13 @@ hipError_t launch_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, 
     return hipGetLastError();
 }
 
-// counters renumbered: record i of `src` (4 x u64, three live words) is added to record perm[i] of `dst` (several may name one: atomics).
-// Dictionaries of different GPUs number the barcodes in their own order: hast_counts_permute brings every context's counters into the
-// merged numbering before the one all-reduce.  (Lives here, with the dictionary, not with the classification kernels.)
-__global__ void __launch_bounds__(256) k_counts_permute(unsigned long long *dst, const unsigned long long *src, const uint32_t *perm, size_t n_old, size_t n_new) {
+// counters renumbered: record i < n_perm of `src` (4 x u64, three live words) is added to record perm[i] of `dst` (several may name one:
+// atomics), the records from n_perm on keep their places.  Dictionaries of different GPUs number the barcodes in their own order:
+// hast_counts_permute brings every context's counters into the first dictionary's numbering before the one all-reduce.  (Lives here,
+// with the dictionary, not with the classification kernels.)
+__global__ void __launch_bounds__(256) k_counts_permute(unsigned long long *dst, const unsigned long long *src, const uint32_t *perm, size_t n_perm, size_t n_old, size_t n_new) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_old; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t to = perm[i];
+        const size_t to = i < n_perm ? (size_t)perm[i] : i;
         if (to >= n_new) continue;
         for (int w = 0; w < 3; ++w) {
             const unsigned long long v = src[4 * i + w];
@@ -589,10 +590,10 @@ __global__ void __launch_bounds__(256) k_counts_permute(unsigned long long *dst,
         }
     }
 }
-hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_old, size_t n_new, hipStream_t s) {
+hipError_t launch_counts_permute(unsigned long long *d_dst, const unsigned long long *d_src, const uint32_t *d_perm, size_t n_perm, size_t n_old, size_t n_new, hipStream_t s) {
     if (n_old == 0) return hipSuccess;
     const size_t blocks = (n_old + 256 * 16 - 1) / (256 * 16);
-    hipLaunchKernelGGL(k_counts_permute, dim3((unsigned)(blocks < 1 ? 1 : blocks > 65535 ? 65535 : blocks)), dim3(256), 0, s, d_dst, d_src, d_perm, n_old, n_new);
+    hipLaunchKernelGGL(k_counts_permute, dim3((unsigned)(blocks < 1 ? 1 : blocks > 65535 ? 65535 : blocks)), dim3(256), 0, s, d_dst, d_src, d_perm, n_perm, n_old, n_new);
     return hipGetLastError();
 }
 

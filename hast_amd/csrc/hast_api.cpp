@@ -869,21 +869,21 @@ hast_status hast_counts_resize(hast_ctx *c, size_t n) {
     return HAST_OK;
 }
 
-hast_status hast_counts_permute(hast_ctx *c, const uint32_t *perm, size_t n_old, size_t n_new) {
+hast_status hast_counts_permute(hast_ctx *c, const uint32_t *perm, size_t n_perm, size_t n_new) {
     if (hast_status st = use(c)) return st;
     if (!c->d_counts || !c->counts_owned) return fail(HAST_ERR_INVALID, "hast_counts_permute: library-owned counters only (hast_counts_resize)");
-    if (n_old > c->n_barcodes || (n_old && !perm)) return fail(HAST_ERR_INVALID, "hast_counts_permute: n_old %zu > %zu counters", n_old, c->n_barcodes);
-    for (size_t i = 0; i < n_old; i++)
+    if (n_perm > c->n_barcodes || (n_perm && !perm)) return fail(HAST_ERR_INVALID, "hast_counts_permute: %zu ids > %zu counters", n_perm, c->n_barcodes);
+    for (size_t i = 0; i < n_perm; i++)
         if (perm[i] >= n_new && perm[i] != 0xFFFFFFFFu) return fail(HAST_ERR_INVALID, "hast_counts_permute: perm[%zu] = %u is outside the %zu new records", i, perm[i], n_new);
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned long long *d_new = nullptr;
     uint32_t *d_perm = nullptr;
     const size_t bytes = (n_new ? n_new : 1) * 4 * sizeof(unsigned long long);
     HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_new), bytes));
-    hipError_t e = dev_malloc(reinterpret_cast<void **>(&d_perm), (n_old ? n_old : 1) * sizeof(uint32_t));
+    hipError_t e = dev_malloc(reinterpret_cast<void **>(&d_perm), (n_perm ? n_perm : 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(d_new, 0, bytes, c->stream);
-    if (e == hipSuccess && n_old) e = hipMemcpyAsync(d_perm, perm, n_old * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_counts_permute(d_new, c->d_counts, d_perm, n_old, n_new, c->stream);
+    if (e == hipSuccess && n_perm) e = hipMemcpyAsync(d_perm, perm, n_perm * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_counts_permute(d_new, c->d_counts, d_perm, n_perm, c->n_barcodes, n_new, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (d_perm) (void)hipFree(d_perm);
     if (e != hipSuccess) {

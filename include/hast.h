@@ -206,10 +206,11 @@ hast_status hast_counts_add_votes(hast_ctx *, const uint32_t *d_votes, const uin
  * only one), and the totals are handed back to every context.  The communicators of a device list
  * are created by the first call that names it and kept until the process ends (later calls only enqueue the all-reduce). */
 hast_status hast_counts_allreduce(hast_ctx *const *ctxs, int n_ctx);
-/* New counters of n_new records (zeroed), record i of the old ones (i < n_old <= the old size) ADDED to record perm[i] (perm: host array;
- * several old records may name one new record; 0xFFFFFFFF: the record is dropped): how contexts whose dictionaries numbered the barcodes differently -- one device dictionary
- * per GPU -- are brought into one id space before hast_counts_allreduce sums them. */
-hast_status hast_counts_permute(hast_ctx *, const uint32_t *perm, size_t n_old, size_t n_new);
+/* New counters of n_new records (zeroed): record i < n_perm of the old ones is ADDED to record perm[i] (perm: host array; several old
+ * records may name one new record; 0xFFFFFFFF: dropped), the old records from n_perm on keep their places.  How contexts whose
+ * dictionaries numbered the barcodes differently -- one device dictionary per GPU -- are brought into one id space (hast_names_merge
+ * gives perm) before hast_counts_allreduce sums them. */
+hast_status hast_counts_permute(hast_ctx *, const uint32_t *perm, size_t n_perm, size_t n_new);
 
 /* ---- classification: MultiThread::process_reads (classify.cpp:186-209) ---------------------
  * For each read: whole-read skip when it holds an upper-case 'N' (containN, :182-185,190-193);
@@ -315,11 +316,15 @@ hast_status hast_names_create(hast_ctx *, size_t max_barcodes, hast_names **out)
  * bytes and what arrives once every id is out; the caller names those in an id range of its own at or above hast_names_limit().
  * hast_names_count: ids handed out so far; hast_names_texts: the text records (16 bytes: length byte + text) of ids [first, first + n),
  * read once at the end for printing.  Dictionaries of different GPUs number independently: their counters are merged by text
- * (hast_counts_permute, then hast_counts_allreduce). */
+ * (hast_names_merge into the first dictionary's numbering, hast_counts_permute, then hast_counts_allreduce). */
 hast_status hast_names_create_dict(hast_ctx *, size_t max_barcodes, hast_names **out);
 size_t      hast_names_limit(const hast_names *);
 hast_status hast_names_count(hast_names *, size_t *n_ids);
 hast_status hast_names_texts(hast_names *, size_t first, size_t n, uint8_t *out16);
+/* Two dictionaries, one numbering: ids_out[i] = the id that dst has for src's text of id first + i (i < n) -- a text dst does not know
+ * yet gets dst's next id there and then.  On the GPU: src's text records are copied to dst's device (peer to peer when that is another
+ * GPU) and go through dst's naming kernel; no host map.  HAST_ERR_TABLE_FULL when dst has no id left for a new text. */
+hast_status hast_names_merge(hast_names *dst, hast_names *src, size_t first, size_t n, uint32_t *ids_out);
 void        hast_names_destroy(hast_names *);
 /* Entries the caller knows: n text records (16 bytes each: length byte + up to 15 bytes of text, the format of hast_fq_block.bc_text)
  * with their ids -- e.g. a table barcode -> class for a routing stream (hast_fq_set_route).  Returns when they are on the device. */
