@@ -964,8 +964,8 @@ int main(int argc, char **argv) {
             if (!b.bytes) {
                 // a block that was filled on the device: the host copy is fetched only when a record's barcode text did not fit the
                 // framer's 16-byte copy (longer than 15 bytes), or when there are no such copies (more records than they hold)
-                bool need = !b.bc_text;
-                for (size_t j = 0; !need && j < nu; j++) need = b.bc_text[16 * (b.unknown ? b.unknown[j] : j)] == 0xFF;
+                bool need = !b.bc_text && nu > 0;
+                for (size_t j = 0; !need && b.bc_text && j < nu; j++) need = b.bc_text[16 * (b.unknown ? b.unknown[j] : j)] == 0xFF;
                 if (need) CK(hast_fq_block_host_bytes(f.fq, &b.bytes), "fetching a block");
             }
             auto name_range = [&](int t, size_t lo, size_t hi_) {

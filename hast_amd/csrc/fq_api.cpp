@@ -32,12 +32,13 @@ struct Slot {
     uint32_t *d_tile = nullptr, *d_nl = nullptr;
     uint64_t *d_off = nullptr;
     uint32_t *d_len = nullptr, *d_bcpos = nullptr, *d_bclen = nullptr, *d_ids = nullptr, *d_votes = nullptr;
-    uint32_t *d_text = nullptr;                        // [h_cap][4]: the barcode text records, for the device-side name cache
+    uint32_t *d_text = nullptr;                        // [max_rec][4]: the barcode text record of EVERY record of the block, for the naming kernel
     uint32_t *h_nids = nullptr;                        // pinned: ids the device dictionary had handed out when this block was named
     uint32_t *h_unknown = nullptr;                     // pinned [1 + h_cap]: count, then the records the cache did not know
     NamePub *h_pubs = nullptr;                         // pinned [h_cap]: what this block teaches the cache
     hipEvent_t named = nullptr;
     bool use_cache = false;                            // this block's ids came from the cache (unknown list valid)
+    bool host_texts = false;                           // ... and the pinned copy of its text records is complete (not a block that outgrew the arrays)
     uint32_t *h_bc = nullptr, *h_ids = nullptr;        // pinned: h_bc = [pos x h_cap | len x h_cap], written by the records kernel itself
     size_t h_cap = 0;                                  // records the pinned arrays hold (a block with more: grown, copied)
     size_t k_cap = 0;                                  // ... the capacity the kernel of the submitted block was given
@@ -116,21 +117,21 @@ struct hast_fq {
 };
 
 // Every per-record array of a slot has ONE capacity, h_cap, and is only ever resized here: h_bc = [pos | len | 4 words of
-// text] x cap, h_ids, d_text, h_unknown (1 + cap), h_pubs.  The records kernel is handed h_cap and writes text records at
-// h_bc + 2*h_cap and d_text[4*i]; k_fq_name writes up to n + 1 words of h_unknown; hast_fq_commit fills up to n h_pubs.
+// text] x cap, h_ids, h_unknown (1 + cap), h_pubs.  The records kernel is handed h_cap and writes text records at
+// h_bc + 2*h_cap (the first h_cap records) and d_text[4*i] (every record: the device array holds the whole record table); the naming
+// kernel writes up to n ids and n + 1 words of h_unknown, so a block with more records than h_cap grows the arrays BEFORE it is named;
+// hast_fq_commit fills up to n h_pubs.
 static hast_status grow_records(Slot &s, size_t cap) {
     // (parked, not freed: hipFree / hipHostFree wait for every stream of the device, hast_internal.h)
     park_pinned(s.h_bc, 6 * s.h_cap * sizeof(uint32_t), 3);
     park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t), 3);
     park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), 3);
     park_pinned(s.h_pubs, s.h_cap * sizeof(NamePub), 3);
-    park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t), 3);
-    s.h_bc = s.h_ids = s.h_unknown = s.d_text = nullptr;
+    s.h_bc = s.h_ids = s.h_unknown = nullptr;
     s.h_pubs = nullptr;
     s.h_cap = 0;
     FQ_TRY(pinned_malloc((void **)&s.h_bc, (2 + 4) * cap * sizeof(uint32_t), hipHostMallocDefault));
     FQ_TRY(pinned_malloc((void **)&s.h_ids, cap * sizeof(uint32_t), hipHostMallocDefault));
-    FQ_TRY(dev_malloc((void **)&s.d_text, 4 * cap * sizeof(uint32_t)));
     FQ_TRY(pinned_malloc((void **)&s.h_unknown, (1 + cap) * sizeof(uint32_t), hipHostMallocDefault));
     FQ_TRY(pinned_malloc((void **)&s.h_pubs, cap * sizeof(NamePub), hipHostMallocDefault));
     s.h_cap = cap;
@@ -150,7 +151,7 @@ static void free_slot(Slot &s) {
     park_pinned(s.h_ids, s.h_cap * sizeof(uint32_t), 3);
     park_pinned(s.h_unknown, (1 + s.h_cap) * sizeof(uint32_t), 3);
     park_pinned(s.h_pubs, s.h_cap * sizeof(NamePub), 3);
-    park_device(s.d_text, 4 * s.h_cap * sizeof(uint32_t), 3);
+    park_device(s.d_text, 0, 3);
     if (s.named) (void)hipEventDestroy(s.named);
     for (void *p : {(void *)s.d_buf, (void *)s.d_st, (void *)s.d_tile, (void *)s.d_nl, (void *)s.d_off, (void *)s.d_len, (void *)s.d_bcpos,
                     (void *)s.d_bclen, (void *)s.d_ids, (void *)s.d_votes, (void *)s.d_rstart, (void *)s.d_rlen, (void *)s.d_rtile, (void *)s.d_rcls,
@@ -460,6 +461,7 @@ static hast_status alloc_slot(Slot &s, size_t buf, size_t max_rec, size_t pad, s
     FQ_TRY(dev_malloc((void **)&s.d_off, max_rec * sizeof(uint64_t)));
     for (uint32_t **p : {&s.d_len, &s.d_bcpos, &s.d_bclen, &s.d_ids}) FQ_TRY(dev_malloc((void **)p, max_rec * sizeof(uint32_t)));
     FQ_TRY(dev_malloc((void **)&s.d_votes, max_rec * 2 * sizeof(uint32_t)));
+    FQ_TRY(dev_malloc((void **)&s.d_text, max_rec * 4 * sizeof(uint32_t)));
     // records the pinned per-record arrays hold (34 B each: page pinning is ~0.7 ms per MB, six slots a stream): a record of 100-bp
     // reads is ~240 bytes, of 150-bp reads ~340; a block of shorter ones takes the copy path and grows the arrays (hast_fq_next)
     size_t cap = block / 224 + 4096;
@@ -777,7 +779,9 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
         FQ_TRY(hipEventRecord(s.parsed, hs));
     }
     // ids from the device-side name cache (after a few blocks nearly every barcode of a block has been seen before)
-    s.use_cache = snames && n && !by_copy;
+    s.host_texts = !by_copy;
+    s.use_cache = snames && n;                 // (also a block that outgrew the pinned arrays: they have just been regrown, and the text records
+                                               // of all its records are on the device -- every record goes through ONE dictionary)
     if (s.use_cache) {
         s.h_unknown[0] = 0;
         if (snames->dict) {
@@ -948,7 +952,7 @@ hast_status hast_fq_commit(hast_fq *f) {
                 const uint32_t i = s.h_unknown[1 + j];
                 if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %u is outside the %zu counters", s.h_ids[i], i, nbc);
                 const uint32_t *t = s.h_bc + 2 * s.h_cap + 4 * (size_t)i;
-                if (nm->dict) continue;                                                       // (a dictionary names by itself: what it left is the host's for good)
+                if (nm->dict || !s.host_texts) continue;                                      // (a dictionary names by itself: what it left is the host's for good)
                 if ((t[0] & 0xFFu) == 0xFFu || nm->count + np >= nm->limit) continue;          // long barcodes stay with the host
                 NamePub &p = s.h_pubs[np++];
                 p.key[0] = t[0]; p.key[1] = t[1]; p.key[2] = t[2]; p.key[3] = t[3];

@@ -128,7 +128,17 @@ __device__ __forceinline__ void fq_emit_record(const uint8_t *buf, FqState *st, 
             for (uint32_t j = 0; j < bl; ++j) w[(j + 1) >> 2] |= (uint32_t)buf[start + j] << (8 * ((j + 1) & 3));
         } else w[0] = 0xFF;
         reinterpret_cast<uint4 *>(h_bc + 2 * (size_t)h_cap)[i] = make_uint4(w[0], w[1], w[2], w[3]);
-        reinterpret_cast<uint4 *>(d_text)[i] = make_uint4(w[0], w[1], w[2], w[3]);          // the same record for k_fq_name
+    }
+    {   // the same text record for the naming kernel, for EVERY record of the block (d_text holds the whole record table): the dictionary
+        // must see a barcode whichever block it comes in -- one named by the host in a block with more records than the pinned arrays
+        // hold and by the device in the next block would have two ids
+        const uint32_t bl = (uint32_t)(stop - start);
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (bl <= 15) {
+            w[0] = bl;
+            for (uint32_t j = 0; j < bl; ++j) w[(j + 1) >> 2] |= (uint32_t)buf[start + j] << (8 * ((j + 1) & 3));
+        } else w[0] = 0xFF;
+        reinterpret_cast<uint4 *>(d_text)[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     atomicMax(&st->max_len, len);
     atomicAdd(reinterpret_cast<unsigned long long *>(&st->bases), (unsigned long long)len);

@@ -110,7 +110,8 @@ def test_cli_multi_gpu_matches_reference_golden(exe, golden_workdir, case, run, 
                                        ({"HAST_NAME_DICT": "context"}, ["--devices", "0,0,0", "--batch-reads", "50", "--initial-barcodes", "50"]),
                                        ({"HAST_NAME_DICT": "context", "HAST_NAME_CACHE": "64"}, ["--devices", "0,0", "--batch-reads", "120", "--initial-barcodes", "7"]),
                                        ({"HAST_NAME_DICT": "context", "HAST_DEAL": "files"}, ["--devices", "0,0"]),
-                                       ({}, ["--initial-barcodes", "3", "--batch-reads", "31"])])
+                                       ({}, ["--initial-barcodes", "3", "--batch-reads", "31"]),
+                                       ({"HAST_FQ_HOST_RECORDS": "7"}, ["--batch-reads", "40"]), ({"HAST_FQ_HOST_RECORDS": "7", "HAST_NAME_DICT": "0"}, ["--batch-reads", "40"])])
 @pytest.mark.parametrize("case,run", golden_cases("s01"))
 def test_cli_who_numbers_the_barcodes(exe, golden_workdir, case, run, env, extra):
     """The ids of the barcodes come from the GPU's own dictionary (round 6; classify.cpp:52-56 on the device: the naming kernel claims
@@ -118,7 +119,9 @@ def test_cli_who_numbers_the_barcodes(exe, golden_workdir, case, run, env, extra
     as the real reference binary with: the host's dictionary as up to round 5 (HAST_NAME_DICT=0); a dictionary of 64 ids, so that
     most barcodes are named by the host in its own id range above the device's (and the counters regrow under both numberings);
     one dictionary per CONTEXT (what several GPUs have: each numbers in its own order), the counters merged by text -- at the end, and
-    at every regrowth in the middle of the run; whole files dealt to the contexts."""
+    at every regrowth in the middle of the run; whole files dealt to the contexts; blocks with more records than the pinned per-record
+    arrays hold (HAST_FQ_HOST_RECORDS=7: the first block of every buffer) among blocks that fit -- a barcode named by the host in one
+    block and by the device in the next would print two rows."""
     if case not in ("rand_k21", "edge_k7") and (extra or len(env) > 1):
         pytest.skip("the combinations run on two cases (suite time)")
     meta = load_case(case)["runs"][run]
