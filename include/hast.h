@@ -409,7 +409,7 @@ hast_status hast_fq_next_routed(hast_fq *, hast_fq_routed *out);
  * also frames the records.  hast_gz inflates such a file on the GPU: the COMPRESSED bytes cross PCIe (5-6 x fewer than the
  * FASTQ text) and the inflated bytes are written where the caller wants them in HBM -- e.g. straight into a block of the FASTQ
  * framer (hast_fq_submit_device), which reads them where they lie.  Method (hast_amd/csrc/gz_core.h, gz_chain.h, gz_kernels.hip):
- * every 32-KB chunk of the compressed bytes searches its first dynamic-block header and is decoded by ONE WAVE into 16-bit
+ * every 16-KB chunk of the compressed bytes (round 6; 32 KB until then) searches its first dynamic-block header and is decoded by ONE WAVE into 16-bit
  * symbols with the 32 KB in front of it unknown ("marker" symbols); a chunk counts iff the chunk in front of it ended exactly
  * at its start (holes are decoded by follow-up jobs); windows are resolved in stream order, markers translated, and every
  * member's CRC-32 and ISIZE are checked (CRC by slices on the device, combined with GF(2) operators), so a decoding bug or a
@@ -443,7 +443,9 @@ typedef struct {
     uint64_t ring_laps;        /* times the upload position wrapped round the ring */
 } hast_gz_stats;
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
-/* test / tuning entry: compressed bytes per chunk (0 = 32768), chunks per pass (0 = 4096), symbols of room per compressed byte (0 = 12) */
+/* test / tuning entry: compressed bytes per chunk (0 = 16384), chunks per pass (0 = 6144; 4096 with a chunk size given), symbols of room per
+ * compressed byte (0 = 20 with the default geometry, else 12).  A pass's arena holds symbol slots for 70 % of its chunks (those WITH a block
+ * start take one on the device; HAST_GZ_SLOT_FRACTION fixes the share, by default it follows what the passes find). */
 hast_status hast_gz_open_ex(hast_ctx *, const char *path, size_t chunk_bytes, size_t chunks_per_pass, double room, hast_gz **out);
 /* ONE .gz file inflated by several GPUs (the reference deals the reads of one file to all its workers whatever the file's encoding,
  * classify.cpp:211-219,245-254; HAST's inputs are two .fq.gz files, HAST.sh:162-166): the passes of the one deflate stream (4096

@@ -575,6 +575,31 @@ def test_cli_one_million_barcodes_vs_oracle(exe, oracle_dir, tmp_path):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def test_cli_stats_json(exe, golden_workdir, tmp_path):
+    """--stats-json FILE: every __stats_*__ line of --stats as ONE JSON object (SURVEY section 5's machine-readable summary): sections by
+    name, numbers as numbers, a section printed once per .gz input as an array"""
+    import json
+    meta = load_case("rand_k21")["runs"]["pair_w104"]
+    d = golden_workdir / "rand_k21"
+    out = tmp_path / "stats.json"
+    r = subprocess.run([exe] + meta["argv"] + ["--stats-json", str(out)], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert r.stdout == open(d / meta["expected"], "rb").read()
+    js = json.load(open(out))
+    assert js["stats"]["K"] == 21 and js["stats"]["reads"] > 0 and js["stats"]["barcodes"] > 0
+    assert js["stats_phases"]["total_s"] >= js["stats_phases"]["read_phase_s"] >= 0
+    assert js["stats_read_phase"]["records_named_on_host"] == 0
+    assert js["stats_filter"]["mode"] in ("exact_entries", "prints") and js["stats_hbm"]["total_bytes"] > 1e11
+    assert js["stats_dictionary"]["on"] == "device" and js["stats_dictionary"]["dictionaries"] == 1
+    if any(a.endswith(".gz") for a in meta["argv"]):
+        gz = js["stats_gz"] if isinstance(js["stats_gz"], list) else [js["stats_gz"]]
+        assert all(g["inflated_bytes"] > g["compressed_bytes"] > 0 and g["chain_walk_s"] >= 0 for g in gz)
+    # the same lines are on stderr
+    assert "__stats_phases__" in r.stderr.decode()
+    r = subprocess.run([exe] + meta["argv"] + ["--stats-json", "-"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and json.loads(r.stderr.decode().strip().splitlines()[-1])["stats"]["K"] == 21
+
+
 def _free_bytes(path):
     st = os.statvfs(path)
     return st.f_bavail * st.f_frsize
