@@ -458,7 +458,20 @@ int main(int argc, char **argv) {
             fclose(fp);
         }
     }
+    // Bytes per block of an input.  A block costs a dozen small kernels and two host round trips besides its bytes.  For a .gz input
+    // inflated on the GPU that is what bounds the read phase at BASELINE size (2 x 34 GB = 4 090 blocks of 16 MB): 64-MB blocks 1.70-1.82 s
+    // against 2.23-2.26 s, alternating on one box (profiles/round6_cli_c2_ab_blocks.txt) -- and such a stream has no block to pin on
+    // the host.  Plain files stay at 16 MB: their read phase is the PCIe upload whatever the block (1.43-1.48 s with 32 MB against
+    // 1.34-1.50 s), their blocks are pinned host memory (0.7 ms per MB, six buffers a stream), and small .gz inputs want their first
+    // block early.
+    auto cap_of = [&](size_t file_index) -> size_t {
+        if (block_given || host_parse || !dev_gz[file_index]) return fq_cap;
+        struct stat sb;
+        if (stat(read[file_index].c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) return fq_cap;
+        return (uint64_t)sb.st_size >= (1ull << 30) ? (size_t)(64u << 20) : fq_cap;
+    };
     auto make_fq = [&](size_t file_index, hast_fq **out) -> hast_status {
+        const size_t fq_cap = cap_of(file_index);
         // (a .gz file inflated on the GPUs: the passes of its one deflate stream go to the GPUs in turn, hast_gz_open_multi, and its
         // inflated blocks -- written on the device -- are dealt to the contexts like a plain file's)
         if (stripe)
@@ -863,7 +876,6 @@ int main(int argc, char **argv) {
         uint64_t wake_gen = 0;
         std::vector<std::unique_ptr<Feed>> active;
         size_t next_file = 0;
-        const size_t cap = fq_cap;
         auto open_next = [&]() {
             const std::string &r = read[next_file];
             fprintf(stderr, "__process read: %s\n", r.c_str());
@@ -885,6 +897,7 @@ int main(int argc, char **argv) {
                     }
                 } else if (gs != HAST_OK) die(2, ("cannot open " + r).c_str());
             }
+            const size_t cap = cap_of(next_file);              // (after a .gz input has gone to the host decoders, if it had to)
             if (!f->gz) {
                 if (!f->src.open(r, cap, false)) die(2, ("cannot open " + r).c_str());
                 f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));
@@ -896,6 +909,7 @@ int main(int argc, char **argv) {
             f->ctx_index = next_file % ctxs.size();
             next_file++;
             Feed *fp = f.get();
+            if (hast_fq_block_bytes(f->fq) != cap) die(4, "internal: a stream's block size is not its input's");
             f->th = std::thread([fp, cap, &wake_mu, &wake_cv, &wake_gen] {
                 for (;;) {
                     uint8_t *buf;
@@ -1385,7 +1399,6 @@ int main(int argc, char **argv) {
             done_fq.clear();
             std::vector<std::thread> closers;
             size_t next_file = 0;
-            const size_t cap = fq_cap;
             // inputs with one basename write the same four files: the awk loop lets the later one overwrite the earlier -- one at a time then
             bool same_prefix = false;
             {
@@ -1413,6 +1426,7 @@ int main(int argc, char **argv) {
                         dev_gz[next_file] = 0;
                     } else if (gs != HAST_OK) die(2, ("cannot open " + x).c_str());
                 }
+                const size_t cap = cap_of(next_file);
                 if (!f->gz) {
                     if (!f->src.open(x, cap, false)) die(2, ("cannot open " + x).c_str());
                     f->src.set_readers(std::max(4, std::min(16, t_num / (int)std::min<size_t>(read.size(), 2))));

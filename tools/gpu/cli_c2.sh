@@ -28,7 +28,7 @@ el() { python3 -c "print(round($2-$1,2))"; }
 echo "== box: $(nproc) hardware threads, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), memory.max $(cat /sys/fs/cgroup/memory.max 2>/dev/null), /dev/shm $(df -h /dev/shm | tail -1 | awk '{print $4}') free"
 t0=$(now); GEN_FASTQ_MAX_GB=90 tools/gen_fastq $D $NPAIRS $KEYS $BARCODES 21 150 32 0 || exit 1; t1=$(now)
 echo "== generated in $(el $t0 $t1) s: $((2*NPAIRS)) reads of 150 bp, $KEYS + $KEYS 21-mers, $BARCODES barcodes; $(stat -c %s $D/r1.fq) bytes per FASTQ file, $(stat -c %s $D/hap0.mer) per k-mer file"
-if has runs || has route || has prof; then
+if has runs || has route || has prof || has blocks || has ab; then
 t0=$(now); tools/pgzip1 $D/r1.fq $D/r1.fq.gz $LEVEL 16 32 && tools/pgzip1 $D/r2.fq $D/r2.fq.gz $LEVEL 16 32 || exit 1; t1=$(now)
 echo "== compressed in $(el $t0 $t1) s (tools/pgzip1 level $LEVEL: ONE gzip member per file): $(stat -c %s $D/r1.fq.gz) + $(stat -c %s $D/r2.fq.gz) bytes"
 fi
@@ -71,6 +71,28 @@ run gz $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
 run gz_again $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
 run gz_devices_0_0_0_0 $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz --devices 0,0,0,0
 run gz_host_inflate $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz --inflate host
+fi
+if has blocks; then          # the ingest block size (default 16 MB): what a block costs besides its bytes -- a dozen small kernels and two host round trips
+  for mb in 16 32 64 128; do
+    run plain_block_${mb}mb $PY $ARGS --read $D/r1.fq --read $D/r2.fq --block-mb $mb
+    run gz_block_${mb}mb $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz --block-mb $mb
+  done
+fi
+if has ab; then              # the block size that follows the input's size (default) against 16 MB, alternating, with the cgroup's CPU throttle counters
+  thr() { awk '/nr_throttled|throttled_usec/ {printf "%s=%s ", $1, $2}' /sys/fs/cgroup/cpu.stat 2>/dev/null; }
+  for rep in 1 2 3; do
+    echo "   cpu.stat before: $(thr)"
+    run gz_auto_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+    echo "   cpu.stat: $(thr)"
+    run gz_16mb_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz --block-mb 16
+    echo "   cpu.stat: $(thr)"
+    run plain_auto_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+    echo "   cpu.stat: $(thr)"
+    run plain_16mb_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq --block-mb 16
+    echo "   cpu.stat: $(thr)"
+    run plain_auto_t8_$rep $PY ${ARGS/-t 32/-t 8} --read $D/r1.fq --read $D/r2.fq
+    echo "   cpu.stat: $(thr)"
+  done
 fi
 if has route; then
   KEEP=plain_route run plain_route $PY $ARGS --read $D/r1.fq --read $D/r2.fq --phase-reads
