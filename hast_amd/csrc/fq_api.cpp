@@ -39,6 +39,7 @@ struct Slot {
     hipEvent_t named = nullptr;
     bool use_cache = false;                            // this block's ids came from the cache (unknown list valid)
     bool host_texts = false;                           // ... and the pinned copy of its text records is complete (not a block that outgrew the arrays)
+    bool named_early = false;                          // a dictionary named this block right behind its framing, on the framing's stream (`named` is there)
     uint32_t *h_bc = nullptr, *h_ids = nullptr;        // pinned: h_bc = [pos x h_cap | len x h_cap], written by the records kernel itself
     size_t h_cap = 0;                                  // records the pinned arrays hold (a block with more: grown, copied)
     size_t k_cap = 0;                                  // ... the capacity the kernel of the submitted block was given
@@ -77,6 +78,7 @@ struct hast_names {            // device-side cache barcode text -> id of one GP
     size_t count = 0, limit = 0;                       // entries published / published at most (half the slots)
     // dictionary mode (hast_names_create_dict): the table hands out the ids itself -- ids 0 .. limit-1, one counter, the texts by id
     bool dict = false;
+    bool name_early = false;                           // HAST_NAME_EARLY=1 (measurements): the naming kernel behind the framing kernels, on their stream (below)
     uint32_t *d_n_ids = nullptr;
     void *d_text_of_id = nullptr;                      // [limit][16]
 };
@@ -169,6 +171,23 @@ static int dev_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lane
 static hast_ctx *ctx_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].ctx : f->ctx; }
 static hast_names *names_of(const hast_fq *f, const Slot &s) { return f->striped ? f->lanes[(size_t)s.lane].names : f->names; }
 
+// Tried in round 6, OFF by default (HAST_NAME_EARLY=1): a dictionary naming a block right behind its framing, on the framing's stream --
+// the naming kernel needs nothing from the host, and on the context's stream it queues behind the classification of the blocks in front,
+// so that hast_fq_next waits ~0.8 ms a block (0.8 s of a 1.7-s read phase at BASELINE config 2's size).  With it that wait is gone
+// (0.02 s) -- and the read phase is no shorter: the time reappears as waiting for the .gz stream's bytes (1.94-1.96 s against 1.63-1.70 s,
+// plain files 1.49-1.59 against 1.52-1.75 s, alternating: profiles/round6_cli_c2_ab_naming.txt).  The host's wait was not what bounded
+// the pipeline; the kernel on the framing stream delays the next block's framing instead.
+static hast_status enqueue_names_early(Slot &s, hast_names *nm, hipStream_t hs) {
+    s.named_early = false;
+    if (!nm || !nm->dict || !nm->name_early || !s.h_cap) return HAST_OK;
+    s.h_unknown[0] = 0;
+    FQ_TRY(launch_fq_name_claim_framed(s.d_text, s.d_st, (uint32_t)s.h_cap, nm->d_tab, nm->mask, nm->d_n_ids, (uint32_t)nm->limit, nm->d_text_of_id, s.h_ids, s.h_unknown, hs));
+    FQ_TRY(hipMemcpyAsync(s.h_nids, nm->d_n_ids, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+    FQ_TRY(hipEventRecord(s.named, hs));
+    s.named_early = true;
+    return HAST_OK;
+}
+
 // Routing streams: behind the framing of a block, on the same stream -- class and extent of every record, prefix sums, the records copied
 // into four runs, the runs and their sizes to pinned host memory (fq_kernels.hip, "routing").  view_bytes bounds what the runs can hold.
 static hast_status enqueue_route(hast_fq *f, Slot &s, hast_names *tab, bool striped, int last, size_t view_bytes, hipStream_t hs) {
@@ -224,8 +243,9 @@ static hast_status advance_striped_once(hast_fq *f, bool wait, size_t upto) {
                                        s.d_bcpos, s.d_bclen, s.h_bc, s.d_text, (uint32_t)s.h_cap, (uint32_t)f->k, ln.parse_stream));
         s.k_cap = s.h_cap;
         FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, ln.parse_stream));
-        if (f->route)
+        if (f->route) {
             if (hast_status st = enqueue_route(f, s, f->route_tab[(size_t)s.lane], true, s.eof_view ? 1 : 0, f->pad + s.n_bytes + s.n_over, ln.parse_stream)) return st;
+        } else if (hast_status st = enqueue_names_early(s, ln.names, ln.parse_stream)) return st;
         FQ_TRY(hipEventRecord(s.parsed, ln.parse_stream));
         f->nl_before = nl_before;
         f->n_framed++;
@@ -344,6 +364,7 @@ hast_status hast_names_create_dict(hast_ctx *ctx, size_t max_barcodes, hast_name
         return set_error(e == hipErrorOutOfMemory ? HAST_ERR_OOM : HAST_ERR_HIP, "name dictionary: %s", hipGetErrorString(e));
     }
     nm->dict = true;
+    if (const char *e = getenv("HAST_NAME_EARLY")) nm->name_early = atoi(e) != 0;
     return HAST_OK;
 }
 size_t hast_names_limit(const hast_names *nm) { return nm ? nm->limit : 0; }
@@ -704,8 +725,9 @@ static hast_status submit_block(hast_fq *f, size_t n_bytes, int last, bool dev_s
                            s.d_len, s.d_bcpos, s.d_bclen, s.h_bc, s.d_text, (uint32_t)s.h_cap, (uint32_t)f->k, last, hs));
     s.k_cap = s.h_cap;
     FQ_TRY(hipMemcpyAsync(s.h_st, s.d_st, sizeof(FqState), hipMemcpyDeviceToHost, hs));
-    if (f->route)
+    if (f->route) {
         if (hast_status st = enqueue_route(f, s, f->route_tab[0], false, last, f->pad + n_bytes, hs)) return st;
+    } else if (hast_status st = enqueue_names_early(s, f->names, hs)) return st;
     FQ_TRY(hipEventRecord(s.parsed, hs));
     s.state = Slot::SUBMITTED;
     f->n_submitted++;
@@ -782,7 +804,9 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
     s.host_texts = !by_copy;
     s.use_cache = snames && n;                 // (also a block that outgrew the pinned arrays: they have just been regrown, and the text records
                                                // of all its records are on the device -- every record goes through ONE dictionary)
-    if (s.use_cache) {
+    if (s.use_cache && s.named_early && !by_copy) {
+        // (named behind its framing: `named` lies in front of `parsed` on that stream, the ids are there)
+    } else if (s.use_cache) {
         s.h_unknown[0] = 0;
         if (snames->dict) {
             FQ_TRY(launch_fq_name_claim(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, snames->d_n_ids, (uint32_t)snames->limit, snames->d_text_of_id, s.h_ids,

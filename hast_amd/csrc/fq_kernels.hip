@@ -516,8 +516,11 @@ hipError_t launch_fq_route(const uint8_t *d_buf, const FqState *d_st, const uint
 // end, for printing) and publishes.  The same state machine as k_names_insert, for the same reason: two lanes of one wave may meet the
 // same new barcode.  Left to the host: texts longer than 15 bytes and what arrives once `limit` ids are out (the host names those in an
 // id range of its own, above `limit`).  Streams of several contexts of ONE GPU may run this on one table at the same time.
-__global__ void __launch_bounds__(256) k_fq_name_claim(const uint32_t *text, uint32_t n, NameEntry *tab, uint32_t mask, uint32_t *n_ids, uint32_t limit,
+__global__ void __launch_bounds__(256) k_fq_name_claim(const uint32_t *text, uint32_t n, const FqState *st, NameEntry *tab, uint32_t mask, uint32_t *n_ids, uint32_t limit,
                                                        uint4 *text_of_id, uint32_t *h_ids, uint32_t *h_unknown) {
+    // (st != NULL: launched right behind the framing kernels, before the host knows the block's record count -- the count is the framer's,
+    // at most n = what the pinned id arrays hold: a block with more records is named again, in full, once they have been regrown)
+    if (st) n = st->n_rec < n ? st->n_rec : n;
     const uint32_t n_round = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
     for (uint32_t r = 0; r < n_round; ++r) {
         const uint32_t i = r * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
@@ -571,7 +574,15 @@ __global__ void __launch_bounds__(256) k_fq_name_claim(const uint32_t *text, uin
 hipError_t launch_fq_name_claim(const uint32_t *d_text, uint32_t n, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit, void *d_text_of_id,
                                 uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fq_name_claim, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, tab, mask, d_n_ids, limit,
+    hipLaunchKernelGGL(k_fq_name_claim, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, (const FqState *)nullptr, tab, mask, d_n_ids,
+                       limit, reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown);
+    return hipGetLastError();
+}
+// the same behind the framing kernels of a block, on their stream: the record count is read from the block's state on the device
+hipError_t launch_fq_name_claim_framed(const uint32_t *d_text, const FqState *d_st, uint32_t cap, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit,
+                                       void *d_text_of_id, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
+    if (cap == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fq_name_claim, dim3((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024), dim3(256), 0, s, d_text, cap, d_st, tab, mask, d_n_ids, limit,
                        reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown);
     return hipGetLastError();
 }

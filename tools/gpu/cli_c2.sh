@@ -28,7 +28,7 @@ el() { python3 -c "print(round($2-$1,2))"; }
 echo "== box: $(nproc) hardware threads, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), memory.max $(cat /sys/fs/cgroup/memory.max 2>/dev/null), /dev/shm $(df -h /dev/shm | tail -1 | awk '{print $4}') free"
 t0=$(now); GEN_FASTQ_MAX_GB=90 tools/gen_fastq $D $NPAIRS $KEYS $BARCODES 21 150 32 0 || exit 1; t1=$(now)
 echo "== generated in $(el $t0 $t1) s: $((2*NPAIRS)) reads of 150 bp, $KEYS + $KEYS 21-mers, $BARCODES barcodes; $(stat -c %s $D/r1.fq) bytes per FASTQ file, $(stat -c %s $D/hap0.mer) per k-mer file"
-if has runs || has route || has prof || has blocks || has ab; then
+if has runs || has route || has prof || has blocks || has ab || has abname; then
 t0=$(now); tools/pgzip1 $D/r1.fq $D/r1.fq.gz $LEVEL 16 32 && tools/pgzip1 $D/r2.fq $D/r2.fq.gz $LEVEL 16 32 || exit 1; t1=$(now)
 echo "== compressed in $(el $t0 $t1) s (tools/pgzip1 level $LEVEL: ONE gzip member per file): $(stat -c %s $D/r1.fq.gz) + $(stat -c %s $D/r2.fq.gz) bytes"
 fi
@@ -92,6 +92,14 @@ if has ab; then              # the block size that follows the input's size (def
     echo "   cpu.stat: $(thr)"
     run plain_auto_t8_$rep $PY ${ARGS/-t 32/-t 8} --read $D/r1.fq --read $D/r2.fq
     echo "   cpu.stat: $(thr)"
+  done
+fi
+if has abname; then          # a dictionary names a block behind its framing (HAST_NAME_EARLY=1, tried in round 6) against in hast_fq_next on the context's stream (the default)
+  for rep in 1 2 3; do
+    HAST_NAME_EARLY=1 run gz_name_early_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+    HAST_NAME_EARLY=0 run gz_name_in_next_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+    HAST_NAME_EARLY=1 run plain_name_early_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+    HAST_NAME_EARLY=0 run plain_name_in_next_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
   done
 fi
 if has route; then
