@@ -520,11 +520,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
 //   k_gz_carry   one workgroup walks the groups: the window in front of each group (gwin[g]) from the last map of the group before
 //   k_gz_window  every chunk at once: W[c] = maps[c] resolved through gwin[group of c]
 constexpr uint32_t kGroup = 64;
+// (round 6: ONE map / window in LDS, composed in place -- a lane keeps its 32 new entries in registers over the barrier.  With two
+// buffers k_gz_maps took 128 KB of the CU's 160: it could only start on a CU nothing else held LDS on, and while the classifier's
+// workgroups -- 32 KB each, on every CU, also the ones the decode passes leave free -- came and went it waited: windows_crc_s of a
+// 34-GB stream 0.6 s in most runs and 2.5-3.3 s in others, profiles/round6_cli_c2_ab_free_cus.txt)
 __global__ void __launch_bounds__(1024) k_gz_maps(const AccDev *acc, uint32_t n_acc, uint16_t *maps) {
-    extern __shared__ uint16_t s_map[];                                       // 2 x kWindow
+    extern __shared__ uint16_t s_map[];                                       // kWindow entries
     const uint32_t tid = threadIdx.x;
     const uint32_t c0 = blockIdx.x * kGroup, c1 = c0 + kGroup < n_acc ? c0 + kGroup : n_acc;
-    uint16_t *cur = s_map, *nxt = s_map + kWindow;
+    uint16_t *cur = s_map;
+    constexpr uint32_t kPer = kWindow / 1024;
     for (uint32_t k = tid; k < kWindow; k += 1024) cur[k] = (uint16_t)(kMarker + k);      // the identity: byte k of the window in front of the group
     __syncthreads();
     for (uint32_t c = c0; c < c1; ++c) {
@@ -532,26 +537,30 @@ __global__ void __launch_bounds__(1024) k_gz_maps(const AccDev *acc, uint32_t n_
         const uint16_t *s = a.sym;
         const uint32_t own = a.n_out < kWindow ? a.n_out : kWindow;           // symbols of this chunk in its window
         uint16_t *out = maps + (size_t)c * kWindow;
-        for (uint32_t k = tid; k < kWindow; k += 1024) {
+        uint16_t nv[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint32_t k = tid + q * 1024;
             uint16_t v;
             if (k < kWindow - own) v = a.no_history ? (uint16_t)0 : cur[k + own];      // the window in front, shifted (nothing in front of a member)
             else {
                 v = s[a.n_out - own + (k - (kWindow - own))];
                 if (v >= kMarker) v = cur[v - kMarker];
             }
-            nxt[k] = v;
+            nv[q] = v;
             out[k] = v;
         }
+        __syncthreads();                                                       // (every lane has read the old map)
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) cur[tid + q * 1024] = nv[q];
         __syncthreads();
-        uint16_t *t = cur;
-        cur = nxt;
-        nxt = t;
     }
 }
 __global__ void __launch_bounds__(1024) k_gz_carry(const uint16_t *maps, uint32_t n_acc, const uint8_t *carry, uint8_t *gwin) {
-    extern __shared__ uint8_t s_win[];                                        // 2 x kWindow
+    extern __shared__ uint8_t s_win[];                                        // kWindow bytes
     const uint32_t tid = threadIdx.x;
-    uint8_t *cur = s_win, *nxt = s_win + kWindow;
+    uint8_t *cur = s_win;
+    constexpr uint32_t kPer = kWindow / 1024;
     for (uint32_t k = tid; k < kWindow; k += 1024) cur[k] = carry[k];
     __syncthreads();
     const uint32_t n_groups = (n_acc + kGroup - 1) / kGroup;
@@ -560,14 +569,16 @@ __global__ void __launch_bounds__(1024) k_gz_carry(const uint16_t *maps, uint32_
         for (uint32_t k = tid; k < kWindow; k += 1024) out[k] = cur[k];
         const uint32_t last = (g + 1) * kGroup < n_acc ? (g + 1) * kGroup - 1 : n_acc - 1;
         const uint16_t *m = maps + (size_t)last * kWindow;
-        for (uint32_t k = tid; k < kWindow; k += 1024) {
-            const uint16_t v = m[k];
-            nxt[k] = v < kMarker ? (uint8_t)v : cur[v - kMarker];
+        uint8_t nv[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint16_t v = m[tid + q * 1024];
+            nv[q] = v < kMarker ? (uint8_t)v : cur[v - kMarker];
         }
         __syncthreads();
-        uint8_t *t = cur;
-        cur = nxt;
-        nxt = t;
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) cur[tid + q * 1024] = nv[q];
+        __syncthreads();
     }
 }
 __global__ void __launch_bounds__(256) k_gz_window(const uint16_t *maps, uint32_t n_acc, const uint8_t *gwin, uint8_t *windows) {
@@ -682,14 +693,14 @@ hipError_t launch_windows(const AccDev *d_acc, uint32_t n, uint8_t *d_windows, c
     uint8_t *gwin = reinterpret_cast<uint8_t *>(maps + (size_t)n * kWindow);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gz_maps), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWindow * (int)sizeof(uint16_t));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gz_carry), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (int)kWindow);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gz_maps), hipFuncAttributeMaxDynamicSharedMemorySize, kWindow * (int)sizeof(uint16_t));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gz_carry), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWindow);
         if (e != hipSuccess) return e;
         attr = true;
     }
     const uint32_t n_groups = (n + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(k_gz_maps, dim3(n_groups), dim3(1024), 2 * kWindow * sizeof(uint16_t), s, d_acc, n, maps);
-    hipLaunchKernelGGL(k_gz_carry, dim3(1), dim3(1024), 2 * kWindow, s, maps, n, d_carry, gwin);
+    hipLaunchKernelGGL(k_gz_maps, dim3(n_groups), dim3(1024), kWindow * sizeof(uint16_t), s, d_acc, n, maps);
+    hipLaunchKernelGGL(k_gz_carry, dim3(1), dim3(1024), kWindow, s, maps, n, d_carry, gwin);
     hipLaunchKernelGGL(k_gz_window, dim3(n), dim3(256), 0, s, maps, n, gwin, d_windows);
     return hipGetLastError();
 }

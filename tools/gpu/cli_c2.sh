@@ -28,7 +28,7 @@ el() { python3 -c "print(round($2-$1,2))"; }
 echo "== box: $(nproc) hardware threads, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), memory.max $(cat /sys/fs/cgroup/memory.max 2>/dev/null), /dev/shm $(df -h /dev/shm | tail -1 | awk '{print $4}') free"
 t0=$(now); GEN_FASTQ_MAX_GB=90 tools/gen_fastq $D $NPAIRS $KEYS $BARCODES 21 150 32 0 || exit 1; t1=$(now)
 echo "== generated in $(el $t0 $t1) s: $((2*NPAIRS)) reads of 150 bp, $KEYS + $KEYS 21-mers, $BARCODES barcodes; $(stat -c %s $D/r1.fq) bytes per FASTQ file, $(stat -c %s $D/hap0.mer) per k-mer file"
-if has runs || has route || has prof || has blocks || has ab || has abname; then
+if has runs || has route || has prof || has blocks || has ab || has abname || has abcus; then
 t0=$(now); tools/pgzip1 $D/r1.fq $D/r1.fq.gz $LEVEL 16 32 && tools/pgzip1 $D/r2.fq $D/r2.fq.gz $LEVEL 16 32 || exit 1; t1=$(now)
 echo "== compressed in $(el $t0 $t1) s (tools/pgzip1 level $LEVEL: ONE gzip member per file): $(stat -c %s $D/r1.fq.gz) + $(stat -c %s $D/r2.fq.gz) bytes"
 fi
@@ -100,6 +100,13 @@ if has abname; then          # a dictionary names a block behind its framing (HA
     HAST_NAME_EARLY=0 run gz_name_in_next_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
     HAST_NAME_EARLY=1 run plain_name_early_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
     HAST_NAME_EARLY=0 run plain_name_in_next_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+  done
+fi
+if has abcus; then           # CUs the decode passes leave to the kernels behind them (HAST_GZ_FREE_CUS, default 32), alternating
+  for rep in ${CUS_REPS:-1 2 3}; do
+    for cus in ${CUS_LIST:-32 16 0 64}; do
+      HAST_GZ_FREE_CUS=$cus run gz_free_cus_${cus}_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+    done
   done
 fi
 if has route; then
