@@ -4,12 +4,13 @@ parseName :112-119), on byte streams cut into blocks at arbitrary places -- reco
 borders all the time -- and the per-barcode counters after the commit against the oracle."""
 import ctypes as C
 import random
+import re
 
 import numpy as np
 import pytest
 
 import hast_amd
-from hast_amd.binding import FqBlock, make_params
+from hast_amd.binding import FqBlock, FqRouted, make_params
 from tests import oracle_binding as ob
 
 pytestmark = pytest.mark.gpu
@@ -683,3 +684,130 @@ def test_fq_striped_stream_fuzz_line_phases(oracle_lib):
     finally:
         for c in ctxs:
             c.close()
+
+
+def _awk_route(data, cls_of):
+    """quartering_fastq.awk:21-49 on a byte string: (runs per class 0..3, dropped field-2 texts in order)"""
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    out, dropped, cls = [bytearray() for _ in range(4)], [], 0
+    for i, line in enumerate(lines):
+        if i % 4 == 0:
+            f = re.split(rb"[#/]", line)
+            if len(f) > 1 and f[1] != b"0_0_0":
+                cls = cls_of.get(f[1], -1)
+                if cls < 0:
+                    dropped.append(f[1])
+            else:
+                cls = 0
+        if cls >= 0:
+            out[cls] += line + b"\n"
+    return [bytes(o) for o in out], dropped
+
+
+@pytest.mark.parametrize("tail", ["plain", "no_final_newline", "unterminated_header", "bases_no_newline"])
+@pytest.mark.parametrize("chunk,n_ctx", [((700, 4096), 1), ((4096, 4096), 1), ((50_000, 65536), 1), ((4096, 4096), 2), ((8192, 8192), 3)])
+def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
+    """hast_fq_set_route / hast_fq_next_routed (include/hast.h "routing": the wrapper's steps 10-11, quartering_fastq.awk) through the C
+    ABI: a FASTQ whose headers take every branch -- no field 2, "0_0_0", empty field, a field 2 that is not what parseName takes, texts
+    longer than a text record (18 bytes), barcodes in no list -- goes through a routing stream (plain and striped over contexts of one
+    GPU) in blocks of 700 bytes to 64 KB; the four runs of every block (or, where the device hands a block over, the records by its
+    extents and classes with the undecided ones decided here by awk's rule) put together must be what the awk program writes, and the
+    dropped barcodes the ones it reports, in order."""
+    import zlib
+    lo, hi = chunk
+    rng = random.Random(1000 + lo + n_ctx)
+    k = 21
+    keys = hast_amd.synth_keys_host(make_params(k, 100, 500, 1), 0, 0, 500)
+    data = make_fastq(rng, 1200, k, keys, tail)
+    # the lists: every short barcode of the input by a hash of its text -- a fifth of them in no list (awk: ERROR line, record dropped)
+    fields = set()
+    for i, line in enumerate(data.split(b"\n")):
+        if i % 4 == 0:
+            f = re.split(rb"[#/]", line)
+            if len(f) > 1:
+                fields.add(f[1])
+    cls_of = {t: 1 + zlib.crc32(t) % 3 for t in fields if zlib.crc32(t) % 5 != 0 and t != b"0_0_0"}
+    want, want_dropped = _awk_route(data, cls_of)
+    lib = hast_amd.lib()
+    ctxs = [hast_amd.Context(k) for _ in range(n_ctx)]
+    try:
+        short = [(t, c) for t, c in cls_of.items() if len(t) <= 15]
+        text16 = np.zeros((max(len(short), 1), 16), np.uint8)
+        ids = np.zeros(max(len(short), 1), np.uint32)
+        for i, (t, c) in enumerate(short):
+            text16[i, 0] = len(t)
+            text16[i, 1:1 + len(t)] = np.frombuffer(t, np.uint8)
+            ids[i] = c
+        tab = C.c_void_p()
+        assert lib.hast_names_create(ctxs[0]._h, 4096, C.byref(tab)) == 0, lib.hast_last_error()
+        assert lib.hast_names_insert(tab, text16.ctypes.data_as(C.POINTER(C.c_uint8)), ids.ctypes.data_as(C.POINTER(C.c_uint32)), len(short)) == 0, lib.hast_last_error()
+        fq = C.c_void_p()
+        if n_ctx > 1:
+            arr = (C.c_void_p * n_ctx)(*[c._h for c in ctxs])
+            assert lib.hast_fq_create_striped(arr, n_ctx, hi, 2, None, C.byref(fq)) == 0, lib.hast_last_error()
+        else:
+            assert lib.hast_fq_create(ctxs[0]._h, hi, 3, None, C.byref(fq)) == 0, lib.hast_last_error()
+        tabs = (C.c_void_p * n_ctx)(*[tab.value] * n_ctx)
+        assert lib.hast_fq_set_route(fq, tabs, n_ctx) == 0, lib.hast_last_error()
+        got, dropped, st = [bytearray() for _ in range(4)], [], {"host_blocks": 0, "blocks": 0}
+
+        def decide(head):
+            f = re.split(rb"[#/]", head)
+            if len(f) <= 1 or f[1] == b"0_0_0":
+                return 0
+            c = cls_of.get(f[1], -1)
+            if c < 0:
+                dropped.append(f[1])
+            return c
+
+        def drain():
+            b = FqRouted()
+            assert lib.hast_fq_next_routed(fq, C.byref(b)) == 0, lib.hast_last_error()
+            st["blocks"] += 1
+            if not b.host_block:
+                for c in range(4):
+                    got[c] += bytes(b.run[c][:b.run_bytes[c]])
+            else:
+                st["host_blocks"] += 1
+                for i in range(b.n_slots):
+                    cl = b.rec_class[i]
+                    if cl == 0xFD:
+                        continue
+                    rec = bytes(b.bytes[b.rec_start[i]:b.rec_start[i] + b.rec_len[i]])
+                    if cl > 3:
+                        cl = decide(rec.split(b"\n", 1)[0])
+                    if cl >= 0:
+                        got[cl] += rec
+            if b.tail_bytes:
+                rest = bytes(b.tail[:b.tail_bytes])
+                cl = decide(rest.split(b"\n", 1)[0])
+                if cl >= 0:
+                    got[cl] += rest + (b"" if rest.endswith(b"\n") else b"\n")
+            assert lib.hast_fq_commit(fq) == 0, lib.hast_last_error()
+
+        pos, pending = 0, 0
+        while True:
+            n = min(len(data) - pos, hi if n_ctx > 1 else rng.randint(lo, hi))
+            buf = C.POINTER(C.c_uint8)()
+            assert lib.hast_fq_acquire(fq, C.byref(buf)) == 0, lib.hast_last_error()
+            C.memmove(buf, data[pos:pos + n], n)
+            pos += n
+            last = pos >= len(data)
+            assert lib.hast_fq_submit(fq, n, 1 if last else 0) == 0, lib.hast_last_error()
+            pending += 1
+            while pending > (0 if last else 1):
+                drain()
+                pending -= 1
+            if last:
+                break
+        lib.hast_fq_destroy(fq)
+        lib.hast_names_destroy(tab)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert [bytes(g) for g in got] == want
+    assert dropped == want_dropped and len(dropped) > 10
+    assert 0 < st["host_blocks"] <= st["blocks"]              # long texts and unlisted barcodes: those blocks are the caller's
+    assert all(len(w) > 1000 for w in want)
