@@ -181,7 +181,8 @@ static hast_status enqueue_names_early(Slot &s, hast_names *nm, hipStream_t hs) 
     s.named_early = false;
     if (!nm || !nm->dict || !nm->name_early || !s.h_cap) return HAST_OK;
     s.h_unknown[0] = 0;
-    FQ_TRY(launch_fq_name_claim_framed(s.d_text, s.d_st, (uint32_t)s.h_cap, nm->d_tab, nm->mask, nm->d_n_ids, (uint32_t)nm->limit, nm->d_text_of_id, s.h_ids, s.h_unknown, hs));
+    FQ_TRY(launch_fq_name_claim_framed(s.d_text, s.d_st, (uint32_t)s.h_cap, nm->d_tab, nm->mask, nm->d_n_ids, (uint32_t)nm->limit, nm->d_text_of_id, s.h_ids, s.h_unknown,
+                                       s.d_ids, hs));
     FQ_TRY(hipMemcpyAsync(s.h_nids, nm->d_n_ids, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
     FQ_TRY(hipEventRecord(s.named, hs));
     s.named_early = true;
@@ -411,7 +412,7 @@ hast_status hast_names_merge(hast_names *dst, hast_names *src, size_t first, siz
     for (size_t at = 0; e == hipSuccess && at < n; at += 1u << 24) {           // (the kernel counts records in 32 bits: 16M a launch)
         const uint32_t m = (uint32_t)std::min<size_t>(n - at, 1u << 24);
         e = launch_fq_name_claim(reinterpret_cast<const uint32_t *>(d_text + 16 * at), m, dst->d_tab, dst->mask, dst->d_n_ids, (uint32_t)dst->limit, dst->d_text_of_id,
-                                 d_ids + at, d_unknown, hs);
+                                 d_ids + at, d_unknown, nullptr, hs);
     }
     uint32_t n_unknown = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(ids_out, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost, hs);
@@ -810,7 +811,7 @@ hast_status hast_fq_next(hast_fq *f, hast_fq_block *out) {
         s.h_unknown[0] = 0;
         if (snames->dict) {
             FQ_TRY(launch_fq_name_claim(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, snames->d_n_ids, (uint32_t)snames->limit, snames->d_text_of_id, s.h_ids,
-                                        s.h_unknown, hs));
+                                        s.h_unknown, s.d_ids, hs));
             FQ_TRY(hipMemcpyAsync(s.h_nids, snames->d_n_ids, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
         } else FQ_TRY(launch_fq_name(s.d_text, (uint32_t)n, snames->d_tab, snames->mask, s.h_ids, s.h_unknown, hs));
         FQ_TRY(hipEventRecord(s.named, hs));
@@ -986,7 +987,10 @@ hast_status hast_fq_commit(hast_fq *f) {
                 FQ_TRY(launch_names_insert(s.h_pubs, np, nm->d_tab, nm->mask, hs));
                 nm->count += np;                               // (an upper bound: a barcode met twice in one block is counted twice)
             }
-            if (hast_status c = commit_framed(sctx, s.d_votes, s.h_ids, n, hs)) return c;
+            // (a block the dictionary named completely: its ids lie in device memory as well -- the bookkeeping kernel reads them there)
+            static const bool ids_from_host = [] { const char *e = getenv("HAST_COMMIT_IDS"); return e && !strcmp(e, "host"); }();
+            const bool from_device = nm && nm->dict && nu == 0 && !ids_from_host;
+            if (hast_status c = commit_framed(sctx, s.d_votes, from_device ? s.d_ids : s.h_ids, n, hs)) return c;
         } else {
             for (size_t i = 0; i < n; ++i)
                 if (s.h_ids[i] >= nbc) return set_error(HAST_ERR_INVALID, "barcode id %u of record %zu is outside the %zu counters", s.h_ids[i], i, nbc);

@@ -41,11 +41,12 @@ constexpr uint32_t kNameUnknown = 0xFFFFFFFFu;
 hipError_t launch_fq_name(const uint32_t *d_text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s);
 hipError_t launch_names_insert(const NamePub *pubs, uint32_t n, NameEntry *tab, uint32_t mask, hipStream_t s);
 // the dictionary variant: unknown texts get the next id from *d_n_ids (while < limit) and are filed under it in d_text_of_id[id] (16 B each)
+// (d_ids: the same ids in device memory as well, or NULL)
 hipError_t launch_fq_name_claim(const uint32_t *d_text, uint32_t n, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit, void *d_text_of_id,
-                                uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s);
+                                uint32_t *h_ids, uint32_t *h_unknown, uint32_t *d_ids, hipStream_t s);
 // ... launched behind a block's framing kernels on their stream: n = min(d_st->n_rec, cap), read on the device
 hipError_t launch_fq_name_claim_framed(const uint32_t *d_text, const FqState *d_st, uint32_t cap, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit,
-                                       void *d_text_of_id, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s);
+                                       void *d_text_of_id, uint32_t *h_ids, uint32_t *h_unknown, uint32_t *d_ids, hipStream_t s);
 
 hipError_t launch_fq_block(uint8_t *d_buf, FqState *d_st, const uint8_t *d_prev_buf, const FqState *d_prev_st, uint64_t pad, uint64_t n_bytes,
                            uint32_t *d_tile_cnt, uint32_t *d_nl, uint64_t *d_off, uint32_t *d_len, uint32_t *d_bc_pos, uint32_t *d_bc_len,

@@ -517,7 +517,7 @@ hipError_t launch_fq_route(const uint8_t *d_buf, const FqState *d_st, const uint
 // same new barcode.  Left to the host: texts longer than 15 bytes and what arrives once `limit` ids are out (the host names those in an
 // id range of its own, above `limit`).  Streams of several contexts of ONE GPU may run this on one table at the same time.
 __global__ void __launch_bounds__(256) k_fq_name_claim(const uint32_t *text, uint32_t n, const FqState *st, NameEntry *tab, uint32_t mask, uint32_t *n_ids, uint32_t limit,
-                                                       uint4 *text_of_id, uint32_t *h_ids, uint32_t *h_unknown) {
+                                                       uint4 *text_of_id, uint32_t *h_ids, uint32_t *h_unknown, uint32_t *d_ids) {
     // (st != NULL: launched right behind the framing kernels, before the host knows the block's record count -- the count is the framer's,
     // at most n = what the pinned id arrays hold: a block with more records is named again, in full, once they have been regrown)
     if (st) n = st->n_rec < n ? st->n_rec : n;
@@ -567,23 +567,26 @@ __global__ void __launch_bounds__(256) k_fq_name_claim(const uint32_t *text, uin
         }
         if (mine) {
             h_ids[i] = id;
+            // (the same ids in device memory: a block the dictionary named completely is booked from there -- the bookkeeping kernel reading
+            // 50 000 ids out of pinned host memory took as long as the classification of the block, round6_cli_c2_gz_kernel_stats_final.csv)
+            if (d_ids) d_ids[i] = id;
             if (id == kNameUnknown) h_unknown[1 + atomicAdd(&h_unknown[0], 1u)] = i;             // (pinned host memory)
         }
     }
 }
 hipError_t launch_fq_name_claim(const uint32_t *d_text, uint32_t n, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit, void *d_text_of_id,
-                                uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
+                                uint32_t *h_ids, uint32_t *h_unknown, uint32_t *d_ids, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fq_name_claim, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, s, d_text, n, (const FqState *)nullptr, tab, mask, d_n_ids,
-                       limit, reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown);
+                       limit, reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown, d_ids);
     return hipGetLastError();
 }
 // the same behind the framing kernels of a block, on their stream: the record count is read from the block's state on the device
 hipError_t launch_fq_name_claim_framed(const uint32_t *d_text, const FqState *d_st, uint32_t cap, NameEntry *tab, uint32_t mask, uint32_t *d_n_ids, uint32_t limit,
-                                       void *d_text_of_id, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {
+                                       void *d_text_of_id, uint32_t *h_ids, uint32_t *h_unknown, uint32_t *d_ids, hipStream_t s) {
     if (cap == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fq_name_claim, dim3((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024), dim3(256), 0, s, d_text, cap, d_st, tab, mask, d_n_ids, limit,
-                       reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown);
+                       reinterpret_cast<uint4 *>(d_text_of_id), h_ids, h_unknown, d_ids);
     return hipGetLastError();
 }
 hipError_t launch_fq_name(const uint32_t *d_text, uint32_t n, const NameEntry *tab, uint32_t mask, uint32_t *h_ids, uint32_t *h_unknown, hipStream_t s) {

@@ -28,7 +28,7 @@ el() { python3 -c "print(round($2-$1,2))"; }
 echo "== box: $(nproc) hardware threads, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), memory.max $(cat /sys/fs/cgroup/memory.max 2>/dev/null), /dev/shm $(df -h /dev/shm | tail -1 | awk '{print $4}') free"
 t0=$(now); GEN_FASTQ_MAX_GB=90 tools/gen_fastq $D $NPAIRS $KEYS $BARCODES 21 150 32 0 || exit 1; t1=$(now)
 echo "== generated in $(el $t0 $t1) s: $((2*NPAIRS)) reads of 150 bp, $KEYS + $KEYS 21-mers, $BARCODES barcodes; $(stat -c %s $D/r1.fq) bytes per FASTQ file, $(stat -c %s $D/hap0.mer) per k-mer file"
-if has runs || has route || has prof || has blocks || has ab || has abname || has abcus; then
+if has runs || has route || has prof || has blocks || has ab || has abname || has abcus || has abids; then
 t0=$(now); tools/pgzip1 $D/r1.fq $D/r1.fq.gz $LEVEL 16 32 && tools/pgzip1 $D/r2.fq $D/r2.fq.gz $LEVEL 16 32 || exit 1; t1=$(now)
 echo "== compressed in $(el $t0 $t1) s (tools/pgzip1 level $LEVEL: ONE gzip member per file): $(stat -c %s $D/r1.fq.gz) + $(stat -c %s $D/r2.fq.gz) bytes"
 fi
@@ -108,6 +108,17 @@ if has abcus; then           # CUs the decode passes leave to the kernels behind
       HAST_GZ_FREE_CUS=$cus run gz_free_cus_${cus}_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
     done
   done
+fi
+if has abids; then           # the bookkeeping kernel reads a block's ids in device memory (default, round 6) against out of pinned host memory (HAST_COMMIT_IDS=host)
+  for rep in 1 2 3; do
+    run gz_ids_device_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+    HAST_COMMIT_IDS=host run gz_ids_host_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+    run plain_ids_device_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+    HAST_COMMIT_IDS=host run plain_ids_host_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+  done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/round6_prof_c2 -- $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz > $D/out.prof 2> $D/err.prof
+  f=$(ls $O/round6_prof_c2/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/round6_cli_c2_gz_kernel_stats_ids_on_device.csv && head -12 $f | cut -c1-200
+  rm -rf $O/round6_prof_c2
 fi
 if has route; then
   KEEP=plain_route run plain_route $PY $ARGS --read $D/r1.fq --read $D/r2.fq --phase-reads
