@@ -60,7 +60,7 @@ def make_fastq(rng, n, k, keys, tail):
     return text.encode()
 
 
-def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=(), eager=False, dict_mode=False):
+def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=(), eager=False, dict_mode=False, keep_names=None):
     """feed `data` to hast_fq_* in pieces of lo..hi bytes, name the records the way the CLI does; returns the barcodes in record
     order, the dictionary, the base count, the per-block short-read flags and how many records the host had to name.
     dict_mode: the table is the DICTIONARY (hast_names_create_dict): the device hands out the ids below hast_names_limit itself, the
@@ -171,7 +171,9 @@ def stream_through_framer(ctx, data, lo, hi, cache, rng, n_buffers=3, more_ctxs=
         for bc, i in dev.items():
             assert raw[16 * i] == len(bc) and raw[16 * i + 1:16 * i + 1 + len(bc)] == bc, (bc, i)
     for h in nms + [nm]:
-        if h:
+        if h and keep_names is not None:
+            keep_names.append(h)               # (the caller destroys it)
+        elif h:
             lib.hast_names_destroy(h)
     if len(ctxs) > 1:
         return got, names, st["n_bases"], short, st["host_named"], st["lane_records"]
@@ -811,3 +813,82 @@ def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
     assert dropped == want_dropped and len(dropped) > 10
     assert 0 < st["host_blocks"] <= st["blocks"]              # long texts and unlisted barcodes: those blocks are the caller's
     assert all(len(w) > 1000 for w in want)
+
+
+def test_two_dictionaries_one_numbering():
+    """hast_names_merge (include/hast.h): what several GPUs need -- each GPU's dictionary numbers the barcodes in the order in which ITS blocks
+    meet them, and before the counters can be summed the second dictionary's ids are expressed in the first one's numbering, ON THE GPU: its
+    text records go through the first dictionary's naming kernel (an id that is there, or the next new one).  Two dictionaries on one GPU,
+    fed two FASTQ streams with overlapping barcode sets; then perm = merge(A <- B): a text both know maps to A's id, a text only B knows
+    gets a new id at the end of A, whose text record is that text; merging again changes nothing; and counters of B renumbered by perm
+    (hast_counts_permute) add up with A's to what one dictionary over both streams counts."""
+    lib = hast_amd.lib()
+    k, n_keys = 21, 2000
+    p = make_params(k, 100, n_keys, 1)
+    keys = [hast_amd.synth_keys_host(p, h, 0, n_keys) for h in (0, 1)]
+    rng = random.Random(77)
+    data = [make_fastq(random.Random(s0), 900, k, np.concatenate(keys), "plain") for s0 in (5, 6)]
+    kept = []
+    res = []
+    with hast_amd.Context(k) as ctx:
+        ctx.table_reserve(2 * n_keys)
+        ctx.table_insert_keys(0, keys[0])
+        ctx.table_insert_keys(1, keys[1])
+        counts = []
+        for d in data + [data[0] + data[1]]:
+            ctx.counts_resize((1 << 12) + 4096)
+            got, names, n_bases, short, host_named = stream_through_framer(ctx, d, 4096, 4096, 1 << 12, rng, dict_mode=True, keep_names=kept)
+            assert not any(short)
+            res.append(names)
+            limit = lib.hast_names_limit(kept[-1])
+            counts.append((ctx.counts_read(limit + 4096), limit))
+        A, B, AB = kept
+        nA, nB = C.c_size_t(), C.c_size_t()
+        assert lib.hast_names_count(A, C.byref(nA)) == 0 and lib.hast_names_count(B, C.byref(nB)) == 0
+        perm = (C.c_uint32 * nB.value)()
+        assert lib.hast_names_merge(A, B, 0, nB.value, perm) == 0, lib.hast_last_error()
+        nA2 = C.c_size_t()
+        assert lib.hast_names_count(A, C.byref(nA2)) == 0
+        limit = counts[0][1]
+        devA = {t: i for t, i in res[0].items() if i < limit}
+        devB = {t: i for t, i in res[1].items() if i < limit}
+        only_b = [t for t in devB if t not in devA]
+        assert len(only_b) > 5 and len(set(devA) & set(devB)) > 5
+        assert nA2.value == nA.value + len(only_b)
+        txt = (C.c_uint8 * (16 * nA2.value))()
+        assert lib.hast_names_texts(A, 0, nA2.value, txt) == 0
+        raw = bytes(txt)
+        for t, i in devB.items():
+            g = perm[i]
+            if t in devA:
+                assert g == devA[t], (t, g, devA[t])
+            else:
+                assert nA.value <= g < nA2.value
+            assert raw[16 * g] == len(t) and raw[16 * g + 1:16 * g + 1 + len(t)] == t, (t, g)
+        perm2 = (C.c_uint32 * nB.value)()
+        assert lib.hast_names_merge(A, B, 0, nB.value, perm2) == 0 and list(perm2) == list(perm)
+        assert lib.hast_names_count(A, C.byref(nA)) == 0 and nA.value == nA2.value
+        # the counters: B's, renumbered on the device (hast_counts_permute), + A's == what ONE dictionary counted over both streams
+        (ca, _), (cb, _), (cab, _) = counts
+        n_cnt = limit + 4096
+        ctx.counts_resize(n_cnt)
+        packed = np.concatenate([cb[w] for w in range(3)]).astype(np.uint64)
+        d_packed = ctx.alloc(packed.nbytes)
+        assert lib.hast_memcpy_h2d(ctx._h, C.c_void_p(d_packed), packed.ctypes.data_as(C.c_void_p), packed.nbytes) == 0
+        ctx.counts_unpack(d_packed, n_cnt)
+        ctx.sync()
+        assert lib.hast_counts_permute(ctx._h, perm, nB.value, n_cnt) == 0, lib.hast_last_error()
+        moved_dev = ctx.counts_read(n_cnt)
+        for w in range(3):
+            moved = np.zeros(n_cnt, np.uint64)
+            np.add.at(moved, np.array(list(perm), dtype=np.int64), cb[w][:nB.value])
+            moved[nB.value:] += cb[w][nB.value:]              # (the records behind the dictionary's ids keep their places)
+            assert np.array_equal(moved_dev[w], moved), w
+        ab_dev = {t: i for t, i in res[2].items() if i < limit}
+        assert set(ab_dev) == set(devA) | set(devB)
+        for t, i in ab_dev.items():
+            g = devA[t] if t in devA else perm[devB[t]]
+            for w in range(3):
+                assert int(ca[w][g] if t in devA else 0) + int(moved_dev[w][g]) == int(cab[w][i]), (t, w)
+        for h in kept:
+            lib.hast_names_destroy(h)
