@@ -3,6 +3,7 @@
 parseName :112-119), on byte streams cut into blocks at arbitrary places -- records, headers and barcodes straddle block
 borders all the time -- and the per-barcode counters after the commit against the oracle."""
 import ctypes as C
+import os
 import random
 import re
 
@@ -708,32 +709,13 @@ def _awk_route(data, cls_of):
     return [bytes(o) for o in out], dropped
 
 
-@pytest.mark.parametrize("tail", ["plain", "no_final_newline", "unterminated_header", "bases_no_newline"])
-@pytest.mark.parametrize("chunk,n_ctx", [((700, 4096), 1), ((4096, 4096), 1), ((50_000, 65536), 1), ((4096, 4096), 2), ((8192, 8192), 3)])
-def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
-    """hast_fq_set_route / hast_fq_next_routed (include/hast.h "routing": the wrapper's steps 10-11, quartering_fastq.awk) through the C
-    ABI: a FASTQ whose headers take every branch -- no field 2, "0_0_0", empty field, a field 2 that is not what parseName takes, texts
-    longer than a text record (18 bytes), barcodes in no list -- goes through a routing stream (plain and striped over contexts of one
-    GPU) in blocks of 700 bytes to 64 KB; the four runs of every block (or, where the device hands a block over, the records by its
-    extents and classes with the undecided ones decided here by awk's rule) put together must be what the awk program writes, and the
-    dropped barcodes the ones it reports, in order."""
-    import zlib
-    lo, hi = chunk
-    rng = random.Random(1000 + lo + n_ctx)
-    k = 21
-    keys = hast_amd.synth_keys_host(make_params(k, 100, 500, 1), 0, 0, 500)
-    data = make_fastq(rng, 1200, k, keys, tail)
-    # the lists: every short barcode of the input by a hash of its text -- a fifth of them in no list (awk: ERROR line, record dropped)
-    fields = set()
-    for i, line in enumerate(data.split(b"\n")):
-        if i % 4 == 0:
-            f = re.split(rb"[#/]", line)
-            if len(f) > 1:
-                fields.add(f[1])
-    cls_of = {t: 1 + zlib.crc32(t) % 3 for t in fields if zlib.crc32(t) % 5 != 0 and t != b"0_0_0"}
-    want, want_dropped = _awk_route(data, cls_of)
+def route_through_abi(data, cls_of, lo, hi, n_ctx, rng, k=21):
+    """`data` through a routing stream (hast_fq_set_route / hast_fq_next_routed), plain or striped over n_ctx contexts of one GPU, in
+    pieces of lo..hi bytes; what the device hands over (a block with a text longer than a text record or a barcode in no list, the partial
+    record at the end of the file) is decided here by awk's rule.  Returns (the four runs, the dropped field-2 texts, block counts)."""
     lib = hast_amd.lib()
     ctxs = [hast_amd.Context(k) for _ in range(n_ctx)]
+    got, dropped, st = [bytearray() for _ in range(4)], [], {"host_blocks": 0, "blocks": 0}
     try:
         short = [(t, c) for t, c in cls_of.items() if len(t) <= 15]
         text16 = np.zeros((max(len(short), 1), 16), np.uint8)
@@ -743,7 +725,7 @@ def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
             text16[i, 1:1 + len(t)] = np.frombuffer(t, np.uint8)
             ids[i] = c
         tab = C.c_void_p()
-        assert lib.hast_names_create(ctxs[0]._h, 4096, C.byref(tab)) == 0, lib.hast_last_error()
+        assert lib.hast_names_create(ctxs[0]._h, max(4096, len(short)), C.byref(tab)) == 0, lib.hast_last_error()
         assert lib.hast_names_insert(tab, text16.ctypes.data_as(C.POINTER(C.c_uint8)), ids.ctypes.data_as(C.POINTER(C.c_uint32)), len(short)) == 0, lib.hast_last_error()
         fq = C.c_void_p()
         if n_ctx > 1:
@@ -753,7 +735,6 @@ def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
             assert lib.hast_fq_create(ctxs[0]._h, hi, 3, None, C.byref(fq)) == 0, lib.hast_last_error()
         tabs = (C.c_void_p * n_ctx)(*[tab.value] * n_ctx)
         assert lib.hast_fq_set_route(fq, tabs, n_ctx) == 0, lib.hast_last_error()
-        got, dropped, st = [bytearray() for _ in range(4)], [], {"host_blocks": 0, "blocks": 0}
 
         def decide(head):
             f = re.split(rb"[#/]", head)
@@ -809,10 +790,82 @@ def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
     finally:
         for c in ctxs:
             c.close()
-    assert [bytes(g) for g in got] == want
+    return [bytes(g) for g in got], dropped, st
+
+
+@pytest.mark.parametrize("tail", ["plain", "no_final_newline", "unterminated_header", "bases_no_newline"])
+@pytest.mark.parametrize("chunk,n_ctx", [((700, 4096), 1), ((4096, 4096), 1), ((50_000, 65536), 1), ((4096, 4096), 2), ((8192, 8192), 3)])
+def test_fq_routing_through_the_abi(tail, chunk, n_ctx):
+    """hast_fq_set_route / hast_fq_next_routed (include/hast.h "routing": the wrapper's steps 10-11, quartering_fastq.awk) through the C
+    ABI: a FASTQ whose headers take every branch -- no field 2, "0_0_0", empty field, a field 2 that is not what parseName takes, texts
+    longer than a text record (18 bytes), barcodes in no list -- goes through a routing stream (plain and striped over contexts of one
+    GPU) in blocks of 700 bytes to 64 KB; the four runs of every block (or, where the device hands a block over, the records by its
+    extents and classes with the undecided ones decided here by awk's rule) put together must be what the awk program writes, and the
+    dropped barcodes the ones it reports, in order.  (_awk_route is pinned to the real awk program's outputs by
+    tests/test_quartering_cpu.py::test_awk_model_of_the_gpu_tests_equals_the_awk_program.)"""
+    import zlib
+    lo, hi = chunk
+    rng = random.Random(1000 + lo + n_ctx)
+    k = 21
+    keys = hast_amd.synth_keys_host(make_params(k, 100, 500, 1), 0, 0, 500)
+    data = make_fastq(rng, 1200, k, keys, tail)
+    # the lists: every short barcode of the input by a hash of its text -- a fifth of them in no list (awk: ERROR line, record dropped)
+    fields = set()
+    for i, line in enumerate(data.split(b"\n")):
+        if i % 4 == 0:
+            f = re.split(rb"[#/]", line)
+            if len(f) > 1:
+                fields.add(f[1])
+    cls_of = {t: 1 + zlib.crc32(t) % 3 for t in fields if zlib.crc32(t) % 5 != 0 and t != b"0_0_0"}
+    want, want_dropped = _awk_route(data, cls_of)
+    got, dropped, st = route_through_abi(data, cls_of, lo, hi, n_ctx, rng)
+    assert got == want
     assert dropped == want_dropped and len(dropped) > 10
     assert 0 < st["host_blocks"] <= st["blocks"]              # long texts and unlisted barcodes: those blocks are the caller's
     assert all(len(w) > 1000 for w in want)
+
+
+@pytest.mark.parametrize("n_ctx,block", [(1, 16384), (2, 8192)])
+def test_fq_routing_equals_the_awk_program_on_its_goldens(n_ctx, block):
+    """the device router through the ABI on the quartering goldens -- inputs, barcode lists and the outputs of the REAL awk program
+    (01.classify_stlfr_reads/quartering_fastq.awk under mawk; tests/golden/gen_golden.py): the hand-made edge case byte for byte incl.
+    the ERROR line, the two rand_k21 files (the second with its unterminated tail record) by size and md5 of each of the four files"""
+    import gzip
+    import hashlib
+    import json
+    from tests.conftest import GOLDEN
+    exp = json.load(open(os.path.join(GOLDEN, "quartering", "expected.json")))
+    rng = random.Random(4)
+    # the edge case
+    e = exp["edge"]
+    cls_of = {}
+    for name, c in (("p.bc", 1), ("m.bc", 2), ("h.bc", 3)):
+        for line in e["inputs"][name].encode().splitlines():
+            cls_of.setdefault(re.split(rb"[#/]", line)[0], c)
+    got, dropped, st = route_through_abi(e["inputs"]["e.fq"].encode(), cls_of, 4096, 4096, n_ctx, rng, k=7)
+    names = {0: "e.fq.nobarcode.fastq", 1: "e.fq.paternal.fastq", 2: "e.fq.maternal.fastq", 3: "e.fq.homozygous.fastq"}
+    for c in range(4):
+        assert got[c].decode() == e["outputs"].get(names[c], ""), names[c]
+    assert "".join("ERROR : unclassify barcode : %s\n" % d.decode() for d in dropped) == e["stderr"]
+    # rand_k21 with the lists the wrapper derived from the reference's own output
+    cls_of = {}
+    for name, c in (("paternal", 1), ("maternal", 2), ("homozygous", 3)):
+        for line in open(os.path.join(GOLDEN, "quartering", name + ".unique.barcodes"), "rb").read().splitlines():
+            cls_of.setdefault(re.split(rb"[#/]", line)[0], c)
+    for fq in ("r1.fq", "r2.fq"):
+        data = gzip.open(os.path.join(GOLDEN, "rand_k21", fq + ".gz")).read()
+        if fq == "r2.fq":
+            data = data[:-1] + b"\n" + exp["r2_tail"].encode()
+        got, dropped, st = route_through_abi(data, cls_of, block, block, n_ctx, rng)
+        want = exp["files"][fq]
+        for c, cls in enumerate(("nobarcode", "paternal", "maternal", "homozygous")):
+            if cls in want:
+                assert (len(got[c]), hashlib.md5(got[c]).hexdigest()) == (want[cls]["bytes"], want[cls]["md5"]), (fq, cls)
+            else:
+                assert got[c] == b"", (fq, cls)
+        err = "".join("ERROR : unclassify barcode : %s\n" % d.decode() for d in dropped).encode()
+        assert hashlib.md5(err).hexdigest() == want["stderr_md5"], fq
+        assert st["blocks"] > 10
 
 
 def test_two_dictionaries_one_numbering():

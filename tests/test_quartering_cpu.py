@@ -148,3 +148,38 @@ def test_block_reads_by_several_readers_equal_a_single_reader(exe, tmp_path):
         sums.append([hashlib.md5(o.read_bytes()).hexdigest() if o.exists() else None for o in outs] + [hashlib.md5(r.stderr).hexdigest()])
         assert sums[-1][0] is not None and outs[0].stat().st_size > 10_000_000
     assert sums[0] == sums[1] == sums[2]
+
+
+def test_awk_model_of_the_gpu_tests_equals_the_awk_program():
+    """tests/test_fq_gpu.py checks the device router against a ten-line Python restatement of quartering_fastq.awk:21-49 (_awk_route):
+    that restatement against the REAL awk program's outputs on the hand-made edge case (every branch) and on the rand_k21 files"""
+    import re
+    from tests.test_fq_gpu import _awk_route
+    exp = json.load(open(os.path.join(GOLDEN, "quartering", "expected.json")))
+    e = exp["edge"]
+    cls_of = {}
+    for name, c in (("p.bc", 1), ("m.bc", 2), ("h.bc", 3)):
+        for line in e["inputs"][name].encode().splitlines():
+            cls_of.setdefault(re.split(rb"[#/]", line)[0], c)
+    out, dropped = _awk_route(e["inputs"]["e.fq"].encode(), cls_of)
+    names = {0: "e.fq.nobarcode.fastq", 1: "e.fq.paternal.fastq", 2: "e.fq.maternal.fastq", 3: "e.fq.homozygous.fastq"}
+    for c in range(4):
+        assert out[c].decode() == e["outputs"].get(names[c], ""), names[c]
+    assert "".join("ERROR : unclassify barcode : %s\n" % d.decode() for d in dropped) == e["stderr"]
+    cls_of = {}
+    for name, c in (("paternal", 1), ("maternal", 2), ("homozygous", 3)):
+        for line in open(os.path.join(GOLDEN, "quartering", name + ".unique.barcodes"), "rb").read().splitlines():
+            cls_of.setdefault(re.split(rb"[#/]", line)[0], c)
+    for fq in ("r1.fq", "r2.fq"):
+        data = gzip.open(os.path.join(GOLDEN, "rand_k21", fq + ".gz")).read()
+        if fq == "r2.fq":
+            data = data[:-1] + b"\n" + exp["r2_tail"].encode()
+        out, dropped = _awk_route(data, cls_of)
+        want = exp["files"][fq]
+        for c, cls in enumerate(("nobarcode", "paternal", "maternal", "homozygous")):
+            if cls in want:
+                assert (len(out[c]), hashlib.md5(out[c]).hexdigest()) == (want[cls]["bytes"], want[cls]["md5"]), (fq, cls)
+            else:
+                assert out[c] == b""
+        err = "".join("ERROR : unclassify barcode : %s\n" % d.decode() for d in dropped).encode()
+        assert hashlib.md5(err).hexdigest() == want["stderr_md5"]
