@@ -653,7 +653,25 @@ int main(int argc, char **argv) {
     CK(hast_table_sizes(ctx, &n_set[0], &n_set[1]), "counting set sizes");
     if (!save_table.empty()) CK(hast_table_save(ctx, save_table.c_str()), "writing --save-table file");
     // the other GPUs get a copy of the finished table (after the adaptor scrub), peer to peer
-    for (size_t i = 1; i < ctxs.size(); i++) CK(hast_table_clone(ctxs[i], ctx), "copying the k-mer table to another GPU");
+    // (all at once: every GPU pulls its copy over its own xGMI link from the first one -- one after the other, seven copies of the 50 GB
+    // of BASELINE config 3's table and filter are seven times the one copy's time.  The source's filter is built first, once: the clones
+    // only read the source then.)
+    if (ctxs.size() > 1) {
+        CK(hast_filter_build(ctx), "building the k-mer filter");
+        std::vector<std::thread> cloners;
+        std::vector<std::string> clone_err(ctxs.size());
+        for (size_t i = 1; i < ctxs.size(); i++)
+            cloners.emplace_back([&, i] {
+                if (hast_table_clone(ctxs[i], ctx) != HAST_OK) clone_err[i] = std::string("copying the k-mer table to another GPU (") + hast_last_error() + ")";
+            });
+        for (std::thread &t : cloners) t.join();
+        for (const std::string &e : clone_err)
+            if (!e.empty()) {
+                fprintf(stderr, "classify: ERROR: %s\n", e.c_str());
+                fflush(stderr);
+                _exit(4);
+            }
+    }
     size_t next_ctx = 0;
     const double t_pre_wait0 = now_s();
     if (pre_thread.joinable()) {

@@ -171,8 +171,18 @@ int main(int argc, char **argv) {
     for (size_t i = 1; i < devices.size(); i++) {
         hast_ctx *c2 = nullptr;
         if (hast_ctx_create(devices[i], (int)K, &c2) != HAST_OK) die(4, "cannot create GPU context");
-        if (hast_table_clone(c2, ctx) != HAST_OK) die(4, "copying the k-mer table to another GPU");
         ctxs.push_back(c2);
+    }
+    if (ctxs.size() > 1) {
+        // (all at once: every GPU pulls its copy over its own xGMI link; the source's filter is built first, the clones only read the source)
+        if (hast_filter_build(ctx) != HAST_OK) die(4, "building the k-mer filter");
+        std::vector<std::thread> cloners;
+        std::vector<int> failed(ctxs.size(), 0);
+        for (size_t i = 1; i < ctxs.size(); i++)
+            cloners.emplace_back([&, i] { failed[i] = hast_table_clone(ctxs[i], ctx) != HAST_OK; });
+        for (std::thread &t : cloners) t.join();
+        for (int f : failed)
+            if (f) die(4, "copying the k-mer table to another GPU");
     }
     // ---- reads: block ingest with t_num parser threads (ingest.h), one GPU batch per block ------------------------
     // Framing as in the reference: FASTQ = 4 getlines per record, the header must be newline-terminated (s03:255-263);
