@@ -496,10 +496,19 @@ int main(int argc, char **argv) {
                 }
             });
         ctxs.push_back(ctx);
-        for (size_t i = 1; i < devices.size(); i++) {
-            hast_ctx *c2 = nullptr;
-            if (hast_ctx_create(devices[i], (int)K, &c2) != HAST_OK) die(4, "cannot create GPU context");
-            ctxs.push_back(c2);
+        {
+            // (the other GPUs' contexts at the same time: a context is a device's first HIP calls and a few streams, 50-100 ms each)
+            std::vector<hast_ctx *> made(devices.size(), nullptr);
+            std::vector<std::thread> makers;
+            for (size_t i = 1; i < devices.size(); i++)
+                makers.emplace_back([&, i] {
+                    if (hast_ctx_create(devices[i], (int)K, &made[i]) != HAST_OK) made[i] = nullptr;
+                });
+            for (std::thread &t : makers) t.join();
+            for (size_t i = 1; i < devices.size(); i++) {
+                if (!made[i]) die(4, "cannot create GPU context");
+                ctxs.push_back(made[i]);
+            }
         }
         if (host_parse) return;
         const char *deal = getenv("HAST_DEAL");
