@@ -769,7 +769,9 @@ int main(int argc, char **argv) {
             mx = std::max(mx, part_max[t]);
             if (part_err[t]) {
                 fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, cur_name->c_str());
-                exit(3);                                                                   // reference: assert abort
+                fflush(stdout);                                                            // reference: assert abort.  _exit: the HBM sampler and the
+                fflush(stderr);                                                            // library's threads are inside the HIP runtime -- exit() would take
+                _exit(3);                                                                  // it down under them (seen: SIGSEGV instead of status 3)
             }
         }
         if (dict.size() > acc.device_cap) flush_counts(ctxs, acc, naming, pool, dict.size(), std::max(dict.size() * 2, acc.device_cap * 2));
@@ -996,7 +998,9 @@ int main(int argc, char **argv) {
             t_gpu_wait += t1 - t0;
             if (b.short_read) {
                 fprintf(stderr, "classify: ERROR: read shorter than K=%zu in %s\n", K, f.name.c_str());
-                exit(3);                                                                   // reference: assert abort (kmer.h:171)
+                fflush(stdout);                                                            // reference: assert abort (kmer.h:171); _exit as above
+                fflush(stderr);
+                _exit(3);
             }
             const size_t n = (size_t)b.n_records;
             if (hast_fq_lanes(f.fq) <= 1 || !stripe) whole_file_records[f.ctx_index] += n;

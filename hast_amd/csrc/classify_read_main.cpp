@@ -14,6 +14,7 @@
 // dumps are.  The reference would also store other bytes literally (s03:59-65); we stop with exit 3 instead.
 #include <getopt.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
@@ -36,7 +37,10 @@ namespace {
     const char *e = hast_last_error();
     if (e && *e) fprintf(stderr, " (%s)", e);
     fputc('\n', stderr);
-    exit(code);
+    // (no destructors: a batch may be on the GPU in the background thread, and exit() would take the HIP runtime down under it)
+    fflush(stdout);
+    fflush(stderr);
+    _exit(code);
 }
 
 void print_usage() {   // same flags as the reference (s03:316-324); stderr is free-form

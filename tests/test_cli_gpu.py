@@ -165,6 +165,16 @@ def test_cli_usage_and_errors(exe, golden_workdir, tmp_path):
     r = subprocess.run([exe, "--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", str(short)], cwd=d,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 3                           # the reference aborts (kmer.h:171)
+    # the same behind 40 000 good records, with --stats (the HBM sampler thread polls the runtime) and the library's threads at work: still
+    # status 3 and the message, not a SIGSEGV out of a runtime that exit() was taking down under them (round 6)
+    late = tmp_path / "late_short.fq"
+    good = (golden_workdir / "edge_k7" / "r1.fq").read_text()
+    n_good = good.count("\n") // 4
+    late.write_text(good * (40000 // max(n_good, 1) + 1) + "@x#1_1_1/1\nACG\n+\nFFF\n")
+    for _ in range(3):
+        r = subprocess.run([exe, "--hap0", "hap0.mer", "--hap1", "hap1.mer", "--read", str(late), "-t", "8", "--stats"], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 3 and b"read shorter than K" in r.stderr, (r.returncode, r.stderr[-300:])
 
 
 def _write_case(tmp_path, n_records, seed, gz, long_reads=False):
