@@ -93,22 +93,24 @@ struct Arena {
 
 // What ONE GPU holds of a stream.  The nominal pass of a unit's segment j + 1 (search + decode of its chunks: where the time goes) is
 // launched BEFORE its segment j's results are walked, so that the GPU decodes while the host chains, the single-wave follow-up jobs
-// run and the consumer translates: job arrays in two copies (j & 1), follow-up jobs in a third, two symbol arenas taking turns (three until
-// round 5: no faster, hast_gz::n_arenas), the work behind a nominal pass on a stream of its own, the reader's translate
-// kernels (and the copies towards another GPU) on yet another.
+// run and the consumer translates; since the end of round 6 segment j + 1's pass is launched together with segment j's, on a second stream
+// (hast_gz::ahead): job arrays in three copies (j % 3), follow-up jobs in a fourth, three symbol arenas taking turns (one pass of a unit at
+// a time, HAST_GZ_AHEAD=0: two), the work behind a nominal pass on a stream of its own, the reader's translate kernels (and the copies
+// towards another GPU) on yet another.
 struct Unit {
     int device = 0;
     uint32_t *d_in = nullptr;                 // the compressed file + zero padding
-    DevBuf jobs[2], fjobs, bounce;            // (bounce: where the reader's bytes are translated to when its buffer is on another GPU)
-    ChunkJob *h_jobs[2] = {nullptr, nullptr}, *h_fjobs = nullptr;   // pinned
-    hipEvent_t nom_done[2] = {nullptr, nullptr};
+    static constexpr int kJobCopies = 3;      // (two passes in flight + the one being walked: hast_gz::ahead)
+    DevBuf jobs[kJobCopies], fjobs, bounce;   // (bounce: where the reader's bytes are translated to when its buffer is on another GPU)
+    ChunkJob *h_jobs[kJobCopies] = {nullptr, nullptr, nullptr}, *h_fjobs = nullptr;   // pinned
+    hipEvent_t nom_done[kJobCopies] = {nullptr, nullptr, nullptr};
     uint32_t *h_crc = nullptr;                // pinned
     size_t h_crc_cap = 0;
     static constexpr int kArenas = 3;
     Arena arena[kArenas];
-    hipStream_t up_stream = nullptr, dec_stream = nullptr, post_stream = nullptr, xl_stream = nullptr;
+    hipStream_t up_stream = nullptr, dec_stream = nullptr, dec_stream2 = nullptr, post_stream = nullptr, xl_stream = nullptr;
     hipEvent_t xl_done = nullptr;             // behind the reader's last launches on xl_stream
-    int dec_masked_free = 0;                  // != 0: dec_stream is a CU-masked stream out of the process's pool (goes back there)
+    int dec_masked_free = 0, dec2_masked_free = 0;      // != 0: dec_stream / dec_stream2 is a CU-masked stream out of the process's pool (goes back there)
 };
 
 }  // namespace
@@ -160,9 +162,14 @@ struct hast_gz {
     // stats
     hast_gz_stats st{};
     Unit &unit_of(size_t k) { return *units[k % units.size()]; }
-    int n_arenas = 2;                         // symbol arenas a unit takes turns with (HAST_GZ_ARENAS: 2 or 3)
+    int n_arenas = 3;                         // symbol arenas a unit takes turns with (3 with `ahead`, else 2; HAST_GZ_ARENAS)
     Arena &arena_of(size_t k) { return unit_of(k).arena[(k / units.size()) % (size_t)n_arenas]; }
-    int jobs_of(size_t k) const { return (int)((k / units.size()) & 1); }
+    int jobs_of(size_t k) const { return (int)((k / units.size()) % (size_t)Unit::kJobCopies); }
+    // ahead = 1: a unit's passes j and j + 1 are on the GPU TOGETHER (two streams, three arenas, three job arrays): a pass lasts as long as
+    // its slowest wave -- a whole deflate block -- and its last third runs a thinning set of waves; the next pass's
+    // waves take the slots they leave.  HAST_GZ_AHEAD=0: one pass of a unit at a time, as until round 6
+    int ahead = 1;
+    hipStream_t dec_stream_of(size_t k) { Unit &U = unit_of(k); return ahead && U.dec_stream2 && ((k / units.size()) & 1) ? U.dec_stream2 : U.dec_stream; }
     void job_view(ChunkJob &j) const {         // where job j finds the file's words (ring: the lap its first bit lies in)
         j.in_adj_words = 0;
         j.limit_bits = 0;
@@ -401,6 +408,7 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     N.t0 = now_s();
     const int jb = g->jobs_of(k);
     ChunkJob *hj = U.h_jobs[jb];
+    hipStream_t ds = g->dec_stream_of(k);
     size_t n_jobs = 0;
     const size_t n_slots = g->pool_slots(c1 - c0);
     GZ_HIP(A.syms.ensure(n_slots * g->slot_syms * sizeof(uint16_t) + 64));
@@ -425,13 +433,13 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     }
     N.n_jobs = n_jobs;
     if (n_jobs) {
-        GZ_HIP(hipMemcpyAsync(U.jobs[jb].p, hj, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, U.dec_stream));
-        GZ_HIP(hipMemsetAsync(A.cursor.p, 0, 64, U.dec_stream));
-        GZ_HIP(launch_search((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, U.dec_stream));
-        GZ_HIP(launch_decode((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, (uint16_t *)A.syms.p, (uint32_t *)A.cursor.p, (uint32_t)n_slots, U.dec_stream));
-        GZ_HIP(hipMemcpyAsync(hj, U.jobs[jb].p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, U.dec_stream));
+        GZ_HIP(hipMemcpyAsync(U.jobs[jb].p, hj, n_jobs * sizeof(ChunkJob), hipMemcpyHostToDevice, ds));
+        GZ_HIP(hipMemsetAsync(A.cursor.p, 0, 64, ds));
+        GZ_HIP(launch_search((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, ds));
+        GZ_HIP(launch_decode((ChunkJob *)U.jobs[jb].p, (uint32_t)n_jobs, U.d_in, N.input_bits, (uint16_t *)A.syms.p, (uint32_t *)A.cursor.p, (uint32_t)n_slots, ds));
+        GZ_HIP(hipMemcpyAsync(hj, U.jobs[jb].p, n_jobs * sizeof(ChunkJob), hipMemcpyDeviceToHost, ds));
     }
-    GZ_HIP(hipEventRecord(U.nom_done[jb], U.dec_stream));
+    GZ_HIP(hipEventRecord(U.nom_done[jb], ds));
     N.launched = true;
     return "";
 }
@@ -600,6 +608,7 @@ void produce_loop(hast_gz *g) {
         ++next_k;
         return true;
     };
+    const size_t depth = nu * (size_t)(1 + g->ahead);               // passes that may be on the GPUs behind the one being walked
     while (!finished && !stopped && bad.empty()) {
         if (fl.empty()) {
             if (all_launched) { bad = "gz: internal: the chain of chunks stalled"; break; }
@@ -607,9 +616,13 @@ void produce_loop(hast_gz *g) {
         }
         const Nominal cur = fl.front();
         Unit &U = g->unit_of(cur.k);
+        // (ahead: the pass behind the one waited for goes out BEFORE the wait -- it runs beside it)
+        while (g->ahead && !all_launched && next_k < cur.k + depth && bad.empty() && !stopped)
+            if (!launch(false)) break;
+        if (!bad.empty() || stopped) break;
         if (hipSetDevice(U.device) != hipSuccess || hipEventSynchronize(U.nom_done[g->jobs_of(cur.k)]) != hipSuccess) { bad = "gz: the decode pass failed"; break; }
         // the next segments' passes go to the GPUs now if their bytes and arenas are there (otherwise behind this segment's hand-over)
-        while (!all_launched && next_k <= cur.k + nu && bad.empty() && !stopped)
+        while (!all_launched && next_k <= cur.k + depth && bad.empty() && !stopped)
             if (!launch(false)) break;
         if (!bad.empty() || stopped) break;
         bad = finish_segment(g, cur, finished);
@@ -700,7 +713,9 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     // footprint small: on some boxes of the pool ONE HIP call of a process that starts right after another one freed tens of GB blocks
     // for 0.7-6 s (hipMalloc or hipStreamCreate, whichever comes first -- tools/probe/malloc_probe.py; the tree before did the same there).
     g->seg_chunks = seg_chunks ? seg_chunks : (chunk_bytes ? 4096 : 6144);
-    if (const char *e = getenv("HAST_GZ_ARENAS")) g->n_arenas = std::min((int)Unit::kArenas, std::max(2, atoi(e)));
+    if (const char *e = getenv("HAST_GZ_AHEAD")) g->ahead = atoi(e) > 0 ? 1 : 0;
+    g->n_arenas = g->ahead ? 3 : 2;
+    if (const char *e = getenv("HAST_GZ_ARENAS")) g->n_arenas = std::min((int)Unit::kArenas, std::max(g->ahead ? 3 : 2, atoi(e)));
     if (room <= 0)
         if (const char *e = getenv("HAST_GZ_ROOM")) room = atof(e);          // (measurements: symbols of room per compressed byte of a chunk)
     if (const char *e = getenv("HAST_GZ_SLOT_FRACTION")) {
@@ -734,7 +749,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         // (a deflate block: at most a piece, or the stream is refused), the piece in flight, the piece being filled and one of slack;
         // by default 2 GB, so that only files beyond that (HAST's real inputs: 50-100 GB) go round
         const uint64_t pass = (uint64_t)seg * g->chunk_bytes;
-        const uint64_t need = (uint64_t)(nu + 2) * pass + std::min<uint64_t>(pass, 16u << 20) + 4 * (uint64_t)g->piece;
+        const uint64_t need = (uint64_t)(nu * (size_t)(1 + g->ahead) + 2) * pass + std::min<uint64_t>(pass, 16u << 20) + 4 * (uint64_t)g->piece;
         uint64_t ring = 2ull << 30;
         if (const char *e = getenv("HAST_GZ_RING_BYTES")) ring = (uint64_t)std::max(0L, atol(e));
         ring = std::max(ring, need);
@@ -779,6 +794,13 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
                 if (U.dec_stream) U.dec_masked_free = free_cus;
             }
             if (!U.dec_stream) step(hipStreamCreateWithFlags(&U.dec_stream, hipStreamNonBlocking));
+            if (g->ahead && n_seg > 2) {                              // (the second of two passes that run side by side)
+                if (U.dec_masked_free) {
+                    U.dec_stream2 = masked_stream_get(U.device, n_cu, free_cus);
+                    if (U.dec_stream2) U.dec2_masked_free = free_cus;
+                }
+                if (!U.dec_stream2) step(hipStreamCreateWithFlags(&U.dec_stream2, hipStreamNonBlocking));
+            }
         }
         // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass: a stream of its own
         // (a high-priority one made no difference in an A/B: the free CUs are what lets its kernels start); the reader's translate kernels
@@ -787,7 +809,7 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         step(hipStreamCreateWithFlags(&U.xl_stream, hipStreamNonBlocking));
         step(hipEventCreateWithFlags(&U.xl_done, hipEventDisableTiming));
         tr("streams");
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < Unit::kJobCopies; ++i) {
             step(pinned_malloc((void **)&U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), hipHostMallocDefault));
             step(U.jobs[i].ensure(g->h_jobs_cap * sizeof(ChunkJob)));
             step(hipEventCreateWithFlags(&U.nom_done[i], hipEventDisableTiming));
@@ -798,7 +820,8 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         tr("job buffers");
         // the unit's first symbol arena now, the other one when its first pass is launched (launch_nominal) -- 3.2 GB each: 5-10 ms of
         // hipMalloc on most boxes of the pool, 0.6 s on some (profiles/round5_hipstall_slow_box_parked.txt), so there are as few of them
-        // as the pipeline needs (TWO arenas decode as fast as three: profiles/round5_ab_gz_two_arenas.txt) and the first one has its
+        // as the pipeline needs (one pass at a time: TWO arenas decode as fast as three, profiles/round5_ab_gz_two_arenas.txt; two passes side
+        // by side: three) and the first one has its
         // final size at once although the file's first pass is a short one (it would be parked and allocated again two passes on).
         // That there IS room for the later one is checked here, so that a device without it is refused at the door (the caller then
         // inflates on the host) instead of failing in mid-file
@@ -862,7 +885,7 @@ void hast_gz_close(hast_gz *g) {
     for (auto &up : g->units) {
         Unit &U = *up;
         (void)hipSetDevice(U.device);
-        for (hipStream_t st : {U.dec_stream, U.post_stream, U.up_stream, U.xl_stream})
+        for (hipStream_t st : {U.dec_stream, U.dec_stream2, U.post_stream, U.up_stream, U.xl_stream})
             if (st) (void)hipStreamSynchronize(st);
         tr("streams drained");
         for (Arena &a : U.arena) {
@@ -871,7 +894,7 @@ void hast_gz_close(hast_gz *g) {
             for (DevBuf *b : {&a.syms, &a.windows, &a.acc, &a.need, &a.crc, &a.carry, &a.cursor}) b->release();
             for (DevBuf &b : a.gap) b.release();
         }
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < Unit::kJobCopies; ++i) {
             U.jobs[i].release();
             park_pinned(U.h_jobs[i], g->h_jobs_cap * sizeof(ChunkJob), 1);
             if (U.nom_done[i]) (void)hipEventDestroy(U.nom_done[i]);
@@ -885,6 +908,8 @@ void hast_gz_close(hast_gz *g) {
         if (U.up_stream) (void)hipStreamDestroy(U.up_stream);
         if (U.dec_stream && U.dec_masked_free) masked_stream_put(U.device, U.dec_masked_free, U.dec_stream);     // (drained above)
         else if (U.dec_stream) (void)hipStreamDestroy(U.dec_stream);
+        if (U.dec_stream2 && U.dec2_masked_free) masked_stream_put(U.device, U.dec2_masked_free, U.dec_stream2);
+        else if (U.dec_stream2) (void)hipStreamDestroy(U.dec_stream2);
         if (U.post_stream) (void)hipStreamDestroy(U.post_stream);
         if (U.xl_stream) (void)hipStreamDestroy(U.xl_stream);
     }

@@ -224,6 +224,15 @@ class Chain {
             return false;
         }
         if (j.status & kStStarved) {
+            if (j.limit_bits && j.limit_bits < input_bits) {
+                // not the input ended but the job's VIEW of a ring (ChunkJob.limit_bits: its lap and a piece behind it) -- a job that ran
+                // on from its first boundary into blocks no search can find (a member's final block).  What it committed stands; a
+                // follow-up job, with the view of where IT starts, goes on from there.  A job that committed nothing met a block
+                // longer than the margin
+                if (j.end_bit > j.start_bit) return true;
+                err_ = "gz: a deflate block reaches further than the ring of compressed bytes on the device lets one job read";
+                return false;
+            }
             if (input_bits >= file_size_ * 8) { err_ = "gz: input ends inside a compressed block"; return false; }
             st_.retry_bits = input_bits;                           // the rest of this block is not on the device yet
             return true;

@@ -445,7 +445,8 @@ typedef struct {
 hast_status hast_gz_open(hast_ctx *, const char *path, hast_gz **out);
 /* test / tuning entry: compressed bytes per chunk (0 = 16384), chunks per pass (0 = 6144; 4096 with a chunk size given), symbols of room per
  * compressed byte (0 = 20 with the default geometry, else 12).  A pass's arena holds symbol slots for 70 % of its chunks (those WITH a block
- * start take one on the device; HAST_GZ_SLOT_FRACTION fixes the share, by default it follows what the passes find). */
+ * start take one on the device; HAST_GZ_SLOT_FRACTION fixes the share, by default it follows what the passes find).  Two passes of a
+ * stream are on the GPU at a time, on two streams, with three arenas to take turns (HAST_GZ_AHEAD=0: one pass, two arenas). */
 hast_status hast_gz_open_ex(hast_ctx *, const char *path, size_t chunk_bytes, size_t chunks_per_pass, double room, hast_gz **out);
 /* ONE .gz file inflated by several GPUs (the reference deals the reads of one file to all its workers whatever the file's encoding,
  * classify.cpp:211-219,245-254; HAST's inputs are two .fq.gz files, HAST.sh:162-166): the passes of the one deflate stream (4096
