@@ -270,6 +270,16 @@ static void run_job(ChunkJob &j, uint64_t nbits, std::vector<uint16_t> &sym, std
 // for input that is not there (a ring can keep a few passes and a piece of the file, not more); "the end of the input" is never
 // announced before the last segment, as the ring's uploader never gets there before the chain has moved on
 static uint64_t g_ring_lag = 0;
+// -v RING:PIECE: every job sees the file as a job on the device sees a ring of RING bytes with pieces of PIECE (gz_api.cpp job_view): from
+// the lap its first bit lies in to a piece behind that lap's end (ChunkJob.limit_bits) -- what lies behind is "not there" for it, also
+// when the whole input is (a job that runs on into a member's final block can get there: the chain must follow it up, not call it the
+// end of the input)
+static uint64_t g_view_ring = 0, g_view_piece = 0;
+static void view(ChunkJob &j) {
+    j.limit_bits = 0;
+    if (g_view_ring) j.limit_bits = (((j.from_bit >> 3) / g_view_ring + 1) * g_view_ring + g_view_piece) * 8;
+}
+static uint64_t seen(const ChunkJob &j, uint64_t input_bits) { return j.limit_bits && j.limit_bits < input_bits ? j.limit_bits : input_bits; }
 
 int main(int argc, char **argv) {
     size_t chunk = 32768, seg = 64;
@@ -283,6 +293,11 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-w")) g_wave = true;
         else if (!strcmp(argv[i], "-f")) fuzz = atol(argv[++i]);
         else if (!strcmp(argv[i], "-e")) g_ring_lag = (uint64_t)atol(argv[++i]);     // a ring on the device: see below
+        else if (!strcmp(argv[i], "-v")) {
+            const char *a = argv[++i], *c = strchr(a, ':');
+            g_view_ring = (uint64_t)atol(a);
+            g_view_piece = c ? (uint64_t)atol(c + 1) : 65536;
+        }
         else path = argv[i];
     }
     if (fuzz) {
@@ -438,7 +453,9 @@ int main(int argc, char **argv) {
             j.sym_cap = (uint32_t)(chunk * room) + 600;
             bufs.push_back(new Buf);
             j.sym_off = bufs.size() - 1;
-            run_job(j, all_in ? g_size * 8 : input_bits, bufs.back()->sym, tabs);
+            view(j);
+            run_job(j, seen(j, all_in ? g_size * 8 : input_bits), bufs.back()->sym, tabs);
+            if ((j.status & kStStarved) && j.limit_bits && j.limit_bits < (all_in ? g_size * 8 : input_bits)) fprintf(stderr, "view ended: a pass's job from bit %llu\n", (unsigned long long)j.start_bit);
             jobs.push_back(j);
         }
         chain.add_candidates(jobs.data(), jobs.size(), all_in);
@@ -450,7 +467,9 @@ int main(int argc, char **argv) {
                 j.sym_cap = (uint32_t)std::min<uint64_t>(g.want_syms, 1u << 27);
                 bufs.push_back(new Buf);
                 j.sym_off = bufs.size() - 1;
-                run_job(j, all_in ? g_size * 8 : input_bits, bufs.back()->sym, tabs);
+                view(j);
+                run_job(j, seen(j, all_in ? g_size * 8 : input_bits), bufs.back()->sym, tabs);
+                if ((j.status & kStStarved) && j.limit_bits && j.limit_bits < (all_in ? g_size * 8 : input_bits)) fprintf(stderr, "view ended: a follow-up job from bit %llu\n", (unsigned long long)j.start_bit);
                 res.push_back(j);
             }
             chain.gap_done(res.data(), res.size(), all_in ? g_size * 8 : input_bits);

@@ -83,6 +83,37 @@ def test_the_chain_keeps_up_with_a_ring(driver, tmp_path, name):
         assert got.stdout == want, (name, chunk, seg, room)
 
 
+def test_a_job_that_reaches_the_end_of_its_view_of_a_ring_is_followed_up(driver, tmp_path):
+    """On the device a job sees a ring from the lap its first bit lies in to a piece behind that lap's end (ChunkJob.limit_bits).  A job
+    that runs on from its first boundary into a block no search can find -- a member's FINAL block -- can reach that end with all of the
+    input on the device: the chain keeps what the job committed and sends a follow-up job (whose view starts where IT starts) instead of
+    reporting "input ends inside a compressed block" (round 6: tests/test_gz_gpu.py met it when the ring's size changed).  The driver's
+    -v RING:PIECE gives every job that view; the rings the library gives the GPU test's geometries, over two level-9 members and members
+    with stored blocks in between (16 KB x 5 chunks a pass under a ring of 704 KB is the case the GPU test met)."""
+    rng = random.Random(77)
+    fq = fastq(rng, 30_000)
+    noise = bytes(rng.getrandbits(8) for _ in range(300_000))
+    blobs = {"l9_members": member(fq[:1_000_000], 9) + member(fq[1_000_000:], 9),
+             "stored_between": member(fq[:700_000], 6) + member(noise, 6) + member(fq[700_000:], 4)}
+    met = 0
+    for name, blob in blobs.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        want = inflate_all(blob)
+        for chunk, seg, room in ((16384, 5, 12), (32768, 2, 12)):
+            # the ring gz_api.cpp gives such a stream under HAST_GZ_RING_BYTES=131072, pieces of 64 KB (two passes side by side, and one at a time), and its neighbours
+            for passes in ((4, 3) if chunk == 16384 else (4,)):
+                need = passes * chunk * seg + chunk * seg + 4 * 65536
+                ring = (max(131072, need) + 65535) // 65536 * 65536
+                for r in (ring, ring + 65536):
+                    got = subprocess.run([driver, "-e", str(1 << 30), "-v", "%d:65536" % r, "-c", str(chunk), "-s", str(seg), "-r", str(room), str(p)],
+                                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                    assert got.returncode == 0, (name, r, chunk, got.stderr[-300:])
+                    assert got.stdout == want, (name, r, chunk)
+                    met += b"view ended" in got.stderr
+    assert met > 0                                     # (the case was there: the driver says when a job's view ended before the input did)
+
+
 def test_search_kernels_strict_parse_equals_the_full_one(driver_exe):
     """header_parses8 (what a lane of k_gz_search runs: counts in packed words, a 128-byte table) == header_parses (gz_core.h's
     read_dynamic with zlib's completeness rules) on 400 000 random bit strings, half of them behind a valid code-length code"""
