@@ -94,23 +94,24 @@ struct Arena {
 // What ONE GPU holds of a stream.  The nominal pass of a unit's segment j + 1 (search + decode of its chunks: where the time goes) is
 // launched BEFORE its segment j's results are walked, so that the GPU decodes while the host chains, the single-wave follow-up jobs
 // run and the consumer translates; since the end of round 6 segment j + 1's pass is launched together with segment j's, on a second stream
-// (hast_gz::ahead): job arrays in three copies (j % 3), follow-up jobs in a fourth, three symbol arenas taking turns (one pass of a unit at
+// (hast_gz::ahead): job arrays in ahead + 2 copies, follow-up jobs in one more, ahead + 2 symbol arenas taking turns (one pass of a unit at
 // a time, HAST_GZ_AHEAD=0: two), the work behind a nominal pass on a stream of its own, the reader's translate kernels (and the copies
 // towards another GPU) on yet another.
 struct Unit {
     int device = 0;
     uint32_t *d_in = nullptr;                 // the compressed file + zero padding
-    static constexpr int kJobCopies = 3;      // (two passes in flight + the one being walked: hast_gz::ahead)
+    static constexpr int kJobCopies = 4;      // (hast_gz::ahead + 1 passes in flight + the one being walked)
     DevBuf jobs[kJobCopies], fjobs, bounce;   // (bounce: where the reader's bytes are translated to when its buffer is on another GPU)
-    ChunkJob *h_jobs[kJobCopies] = {nullptr, nullptr, nullptr}, *h_fjobs = nullptr;   // pinned
-    hipEvent_t nom_done[kJobCopies] = {nullptr, nullptr, nullptr};
+    ChunkJob *h_jobs[kJobCopies] = {}, *h_fjobs = nullptr;   // pinned
+    hipEvent_t nom_done[kJobCopies] = {};
     uint32_t *h_crc = nullptr;                // pinned
     size_t h_crc_cap = 0;
-    static constexpr int kArenas = 3;
+    static constexpr int kArenas = 4;
     Arena arena[kArenas];
-    hipStream_t up_stream = nullptr, dec_stream = nullptr, dec_stream2 = nullptr, post_stream = nullptr, xl_stream = nullptr;
+    static constexpr int kDecStreams = 3;     // (a unit's passes that run side by side: one stream each)
+    hipStream_t up_stream = nullptr, dec_stream[kDecStreams] = {}, post_stream = nullptr, xl_stream = nullptr;
     hipEvent_t xl_done = nullptr;             // behind the reader's last launches on xl_stream
-    int dec_masked_free = 0, dec2_masked_free = 0;      // != 0: dec_stream / dec_stream2 is a CU-masked stream out of the process's pool (goes back there)
+    int dec_masked_free[kDecStreams] = {};    // != 0: that dec_stream is a CU-masked stream out of the process's pool (goes back there)
 };
 
 }  // namespace
@@ -164,12 +165,17 @@ struct hast_gz {
     Unit &unit_of(size_t k) { return *units[k % units.size()]; }
     int n_arenas = 3;                         // symbol arenas a unit takes turns with (3 with `ahead`, else 2; HAST_GZ_ARENAS)
     Arena &arena_of(size_t k) { return unit_of(k).arena[(k / units.size()) % (size_t)n_arenas]; }
-    int jobs_of(size_t k) const { return (int)((k / units.size()) % (size_t)Unit::kJobCopies); }
+    int jobs_of(size_t k) const { return (int)((k / units.size()) % (size_t)(ahead + 2)); }
     // ahead = 1: a unit's passes j and j + 1 are on the GPU TOGETHER (two streams, three arenas, three job arrays): a pass lasts as long as
     // its slowest wave -- a whole deflate block -- and its last third runs a thinning set of waves; the next pass's
-    // waves take the slots they leave.  HAST_GZ_AHEAD=0: one pass of a unit at a time, as until round 6
+    // waves take the slots they leave.  HAST_GZ_AHEAD=0: one pass of a unit at a time, as until round 6; =2: three side by side (four arenas:
+    // ~4 % more for 2.8 GB more, profiles/round6_gz_ahead_sweep.txt)
     int ahead = 1;
-    hipStream_t dec_stream_of(size_t k) { Unit &U = unit_of(k); return ahead && U.dec_stream2 && ((k / units.size()) & 1) ? U.dec_stream2 : U.dec_stream; }
+    hipStream_t dec_stream_of(size_t k) {
+        Unit &U = unit_of(k);
+        hipStream_t s = U.dec_stream[(k / units.size()) % (size_t)(ahead + 1)];
+        return s ? s : U.dec_stream[0];
+    }
     void job_view(ChunkJob &j) const {         // where job j finds the file's words (ring: the lap its first bit lies in)
         j.in_adj_words = 0;
         j.limit_bits = 0;
@@ -713,9 +719,9 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
     // footprint small: on some boxes of the pool ONE HIP call of a process that starts right after another one freed tens of GB blocks
     // for 0.7-6 s (hipMalloc or hipStreamCreate, whichever comes first -- tools/probe/malloc_probe.py; the tree before did the same there).
     g->seg_chunks = seg_chunks ? seg_chunks : (chunk_bytes ? 4096 : 6144);
-    if (const char *e = getenv("HAST_GZ_AHEAD")) g->ahead = atoi(e) > 0 ? 1 : 0;
-    g->n_arenas = g->ahead ? 3 : 2;
-    if (const char *e = getenv("HAST_GZ_ARENAS")) g->n_arenas = std::min((int)Unit::kArenas, std::max(g->ahead ? 3 : 2, atoi(e)));
+    if (const char *e = getenv("HAST_GZ_AHEAD")) g->ahead = std::min(Unit::kDecStreams - 1, std::max(0, atoi(e)));
+    g->n_arenas = g->ahead + 2;
+    if (const char *e = getenv("HAST_GZ_ARENAS")) g->n_arenas = std::min((int)Unit::kArenas, std::max(g->ahead + 2, atoi(e)));
     if (room <= 0)
         if (const char *e = getenv("HAST_GZ_ROOM")) room = atof(e);          // (measurements: symbols of room per compressed byte of a chunk)
     if (const char *e = getenv("HAST_GZ_SLOT_FRACTION")) {
@@ -790,16 +796,16 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
             if (hipGetDeviceProperties(&prop, U.device) == hipSuccess) n_cu = prop.multiProcessorCount;
             if (const char *fc = getenv("HAST_GZ_FREE_CUS")) free_cus = atoi(fc);
             if (e == hipSuccess && n_cu > 0 && free_cus > 0 && free_cus < n_cu) {
-                U.dec_stream = masked_stream_get(U.device, n_cu, free_cus);
-                if (U.dec_stream) U.dec_masked_free = free_cus;
+                U.dec_stream[0] = masked_stream_get(U.device, n_cu, free_cus);
+                if (U.dec_stream[0]) U.dec_masked_free[0] = free_cus;
             }
-            if (!U.dec_stream) step(hipStreamCreateWithFlags(&U.dec_stream, hipStreamNonBlocking));
-            if (g->ahead && n_seg > 2) {                              // (the second of two passes that run side by side)
-                if (U.dec_masked_free) {
-                    U.dec_stream2 = masked_stream_get(U.device, n_cu, free_cus);
-                    if (U.dec_stream2) U.dec2_masked_free = free_cus;
+            if (!U.dec_stream[0]) step(hipStreamCreateWithFlags(&U.dec_stream[0], hipStreamNonBlocking));
+            for (int i = 1; i <= g->ahead && n_seg > 2; ++i) {       // (the other passes that run beside it)
+                if (U.dec_masked_free[0]) {
+                    U.dec_stream[i] = masked_stream_get(U.device, n_cu, free_cus);
+                    if (U.dec_stream[i]) U.dec_masked_free[i] = free_cus;
                 }
-                if (!U.dec_stream2) step(hipStreamCreateWithFlags(&U.dec_stream2, hipStreamNonBlocking));
+                if (!U.dec_stream[i]) step(hipStreamCreateWithFlags(&U.dec_stream[i], hipStreamNonBlocking));
             }
         }
         // what follows a nominal pass (follow-up jobs, windows, CRC-32) must not queue behind the NEXT segment's pass: a stream of its own
@@ -885,7 +891,7 @@ void hast_gz_close(hast_gz *g) {
     for (auto &up : g->units) {
         Unit &U = *up;
         (void)hipSetDevice(U.device);
-        for (hipStream_t st : {U.dec_stream, U.dec_stream2, U.post_stream, U.up_stream, U.xl_stream})
+        for (hipStream_t st : {U.dec_stream[0], U.dec_stream[1], U.dec_stream[2], U.post_stream, U.up_stream, U.xl_stream})
             if (st) (void)hipStreamSynchronize(st);
         tr("streams drained");
         for (Arena &a : U.arena) {
@@ -906,10 +912,10 @@ void hast_gz_close(hast_gz *g) {
         park_pinned(U.h_crc, 0, 1);
         if (U.xl_done) (void)hipEventDestroy(U.xl_done);
         if (U.up_stream) (void)hipStreamDestroy(U.up_stream);
-        if (U.dec_stream && U.dec_masked_free) masked_stream_put(U.device, U.dec_masked_free, U.dec_stream);     // (drained above)
-        else if (U.dec_stream) (void)hipStreamDestroy(U.dec_stream);
-        if (U.dec_stream2 && U.dec2_masked_free) masked_stream_put(U.device, U.dec2_masked_free, U.dec_stream2);
-        else if (U.dec_stream2) (void)hipStreamDestroy(U.dec_stream2);
+        for (int i = 0; i < Unit::kDecStreams; ++i) {
+            if (U.dec_stream[i] && U.dec_masked_free[i]) masked_stream_put(U.device, U.dec_masked_free[i], U.dec_stream[i]);     // (drained above)
+            else if (U.dec_stream[i]) (void)hipStreamDestroy(U.dec_stream[i]);
+        }
         if (U.post_stream) (void)hipStreamDestroy(U.post_stream);
         if (U.xl_stream) (void)hipStreamDestroy(U.xl_stream);
     }
