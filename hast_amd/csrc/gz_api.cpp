@@ -194,9 +194,28 @@ namespace {
         if (e_ != hipSuccess) return std::string(#expr ": ") + hipGetErrorString(e_);          \
     } while (0)
 
+// HAST_GZ_TRACE=1: where a segment's time goes on the producer's thread (allocations, waits), one line per step that took > 1 ms
+bool gz_trace() {
+    static const bool on = getenv("HAST_GZ_TRACE") != nullptr;
+    return on;
+}
+struct TraceStep {
+    const hast_gz *g;
+    size_t k;
+    const char *what;
+    double t0;
+    TraceStep(const hast_gz *g_, size_t k_, const char *w) : g(g_), k(k_), what(w), t0(gz_trace() ? now_s() : 0) {}
+    ~TraceStep();
+};
+
 // CU-masked streams are created once per (device, free CUs) and handed from stream to stream of compressed input, never destroyed:
 // creating one right after another had been destroyed hung inside the runtime every other time (a stream closed early with passes
 // in flight, then the next file opened: tests/test_gz_gpu.py test_a_stream_closed_early_with_passes_in_flight).
+TraceStep::~TraceStep() {
+    if (!gz_trace()) return;
+    const double dt = now_s() - t0;
+    if (dt > 1e-3) fprintf(stderr, "gz seg %zu of %s: %s %.3f s\n", k, g->path.c_str(), what, dt);
+}
 struct MaskedStreams {
     std::mutex mu;
     std::vector<std::pair<std::pair<int, int>, hipStream_t>> idle;      // ((device, free CUs), stream)
@@ -402,6 +421,7 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
         if (g->stop) { stopped = true; return ""; }
     }
     if (A.done_recorded) {                                          // the batch that lived here: its last translate must be through
+        TraceStep ts(g, k, "waiting for the arena's last translate");
         GZ_HIP(hipEventSynchronize(A.done));
         A.done_recorded = false;
     }
@@ -417,8 +437,11 @@ std::string launch_nominal(hast_gz *g, size_t k, size_t n_chunks, uint64_t first
     hipStream_t ds = g->dec_stream_of(k);
     size_t n_jobs = 0;
     const size_t n_slots = g->pool_slots(c1 - c0);
-    GZ_HIP(A.syms.ensure(n_slots * g->slot_syms * sizeof(uint16_t) + 64));
-    GZ_HIP(A.cursor.ensure(64));
+    {
+        TraceStep ts(g, k, "symbol arena (ensure)");
+        GZ_HIP(A.syms.ensure(n_slots * g->slot_syms * sizeof(uint16_t) + 64));
+        GZ_HIP(A.cursor.ensure(64));
+    }
     const uint64_t sym_base = reinterpret_cast<uintptr_t>(A.syms.p) / 2;      // job.sym_off counts u16 from address 0
     for (size_t c = c0; c < c1; ++c) {
         ChunkJob &j = hj[n_jobs];
@@ -533,11 +556,14 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
         }
         b->out_lo = b->acc.front().out_off;
         b->out_hi = b->acc.back().out_off + b->acc.back().job.n_out;
-        GZ_HIP(A.acc.ensure(n * sizeof(AccDev)));
-        GZ_HIP(A.windows.ensure(n * (size_t)kWindow));
-        GZ_HIP(A.need.ensure(windows_scratch_bytes((uint32_t)n)));
-        GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
-        GZ_HIP(A.carry.ensure(kWindow));
+        {
+            TraceStep ts(g, N.k, "windows / maps / crc buffers (ensure)");
+            GZ_HIP(A.acc.ensure(n * sizeof(AccDev)));
+            GZ_HIP(A.windows.ensure(n * (size_t)kWindow));
+            GZ_HIP(A.need.ensure(windows_scratch_bytes((uint32_t)n)));
+            GZ_HIP(A.crc.ensure(n * sizeof(uint32_t)));
+            GZ_HIP(A.carry.ensure(kWindow));
+        }
         if (U.h_crc_cap < n) {
             park_pinned(U.h_crc, 0, 2);
             U.h_crc = nullptr;
@@ -546,8 +572,12 @@ std::string finish_segment(hast_gz *g, const Nominal &N, bool &finished) {
             U.h_crc_cap = n + n / 2 + 64;
         }
         // (pageable source: the copy is done with `host` when the call returns)
-        GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, U.post_stream));
-        GZ_HIP(hipStreamSynchronize(U.post_stream));
+        {
+            TraceStep ts(g, N.k, "accepted chunks to the device");
+            GZ_HIP(hipMemcpyAsync(A.acc.p, host.data(), n * sizeof(AccDev), hipMemcpyHostToDevice, U.post_stream));
+            GZ_HIP(hipStreamSynchronize(U.post_stream));
+        }
+        TraceStep ts_w(g, N.k, "windows + CRC-32 kernels, carry back");
         // the 32 KB in front of this batch: what the batch before it left (pinned host memory: the batch before may live on another GPU)
         GZ_HIP(hipMemcpyAsync(A.carry.p, g->h_carry, kWindow, hipMemcpyHostToDevice, U.post_stream));
         GZ_HIP(launch_windows((const AccDev *)A.acc.p, (uint32_t)n, (uint8_t *)A.windows.p, (const uint8_t *)A.carry.p, A.need.p, U.post_stream));
@@ -626,7 +656,10 @@ void produce_loop(hast_gz *g) {
         while (g->ahead && !all_launched && next_k < cur.k + depth && bad.empty() && !stopped)
             if (!launch(false)) break;
         if (!bad.empty() || stopped) break;
-        if (hipSetDevice(U.device) != hipSuccess || hipEventSynchronize(U.nom_done[g->jobs_of(cur.k)]) != hipSuccess) { bad = "gz: the decode pass failed"; break; }
+        {
+            TraceStep ts(g, cur.k, "waiting for the pass (search + decode)");
+            if (hipSetDevice(U.device) != hipSuccess || hipEventSynchronize(U.nom_done[g->jobs_of(cur.k)]) != hipSuccess) { bad = "gz: the decode pass failed"; break; }
+        }
         // the next segments' passes go to the GPUs now if their bytes and arenas are there (otherwise behind this segment's hand-over)
         while (!all_launched && next_k <= cur.k + depth && bad.empty() && !stopped)
             if (!launch(false)) break;
@@ -831,6 +864,14 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
         // final size at once although the file's first pass is a short one (it would be parked and allocated again two passes on).
         // That there IS room for the later one is checked here, so that a device without it is refused at the door (the caller then
         // inflates on the host) instead of failing in mid-file
+        // HAST_GZ_PREALLOC=1: EVERYTHING a stream's passes will need is allocated here instead of at its first use (the later arenas, every
+        // arena's window / map / CRC buffers).  Tried on the round's last day against the runs whose read phase takes 0.6-1.7 s instead of
+        // 0.2 s (one in five on some boxes of the pool, none on others): there a hipMalloc in the middle of the read phase took 0.6-1.3 s
+        // and held up every stream of the process while it did ("windows / maps / crc buffers (ensure) 1.330 s" in both files' producers
+        // at once, profiles/round6_gz_slow_hunt.txt).  Allocating here MOVES that stall (open_s 0.8-2.5 s, the k-mer load beside it waiting
+        // as long), it does not remove it: the whole process takes as long either way (40 runs each, alternating) -- a process that starts
+        // right behind another one's exit pays it at one of its first large allocations.  Off by default
+        static const bool prealloc = getenv("HAST_GZ_PREALLOC") && atoi(getenv("HAST_GZ_PREALLOC")) > 0;
         size_t later = 0;
         for (int i = 0; i < g->n_arenas && e == hipSuccess; ++i) {
             const size_t k = ui + (size_t)i * nu;
@@ -838,8 +879,27 @@ hast_status hast_gz_open_multi_ex(hast_ctx *const *ctxs, int n_ctx, const char *
             const size_t first = n_seg == 1 ? std::max(s0, std::min(seg, n_chunks)) : s0;
             const size_t chunks = k == 0 ? (n_seg > (size_t)g->n_arenas * nu ? std::max(first, seg) : first) : seg;
             const size_t bytes = g->pool_slots(chunks) * (size_t)g->slot_syms * sizeof(uint16_t) + 64;
-            if (i == 0) step(U.arena[i].syms.ensure(bytes));
+            Arena &a = U.arena[i];
+            if (i == 0 || prealloc) step(a.syms.ensure(bytes));
             else later += bytes + chunks * ((size_t)kWindow * 3 + 64);              // (+ windows, maps, per-chunk words of a batch)
+            if (prealloc) {
+                const size_t n_max = chunks + 64;                                   // accepted chunks of a batch: a pass's, and a few follow-up jobs'
+                step(a.cursor.ensure(64));
+                step(a.acc.ensure(n_max * sizeof(AccDev)));
+                step(a.windows.ensure(n_max * (size_t)kWindow));
+                step(a.need.ensure(windows_scratch_bytes((uint32_t)n_max)));
+                step(a.crc.ensure(n_max * sizeof(uint32_t)));
+                step(a.carry.ensure(kWindow));
+                a.gap.emplace_back();
+                step(a.gap[0].ensure(8u << 20));                                    // (a round of follow-up jobs' symbols; grows when one needs more)
+                if (U.h_crc_cap < n_max && e == hipSuccess) {
+                    park_pinned(U.h_crc, 0, 2);
+                    U.h_crc = nullptr;
+                    U.h_crc_cap = 0;
+                    step(pinned_malloc((void **)&U.h_crc, (n_max + n_max / 2 + 64) * sizeof(uint32_t), hipHostMallocDefault));
+                    if (e == hipSuccess) U.h_crc_cap = n_max + n_max / 2 + 64;
+                }
+            }
         }
         if (e == hipSuccess && later) {
             size_t free_b = 0, total_b = 0;

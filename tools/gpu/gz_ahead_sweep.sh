@@ -1,6 +1,6 @@
 # round 6: passes of a .gz file side by side (HAST_GZ_AHEAD = 0, 1, 2) x chunks per pass: read phase and HBM at the peak over the 20M-read pairs
 # (two single-member gzip -6 files, constant and noisy quality lines), variants in turn, REPS times.
-# usage: gpurun -- 'bash tools/gpu/gz_ahead_sweep.sh > gpurun_out/gz_ahead_sweep.txt 2>&1'      VARIANTS="ahead:pass ..."  (pass 0 = the default, 6144)
+# usage: gpurun -- 'bash tools/gpu/gz_ahead_sweep.sh > gpurun_out/gz_ahead_sweep.txt 2>&1'      VARIANTS="ahead:pass[:free CUs] ..."  (pass 0 = the default, 6144)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 D=$(mktemp -d /dev/shm/hast_asw.XXXXXX); trap 'rm -rf $D' EXIT
@@ -14,10 +14,10 @@ for q in ${QUALS:-const noisy}; do
   hast_amd/classify $ARGS > /dev/null 2>&1       # (the box's first run)
   for rep in $(seq 1 ${REPS:-4}); do
     for v in $VARIANTS; do
-      IFS=: read a p <<< "$v"
-      envs="HAST_GZ_AHEAD=$a"; [ "$p" != 0 ] && envs="$envs HAST_GZ_PASS_CHUNKS=$p HAST_GZ_ROOM=20"
+      IFS=: read a p cus <<< "$v"
+      envs="HAST_GZ_AHEAD=$a"; [ "$p" != 0 ] && envs="$envs HAST_GZ_PASS_CHUNKS=$p HAST_GZ_ROOM=20"; [ -n "$cus" ] && envs="$envs HAST_GZ_FREE_CUS=$cus"
       env $envs hast_amd/classify $ARGS > $D/out 2> $D/err
-      echo "ahead=$a pass=$p rep=$rep rc=$? md5=$(md5sum < $D/out | cut -c1-8) $(grep -o "read_phase_s=[0-9.]*" $D/err) $(grep -h __stats_gz__ $D/err | grep -o "followup_jobs=[0-9]*" | tr '\n' ' ') $(grep -o "in_use_peak_bytes=[0-9]*" $D/err)"
+      echo "ahead=$a pass=$p${cus:+ free_cus=$cus} rep=$rep rc=$? md5=$(md5sum < $D/out | cut -c1-8) $(grep -o "read_phase_s=[0-9.]*" $D/err) $(grep -h __stats_gz__ $D/err | grep -o "followup_jobs=[0-9]*" | tr '\n' ' ') $(grep -o "in_use_peak_bytes=[0-9]*" $D/err)"
     done
   done
 done
