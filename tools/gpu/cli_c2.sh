@@ -28,7 +28,7 @@ el() { python3 -c "print(round($2-$1,2))"; }
 echo "== box: $(nproc) hardware threads, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), memory.max $(cat /sys/fs/cgroup/memory.max 2>/dev/null), /dev/shm $(df -h /dev/shm | tail -1 | awk '{print $4}') free"
 t0=$(now); GEN_FASTQ_MAX_GB=90 tools/gen_fastq $D $NPAIRS $KEYS $BARCODES 21 150 32 0 || exit 1; t1=$(now)
 echo "== generated in $(el $t0 $t1) s: $((2*NPAIRS)) reads of 150 bp, $KEYS + $KEYS 21-mers, $BARCODES barcodes; $(stat -c %s $D/r1.fq) bytes per FASTQ file, $(stat -c %s $D/hap0.mer) per k-mer file"
-if has runs || has route || has prof || has blocks || has ab || has abname || has abcus || has abids || has abahead; then
+if has runs || has route || has prof || has blocks || has ab || has abname || has abcus || has abids || has abahead || has paused; then
 t0=$(now); tools/pgzip1 $D/r1.fq $D/r1.fq.gz $LEVEL 16 32 && tools/pgzip1 $D/r2.fq $D/r2.fq.gz $LEVEL 16 32 || exit 1; t1=$(now)
 echo "== compressed in $(el $t0 $t1) s (tools/pgzip1 level $LEVEL: ONE gzip member per file): $(stat -c %s $D/r1.fq.gz) + $(stat -c %s $D/r2.fq.gz) bytes"
 fi
@@ -107,6 +107,16 @@ if has abcus; then           # CUs the decode passes leave to the kernels behind
     for cus in ${CUS_LIST:-32 16 0 64}; do
       HAST_GZ_FREE_CUS=$cus run gz_free_cus_${cus}_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
     done
+  done
+fi
+if has paused; then          # every run `sleep $PAUSE` (5 s) behind the exit of the one in front: what a process costs that does not start while the driver takes the last one apart (profiles/round6_gz_slow_hunt.txt)
+  for rep in 1 2 3 4; do
+    sleep ${PAUSE:-5}; run plain_paused_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+    sleep ${PAUSE:-5}; run gz_paused_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
+  done
+  for rep in 1 2; do
+    run plain_back_to_back_$rep $PY $ARGS --read $D/r1.fq --read $D/r2.fq
+    run gz_back_to_back_$rep $PY $ARGS --read $D/r1.fq.gz --read $D/r2.fq.gz
   done
 fi
 if has abahead; then         # two passes of a file on the GPU together (HAST_GZ_AHEAD=1, the default since round 6's last day) against one at a time (=0), alternating
