@@ -45,6 +45,41 @@ def test_same_bytes_as_zlib(ctx, tmp_path, name):
         assert st["out_bytes"] == len(want) and st["compressed_bytes"] == len(CASES[name])
 
 
+@pytest.mark.parametrize("ahead", [0, 1, 2])
+def test_passes_side_by_side(ctx, tmp_path, monkeypatch, ahead):
+    """HAST_GZ_AHEAD: how many further passes of a stream are on the GPU beside the one in front (gz_api.cpp hast_gz::ahead; default 1:
+    two decode streams, three symbol arenas, three job arrays; 0 = one pass at a time, as until round 6; 2 = three side by side): a FASTQ
+    of many passes, members back to back, stored blocks in between, with slots that hold a block and slots too small for any -- the bytes
+    are zlib's in every mode, also through a ring of the compressed bytes and with damage in a late pass reported as an error."""
+    monkeypatch.setenv("HAST_GZ_AHEAD", str(ahead))
+    rng = random.Random(5 + ahead)
+    fq = fastq(rng, 20_000)
+    noise = bytes(rng.getrandbits(8) for _ in range(100_000))
+    data = fq[:900_000] + noise + fq[900_000:]
+    blob = member(fq[:900_000], 6) + member(noise, 6) + member(fq[900_000:], 9)
+    p = tmp_path / "many_passes.gz"
+    p.write_bytes(blob)
+    for chunk, seg, room in ((4096, 4, 50), (16384, 5, 12), (1024, 16, 200), (4096, 4, 0)):
+        with hast_amd.GzReader(ctx, str(p), chunk, seg, room) as z:
+            got = z.read_all(1 << 20)
+            st = z.stats()
+        assert got == data, (ahead, chunk, seg, room, len(got), len(data))
+        assert st["members"] == 3
+    monkeypatch.setenv("HAST_GZ_PIECE_BYTES", "65536")
+    monkeypatch.setenv("HAST_GZ_RING_BYTES", "131072")
+    with hast_amd.GzReader(ctx, str(p), 4096, 4, 50) as z:
+        got = z.read_all(99_999)
+        st = z.stats()
+    assert got == data and st["ring_bytes"] > 0 and st["ring_laps"] >= 1, (ahead, st)
+    bad = bytearray(blob)
+    bad[len(blob) * 3 // 4] ^= 0x10
+    q = tmp_path / "damaged_late.gz"
+    q.write_bytes(bytes(bad))
+    with pytest.raises(hast_amd.HastError):
+        with hast_amd.GzReader(ctx, str(q), 4096, 4, 50) as z:
+            z.read_all(1 << 20)
+
+
 def test_tiny_reads_and_reads_across_batches(ctx, tmp_path):
     p = tmp_path / "fq.gz"
     p.write_bytes(CASES["fastq_l6"])
