@@ -158,6 +158,24 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/round6_prof_c2 -- $PY
 echo "-- under rocprofv3 (gz): rc=$? md5=$(md5sum < $D/out.prof | cut -c1-12) $(grep -h __stats_phases__ $D/err.prof | cut -c1-300)"
 grep -v "^[EW]2026" $D/err.prof | tail -4 | cut -c1-300 | sed 's/^/     /'
 f=$(ls $O/round6_prof_c2/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/round6_cli_c2_gz_kernel_stats.csv && head -16 $f
+# sum against UNION of every kernel's launches (two files decode at once, and since the round's last day two passes of each)
+t=$(ls $O/round6_prof_c2/*/*kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$t" ] && python3 - "$t" <<'PYEOF'
+import csv, sys, collections
+iv = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    iv[r["Kernel_Name"].split("(")[0].split("::")[-1].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+def union(v):
+    v = sorted(v); tot = 0; cs, ce = v[0]
+    for s, e in v[1:]:
+        if s > ce: tot += ce - cs; cs, ce = s, e
+        else: ce = max(ce, e)
+    return tot + ce - cs
+allv = [x for v in iv.values() for x in v]
+print("     all kernels: %d launches, sum %.0f ms, union %.0f ms, first start to last end %.0f ms" % (len(allv), sum(e - s for s, e in allv) / 1e6, union(allv) / 1e6, (max(e for s, e in allv) - min(s for s, e in allv)) / 1e6))
+for n, v in sorted(iv.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[:12]:
+    print("     %-44s launches %6d  sum %8.1f ms  union %8.1f ms" % (n[:44], len(v), sum(e - s for s, e in v) / 1e6, union(v) / 1e6))
+PYEOF
 rm -rf $O/round6_prof_c2
 fi
 # the checkers: the oracle's program over all the reads; the real reference binary on the first 2M reads of each file
