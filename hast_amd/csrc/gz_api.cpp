@@ -208,14 +208,15 @@ struct TraceStep {
     ~TraceStep();
 };
 
-// CU-masked streams are created once per (device, free CUs) and handed from stream to stream of compressed input, never destroyed:
-// creating one right after another had been destroyed hung inside the runtime every other time (a stream closed early with passes
-// in flight, then the next file opened: tests/test_gz_gpu.py test_a_stream_closed_early_with_passes_in_flight).
 TraceStep::~TraceStep() {
     if (!gz_trace()) return;
     const double dt = now_s() - t0;
     if (dt > 1e-3) fprintf(stderr, "gz seg %zu of %s: %s %.3f s\n", k, g->path.c_str(), what, dt);
 }
+
+// CU-masked streams are created once per (device, free CUs) and handed from stream to stream of compressed input, never destroyed:
+// creating one right after another had been destroyed hung inside the runtime every other time (a stream closed early with passes
+// in flight, then the next file opened: tests/test_gz_gpu.py test_a_stream_closed_early_with_passes_in_flight).
 struct MaskedStreams {
     std::mutex mu;
     std::vector<std::pair<std::pair<int, int>, hipStream_t>> idle;      // ((device, free CUs), stream)
