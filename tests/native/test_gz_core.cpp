@@ -20,7 +20,11 @@ using namespace hast::gz;
 static std::vector<uint32_t> g_words;       // the file, zero padded
 static uint64_t g_size = 0;
 
-static bool g_wave = false;      // -w: Huffman blocks decoded the way k_gz_decode does it (64 token parses per step, chain, rounds)
+static bool g_wave = false;
+// -S (with -w): what the wave's steps were made of, to stderr at the end -- steps, rounds, rounds with a match, rounds with a copy out of the
+// symbol buffer itself (further back than kRing), tokens, matches, long matches (profiles/round6_gz_decode_latency_ab.txt quotes these)
+static bool g_stats = false;
+static struct { unsigned long long steps, full, rounds, rounds_match, rounds_far, syms, toks, matches, longs, longs_far; } g_st;      // -w: Huffman blocks decoded the way k_gz_decode does it (64 token parses per step, chain, rounds)
 
 // ---- the symbol loop of k_gz_decode (gz_kernels.hip), lane by lane: every lane parses a token at its own bit offset (parse_token),
 // the chain of real tokens is walked from offset 0, the chain's tokens are written out in rounds of at most 64 symbols (a token
@@ -44,6 +48,8 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
         Token tk[64];
         for (uint32_t lane = 0; lane < 64; ++lane) tk[lane] = full ? parse_token(bits_at(w, pos + lane), lit, dst) : parse_token_fast(bits_at(w, pos + lane), lit, dst);
         const bool was_full = full;
+        g_st.steps++;
+        g_st.full += full;
         full = false;
         uint32_t p = 0;
         bool again = false;
@@ -81,12 +87,17 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
                 if (n2 + nsym > cap) return kStNoRoom;
                 const uint32_t bstart = n2;
                 const int64_t ring_lo = (int64_t)bstart - (int64_t)kRing;
+                bool r_match = false, r_far = false;
+                g_st.rounds++;
+                g_st.syms += nsym;
+                g_st.toks += (unsigned)__builtin_popcountll(cur);
                 // the round's tokens at the lanes of their symbols: literals as themselves, a match at its first symbol
                 uint32_t s_tok[64];
                 for (uint32_t j = 0; j < 64; ++j) s_tok[j] = 0;
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     if (!((cur >> lane) & 1)) continue;
                     const uint32_t st = start[lane] - base;
+                    if (tk[lane].dist) g_st.matches++;
                     if (tk[lane].dist) s_tok[st] = kIsMatch | st | (tk[lane].dist << 14);
                     else {
                         s_tok[st] = kIsLit | (tk[lane].val & 0xFF);
@@ -101,6 +112,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
                     for (uint32_t q = 0; q <= j; ++q)
                         if (s_tok[q] & kIsMatch) L = q;                  // the last match that starts at or in front of j
                     if (L == 64) { fprintf(stderr, "a symbol without a token\n"); abort(); }
+                    r_match = true;
                     const uint32_t tv = s_tok[L], off = tv & 63, dist = (tv >> 14) & 0xFFFF, k = j - off;
                     uint32_t kk = k;
                     if (k >= dist) {
@@ -111,7 +123,7 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
                     const int64_t src = (int64_t)bstart + (int64_t)off - (int64_t)dist + (int64_t)kk;
                     if (src >= (int64_t)bstart) { fprintf(stderr, "source inside its own round\n"); abort(); }
                     if (src < 0) outv[j] = (uint16_t)(kMarker + (uint32_t)((int64_t)kWindow + src));
-                    else if (src < ring_lo) outv[j] = sym[src];
+                    else if (src < ring_lo) { outv[j] = sym[src]; r_far = true; }
                     else outv[j] = ring_at(src);
                 }
                 for (uint32_t j = 0; j < nsym; ++j) {
@@ -121,6 +133,8 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
                 base += nsym;
                 n2 += nsym;
                 rem &= ~cur;
+                g_st.rounds_match += r_match;
+                g_st.rounds_far += r_far;
             }
             if (!stop) break;
             const uint32_t kind = stop >> 7, tl = stop & 127;
@@ -147,6 +161,8 @@ static uint32_t decode_block_wave(const uint32_t *w, uint64_t nbits, uint64_t &p
             if (distance > n2 && (no_history || distance > kWindow)) { err = kErrTooFar; return kStError; }
             if (n2 + len > cap) return kStNoRoom;
             const bool near = ring_holds_long_match(distance, len);
+            g_st.longs++;
+            g_st.longs_far += !near;
             for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                 uint16_t outv[64];
                 for (uint32_t lane = 0; lane < 64 && k0 + lane < len; ++lane) {
@@ -291,6 +307,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-s")) seg = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "-r")) room = atof(argv[++i]);
         else if (!strcmp(argv[i], "-w")) g_wave = true;
+        else if (!strcmp(argv[i], "-S")) g_stats = true;
         else if (!strcmp(argv[i], "-f")) fuzz = atol(argv[++i]);
         else if (!strcmp(argv[i], "-e")) g_ring_lag = (uint64_t)atol(argv[++i]);     // a ring on the device: see below
         else if (!strcmp(argv[i], "-v")) {
@@ -498,5 +515,8 @@ int main(int argc, char **argv) {
         return 3;
     }
     if (!out.empty()) fwrite(out.data(), 1, out.size(), stdout);
+    if (g_stats && g_wave)
+        fprintf(stderr, "wave steps %llu (with second-level tables %llu) rounds %llu with_match %llu with_far_copy %llu symbols_in_rounds %llu tokens %llu matches %llu long_matches %llu long_far %llu\n",
+                g_st.steps, g_st.full, g_st.rounds, g_st.rounds_match, g_st.rounds_far, g_st.syms, g_st.toks, g_st.matches, g_st.longs, g_st.longs_far);
     return 0;
 }

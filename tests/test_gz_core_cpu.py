@@ -114,6 +114,22 @@ def test_a_job_that_reaches_the_end_of_its_view_of_a_ring_is_followed_up(driver,
     assert met > 0                                     # (the case was there: the driver says when a job's view ended before the input did)
 
 
+def test_what_the_waves_steps_are_made_of(driver_exe, tmp_path):
+    """-w -S: the counters the measurements quote (profiles/round6_gz_decode_latency_ab.txt: on a FASTQ's lines nearly every round of
+    k_gz_decode copies from further back than the ring of recent symbols) -- they add up, and a gzip -6 FASTQ has that property"""
+    import re
+    p = tmp_path / "fq.gz"
+    p.write_bytes(CASES["fastq_l6"])
+    r = subprocess.run([driver_exe, "-w", "-S", "-c", "16384", "-r", "20", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == inflate_all(CASES["fastq_l6"])
+    m = re.search(rb"wave steps (\d+) \(with second-level tables (\d+)\) rounds (\d+) with_match (\d+) with_far_copy (\d+) symbols_in_rounds (\d+) tokens (\d+) matches (\d+) long_matches (\d+) long_far (\d+)", r.stderr)
+    assert m, r.stderr[-300:]
+    steps, full, rounds, with_match, with_far, syms, toks, matches, longs, longs_far = (int(x) for x in m.groups())
+    assert full <= steps and with_far <= with_match <= rounds and matches <= toks and longs_far <= longs
+    assert toks <= syms <= rounds * 64                  # (symbols of everything decoded: a chunk whose result the chain did not accept is decoded again)
+    assert with_far * 2 > rounds                       # (most rounds reach further back than kRing = 512 symbols)
+
+
 def test_search_kernels_strict_parse_equals_the_full_one(driver_exe):
     """header_parses8 (what a lane of k_gz_search runs: counts in packed words, a 128-byte table) == header_parses (gz_core.h's
     read_dynamic with zlib's completeness rules) on 400 000 random bit strings, half of them behind a valid code-length code"""
